@@ -1,0 +1,268 @@
+"""
+Generates the golden vectors under tests/golden/ by IMPORTING THE REFERENCE.
+
+Runs only in the build container (needs /root/reference on disk); the GPU box never
+sees the reference.  rdkit / boto3 are absent, so import-time-only stubs are inserted
+into sys.modules (SURVEY.md section 8c recipe).  Output: small .npz/.json fixtures (data
+only: inputs, weights and the reference's outputs).
+
+    python tests/golden/gen_golden.py
+"""
+import json
+import os
+import random
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def _stub_modules():
+    class _Any(types.ModuleType):
+        def __getattr__(self, name):
+            if name.startswith("__"):
+                raise AttributeError(name)
+            return _Any(self.__name__ + "." + name)
+
+        def __call__(self, *a, **k):
+            return None
+
+    names = [
+        "boto3", "botocore", "botocore.client",
+        "rdkit", "rdkit.Chem", "rdkit.DataStructs", "rdkit.RDLogger",
+        "rdkit.Chem.AllChem", "rdkit.Chem.Crippen", "rdkit.Chem.Descriptors", "rdkit.Chem.Draw",
+        "rdkit.Chem.Lipinski", "rdkit.Chem.PandasTools", "rdkit.Chem.rdMolDescriptors",
+        "rdkit.Chem.MolStandardize", "rdkit.Chem.MolStandardize.rdMolStandardize",
+        "rdkit.Chem.rdForceFieldHelpers", "rdkit.Chem.SaltRemover", "rdkit.Chem.rdchem",
+        "rdkit.Chem.Scaffolds", "rdkit.Chem.Scaffolds.MurckoScaffold", "rdkit.Chem.rdmolops",
+    ]
+    for n in names:
+        if n not in sys.modules:
+            sys.modules[n] = _Any(n)
+    for n in names:
+        if "." in n:
+            parent, child = n.rsplit(".", 1)
+            setattr(sys.modules[parent], child, sys.modules[n])
+    sys.modules["rdkit.Chem"].CanonSmiles = lambda s: s
+
+
+_stub_modules()
+sys.path.insert(0, REF)
+
+from coati.models.encoding import basic_transformer as ref_bt  # noqa: E402
+from coati.models.encoding import e_gcl_sparse as ref_gcl  # noqa: E402
+from coati.models.encoding import e3gnn_clip as ref_e3  # noqa: E402
+from coati.models.encoding import smiles_xformer as ref_sx  # noqa: E402
+from coati.models.encoding import clip_e2e as ref_clip  # noqa: E402
+from coati.models.encoding.tokenizers import get_vocab  # noqa: E402
+from coati.models.encoding.tokenizers.trie_tokenizer import TrieTokenizer  # noqa: E402
+from coati.common.periodic_table import PERIODIC_TABLE  # noqa: E402
+
+
+class Tok:
+    """Tokenizer duck type with the probed special ids."""
+    pad_token, stop_token, smiles_token, suffix_token, middle_token, unk_token, clip_token = 0, 1, 2, 5, 6, 7, 8
+    vocab = {"[UNK]": 7, "[STOP]": 1, "[PAD]": 0}
+
+    def __init__(self, n_token, n_seq):
+        self.n_token = n_token
+        self.n_seq = n_seq
+        self.keys = list(range(n_token))
+
+
+SMALL = dict(
+    n_layer_e3gnn=2, n_layer_xformer=2, n_hidden_xformer=64, n_hidden_e3nn=64,
+    n_embd_common=64, n_head=4, n_seq=24, n_tok=48, biases=True, torch_emb=False,
+    residual=False, norm_clips=True, norm_embed=False, token_mlp=True,
+)
+
+
+def synth_batch(B, T, A, V, seed, n_special=12, bad_row=True, far_atom=True):
+    g = torch.Generator().manual_seed(seed)
+    raw = torch.zeros(B, T, dtype=torch.long)
+    tok = torch.zeros(B, T, dtype=torch.long)
+    for b in range(B):
+        L = int(torch.randint(4, T - 4, (1,), generator=g)) if b else T - 4
+        body = torch.randint(n_special, V, (L,), generator=g)
+        raw[b, 0] = 2
+        raw[b, 1 : 1 + L] = body
+        raw[b, 1 + L] = 1
+        if b % 3 != 2:
+            tok[b, 0], tok[b, 1], tok[b, 2] = 8, 7, 2
+            tok[b, 3 : 3 + L] = body
+            tok[b, 3 + L] = 1
+        else:
+            tok[b, 0] = 2
+            tok[b, 1 : 1 + L] = body
+            tok[b, 1 + L] = 1
+    if bad_row:
+        tok[B - 1] = 0
+        raw[B - 1] = 0
+        raw[B - 1, 0] = 1
+    raw = raw[:, : T - 2].contiguous()  # clip_ar_xform truncates each stack to its longest row
+    atoms = torch.zeros(B, A, dtype=torch.long)
+    elems = torch.tensor([1, 6, 7, 8, 9, 16, 17, 35])
+    for b in range(B):
+        n = int(torch.randint(3, A + 1, (1,), generator=g)) if b else A
+        atoms[b, :n] = elems[torch.randint(0, len(elems), (n,), generator=g)]
+    coords = torch.randn(B, A, 3, generator=g) * 1.5
+    if far_atom:
+        coords[0, 1] = coords[0, 0] + torch.tensor([6.0, 0.0, 0.0])  # a pair beyond the 5 A cutoff
+        coords[1, 2] = coords[1, 1]  # coincident atoms: r == 0
+    return raw, tok, atoms, coords
+
+
+def y_next(tokens):
+    y = torch.zeros_like(tokens)
+    y[:, : tokens.shape[1] - 1] = tokens[:, 1:].clone()
+    for t in (8, 0, 7, 5, 6):
+        y[y == t] = -1
+    return y
+
+
+def npify(d):
+    return {k: (v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in d.items()}
+
+
+def main():
+    torch.manual_seed(0)
+    out = {}
+
+    # ---- G16 tokenizer constants + G9 periodic LUT -------------------------------------------
+    consts = {}
+    for name in ("mar", "may_closedparen", "coati2_12_12"):
+        try:
+            t = TrieTokenizer(n_seq=250, **get_vocab(name), **({"side_tasks": False} if name == "coati2_12_12" else {}))
+        except Exception:
+            t = TrieTokenizer(n_seq=250, side_tasks=False, **get_vocab(name))
+        consts[name] = dict(
+            n_token=t.n_token, pad=t.pad_token, stop=t.stop_token, smiles=t.smiles_token,
+            suffix=t.suffix_token, middle=t.middle_token, unk=t.unk_token, clip=t.clip_token,
+            n_special=len(t.special_tokens),
+        )
+    lut = [[e["xpos"], e["ypos"]] for e in PERIODIC_TABLE]
+    with open(os.path.join(OUT, "constants.json"), "w") as f:
+        json.dump({"tokenizers": consts, "xy_lut": lut}, f)
+
+    # ---- G1 rotary, G4 gelu ------------------------------------------------------------------
+    emb = ref_bt.RotaryEmbedding(n_seq=24, n_embd=64, n_tok=48, n_head=4)
+    q = torch.randn(2, 4, 12, 16)
+    k = torch.randn(2, 4, 12, 16)
+    qr, kr = emb.rotary_embed(q, k)
+    x = torch.linspace(-6, 6, 97)
+    out.update(rot_q=q, rot_k=k, rot_qr=qr, rot_kr=kr, rot_cos=emb.cos_cached, rot_sin=emb.sin_cached,
+               gelu_x=x, gelu_y=ref_bt.NewGELU()(x))
+
+    # ---- G7 neighbour list / cutoff ----------------------------------------------------------
+    raw, tok, atoms, coords = synth_batch(5, 16, 8, 48, seed=11)
+    nm = (atoms > 0).float()
+    Is, Js, Ks, Ds = ref_gcl.make_neighborlist(coords, nm)
+    dd = torch.tensor([-1.0, 0.0, 0.5, 2.5, 4.999, 5.0, 7.0])
+    out.update(nl_atoms=atoms, nl_coords=coords, nl_Is=Is, nl_Js=Js, nl_Ks=Ks, nl_Ds=Ds,
+               cut_d=dd, cut_f=ref_gcl.cubic_cutoff(dd))
+
+    # ---- the small model ---------------------------------------------------------------------
+    torch.manual_seed(1)
+    model = ref_clip.e3gnn_smiles_clip_e2e(**SMALL)
+    # default inits leave LN affine = (1,0) and some tiny coord weights; perturb so every
+    # parameter matters in the pins.
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if p.dim() == 1:
+                p.add_(0.05 * torch.randn_like(p))
+    sd = {k: v.clone() for k, v in model.state_dict().items() if not k.endswith(".attn.bias")}
+    np.savez_compressed(os.path.join(OUT, "small_model.npz"), **npify(sd))
+    tokz = Tok(48, 24)
+
+    # G8/G9 GNN
+    h_point = model.point_encoder(atoms, coords)
+    nodes = torch.tensor([[ref_e3.XY_ONE_HOT_FULL(int(a)) for a in m] for m in atoms.tolist()], dtype=torch.float32)
+    h0 = model.point_encoder.embedding_norm(model.point_encoder.embedding(nodes))
+    h1, _ = model.point_encoder.gcl_0(h0, coords, nm, h0=nodes)
+    out.update(gnn_h0=h0, gnn_h1=h1, gnn_out=h_point)
+
+    # G2/G3/G5/G6 transformer pieces
+    xin = torch.randn(3, 10, 64)
+    blk = model.xformer.transformer.h[0]
+    out.update(blk_x=xin, blk_attn=blk.attn(blk.ln_1(xin), model.xformer.emb), blk_y=blk(xin, model.xformer.emb))
+    enc_x = model.xformer.xformer(raw)
+    out.update(enc_x=enc_x, enc_stop=model.xformer.encode(raw, tokz))
+
+    # G10 forward_dist for p in {0,1} and a mixed mask (torch.rand patched)
+    batch = dict(raw_tokens=raw, tokens=tok, atoms=atoms, coords=coords, y_next=y_next(tok))
+    out.update({f"b_{k}": v for k, v in batch.items()})
+    for tag, p in (("p0", 0.0), ("p1", 1.0)):
+        he, hs, lg, bad = model.forward_dist(raw, tok, atoms, coords, tokz, p_clip_emb_smi=p)
+        out.update({f"fd_{tag}_h_e3gnn": he, f"fd_{tag}_h_smiles": hs, f"fd_{tag}_logits": lg, f"fd_{tag}_bad": bad})
+    mixed = torch.tensor([0.9, 0.1, 0.7, 0.2, 0.6])
+    real_rand = torch.rand
+    torch.rand = lambda *a, **k: mixed.clone()
+    he, hs, lg, bad = model.forward_dist(raw, tok, atoms, coords, tokz, p_clip_emb_smi=0.5)
+    torch.rand = real_rand
+    out.update(fd_mix_use_point=(mixed > 0.5), fd_mix_logits=lg)
+
+    # G11 clip loss (+grads), G12 AR CE
+    cl = ref_clip.clip_loss()
+    a = torch.randn(6, 64, requires_grad=True)
+    b = torch.randn(6, 64, requires_grad=True)
+    badr = torch.tensor([False, False, True, False, False, True])
+    l0 = cl(a, b, torch.zeros(6, dtype=torch.bool))
+    l1 = cl(a, b, badr)
+    ga, gb = torch.autograd.grad(l1.sum(), (a, b))
+    out.update(cl_a=a, cl_b=b, cl_bad=badr, cl_l0=l0, cl_l1=l1, cl_ga=ga, cl_gb=gb)
+
+    # G13 full step: loss, grads, grad-norm, weights after 1 and 3 AdamW steps
+    teu = float(np.log(float(48)) / np.log(2.0))
+    opt = torch.optim.AdamW(model.parameters(), lr=5e-4, weight_decay=0.1, betas=(0.9, 0.99), eps=1e-8)
+    losses = []
+    for step in range(3):
+        opt.zero_grad()
+        he, hs, lg, bad = model.forward_dist(raw, tok, atoms, coords, tokz, p_clip_emb_smi=0.0)
+        ar = torch.nn.functional.cross_entropy(lg.view(-1, lg.size(-1)), batch["y_next"].view(-1), ignore_index=-1)
+        c = cl(hs, he, bad).mean()
+        loss = ar + c * teu
+        loss.backward()
+        if step == 0:
+            grads = {"grad." + n: (p.grad.clone() if p.grad is not None else torch.zeros_like(p))
+                     for n, p in model.named_parameters()}
+            np.savez_compressed(os.path.join(OUT, "small_step_grads.npz"), **npify(grads))
+            out.update(step_ar=ar, step_clip=c, step_loss=loss)
+        gn = torch.nn.utils.clip_grad_norm_(model.parameters(), 10.0)
+        if step == 0:
+            out.update(step_gradnorm=gn)
+        opt.step()
+        losses.append(float(loss))
+        if step in (0, 2):
+            sdn = {k: v.clone() for k, v in model.state_dict().items() if not k.endswith(".attn.bias")}
+            np.savez_compressed(os.path.join(OUT, f"small_model_after{step + 1}.npz"), **npify(sdn))
+    out.update(step_losses=np.array(losses, dtype=np.float64))
+
+    # a second step-grad pin with large gradients so that clip_grad_norm actually clips
+    out.update(teu=np.array(teu))
+
+    np.savez_compressed(os.path.join(OUT, "small_vectors.npz"), **npify(out))
+
+    # ---- G15 clip_ar_xform tail (tokenizer 'mar', CanonSmiles stubbed to identity) -----------
+    tk = TrieTokenizer(n_seq=40, **get_vocab("mar"))
+    random.seed(5)
+    smiles = ["c1ccccc1", "CC(=O)O", "CCN(CC)CC", "C\u00e9C", "c1ccc2ccccc2c1O"]
+    bt = {
+        "smiles": np.array(smiles, dtype=object),
+        "source_collection": np.array(["x"] * len(smiles), dtype=object),
+        "atoms": np.array([[6, 6, 8, 0]] * len(smiles)),
+        "coords": np.zeros((len(smiles), 4, 3)),
+    }
+    res = ref_clip.clip_ar_xform(bt, tk, p_dataset=0.0, p_formula=0.0, p_fim=0.0, p_graph=0.0,
+                                 p_clip=0.9, p_clip_cut=0.3, p_randsmiles=0.0)
+    xf = dict(tokens=res["tokens"], raw_tokens=res["raw_tokens"], y_next=res["y_next"])
+    # the un-truncated stacks are re-derivable: pad back to n_seq with zeros
+    np.savez_compressed(os.path.join(OUT, "xform_tail.npz"), **npify(xf))
+    print("golden vectors written to", OUT)
+
+
+if __name__ == "__main__":
+    main()
