@@ -1,0 +1,108 @@
+"""ctypes binding of libcoati_hip.so (C ABI: include/coati_hip.h).  There is no CPU fallback: if the library is
+missing or a call fails, a RuntimeError is raised."""
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_void_p
+
+from . import build as _build
+
+P, I, L, F = c_void_p, c_int, c_int64, c_float
+
+
+class CoatiConfig(ctypes.Structure):
+    _fields_ = [
+        ("n_layer_xformer", c_int32), ("n_layer_e3gnn", c_int32), ("n_hidden_xformer", c_int32),
+        ("n_hidden_e3nn", c_int32), ("n_embd_common", c_int32), ("n_head", c_int32), ("n_seq", c_int32),
+        ("n_tok", c_int32), ("msg_cutoff", c_float), ("pad_token", c_int32), ("stop_token", c_int32),
+        ("unk_token", c_int32),
+    ]
+
+
+_SIGS = {
+    "coati_gemm_nt": [P, I, L, P, L, I, I, I, P, L, I, P, P, P, L, I, P],
+    "coati_gemm_ce_partial": [P, L, P, L, I, I, I, P, P],
+    "coati_ce_finish": [P, I, P, L, P, L, P, P, P, I, I, I, P],
+    "coati_gemm_ce_bwd": [P, L, P, L, I, I, I, P, L, I, P, P, P, P],
+    "coati_wgrad": [P, I, L, P, L, I, I, I, P, L, P, I, P],
+    "coati_sgemm": [P, L, L, P, L, L, P, L, I, I, I, P, F, I, P],
+    "coati_layernorm_fwd": [P, L, P, P, P, L, P, L, P, P, I, I, P],
+    "coati_layernorm_bwd": [P, I, L, P, L, I, P, P, P, P, P, P, P, I, I, P],
+    "coati_attn_fwd": [P, P, P, P, P, I, I, I, P],
+    "coati_attn_bwd": [P, P, P, P, P, P, P, I, I, I, P],
+    "coati_embed_fwd": [P, P, P, I, P, I, I, I, I, P],
+    "coati_embed_bwd": [P, P, P, P, I, I, I, I, I, P],
+    "coati_find_stop": [P, I, P, P, I, I, P],
+    "coati_gather_rows": [P, P, P, I, I, I, P],
+    "coati_scatter_rows_add": [P, P, P, I, I, I, P],
+    "coati_bad_rows": [P, P, I, I, P],
+    "coati_gnn_embed": [P, P, P, P, P, P, P, L, P, P, I, I, P],
+    "coati_gnn_geom": [P, P, F, P, P, I, I, P],
+    "coati_gnn_edge_pre": [P, L, P, P, L, P, P, I, I, I, P],
+    "coati_gnn_edge_reduce": [P, P, P, L, I, I, I, P],
+    "coati_infonce_rows": [P, L, I, I, I, P, P, P, F, P],
+    "coati_grad_sqnorm": [P, L, P, I, P, F, P, P],
+    "coati_adamw": [P, P, P, P, P, L, F, F, F, F, F, I, P, F, P],
+    "coati_engine_create": [POINTER(CoatiConfig), POINTER(c_void_p)],
+    "coati_engine_entry": [P, I, c_char_p, I, POINTER(c_int64), POINTER(c_int32), POINTER(c_int32)],
+    "coati_engine_bind": [P, P, P, P, P, P, P, P, P, P],
+    "coati_engine_refresh_shadows": [P, P],
+    "coati_engine_forward": [P, P, L, I, I, I, I, P, P, P, P, P, P, P, P, P, P, I, P],
+    "coati_engine_logits": [P, P, L, P],
+    "coati_engine_infonce": [P, P, P, P, P, P, I, I, I, F, P, P, P, P],
+    "coati_engine_backward": [P, P, P, I, P],
+    "coati_engine_optimizer_step": [P, F, F, F, F, F, F, I, P, P],
+    "coati_engine_prof_select": [P, I],
+    "coati_engine_prof_collect": [P, POINTER(c_double), POINTER(c_int64), POINTER(c_double)],
+}
+
+_lib = None
+
+
+def lib():
+    """Loads (building if the sources are newer) the HIP library.  Raises if it cannot be loaded."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.LIB
+    if not os.path.exists(path) or (os.environ.get("COATI_AMD_REBUILD") == "1"):
+        _build.build()
+    if not os.path.exists(path):
+        raise RuntimeError(f"coati_amd: {path} is missing and could not be built; there is no CPU fallback")
+    l = ctypes.CDLL(path)
+    l.coati_last_error.restype = c_char_p
+    l.coati_abi_version.restype = c_int
+    for name, sig in _SIGS.items():
+        fn = getattr(l, name)
+        fn.argtypes = sig
+        fn.restype = c_int
+    l.coati_engine_destroy.argtypes = [P]
+    l.coati_engine_destroy.restype = None
+    for name in ("coati_engine_param_elems", "coati_engine_shadow_elems"):
+        getattr(l, name).argtypes = [P]
+        getattr(l, name).restype = c_int64
+    l.coati_engine_workspace_bytes.argtypes = [P, I, I, I, I, I]
+    l.coati_engine_workspace_bytes.restype = c_int64
+    l.coati_engine_n_entries.argtypes = [P]
+    l.coati_engine_n_entries.restype = c_int
+    l.coati_engine_site_count.restype = c_int
+    l.coati_engine_site_name.argtypes = [I]
+    l.coati_engine_site_name.restype = c_char_p
+    _lib = l
+    return l
+
+
+def exported_symbols():
+    return sorted(list(_SIGS) + ["coati_last_error", "coati_abi_version", "coati_engine_destroy",
+                                 "coati_engine_param_elems", "coati_engine_shadow_elems",
+                                 "coati_engine_workspace_bytes", "coati_engine_n_entries",
+                                 "coati_engine_site_count", "coati_engine_site_name"])
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().coati_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"libcoati_hip: {what} failed (code {rc}): {msg}")
+
+
+def call(name, *args):
+    check(getattr(lib(), name)(*args), name)

@@ -1,0 +1,65 @@
+"""Builds libcoati_hip.so (hand-written HIP for gfx950) in-tree with hipcc.  No JIT cache, no torch extension:
+the library has a plain C ABI (include/coati_hip.h) and is loaded with ctypes."""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+LIB = os.path.join(LIBDIR, "libcoati_hip.so")
+OBJDIR = os.path.join(HERE, "build")
+HIP_UNITS = ["gemm.hip", "norm.hip", "attention.hip", "embed.hip", "gnn.hip", "loss.hip", "optim.hip"]
+CPP_UNITS = ["engine.cpp", "capi.cpp"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
+
+
+def _hipcc():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    return "hipcc"
+
+
+def _sources():
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)]
+    deps.append(os.path.join(os.path.dirname(HERE), "include", "coati_hip.h"))
+    return deps
+
+
+def needs_build():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(p) > t for p in _sources())
+
+
+def build(force=False, verbose=True):
+    if not force and not needs_build():
+        return LIB
+    os.makedirs(LIBDIR, exist_ok=True)
+    os.makedirs(OBJDIR, exist_ok=True)
+    hipcc = _hipcc()
+
+    def compile_one(unit):
+        src = os.path.join(CSRC, unit)
+        obj = os.path.join(OBJDIR, unit + ".o")
+        cmd = [hipcc] + FLAGS + (["-x", "hip"] if unit.endswith(".cpp") else []) + ["-c", src, "-o", obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {unit}:\n{r.stderr}")
+        return obj
+
+    with ThreadPoolExecutor(max_workers=8) as ex:
+        objs = list(ex.map(compile_one, HIP_UNITS + CPP_UNITS))
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed:\n{r.stderr}")
+    if verbose:
+        print(f"[coati_amd] built {LIB}", file=sys.stderr)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

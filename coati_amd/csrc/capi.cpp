@@ -1,0 +1,127 @@
+// C ABI wrappers of the fine-grained operators (declared in include/coati_hip.h).
+#include <string.h>
+
+#include "../../include/coati_hip.h"
+#include "kernels.h"
+
+#define S_(x) ((hipStream_t)(x))
+#define LL(x) (reinterpret_cast<const long long*>(x))
+
+extern "C" {
+
+int coati_gemm_nt(const void* A, int a_f32, int64_t lda, const uint16_t* B, int64_t ldb, int M, int N, int K,
+                  void* C, int64_t ldc, int n_store, const float* bias, const void* aux_in, void* aux_out,
+                  int64_t ld_aux, int epi, void* stream) {
+  COATI_CHECK_ARG(epi >= EPI_BF16 && epi <= EPI_ACC_F32, "coati_gemm_nt: epilogue %d is not a plain epilogue", epi);
+  GemmArgs a;
+  memset(&a, 0, sizeof(a));
+  a.A = A; a.lda = lda; a.B = B; a.ldb = ldb; a.M = M; a.N = N; a.K = K; a.C = C; a.ldc = ldc; a.n_store = n_store;
+  a.bias = bias; a.aux_in = aux_in; a.aux_out = aux_out; a.ld_aux = ld_aux;
+  return launch_gemm_nt(a, a_f32, epi, S_(stream));
+}
+
+int coati_gemm_ce_partial(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw, int M, int V, int K,
+                          void* partial, void* stream) {
+  GemmArgs a;
+  memset(&a, 0, sizeof(a));
+  a.A = A; a.lda = lda; a.B = W; a.ldb = ldw; a.M = M; a.N = V; a.K = K; a.partial = reinterpret_cast<float2*>(partial);
+  return launch_gemm_nt(a, 0, EPI_CE_PARTIAL, S_(stream));
+}
+
+int coati_ce_finish(const void* partial, int tiles_n, const uint16_t* A, int64_t lda, const uint16_t* W,
+                    int64_t ldw, const int64_t* target, float* lse, float* scal, int M, int K, int V, void* stream) {
+  return launch_ce_finish(reinterpret_cast<const float2*>(partial), tiles_n, A, lda, W, ldw, LL(target), lse, scal, M, K, V, S_(stream));
+}
+
+int coati_gemm_ce_bwd(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw, int M, int V, int K,
+                      uint16_t* dlogits, int64_t ldd, int n_store, const float* lse, const int64_t* target,
+                      const float* scal, void* stream) {
+  GemmArgs a;
+  memset(&a, 0, sizeof(a));
+  a.A = A; a.lda = lda; a.B = W; a.ldb = ldw; a.M = M; a.N = V; a.K = K; a.C = dlogits; a.ldc = ldd; a.n_store = n_store;
+  a.lse = lse; a.target = LL(target); a.scal = scal;
+  return launch_gemm_nt(a, 0, EPI_CE_BWD, S_(stream));
+}
+
+int coati_wgrad(const void* A, int a_f32, int64_t lda, const uint16_t* B, int64_t ldb, int M, int N, int K,
+                float* dW, int64_t ldw, float* dbias, int n_out, void* stream) {
+  WgradArgs a;
+  a.A = A; a.lda = lda; a.B = B; a.ldb = ldb; a.M = M; a.N = N; a.K = K; a.dW = dW; a.ldw = ldw; a.dbias = dbias; a.n_out = n_out;
+  return launch_wgrad(a, a_f32, S_(stream));
+}
+
+int coati_sgemm(const float* A, int64_t ars, int64_t acs, const float* B, int64_t brs, int64_t bcs, float* C,
+                int64_t ldc, int M, int N, int K, const float* bias, float alpha, int accumulate, void* stream) {
+  return launch_sgemm(A, ars, acs, B, brs, bcs, C, ldc, M, N, K, bias, alpha, accumulate, S_(stream));
+}
+
+int coati_layernorm_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, uint16_t* y16,
+                        int64_t ld16, float* y32, int64_t ld32, float* mean, float* rstd, int M, int C, void* stream) {
+  return launch_layernorm_fwd(x, ldx, gamma, beta, y16, ld16, y32, ld32, mean, rstd, M, C, S_(stream));
+}
+int coati_layernorm_bwd(const void* dy, int dy_f32, int64_t lddy, const float* x, int64_t ldx, int x_is_xhat,
+                        const float* mean, const float* rstd, const float* gamma, const float* dres, float* dx,
+                        float* dgamma, float* dbeta, int M, int C, void* stream) {
+  return launch_layernorm_bwd(dy, dy_f32, lddy, x, ldx, x_is_xhat, mean, rstd, gamma, dres, dx, dgamma, dbeta, M, C, S_(stream));
+}
+
+int coati_attn_fwd(const uint16_t* qkv, uint16_t* y, float* lse, const float* cos_t, const float* sin_t, int B, int T,
+                   int n_head, void* stream) {
+  return launch_attn_fwd(qkv, y, lse, cos_t, sin_t, B, T, n_head, S_(stream));
+}
+int coati_attn_bwd(const uint16_t* qkv, const uint16_t* y, const uint16_t* dy, const float* lse, uint16_t* dqkv,
+                   const float* cos_t, const float* sin_t, int B, int T, int n_head, void* stream) {
+  return launch_attn_bwd(qkv, y, dy, lse, dqkv, cos_t, sin_t, B, T, n_head, S_(stream));
+}
+
+int coati_embed_fwd(const int64_t* idx, const float* table, const float* injection, int unk_token, float* x, int B,
+                    int T, int C, int V, void* stream) {
+  return launch_embed_fwd(LL(idx), table, injection, unk_token, x, B, T, C, V, S_(stream));
+}
+int coati_embed_bwd(const int64_t* idx, const float* dx, float* dtable, float* dinjection, int unk_token, int B, int T,
+                    int C, int V, void* stream) {
+  return launch_embed_bwd(LL(idx), dx, dtable, dinjection, unk_token, B, T, C, V, S_(stream));
+}
+int coati_find_stop(const int64_t* idx, int stop_token, int32_t* pos, int32_t* err, int B, int T, void* stream) {
+  return launch_find_stop(LL(idx), stop_token, pos, err, B, T, S_(stream));
+}
+int coati_gather_rows(const float* x, const int32_t* pos, float* out, int B, int T, int C, void* stream) {
+  return launch_gather_rows(x, pos, out, B, T, C, S_(stream));
+}
+int coati_scatter_rows_add(const float* dout, const int32_t* pos, float* dx, int B, int T, int C, void* stream) {
+  return launch_scatter_rows_add(dout, pos, dx, B, T, C, S_(stream));
+}
+int coati_bad_rows(const int64_t* tokens, uint8_t* bad, int B, int T, void* stream) {
+  return launch_bad_rows(LL(tokens), bad, B, T, S_(stream));
+}
+
+int coati_gnn_embed(const int64_t* atoms, const int32_t* lut_ix, const int32_t* lut_iy, const float* W, const float* b,
+                    float* h32, uint16_t* h16, int64_t ld16, float* rstd, float* mask, int BA, int H, void* stream) {
+  return launch_gnn_embed(LL(atoms), lut_ix, lut_iy, W, b, h32, h16, ld16, rstd, mask, BA, H, S_(stream));
+}
+int coati_gnn_geom(const float* coords, const float* mask, float cutoff, float* d2, float* w, int B, int A, void* stream) {
+  return launch_gnn_geom(coords, mask, cutoff, d2, w, B, A, S_(stream));
+}
+int coati_gnn_edge_pre(const uint16_t* P, int64_t ldp, const float* d2, const float* w1c, int64_t w1c_stride,
+                       const float* b1, uint16_t* e1, int B, int A, int H, void* stream) {
+  return launch_gnn_edge_pre(P, ldp, d2, nullptr, w1c, w1c_stride, b1, e1, B, A, H, S_(stream));
+}
+int coati_gnn_edge_reduce(const uint16_t* s2, const float* w, uint16_t* mi, int64_t ldmi, int B, int A, int H, void* stream) {
+  return launch_gnn_edge_reduce(s2, w, mi, ldmi, B, A, H, S_(stream));
+}
+
+int coati_infonce_rows(float* logits, int64_t ld, int R, int N, int label0, const uint8_t* bad, float* loss_sum,
+                       const float* inv_count, float gscale, void* stream) {
+  return launch_infonce_rows(logits, ld, R, N, label0, bad, loss_sum, inv_count, gscale, S_(stream));
+}
+
+int coati_grad_sqnorm(const float* g, int64_t n, float* partial, int n_partial, float* out_norm, float max_norm,
+                      float* out_coef, void* stream) {
+  return launch_grad_sqnorm(g, n, partial, n_partial, out_norm, max_norm, out_coef, S_(stream));
+}
+int coati_adamw(float* p, const float* g, float* m, float* v, uint16_t* shadow, int64_t n, float lr, float b1, float b2,
+                float eps, float wd, int step, const float* coef, float gscale, void* stream) {
+  return launch_adamw(p, g, m, v, shadow, n, lr, b1, b2, eps, wd, step, coef, gscale, S_(stream));
+}
+
+}  // extern "C"

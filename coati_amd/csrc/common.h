@@ -1,0 +1,109 @@
+// Shared device/host helpers for the gfx950 (CDNA4) kernels of libcoati_hip.so.
+// Written for MI355X only: wave = 64 lanes, MFMA 32x32x16 bf16, 160 KiB LDS per CU.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef unsigned short bf16_t;  // raw bf16 storage
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+#define COATI_OK 0
+#define COATI_EARG (-1)
+#define COATI_ESHAPE (-2)
+#define COATI_EHIP (-3)
+
+void coati_set_error(const char* fmt, ...);
+
+#define COATI_CHECK_ARG(cond, ...)        \
+  do {                                    \
+    if (!(cond)) {                        \
+      coati_set_error(__VA_ARGS__);       \
+      return COATI_EARG;                  \
+    }                                     \
+  } while (0)
+
+#define COATI_CHECK_SHAPE(cond, ...)      \
+  do {                                    \
+    if (!(cond)) {                        \
+      coati_set_error(__VA_ARGS__);       \
+      return COATI_ESHAPE;                \
+    }                                     \
+  } while (0)
+
+#define COATI_LAUNCH_CHECK(name)                                                   \
+  do {                                                                             \
+    hipError_t _e = hipGetLastError();                                             \
+    if (_e != hipSuccess) {                                                        \
+      coati_set_error("%s: HIP launch failed: %s", name, hipGetErrorString(_e));  \
+      return COATI_EHIP;                                                           \
+    }                                                                              \
+  } while (0)
+
+#define COATI_TRY(expr)            \
+  do {                             \
+    int _rc = (expr);              \
+    if (_rc != COATI_OK) return _rc; \
+  } while (0)
+
+// ---- bf16 <-> f32 (round to nearest even, same as torch's .bfloat16()) ---------------------
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  unsigned u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x0040u);  // quiet NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((unsigned)h) << 16); }
+__device__ __forceinline__ unsigned pack2bf(float lo, float hi) {
+  return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+}
+__device__ __forceinline__ float bflo(unsigned u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bfhi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
+
+// 8 consecutive bf16 <-> 8 floats
+__device__ __forceinline__ void unpack8(const uint4& u, float* v) {
+  v[0] = bflo(u.x); v[1] = bfhi(u.x); v[2] = bflo(u.y); v[3] = bfhi(u.y);
+  v[4] = bflo(u.z); v[5] = bfhi(u.z); v[6] = bflo(u.w); v[7] = bfhi(u.w);
+}
+__device__ __forceinline__ uint4 pack8(const float* v) {
+  uint4 u;
+  u.x = pack2bf(v[0], v[1]); u.y = pack2bf(v[2], v[3]);
+  u.z = pack2bf(v[4], v[5]); u.w = pack2bf(v[6], v[7]);
+  return u;
+}
+
+// ---- activations (fp32 math) --------------------------------------------------------------------
+// NewGELU, tanh form (reference basic_transformer.py:12-28)
+__device__ __forceinline__ float gelu_f(float x) {
+  const float k = 0.7978845608028654f;  // sqrt(2/pi)
+  float u = k * (x + 0.044715f * x * x * x);
+  return 0.5f * x * (1.0f + tanhf(u));
+}
+__device__ __forceinline__ float dgelu_f(float x) {
+  const float k = 0.7978845608028654f;
+  float x2 = x * x;
+  float u = k * (x + 0.044715f * x * x2);
+  float t = tanhf(u);
+  float du = k * (1.0f + 3.0f * 0.044715f * x2);
+  return 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * du;
+}
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float silu_f(float x) { return x * sigmoid_f(x); }
+__device__ __forceinline__ float dsilu_f(float x) {
+  float s = sigmoid_f(x);
+  return s * (1.0f + x * (1.0f - s));
+}
+
+// ---- wave reductions (64 lanes) -----------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }

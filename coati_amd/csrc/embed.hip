@@ -1,0 +1,199 @@
+// Token-side gather/scatter kernels (HBM-bound row copies; one 64-lane wave per token row, float4 lanes).
+//   embed_fwd        x[b,t,:] = tok_emb[idx[b,t]]  or  injection[b] where idx == [UNK]
+//                    (reference basic_transformer.py:80-81, smiles_xformer.py:444-448)
+//   embed_bwd        scatter-add of dx into the embedding table / the injected row
+//   find_stop        position of the single [STOP] per row (smiles_xformer.py:50-68)
+//   gather/scatter   row pick at the stop position and its transpose
+//   bad_rows         augmented_tokens.sum(-1) < 1 (clip_e2e.py:813)
+#include "kernels.h"
+
+__global__ __launch_bounds__(256) void embed_fwd_kernel(const long long* __restrict__ idx, const float* __restrict__ table,
+                                                        const float* __restrict__ injection, int unk, float* __restrict__ x,
+                                                        int M, int T, int C, int V) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int m = blockIdx.x * 4 + wave;
+  if (m >= M) return;
+  long long tok = idx[m];
+  const float* src;
+  if (injection != nullptr && tok == unk) {
+    src = injection + (long long)(m / T) * C;
+  } else {
+    if (tok < 0) tok = 0;
+    if (tok >= V) tok = V - 1;
+    src = table + tok * C;
+  }
+  float* dst = x + (long long)m * C;
+  for (int c = lane * 4; c < C; c += 256) *reinterpret_cast<float4*>(dst + c) = *reinterpret_cast<const float4*>(src + c);
+}
+
+int launch_embed_fwd(const long long* idx, const float* table, const float* injection, int unk_token, float* x,
+                     int B, int T, int C, int V, hipStream_t s) {
+  COATI_CHECK_ARG(idx && table && x, "embed_fwd: null operand");
+  COATI_CHECK_SHAPE(B > 0 && T > 0 && C % 4 == 0 && V > 0, "embed_fwd: unsupported shape");
+  const int M = B * T;
+  hipLaunchKernelGGL(embed_fwd_kernel, dim3(cdiv(M, 4)), dim3(256), 0, s, idx, table, injection, unk_token, x, M, T, C, V);
+  COATI_LAUNCH_CHECK("embed_fwd");
+  return COATI_OK;
+}
+
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const long long* __restrict__ idx, const float* __restrict__ dx,
+                                                        float* __restrict__ dtable, float* __restrict__ dinj, int unk,
+                                                        int M, int T, int C, int V) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int m = blockIdx.x * 4 + wave;
+  if (m >= M) return;
+  long long tok = idx[m];
+  float* dst;
+  if (dinj != nullptr && tok == unk) {
+    dst = dinj + (long long)(m / T) * C;
+  } else {
+    if (tok < 0) tok = 0;
+    if (tok >= V) tok = V - 1;
+    dst = dtable + tok * C;
+  }
+  const float* src = dx + (long long)m * C;
+  for (int c = lane * 4; c < C; c += 256) {
+    const float4 g = *reinterpret_cast<const float4*>(src + c);
+    // rows behind the [STOP] token (all the padding) carry exactly-zero gradient under causal attention:
+    // adding 0.0f is a no-op, so skipping it is exact and removes the [PAD]-row atomic hot spot.
+    if (g.x != 0.f) atomicAdd(dst + c, g.x);
+    if (g.y != 0.f) atomicAdd(dst + c + 1, g.y);
+    if (g.z != 0.f) atomicAdd(dst + c + 2, g.z);
+    if (g.w != 0.f) atomicAdd(dst + c + 3, g.w);
+  }
+}
+
+int launch_embed_bwd(const long long* idx, const float* dx, float* dtable, float* dinjection, int unk_token,
+                     int B, int T, int C, int V, hipStream_t s) {
+  COATI_CHECK_ARG(idx && dx && dtable, "embed_bwd: null operand");
+  COATI_CHECK_SHAPE(B > 0 && T > 0 && C % 4 == 0 && V > 0, "embed_bwd: unsupported shape");
+  const int M = B * T;
+  hipLaunchKernelGGL(embed_bwd_kernel, dim3(cdiv(M, 4)), dim3(256), 0, s, idx, dx, dtable, dinjection, unk_token, M, T, C, V);
+  COATI_LAUNCH_CHECK("embed_bwd");
+  return COATI_OK;
+}
+
+__global__ void find_stop_kernel(const long long* __restrict__ idx, int stop, int* __restrict__ pos, int* __restrict__ err,
+                                 int B, int T) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  int n = 0, p = 0;
+  for (int t = 0; t < T; ++t)
+    if (idx[(long long)b * T + t] == stop) { if (n == 0) p = t; ++n; }
+  pos[b] = p;
+  if (n != 1) atomicOr(err, 1);
+}
+
+int launch_find_stop(const long long* idx, int stop_token, int* pos, int* err, int B, int T, hipStream_t s) {
+  COATI_CHECK_ARG(idx && pos && err, "find_stop: null operand");
+  hipLaunchKernelGGL(find_stop_kernel, dim3(cdiv(B, 128)), dim3(128), 0, s, idx, stop_token, pos, err, B, T);
+  COATI_LAUNCH_CHECK("find_stop");
+  return COATI_OK;
+}
+
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ x, const int* __restrict__ pos,
+                                                          float* __restrict__ out, int B, int T, int C) {
+  const int lane = threadIdx.x & 63, b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;
+  const float* src = x + ((long long)b * T + pos[b]) * C;
+  for (int c = lane * 4; c < C; c += 256) *reinterpret_cast<float4*>(out + (long long)b * C + c) = *reinterpret_cast<const float4*>(src + c);
+}
+
+int launch_gather_rows(const float* x, const int* pos, float* out, int B, int T, int C, hipStream_t s) {
+  COATI_CHECK_ARG(x && pos && out, "gather_rows: null operand");
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(cdiv(B, 4)), dim3(256), 0, s, x, pos, out, B, T, C);
+  COATI_LAUNCH_CHECK("gather_rows");
+  return COATI_OK;
+}
+
+__global__ __launch_bounds__(256) void scatter_rows_add_kernel(const float* __restrict__ dout, const int* __restrict__ pos,
+                                                               float* __restrict__ dx, int B, int T, int C) {
+  const int lane = threadIdx.x & 63, b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;
+  float* dst = dx + ((long long)b * T + pos[b]) * C;
+  for (int c = lane * 4; c < C; c += 256) {
+    float4 d = *reinterpret_cast<float4*>(dst + c);
+    const float4 g = *reinterpret_cast<const float4*>(dout + (long long)b * C + c);
+    d.x += g.x; d.y += g.y; d.z += g.z; d.w += g.w;
+    *reinterpret_cast<float4*>(dst + c) = d;
+  }
+}
+
+int launch_scatter_rows_add(const float* dout, const int* pos, float* dx, int B, int T, int C, hipStream_t s) {
+  COATI_CHECK_ARG(dout && pos && dx, "scatter_rows_add: null operand");
+  hipLaunchKernelGGL(scatter_rows_add_kernel, dim3(cdiv(B, 4)), dim3(256), 0, s, dout, pos, dx, B, T, C);
+  COATI_LAUNCH_CHECK("scatter_rows_add");
+  return COATI_OK;
+}
+
+__global__ void bad_rows_kernel(const long long* __restrict__ tok, unsigned char* __restrict__ bad, int B, int T) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  long long sum = 0;
+  for (int t = 0; t < T; ++t) sum += tok[(long long)b * T + t];
+  bad[b] = sum < 1 ? 1 : 0;
+}
+
+int launch_bad_rows(const long long* tokens, unsigned char* bad, int B, int T, hipStream_t s) {
+  COATI_CHECK_ARG(tokens && bad, "bad_rows: null operand");
+  hipLaunchKernelGGL(bad_rows_kernel, dim3(cdiv(B, 128)), dim3(128), 0, s, tokens, bad, B, T);
+  COATI_LAUNCH_CHECK("bad_rows");
+  return COATI_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// cross-entropy finish (lmhead): merge per-tile (max, sumexp) partials into lse[row]; target logit by a
+// direct bf16 dot product (same operands the MFMA saw); accumulate sum(lse - logit_t) and the count.
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ce_finish_kernel(const float2* __restrict__ partial, int tiles_n,
+                                                        const bf16_t* __restrict__ a, long long lda,
+                                                        const bf16_t* __restrict__ W, long long ldw,
+                                                        const long long* __restrict__ target, float* __restrict__ lse,
+                                                        float* __restrict__ scal, int M, int C, int V) {
+  __shared__ float red[2][4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float loss_acc = 0.f, cnt_acc = 0.f;
+  for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+    float mx = -INFINITY;
+    for (int t = lane; t < tiles_n; t += 64) mx = fmaxf(mx, partial[(long long)row * tiles_n + t].x);
+    mx = wave_max(mx);
+    float sm = 0.f;
+    for (int t = lane; t < tiles_n; t += 64) {
+      const float2 p = partial[(long long)row * tiles_n + t];
+      sm += p.y * __expf(p.x - mx);
+    }
+    sm = wave_sum(sm);
+    const float l = mx + __logf(sm);
+    if (lane == 0) lse[row] = l;
+    const long long tgt = target[row];
+    if (tgt >= 0 && tgt < V) {
+      float dot = 0.f;
+      for (int c = lane * 4; c < C; c += 256) {
+        const uint2 ua = *reinterpret_cast<const uint2*>(a + (long long)row * lda + c);
+        const uint2 uw = *reinterpret_cast<const uint2*>(W + tgt * ldw + c);
+        dot += bflo(ua.x) * bflo(uw.x) + bfhi(ua.x) * bfhi(uw.x) + bflo(ua.y) * bflo(uw.y) + bfhi(ua.y) * bfhi(uw.y);
+      }
+      dot = wave_sum(dot);
+      loss_acc += l - dot;
+      cnt_acc += 1.f;
+    }
+  }
+  if (lane == 0) { red[0][wave] = loss_acc; red[1][wave] = cnt_acc; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicAdd(scal + 0, red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+    atomicAdd(scal + 1, red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+  }
+}
+
+int launch_ce_finish(const float2* partial, int tiles_n, const bf16_t* a, long long lda, const bf16_t* W,
+                     long long ldw, const long long* target, float* lse, float* scal, int M, int C, int V,
+                     hipStream_t s) {
+  COATI_CHECK_ARG(partial && a && W && target && lse && scal, "ce_finish: null operand");
+  COATI_CHECK_SHAPE(C % 4 == 0 && lda % 4 == 0 && ldw % 4 == 0, "ce_finish: alignment");
+  int blocks = cdiv(M, 4);
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(ce_finish_kernel, dim3(blocks), dim3(256), 0, s, partial, tiles_n, a, lda, W, ldw, target, lse, scal, M, C, V);
+  COATI_LAUNCH_CHECK("ce_finish");
+  return COATI_OK;
+}

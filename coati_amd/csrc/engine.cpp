@@ -1,0 +1,832 @@
+// Engine: the launch sequence of one contrastive + autoregressive training step (reference
+// clip_e2e.py:772-814 forward_dist, train_coati.py:237-277 do_minibatch) as host C++ that enqueues the
+// gfx950 kernels back to back on one HIP stream.  No device allocation, no host<->device sync.
+//
+// Memory model (all buffers owned by the caller):
+//   params / grads / adam m,v : one flat f32 buffer each; the table below maps the reference's state_dict
+//                               names to (offset, rows, cols).  Offsets are 64-element aligned, pads stay zero.
+//   shadow                    : bf16 GEMM operands: [0, param_elems) mirrors params elementwise; behind it the
+//                               transposed (dgrad) and packed (GNN edge layer) weight copies.
+//   workspace                 : saved activations of both transformer passes and the GNN + backward scratch,
+//                               carved deterministically per (B, T1, T2, A).
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/coati_hip.h"
+#include "kernels.h"
+
+static thread_local char g_err[512] = "";
+void coati_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char* coati_last_error(void) { return g_err; }
+extern "C" int coati_abi_version(void) { return COATI_ABI_VERSION; }
+
+namespace {
+
+struct Entry {
+  std::string name;
+  int64_t off;
+  int rows, cols;
+};
+
+enum Site {
+  SITE_QKV_FWD = 0, SITE_PROJ_FWD, SITE_FC1_FWD, SITE_FC2_FWD, SITE_ATTN_FWD, SITE_LN_FWD, SITE_LMHEAD_FWD,
+  SITE_FC2_DGRAD, SITE_FC1_DGRAD, SITE_PROJ_DGRAD, SITE_QKV_DGRAD, SITE_XF_WGRAD, SITE_ATTN_BWD, SITE_LN_BWD,
+  SITE_LMHEAD_DLOGITS, SITE_LMHEAD_DGRAD, SITE_LMHEAD_WGRAD, SITE_GNN_EDGE_GEMM, SITE_GNN_NODE_GEMM,
+  SITE_GNN_WGRAD, SITE_GNN_ELEMWISE, SITE_EMBED, SITE_OPTIM, SITE_COUNT
+};
+const char* kSiteNames[SITE_COUNT] = {
+    "qkv_fwd", "proj_fwd", "fc1_fwd", "fc2_fwd", "attn_fwd", "ln_fwd", "lmhead_fwd", "fc2_dgrad", "fc1_dgrad",
+    "proj_dgrad", "qkv_dgrad", "xf_wgrad", "attn_bwd", "ln_bwd", "lmhead_dlogits", "lmhead_dgrad", "lmhead_wgrad",
+    "gnn_edge_gemm", "gnn_node_gemm", "gnn_wgrad", "gnn_elemwise", "embed", "optim"};
+
+struct XLayerP {  // offsets into the flat parameter buffer
+  int64_t ln1w, ln1b, attnw, attnb, projw, projb, ln2w, ln2b, fc1w, fc1b, fc2w, fc2b;
+  int64_t attnT, projT, fc1T, fc2T;  // offsets into the shadow buffer
+};
+struct GLayerP {
+  int64_t e0w, e0b, e3w, e3b, n0w, n0b, n3w, n3b, c0w, c0b, c2w;
+  int64_t w1ab, w1abT, e3T, n0T, n3T;  // shadow extras
+};
+
+struct XPass {  // saved activations of one transformer pass
+  int B, T, M;
+  const long long* idx;
+  std::vector<float*> x;      // L+1 residual-stream snapshots [M,C]
+  std::vector<float*> xmid;   // L
+  std::vector<float*> mean1, rstd1, mean2, rstd2, lse;
+  std::vector<bf16_t*> a1, qkv, y, a2, hpre, g;
+  float *meanf, *rstdf, *xf32;
+  bf16_t* af;
+};
+
+struct Arena {
+  char* base;
+  size_t off, cap;
+  bool dry;
+  template <typename T>
+  T* take(size_t n) {
+    off = (off + 255) & ~(size_t)255;
+    T* p = dry ? nullptr : reinterpret_cast<T*>(base + off);
+    off += n * sizeof(T);
+    return p;
+  }
+};
+
+}  // namespace
+
+struct coati_engine {
+  coati_config cfg;
+  std::vector<Entry> entries;
+  int64_t n_params = 0, n_shadow = 0;
+  int Vpad = 0;
+  // parameter offsets
+  int64_t tok_emb = 0, lnfw = 0, lnfb = 0, lmhead = 0, lmheadT = 0;
+  std::vector<XLayerP> xl;
+  std::vector<GLayerP> gl;
+  int64_t gembw = 0, gembb = 0, gd0w = 0, gd0b = 0, gd3w = 0, gd3b = 0, gd0T = 0, gd3T = 0;
+  int64_t p2c_lnw = 0, p2c_lnb = 0, p2c_w = 0, p2c_b = 0, s2c_lnw = 0, s2c_lnb = 0, s2c_w = 0, s2c_b = 0, tokw = 0, tokb = 0;
+  // bound buffers
+  float *P = nullptr, *G = nullptr, *Mo = nullptr, *Vo = nullptr;
+  bf16_t* S = nullptr;
+  const float *cos_t = nullptr, *sin_t = nullptr;
+  const int *lut_ix = nullptr, *lut_iy = nullptr;
+  // per-step state (pointers into the caller's workspace)
+  bool have_fwd = false;
+  int B = 0, T1 = 0, T2 = 0, A = 0;
+  XPass p1, p2;
+  const long long *y_next = nullptr, *atoms = nullptr;
+  const unsigned char* use_point = nullptr;
+  float* scal = nullptr;
+  // heads
+  float *hpoint, *hp_ln, *hp_mean, *hp_rstd, *hstop, *hs_ln, *hs_mean, *hs_rstd, *h_e3gnn, *h_smiles;
+  float *sa, *sb, *ptok, *stok, *cliptok, *ones;
+  int* stop_pos;
+  int* err_flag;
+  // lm head
+  float2* ce_partial;
+  float* ce_lse;
+  bf16_t* dlogits;
+  // gnn
+  std::vector<float*> g_h32, g_rstd;
+  std::vector<bf16_t*> g_hcat, g_P, g_e1, g_s2, g_upre, g_t;
+  bf16_t *g_hfin16, *g_dpre, *g_td;
+  float *g_mask, *g_d2, *g_w, *g_o, *g_o2;
+  // backward scratch
+  float *DX, *dcliptok, *dptok, *dstok, *dsa, *dsb, *dhe, *dhs, *dhs_ln, *dhstop, *dhp_ln, *dhpoint;
+  bf16_t *dh4, *da, *dyb, *dqkv;
+  float *g_DH, *g_DO;
+  bf16_t *g_do2, *g_dtd, *g_du, *g_dmi, *g_ds2, *g_dpre1, *g_dP;
+  float* opt_partial;
+  // profiling
+  int prof_site = -1;
+  std::vector<hipEvent_t> ev;
+  int ev_used = 0;
+  double prof_flops = 0.0;
+};
+
+namespace {
+
+int64_t add_entry(coati_engine* e, const std::string& name, int rows, int cols) {
+  const int64_t n = (int64_t)rows * (cols > 0 ? cols : 1);
+  const int64_t off = e->n_params;
+  e->entries.push_back({name, off, rows, cols});
+  e->n_params = (off + n + 63) & ~(int64_t)63;
+  return off;
+}
+int64_t add_shadow(coati_engine* e, int64_t n) {
+  const int64_t off = e->n_shadow;
+  e->n_shadow = (off + n + 63) & ~(int64_t)63;
+  return off;
+}
+
+void build_layout(coati_engine* e) {
+  const coati_config& c = e->cfg;
+  const int C = c.n_hidden_xformer, H = c.n_hidden_e3nn, E = c.n_embd_common, V = c.n_tok;
+  e->Vpad = (V + 63) & ~63;
+  // --- transformer (smiles_xformer.py:71-100, basic_transformer.py:103-169) ---
+  e->tok_emb = add_entry(e, "xformer.emb.tok_emb.weight", V, C);
+  e->xl.resize(c.n_layer_xformer);
+  for (int l = 0; l < c.n_layer_xformer; ++l) {
+    const std::string p = "xformer.transformer.h." + std::to_string(l) + ".";
+    XLayerP& x = e->xl[l];
+    x.ln1w = add_entry(e, p + "ln_1.weight", C, 0);
+    x.ln1b = add_entry(e, p + "ln_1.bias", C, 0);
+    x.attnw = add_entry(e, p + "attn.c_attn.weight", 3 * C, C);
+    x.attnb = add_entry(e, p + "attn.c_attn.bias", 3 * C, 0);
+    x.projw = add_entry(e, p + "attn.c_proj.weight", C, C);
+    x.projb = add_entry(e, p + "attn.c_proj.bias", C, 0);
+    x.ln2w = add_entry(e, p + "ln_2.weight", C, 0);
+    x.ln2b = add_entry(e, p + "ln_2.bias", C, 0);
+    x.fc1w = add_entry(e, p + "mlpf.0.weight", 4 * C, C);
+    x.fc1b = add_entry(e, p + "mlpf.0.bias", 4 * C, 0);
+    x.fc2w = add_entry(e, p + "mlpf.2.weight", C, 4 * C);
+    x.fc2b = add_entry(e, p + "mlpf.2.bias", C, 0);
+  }
+  e->lnfw = add_entry(e, "xformer.transformer.ln_f.weight", C, 0);
+  e->lnfb = add_entry(e, "xformer.transformer.ln_f.bias", C, 0);
+  e->lmhead = add_entry(e, "xformer.lm_head.weight", V, C);
+  // --- point encoder (e3gnn_clip.py:75-104, e_gcl_sparse.py:130-150) ---
+  e->gembw = add_entry(e, "point_encoder.embedding.weight", H, 28);
+  e->gembb = add_entry(e, "point_encoder.embedding.bias", H, 0);
+  e->gd0w = add_entry(e, "point_encoder.node_dec.0.weight", H, H);
+  e->gd0b = add_entry(e, "point_encoder.node_dec.0.bias", H, 0);
+  e->gd3w = add_entry(e, "point_encoder.node_dec.3.weight", H, H);
+  e->gd3b = add_entry(e, "point_encoder.node_dec.3.bias", H, 0);
+  e->gl.resize(c.n_layer_e3gnn);
+  for (int l = 0; l < c.n_layer_e3gnn; ++l) {
+    const std::string p = "point_encoder.gcl_" + std::to_string(l) + ".";
+    GLayerP& g = e->gl[l];
+    g.e0w = add_entry(e, p + "edge_mlp.0.weight", H, 2 * H + 1);
+    g.e0b = add_entry(e, p + "edge_mlp.0.bias", H, 0);
+    g.e3w = add_entry(e, p + "edge_mlp.3.weight", H, H);
+    g.e3b = add_entry(e, p + "edge_mlp.3.bias", H, 0);
+    g.n0w = add_entry(e, p + "node_mlp.0.weight", H, 2 * H);
+    g.n0b = add_entry(e, p + "node_mlp.0.bias", H, 0);
+    g.n3w = add_entry(e, p + "node_mlp.3.weight", H, H);
+    g.n3b = add_entry(e, p + "node_mlp.3.bias", H, 0);
+    // coord_mlp is evaluated and discarded by the reference (e3gnn_clip.py:132): parameters kept for
+    // state_dict parity, never read, gradient stays zero.
+    g.c0w = add_entry(e, p + "coord_mlp.0.weight", H, H);
+    g.c0b = add_entry(e, p + "coord_mlp.0.bias", H, 0);
+    g.c2w = add_entry(e, p + "coord_mlp.2.weight", 1, H);
+  }
+  // --- heads (clip_e2e.py:419-435) ---
+  e->p2c_lnw = add_entry(e, "point_to_clip.0.weight", H, 0);
+  e->p2c_lnb = add_entry(e, "point_to_clip.0.bias", H, 0);
+  e->p2c_w = add_entry(e, "point_to_clip.1.weight", E, H);
+  e->p2c_b = add_entry(e, "point_to_clip.1.bias", E, 0);
+  e->s2c_lnw = add_entry(e, "smiles_to_clip.0.weight", E, 0);
+  e->s2c_lnb = add_entry(e, "smiles_to_clip.0.bias", E, 0);
+  e->s2c_w = add_entry(e, "smiles_to_clip.1.weight", E, C);
+  e->s2c_b = add_entry(e, "smiles_to_clip.1.bias", E, 0);
+  e->tokw = add_entry(e, "point_clip_to_special_tokens.1.weight", E, E);
+  e->tokb = add_entry(e, "point_clip_to_special_tokens.1.bias", E, 0);
+
+  // --- shadow extras ---
+  e->n_shadow = e->n_params;
+  for (auto& x : e->xl) {
+    x.attnT = add_shadow(e, (int64_t)C * 3 * C);
+    x.projT = add_shadow(e, (int64_t)C * C);
+    x.fc1T = add_shadow(e, (int64_t)C * 4 * C);
+    x.fc2T = add_shadow(e, (int64_t)4 * C * C);
+  }
+  e->lmheadT = add_shadow(e, (int64_t)C * e->Vpad);
+  for (auto& g : e->gl) {
+    g.w1ab = add_shadow(e, (int64_t)2 * H * H);
+    g.w1abT = add_shadow(e, (int64_t)H * 2 * H);
+    g.e3T = add_shadow(e, (int64_t)H * H);
+    g.n0T = add_shadow(e, (int64_t)2 * H * H);
+    g.n3T = add_shadow(e, (int64_t)H * H);
+  }
+  e->gd0T = add_shadow(e, (int64_t)H * H);
+  e->gd3T = add_shadow(e, (int64_t)H * H);
+}
+
+// ---- profiling wrapper ---------------------------------------------------------------------------------
+struct ProfScope {
+  coati_engine* e;
+  hipStream_t s;
+  bool on;
+  ProfScope(coati_engine* e_, int site, double flops, hipStream_t s_) : e(e_), s(s_), on(false) {
+    if (e->prof_site == site && e->ev_used + 2 <= (int)e->ev.size()) {
+      on = true;
+      hipEventRecord(e->ev[e->ev_used], s);
+      e->prof_flops += flops;
+    }
+  }
+  ~ProfScope() {
+    if (on) {
+      hipEventRecord(e->ev[e->ev_used + 1], s);
+      e->ev_used += 2;
+    }
+  }
+};
+
+// ---- GEMM helpers -------------------------------------------------------------------------------------
+int gemm(coati_engine* e, int site, const void* A, int a_f32, int64_t lda, const bf16_t* Bm, int64_t ldb, int M,
+         int N, int K, void* Cm, int64_t ldc, const float* bias, int epi, const void* aux_in, void* aux_out,
+         int64_t ld_aux, hipStream_t s) {
+  GemmArgs a;
+  memset(&a, 0, sizeof(a));
+  a.A = A; a.lda = lda; a.B = Bm; a.ldb = ldb; a.M = M; a.N = N; a.K = K; a.C = Cm; a.ldc = ldc; a.bias = bias;
+  a.aux_in = aux_in; a.aux_out = aux_out; a.ld_aux = ld_aux;
+  ProfScope ps(e, site, 2.0 * M * N * K, s);
+  return launch_gemm_nt(a, a_f32, epi, s);
+}
+int wgrad(coati_engine* e, int site, const void* A, int a_f32, int64_t lda, const bf16_t* Bm, int64_t ldb, int M,
+          int N, int K, float* dW, int64_t ldw, float* dbias, int n_out, hipStream_t s) {
+  WgradArgs a;
+  a.A = A; a.lda = lda; a.B = Bm; a.ldb = ldb; a.M = M; a.N = N; a.K = K; a.dW = dW; a.ldw = ldw; a.dbias = dbias;
+  a.n_out = n_out;
+  ProfScope ps(e, site, 2.0 * M * N * K, s);
+  return launch_wgrad(a, a_f32, s);
+}
+
+// ---- workspace carving -----------------------------------------------------------------------------------
+void carve_pass(coati_engine* e, Arena& ar, XPass& p, int B, int T) {
+  const int L = e->cfg.n_layer_xformer, C = e->cfg.n_hidden_xformer, nh = e->cfg.n_head;
+  const size_t M = (size_t)B * T;
+  p.B = B; p.T = T; p.M = (int)M;
+  p.x.assign(L + 1, nullptr); p.xmid.assign(L, nullptr);
+  p.mean1.assign(L, nullptr); p.rstd1.assign(L, nullptr); p.mean2.assign(L, nullptr); p.rstd2.assign(L, nullptr);
+  p.lse.assign(L, nullptr);
+  p.a1.assign(L, nullptr); p.qkv.assign(L, nullptr); p.y.assign(L, nullptr); p.a2.assign(L, nullptr);
+  p.hpre.assign(L, nullptr); p.g.assign(L, nullptr);
+  for (int l = 0; l <= L; ++l) p.x[l] = ar.take<float>(M * C);
+  for (int l = 0; l < L; ++l) {
+    p.xmid[l] = ar.take<float>(M * C);
+    p.mean1[l] = ar.take<float>(M); p.rstd1[l] = ar.take<float>(M);
+    p.mean2[l] = ar.take<float>(M); p.rstd2[l] = ar.take<float>(M);
+    p.lse[l] = ar.take<float>((size_t)B * nh * T);
+    p.a1[l] = ar.take<bf16_t>(M * C);
+    p.qkv[l] = ar.take<bf16_t>(M * 3 * C);
+    p.y[l] = ar.take<bf16_t>(M * C);
+    p.a2[l] = ar.take<bf16_t>(M * C);
+    p.hpre[l] = ar.take<bf16_t>(M * 4 * C);
+    p.g[l] = ar.take<bf16_t>(M * 4 * C);
+  }
+  p.meanf = ar.take<float>(M); p.rstdf = ar.take<float>(M);
+  p.xf32 = ar.take<float>(M * C);
+  p.af = ar.take<bf16_t>(M * C);
+}
+
+size_t carve(coati_engine* e, Arena& ar, int B, int T1, int T2, int A, int Bg) {
+  const coati_config& c = e->cfg;
+  const int C = c.n_hidden_xformer, H = c.n_hidden_e3nn, E = c.n_embd_common, Lg = c.n_layer_e3gnn;
+  const size_t Mmax = (size_t)B * (T1 > T2 ? T1 : T2), M2 = (size_t)B * T2;
+  const size_t BA = (size_t)B * A, Me = BA * A;
+  (void)Bg;
+  carve_pass(e, ar, e->p1, B, T1);
+  carve_pass(e, ar, e->p2, B, T2);
+  // heads
+  e->hpoint = ar.take<float>((size_t)B * H); e->hp_ln = ar.take<float>((size_t)B * H);
+  e->hp_mean = ar.take<float>(B); e->hp_rstd = ar.take<float>(B);
+  e->hstop = ar.take<float>((size_t)B * C); e->hs_ln = ar.take<float>((size_t)B * C);
+  e->hs_mean = ar.take<float>(B); e->hs_rstd = ar.take<float>(B);
+  e->h_e3gnn = ar.take<float>((size_t)B * E); e->h_smiles = ar.take<float>((size_t)B * E);
+  e->sa = ar.take<float>((size_t)B * E); e->sb = ar.take<float>((size_t)B * E);
+  e->ptok = ar.take<float>((size_t)B * E); e->stok = ar.take<float>((size_t)B * E);
+  e->cliptok = ar.take<float>((size_t)B * E);
+  e->ones = ar.take<float>(B);
+  e->stop_pos = ar.take<int>(B);
+  e->err_flag = ar.take<int>(4);
+  // lm head
+  const int tiles_v = cdiv(c.n_tok, 128);
+  e->ce_partial = ar.take<float2>(M2 * tiles_v);
+  e->ce_lse = ar.take<float>(M2);
+  e->dlogits = ar.take<bf16_t>(M2 * e->Vpad);
+  // gnn
+  e->g_h32.assign(Lg + 1, nullptr); e->g_rstd.assign(Lg + 1, nullptr);
+  e->g_hcat.assign(Lg, nullptr); e->g_P.assign(Lg, nullptr); e->g_e1.assign(Lg, nullptr); e->g_s2.assign(Lg, nullptr);
+  e->g_upre.assign(Lg, nullptr); e->g_t.assign(Lg, nullptr);
+  for (int l = 0; l <= Lg; ++l) { e->g_h32[l] = ar.take<float>(BA * H); e->g_rstd[l] = ar.take<float>(BA); }
+  for (int l = 0; l < Lg; ++l) {
+    e->g_hcat[l] = ar.take<bf16_t>(BA * 2 * H); e->g_P[l] = ar.take<bf16_t>(BA * 2 * H);
+    e->g_e1[l] = ar.take<bf16_t>(Me * H); e->g_s2[l] = ar.take<bf16_t>(Me * H);
+    e->g_upre[l] = ar.take<bf16_t>(BA * H); e->g_t[l] = ar.take<bf16_t>(BA * H);
+  }
+  e->g_hfin16 = ar.take<bf16_t>(BA * H); e->g_dpre = ar.take<bf16_t>(BA * H); e->g_td = ar.take<bf16_t>(BA * H);
+  e->g_mask = ar.take<float>(BA); e->g_d2 = ar.take<float>(Me); e->g_w = ar.take<float>(Me);
+  e->g_o = ar.take<float>(BA * H); e->g_o2 = ar.take<float>(BA * H);
+  // backward scratch
+  e->DX = ar.take<float>(Mmax * C);
+  e->dh4 = ar.take<bf16_t>(Mmax * 4 * C); e->da = ar.take<bf16_t>(Mmax * C); e->dyb = ar.take<bf16_t>(Mmax * C);
+  e->dqkv = ar.take<bf16_t>(Mmax * 3 * C);
+  e->dcliptok = ar.take<float>((size_t)B * E); e->dptok = ar.take<float>((size_t)B * E); e->dstok = ar.take<float>((size_t)B * E);
+  e->dsa = ar.take<float>((size_t)B * E); e->dsb = ar.take<float>((size_t)B * E);
+  e->dhe = ar.take<float>((size_t)B * E); e->dhs = ar.take<float>((size_t)B * E);
+  e->dhs_ln = ar.take<float>((size_t)B * C); e->dhstop = ar.take<float>((size_t)B * C);
+  e->dhp_ln = ar.take<float>((size_t)B * H); e->dhpoint = ar.take<float>((size_t)B * H);
+  e->g_DH = ar.take<float>(BA * H); e->g_DO = ar.take<float>(BA * H);
+  e->g_do2 = ar.take<bf16_t>(BA * H); e->g_dtd = ar.take<bf16_t>(BA * H); e->g_du = ar.take<bf16_t>(BA * H);
+  e->g_dmi = ar.take<bf16_t>(BA * H); e->g_ds2 = ar.take<bf16_t>(Me * H); e->g_dpre1 = ar.take<bf16_t>(Me * H);
+  e->g_dP = ar.take<bf16_t>(BA * 2 * H);
+  e->opt_partial = ar.take<float>(1024);
+  return (ar.off + 255) & ~(size_t)255;
+}
+
+// ---- transformer pass ---------------------------------------------------------------------------------
+int xformer_fwd(coati_engine* e, XPass& p, const float* injection, hipStream_t s) {
+  const coati_config& c = e->cfg;
+  const int C = c.n_hidden_xformer, L = c.n_layer_xformer, M = p.M;
+  {
+    ProfScope ps(e, SITE_EMBED, 0, s);
+    COATI_TRY(launch_embed_fwd(p.idx, e->P + e->tok_emb, injection, c.unk_token, p.x[0], p.B, p.T, C, c.n_tok, s));
+  }
+  for (int l = 0; l < L; ++l) {
+    const XLayerP& w = e->xl[l];
+    {
+      ProfScope ps(e, SITE_LN_FWD, 0, s);
+      COATI_TRY(launch_layernorm_fwd(p.x[l], C, e->P + w.ln1w, e->P + w.ln1b, p.a1[l], C, nullptr, 0, p.mean1[l], p.rstd1[l], M, C, s));
+    }
+    COATI_TRY(gemm(e, SITE_QKV_FWD, p.a1[l], 0, C, e->S + w.attnw, C, M, 3 * C, C, p.qkv[l], 3 * C, e->P + w.attnb, EPI_BF16, nullptr, nullptr, 0, s));
+    {
+      ProfScope ps(e, SITE_ATTN_FWD, 4.0 * p.B * (double)p.T * p.T * C, s);
+      COATI_TRY(launch_attn_fwd(p.qkv[l], p.y[l], p.lse[l], e->cos_t, e->sin_t, p.B, p.T, c.n_head, s));
+    }
+    COATI_TRY(gemm(e, SITE_PROJ_FWD, p.y[l], 0, C, e->S + w.projw, C, M, C, C, p.xmid[l], C, e->P + w.projb, EPI_RES_F32, p.x[l], nullptr, C, s));
+    {
+      ProfScope ps(e, SITE_LN_FWD, 0, s);
+      COATI_TRY(launch_layernorm_fwd(p.xmid[l], C, e->P + w.ln2w, e->P + w.ln2b, p.a2[l], C, nullptr, 0, p.mean2[l], p.rstd2[l], M, C, s));
+    }
+    COATI_TRY(gemm(e, SITE_FC1_FWD, p.a2[l], 0, C, e->S + w.fc1w, C, M, 4 * C, C, p.g[l], 4 * C, e->P + w.fc1b, EPI_GELU, nullptr, p.hpre[l], 4 * C, s));
+    COATI_TRY(gemm(e, SITE_FC2_FWD, p.g[l], 0, 4 * C, e->S + w.fc2w, 4 * C, M, C, 4 * C, p.x[l + 1], C, e->P + w.fc2b, EPI_RES_F32, p.xmid[l], nullptr, C, s));
+  }
+  ProfScope ps(e, SITE_LN_FWD, 0, s);
+  return launch_layernorm_fwd(p.x[L], C, e->P + e->lnfw, e->P + e->lnfb, p.af, C, p.xf32, C, p.meanf, p.rstdf, M, C, s);
+}
+
+// dyf: gradient w.r.t. ln_f output, bf16 (decoder pass) or f32 (encoder pass)
+int xformer_bwd(coati_engine* e, XPass& p, const void* dyf, int dyf_f32, float* dinjection, hipStream_t s) {
+  const coati_config& c = e->cfg;
+  const int C = c.n_hidden_xformer, L = c.n_layer_xformer, M = p.M;
+  float* DX = e->DX;
+  {
+    ProfScope ps(e, SITE_LN_BWD, 0, s);
+    COATI_TRY(launch_layernorm_bwd(dyf, dyf_f32, C, p.x[L], C, 0, p.meanf, p.rstdf, e->P + e->lnfw, nullptr, DX, e->G + e->lnfw, e->G + e->lnfb, M, C, s));
+  }
+  for (int l = L - 1; l >= 0; --l) {
+    const XLayerP& w = e->xl[l];
+    // x[l+1] = xmid + g W2^T + b2
+    COATI_TRY(gemm(e, SITE_FC2_DGRAD, DX, 1, C, e->S + w.fc2T, C, M, 4 * C, C, e->dh4, 4 * C, nullptr, EPI_DGELU, p.hpre[l], nullptr, 4 * C, s));
+    COATI_TRY(wgrad(e, SITE_XF_WGRAD, DX, 1, C, p.g[l], 4 * C, M, C, 4 * C, e->G + w.fc2w, 4 * C, e->G + w.fc2b, 0, s));
+    // hpre = a2 W1^T + b1
+    COATI_TRY(gemm(e, SITE_FC1_DGRAD, e->dh4, 0, 4 * C, e->S + w.fc1T, 4 * C, M, C, 4 * C, e->da, C, nullptr, EPI_BF16, nullptr, nullptr, 0, s));
+    COATI_TRY(wgrad(e, SITE_XF_WGRAD, e->dh4, 0, 4 * C, p.a2[l], C, M, 4 * C, C, e->G + w.fc1w, C, e->G + w.fc1b, 0, s));
+    {
+      ProfScope ps(e, SITE_LN_BWD, 0, s);
+      COATI_TRY(launch_layernorm_bwd(e->da, 0, C, p.xmid[l], C, 0, p.mean2[l], p.rstd2[l], e->P + w.ln2w, DX, DX, e->G + w.ln2w, e->G + w.ln2b, M, C, s));
+    }
+    // xmid = x[l] + y Wp^T + bp
+    COATI_TRY(gemm(e, SITE_PROJ_DGRAD, DX, 1, C, e->S + w.projT, C, M, C, C, e->dyb, C, nullptr, EPI_BF16, nullptr, nullptr, 0, s));
+    COATI_TRY(wgrad(e, SITE_XF_WGRAD, DX, 1, C, p.y[l], C, M, C, C, e->G + w.projw, C, e->G + w.projb, 0, s));
+    {
+      ProfScope ps(e, SITE_ATTN_BWD, 10.0 * p.B * (double)p.T * p.T * C, s);
+      COATI_TRY(launch_attn_bwd(p.qkv[l], p.y[l], e->dyb, p.lse[l], e->dqkv, e->cos_t, e->sin_t, p.B, p.T, c.n_head, s));
+    }
+    COATI_TRY(gemm(e, SITE_QKV_DGRAD, e->dqkv, 0, 3 * C, e->S + w.attnT, 3 * C, M, C, 3 * C, e->da, C, nullptr, EPI_BF16, nullptr, nullptr, 0, s));
+    COATI_TRY(wgrad(e, SITE_XF_WGRAD, e->dqkv, 0, 3 * C, p.a1[l], C, M, 3 * C, C, e->G + w.attnw, C, e->G + w.attnb, 0, s));
+    {
+      ProfScope ps(e, SITE_LN_BWD, 0, s);
+      COATI_TRY(launch_layernorm_bwd(e->da, 0, C, p.x[l], C, 0, p.mean1[l], p.rstd1[l], e->P + w.ln1w, DX, DX, e->G + w.ln1w, e->G + w.ln1b, M, C, s));
+    }
+  }
+  ProfScope ps(e, SITE_EMBED, 0, s);
+  return launch_embed_bwd(p.idx, DX, e->G + e->tok_emb, dinjection, c.unk_token, p.B, p.T, C, c.n_tok, s);
+}
+
+// ---- point encoder -------------------------------------------------------------------------------------
+int gnn_fwd(coati_engine* e, const long long* atoms, const float* coords, hipStream_t s) {
+  const coati_config& c = e->cfg;
+  const int H = c.n_hidden_e3nn, Lg = c.n_layer_e3gnn, B = e->B, A = e->A, BA = B * A, Me = BA * A;
+  {
+    ProfScope ps(e, SITE_GNN_ELEMWISE, 0, s);
+    bf16_t* h16 = Lg > 0 ? e->g_hcat[0] : e->g_hfin16;
+    COATI_TRY(launch_gnn_embed(atoms, e->lut_ix, e->lut_iy, e->P + e->gembw, e->P + e->gembb, e->g_h32[0], h16, Lg > 0 ? 2 * H : H, e->g_rstd[0], e->g_mask, BA, H, s));
+    COATI_TRY(launch_gnn_geom(coords, e->g_mask, c.msg_cutoff, e->g_d2, e->g_w, B, A, s));
+  }
+  for (int l = 0; l < Lg; ++l) {
+    const GLayerP& w = e->gl[l];
+    COATI_TRY(gemm(e, SITE_GNN_NODE_GEMM, e->g_hcat[l], 0, 2 * H, e->S + w.w1ab, H, BA, 2 * H, H, e->g_P[l], 2 * H, nullptr, EPI_BF16, nullptr, nullptr, 0, s));
+    {
+      ProfScope ps(e, SITE_GNN_ELEMWISE, 0, s);
+      COATI_TRY(launch_gnn_edge_pre(e->g_P[l], 2 * H, e->g_d2, e->g_w, e->P + w.e0w + 2 * H, 2 * H + 1, e->P + w.e0b, e->g_e1[l], B, A, H, s));
+    }
+    COATI_TRY(gemm(e, SITE_GNN_EDGE_GEMM, e->g_e1[l], 0, H, e->S + w.e3w, H, Me, H, H, e->g_s2[l], H, e->P + w.e3b, EPI_BF16, nullptr, nullptr, 0, s));
+    {
+      ProfScope ps(e, SITE_GNN_ELEMWISE, 0, s);
+      COATI_TRY(launch_gnn_edge_reduce(e->g_s2[l], e->g_w, e->g_hcat[l] + H, 2 * H, B, A, H, s));
+    }
+    COATI_TRY(gemm(e, SITE_GNN_NODE_GEMM, e->g_hcat[l], 0, 2 * H, e->S + w.n0w, 2 * H, BA, H, 2 * H, e->g_t[l], H, e->P + w.n0b, EPI_SILU, nullptr, e->g_upre[l], H, s));
+    COATI_TRY(gemm(e, SITE_GNN_NODE_GEMM, e->g_t[l], 0, H, e->S + w.n3w, H, BA, H, H, e->g_o, H, e->P + w.n3b, EPI_RES_F32, e->g_h32[l], nullptr, H, s));
+    {
+      ProfScope ps(e, SITE_GNN_ELEMWISE, 0, s);
+      const bool last = (l + 1 == Lg);
+      COATI_TRY(launch_layernorm_fwd(e->g_o, H, nullptr, nullptr, last ? e->g_hfin16 : e->g_hcat[l + 1], last ? H : 2 * H, e->g_h32[l + 1], H, nullptr, e->g_rstd[l + 1], BA, H, s));
+    }
+  }
+  COATI_TRY(gemm(e, SITE_GNN_NODE_GEMM, e->g_hfin16, 0, H, e->S + e->gd0w, H, BA, H, H, e->g_td, H, e->P + e->gd0b, EPI_SILU, nullptr, e->g_dpre, H, s));
+  COATI_TRY(gemm(e, SITE_GNN_NODE_GEMM, e->g_td, 0, H, e->S + e->gd3w, H, BA, H, H, e->g_o2, H, e->P + e->gd3b, EPI_F32, nullptr, nullptr, 0, s));
+  ProfScope ps(e, SITE_GNN_ELEMWISE, 0, s);
+  return launch_gnn_readout(e->g_o2, e->g_mask, e->hpoint, B, A, H, s);
+}
+
+int gnn_bwd(coati_engine* e, const float* dhpoint, hipStream_t s) {
+  const coati_config& c = e->cfg;
+  const int H = c.n_hidden_e3nn, Lg = c.n_layer_e3gnn, B = e->B, A = e->A, BA = B * A, Me = BA * A;
+  float *DH = e->g_DH, *DO = e->g_DO;
+  {
+    ProfScope ps(e, SITE_GNN_ELEMWISE, 0, s);
+    COATI_TRY(launch_gnn_readout_bwd(dhpoint, e->g_mask, e->g_do2, B, A, H, s));
+  }
+  COATI_TRY(gemm(e, SITE_GNN_NODE_GEMM, e->g_do2, 0, H, e->S + e->gd3T, H, BA, H, H, e->g_dtd, H, nullptr, EPI_DSILU, e->g_dpre, nullptr, H, s));
+  COATI_TRY(wgrad(e, SITE_GNN_WGRAD, e->g_do2, 0, H, e->g_td, H, BA, H, H, e->G + e->gd3w, H, e->G + e->gd3b, 0, s));
+  COATI_TRY(gemm(e, SITE_GNN_NODE_GEMM, e->g_dtd, 0, H, e->S + e->gd0T, H, BA, H, H, DH, H, nullptr, EPI_F32, nullptr, nullptr, 0, s));
+  COATI_TRY(wgrad(e, SITE_GNN_WGRAD, e->g_dtd, 0, H, e->g_hfin16, H, BA, H, H, e->G + e->gd0w, H, e->G + e->gd0b, 0, s));
+  for (int l = Lg - 1; l >= 0; --l) {
+    const GLayerP& w = e->gl[l];
+    {
+      ProfScope ps(e, SITE_GNN_ELEMWISE, 0, s);
+      COATI_TRY(launch_layernorm_bwd(DH, 1, H, e->g_h32[l + 1], H, 1, nullptr, e->g_rstd[l + 1], nullptr, nullptr, DO, nullptr, nullptr, BA, H, s));
+    }
+    // o = h + t W4^T + b4
+    COATI_TRY(gemm(e, SITE_GNN_NODE_GEMM, DO, 1, H, e->S + w.n3T, H, BA, H, H, e->g_du, H, nullptr, EPI_DSILU, e->g_upre[l], nullptr, H, s));
+    COATI_TRY(wgrad(e, SITE_GNN_WGRAD, DO, 1, H, e->g_t[l], H, BA, H, H, e->G + w.n3w, H, e->G + w.n3b, 0, s));
+    // u = [h | mi] W3^T + b3 ; W3T is [2H rows][H]
+    COATI_TRY(gemm(e, SITE_GNN_NODE_GEMM, e->g_du, 0, H, e->S + w.n0T, H, BA, H, H, DO, H, nullptr, EPI_ACC_F32, nullptr, nullptr, 0, s));
+    COATI_TRY(gemm(e, SITE_GNN_NODE_GEMM, e->g_du, 0, H, e->S + w.n0T + (int64_t)H * H, H, BA, H, H, e->g_dmi, H, nullptr, EPI_BF16, nullptr, nullptr, 0, s));
+    COATI_TRY(wgrad(e, SITE_GNN_WGRAD, e->g_du, 0, H, e->g_hcat[l], 2 * H, BA, H, 2 * H, e->G + w.n0w, 2 * H, e->G + w.n0b, 0, s));
+    {
+      ProfScope ps(e, SITE_GNN_ELEMWISE, 0, s);
+      COATI_TRY(launch_gnn_edge_reduce_bwd(e->g_dmi, H, e->g_s2[l], e->g_w, e->g_ds2, B, A, H, s));
+    }
+    {
+      GemmArgs a;
+      memset(&a, 0, sizeof(a));
+      a.A = e->g_ds2; a.lda = H; a.B = e->S + w.e3T; a.ldb = H; a.M = Me; a.N = H; a.K = H; a.C = e->g_dpre1; a.ldc = H;
+      a.P = e->g_P[l]; a.ldp = 2 * H; a.d2 = e->g_d2; a.w1c = e->P + w.e0w + 2 * H; a.w1c_stride = 2 * H + 1;
+      a.b1 = e->P + w.e0b; a.natom = A; a.H = H;
+      ProfScope ps(e, SITE_GNN_EDGE_GEMM, 2.0 * Me * H * H, s);
+      COATI_TRY(launch_gemm_nt(a, 0, EPI_EDGE_DPRE, s));
+    }
+    COATI_TRY(wgrad(e, SITE_GNN_WGRAD, e->g_ds2, 0, H, e->g_e1[l], H, Me, H, H, e->G + w.e3w, H, e->G + w.e3b, 0, s));
+    {
+      ProfScope ps(e, SITE_GNN_ELEMWISE, 0, s);
+      COATI_TRY(launch_gnn_edge_pre_bwd(e->g_dpre1, e->g_d2, e->g_dP, 2 * H, e->G + w.e0w + 2 * H, 2 * H + 1, e->G + w.e0b, B, A, H, s));
+    }
+    COATI_TRY(gemm(e, SITE_GNN_NODE_GEMM, e->g_dP, 0, 2 * H, e->S + w.w1abT, 2 * H, BA, H, 2 * H, DO, H, nullptr, EPI_ACC_F32, nullptr, nullptr, 0, s));
+    COATI_TRY(wgrad(e, SITE_GNN_WGRAD, e->g_dP, 0, 2 * H, e->g_hcat[l], 2 * H, BA, H, H, e->G + w.e0w, 2 * H + 1, nullptr, 0, s));
+    COATI_TRY(wgrad(e, SITE_GNN_WGRAD, e->g_dP + H, 0, 2 * H, e->g_hcat[l], 2 * H, BA, H, H, e->G + w.e0w + H, 2 * H + 1, nullptr, 0, s));
+    float* t = DH; DH = DO; DO = t;
+  }
+  {
+    ProfScope ps(e, SITE_GNN_ELEMWISE, 0, s);
+    COATI_TRY(launch_layernorm_bwd(DH, 1, H, e->g_h32[0], H, 1, nullptr, e->g_rstd[0], nullptr, nullptr, DO, nullptr, nullptr, BA, H, s));
+    COATI_TRY(launch_gnn_embed_bwd(e->atoms, e->lut_ix, e->lut_iy, DO, e->G + e->gembw, e->G + e->gembb, BA, H, s));
+  }
+  return COATI_OK;
+}
+
+// fp32 Linear backward on [B, *] head tensors: dW += dY^T X ; db += colsum(dY) ; dX = dY W
+int head_linear_bwd(coati_engine* e, const float* dY, const float* X, int64_t w_off, int64_t b_off, float* dX, int B,
+                    int N, int K, hipStream_t s) {
+  const float* W = e->P + w_off;
+  COATI_TRY(launch_sgemm(dY, 1, N, X, K, 1, e->G + w_off, K, N, K, B, nullptr, 1.f, 1, s));          // dW[n,k] += sum_b dY[b,n] X[b,k]
+  COATI_TRY(launch_sgemm(e->ones, 0, 1, dY, N, 1, e->G + b_off, N, 1, N, B, nullptr, 1.f, 1, s));    // db[n] += sum_b dY[b,n]
+  if (dX) COATI_TRY(launch_sgemm(dY, N, 1, W, K, 1, dX, K, B, K, N, nullptr, 1.f, 0, s));            // dX[b,k] = sum_n dY[b,n] W[n,k]
+  return COATI_OK;
+}
+
+}  // namespace
+
+// =====================================================================================================
+// C ABI: engine
+// =====================================================================================================
+extern "C" {
+
+int coati_engine_create(const coati_config* cfg, coati_engine** out) {
+  COATI_CHECK_ARG(cfg && out, "engine_create: null argument");
+  const int C = cfg->n_hidden_xformer, H = cfg->n_hidden_e3nn, E = cfg->n_embd_common;
+  COATI_CHECK_SHAPE(cfg->n_head > 0 && C == cfg->n_head * 16, "engine_create: head size must be 16 (C=%d, n_head=%d)", C, cfg->n_head);
+  COATI_CHECK_SHAPE(C % 64 == 0 && H % 64 == 0 && C <= 1024 && H <= 1024, "engine_create: C=%d and H=%d must be multiples of 64 (<=1024)", C, H);
+  COATI_CHECK_SHAPE(E == C, "engine_create: n_embd_common (%d) must equal n_hidden_xformer (%d)", E, C);
+  COATI_CHECK_SHAPE(cfg->n_seq > 0 && cfg->n_seq <= 256 && cfg->n_tok > 8, "engine_create: n_seq must be <= 256");
+  COATI_CHECK_SHAPE(cfg->n_layer_xformer >= 1 && cfg->n_layer_e3gnn >= 0, "engine_create: bad layer counts");
+  coati_engine* e = new coati_engine();
+  e->cfg = *cfg;
+  build_layout(e);
+  *out = e;
+  return COATI_OK;
+}
+
+void coati_engine_destroy(coati_engine* e) {
+  if (!e) return;
+  for (auto ev : e->ev) hipEventDestroy(ev);
+  delete e;
+}
+
+int64_t coati_engine_param_elems(const coati_engine* e) { return e ? e->n_params : 0; }
+int coati_engine_n_entries(const coati_engine* e) { return e ? (int)e->entries.size() : 0; }
+int coati_engine_entry(const coati_engine* e, int i, char* name, int name_cap, int64_t* offset, int32_t* rows, int32_t* cols) {
+  COATI_CHECK_ARG(e && i >= 0 && i < (int)e->entries.size() && name && name_cap > 0, "engine_entry: bad argument");
+  const Entry& en = e->entries[i];
+  snprintf(name, name_cap, "%s", en.name.c_str());
+  if (offset) *offset = en.off;
+  if (rows) *rows = en.rows;
+  if (cols) *cols = en.cols;
+  return COATI_OK;
+}
+int64_t coati_engine_shadow_elems(const coati_engine* e) { return e ? e->n_shadow : 0; }
+
+int64_t coati_engine_workspace_bytes(const coati_engine* e, int B, int T1, int T2, int A, int Bg) {
+  if (!e || B <= 0 || T1 <= 0 || T2 <= 0 || A <= 0) return 0;
+  coati_engine tmp = *e;  // carve on a copy: no side effects on the live engine
+  tmp.ev.clear();
+  Arena ar{nullptr, 0, 0, true};
+  return (int64_t)carve(&tmp, ar, B, T1, T2, A, Bg);
+}
+
+int coati_engine_bind(coati_engine* e, float* params, float* grads, float* adam_m, float* adam_v, uint16_t* shadow,
+                      const float* rope_cos, const float* rope_sin, const int32_t* lut_ix, const int32_t* lut_iy) {
+  COATI_CHECK_ARG(e && params && shadow && rope_cos && rope_sin && lut_ix && lut_iy, "engine_bind: null argument");
+  e->P = params; e->G = grads; e->Mo = adam_m; e->Vo = adam_v; e->S = shadow;
+  e->cos_t = rope_cos; e->sin_t = rope_sin; e->lut_ix = lut_ix; e->lut_iy = lut_iy;
+  return COATI_OK;
+}
+
+int coati_engine_refresh_shadows(coati_engine* e, void* stream) {
+  COATI_CHECK_ARG(e && e->P && e->S, "refresh_shadows: engine not bound");
+  hipStream_t s = (hipStream_t)stream;
+  const coati_config& c = e->cfg;
+  const int C = c.n_hidden_xformer, H = c.n_hidden_e3nn;
+  ProfScope ps(e, SITE_OPTIM, 0, s);
+  COATI_TRY(launch_cast_bf16(e->P, e->S, e->n_params, s));
+  for (const XLayerP& w : e->xl) {
+    COATI_TRY(launch_transpose_cast(e->P + w.attnw, C, e->S + w.attnT, 3 * C, 3 * C, C, s));
+    COATI_TRY(launch_transpose_cast(e->P + w.projw, C, e->S + w.projT, C, C, C, s));
+    COATI_TRY(launch_transpose_cast(e->P + w.fc1w, C, e->S + w.fc1T, 4 * C, 4 * C, C, s));
+    COATI_TRY(launch_transpose_cast(e->P + w.fc2w, 4 * C, e->S + w.fc2T, C, C, 4 * C, s));
+  }
+  COATI_TRY(launch_transpose_cast(e->P + e->lmhead, C, e->S + e->lmheadT, e->Vpad, c.n_tok, C, s));
+  for (const GLayerP& w : e->gl) {
+    // W1 is [H, 2H+1]: receiver block W1a = cols [0,H), sender block W1b = cols [H,2H)
+    COATI_TRY(launch_pack_rows_cast(e->P + w.e0w, 2 * H + 1, e->S + w.w1ab, H, H, H, s));
+    COATI_TRY(launch_pack_rows_cast(e->P + w.e0w + H, 2 * H + 1, e->S + w.w1ab + (int64_t)H * H, H, H, H, s));
+    // W1abT [H][2H]: T[k][n] = W1ab[n][k]
+    COATI_TRY(launch_transpose_cast(e->P + w.e0w, 2 * H + 1, e->S + w.w1abT, 2 * H, H, H, s));
+    COATI_TRY(launch_transpose_cast(e->P + w.e0w + H, 2 * H + 1, e->S + w.w1abT + H, 2 * H, H, H, s));
+    COATI_TRY(launch_transpose_cast(e->P + w.e3w, H, e->S + w.e3T, H, H, H, s));
+    COATI_TRY(launch_transpose_cast(e->P + w.n0w, 2 * H, e->S + w.n0T, H, H, 2 * H, s));
+    COATI_TRY(launch_transpose_cast(e->P + w.n3w, H, e->S + w.n3T, H, H, H, s));
+  }
+  COATI_TRY(launch_transpose_cast(e->P + e->gd0w, H, e->S + e->gd0T, H, H, H, s));
+  COATI_TRY(launch_transpose_cast(e->P + e->gd3w, H, e->S + e->gd3T, H, H, H, s));
+  return COATI_OK;
+}
+
+int coati_engine_forward(coati_engine* e, void* workspace, int64_t workspace_bytes, int B, int T1, int T2, int A,
+                         const int64_t* raw_tokens, const int64_t* tokens, const int64_t* y_next,
+                         const int64_t* atoms, const float* coords, const uint8_t* use_point, float* h_e3gnn,
+                         float* h_smiles, uint8_t* bad_rows, float* scal, int train, void* stream) {
+  COATI_CHECK_ARG(e && e->P && e->S, "engine_forward: engine not bound");
+  COATI_CHECK_ARG(workspace && raw_tokens && tokens && atoms && coords && use_point && scal, "engine_forward: null argument");
+  COATI_CHECK_ARG(!train || (e->G && y_next), "engine_forward: training needs grads and y_next");
+  const coati_config& c = e->cfg;
+  COATI_CHECK_SHAPE(B > 0 && T1 > 0 && T2 > 0 && A > 1 && T1 <= c.n_seq && T2 <= c.n_seq,
+                    "engine_forward: unsupported shape B=%d T1=%d T2=%d A=%d (n_seq=%d)", B, T1, T2, A, c.n_seq);
+  hipStream_t s = (hipStream_t)stream;
+  const int C = c.n_hidden_xformer, H = c.n_hidden_e3nn, E = c.n_embd_common;
+  Arena ar{reinterpret_cast<char*>(workspace), 0, (size_t)workspace_bytes, false};
+  const size_t need = carve(e, ar, B, T1, T2, A, B);
+  COATI_CHECK_ARG((int64_t)need <= workspace_bytes, "engine_forward: workspace too small (%zu > %lld)", need, (long long)workspace_bytes);
+  e->B = B; e->T1 = T1; e->T2 = T2; e->A = A;
+  e->p1.idx = reinterpret_cast<const long long*>(raw_tokens);
+  e->p2.idx = reinterpret_cast<const long long*>(tokens);
+  e->y_next = reinterpret_cast<const long long*>(y_next);
+  e->atoms = reinterpret_cast<const long long*>(atoms);
+  e->use_point = use_point;
+  e->scal = scal;
+  e->have_fwd = false;
+
+#define HIPCHK(x) do { hipError_t _h = (x); if (_h != hipSuccess) { coati_set_error("%s: %s", #x, hipGetErrorString(_h)); return COATI_EHIP; } } while (0)
+  HIPCHK(hipMemsetAsync(scal, 0, 16 * sizeof(float), s));
+  HIPCHK(hipMemsetAsync(e->err_flag, 0, 4 * sizeof(int), s));
+  if (train) HIPCHK(hipMemsetAsync(e->G, 0, (size_t)e->n_params * sizeof(float), s));
+  {
+    // ones[B] for bias column sums
+    std::vector<float> dummy;  // (filled on device below)
+    HIPCHK(hipMemsetD32Async((hipDeviceptr_t)e->ones, 0x3f800000, B, s));
+  }
+
+  // ---- point encoder + point_to_clip (clip_e2e.py:454-461) ----
+  COATI_TRY(gnn_fwd(e, e->atoms, coords, s));
+  COATI_TRY(launch_layernorm_fwd(e->hpoint, H, e->P + e->p2c_lnw, e->P + e->p2c_lnb, nullptr, 0, e->hp_ln, H, e->hp_mean, e->hp_rstd, B, H, s));
+  COATI_TRY(launch_sgemm(e->hp_ln, H, 1, e->P + e->p2c_w, 1, H, e->h_e3gnn, E, B, E, H, e->P + e->p2c_b, 1.f, 0, s));
+  // ---- encoder pass + smiles_to_clip (clip_e2e.py:448-452) ----
+  COATI_TRY(xformer_fwd(e, e->p1, nullptr, s));
+  COATI_TRY(launch_find_stop(e->p1.idx, c.stop_token, e->stop_pos, e->err_flag, B, T1, s));
+  COATI_TRY(launch_gather_rows(e->p1.xf32, e->stop_pos, e->hstop, B, T1, C, s));
+  COATI_TRY(launch_layernorm_fwd(e->hstop, C, e->P + e->s2c_lnw, e->P + e->s2c_lnb, nullptr, 0, e->hs_ln, C, e->hs_mean, e->hs_rstd, B, C, s));
+  COATI_TRY(launch_sgemm(e->hs_ln, C, 1, e->P + e->s2c_w, 1, C, e->h_smiles, E, B, E, C, e->P + e->s2c_b, 1.f, 0, s));
+  // ---- special token (clip_e2e.py:800-808) ----
+  COATI_TRY(launch_silu_fwd(e->h_e3gnn, e->sa, (long long)B * E, s));
+  COATI_TRY(launch_silu_fwd(e->h_smiles, e->sb, (long long)B * E, s));
+  COATI_TRY(launch_sgemm(e->sa, E, 1, e->P + e->tokw, 1, E, e->ptok, E, B, E, E, e->P + e->tokb, 1.f, 0, s));
+  COATI_TRY(launch_sgemm(e->sb, E, 1, e->P + e->tokw, 1, E, e->stok, E, B, E, E, e->P + e->tokb, 1.f, 0, s));
+  COATI_TRY(launch_select_rows(use_point, e->ptok, e->stok, e->cliptok, B, E, s));
+  // ---- decoder pass with injection (smiles_xformer.py:426-452) ----
+  COATI_TRY(xformer_fwd(e, e->p2, e->cliptok, s));
+  if (bad_rows) COATI_TRY(launch_bad_rows(e->p2.idx, bad_rows, B, T2, s));
+  // ---- lm_head + AR cross-entropy, logits never materialised (smiles_xformer.py:453, train_coati.py:260-265) ----
+  if (y_next) {
+    const int M2 = B * T2, tiles_v = cdiv(c.n_tok, 128);
+    GemmArgs a;
+    memset(&a, 0, sizeof(a));
+    a.A = e->p2.af; a.lda = C; a.B = e->S + e->lmhead; a.ldb = C; a.M = M2; a.N = c.n_tok; a.K = C; a.partial = e->ce_partial;
+    {
+      ProfScope ps(e, SITE_LMHEAD_FWD, 2.0 * M2 * c.n_tok * C, s);
+      COATI_TRY(launch_gemm_nt(a, 0, EPI_CE_PARTIAL, s));
+    }
+    COATI_TRY(launch_ce_finish(e->ce_partial, tiles_v, e->p2.af, C, e->S + e->lmhead, C, e->y_next, e->ce_lse, scal, M2, C, c.n_tok, s));
+  }
+  if (h_e3gnn) HIPCHK(hipMemcpyAsync(h_e3gnn, e->h_e3gnn, (size_t)B * E * sizeof(float), hipMemcpyDeviceToDevice, s));
+  if (h_smiles) HIPCHK(hipMemcpyAsync(h_smiles, e->h_smiles, (size_t)B * E * sizeof(float), hipMemcpyDeviceToDevice, s));
+  HIPCHK(hipMemcpyAsync(scal + 6, e->err_flag, sizeof(int), hipMemcpyDeviceToDevice, s));
+  e->have_fwd = true;
+  return COATI_OK;
+}
+
+int coati_engine_logits(coati_engine* e, float* logits, int64_t ldl, void* stream) {
+  COATI_CHECK_ARG(e && e->have_fwd && logits, "engine_logits: no forward to read");
+  const coati_config& c = e->cfg;
+  hipStream_t s = (hipStream_t)stream;
+  return gemm(e, SITE_LMHEAD_FWD, e->p2.af, 0, c.n_hidden_xformer, e->S + e->lmhead, c.n_hidden_xformer, e->B * e->T2, c.n_tok,
+              c.n_hidden_xformer, logits, ldl, nullptr, EPI_F32, nullptr, nullptr, 0, s);
+}
+
+int coati_engine_infonce(coati_engine* e, const float* S_loc, const float* C_loc, const float* S_all,
+                         const float* C_all, const uint8_t* bad_all, int B, int Bg, int row0, float gscale,
+                         float* dS_all, float* dC_all, float* scal, void* stream) {
+  COATI_CHECK_ARG(e && S_loc && C_loc && S_all && C_all && bad_all && dS_all && dC_all && scal, "engine_infonce: null argument");
+  COATI_CHECK_SHAPE(B > 0 && Bg >= B && row0 >= 0 && row0 + B <= Bg, "engine_infonce: bad row range");
+  hipStream_t s = (hipStream_t)stream;
+  const int E = e->cfg.n_embd_common;
+  // logits scratch lives in the (now idle) backward scratch of the decoder pass: [B, Bg] f32 x 2
+  COATI_CHECK_SHAPE((size_t)2 * B * Bg * sizeof(float) <= (size_t)e->B * (e->T1 > e->T2 ? e->T1 : e->T2) * 4 * e->cfg.n_hidden_xformer * sizeof(bf16_t),
+                    "engine_infonce: Bg=%d too large for the logits scratch", Bg);
+  COATI_CHECK_ARG(e->have_fwd && B == e->B, "engine_infonce: call forward first");
+  float* L1 = reinterpret_cast<float*>(e->dh4);
+  float* L2 = L1 + (size_t)B * Bg;
+  COATI_TRY(launch_count_valid(bad_all, Bg, scal + 4, scal + 7, s));
+  // L1 = S_loc C_all^T ; L2 = C_loc S_all^T     (clip_e2e.py:36-37, local rows only)
+  COATI_TRY(launch_sgemm(S_loc, E, 1, C_all, 1, E, L1, Bg, B, Bg, E, nullptr, 1.f, 0, s));
+  COATI_TRY(launch_sgemm(C_loc, E, 1, S_all, 1, E, L2, Bg, B, Bg, E, nullptr, 1.f, 0, s));
+  COATI_TRY(launch_infonce_rows(L1, Bg, B, Bg, row0, bad_all, scal + 2, scal + 7, gscale, s));
+  COATI_TRY(launch_infonce_rows(L2, Bg, B, Bg, row0, bad_all, scal + 3, scal + 7, gscale, s));
+  // column-side gradients: dC_all = dL1^T S_loc ; dS_all = dL2^T C_loc
+  COATI_TRY(launch_sgemm(L1, 1, Bg, S_loc, E, 1, dC_all, E, Bg, E, B, nullptr, 1.f, 0, s));
+  COATI_TRY(launch_sgemm(L2, 1, Bg, C_loc, E, 1, dS_all, E, Bg, E, B, nullptr, 1.f, 0, s));
+  // row-side gradients added into the local row block: dS_loc += dL1 C_all ; dC_loc += dL2 S_all
+  COATI_TRY(launch_sgemm(L1, Bg, 1, C_all, E, 1, dS_all + (size_t)row0 * E, E, B, E, Bg, nullptr, 1.f, 1, s));
+  COATI_TRY(launch_sgemm(L2, Bg, 1, S_all, E, 1, dC_all + (size_t)row0 * E, E, B, E, Bg, nullptr, 1.f, 1, s));
+  return COATI_OK;
+}
+
+int coati_engine_backward(coati_engine* e, const float* dh_smiles, const float* dh_e3gnn, int stage, void* stream) {
+  COATI_CHECK_ARG(e && e->have_fwd && e->G, "engine_backward: no forward / gradient buffer");
+  COATI_CHECK_ARG(stage >= 0 && stage <= 3, "engine_backward: bad stage");
+  hipStream_t s = (hipStream_t)stream;
+  const coati_config& c = e->cfg;
+  const int C = c.n_hidden_xformer, H = c.n_hidden_e3nn, E = c.n_embd_common, B = e->B;
+  if (stage == 0 || stage == 1) {
+    const int M2 = B * e->T2;
+    // ---- lm_head backward: dlogits (bf16) -> d(af), dW_lm ----
+    {
+      GemmArgs a;
+      memset(&a, 0, sizeof(a));
+      a.A = e->p2.af; a.lda = C; a.B = e->S + e->lmhead; a.ldb = C; a.M = M2; a.N = c.n_tok; a.K = C;
+      a.C = e->dlogits; a.ldc = e->Vpad; a.n_store = e->Vpad; a.lse = e->ce_lse; a.target = e->y_next; a.scal = e->scal;
+      ProfScope ps(e, SITE_LMHEAD_DLOGITS, 2.0 * M2 * c.n_tok * C, s);
+      COATI_TRY(launch_gemm_nt(a, 0, EPI_CE_BWD, s));
+    }
+    COATI_TRY(gemm(e, SITE_LMHEAD_DGRAD, e->dlogits, 0, e->Vpad, e->S + e->lmheadT, e->Vpad, M2, C, e->Vpad, e->da, C, nullptr, EPI_BF16, nullptr, nullptr, 0, s));
+    COATI_TRY(wgrad(e, SITE_LMHEAD_WGRAD, e->dlogits, 0, e->Vpad, e->p2.af, C, M2, e->Vpad, C, e->G + e->lmhead, C, nullptr, c.n_tok, s));
+    // ---- decoder pass ----
+    HIPCHK(hipMemsetAsync(e->dcliptok, 0, (size_t)B * E * sizeof(float), s));
+    COATI_TRY(xformer_bwd(e, e->p2, e->da, 0, e->dcliptok, s));
+    // ---- special-token head: cliptok = where(use_point, ptok, stok) ----
+    HIPCHK(hipMemsetAsync(e->dptok, 0, (size_t)B * E * sizeof(float), s));
+    HIPCHK(hipMemsetAsync(e->dstok, 0, (size_t)B * E * sizeof(float), s));
+    COATI_TRY(launch_select_rows_bwd(e->use_point, e->dcliptok, e->dptok, e->dstok, B, E, s));
+    COATI_TRY(head_linear_bwd(e, e->dptok, e->sa, e->tokw, e->tokb, e->dsa, B, E, E, s));
+    COATI_TRY(head_linear_bwd(e, e->dstok, e->sb, e->tokw, e->tokb, e->dsb, B, E, E, s));
+    // dh = external (contrastive) gradient + SiLU' path
+    if (dh_e3gnn) HIPCHK(hipMemcpyAsync(e->dhe, dh_e3gnn, (size_t)B * E * sizeof(float), hipMemcpyDeviceToDevice, s));
+    else HIPCHK(hipMemsetAsync(e->dhe, 0, (size_t)B * E * sizeof(float), s));
+    if (dh_smiles) HIPCHK(hipMemcpyAsync(e->dhs, dh_smiles, (size_t)B * E * sizeof(float), hipMemcpyDeviceToDevice, s));
+    else HIPCHK(hipMemsetAsync(e->dhs, 0, (size_t)B * E * sizeof(float), s));
+    COATI_TRY(launch_silu_bwd(e->h_e3gnn, e->dsa, e->dhe, (long long)B * E, 1, s));
+    COATI_TRY(launch_silu_bwd(e->h_smiles, e->dsb, e->dhs, (long long)B * E, 1, s));
+    // smiles_to_clip / point_to_clip: Linear then LayerNorm backward
+    COATI_TRY(head_linear_bwd(e, e->dhs, e->hs_ln, e->s2c_w, e->s2c_b, e->dhs_ln, B, E, C, s));
+    COATI_TRY(launch_layernorm_bwd(e->dhs_ln, 1, C, e->hstop, C, 0, e->hs_mean, e->hs_rstd, e->P + e->s2c_lnw, nullptr, e->dhstop, e->G + e->s2c_lnw, e->G + e->s2c_lnb, B, C, s));
+    COATI_TRY(head_linear_bwd(e, e->dhe, e->hp_ln, e->p2c_w, e->p2c_b, e->dhp_ln, B, E, H, s));
+    COATI_TRY(launch_layernorm_bwd(e->dhp_ln, 1, H, e->hpoint, H, 0, e->hp_mean, e->hp_rstd, e->P + e->p2c_lnw, nullptr, e->dhpoint, e->G + e->p2c_lnw, e->G + e->p2c_lnb, B, H, s));
+  }
+  if (stage == 0 || stage == 2) {
+    // ---- encoder pass: gradient enters at the [STOP] rows of ln_f's output ----
+    float* dxf = reinterpret_cast<float*>(e->dh4);  // [M1, C] f32 scratch (dh4 is idle here: 4C bf16 >= C f32)
+    HIPCHK(hipMemsetAsync(dxf, 0, (size_t)e->p1.M * C * sizeof(float), s));
+    COATI_TRY(launch_scatter_rows_add(e->dhstop, e->stop_pos, dxf, B, e->T1, C, s));
+    // xformer_bwd consumes dyf in its first kernel (ln_f backward) before dh4 is rewritten
+    COATI_TRY(xformer_bwd(e, e->p1, dxf, 1, nullptr, s));
+  }
+  if (stage == 0 || stage == 3) {
+    COATI_TRY(gnn_bwd(e, e->dhpoint, s));
+  }
+  return COATI_OK;
+}
+
+int coati_engine_optimizer_step(coati_engine* e, float lr, float beta1, float beta2, float eps, float weight_decay,
+                                float max_norm, int step, float* scal, void* stream) {
+  COATI_CHECK_ARG(e && e->P && e->G && e->Mo && e->Vo && scal, "optimizer_step: engine not bound for training");
+  COATI_CHECK_ARG(e->have_fwd, "optimizer_step: needs the workspace of a forward call");
+  hipStream_t s = (hipStream_t)stream;
+  {
+    ProfScope ps(e, SITE_OPTIM, 0, s);
+    COATI_TRY(launch_grad_sqnorm(e->G, e->n_params, e->opt_partial, 1024, scal + 5, max_norm, scal + 8, s));
+    COATI_TRY(launch_adamw(e->P, e->G, e->Mo, e->Vo, nullptr, e->n_params, lr, beta1, beta2, eps, weight_decay, step, scal + 8, 1.f, s));
+  }
+  return coati_engine_refresh_shadows(e, stream);
+}
+
+int coati_engine_prof_select(coati_engine* e, int site) {
+  COATI_CHECK_ARG(e && site >= -1 && site < SITE_COUNT, "prof_select: bad site");
+  if (site >= 0 && e->ev.empty()) {
+    e->ev.resize(8192);
+    for (auto& ev : e->ev) {
+      if (hipEventCreate(&ev) != hipSuccess) {
+        coati_set_error("prof_select: hipEventCreate failed");
+        return COATI_EHIP;
+      }
+    }
+  }
+  e->prof_site = site;
+  e->ev_used = 0;
+  e->prof_flops = 0.0;
+  return COATI_OK;
+}
+
+int coati_engine_prof_collect(coati_engine* e, double* total_ms, int64_t* launches, double* flops_per_launch) {
+  COATI_CHECK_ARG(e && total_ms && launches, "prof_collect: null argument");
+  double tot = 0.0;
+  for (int i = 0; i + 1 < e->ev_used; i += 2) {
+    hipEventSynchronize(e->ev[i + 1]);
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, e->ev[i], e->ev[i + 1]) != hipSuccess) {
+      coati_set_error("prof_collect: hipEventElapsedTime failed");
+      return COATI_EHIP;
+    }
+    tot += ms;
+  }
+  *total_ms = tot;
+  *launches = e->ev_used / 2;
+  if (flops_per_launch) *flops_per_launch = e->ev_used ? e->prof_flops / (e->ev_used / 2) : 0.0;
+  e->ev_used = 0;
+  e->prof_flops = 0.0;
+  return COATI_OK;
+}
+
+int coati_engine_site_count(void) { return SITE_COUNT; }
+const char* coati_engine_site_name(int site) { return (site >= 0 && site < SITE_COUNT) ? kSiteNames[site] : ""; }
+
+}  // extern "C"

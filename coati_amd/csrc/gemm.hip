@@ -1,0 +1,631 @@
+// GEMM family for gfx950: bf16 MFMA (v_mfma_f32_32x32x16_bf16) with fp32 accumulation.
+//
+//   gemm_nt   C[M,N] = A[M,K] * B[N,K]^T  with fused epilogues        (all Linear forwards, dgrads)
+//   wgrad_tn  dW[N,K] += A[M,N]^T * B[M,K] (+ column sums of A)       (all weight/bias gradients)
+//   sgemm     exact-f32 MFMA (v_mfma_f32_32x32x2_f32), generic strides (contrastive head, [B,256] maths)
+//
+// Tiling: 128x128 output tile per 256-thread workgroup (4 waves as 2x2, each 64x64 = 2x2 MFMA tiles),
+// BK = 64, register-staged global->LDS double buffer (one barrier per k-tile).  LDS rows are padded to
+// 72 halfs (144 B): 16 consecutive rows then hit 16 distinct 16-B slots of the 256-B bank row, so the
+// ds_read_b128 fragment reads are conflict-free without an XOR swizzle.  The accumulator tile is
+// transposed through LDS so the epilogue works on 8 consecutive columns per lane (16-B stores).
+#include "kernels.h"
+
+#define BM 128
+#define BN 128
+#define BK 64
+#define PITCH 72       // halfs per LDS row
+#define CPITCH 132     // floats per LDS row of the staged accumulator tile
+#define TILE_HALFS (128 * PITCH)
+#define GEMM_LDS_BYTES (4 * TILE_HALFS * 2)   // 73,728 B  (>= 128*132*4 = 67,584 B for the C stage)
+
+__device__ __forceinline__ int xcd_swizzle(int bid, int nwg) {
+  // blocks are dispatched round-robin over the 8 XCDs; give each XCD a contiguous run of tiles so
+  // neighbouring tiles (same A row panel) share an L2.  Bijective for any nwg.
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
+// ---- staging: global -> registers -> LDS --------------------------------------------------------
+struct StageB16 { uint4 v[4]; };
+struct StageF32 { float4 v[8]; };
+
+__device__ __forceinline__ void stage_load(StageB16& s, const bf16_t* base, long long ld, int row0, int rows,
+                                           int k0, int tid) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = tid + 256 * i, row = c >> 3, kc = (c & 7) * 8;
+    const int g = row0 + row;
+    s.v[i] = (g < rows) ? *reinterpret_cast<const uint4*>(base + (long long)g * ld + k0 + kc) : make_uint4(0, 0, 0, 0);
+  }
+}
+__device__ __forceinline__ void stage_store(const StageB16& s, bf16_t* S, int tid) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = tid + 256 * i, row = c >> 3, kc = (c & 7) * 8;
+    *reinterpret_cast<uint4*>(S + row * PITCH + kc) = s.v[i];
+  }
+}
+__device__ __forceinline__ void stage_load(StageF32& s, const float* base, long long ld, int row0, int rows,
+                                           int k0, int tid) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = tid + 256 * i, row = c >> 4, kc = (c & 15) * 4;
+    const int g = row0 + row;
+    s.v[i] = (g < rows) ? *reinterpret_cast<const float4*>(base + (long long)g * ld + k0 + kc)
+                        : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+__device__ __forceinline__ void stage_store(const StageF32& s, bf16_t* S, int tid) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = tid + 256 * i, row = c >> 4, kc = (c & 15) * 4;
+    uint2 u;
+    u.x = pack2bf(s.v[i].x, s.v[i].y);
+    u.y = pack2bf(s.v[i].z, s.v[i].w);
+    *reinterpret_cast<uint2*>(S + row * PITCH + kc) = u;
+  }
+}
+
+// ---- MFMA over one staged k-tile: each wave owns a 64x64 sub-tile ----------------------------------
+__device__ __forceinline__ void mma_ktile(const bf16_t* As, const bf16_t* Bs, int wm, int wn, int lane,
+                                          f32x16 (&acc)[2][2]) {
+  const int r = lane & 31, kg = (lane >> 5) * 8;
+#pragma unroll
+  for (int ks = 0; ks < BK / 16; ++ks) {
+    bf16x8 a[2], b[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      a[i] = *reinterpret_cast<const bf16x8*>(As + (wm * 64 + i * 32 + r) * PITCH + ks * 16 + kg);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      b[j] = *reinterpret_cast<const bf16x8*>(Bs + (wn * 64 + j * 32 + r) * PITCH + ks * 16 + kg);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+  }
+}
+
+// C/D fragment of v_mfma_f32_32x32x16: lane holds col = lane&31, rows (r&3) + 8*(r>>2) + 4*(lane>>5)
+__device__ __forceinline__ int frag_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+// ---- epilogue on 8 consecutive columns of one row ----------------------------------------------------
+template <int EPI>
+__device__ __forceinline__ void epilogue8(const GemmArgs& p, int row, int col0, float (&v)[8], bool rowok,
+                                          int tile_n, int tiles_n) {
+  const int N = p.N;
+  if (p.bias != nullptr) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      if (col0 + e < N) v[e] += p.bias[col0 + e];
+  }
+  if (EPI == EPI_CE_PARTIAL) {
+    // every lane of the 16-lane group that shares this row takes part in the shuffles
+    float mx = -INFINITY;
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      if (col0 + e < N) mx = fmaxf(mx, v[e]);
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    float sm = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      if (col0 + e < N) sm += __expf(v[e] - mx);
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) sm += __shfl_xor(sm, o, 64);
+    if (rowok && (threadIdx.x & 15) == 0) p.partial[(long long)row * tiles_n + tile_n] = make_float2(mx, sm);
+    return;
+  }
+  if (!rowok) return;
+  const int nst = p.n_store > N ? p.n_store : N;
+  if (col0 >= nst) return;
+  const long long off = (long long)row * p.ldc + col0;
+  const long long aoff = (long long)row * p.ld_aux + col0;
+  const bool full = (col0 + 8 <= N);
+
+  if (EPI == EPI_F32 || EPI == EPI_RES_F32 || EPI == EPI_ACC_F32) {
+    float* C = reinterpret_cast<float*>(p.C);
+    if (full) {
+      float4 o0 = make_float4(v[0], v[1], v[2], v[3]), o1 = make_float4(v[4], v[5], v[6], v[7]);
+      if (EPI == EPI_RES_F32) {
+        const float* R = reinterpret_cast<const float*>(p.aux_in);
+        const float4 r0 = *reinterpret_cast<const float4*>(R + aoff), r1 = *reinterpret_cast<const float4*>(R + aoff + 4);
+        o0.x += r0.x; o0.y += r0.y; o0.z += r0.z; o0.w += r0.w;
+        o1.x += r1.x; o1.y += r1.y; o1.z += r1.z; o1.w += r1.w;
+      }
+      if (EPI == EPI_ACC_F32) {
+        const float4 r0 = *reinterpret_cast<const float4*>(C + off), r1 = *reinterpret_cast<const float4*>(C + off + 4);
+        o0.x += r0.x; o0.y += r0.y; o0.z += r0.z; o0.w += r0.w;
+        o1.x += r1.x; o1.y += r1.y; o1.z += r1.z; o1.w += r1.w;
+      }
+      *reinterpret_cast<float4*>(C + off) = o0;
+      *reinterpret_cast<float4*>(C + off + 4) = o1;
+    } else {
+      for (int e = 0; e < 8; ++e) {
+        if (col0 + e >= nst) break;
+        float o = (col0 + e < N) ? v[e] : 0.f;
+        if (col0 + e < N) {
+          if (EPI == EPI_RES_F32) o += reinterpret_cast<const float*>(p.aux_in)[aoff + e];
+          if (EPI == EPI_ACC_F32) o += C[off + e];
+        }
+        C[off + e] = o;
+      }
+    }
+    return;
+  }
+
+  // bf16 outputs
+  float o[8];
+  if (EPI == EPI_BF16) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = v[e];
+  } else if (EPI == EPI_GELU || EPI == EPI_SILU) {
+    bf16_t* X = reinterpret_cast<bf16_t*>(p.aux_out);
+    if (full) {
+      *reinterpret_cast<uint4*>(X + aoff) = pack8(v);
+    } else {
+      for (int e = 0; e < 8 && col0 + e < N; ++e) X[aoff + e] = f2bf(v[e]);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (EPI == EPI_GELU) ? gelu_f(v[e]) : silu_f(v[e]);
+  } else if (EPI == EPI_DGELU || EPI == EPI_DSILU) {
+    const bf16_t* X = reinterpret_cast<const bf16_t*>(p.aux_in);
+    float x[8];
+    if (full) {
+      unpack8(*reinterpret_cast<const uint4*>(X + aoff), x);
+    } else {
+      for (int e = 0; e < 8; ++e) x[e] = (col0 + e < N) ? bf2f(X[aoff + e]) : 0.f;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = v[e] * ((EPI == EPI_DGELU) ? dgelu_f(x[e]) : dsilu_f(x[e]));
+  } else if (EPI == EPI_CE_BWD) {
+    const long long tgt = p.target[row];
+    const float cnt = p.scal[1];
+    const float inv = (tgt >= 0 && cnt > 0.f) ? 1.0f / cnt : 0.f;
+    const float l = p.lse[row];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float pr = __expf(v[e] - l);
+      if ((long long)(col0 + e) == tgt) pr -= 1.0f;
+      o[e] = pr * inv;
+    }
+  } else if (EPI == EPI_EDGE_DPRE) {
+    const int A = p.natom, H = p.H;
+    const int bj = row / A, b = row / (A * A), k = row - bj * A;
+    const bf16_t* Pa = p.P + (long long)bj * p.ldp + col0;
+    const bf16_t* Pb = p.P + (long long)(b * A + k) * p.ldp + H + col0;
+    const float d2 = p.d2[row];
+    float pa[8], pb[8];
+    if (full) {
+      unpack8(*reinterpret_cast<const uint4*>(Pa), pa);
+      unpack8(*reinterpret_cast<const uint4*>(Pb), pb);
+    } else {
+      for (int e = 0; e < 8; ++e) {
+        pa[e] = (col0 + e < N) ? bf2f(Pa[e]) : 0.f;
+        pb[e] = (col0 + e < N) ? bf2f(Pb[e]) : 0.f;
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int c = col0 + e;
+      float pre = 0.f;
+      if (c < N) pre = pa[e] + pb[e] + d2 * p.w1c[(long long)c * p.w1c_stride] + p.b1[c];
+      o[e] = v[e] * dsilu_f(pre);
+    }
+  }
+  bf16_t* C = reinterpret_cast<bf16_t*>(p.C);
+  if (col0 + 8 <= nst) {
+    if (!full) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if (col0 + e >= N) o[e] = 0.f;
+    }
+    *reinterpret_cast<uint4*>(C + off) = pack8(o);
+  } else {
+    for (int e = 0; e < 8 && col0 + e < nst; ++e) C[off + e] = (col0 + e < N) ? f2bf(o[e]) : (bf16_t)0;
+  }
+}
+
+// ---- NT GEMM kernel -------------------------------------------------------------------------------------
+template <typename AT, typename STAGE_A, int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  bf16_t* const lds = reinterpret_cast<bf16_t*>(smem);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tiles_n = (p.N + BN - 1) / BN;
+  const int wg = xcd_swizzle(blockIdx.x, gridDim.x);
+  const int tile_m = wg / tiles_n, tile_n = wg - tile_m * tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const AT* A = reinterpret_cast<const AT*>(p.A);
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = p.K / BK;
+  STAGE_A sa;
+  StageB16 sb;
+  stage_load(sa, A, p.lda, m0, p.M, 0, tid);
+  stage_load(sb, p.B, p.ldb, n0, p.N, 0, tid);
+  stage_store(sa, lds, tid);
+  stage_store(sb, lds + 2 * TILE_HALFS, tid);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) {
+      stage_load(sa, A, p.lda, m0, p.M, (kt + 1) * BK, tid);
+      stage_load(sb, p.B, p.ldb, n0, p.N, (kt + 1) * BK, tid);
+    }
+    mma_ktile(lds + cur * TILE_HALFS, lds + (2 + cur) * TILE_HALFS, wm, wn, lane, acc);
+    if (kt + 1 < nk) {
+      stage_store(sa, lds + (cur ^ 1) * TILE_HALFS, tid);
+      stage_store(sb, lds + (2 + (cur ^ 1)) * TILE_HALFS, tid);
+    }
+    __syncthreads();
+  }
+
+  // accumulators -> LDS (fp32) -> row-contiguous epilogue
+  float* Cs = reinterpret_cast<float*>(smem);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        Cs[(wm * 64 + i * 32 + frag_row(r, lane)) * CPITCH + wn * 64 + j * 32 + (lane & 31)] = acc[i][j][r];
+  __syncthreads();
+#pragma unroll 1
+  for (int i = 0; i < 8; ++i) {
+    const int task = tid + 256 * i, r = task >> 4, cg = task & 15;
+    float v[8];
+    const float4 c0 = *reinterpret_cast<const float4*>(Cs + r * CPITCH + cg * 8);
+    const float4 c1 = *reinterpret_cast<const float4*>(Cs + r * CPITCH + cg * 8 + 4);
+    v[0] = c0.x; v[1] = c0.y; v[2] = c0.z; v[3] = c0.w; v[4] = c1.x; v[5] = c1.y; v[6] = c1.z; v[7] = c1.w;
+    epilogue8<EPI>(p, m0 + r, n0 + cg * 8, v, (m0 + r) < p.M, tile_n, tiles_n);
+  }
+}
+
+template <typename AT, typename STAGE_A, int EPI>
+static int launch_nt_t(const GemmArgs& a, hipStream_t s) {
+  static bool attr_set = false;
+  auto kern = gemm_nt_kernel<AT, STAGE_A, EPI>;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       GEMM_LDS_BYTES);
+    if (e != hipSuccess) {
+      coati_set_error("gemm_nt: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+      return COATI_EHIP;
+    }
+    attr_set = true;
+  }
+  const int tiles = cdiv(a.M, BM) * cdiv(a.N, BN);
+  hipLaunchKernelGGL(kern, dim3(tiles), dim3(256), GEMM_LDS_BYTES, s, a);
+  COATI_LAUNCH_CHECK("gemm_nt");
+  return COATI_OK;
+}
+
+int launch_gemm_nt(const GemmArgs& a, int a_f32, int epi, hipStream_t s) {
+  COATI_CHECK_ARG(a.A && a.B, "gemm_nt: null operand");
+  COATI_CHECK_ARG(a.C || epi == EPI_CE_PARTIAL, "gemm_nt: null output");
+  COATI_CHECK_SHAPE(a.M > 0 && a.N > 0 && a.K > 0 && a.K % BK == 0, "gemm_nt: K=%d must be a positive multiple of %d", a.K, BK);
+  COATI_CHECK_SHAPE(a.lda % (a_f32 ? 4 : 8) == 0 && a.ldb % 8 == 0, "gemm_nt: lda/ldb alignment (lda=%lld ldb=%lld)", a.lda, a.ldb);
+  const bool out_f32 = (epi == EPI_F32 || epi == EPI_RES_F32 || epi == EPI_ACC_F32);
+  if (epi != EPI_CE_PARTIAL)
+    COATI_CHECK_SHAPE(a.ldc % (out_f32 ? 4 : 8) == 0, "gemm_nt: ldc=%lld alignment", a.ldc);
+  if (epi == EPI_RES_F32) COATI_CHECK_ARG(a.aux_in && a.ld_aux % 4 == 0, "gemm_nt: residual missing/misaligned");
+  if (epi == EPI_GELU || epi == EPI_SILU) COATI_CHECK_ARG(a.aux_out && a.ld_aux % 8 == 0, "gemm_nt: aux_out missing");
+  if (epi == EPI_DGELU || epi == EPI_DSILU) COATI_CHECK_ARG(a.aux_in && a.ld_aux % 8 == 0, "gemm_nt: aux_in missing");
+  if (epi == EPI_CE_PARTIAL) COATI_CHECK_ARG(a.partial, "gemm_nt: partial buffer missing");
+  if (epi == EPI_CE_BWD) COATI_CHECK_ARG(a.lse && a.target && a.scal, "gemm_nt: CE operands missing");
+  if (epi == EPI_EDGE_DPRE) COATI_CHECK_ARG(a.P && a.d2 && a.w1c && a.b1 && a.natom > 0 && a.ldp % 8 == 0, "gemm_nt: edge operands missing");
+#define NT_CASE(E)                                                                  \
+  case E:                                                                           \
+    return a_f32 ? launch_nt_t<float, StageF32, E>(a, s) : launch_nt_t<bf16_t, StageB16, E>(a, s);
+#define NT_CASE_B16(E)                                                              \
+  case E:                                                                           \
+    COATI_CHECK_ARG(!a_f32, "gemm_nt: epilogue %d has no f32-A variant", (int)E);   \
+    return launch_nt_t<bf16_t, StageB16, E>(a, s);
+  switch (epi) {
+    NT_CASE(EPI_BF16)
+    NT_CASE(EPI_F32)
+    NT_CASE_B16(EPI_RES_F32)
+    NT_CASE_B16(EPI_GELU)
+    NT_CASE(EPI_DGELU)
+    NT_CASE_B16(EPI_SILU)
+    NT_CASE(EPI_DSILU)
+    NT_CASE_B16(EPI_ACC_F32)
+    NT_CASE_B16(EPI_CE_PARTIAL)
+    NT_CASE_B16(EPI_CE_BWD)
+    NT_CASE_B16(EPI_EDGE_DPRE)
+    default:
+      coati_set_error("gemm_nt: unknown epilogue %d", epi);
+      return COATI_EARG;
+  }
+#undef NT_CASE
+#undef NT_CASE_B16
+}
+
+// =================================================================================================
+// wgrad: dW[N,K] += A[M,N]^T * B[M,K]
+// The reduction runs over m, which is the strided dimension of both operands, so each staged
+// [64 m][128 cols] tile is transposed in registers (4x8 bf16 blocks) on its way into LDS, giving
+// the same [128][PITCH] k-contiguous image the NT kernel uses.  The 8 per-lane 8-byte LDS stores
+// are issued in a lane-rotated order so the 16 lanes of a store group fall on different banks.
+// =================================================================================================
+struct StageT { uint4 v[4]; };   // 4 m-rows x 8 columns (bf16)
+
+template <typename AT>
+__device__ __forceinline__ void stage_load_t(StageT& s, const AT* base, long long ld, int m0, int m_end, int c0,
+                                             int ncols, int tid);
+
+template <>
+__device__ __forceinline__ void stage_load_t<bf16_t>(StageT& s, const bf16_t* base, long long ld, int m0, int m_end,
+                                                     int c0, int ncols, int tid) {
+  const int noct = tid & 15, mq = tid >> 4;
+  const int col = c0 + noct * 8;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int m = m0 + mq * 4 + r;
+    s.v[r] = (m < m_end && col < ncols) ? *reinterpret_cast<const uint4*>(base + (long long)m * ld + col)
+                                        : make_uint4(0, 0, 0, 0);
+  }
+}
+template <>
+__device__ __forceinline__ void stage_load_t<float>(StageT& s, const float* base, long long ld, int m0, int m_end,
+                                                    int c0, int ncols, int tid) {
+  const int noct = tid & 15, mq = tid >> 4;
+  const int col = c0 + noct * 8;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int m = m0 + mq * 4 + r;
+    if (m < m_end && col < ncols) {
+      const float4 f0 = *reinterpret_cast<const float4*>(base + (long long)m * ld + col);
+      const float4 f1 = *reinterpret_cast<const float4*>(base + (long long)m * ld + col + 4);
+      s.v[r] = make_uint4(pack2bf(f0.x, f0.y), pack2bf(f0.z, f0.w), pack2bf(f1.x, f1.y), pack2bf(f1.z, f1.w));
+    } else {
+      s.v[r] = make_uint4(0, 0, 0, 0);
+    }
+  }
+}
+
+__device__ __forceinline__ unsigned sel_dword(const uint4& u, int d) {
+  return d == 0 ? u.x : (d == 1 ? u.y : (d == 2 ? u.z : u.w));
+}
+
+__device__ __forceinline__ void stage_store_t(const StageT& s, bf16_t* S, int tid) {
+  const int noct = tid & 15, mq = tid >> 4;
+  // out[e] = the 4 m-values of column e: (lo dword: rows 0,1 ; hi dword: rows 2,3)
+  unsigned lo[8], hi[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int d = e >> 1;
+    const unsigned x0 = sel_dword(s.v[0], d), x1 = sel_dword(s.v[1], d);
+    const unsigned x2 = sel_dword(s.v[2], d), x3 = sel_dword(s.v[3], d);
+    if (e & 1) {
+      lo[e] = (x0 >> 16) | (x1 & 0xffff0000u);
+      hi[e] = (x2 >> 16) | (x3 & 0xffff0000u);
+    } else {
+      lo[e] = (x0 & 0xffffu) | (x1 << 16);
+      hi[e] = (x2 & 0xffffu) | (x3 << 16);
+    }
+  }
+  // barrel-rotate by (noct & 7) so that slot s holds column (s + noct) & 7
+#pragma unroll
+  for (int bit = 0; bit < 3; ++bit) {
+    const int sh = 1 << bit;
+    const bool on = (noct >> bit) & 1;
+    unsigned nlo[8], nhi[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      nlo[e] = on ? lo[(e + sh) & 7] : lo[e];
+      nhi[e] = on ? hi[(e + sh) & 7] : hi[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { lo[e] = nlo[e]; hi[e] = nhi[e]; }
+  }
+#pragma unroll
+  for (int sl = 0; sl < 8; ++sl) {
+    const int e = (sl + noct) & 7;
+    *reinterpret_cast<uint2*>(S + (noct * 8 + e) * PITCH + mq * 4) = make_uint2(lo[sl], hi[sl]);
+  }
+}
+
+template <typename AT, bool BIAS>
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs p, int tiles_k, int chunks_per_split) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  bf16_t* const lds = reinterpret_cast<bf16_t*>(smem);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tile_n = blockIdx.x / tiles_k, tile_k = blockIdx.x - tile_n * tiles_k;
+  const int n0 = tile_n * BM, k0 = tile_k * BN;
+  const int nchunks = (p.M + BK - 1) / BK;
+  const int c_begin = blockIdx.y * chunks_per_split;
+  int c_end = c_begin + chunks_per_split;
+  if (c_end > nchunks) c_end = nchunks;
+  if (c_begin >= c_end) return;
+  const AT* A = reinterpret_cast<const AT*>(p.A);
+  const int nout = p.n_out > 0 ? p.n_out : p.N;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  float csum[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) csum[e] = 0.f;
+  const bool do_bias = BIAS && (tile_k == 0);
+
+  StageT sa, sb;
+  stage_load_t<AT>(sa, A, p.lda, c_begin * BK, p.M, n0, p.N, tid);
+  stage_load_t<bf16_t>(sb, p.B, p.ldb, c_begin * BK, p.M, k0, p.K, tid);
+  if (do_bias) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float f[8];
+      unpack8(sa.v[r], f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) csum[e] += f[e];
+    }
+  }
+  stage_store_t(sa, lds, tid);
+  stage_store_t(sb, lds + 2 * TILE_HALFS, tid);
+  __syncthreads();
+  for (int c = c_begin; c < c_end; ++c) {
+    const int cur = (c - c_begin) & 1;
+    const bool more = (c + 1 < c_end);
+    if (more) {
+      stage_load_t<AT>(sa, A, p.lda, (c + 1) * BK, p.M, n0, p.N, tid);
+      stage_load_t<bf16_t>(sb, p.B, p.ldb, (c + 1) * BK, p.M, k0, p.K, tid);
+    }
+    mma_ktile(lds + cur * TILE_HALFS, lds + (2 + cur) * TILE_HALFS, wm, wn, lane, acc);
+    if (more) {
+      if (do_bias) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float f[8];
+          unpack8(sa.v[r], f);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) csum[e] += f[e];
+        }
+      }
+      stage_store_t(sa, lds + (cur ^ 1) * TILE_HALFS, tid);
+      stage_store_t(sb, lds + (2 + (cur ^ 1)) * TILE_HALFS, tid);
+    }
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = n0 + wm * 64 + i * 32 + frag_row(r, lane);
+        const int k = k0 + wn * 64 + j * 32 + (lane & 31);
+        if (n < nout && k < p.K) atomicAdd(p.dW + (long long)n * p.ldw + k, acc[i][j][r]);
+      }
+
+  if (do_bias) {
+    // reduce the 16 m-quads that share a column octet, then one atomic per column
+    float* red = reinterpret_cast<float*>(smem);  // [16 mq][128 cols]
+    const int noct = tid & 15, mq = tid >> 4;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[mq * 128 + noct * 8 + e] = csum[e];
+    __syncthreads();
+    if (tid < 128) {
+      float t = 0.f;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) t += red[q * 128 + tid];
+      if (n0 + tid < nout) atomicAdd(p.dbias + n0 + tid, t);
+    }
+  }
+}
+
+template <typename AT, bool BIAS>
+static int launch_wgrad_t(const WgradArgs& a, hipStream_t s) {
+  static bool attr_set = false;
+  auto kern = wgrad_kernel<AT, BIAS>;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       GEMM_LDS_BYTES);
+    if (e != hipSuccess) {
+      coati_set_error("wgrad: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+      return COATI_EHIP;
+    }
+    attr_set = true;
+  }
+  const int tiles_n = cdiv(a.N, BM), tiles_k = cdiv(a.K, BN);
+  const int tiles = tiles_n * tiles_k;
+  const int nchunks = cdiv(a.M, BK);
+  // ~2 workgroups per CU over the whole launch; every split keeps >= 8 chunks (512 rows) of work
+  int splits = cdiv(512, tiles);
+  if (splits > cdiv(nchunks, 8)) splits = cdiv(nchunks, 8);
+  if (splits < 1) splits = 1;
+  const int cps = cdiv(nchunks, splits);
+  splits = cdiv(nchunks, cps);
+  hipLaunchKernelGGL(kern, dim3(tiles, splits), dim3(256), GEMM_LDS_BYTES, s, a, tiles_k, cps);
+  COATI_LAUNCH_CHECK("wgrad");
+  return COATI_OK;
+}
+
+int launch_wgrad(const WgradArgs& a, int a_f32, hipStream_t s) {
+  COATI_CHECK_ARG(a.A && a.B && a.dW, "wgrad: null operand");
+  COATI_CHECK_SHAPE(a.M > 0 && a.N > 0 && a.K > 0, "wgrad: empty problem");
+  COATI_CHECK_SHAPE(a.N % 8 == 0 && a.K % 8 == 0, "wgrad: N=%d and K=%d must be multiples of 8", a.N, a.K);
+  COATI_CHECK_SHAPE(a.lda % 8 == 0 && a.ldb % 8 == 0, "wgrad: lda/ldb alignment");
+  if (a_f32) return a.dbias ? launch_wgrad_t<float, true>(a, s) : launch_wgrad_t<float, false>(a, s);
+  return a.dbias ? launch_wgrad_t<bf16_t, true>(a, s) : launch_wgrad_t<bf16_t, false>(a, s);
+}
+
+// =================================================================================================
+// exact-f32 MFMA GEMM with generic strides (small problems: heads, InfoNCE logits and their grads)
+// =================================================================================================
+#define SPITCH 65
+__global__ __launch_bounds__(256) void sgemm_kernel(const float* __restrict__ A, long long ars, long long acs,
+                                                    const float* __restrict__ B, long long brs, long long bcs,
+                                                    float* __restrict__ C, long long ldc, int M, int N, int K,
+                                                    const float* __restrict__ bias, float alpha, int accumulate) {
+  __shared__ float As[16 * SPITCH];
+  __shared__ float Bs[16 * SPITCH];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const bool a_kfast = (acs == 1), b_kfast = (brs == 1);
+  for (int k0 = 0; k0 < K; k0 += 16) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int id = tid + 256 * i;
+      int m, k;
+      if (a_kfast) { k = id & 15; m = id >> 4; } else { m = id & 63; k = id >> 6; }
+      const int gm = m0 + m, gk = k0 + k;
+      As[k * SPITCH + m] = (gm < M && gk < K) ? A[gm * ars + gk * acs] : 0.f;
+      int n, kb;
+      if (b_kfast) { kb = id & 15; n = id >> 4; } else { n = id & 63; kb = id >> 6; }
+      const int gn = n0 + n, gkb = k0 + kb;
+      Bs[kb * SPITCH + n] = (gn < N && gkb < K) ? B[gkb * brs + gn * bcs] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+      const int k = 2 * kk + (lane >> 5);
+      const float a = As[k * SPITCH + wm * 32 + (lane & 31)];
+      const float b = Bs[k * SPITCH + wn * 32 + (lane & 31)];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int m = m0 + wm * 32 + frag_row(r, lane), n = n0 + wn * 32 + (lane & 31);
+    if (m < M && n < N) {
+      float v = alpha * acc[r];
+      if (bias) v += bias[n];
+      float* c = C + (long long)m * ldc + n;
+      *c = accumulate ? (*c + v) : v;
+    }
+  }
+}
+
+int launch_sgemm(const float* A, long long ars, long long acs, const float* B, long long brs, long long bcs,
+                 float* C, long long ldc, int M, int N, int K, const float* bias, float alpha, int accumulate,
+                 hipStream_t s) {
+  COATI_CHECK_ARG(A && B && C, "sgemm: null operand");
+  COATI_CHECK_SHAPE(M > 0 && N > 0 && K > 0, "sgemm: empty problem");
+  hipLaunchKernelGGL(sgemm_kernel, dim3(cdiv(N, 64), cdiv(M, 64)), dim3(256), 0, s, A, ars, acs, B, brs, bcs, C, ldc,
+                     M, N, K, bias, alpha, accumulate);
+  COATI_LAUNCH_CHECK("sgemm");
+  return COATI_OK;
+}

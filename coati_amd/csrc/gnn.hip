@@ -1,0 +1,329 @@
+// E(3)-GNN point encoder kernels (reference e3gnn_clip.py:108-137, e_gcl_sparse.py:10-77, 169-215, 253-321).
+//
+// MI355X formulation: the neighbour list is a dense, masked [B, A, A] edge grid built once per step on the
+// device (coordinates never change across the 5 layers; the reference rebuilds it 5x with host syncs).
+// Edge (b, j, k): receiver j, sender k, row index (b*A + j)*A + k, weight w = cubic_cutoff(d) * valid.
+// The 513->256 edge Linear is factored  W1 [h_j, h_k, d^2] = W1a h_j + W1b h_k + w1c d^2, so its big part is a
+// node-level MFMA GEMM (P = h [W1a;W1b]^T) and the per-edge part is the gather-add below.
+// All kernels here are HBM/L2-bound gathers and segmented reductions: coalesced rows, no atomics on the
+// per-edge path (messages are grouped by receiver), fp32 maths, bf16 storage for GEMM operands.
+#include "kernels.h"
+
+#define IN_EPS 1e-5f
+
+// ---- atom embedding + instance norm ------------------------------------------------------------------------
+// e = W[:, ix] + W[:, iy] + b  (the 28-wide one-hot times Linear(28,H)), h = (e - mean) / sqrt(var + eps)
+__global__ __launch_bounds__(256) void gnn_embed_kernel(const long long* __restrict__ atoms, const int* __restrict__ lut_ix,
+                                                        const int* __restrict__ lut_iy, const float* __restrict__ W,
+                                                        const float* __restrict__ bias, float* __restrict__ h32,
+                                                        bf16_t* __restrict__ h16, long long ld16, float* __restrict__ rstd_out,
+                                                        float* __restrict__ mask, int BA, int H) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row = blockIdx.x * 4 + wave;
+  if (row >= BA) return;
+  long long z = atoms[row];
+  if (lane == 0) mask[row] = z > 0 ? 1.f : 0.f;
+  if (z < 0) z = 0;
+  if (z > 119) z = 119;
+  const int ix = lut_ix[z], iy = lut_iy[z];
+  float e[16];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int c = lane + 64 * i;
+    float v = 0.f;
+    if (c < H) {
+      v = bias[c];
+      if (ix >= 0) v += W[c * 28 + ix];
+      if (iy >= 0) v += W[c * 28 + iy];
+    }
+    e[i] = v;
+    s += v;
+  }
+  const float mean = wave_sum(s) / (float)H;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i)
+    if (lane + 64 * i < H) q += (e[i] - mean) * (e[i] - mean);
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)H + IN_EPS);
+  if (lane == 0) rstd_out[row] = rstd;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int c = lane + 64 * i;
+    if (c < H) {
+      const float v = (e[i] - mean) * rstd;
+      h32[(long long)row * H + c] = v;
+      h16[(long long)row * ld16 + c] = f2bf(v);
+    }
+  }
+}
+
+int launch_gnn_embed(const long long* atoms, const int* lut_ix, const int* lut_iy, const float* W, const float* b,
+                     float* h32, bf16_t* h16, long long ld16, float* rstd, float* mask, int BA, int H,
+                     hipStream_t s) {
+  COATI_CHECK_ARG(atoms && lut_ix && lut_iy && W && b && h32 && h16 && rstd && mask, "gnn_embed: null operand");
+  COATI_CHECK_SHAPE(BA > 0 && H > 0 && H <= 1024, "gnn_embed: unsupported shape");
+  hipLaunchKernelGGL(gnn_embed_kernel, dim3(cdiv(BA, 4)), dim3(256), 0, s, atoms, lut_ix, lut_iy, W, b, h32, h16, ld16, rstd, mask, BA, H);
+  COATI_LAUNCH_CHECK("gnn_embed");
+  return COATI_OK;
+}
+
+// dW[:, i] = sum over atoms whose one-hot has bit i of de[atom, :]; db = sum over all atoms.
+// grid (29, chunks): block x handles one-hot index x (28 = the bias); deterministic inside a chunk.
+__global__ __launch_bounds__(256) void gnn_embed_bwd_kernel(const long long* __restrict__ atoms, const int* __restrict__ lut_ix,
+                                                            const int* __restrict__ lut_iy, const float* __restrict__ de,
+                                                            float* __restrict__ dW, float* __restrict__ db, int BA, int H,
+                                                            int rows_per_chunk) {
+  const int i = blockIdx.x;
+  const int r0 = blockIdx.y * rows_per_chunk;
+  int r1 = r0 + rows_per_chunk;
+  if (r1 > BA) r1 = BA;
+  for (int c = threadIdx.x; c < H; c += 256) {
+    float acc = 0.f;
+    for (int row = r0; row < r1; ++row) {
+      bool hit = (i == 28);
+      if (!hit) {
+        long long z = atoms[row];
+        if (z < 0) z = 0;
+        if (z > 119) z = 119;
+        hit = (lut_ix[z] == i) || (lut_iy[z] == i);
+      }
+      if (hit) acc += de[(long long)row * H + c];
+    }
+    if (i == 28) atomicAdd(db + c, acc); else atomicAdd(dW + c * 28 + i, acc);
+  }
+}
+
+int launch_gnn_embed_bwd(const long long* atoms, const int* lut_ix, const int* lut_iy, const float* de,
+                         float* dW, float* db, int BA, int H, hipStream_t s) {
+  COATI_CHECK_ARG(atoms && lut_ix && lut_iy && de && dW && db, "gnn_embed_bwd: null operand");
+  const int chunks = BA >= 4096 ? 32 : (BA >= 256 ? 8 : 1);
+  const int rpc = cdiv(BA, chunks);
+  hipLaunchKernelGGL(gnn_embed_bwd_kernel, dim3(29, cdiv(BA, rpc)), dim3(256), 0, s, atoms, lut_ix, lut_iy, de, dW, db, BA, H, rpc);
+  COATI_LAUNCH_CHECK("gnn_embed_bwd");
+  return COATI_OK;
+}
+
+// ---- geometry: squared distances and smooth-cutoff edge weights ---------------------------------------------------
+__global__ void gnn_geom_kernel(const float* __restrict__ coords, const float* __restrict__ mask, float rc,
+                                float* __restrict__ d2o, float* __restrict__ wo, int B, int A) {
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long n = (long long)B * A * A;
+  if (e >= n) return;
+  const int k = (int)(e % A);
+  const long long bj = e / A;
+  const int j = (int)(bj % A);
+  const long long b = bj / A;
+  const float* xj = coords + (b * A + j) * 3;
+  const float* xk = coords + (b * A + k) * 3;
+  const float dx = xj[0] - xk[0], dy = xj[1] - xk[1], dz = xj[2] - xk[2];
+  const float d2 = dx * dx + dy * dy + dz * dz;
+  const float d = sqrtf(d2);
+  const bool valid = (mask[b * A + j] > 0.f) && (mask[b * A + k] > 0.f) && (j != k) && (d < rc);
+  float w = 0.f;
+  if (valid) {
+    // e_gcl_sparse.py:10-24: 1 - 1.5 (r/rc)^2 + 0.5 (r/rc)^3 on (0, rc); 1 at r <= 0
+    const float c2 = -1.5f / (rc * rc), c3 = 0.5f / (rc * rc * rc);
+    w = (d <= 0.f) ? 1.f : (1.f + c2 * d * d + c3 * d * d * d);
+  }
+  d2o[e] = d2;
+  wo[e] = w;
+}
+
+int launch_gnn_geom(const float* coords, const float* mask, float cutoff, float* d2, float* w, int B, int A,
+                    hipStream_t s) {
+  COATI_CHECK_ARG(coords && mask && d2 && w, "gnn_geom: null operand");
+  const long long n = (long long)B * A * A;
+  hipLaunchKernelGGL(gnn_geom_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, coords, mask, cutoff, d2, w, B, A);
+  COATI_LAUNCH_CHECK("gnn_geom");
+  return COATI_OK;
+}
+
+// ---- edge layer 1 (gather-add + SiLU): one wave per receiver (b, j), looping over its A senders ---------------------
+__global__ __launch_bounds__(256) void gnn_edge_pre_kernel(const bf16_t* __restrict__ P, long long ldp,
+                                                           const float* __restrict__ d2, const float* __restrict__ w1c,
+                                                           long long w1c_stride, const float* __restrict__ b1,
+                                                           bf16_t* __restrict__ e1, int BA, int A, int H) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int bj = blockIdx.x * 4 + wave;
+  if (bj >= BA) return;
+  const int b = bj / A;
+  for (int c = lane * 4; c < H; c += 256) {
+    const uint2 ua = *reinterpret_cast<const uint2*>(P + (long long)bj * ldp + c);
+    const float pa[4] = {bflo(ua.x), bfhi(ua.x), bflo(ua.y), bfhi(ua.y)};
+    float wc[4], bb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { wc[i] = w1c[(long long)(c + i) * w1c_stride]; bb[i] = b1[c + i]; }
+    for (int k = 0; k < A; ++k) {
+      const long long row = (long long)bj * A + k;
+      const uint2 ub = *reinterpret_cast<const uint2*>(P + (long long)(b * A + k) * ldp + H + c);
+      const float pb[4] = {bflo(ub.x), bfhi(ub.x), bflo(ub.y), bfhi(ub.y)};
+      const float dd = d2[row];
+      float o[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o[i] = silu_f(pa[i] + pb[i] + dd * wc[i] + bb[i]);
+      *reinterpret_cast<uint2*>(e1 + row * H + c) = make_uint2(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]));
+    }
+  }
+}
+
+int launch_gnn_edge_pre(const bf16_t* P, long long ldp, const float* d2, const float* w, const float* w1c,
+                        long long w1c_stride, const float* b1, bf16_t* e1, int B, int A, int H, hipStream_t s) {
+  (void)w;
+  COATI_CHECK_ARG(P && d2 && w1c && b1 && e1, "gnn_edge_pre: null operand");
+  COATI_CHECK_SHAPE(H % 4 == 0 && ldp % 4 == 0, "gnn_edge_pre: alignment");
+  hipLaunchKernelGGL(gnn_edge_pre_kernel, dim3(cdiv(B * A, 4)), dim3(256), 0, s, P, ldp, d2, w1c, w1c_stride, b1, e1, B * A, A, H);
+  COATI_LAUNCH_CHECK("gnn_edge_pre");
+  return COATI_OK;
+}
+
+// ---- message aggregation: mi[b,j,:] = sum_k SiLU(s2[b,j,k,:]) * w[b,j,k] ------------------------------------------------
+__global__ __launch_bounds__(256) void gnn_edge_reduce_kernel(const bf16_t* __restrict__ s2, const float* __restrict__ w,
+                                                              bf16_t* __restrict__ mi, long long ldmi, int BA, int A, int H) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int bj = blockIdx.x * 4 + wave;
+  if (bj >= BA) return;
+  for (int c = lane * 4; c < H; c += 256) {
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < A; ++k) {
+      const long long row = (long long)bj * A + k;
+      const float ww = w[row];
+      if (ww == 0.f) continue;
+      const uint2 u = *reinterpret_cast<const uint2*>(s2 + row * H + c);
+      acc[0] += silu_f(bflo(u.x)) * ww; acc[1] += silu_f(bfhi(u.x)) * ww;
+      acc[2] += silu_f(bflo(u.y)) * ww; acc[3] += silu_f(bfhi(u.y)) * ww;
+    }
+    *reinterpret_cast<uint2*>(mi + (long long)bj * ldmi + c) = make_uint2(pack2bf(acc[0], acc[1]), pack2bf(acc[2], acc[3]));
+  }
+}
+
+int launch_gnn_edge_reduce(const bf16_t* s2, const float* w, bf16_t* mi, long long ldmi, int B, int A, int H,
+                           hipStream_t s) {
+  COATI_CHECK_ARG(s2 && w && mi, "gnn_edge_reduce: null operand");
+  COATI_CHECK_SHAPE(H % 4 == 0 && ldmi % 4 == 0, "gnn_edge_reduce: alignment");
+  hipLaunchKernelGGL(gnn_edge_reduce_kernel, dim3(cdiv(B * A, 4)), dim3(256), 0, s, s2, w, mi, ldmi, B * A, A, H);
+  COATI_LAUNCH_CHECK("gnn_edge_reduce");
+  return COATI_OK;
+}
+
+// ds2[b,j,k,:] = dmi[b,j,:] * w[b,j,k] * SiLU'(s2[b,j,k,:])
+__global__ __launch_bounds__(256) void gnn_edge_reduce_bwd_kernel(const bf16_t* __restrict__ dmi, long long lddmi,
+                                                                  const bf16_t* __restrict__ s2, const float* __restrict__ w,
+                                                                  bf16_t* __restrict__ ds2, int BA, int A, int H) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int bj = blockIdx.x * 4 + wave;
+  if (bj >= BA) return;
+  for (int c = lane * 4; c < H; c += 256) {
+    const uint2 ug = *reinterpret_cast<const uint2*>(dmi + (long long)bj * lddmi + c);
+    const float g[4] = {bflo(ug.x), bfhi(ug.x), bflo(ug.y), bfhi(ug.y)};
+    for (int k = 0; k < A; ++k) {
+      const long long row = (long long)bj * A + k;
+      const float ww = w[row];
+      uint2 o = make_uint2(0, 0);
+      if (ww != 0.f) {
+        const uint2 u = *reinterpret_cast<const uint2*>(s2 + row * H + c);
+        o = make_uint2(pack2bf(g[0] * ww * dsilu_f(bflo(u.x)), g[1] * ww * dsilu_f(bfhi(u.x))),
+                       pack2bf(g[2] * ww * dsilu_f(bflo(u.y)), g[3] * ww * dsilu_f(bfhi(u.y))));
+      }
+      *reinterpret_cast<uint2*>(ds2 + row * H + c) = o;
+    }
+  }
+}
+
+int launch_gnn_edge_reduce_bwd(const bf16_t* dmi, long long lddmi, const bf16_t* s2, const float* w, bf16_t* ds2,
+                               int B, int A, int H, hipStream_t s) {
+  COATI_CHECK_ARG(dmi && s2 && w && ds2, "gnn_edge_reduce_bwd: null operand");
+  COATI_CHECK_SHAPE(H % 4 == 0 && lddmi % 4 == 0, "gnn_edge_reduce_bwd: alignment");
+  hipLaunchKernelGGL(gnn_edge_reduce_bwd_kernel, dim3(cdiv(B * A, 4)), dim3(256), 0, s, dmi, lddmi, s2, w, ds2, B * A, A, H);
+  COATI_LAUNCH_CHECK("gnn_edge_reduce_bwd");
+  return COATI_OK;
+}
+
+// ---- backward of the gather-add: dPa[b,j] = sum_k dpre[b,j,k], dPb[b,k] = sum_j dpre[b,j,k], dw1c, db1 -------------
+// one block per molecule; thread = channel; sender sums are kept in LDS ([A][H] floats, own column per thread).
+__global__ __launch_bounds__(256) void gnn_edge_pre_bwd_kernel(const bf16_t* __restrict__ dpre, const float* __restrict__ d2,
+                                                               bf16_t* __restrict__ dP, long long lddp, float* __restrict__ dw1c,
+                                                               long long dw1c_stride, float* __restrict__ db1, int A, int H) {
+  extern __shared__ float accB[];  // [A][H]
+  const int b = blockIdx.x;
+  for (int i = threadIdx.x; i < A * H; i += blockDim.x) accB[i] = 0.f;
+  __syncthreads();
+  for (int c = threadIdx.x; c < H; c += blockDim.x) {
+    float sw = 0.f, sb = 0.f;
+    for (int j = 0; j < A; ++j) {
+      float accA = 0.f;
+      for (int k = 0; k < A; ++k) {
+        const long long row = ((long long)b * A + j) * A + k;
+        const float v = bf2f(dpre[row * H + c]);
+        accA += v;
+        accB[k * H + c] += v;
+        sw += v * d2[row];
+        sb += v;
+      }
+      dP[((long long)b * A + j) * lddp + c] = f2bf(accA);
+    }
+    for (int k = 0; k < A; ++k) dP[((long long)b * A + k) * lddp + H + c] = f2bf(accB[k * H + c]);
+    atomicAdd(dw1c + (long long)c * dw1c_stride, sw);
+    atomicAdd(db1 + c, sb);
+  }
+}
+
+int launch_gnn_edge_pre_bwd(const bf16_t* dpre, const float* d2, bf16_t* dP, long long lddp, float* dw1c,
+                            long long dw1c_stride, float* db1, int B, int A, int H, hipStream_t s) {
+  COATI_CHECK_ARG(dpre && d2 && dP && dw1c && db1, "gnn_edge_pre_bwd: null operand");
+  const size_t lds = (size_t)A * H * sizeof(float);
+  COATI_CHECK_SHAPE(lds <= 160 * 1024, "gnn_edge_pre_bwd: A*H=%d exceeds the LDS accumulator", A * H);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gnn_edge_pre_bwd_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) {
+      coati_set_error("gnn_edge_pre_bwd: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+      return COATI_EHIP;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(gnn_edge_pre_bwd_kernel, dim3(B), dim3(256), lds, s, dpre, d2, dP, lddp, dw1c, dw1c_stride, db1, A, H);
+  COATI_LAUNCH_CHECK("gnn_edge_pre_bwd");
+  return COATI_OK;
+}
+
+// ---- masked mean readout (e3gnn_clip.py:134-137) and its backward ----------------------------------------------------
+__global__ __launch_bounds__(256) void gnn_readout_kernel(const float* __restrict__ o, const float* __restrict__ mask,
+                                                          float* __restrict__ hp, int A, int H) {
+  const int b = blockIdx.x;
+  float n = 0.f;
+  for (int a = 0; a < A; ++a) n += mask[b * A + a];
+  n = fmaxf(n, 1.f);
+  for (int c = threadIdx.x; c < H; c += blockDim.x) {
+    float acc = 0.f;
+    for (int a = 0; a < A; ++a) acc += o[((long long)b * A + a) * H + c] * mask[b * A + a];
+    hp[(long long)b * H + c] = acc / n;
+  }
+}
+
+int launch_gnn_readout(const float* o, const float* mask, float* hp, int B, int A, int H, hipStream_t s) {
+  COATI_CHECK_ARG(o && mask && hp, "gnn_readout: null operand");
+  hipLaunchKernelGGL(gnn_readout_kernel, dim3(B), dim3(256), 0, s, o, mask, hp, A, H);
+  COATI_LAUNCH_CHECK("gnn_readout");
+  return COATI_OK;
+}
+
+__global__ __launch_bounds__(256) void gnn_readout_bwd_kernel(const float* __restrict__ dhp, const float* __restrict__ mask,
+                                                              bf16_t* __restrict__ dout, int A, int H) {
+  const int b = blockIdx.x;
+  float n = 0.f;
+  for (int a = 0; a < A; ++a) n += mask[b * A + a];
+  n = fmaxf(n, 1.f);
+  for (int c = threadIdx.x; c < H; c += blockDim.x) {
+    const float g = dhp[(long long)b * H + c] / n;
+    for (int a = 0; a < A; ++a) dout[((long long)b * A + a) * H + c] = f2bf(g * mask[b * A + a]);
+  }
+}
+
+int launch_gnn_readout_bwd(const float* dhp, const float* mask, bf16_t* dout, int B, int A, int H, hipStream_t s) {
+  COATI_CHECK_ARG(dhp && mask && dout, "gnn_readout_bwd: null operand");
+  hipLaunchKernelGGL(gnn_readout_bwd_kernel, dim3(B), dim3(256), 0, s, dhp, mask, dout, A, H);
+  COATI_LAUNCH_CHECK("gnn_readout_bwd");
+  return COATI_OK;
+}

@@ -1,0 +1,169 @@
+// Internal launcher interface shared by the .hip translation units of libcoati_hip.so.
+// Everything here takes raw device pointers + a hipStream_t; nothing allocates device memory.
+#pragma once
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------------
+// GEMM family (gemm.hip)
+// ------------------------------------------------------------------------------------------------
+enum CoatiEpi {
+  EPI_BF16 = 0,        // C(bf16) = acc + bias
+  EPI_F32 = 1,         // C(f32)  = acc + bias
+  EPI_RES_F32 = 2,     // C(f32)  = aux_in(f32) + acc + bias
+  EPI_GELU = 3,        // aux_out(bf16) = acc + bias ; C(bf16) = NewGELU(acc + bias)
+  EPI_DGELU = 4,       // C(bf16) = acc * NewGELU'(aux_in(bf16))
+  EPI_SILU = 5,        // aux_out(bf16) = acc + bias ; C(bf16) = SiLU(acc + bias)
+  EPI_DSILU = 6,       // C(bf16) = acc * SiLU'(aux_in(bf16))
+  EPI_ACC_F32 = 7,     // C(f32) += acc
+  EPI_CE_PARTIAL = 8,  // per (row, 128-col tile): (max, sum exp(v-max)) -> partial[row][tile]
+  EPI_CE_BWD = 9,      // C(bf16) = (exp(acc - lse[row]) - [col==target[row]]) / count   (0 if target<0)
+  EPI_EDGE_DPRE = 10,  // GNN: C(bf16) = acc * SiLU'(Pa[bj] + Pb[bk] + d2*w1c + b1)
+  EPI_COUNT = 11
+};
+
+struct GemmArgs {
+  const void* A;        // [M,K] row-major, bf16 or f32 (a_f32)
+  long long lda;
+  const bf16_t* B;      // [N,K] row-major bf16 (NT: C = A * B^T)
+  long long ldb;
+  int M, N, K;
+  void* C;
+  long long ldc;
+  int n_store;          // columns [N, n_store) of C are written as zero (0 -> = N)
+  const float* bias;    // [N] or null
+  const void* aux_in;
+  void* aux_out;
+  long long ld_aux;
+  // cross-entropy epilogues
+  const float* lse;         // [M]
+  const long long* target;  // [M], -1 = ignore
+  const float* scal;        // scal[1] = number of non-ignored targets
+  float2* partial;          // [M, tiles_n]
+  // GNN edge epilogue
+  const bf16_t* P;          // [B*A, 2H] (Pa | Pb)
+  long long ldp;
+  const float* d2;          // [B*A*A]
+  const float* w1c;         // w1c[c] = w1c[c * w1c_stride]
+  long long w1c_stride;
+  const float* b1;
+  int natom;
+  int H;
+};
+
+int launch_gemm_nt(const GemmArgs& a, int a_f32, int epi, hipStream_t s);
+
+// dW[N,K] (f32, atomic +=) = A[M,N]^T * B[M,K];  dbias[N] (atomic +=) = colsum(A) if non-null
+struct WgradArgs {
+  const void* A;   // [M,N] bf16 or f32
+  long long lda;
+  const bf16_t* B; // [M,K] bf16
+  long long ldb;
+  int M, N, K;
+  float* dW;
+  long long ldw;
+  float* dbias;
+  int n_out;   // rows of dW that exist (0 -> N); columns of A beyond it must be zero
+};
+int launch_wgrad(const WgradArgs& a, int a_f32, hipStream_t s);
+
+// C[M,N] (f32) = sum_k A(m,k) B(k,n) [+ bias[n]] [+ C];  A(m,k) = A[m*ars + k*acs], B(k,n) = B[k*brs + n*bcs]
+// exact-f32 MFMA (v_mfma_f32_32x32x2_f32).  alpha scales the product.
+int launch_sgemm(const float* A, long long ars, long long acs, const float* B, long long brs, long long bcs,
+                 float* C, long long ldc, int M, int N, int K, const float* bias, float alpha, int accumulate,
+                 hipStream_t s);
+
+// ------------------------------------------------------------------------------------------------
+// normalisation (norm.hip)
+// ------------------------------------------------------------------------------------------------
+// y = (x - mean) * rstd [* gamma + beta];  x f32 [M,C];  y16 (bf16, ld16) and/or y32 (f32, ld32) optional.
+int launch_layernorm_fwd(const float* x, long long ldx, const float* gamma, const float* beta, bf16_t* y16,
+                         long long ld16, float* y32, long long ld32, float* mean, float* rstd, int M, int C,
+                         hipStream_t s);
+// dx = [dres +] rstd*(g - mean(g) - xhat*mean(g*xhat)), g = dy*gamma.  dy bf16 or f32.
+// xhat is recomputed from (x, mean, rstd) or, if x_is_xhat, x already holds xhat (affine-free norms).
+int launch_layernorm_bwd(const void* dy, int dy_f32, long long lddy, const float* x, long long ldx, int x_is_xhat,
+                         const float* mean, const float* rstd, const float* gamma, const float* dres,
+                         float* dx, float* dgamma, float* dbeta, int M, int C, hipStream_t s);
+
+// ------------------------------------------------------------------------------------------------
+// attention, head size 16 (attention.hip)
+// ------------------------------------------------------------------------------------------------
+int launch_attn_fwd(const bf16_t* qkv, bf16_t* y, float* lse, const float* cos, const float* sin, int B, int T,
+                    int n_head, hipStream_t s);
+int launch_attn_bwd(const bf16_t* qkv, const bf16_t* y, const bf16_t* dy, const float* lse, bf16_t* dqkv,
+                    const float* cos, const float* sin, int B, int T, int n_head, hipStream_t s);
+
+// ------------------------------------------------------------------------------------------------
+// embedding / token kernels (embed.hip)
+// ------------------------------------------------------------------------------------------------
+int launch_embed_fwd(const long long* idx, const float* table, const float* injection, int unk_token, float* x,
+                     int B, int T, int C, int V, hipStream_t s);
+int launch_embed_bwd(const long long* idx, const float* dx, float* dtable, float* dinjection, int unk_token,
+                     int B, int T, int C, int V, hipStream_t s);
+// pos[b] = position of the single stop token of row b; err[0] |= 1 if some row has != 1 stop tokens
+int launch_find_stop(const long long* idx, int stop_token, int* pos, int* err, int B, int T, hipStream_t s);
+int launch_gather_rows(const float* x, const int* pos, float* out, int B, int T, int C, hipStream_t s);
+// dx[b, pos[b], :] += dout[b, :]
+int launch_scatter_rows_add(const float* dout, const int* pos, float* dx, int B, int T, int C, hipStream_t s);
+// bad[b] = sum_t tokens[b,t] < 1
+int launch_bad_rows(const long long* tokens, unsigned char* bad, int B, int T, hipStream_t s);
+
+// ------------------------------------------------------------------------------------------------
+// fused lm_head cross-entropy pieces (lmhead.hip)
+// ------------------------------------------------------------------------------------------------
+// merges the per-tile partials into lse[M]; adds sum(lse - logit[target]) and the target count into scal[0], scal[1]
+int launch_ce_finish(const float2* partial, int tiles_n, const bf16_t* a, long long lda, const bf16_t* W,
+                     long long ldw, const long long* target, float* lse, float* scal, int M, int C, int V,
+                     hipStream_t s);
+
+// ------------------------------------------------------------------------------------------------
+// E(3)-GNN kernels (gnn.hip)
+// ------------------------------------------------------------------------------------------------
+int launch_gnn_embed(const long long* atoms, const int* lut_ix, const int* lut_iy, const float* W, const float* b,
+                     float* h32, bf16_t* h16, long long ld16, float* rstd, float* mask, int BA, int H,
+                     hipStream_t s);
+int launch_gnn_embed_bwd(const long long* atoms, const int* lut_ix, const int* lut_iy, const float* de,
+                         float* dW, float* db, int BA, int H, hipStream_t s);
+int launch_gnn_geom(const float* coords, const float* mask, float cutoff, float* d2, float* w, int B, int A,
+                    hipStream_t s);
+int launch_gnn_edge_pre(const bf16_t* P, long long ldp, const float* d2, const float* w, const float* w1c,
+                        long long w1c_stride, const float* b1, bf16_t* e1, int B, int A, int H, hipStream_t s);
+int launch_gnn_edge_reduce(const bf16_t* s2, const float* w, bf16_t* mi, long long ldmi, int B, int A, int H,
+                           hipStream_t s);
+int launch_gnn_edge_reduce_bwd(const bf16_t* dmi, long long lddmi, const bf16_t* s2, const float* w, bf16_t* ds2,
+                               int B, int A, int H, hipStream_t s);
+int launch_gnn_edge_pre_bwd(const bf16_t* dpre, const float* d2, bf16_t* dP, long long lddp, float* dw1c,
+                            long long dw1c_stride, float* db1, int B, int A, int H, hipStream_t s);
+int launch_gnn_readout(const float* o, const float* mask, float* hp, int B, int A, int H, hipStream_t s);
+int launch_gnn_readout_bwd(const float* dhp, const float* mask, bf16_t* dout, int B, int A, int H, hipStream_t s);
+
+// ------------------------------------------------------------------------------------------------
+// small fp32 elementwise + contrastive heads (loss.hip)
+// ------------------------------------------------------------------------------------------------
+int launch_silu_fwd(const float* x, float* y, long long n, hipStream_t s);
+int launch_silu_bwd(const float* x, const float* dy, float* dx, long long n, int accumulate, hipStream_t s);
+int launch_select_rows(const unsigned char* use_a, const float* a, const float* b, float* out, int B, int C,
+                       hipStream_t s);
+// da[b] += use_a[b] ? dout[b] : 0 ; db[b] += use_a[b] ? 0 : dout[b]
+int launch_select_rows_bwd(const unsigned char* use_a, const float* dout, float* da, float* db, int B, int C,
+                           hipStream_t s);
+int launch_axpy(const float* x, float* y, float alpha, long long n, hipStream_t s);  // y += alpha*x
+// rows: logits[R, N] (f32, in place -> dlogits).  label of row r = label0 + r, ignored if bad[label].
+// sum of row losses -> scal_out[0] (+=); dlogits = (softmax - onehot) * (*gscale_ptr-free) handled by `gscale`.
+int launch_infonce_rows(float* logits, long long ld, int R, int N, int label0, const unsigned char* bad,
+                        float* loss_sum, const float* inv_count, float gscale, hipStream_t s);
+int launch_count_valid(const unsigned char* bad, int n, float* out_count, float* out_inv, hipStream_t s);
+
+// ------------------------------------------------------------------------------------------------
+// optimiser (optim.hip)
+// ------------------------------------------------------------------------------------------------
+int launch_grad_sqnorm(const float* g, long long n, float* partial, int n_partial, float* out_norm, float max_norm,
+                       float* out_coef, hipStream_t s);
+int launch_adamw(float* p, const float* g, float* m, float* v, bf16_t* shadow, long long n, float lr, float b1,
+                 float b2, float eps, float wd, int step, const float* coef, float gscale, hipStream_t s);
+int launch_cast_bf16(const float* src, bf16_t* dst, long long n, hipStream_t s);
+// dst[c*ld_dst + r] = bf16(src[r*ld_src + c]) for r<rows, c<cols; pad rows [cols, cols_pad) x... see optim.hip
+int launch_transpose_cast(const float* src, long long ld_src, bf16_t* dst, long long ld_dst, int rows, int cols,
+                          hipStream_t s);
+int launch_pack_rows_cast(const float* src, long long ld_src, bf16_t* dst, long long ld_dst, int rows, int cols,
+                          hipStream_t s);

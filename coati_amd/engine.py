@@ -1,0 +1,208 @@
+"""Host-side owner of the flat buffers + thin driver of the C engine (csrc/engine.cpp).
+
+One `Engine` = one model replica on one GPU.  PyTorch owns every byte (parameters, gradients, AdamW state, bf16
+shadows, workspace); the C library only borrows pointers while it enqueues kernels on the current stream."""
+import ctypes
+import math
+from dataclasses import dataclass, asdict
+from typing import Dict, Optional
+
+import torch
+
+from . import _lib
+from .ops import ptr, stream, rope_tables
+from .periodic import onehot_lut
+
+
+@dataclass
+class ModelConfig:
+    """kwargs of the reference's e3gnn_smiles_clip_e2e (clip_e2e.py:357-378) that shape the path."""
+    n_layer_e3gnn: int = 5
+    n_layer_xformer: int = 16
+    n_hidden_xformer: int = 256
+    n_hidden_e3nn: int = 256
+    n_embd_common: int = 256
+    n_head: int = 16
+    n_seq: int = 250
+    n_tok: int = 10322
+    msg_cutoff: float = 5.0
+    pad_token: int = 0
+    stop_token: int = 1
+    unk_token: int = 7
+
+
+SCAL_AR_SUM, SCAL_AR_COUNT, SCAL_CLIP1, SCAL_CLIP2, SCAL_NVALID, SCAL_GRADNORM, SCAL_ERR = 0, 1, 2, 3, 4, 5, 6
+
+
+class Engine:
+    def __init__(self, cfg: ModelConfig, device="cuda:0", train=True):
+        if not torch.cuda.is_available():
+            raise RuntimeError("coati_amd.Engine needs an MI355X (HIP device); there is no CPU fallback")
+        self.cfg = cfg
+        self.device = torch.device(device)
+        self.l = _lib.lib()
+        c = _lib.CoatiConfig(cfg.n_layer_xformer, cfg.n_layer_e3gnn, cfg.n_hidden_xformer, cfg.n_hidden_e3nn,
+                             cfg.n_embd_common, cfg.n_head, cfg.n_seq, cfg.n_tok, cfg.msg_cutoff, cfg.pad_token,
+                             cfg.stop_token, cfg.unk_token)
+        h = ctypes.c_void_p()
+        _lib.check(self.l.coati_engine_create(ctypes.byref(c), ctypes.byref(h)), "coati_engine_create")
+        self.h = h
+        self.n_params = int(self.l.coati_engine_param_elems(h))
+        self.n_shadow = int(self.l.coati_engine_shadow_elems(h))
+        self.layout = {}
+        buf = ctypes.create_string_buffer(256)
+        off, rows, cols = ctypes.c_int64(), ctypes.c_int32(), ctypes.c_int32()
+        for i in range(self.l.coati_engine_n_entries(h)):
+            _lib.check(self.l.coati_engine_entry(h, i, buf, 256, ctypes.byref(off), ctypes.byref(rows), ctypes.byref(cols)), "entry")
+            shape = (rows.value, cols.value) if cols.value > 0 else (rows.value,)
+            self.layout[buf.value.decode()] = (off.value, shape)
+        dev = self.device
+        self.params = torch.zeros(self.n_params, device=dev, dtype=torch.float32)
+        self.grads = torch.zeros(self.n_params, device=dev, dtype=torch.float32) if train else None
+        self.adam_m = torch.zeros(self.n_params, device=dev, dtype=torch.float32) if train else None
+        self.adam_v = torch.zeros(self.n_params, device=dev, dtype=torch.float32) if train else None
+        self.shadow = torch.zeros(self.n_shadow, device=dev, dtype=torch.bfloat16)
+        self.cos, self.sin = rope_tables(cfg.n_seq, cfg.n_hidden_xformer // cfg.n_head, device=dev)
+        ix, iy = onehot_lut()
+        self.lut_ix = torch.tensor(ix, dtype=torch.int32, device=dev)
+        self.lut_iy = torch.tensor(iy, dtype=torch.int32, device=dev)
+        _lib.check(self.l.coati_engine_bind(h, ptr(self.params), ptr(self.grads), ptr(self.adam_m), ptr(self.adam_v),
+                                            ptr(self.shadow), ptr(self.cos), ptr(self.sin), ptr(self.lut_ix),
+                                            ptr(self.lut_iy)), "coati_engine_bind")
+        self.workspace = None
+        self.scal = torch.zeros(16, device=dev, dtype=torch.float32)
+        self._shape = None
+        self.step_count = 0
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.l.coati_engine_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    # ---- parameters -------------------------------------------------------------------------------------
+    def view(self, name, which="params"):
+        off, shape = self.layout[name]
+        n = math.prod(shape)
+        return getattr(self, which)[off:off + n].view(*shape)
+
+    def named_views(self, which="params"):
+        return {k: self.view(k, which) for k in self.layout}
+
+    def load_state_dict(self, sd: Dict[str, torch.Tensor], strict=True):
+        missing = [k for k in self.layout if k not in sd]
+        if strict and missing:
+            raise KeyError(f"missing keys: {missing[:5]}...")
+        with torch.no_grad():
+            for k in self.layout:
+                if k in sd:
+                    self.view(k).copy_(sd[k].to(self.device, torch.float32))
+        self.refresh_shadows()
+        return missing
+
+    def state_dict(self):
+        return {k: v.detach().clone() for k, v in self.named_views().items()}
+
+    def refresh_shadows(self):
+        _lib.check(self.l.coati_engine_refresh_shadows(self.h, stream()), "refresh_shadows")
+
+    # ---- step pieces ---------------------------------------------------------------------------------------
+    def _ensure_workspace(self, B, T1, T2, A):
+        need = int(self.l.coati_engine_workspace_bytes(self.h, B, T1, T2, A, B))
+        if self.workspace is None or self.workspace.numel() < need:
+            self.workspace = None
+            self.workspace = torch.empty(need, device=self.device, dtype=torch.uint8)
+        return need
+
+    def forward(self, raw_tokens, tokens, atoms, coords, use_point, y_next=None, train=True):
+        """forward_dist (+ AR loss sums when y_next is given).  Returns (h_e3gnn, h_smiles, bad_rows)."""
+        B, T1 = raw_tokens.shape
+        T2 = tokens.shape[1]
+        A = atoms.shape[1]
+        for t in (raw_tokens, tokens, atoms):
+            assert t.dtype == torch.int64 and t.is_cuda and t.is_contiguous()
+        coords = coords.to(torch.float32).contiguous()
+        use_point = use_point.to(torch.uint8).contiguous()
+        if y_next is not None:
+            y_next = y_next.contiguous()
+        need = self._ensure_workspace(B, T1, T2, A)
+        E = self.cfg.n_embd_common
+        h_e = torch.empty(B, E, device=self.device, dtype=torch.float32)
+        h_s = torch.empty(B, E, device=self.device, dtype=torch.float32)
+        bad = torch.empty(B, device=self.device, dtype=torch.uint8)
+        self._keep = (raw_tokens, tokens, atoms, coords, use_point, y_next)  # keep inputs alive until backward
+        _lib.check(self.l.coati_engine_forward(self.h, ptr(self.workspace), need, B, T1, T2, A, ptr(raw_tokens), ptr(tokens),
+                                               ptr(y_next), ptr(atoms), ptr(coords), ptr(use_point), ptr(h_e), ptr(h_s),
+                                               ptr(bad), ptr(self.scal), 1 if (train and self.grads is not None) else 0,
+                                               stream()), "coati_engine_forward")
+        self._shape = (B, T1, T2, A)
+        return h_e, h_s, bad
+
+    def logits(self):
+        B, _, T2, _ = self._shape
+        V = self.cfg.n_tok
+        ld = (V + 7) // 8 * 8
+        out = torch.empty(B * T2, ld, device=self.device, dtype=torch.float32)
+        _lib.check(self.l.coati_engine_logits(self.h, ptr(out), ld, stream()), "coati_engine_logits")
+        return out[:, :V].view(B, T2, V)
+
+    def infonce(self, s_loc, c_loc, s_all, c_all, bad_all, row0=0, gscale=1.0):
+        B, Bg = s_loc.shape[0], s_all.shape[0]
+        E = self.cfg.n_embd_common
+        dS = torch.empty(Bg, E, device=self.device, dtype=torch.float32)
+        dC = torch.empty(Bg, E, device=self.device, dtype=torch.float32)
+        _lib.check(self.l.coati_engine_infonce(self.h, ptr(s_loc), ptr(c_loc), ptr(s_all), ptr(c_all), ptr(bad_all), B, Bg,
+                                               row0, float(gscale), ptr(dS), ptr(dC), ptr(self.scal), stream()),
+                   "coati_engine_infonce")
+        return dS, dC
+
+    def backward(self, dh_smiles=None, dh_e3gnn=None, stage=0):
+        _lib.check(self.l.coati_engine_backward(self.h, ptr(dh_smiles), ptr(dh_e3gnn), stage, stream()), "coati_engine_backward")
+
+    def optimizer_step(self, lr, betas=(0.9, 0.99), eps=1e-8, weight_decay=0.1, max_norm=10.0):
+        self.step_count += 1
+        _lib.check(self.l.coati_engine_optimizer_step(self.h, float(lr), betas[0], betas[1], eps, weight_decay, max_norm,
+                                                      self.step_count, ptr(self.scal), stream()), "coati_engine_optimizer_step")
+
+    def token_entropy_unit(self):
+        return math.log(float(self.cfg.n_tok)) / math.log(2.0)
+
+    def train_step(self, batch, use_point, lr, do_clip=True, clip_weight=None, optimizer=True):
+        """One single-GPU do_minibatch (train_coati.py:216-277).  Losses stay on the device in self.scal."""
+        h_e, h_s, bad = self.forward(batch["raw_tokens"], batch["tokens"], batch["atoms"], batch["coords"], use_point,
+                                     y_next=batch["y_next"], train=True)
+        dS = dC = None
+        if do_clip:
+            w = self.token_entropy_unit() if clip_weight is None else clip_weight
+            dS, dC = self.infonce(h_s, h_e, h_s, h_e, bad, row0=0, gscale=0.5 * w)
+        self.backward(dS, dC, 0)
+        if optimizer:
+            self.optimizer_step(lr)
+        return h_e, h_s, bad
+
+    def losses(self):
+        """Host copy of the loss scalars of the last step (synchronises)."""
+        s = self.scal.detach().cpu()
+        err = int(s[SCAL_ERR:SCAL_ERR + 1].view(torch.int32)[0])
+        if err & 1:
+            raise RuntimeError("Some smiles in the batch do not have stop tokens. Did some tokenizations fail?")
+        ar = float(s[SCAL_AR_SUM] / s[SCAL_AR_COUNT]) if s[SCAL_AR_COUNT] > 0 else 0.0
+        nv = float(s[SCAL_NVALID])
+        clip = float(0.5 * (s[SCAL_CLIP1] + s[SCAL_CLIP2]) / nv) if nv > 0 else 0.0
+        return {"ar_loss": ar, "clip_loss": clip, "loss": ar + clip * self.token_entropy_unit(),
+                "grad_norm": float(s[SCAL_GRADNORM]), "n_targets": float(s[SCAL_AR_COUNT]), "n_valid": nv}
+
+    # ---- profiling ---------------------------------------------------------------------------------------------
+    def site_names(self):
+        return [self.l.coati_engine_site_name(i).decode() for i in range(self.l.coati_engine_site_count())]
+
+    def prof_select(self, site):
+        idx = self.site_names().index(site) if isinstance(site, str) else site
+        _lib.check(self.l.coati_engine_prof_select(self.h, idx), "prof_select")
+
+    def prof_collect(self):
+        ms, n, fl = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double()
+        _lib.check(self.l.coati_engine_prof_collect(self.h, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl)), "prof_collect")
+        return ms.value, n.value, fl.value

@@ -1,0 +1,161 @@
+"""Tensor-level wrappers of the fine-grained C-ABI operators.  Every function enqueues HIP kernels on the current
+torch stream and returns torch tensors; nothing here computes on the CPU or falls back to aten."""
+import ctypes
+import math
+
+import torch
+
+from . import _lib
+
+EPI_BF16, EPI_F32, EPI_RES_F32, EPI_GELU, EPI_DGELU, EPI_SILU, EPI_DSILU, EPI_ACC_F32 = range(8)
+BF16 = torch.bfloat16
+
+
+def ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("coati_amd ops need device tensors: the HIP path has no CPU fallback")
+
+
+def gemm_nt(A, W, bias=None, epi=EPI_BF16, aux_in=None, out=None, n_store=0):
+    """C = epilogue(A @ W^T + bias).  A [M,K] bf16|f32, W [N,K] bf16.  Returns C or (C, pre) for GELU/SILU."""
+    _need_cuda(A, W)
+    M, K = A.shape
+    N = W.shape[0]
+    a_f32 = 1 if A.dtype == torch.float32 else 0
+    out_f32 = epi in (EPI_F32, EPI_RES_F32, EPI_ACC_F32)
+    ncol = max(N, n_store)
+    if out is None:
+        out = torch.empty(M, ncol, device=A.device, dtype=torch.float32 if out_f32 else BF16)
+    aux_out = None
+    ld_aux = 0
+    if epi in (EPI_GELU, EPI_SILU):
+        aux_out = torch.empty(M, N, device=A.device, dtype=BF16)
+        ld_aux = aux_out.stride(0)
+    if aux_in is not None:
+        ld_aux = aux_in.stride(0)
+    _lib.call("coati_gemm_nt", ptr(A), a_f32, A.stride(0), ptr(W), W.stride(0), M, N, K, ptr(out), out.stride(0),
+              n_store, ptr(bias), ptr(aux_in), ptr(aux_out), ld_aux, epi, stream())
+    return (out, aux_out) if aux_out is not None else out
+
+
+def wgrad(A, Bm, dW, dbias=None, n_out=0):
+    """dW[N,K] += A[M,N]^T @ Bm[M,K]; dbias[N] += colsum(A)."""
+    _need_cuda(A, Bm, dW)
+    M, N = A.shape
+    K = Bm.shape[1]
+    _lib.call("coati_wgrad", ptr(A), 1 if A.dtype == torch.float32 else 0, A.stride(0), ptr(Bm), Bm.stride(0), M, N, K,
+              ptr(dW), dW.stride(0), ptr(dbias), n_out, stream())
+    return dW
+
+
+def sgemm(A, Bm, trans_a=False, trans_b=False, bias=None, alpha=1.0, out=None, accumulate=False):
+    """out = alpha * op(A) @ op(Bm) (+bias) in exact fp32 (MFMA f32)."""
+    _need_cuda(A, Bm)
+    ars, acs = (A.stride(1), A.stride(0)) if trans_a else (A.stride(0), A.stride(1))
+    brs, bcs = (Bm.stride(1), Bm.stride(0)) if trans_b else (Bm.stride(0), Bm.stride(1))
+    M, K = (A.shape[1], A.shape[0]) if trans_a else A.shape
+    N = Bm.shape[0] if trans_b else Bm.shape[1]
+    if out is None:
+        out = torch.empty(M, N, device=A.device, dtype=torch.float32)
+    _lib.call("coati_sgemm", ptr(A), ars, acs, ptr(Bm), brs, bcs, ptr(out), out.stride(0), M, N, K, ptr(bias),
+              float(alpha), 1 if accumulate else 0, stream())
+    return out
+
+
+def layernorm_fwd(x, gamma=None, beta=None, want16=True, want32=False):
+    _need_cuda(x)
+    M, C = x.shape
+    y16 = torch.empty(M, C, device=x.device, dtype=BF16) if want16 else None
+    y32 = torch.empty(M, C, device=x.device, dtype=torch.float32) if want32 else None
+    mean = torch.empty(M, device=x.device, dtype=torch.float32)
+    rstd = torch.empty(M, device=x.device, dtype=torch.float32)
+    _lib.call("coati_layernorm_fwd", ptr(x), x.stride(0), ptr(gamma), ptr(beta), ptr(y16), C, ptr(y32), C, ptr(mean),
+              ptr(rstd), M, C, stream())
+    return y16, y32, mean, rstd
+
+
+def layernorm_bwd(dy, x, mean, rstd, gamma=None, dres=None, x_is_xhat=False, want_affine_grads=True):
+    _need_cuda(dy, x)
+    M, C = x.shape
+    dx = torch.empty(M, C, device=x.device, dtype=torch.float32)
+    dg = torch.zeros(C, device=x.device, dtype=torch.float32) if (gamma is not None and want_affine_grads) else None
+    db = torch.zeros(C, device=x.device, dtype=torch.float32) if dg is not None else None
+    _lib.call("coati_layernorm_bwd", ptr(dy), 1 if dy.dtype == torch.float32 else 0, dy.stride(0), ptr(x), x.stride(0),
+              1 if x_is_xhat else 0, ptr(mean), ptr(rstd), ptr(gamma), ptr(dres), ptr(dx), ptr(dg), ptr(db), M, C, stream())
+    return dx, dg, db
+
+
+def rope_tables(n_seq, head_size=16, base=10000.0, device="cuda"):
+    """RotaryEmbedding cos/sin caches (reference basic_transformer.py:57-69), computed with torch on the host in the
+    same op order as the reference so the tables are bit-identical, then moved to the device once."""
+    inv_freq = 1.0 / (base ** (torch.arange(0, head_size, 2).float() / head_size))
+    t = torch.arange(n_seq).type_as(inv_freq)
+    freqs = torch.einsum("i,j->ij", t, inv_freq)
+    emb = torch.cat((freqs, freqs), dim=-1)
+    return emb.cos().contiguous().to(device), emb.sin().contiguous().to(device)
+
+
+def attn_fwd(qkv, B, T, n_head, cos, sin):
+    _need_cuda(qkv)
+    C = n_head * 16
+    y = torch.empty(B * T, C, device=qkv.device, dtype=BF16)
+    lse = torch.empty(B, n_head, T, device=qkv.device, dtype=torch.float32)
+    _lib.call("coati_attn_fwd", ptr(qkv), ptr(y), ptr(lse), ptr(cos), ptr(sin), B, T, n_head, stream())
+    return y, lse
+
+
+def attn_bwd(qkv, y, dy, lse, B, T, n_head, cos, sin):
+    dqkv = torch.empty_like(qkv)
+    _lib.call("coati_attn_bwd", ptr(qkv), ptr(y), ptr(dy), ptr(lse), ptr(dqkv), ptr(cos), ptr(sin), B, T, n_head, stream())
+    return dqkv
+
+
+def embed_fwd(idx, table, injection=None, unk=7):
+    B, T = idx.shape
+    V, C = table.shape
+    x = torch.empty(B * T, C, device=table.device, dtype=torch.float32)
+    _lib.call("coati_embed_fwd", ptr(idx), ptr(table), ptr(injection), unk, ptr(x), B, T, C, V, stream())
+    return x
+
+
+def embed_bwd(idx, dx, V, with_injection=False, unk=7):
+    B, T = idx.shape
+    C = dx.shape[1]
+    dt = torch.zeros(V, C, device=dx.device, dtype=torch.float32)
+    di = torch.zeros(B, C, device=dx.device, dtype=torch.float32) if with_injection else None
+    _lib.call("coati_embed_bwd", ptr(idx), ptr(dx), ptr(dt), ptr(di), unk, B, T, C, V, stream())
+    return dt, di
+
+
+def ce_fwd(a, W, target):
+    """Fused lm_head + cross entropy forward.  a [M,K] bf16, W [V,K] bf16, target [M] int64 (-1 ignored).
+    Returns (lse [M], scal[16]) with scal[0] = sum loss, scal[1] = count."""
+    M, K = a.shape
+    V = W.shape[0]
+    tiles = (V + 127) // 128
+    partial = torch.empty(M, tiles, 2, device=a.device, dtype=torch.float32)
+    lse = torch.empty(M, device=a.device, dtype=torch.float32)
+    scal = torch.zeros(16, device=a.device, dtype=torch.float32)
+    _lib.call("coati_gemm_ce_partial", ptr(a), a.stride(0), ptr(W), W.stride(0), M, V, K, ptr(partial), stream())
+    _lib.call("coati_ce_finish", ptr(partial), tiles, ptr(a), a.stride(0), ptr(W), W.stride(0), ptr(target), ptr(lse),
+              ptr(scal), M, K, V, stream())
+    return lse, scal
+
+
+def ce_bwd(a, W, target, lse, scal):
+    M, K = a.shape
+    V = W.shape[0]
+    Vpad = (V + 63) // 64 * 64
+    d = torch.empty(M, Vpad, device=a.device, dtype=BF16)
+    _lib.call("coati_gemm_ce_bwd", ptr(a), a.stride(0), ptr(W), W.stride(0), M, V, K, ptr(d), Vpad, Vpad, ptr(lse),
+              ptr(target), ptr(scal), stream())
+    return d

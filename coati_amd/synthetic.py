@@ -1,0 +1,57 @@
+"""Synthetic SMILES-token + 3D-coordinate batches in the format clip_ar_xform emits (clip_e2e.py:288-330), as
+SURVEY.md section 8(d) specifies them.  Used by bench.py, the smoke test and the parity tests (there is no network
+for the 340 GB dataset and rdkit is absent, so tokens are drawn directly)."""
+import torch
+
+PAD, STOP, SMILES, SUFFIX, MIDDLE, UNK, CLIP = 0, 1, 2, 5, 6, 7, 8
+ELEMENTS = (1, 6, 7, 8, 9, 16, 17)
+
+
+def y_next_from_tokens(tokens):
+    """tail of clip_ar_xform, clip_e2e.py:317-329"""
+    y = torch.zeros_like(tokens)
+    y[:, : tokens.shape[1] - 1] = tokens[:, 1:]
+    for t in (CLIP, PAD, UNK, SUFFIX, MIDDLE):
+        y[y == t] = -1
+    return y
+
+
+def make_batch(B, T, A, V, seed=1234, n_special=1596, p_clip=0.9, p_bad=0.01, min_len=16, device="cpu"):
+    g = torch.Generator().manual_seed(seed)
+    n_special = min(n_special, V - 2)
+    Lmax = T - 4                      # [CLIP][UNK][SMILES] body [STOP]
+    lo = min(min_len, Lmax)
+    lens = torch.randint(lo, Lmax + 1, (B,), generator=g)
+    lens[0] = Lmax                    # keeps the truncated width at T
+    body = torch.randint(n_special, V, (B, Lmax), generator=g)
+    clip_row = torch.rand(B, generator=g) < p_clip
+    clip_row[0] = True
+    bad = torch.rand(B, generator=g) < p_bad
+    bad[0] = False
+    raw = torch.zeros(B, T, dtype=torch.long)
+    tok = torch.zeros(B, T, dtype=torch.long)
+    ar = torch.arange(Lmax).unsqueeze(0)
+    bm = ar < lens.unsqueeze(1)
+    raw[:, 0] = SMILES
+    raw[:, 1:1 + Lmax] = torch.where(bm, body, torch.zeros_like(body))
+    raw[torch.arange(B), 1 + lens] = STOP
+    t3 = torch.zeros(B, T, dtype=torch.long)
+    t3[:, 0], t3[:, 1], t3[:, 2] = CLIP, UNK, SMILES
+    t3[:, 3:3 + Lmax] = torch.where(bm, body, torch.zeros_like(body))
+    t3[torch.arange(B), 3 + lens] = STOP
+    t1 = torch.zeros(B, T, dtype=torch.long)
+    t1[:, :T - 2] = raw[:, :T - 2]
+    tok = torch.where(clip_row.unsqueeze(1), t3, t1)
+    tok[bad] = 0
+    raw[bad] = 0
+    raw[bad, 0] = STOP
+    raw = raw[:, : T - 2].contiguous()  # clip_ar_xform truncates every stack to its longest row
+    el = torch.tensor(ELEMENTS)
+    n_atoms = torch.randint(min(8, A), A + 1, (B,), generator=g)
+    atoms = el[torch.randint(0, len(el), (B, A), generator=g)]
+    atoms = torch.where(torch.arange(A).unsqueeze(0) < n_atoms.unsqueeze(1), atoms, torch.zeros_like(atoms))
+    coords = (torch.randn(B, A, 3, generator=g) * 1.5).float()
+    batch = dict(raw_tokens=raw, tokens=tok, y_next=y_next_from_tokens(tok), atoms=atoms, coords=coords)
+    use_point = torch.rand(B, generator=g) > 0.5
+    batch = {k: v.to(device) for k, v in batch.items()}
+    return batch, use_point.to(device)

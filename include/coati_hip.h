@@ -1,0 +1,205 @@
+/*
+ * coati_hip.h -- C ABI of libcoati_hip.so, the MI355X (gfx950) implementation of COATI's contrastive +
+ * autoregressive training step.
+ *
+ * The reference (terraytherapeutics/COATI) is pure Python on PyTorch: it has no FFI of its own.  The boundary
+ * below is what a Python binding (ctypes) needs in order to replace the aten ops behind
+ * the reference's own operator interface for this path:
+ *
+ *   e3gnn_smiles_clip_e2e.forward_dist                coati/models/encoding/clip_e2e.py:772-814
+ *   e3gnn_clip.forward (+ e_gcl_sparse)               coati/models/encoding/e3gnn_clip.py:108-137,
+ *                                                     coati/models/encoding/e_gcl_sparse.py:27-77,169-321
+ *   RotarySmilesTransformer.xformer / encode /        coati/models/encoding/smiles_xformer.py:50-68,106-112,
+ *     forward_with_replacement                          353-368,426-454
+ *   RotaryBlock / RotarySelfAttention / NewGELU       coati/models/encoding/basic_transformer.py:12-28,83-174
+ *   clip_loss.forward                                 coati/models/encoding/clip_e2e.py:27-47
+ *   do_minibatch (loss, backward, clip, AdamW)        coati/training/train_coati.py:216-277
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative code (COATI_EARG -1 bad argument, COATI_ESHAPE -2
+ *     unsupported shape, COATI_EHIP -3 HIP error); coati_last_error() returns a thread-local message.
+ *     Nothing throws across the boundary.
+ *   - all pointers are DEVICE pointers unless a parameter says "host".  The caller (PyTorch) owns every buffer:
+ *     parameters, gradients, optimiser state, activations/workspace.  The library never allocates device memory.
+ *   - `stream` is a hipStream_t passed as void*; kernels are enqueued on it and the call returns immediately.
+ *   - bf16 tensors are raw uint16_t storage; "f32" = float; token / atom indices are int64_t (torch.long).
+ *   - matrices are row-major with an explicit leading dimension (elements).
+ */
+#ifndef COATI_HIP_H
+#define COATI_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define COATI_ABI_VERSION 1
+
+const char* coati_last_error(void);
+int coati_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Fine-grained operators (one HIP kernel or a short fixed sequence each).  These replace individual aten
+ * ops of the reference and are what the per-op parity tests call.
+ * ---------------------------------------------------------------------------------------------------- */
+
+/* epilogue selector of coati_gemm_nt (values of enum CoatiEpi in csrc/kernels.h) */
+enum {
+  COATI_EPI_BF16 = 0, COATI_EPI_F32 = 1, COATI_EPI_RES_F32 = 2, COATI_EPI_GELU = 3, COATI_EPI_DGELU = 4,
+  COATI_EPI_SILU = 5, COATI_EPI_DSILU = 6, COATI_EPI_ACC_F32 = 7
+};
+
+/* C[M,N] = epilogue(A[M,K] * B[N,K]^T + bias).  Replaces nn.Linear forward (F.linear) and its input-gradient,
+ * fused with the activation / residual that follows it in basic_transformer.py:165-173 and e_gcl_sparse.py:130-145.
+ * A is bf16 (a_f32=0) or f32 converted on load (a_f32=1); B is bf16.  K % 64 == 0. */
+int coati_gemm_nt(const void* A, int a_f32, int64_t lda, const uint16_t* B, int64_t ldb, int M, int N, int K,
+                  void* C, int64_t ldc, int n_store, const float* bias, const void* aux_in, void* aux_out,
+                  int64_t ld_aux, int epi, void* stream);
+
+/* lm_head + cross-entropy without materialising logits (smiles_xformer.py:453 + train_coati.py:260-265):
+ * partial[M, ceil(V/128)] receives per-tile (max, sum exp) pairs; coati_ce_finish merges them into lse[M] and
+ * adds sum(lse - logit[target]) to scal[0] and the number of targets != -1 to scal[1]. */
+int coati_gemm_ce_partial(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw, int M, int V, int K,
+                          void* partial, void* stream);
+int coati_ce_finish(const void* partial, int tiles_n, const uint16_t* A, int64_t lda, const uint16_t* W,
+                    int64_t ldw, const int64_t* target, float* lse, float* scal, int M, int K, int V, void* stream);
+/* dlogits[M, n_store] (bf16) = (softmax(A W^T) - onehot(target)) / scal[1]; rows with target -1 are zero. */
+int coati_gemm_ce_bwd(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw, int M, int V, int K,
+                      uint16_t* dlogits, int64_t ldd, int n_store, const float* lse, const int64_t* target,
+                      const float* scal, void* stream);
+
+/* dW[N,K] (f32, +=) = A[M,N]^T * B[M,K]; dbias[N] (+=) = column sums of A (may be NULL).  Replaces the weight /
+ * bias gradient of every nn.Linear on the path.  Rows n >= n_out of dW are not written (n_out = 0 -> N). */
+int coati_wgrad(const void* A, int a_f32, int64_t lda, const uint16_t* B, int64_t ldb, int M, int N, int K,
+                float* dW, int64_t ldw, float* dbias, int n_out, void* stream);
+
+/* exact-f32 GEMM with generic strides: C[M,N] = alpha * sum_k A[m*ars + k*acs] * B[k*brs + n*bcs] (+ bias[n])
+ * (+ C when accumulate).  Used for the [B,256] projection heads and the InfoNCE logits (clip_e2e.py:36-37). */
+int coati_sgemm(const float* A, int64_t ars, int64_t acs, const float* B, int64_t brs, int64_t bcs, float* C,
+                int64_t ldc, int M, int N, int K, const float* bias, float alpha, int accumulate, void* stream);
+
+/* nn.LayerNorm(C) / InstanceNorm1d applied over the hidden dim (gamma = beta = NULL), eps 1e-5. */
+int coati_layernorm_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, uint16_t* y16,
+                        int64_t ld16, float* y32, int64_t ld32, float* mean, float* rstd, int M, int C,
+                        void* stream);
+int coati_layernorm_bwd(const void* dy, int dy_f32, int64_t lddy, const float* x, int64_t ldx, int x_is_xhat,
+                        const float* mean, const float* rstd, const float* gamma, const float* dres, float* dx,
+                        float* dgamma, float* dbeta, int M, int C, void* stream);
+
+/* RotarySelfAttention core (basic_transformer.py:126-150) for head size 16: RoPE(q,k), causal softmax(q k^T/4) v.
+ * qkv [B*T, 3*nh*16] bf16, y [B*T, nh*16] bf16, lse [B, nh, T] f32, cos/sin [n_seq, 16] f32 (RotaryEmbedding
+ * tables, basic_transformer.py:57-69). */
+int coati_attn_fwd(const uint16_t* qkv, uint16_t* y, float* lse, const float* cos_t, const float* sin_t, int B,
+                   int T, int n_head, void* stream);
+int coati_attn_bwd(const uint16_t* qkv, const uint16_t* y, const uint16_t* dy, const float* lse, uint16_t* dqkv,
+                   const float* cos_t, const float* sin_t, int B, int T, int n_head, void* stream);
+
+/* token embedding gather with [UNK]-slot injection (basic_transformer.py:80-81, smiles_xformer.py:444-448) */
+int coati_embed_fwd(const int64_t* idx, const float* table, const float* injection, int unk_token, float* x,
+                    int B, int T, int C, int V, void* stream);
+int coati_embed_bwd(const int64_t* idx, const float* dx, float* dtable, float* dinjection, int unk_token, int B,
+                    int T, int C, int V, void* stream);
+/* get_stop_token_embs (smiles_xformer.py:50-68): err[0] |= 1 when a row does not hold exactly one stop token */
+int coati_find_stop(const int64_t* idx, int stop_token, int32_t* pos, int32_t* err, int B, int T, void* stream);
+int coati_gather_rows(const float* x, const int32_t* pos, float* out, int B, int T, int C, void* stream);
+int coati_scatter_rows_add(const float* dout, const int32_t* pos, float* dx, int B, int T, int C, void* stream);
+int coati_bad_rows(const int64_t* tokens, uint8_t* bad, int B, int T, void* stream);
+
+/* E(3)-GNN pieces (e3gnn_clip.py:108-137, e_gcl_sparse.py) -- see csrc/gnn.hip for the dense-edge formulation */
+int coati_gnn_embed(const int64_t* atoms, const int32_t* lut_ix, const int32_t* lut_iy, const float* W,
+                    const float* b, float* h32, uint16_t* h16, int64_t ld16, float* rstd, float* mask, int BA,
+                    int H, void* stream);
+int coati_gnn_geom(const float* coords, const float* mask, float cutoff, float* d2, float* w, int B, int A,
+                   void* stream);
+int coati_gnn_edge_pre(const uint16_t* P, int64_t ldp, const float* d2, const float* w1c, int64_t w1c_stride,
+                       const float* b1, uint16_t* e1, int B, int A, int H, void* stream);
+int coati_gnn_edge_reduce(const uint16_t* s2, const float* w, uint16_t* mi, int64_t ldmi, int B, int A, int H,
+                          void* stream);
+
+/* symmetric InfoNCE over local rows x global columns (clip_e2e.py:35-47).  logits [R,N] f32 is overwritten by its
+ * gradient scaled by gscale * inv_count[0]; rows whose label (label0 + r) is a bad row are ignored. */
+int coati_infonce_rows(float* logits, int64_t ld, int R, int N, int label0, const uint8_t* bad, float* loss_sum,
+                       const float* inv_count, float gscale, void* stream);
+
+/* clip_grad_norm_ + AdamW over flat buffers (train_coati.py:145-151, 276-277) */
+int coati_grad_sqnorm(const float* g, int64_t n, float* partial, int n_partial, float* out_norm, float max_norm,
+                      float* out_coef, void* stream);
+int coati_adamw(float* p, const float* g, float* m, float* v, uint16_t* shadow, int64_t n, float lr, float b1,
+                float b2, float eps, float wd, int step, const float* coef, float gscale, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Engine: the whole step behind e3gnn_smiles_clip_e2e.forward_dist + do_minibatch, as a fixed launch
+ * sequence owned by the library (no Python between kernels).  Buffers are still owned by the caller.
+ * ---------------------------------------------------------------------------------------------------- */
+typedef struct coati_config {
+  int32_t n_layer_xformer;  /* clip_e2e.py:357-378 kwargs */
+  int32_t n_layer_e3gnn;
+  int32_t n_hidden_xformer; /* C */
+  int32_t n_hidden_e3nn;    /* H */
+  int32_t n_embd_common;    /* E (must equal C: smiles_to_clip's LayerNorm is sized by E, clip_e2e.py:423-426) */
+  int32_t n_head;           /* C / n_head must be 16 */
+  int32_t n_seq;
+  int32_t n_tok;            /* V */
+  float msg_cutoff;         /* effective cutoff of e_gcl_sparse (always 5.0 in the reference) */
+  int32_t pad_token, stop_token, unk_token;
+} coati_config;
+
+typedef struct coati_engine coati_engine;
+
+int coati_engine_create(const coati_config* cfg, coati_engine** out);
+void coati_engine_destroy(coati_engine* e);
+
+/* parameter table: entry i = (state_dict name, element offset into the flat f32 buffer, rows, cols) */
+int64_t coati_engine_param_elems(const coati_engine* e);
+int coati_engine_n_entries(const coati_engine* e);
+int coati_engine_entry(const coati_engine* e, int i, char* name, int name_cap, int64_t* offset, int32_t* rows,
+                       int32_t* cols);
+int64_t coati_engine_shadow_elems(const coati_engine* e);
+int64_t coati_engine_workspace_bytes(const coati_engine* e, int B, int T1, int T2, int A, int Bg);
+
+/* bind caller-owned buffers: params/grads/adam m/adam v (f32, param_elems), shadow (bf16, shadow_elems, zeroed),
+ * RoPE tables [n_seq,16] f32, periodic-table LUTs [120] int32 (one-hot indices, -1 = none). */
+int coati_engine_bind(coati_engine* e, float* params, float* grads, float* adam_m, float* adam_v, uint16_t* shadow,
+                      const float* rope_cos, const float* rope_sin, const int32_t* lut_ix, const int32_t* lut_iy);
+/* rebuild every bf16 shadow (natural + transposed/packed) from the f32 parameters */
+int coati_engine_refresh_shadows(coati_engine* e, void* stream);
+
+/* forward_dist + AR loss.  raw_tokens [B,T1], tokens [B,T2], y_next [B,T2], atoms [B,A] int64; coords [B,A,3] f32;
+ * use_point [B] uint8 (1 -> inject the point-cloud token; replaces `rand(B) > p_clip_emb_smi`, clip_e2e.py:802).
+ * Outputs: h_e3gnn, h_smiles [B,E] f32; bad_rows [B] uint8; scal[0] = sum AR loss, scal[1] = #targets,
+ * scal[6] = error flags (bit 0: a raw_tokens row without exactly one [STOP]).  Zeroes the gradient buffer. */
+int coati_engine_forward(coati_engine* e, void* workspace, int64_t workspace_bytes, int B, int T1, int T2, int A,
+                         const int64_t* raw_tokens, const int64_t* tokens, const int64_t* y_next,
+                         const int64_t* atoms, const float* coords, const uint8_t* use_point, float* h_e3gnn,
+                         float* h_smiles, uint8_t* bad_rows, float* scal, int train, void* stream);
+/* logits [B*T2, ldl] f32 of the last forward (API parity with forward_dist's third return value) */
+int coati_engine_logits(coati_engine* e, float* logits, int64_t ldl, void* stream);
+
+/* InfoNCE over local rows: S_loc/C_loc [B,E], S_all/C_all [Bg,E], bad_all [Bg]; rank rows start at row0.
+ * Writes dS_all, dC_all [Bg,E] (to be reduce-scattered when Bg > B), adds the two directional loss sums to
+ * scal[2], scal[3], writes the valid-row count to scal[4].  gscale multiplies the gradients. */
+int coati_engine_infonce(coati_engine* e, const float* S_loc, const float* C_loc, const float* S_all,
+                         const float* C_all, const uint8_t* bad_all, int B, int Bg, int row0, float gscale,
+                         float* dS_all, float* dC_all, float* scal, void* stream);
+
+/* backward of the last forward.  dh_smiles / dh_e3gnn [B,E]: gradient of the contrastive term w.r.t. the two
+ * embeddings.  stage: 0 = everything; 1 = lm_head + decoder pass + heads; 2 = encoder pass; 3 = point encoder
+ * (1,2,3 in that order == 0; lets the caller overlap bucketed gradient all-reduces with the remaining stages). */
+int coati_engine_backward(coati_engine* e, const float* dh_smiles, const float* dh_e3gnn, int stage, void* stream);
+
+/* clip_grad_norm_(max_norm) + AdamW + shadow refresh.  scal[5] receives the pre-clip gradient norm. */
+int coati_engine_optimizer_step(coati_engine* e, float lr, float beta1, float beta2, float eps, float weight_decay,
+                                float max_norm, int step, float* scal, void* stream);
+
+/* per-site kernel timing with HIP events on the launch stream (bench.py roofline leg) */
+int coati_engine_prof_select(coati_engine* e, int site);              /* -1 disables */
+int coati_engine_prof_collect(coati_engine* e, double* total_ms, int64_t* launches, double* flops_per_launch);
+int coati_engine_site_count(void);
+const char* coati_engine_site_name(int site);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* COATI_HIP_H */

@@ -1,0 +1,200 @@
+"""Per-operator parity of the HIP kernels (through the C ABI) against plain fp32 torch maths on bf16-rounded
+operands.  Tolerances: bf16 outputs carry one rounding (2^-9 relative) on top of fp32 accumulation-order noise."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from tests.gpu_util import check, rbf, log  # noqa: E402
+
+DEV = "cuda:0"
+TB = 6e-3    # bf16-output tolerance relative to the tensor scale
+TF = 2e-5    # fp32-output tolerance
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from coati_amd import ops as o
+    return o
+
+
+def gelu(x):
+    return 0.5 * x * (1.0 + torch.tanh(math.sqrt(2.0 / math.pi) * (x + 0.044715 * x ** 3)))
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 192, 256), (128, 768, 64), (1000, 130, 128), (64, 64, 1024)])
+def test_gemm_epilogues(ops, M, N, K):
+    g = torch.Generator(device="cpu").manual_seed(M + N + K)
+    A = rbf(torch.randn(M, K, generator=g)).to(DEV)
+    W = rbf(torch.randn(N, K, generator=g) / math.sqrt(K)).to(DEV)
+    bias = torch.randn(N, generator=g).to(DEV)
+    res = torch.randn(M, N, generator=g).to(DEV)
+    ref = A @ W.t() + bias
+    Ab, Wb = A.bfloat16(), W.bfloat16()
+    Np = (N + 7) // 8 * 8
+    def out(dtype):
+        return torch.zeros(M, Np, device=DEV, dtype=dtype)
+    c = ops.gemm_nt(Ab, Wb, bias, ops.EPI_BF16, out=out(torch.bfloat16))
+    check(f"gemm bf16 {M}x{N}x{K}", c[:, :N].float(), ref, TB)
+    c = ops.gemm_nt(Ab, Wb, bias, ops.EPI_F32, out=out(torch.float32))
+    check(f"gemm f32 {M}x{N}x{K}", c[:, :N], ref, TF * 10)
+    c = ops.gemm_nt(A, Wb, bias, ops.EPI_F32, out=out(torch.float32))   # f32 A converted on load
+    check(f"gemm f32(A f32) {M}x{N}x{K}", c[:, :N], ref, TF * 10)
+    if N % 8 == 0:
+        c = ops.gemm_nt(Ab, Wb, bias, ops.EPI_RES_F32, aux_in=res)
+        check(f"gemm res {M}x{N}x{K}", c, ref + res, TF * 10)
+        acc = res.clone()
+        ops.gemm_nt(Ab, Wb, None, ops.EPI_ACC_F32, out=acc)
+        check(f"gemm acc {M}x{N}x{K}", acc, res + A @ W.t(), TF * 10)
+        c, pre = ops.gemm_nt(Ab, Wb, bias, ops.EPI_GELU)
+        check(f"gemm gelu pre {M}x{N}x{K}", pre.float(), ref, TB)
+        check(f"gemm gelu {M}x{N}x{K}", c.float(), gelu(ref), TB)
+        c, pre = ops.gemm_nt(Ab, Wb, bias, ops.EPI_SILU)
+        check(f"gemm silu {M}x{N}x{K}", c.float(), torch.nn.functional.silu(ref), TB)
+        x = rbf(torch.randn(M, N, generator=g)).to(DEV)
+        xg = x.clone().requires_grad_(True)
+        (dg,) = torch.autograd.grad(gelu(xg).sum(), xg)
+        c = ops.gemm_nt(Ab, Wb, None, ops.EPI_DGELU, aux_in=x.bfloat16())
+        check(f"gemm dgelu {M}x{N}x{K}", c.float(), (A @ W.t()) * dg, TB)
+        (ds,) = torch.autograd.grad(torch.nn.functional.silu(xg).sum(), xg)
+        c = ops.gemm_nt(A, Wb, None, ops.EPI_DSILU, aux_in=x.bfloat16())
+        check(f"gemm dsilu(A f32) {M}x{N}x{K}", c.float(), (A @ W.t()) * ds, TB)
+
+
+@pytest.mark.parametrize("M,N,K,f32", [(1000, 256, 128, False), (4099, 768, 256, False), (640, 64, 64, True), (3000, 136, 1024, True)])
+def test_wgrad(ops, M, N, K, f32):
+    g = torch.Generator().manual_seed(M)
+    A = rbf(torch.randn(M, N, generator=g)).to(DEV)
+    X = rbf(torch.randn(M, K, generator=g)).to(DEV)
+    dW0 = torch.randn(N, K + 1, generator=g).to(DEV)     # odd leading dimension, pre-filled: tests "+="
+    db0 = torch.randn(N, generator=g).to(DEV)
+    dW = dW0.clone()
+    db = db0.clone()
+    ops.wgrad(A if f32 else A.bfloat16(), X.bfloat16(), dW[:, :K], db)
+    check(f"wgrad dW {M}x{N}x{K} f32={f32}", dW[:, :K], dW0[:, :K] + A.t() @ X, 3e-5 * math.sqrt(M))
+    check(f"wgrad untouched col {M}", dW[:, K], dW0[:, K], 0.0)
+    check(f"wgrad db {M}x{N}", db, db0 + A.sum(0), 3e-5 * math.sqrt(M))
+
+
+@pytest.mark.parametrize("M,N,K", [(70, 33, 19), (1024, 1024, 256), (1, 256, 1024)])
+def test_sgemm(ops, M, N, K):
+    g = torch.Generator().manual_seed(7)
+    A = torch.randn(M, K, generator=g).to(DEV)
+    Bm = torch.randn(K, N, generator=g).to(DEV)
+    bias = torch.randn(N, generator=g).to(DEV)
+    ref = (A.double() @ Bm.double()).float()
+    check(f"sgemm nn {M}x{N}x{K}", ops.sgemm(A, Bm, bias=bias), ref + bias, 2e-6 * math.sqrt(K))
+    check(f"sgemm tn {M}x{N}x{K}", ops.sgemm(A.t().contiguous(), Bm, trans_a=True), ref, 2e-6 * math.sqrt(K))
+    check(f"sgemm nt {M}x{N}x{K}", ops.sgemm(A, Bm.t().contiguous(), trans_b=True, alpha=0.5), 0.5 * ref, 2e-6 * math.sqrt(K))
+    c0 = torch.randn(M, N, generator=g).to(DEV)
+    c = c0.clone()
+    ops.sgemm(A, Bm, out=c, accumulate=True)
+    check(f"sgemm acc {M}x{N}x{K}", c, c0 + ref, 2e-6 * math.sqrt(K))
+
+
+@pytest.mark.parametrize("M,C,affine", [(1000, 256, True), (77, 64, True), (513, 256, False), (9, 1024, True)])
+def test_layernorm(ops, M, C, affine):
+    g = torch.Generator().manual_seed(C)
+    x = (torch.randn(M, C, generator=g) * 2 + 0.3).to(DEV)
+    gamma = (1 + 0.1 * torch.randn(C, generator=g)).to(DEV) if affine else None
+    beta = (0.1 * torch.randn(C, generator=g)).to(DEV) if affine else None
+    xr = x.clone().requires_grad_(True)
+    gr = gamma.clone().requires_grad_(True) if affine else None
+    br = beta.clone().requires_grad_(True) if affine else None
+    ref = torch.nn.functional.layer_norm(xr, (C,), gr, br, 1e-5)
+    y16, y32, mean, rstd = ops.layernorm_fwd(x, gamma, beta, want16=True, want32=True)
+    check(f"ln fwd32 {M}x{C}", y32, ref, 1e-5)
+    check(f"ln fwd16 {M}x{C}", y16.float(), ref, TB)
+    dy = rbf(torch.randn(M, C, generator=g)).to(DEV)
+    dres = torch.randn(M, C, generator=g).to(DEV)
+    ref.backward(dy)
+    for dyt, tag in ((dy.bfloat16(), "bf16"), (dy, "f32")):
+        dx, dg, db = ops.layernorm_bwd(dyt, x, mean, rstd, gamma, dres=dres)
+        check(f"ln bwd dx {M}x{C} {tag}", dx, xr.grad + dres, 2e-5)
+        if affine:
+            check(f"ln bwd dgamma {M}x{C} {tag}", dg, gr.grad, 1e-4)
+            check(f"ln bwd dbeta {M}x{C} {tag}", db, br.grad, 1e-4)
+    if not affine:
+        dx, _, _ = ops.layernorm_bwd(dy, y32, None, rstd, None, x_is_xhat=True)
+        check(f"ln bwd xhat {M}x{C}", dx, xr.grad, 2e-5)
+
+
+@pytest.mark.parametrize("B,T,nh", [(3, 12, 4), (5, 80, 16), (2, 250, 4), (4, 33, 2)])
+def test_attention(ops, B, T, nh):
+    from oracle import coati_oracle as O
+    C = nh * 16
+    g = torch.Generator().manual_seed(T)
+    qkv = rbf(torch.randn(B * T, 3 * C, generator=g)).to(DEV)
+    dy = rbf(torch.randn(B * T, C, generator=g)).to(DEV)
+    cos, sin = ops.rope_tables(256, 16, device=DEV)
+    y, lse = ops.attn_fwd(qkv.bfloat16(), B, T, nh, cos, sin)
+    # reference (fp32 torch on the same bf16 operands), oracle functions restate basic_transformer.py:126-150
+    qr = qkv.cpu().clone().requires_grad_(True)
+    q, k, v = qr.view(B, T, 3 * C).split(C, dim=2)
+    q = q.view(B, T, nh, 16).transpose(1, 2)
+    k = k.view(B, T, nh, 16).transpose(1, 2)
+    v = v.view(B, T, nh, 16).transpose(1, 2)
+    c_, s_ = O.rope_tables(256, 16)
+    q, k = O.rotary_embed(q, k, c_, s_)
+    att = (q @ k.transpose(-2, -1)) * 0.25
+    att = att.masked_fill(~torch.tril(torch.ones(T, T, dtype=torch.bool)), float("-inf"))
+    lse_ref = torch.logsumexp(att, -1)
+    yr = (torch.softmax(att, -1) @ v).transpose(1, 2).reshape(B * T, C)
+    check(f"attn fwd y B{B} T{T}", y.float().cpu(), yr, 1.2e-2)
+    check(f"attn fwd lse B{B} T{T}", lse.cpu(), lse_ref, 5e-3)
+    yr.backward(dy.cpu())
+    dqkv = ops.attn_bwd(qkv.bfloat16(), y, dy.bfloat16(), lse, B, T, nh, cos, sin)
+    check(f"attn bwd dq B{B} T{T}", dqkv[:, :C].float().cpu(), qr.grad[:, :C], 2e-2)
+    check(f"attn bwd dk B{B} T{T}", dqkv[:, C:2 * C].float().cpu(), qr.grad[:, C:2 * C], 2e-2)
+    check(f"attn bwd dv B{B} T{T}", dqkv[:, 2 * C:].float().cpu(), qr.grad[:, 2 * C:], 2e-2)
+
+
+def test_embed(ops):
+    g = torch.Generator().manual_seed(3)
+    B, T, C, V = 6, 11, 64, 40
+    idx = torch.randint(0, V, (B, T), generator=g)
+    idx[:, 1] = 7
+    idx[2, 5] = 7
+    table = torch.randn(V, C, generator=g)
+    inj = torch.randn(B, C, generator=g)
+    x = ops.embed_fwd(idx.to(DEV), table.to(DEV), inj.to(DEV), unk=7)
+    ref = table[idx]
+    ref[idx == 7] = inj.unsqueeze(1).expand(B, T, C)[idx == 7]
+    check("embed fwd", x.cpu(), ref.view(B * T, C), 0.0)
+    x2 = ops.embed_fwd(idx.to(DEV), table.to(DEV), None, unk=7)
+    check("embed fwd no-inject", x2.cpu(), table[idx].view(B * T, C), 0.0)
+    dx = torch.randn(B * T, C, generator=g)
+    dt, di = ops.embed_bwd(idx.to(DEV), dx.to(DEV), V, with_injection=True, unk=7)
+    rt = torch.zeros(V, C)
+    ri = torch.zeros(B, C)
+    for b in range(B):
+        for t in range(T):
+            if idx[b, t] == 7:
+                ri[b] += dx[b * T + t]
+            else:
+                rt[idx[b, t]] += dx[b * T + t]
+    check("embed bwd table", dt.cpu(), rt, 1e-6)
+    check("embed bwd inject", di.cpu(), ri, 1e-6)
+
+
+@pytest.mark.parametrize("M,V,K", [(200, 48, 64), (700, 10322, 256)])
+def test_lmhead_ce(ops, M, V, K):
+    g = torch.Generator().manual_seed(V)
+    a = rbf(torch.randn(M, K, generator=g)).to(DEV)
+    W = rbf(torch.randn(V, K, generator=g) * 0.2).to(DEV)
+    tgt = torch.randint(0, V, (M,), generator=g)
+    tgt[::5] = -1
+    logits = (a @ W.t()).cpu()
+    lr = logits.clone().requires_grad_(True)
+    loss = torch.nn.functional.cross_entropy(lr, tgt, ignore_index=-1)
+    loss.backward()
+    lse, scal = ops.ce_fwd(a.bfloat16(), W.bfloat16(), tgt.to(DEV))
+    check(f"ce lse V{V}", lse.cpu(), torch.logsumexp(logits, -1), 1e-5)
+    s = scal.cpu()
+    assert int(s[1]) == int((tgt >= 0).sum())
+    check(f"ce loss V{V}", (s[0] / s[1]).reshape(1), loss.detach().reshape(1), 1e-5)
+    d = ops.ce_bwd(a.bfloat16(), W.bfloat16(), tgt.to(DEV), lse, scal)
+    check(f"ce dlogits V{V}", d[:, :V].float().cpu(), lr.grad, 1e-2)
+    assert float(d[:, V:].float().abs().max()) == 0.0 if d.shape[1] > V else True
