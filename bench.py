@@ -1,0 +1,187 @@
+#!/usr/bin/env python
+"""bench.py -- molecules/sec through the full contrastive + AR training step (forward_dist, InfoNCE + AR loss,
+backward, clip-norm, AdamW, DP collectives) on the grande_closed configuration, synthetic data.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (contract in the task statement): whole-job molecules/s with inputs resident in HBM,
+plus `roofline` (dominant kernel, timed live with HIP events on the launch stream) and, at N=1, `cpu_baseline`
+(the oracle's fp32 CPU step on a bounded sample of the same workload, on this box's host cores)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GRANDE = dict(n_layer_e3gnn=5, n_layer_xformer=16, n_hidden_xformer=256, n_hidden_e3nn=256, n_embd_common=256,
+              n_head=16, n_seq=250, n_tok=10322)          # examples/training/train_grande.py:17-35, vocab may_closedparen
+PEAK_BF16_TFLOPS = 2500.0    # dense bf16 MFMA, MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0
+
+
+def cpu_baseline(batch_cpu, use_point, n_mol, threads=None, min_seconds=10.0):
+    """The oracle (fp32 torch restatement of the reference step: forward_dist + both losses + backward + clip-norm +
+    AdamW) timed on the host cores on the first n_mol molecules of the same workload."""
+    from oracle import coati_oracle as O
+    if threads:
+        torch.set_num_threads(threads)
+    cfg = O.OracleConfig(**GRANDE)
+    P = O.init_params(cfg, seed=0)
+    sub = {k: v[:n_mol].clone() for k, v in batch_cpu.items()}
+    up = use_point[:n_mol].clone()
+    M = {k: torch.zeros_like(v) for k, v in P.items()}
+    V = {k: torch.zeros_like(v) for k, v in P.items()}
+
+    def step(i):
+        Pg = {k: v.detach().requires_grad_(True) for k, v in P.items()}
+        loss, *_ = O.step_loss(Pg, cfg, sub, up)
+        loss.backward()
+        grads = {k: (Pg[k].grad if Pg[k].grad is not None else torch.zeros_like(Pg[k])) for k in Pg}
+        _, coef = O.clip_grad_norm(grads, 10.0)
+        for k in P:
+            P[k], M[k], V[k] = O.adamw_update(P[k], grads[k] * coef, M[k], V[k], step=i, lr=5e-4)
+
+    step(1)  # warm-up (allocator, thread pool)
+    t0 = time.time()
+    n = 0
+    while time.time() - t0 < min_seconds or n < 2:
+        n += 1
+        step(n + 1)
+    dt = time.time() - t0
+    return {"value": round(n * n_mol / dt, 3), "unit": "molecules/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} full fp32 steps (fwd+InfoNCE+AR+bwd+clip+AdamW) of the oracle on {n_mol} molecules of the "
+                      f"same workload (T={sub['tokens'].shape[1]}, A={sub['atoms'].shape[1]}, V={GRANDE['n_tok']}), {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=1024, help="molecules per GPU (BASELINE.json configs[1])")
+    ap.add_argument("--seq", type=int, default=80)
+    ap.add_argument("--atoms", type=int, default=16)
+    ap.add_argument("--roofline-site", type=str, default="fc1_fwd")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-mols", type=int, default=32)
+    ap.add_argument("--all-sites", action="store_true", help="extra: per-site kernel time table on stderr")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+    dev = torch.device(f"cuda:{local_rank}")
+    torch.cuda.set_device(dev)
+
+    from coati_amd.engine import Engine, ModelConfig
+    from coati_amd.synthetic import make_batch
+    from coati_amd import distributed as D
+
+    eng = Engine(ModelConfig(**GRANDE), dev)
+    # random-init weights of the grande architecture (no network for checkpoints): N(0, 0.02)-style init
+    g = torch.Generator(device="cpu").manual_seed(0)
+    with torch.no_grad():
+        for name, (off, shape) in eng.layout.items():
+            v = eng.view(name)
+            if len(shape) == 2:
+                v.copy_((torch.randn(shape, generator=g) * (0.02 if "tok_emb" not in name else 1.0)).to(dev))
+            elif ".ln_" in name and name.endswith("weight") or name.endswith("clip.0.weight"):
+                v.fill_(1.0)
+            else:
+                v.zero_()
+    eng.refresh_shadows()
+    batch_cpu, up_cpu = make_batch(args.batch, args.seq, args.atoms, GRANDE["n_tok"], seed=1234 + rank)
+    batch = {k: v.to(dev) for k, v in batch_cpu.items()}
+    up = up_cpu.to(dev)
+
+    def step():
+        if world > 1:
+            D.distributed_train_step(eng, batch, up, lr=5e-4)
+        else:
+            eng.train_step(batch, up, lr=5e-4)
+
+    def sync():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    eng.prof_select(args.roofline_site)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    dt = time.perf_counter() - t0
+    site_ms, site_n, site_flops = eng.prof_collect()
+    eng.prof_select(-1)
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t)
+    losses = D.global_losses(eng) if world > 1 else eng.losses()
+
+    if args.all_sites and rank == 0:
+        rows = []
+        for s in eng.site_names():
+            eng.prof_select(s)
+            step()
+            torch.cuda.synchronize()
+            ms, n, fl = eng.prof_collect()
+            rows.append((ms, s, n, fl))
+        eng.prof_select(-1)
+        tot = sum(r[0] for r in rows)
+        for ms, s, n, fl in sorted(rows, reverse=True):
+            tf = (fl * n / (ms * 1e-3) / 1e12) if ms > 0 and fl > 0 else 0.0
+            print(f"  site {s:16s} {ms:8.3f} ms/step  {100 * ms / max(tot, 1e-9):5.1f}%  launches {n:4d}  {tf:7.1f} TFLOP/s", file=sys.stderr)
+        print(f"  sum of sites {tot:.3f} ms/step", file=sys.stderr)
+
+    if rank == 0:
+        mols = args.batch * world * args.steps
+        avg_ms = site_ms / max(site_n, 1)
+        achieved = (site_flops / (avg_ms * 1e-3) / 1e12) if avg_ms > 0 else 0.0
+        out = {
+            "metric": "molecules/sec (contrastive+AR train step), grande_closed",
+            "value": round(mols / dt, 2),
+            "unit": "molecules/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(1e3 * dt / args.steps, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "bf16",
+            "data": "synthetic",
+            "config": {"workload": f"grande_closed d=256 L=16 nh=16 + E3GNN h=256x5, V=10322, batch {args.batch}/GPU, "
+                                   f"seq_len {args.seq}, {args.atoms}-atom point clouds, InfoNCE + AR loss, bf16 MFMA operands / "
+                                   f"fp32 accumulate + fp32 master weights, random-init weights",
+                       "global_batch": args.batch * world, "seq_len": args.seq, "parallelism": f"dp{world}"},
+            "loss": {k: round(v, 4) for k, v in losses.items() if k in ("ar_loss", "clip_loss", "loss")},
+            "roofline": {"bound": "mfma", "kernel": args.roofline_site, "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                         "avg_launch_ms": round(avg_ms, 5), "launches": site_n, "flops_per_launch": site_flops},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(batch_cpu, up_cpu, args.cpu_mols)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -73,17 +73,19 @@ __device__ __forceinline__ uint4 pack8(const float* v) {
 }
 
 // ---- activations (fp32 math) --------------------------------------------------------------------
-// NewGELU, tanh form (reference basic_transformer.py:12-28)
+// NewGELU, tanh form (reference basic_transformer.py:12-28).  tanh(u) = 1 - 2/(1 + exp(2u)) on the hardware exp unit
+// (v_exp_f32); absolute error < 2e-7, saturates cleanly for |u| large (exp -> inf => 1, exp -> 0 => -1).
+__device__ __forceinline__ float fast_tanh(float u) { return 1.0f - 2.0f / (1.0f + __expf(2.0f * u)); }
 __device__ __forceinline__ float gelu_f(float x) {
   const float k = 0.7978845608028654f;  // sqrt(2/pi)
   float u = k * (x + 0.044715f * x * x * x);
-  return 0.5f * x * (1.0f + tanhf(u));
+  return 0.5f * x * (1.0f + fast_tanh(u));
 }
 __device__ __forceinline__ float dgelu_f(float x) {
   const float k = 0.7978845608028654f;
   float x2 = x * x;
   float u = k * (x + 0.044715f * x * x2);
-  float t = tanhf(u);
+  float t = fast_tanh(u);
   float du = k * (1.0f + 3.0f * 0.044715f * x2);
   return 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * du;
 }

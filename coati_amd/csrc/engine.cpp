@@ -121,7 +121,9 @@ struct coati_engine {
   bf16_t *g_hfin16, *g_dpre, *g_td;
   float *g_mask, *g_d2, *g_w, *g_o, *g_o2;
   // backward scratch
-  float *DX, *dcliptok, *dptok, *dstok, *dsa, *dsb, *dhe, *dhs, *dhs_ln, *dhstop, *dhp_ln, *dhpoint;
+  float *DX;
+  bf16_t *DX16, *g_DO16;
+  float *dcliptok, *dptok, *dstok, *dsa, *dsb, *dhe, *dhs, *dhs_ln, *dhstop, *dhp_ln, *dhpoint;
   bf16_t *dh4, *da, *dyb, *dqkv;
   float *g_DH, *g_DO;
   bf16_t *g_do2, *g_dtd, *g_du, *g_dmi, *g_ds2, *g_dpre1, *g_dP;
@@ -339,6 +341,8 @@ size_t carve(coati_engine* e, Arena& ar, int B, int T1, int T2, int A, int Bg) {
   e->g_o = ar.take<float>(BA * H); e->g_o2 = ar.take<float>(BA * H);
   // backward scratch
   e->DX = ar.take<float>(Mmax * C);
+  e->DX16 = ar.take<bf16_t>(Mmax * C);
+  e->g_DO16 = ar.take<bf16_t>(BA * H);
   e->dh4 = ar.take<bf16_t>(Mmax * 4 * C); e->da = ar.take<bf16_t>(Mmax * C); e->dyb = ar.take<bf16_t>(Mmax * C);
   e->dqkv = ar.take<bf16_t>(Mmax * 3 * C);
   e->dcliptok = ar.take<float>((size_t)B * E); e->dptok = ar.take<float>((size_t)B * E); e->dstok = ar.take<float>((size_t)B * E);
@@ -392,23 +396,23 @@ int xformer_bwd(coati_engine* e, XPass& p, const void* dyf, int dyf_f32, float* 
   float* DX = e->DX;
   {
     ProfScope ps(e, SITE_LN_BWD, 0, s);
-    COATI_TRY(launch_layernorm_bwd(dyf, dyf_f32, C, p.x[L], C, 0, p.meanf, p.rstdf, e->P + e->lnfw, nullptr, DX, e->G + e->lnfw, e->G + e->lnfb, M, C, s));
+    COATI_TRY(launch_layernorm_bwd(dyf, dyf_f32, C, p.x[L], C, 0, p.meanf, p.rstdf, e->P + e->lnfw, nullptr, DX, e->DX16, e->G + e->lnfw, e->G + e->lnfb, M, C, s));
   }
   for (int l = L - 1; l >= 0; --l) {
     const XLayerP& w = e->xl[l];
     // x[l+1] = xmid + g W2^T + b2
-    COATI_TRY(gemm(e, SITE_FC2_DGRAD, DX, 1, C, e->S + w.fc2T, C, M, 4 * C, C, e->dh4, 4 * C, nullptr, EPI_DGELU, p.hpre[l], nullptr, 4 * C, s));
-    COATI_TRY(wgrad(e, SITE_XF_WGRAD, DX, 1, C, p.g[l], 4 * C, M, C, 4 * C, e->G + w.fc2w, 4 * C, e->G + w.fc2b, 0, s));
+    COATI_TRY(gemm(e, SITE_FC2_DGRAD, e->DX16, 0, C, e->S + w.fc2T, C, M, 4 * C, C, e->dh4, 4 * C, nullptr, EPI_DGELU, p.hpre[l], nullptr, 4 * C, s));
+    COATI_TRY(wgrad(e, SITE_XF_WGRAD, e->DX16, 0, C, p.g[l], 4 * C, M, C, 4 * C, e->G + w.fc2w, 4 * C, e->G + w.fc2b, 0, s));
     // hpre = a2 W1^T + b1
     COATI_TRY(gemm(e, SITE_FC1_DGRAD, e->dh4, 0, 4 * C, e->S + w.fc1T, 4 * C, M, C, 4 * C, e->da, C, nullptr, EPI_BF16, nullptr, nullptr, 0, s));
     COATI_TRY(wgrad(e, SITE_XF_WGRAD, e->dh4, 0, 4 * C, p.a2[l], C, M, 4 * C, C, e->G + w.fc1w, C, e->G + w.fc1b, 0, s));
     {
       ProfScope ps(e, SITE_LN_BWD, 0, s);
-      COATI_TRY(launch_layernorm_bwd(e->da, 0, C, p.xmid[l], C, 0, p.mean2[l], p.rstd2[l], e->P + w.ln2w, DX, DX, e->G + w.ln2w, e->G + w.ln2b, M, C, s));
+      COATI_TRY(launch_layernorm_bwd(e->da, 0, C, p.xmid[l], C, 0, p.mean2[l], p.rstd2[l], e->P + w.ln2w, DX, DX, e->DX16, e->G + w.ln2w, e->G + w.ln2b, M, C, s));
     }
     // xmid = x[l] + y Wp^T + bp
-    COATI_TRY(gemm(e, SITE_PROJ_DGRAD, DX, 1, C, e->S + w.projT, C, M, C, C, e->dyb, C, nullptr, EPI_BF16, nullptr, nullptr, 0, s));
-    COATI_TRY(wgrad(e, SITE_XF_WGRAD, DX, 1, C, p.y[l], C, M, C, C, e->G + w.projw, C, e->G + w.projb, 0, s));
+    COATI_TRY(gemm(e, SITE_PROJ_DGRAD, e->DX16, 0, C, e->S + w.projT, C, M, C, C, e->dyb, C, nullptr, EPI_BF16, nullptr, nullptr, 0, s));
+    COATI_TRY(wgrad(e, SITE_XF_WGRAD, e->DX16, 0, C, p.y[l], C, M, C, C, e->G + w.projw, C, e->G + w.projb, 0, s));
     {
       ProfScope ps(e, SITE_ATTN_BWD, 10.0 * p.B * (double)p.T * p.T * C, s);
       COATI_TRY(launch_attn_bwd(p.qkv[l], p.y[l], e->dyb, p.lse[l], e->dqkv, e->cos_t, e->sin_t, p.B, p.T, c.n_head, s));
@@ -417,7 +421,7 @@ int xformer_bwd(coati_engine* e, XPass& p, const void* dyf, int dyf_f32, float* 
     COATI_TRY(wgrad(e, SITE_XF_WGRAD, e->dqkv, 0, 3 * C, p.a1[l], C, M, 3 * C, C, e->G + w.attnw, C, e->G + w.attnb, 0, s));
     {
       ProfScope ps(e, SITE_LN_BWD, 0, s);
-      COATI_TRY(launch_layernorm_bwd(e->da, 0, C, p.x[l], C, 0, p.mean1[l], p.rstd1[l], e->P + w.ln1w, DX, DX, e->G + w.ln1w, e->G + w.ln1b, M, C, s));
+      COATI_TRY(launch_layernorm_bwd(e->da, 0, C, p.x[l], C, 0, p.mean1[l], p.rstd1[l], e->P + w.ln1w, DX, DX, e->DX16, e->G + w.ln1w, e->G + w.ln1b, M, C, s));
     }
   }
   ProfScope ps(e, SITE_EMBED, 0, s);
@@ -476,11 +480,11 @@ int gnn_bwd(coati_engine* e, const float* dhpoint, hipStream_t s) {
     const GLayerP& w = e->gl[l];
     {
       ProfScope ps(e, SITE_GNN_ELEMWISE, 0, s);
-      COATI_TRY(launch_layernorm_bwd(DH, 1, H, e->g_h32[l + 1], H, 1, nullptr, e->g_rstd[l + 1], nullptr, nullptr, DO, nullptr, nullptr, BA, H, s));
+      COATI_TRY(launch_layernorm_bwd(DH, 1, H, e->g_h32[l + 1], H, 1, nullptr, e->g_rstd[l + 1], nullptr, nullptr, DO, e->g_DO16, nullptr, nullptr, BA, H, s));
     }
     // o = h + t W4^T + b4
-    COATI_TRY(gemm(e, SITE_GNN_NODE_GEMM, DO, 1, H, e->S + w.n3T, H, BA, H, H, e->g_du, H, nullptr, EPI_DSILU, e->g_upre[l], nullptr, H, s));
-    COATI_TRY(wgrad(e, SITE_GNN_WGRAD, DO, 1, H, e->g_t[l], H, BA, H, H, e->G + w.n3w, H, e->G + w.n3b, 0, s));
+    COATI_TRY(gemm(e, SITE_GNN_NODE_GEMM, e->g_DO16, 0, H, e->S + w.n3T, H, BA, H, H, e->g_du, H, nullptr, EPI_DSILU, e->g_upre[l], nullptr, H, s));
+    COATI_TRY(wgrad(e, SITE_GNN_WGRAD, e->g_DO16, 0, H, e->g_t[l], H, BA, H, H, e->G + w.n3w, H, e->G + w.n3b, 0, s));
     // u = [h | mi] W3^T + b3 ; W3T is [2H rows][H]
     COATI_TRY(gemm(e, SITE_GNN_NODE_GEMM, e->g_du, 0, H, e->S + w.n0T, H, BA, H, H, DO, H, nullptr, EPI_ACC_F32, nullptr, nullptr, 0, s));
     COATI_TRY(gemm(e, SITE_GNN_NODE_GEMM, e->g_du, 0, H, e->S + w.n0T + (int64_t)H * H, H, BA, H, H, e->g_dmi, H, nullptr, EPI_BF16, nullptr, nullptr, 0, s));
@@ -510,7 +514,7 @@ int gnn_bwd(coati_engine* e, const float* dhpoint, hipStream_t s) {
   }
   {
     ProfScope ps(e, SITE_GNN_ELEMWISE, 0, s);
-    COATI_TRY(launch_layernorm_bwd(DH, 1, H, e->g_h32[0], H, 1, nullptr, e->g_rstd[0], nullptr, nullptr, DO, nullptr, nullptr, BA, H, s));
+    COATI_TRY(launch_layernorm_bwd(DH, 1, H, e->g_h32[0], H, 1, nullptr, e->g_rstd[0], nullptr, nullptr, DO, nullptr, nullptr, nullptr, BA, H, s));
     COATI_TRY(launch_gnn_embed_bwd(e->atoms, e->lut_ix, e->lut_iy, DO, e->G + e->gembw, e->G + e->gembb, BA, H, s));
   }
   return COATI_OK;
@@ -758,9 +762,9 @@ int coati_engine_backward(coati_engine* e, const float* dh_smiles, const float* 
     COATI_TRY(launch_silu_bwd(e->h_smiles, e->dsb, e->dhs, (long long)B * E, 1, s));
     // smiles_to_clip / point_to_clip: Linear then LayerNorm backward
     COATI_TRY(head_linear_bwd(e, e->dhs, e->hs_ln, e->s2c_w, e->s2c_b, e->dhs_ln, B, E, C, s));
-    COATI_TRY(launch_layernorm_bwd(e->dhs_ln, 1, C, e->hstop, C, 0, e->hs_mean, e->hs_rstd, e->P + e->s2c_lnw, nullptr, e->dhstop, e->G + e->s2c_lnw, e->G + e->s2c_lnb, B, C, s));
+    COATI_TRY(launch_layernorm_bwd(e->dhs_ln, 1, C, e->hstop, C, 0, e->hs_mean, e->hs_rstd, e->P + e->s2c_lnw, nullptr, e->dhstop, nullptr, e->G + e->s2c_lnw, e->G + e->s2c_lnb, B, C, s));
     COATI_TRY(head_linear_bwd(e, e->dhe, e->hp_ln, e->p2c_w, e->p2c_b, e->dhp_ln, B, E, H, s));
-    COATI_TRY(launch_layernorm_bwd(e->dhp_ln, 1, H, e->hpoint, H, 0, e->hp_mean, e->hp_rstd, e->P + e->p2c_lnw, nullptr, e->dhpoint, e->G + e->p2c_lnw, e->G + e->p2c_lnb, B, H, s));
+    COATI_TRY(launch_layernorm_bwd(e->dhp_ln, 1, H, e->hpoint, H, 0, e->hp_mean, e->hp_rstd, e->P + e->p2c_lnw, nullptr, e->dhpoint, nullptr, e->G + e->p2c_lnw, e->G + e->p2c_lnb, B, H, s));
   }
   if (stage == 0 || stage == 2) {
     // ---- encoder pass: gradient enters at the [STOP] rows of ln_f's output ----

@@ -36,7 +36,9 @@ __device__ __forceinline__ void stage_load(StageB16& s, const bf16_t* base, long
   for (int i = 0; i < 4; ++i) {
     const int c = tid + 256 * i, row = c >> 3, kc = (c & 7) * 8;
     const int g = row0 + row;
-    s.v[i] = (g < rows) ? *reinterpret_cast<const uint4*>(base + (long long)g * ld + k0 + kc) : make_uint4(0, 0, 0, 0);
+    const int gc = g < rows ? g : rows - 1;   // always a valid address; out-of-range rows are zeroed by select
+    const uint4 t = *reinterpret_cast<const uint4*>(base + (long long)gc * ld + k0 + kc);
+    s.v[i] = (g < rows) ? t : make_uint4(0, 0, 0, 0);
   }
 }
 __device__ __forceinline__ void stage_store(const StageB16& s, bf16_t* S, int tid) {
@@ -52,8 +54,9 @@ __device__ __forceinline__ void stage_load(StageF32& s, const float* base, long 
   for (int i = 0; i < 8; ++i) {
     const int c = tid + 256 * i, row = c >> 4, kc = (c & 15) * 4;
     const int g = row0 + row;
-    s.v[i] = (g < rows) ? *reinterpret_cast<const float4*>(base + (long long)g * ld + k0 + kc)
-                        : make_float4(0.f, 0.f, 0.f, 0.f);
+    const int gc = g < rows ? g : rows - 1;
+    const float4 t = *reinterpret_cast<const float4*>(base + (long long)gc * ld + k0 + kc);
+    s.v[i] = (g < rows) ? t : make_float4(0.f, 0.f, 0.f, 0.f);
   }
 }
 __device__ __forceinline__ void stage_store(const StageF32& s, bf16_t* S, int tid) {
@@ -97,9 +100,13 @@ __device__ __forceinline__ void epilogue8(const GemmArgs& p, int row, int col0, 
                                           int tile_n, int tiles_n) {
   const int N = p.N;
   if (p.bias != nullptr) {
-#pragma unroll
-    for (int e = 0; e < 8; ++e)
-      if (col0 + e < N) v[e] += p.bias[col0 + e];
+    if (col0 + 8 <= N) {
+      const float4 b0 = *reinterpret_cast<const float4*>(p.bias + col0), b1 = *reinterpret_cast<const float4*>(p.bias + col0 + 4);
+      v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+    } else {
+      for (int e = 0; e < 8; ++e)
+        if (col0 + e < N) v[e] += p.bias[col0 + e];
+    }
   }
   if (EPI == EPI_CE_PARTIAL) {
     // every lane of the 16-lane group that shares this row takes part in the shuffles
@@ -250,25 +257,67 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int nk = p.K / BK;
-  STAGE_A sa;
-  StageB16 sb;
-  stage_load(sa, A, p.lda, m0, p.M, 0, tid);
-  stage_load(sb, p.B, p.ldb, n0, p.N, 0, tid);
-  stage_store(sa, lds, tid);
-  stage_store(sb, lds + 2 * TILE_HALFS, tid);
-  __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) {
-      stage_load(sa, A, p.lda, m0, p.M, (kt + 1) * BK, tid);
-      stage_load(sb, p.B, p.ldb, n0, p.N, (kt + 1) * BK, tid);
+  if constexpr (sizeof(AT) == 2) {
+  // Two register stage sets -> two k-tiles of global loads in flight per workgroup (prefetch distance 2): with K = 256
+    // (4 k-tiles) the MFMA work per tile (~0.2 us) is far shorter than the memory latency it has to cover.
+    STAGE_A sa0, sa1;
+    StageB16 sb0, sb1;
+    stage_load(sa0, A, p.lda, m0, p.M, 0, tid);
+    stage_load(sb0, p.B, p.ldb, n0, p.N, 0, tid);
+    if (nk > 1) {
+      stage_load(sa1, A, p.lda, m0, p.M, BK, tid);
+      stage_load(sb1, p.B, p.ldb, n0, p.N, BK, tid);
     }
-    mma_ktile(lds + cur * TILE_HALFS, lds + (2 + cur) * TILE_HALFS, wm, wn, lane, acc);
-    if (kt + 1 < nk) {
-      stage_store(sa, lds + (cur ^ 1) * TILE_HALFS, tid);
-      stage_store(sb, lds + (2 + (cur ^ 1)) * TILE_HALFS, tid);
-    }
+    stage_store(sa0, lds, tid);
+    stage_store(sb0, lds + 2 * TILE_HALFS, tid);
     __syncthreads();
+    for (int kt = 0; kt < nk; kt += 2) {
+      // even tile kt lives in LDS buffer 0; set 0 is free again
+      if (kt + 2 < nk) {
+        stage_load(sa0, A, p.lda, m0, p.M, (kt + 2) * BK, tid);
+        stage_load(sb0, p.B, p.ldb, n0, p.N, (kt + 2) * BK, tid);
+      }
+      mma_ktile(lds, lds + 2 * TILE_HALFS, wm, wn, lane, acc);
+      if (kt + 1 < nk) {
+        stage_store(sa1, lds + TILE_HALFS, tid);
+        stage_store(sb1, lds + 3 * TILE_HALFS, tid);
+      }
+      __syncthreads();
+      if (kt + 1 >= nk) break;
+      // odd tile kt+1 lives in LDS buffer 1; set 1 is free again
+      if (kt + 3 < nk) {
+        stage_load(sa1, A, p.lda, m0, p.M, (kt + 3) * BK, tid);
+        stage_load(sb1, p.B, p.ldb, n0, p.N, (kt + 3) * BK, tid);
+      }
+      mma_ktile(lds + TILE_HALFS, lds + 3 * TILE_HALFS, wm, wn, lane, acc);
+      if (kt + 2 < nk) {
+        stage_store(sa0, lds, tid);
+        stage_store(sb0, lds + 2 * TILE_HALFS, tid);
+      }
+      __syncthreads();
+    }
+  } else {
+    // f32 A: the staging registers of a second set do not fit; plain distance-1 prefetch
+    STAGE_A sa;
+    StageB16 sb;
+    stage_load(sa, A, p.lda, m0, p.M, 0, tid);
+    stage_load(sb, p.B, p.ldb, n0, p.N, 0, tid);
+    stage_store(sa, lds, tid);
+    stage_store(sb, lds + 2 * TILE_HALFS, tid);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+      const int cur = kt & 1;
+      if (kt + 1 < nk) {
+        stage_load(sa, A, p.lda, m0, p.M, (kt + 1) * BK, tid);
+        stage_load(sb, p.B, p.ldb, n0, p.N, (kt + 1) * BK, tid);
+      }
+      mma_ktile(lds + cur * TILE_HALFS, lds + (2 + cur) * TILE_HALFS, wm, wn, lane, acc);
+      if (kt + 1 < nk) {
+        stage_store(sa, lds + (cur ^ 1) * TILE_HALFS, tid);
+        stage_store(sb, lds + (2 + (cur ^ 1)) * TILE_HALFS, tid);
+      }
+      __syncthreads();
+    }
   }
 
   // accumulators -> LDS (fp32) -> row-contiguous epilogue
@@ -281,7 +330,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
       for (int r = 0; r < 16; ++r)
         Cs[(wm * 64 + i * 32 + frag_row(r, lane)) * CPITCH + wn * 64 + j * 32 + (lane & 31)] = acc[i][j][r];
   __syncthreads();
-#pragma unroll 1
+#pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int task = tid + 256 * i, r = task >> 4, cg = task & 15;
     float v[8];
@@ -354,104 +403,111 @@ int launch_gemm_nt(const GemmArgs& a, int a_f32, int epi, hipStream_t s) {
 
 // =================================================================================================
 // wgrad: dW[N,K] += A[M,N]^T * B[M,K]
-// The reduction runs over m, which is the strided dimension of both operands, so each staged
-// [64 m][128 cols] tile is transposed in registers (4x8 bf16 blocks) on its way into LDS, giving
-// the same [128][PITCH] k-contiguous image the NT kernel uses.  The 8 per-lane 8-byte LDS stores
-// are issued in a lane-rotated order so the 16 lanes of a store group fall on different banks.
+// The reduction runs over m, the strided dimension of both operands.  Tiles are staged ROW-MAJOR ([64 m][128 cols],
+// coalesced 16-B loads and ds_write_b128) and the MFMA fragments are fetched with the gfx950 LDS transpose read
+// ds_read_b64_tr_b16: each 16-lane group passes the addresses of a 4(m) x 16(col) block and every lane receives
+// the 4 m-values of its own column (probed on hardware: tools/probes/tr_probe.hip).  Two such reads give the
+// 8 m-consecutive bf16 a 32x32x16 fragment needs -- no register transposes, no scalar LDS traffic.
+// LDS rows are exactly 256 B; the 64-B chunk index is XOR-swizzled with (row & 3) so the four rows of a
+// transpose read fall on different bank windows.  Two register stage sets keep two m-chunks of loads in flight.
 // =================================================================================================
-struct StageT { uint4 v[4]; };   // 4 m-rows x 8 columns (bf16)
+typedef short v4s16 __attribute__((ext_vector_type(4)));
+#define WT_ROW_BYTES 256
+#define WT_TILE_BYTES (64 * WT_ROW_BYTES)          // one [64 m][128 col] bf16 tile
+#define WGRAD_LDS_BYTES (4 * WT_TILE_BYTES)        // 2 operands x 2 stages = 64 KiB
+
+struct StageW { uint4 v[4]; };   // 4 x (one m-row, 8 columns)
+
+__device__ __forceinline__ unsigned wt_offset(int row, int bytecol) {
+  return (unsigned)(row * WT_ROW_BYTES + ((((bytecol >> 6) ^ (row & 3)) << 6) | (bytecol & 63)));
+}
 
 template <typename AT>
-__device__ __forceinline__ void stage_load_t(StageT& s, const AT* base, long long ld, int m0, int m_end, int c0,
-                                             int ncols, int tid);
-
-template <>
-__device__ __forceinline__ void stage_load_t<bf16_t>(StageT& s, const bf16_t* base, long long ld, int m0, int m_end,
-                                                     int c0, int ncols, int tid) {
-  const int noct = tid & 15, mq = tid >> 4;
-  const int col = c0 + noct * 8;
+__device__ __forceinline__ void wstage_load(StageW& s, const AT* base, long long ld, int m0, int m_end, int c0,
+                                            int ncols, int tid) {
+  const int col = c0 + (tid & 15) * 8;
+  const bool colok = col < ncols;
+  const int colc = colok ? col : 0;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int m = m0 + mq * 4 + r;
-    s.v[r] = (m < m_end && col < ncols) ? *reinterpret_cast<const uint4*>(base + (long long)m * ld + col)
-                                        : make_uint4(0, 0, 0, 0);
-  }
-}
-template <>
-__device__ __forceinline__ void stage_load_t<float>(StageT& s, const float* base, long long ld, int m0, int m_end,
-                                                    int c0, int ncols, int tid) {
-  const int noct = tid & 15, mq = tid >> 4;
-  const int col = c0 + noct * 8;
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int m = m0 + mq * 4 + r;
-    if (m < m_end && col < ncols) {
-      const float4 f0 = *reinterpret_cast<const float4*>(base + (long long)m * ld + col);
-      const float4 f1 = *reinterpret_cast<const float4*>(base + (long long)m * ld + col + 4);
-      s.v[r] = make_uint4(pack2bf(f0.x, f0.y), pack2bf(f0.z, f0.w), pack2bf(f1.x, f1.y), pack2bf(f1.z, f1.w));
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + (tid >> 4) + 16 * i;
+    const int mc = m < m_end ? m : m_end - 1;
+    uint4 t;
+    if constexpr (sizeof(AT) == 2) {
+      t = *reinterpret_cast<const uint4*>(base + (long long)mc * ld + colc);
     } else {
-      s.v[r] = make_uint4(0, 0, 0, 0);
+      const float4 f0 = *reinterpret_cast<const float4*>(base + (long long)mc * ld + colc);
+      const float4 f1 = *reinterpret_cast<const float4*>(base + (long long)mc * ld + colc + 4);
+      t = make_uint4(pack2bf(f0.x, f0.y), pack2bf(f0.z, f0.w), pack2bf(f1.x, f1.y), pack2bf(f1.z, f1.w));
     }
+    s.v[i] = (m < m_end && colok) ? t : make_uint4(0, 0, 0, 0);
+  }
+}
+__device__ __forceinline__ void wstage_store(const StageW& s, unsigned char* T, int tid) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = (tid >> 4) + 16 * i;
+    *reinterpret_cast<uint4*>(T + wt_offset(row, (tid & 15) * 16)) = s.v[i];
+  }
+}
+__device__ __forceinline__ void wstage_colsum(const StageW& s, float (&csum)[8]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float f[8];
+    unpack8(s.v[i], f);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) csum[e] += f[e];
   }
 }
 
-__device__ __forceinline__ unsigned sel_dword(const uint4& u, int d) {
-  return d == 0 ? u.x : (d == 1 ? u.y : (d == 2 ? u.z : u.w));
+// fragment for output rows/cols nbase..nbase+31 and reduction rows mbase..mbase+15 of a row-major tile
+__device__ __forceinline__ bf16x8 tr_frag(const unsigned char* T, int mbase, int nbase, int lane) {
+  const int g = lane >> 4, kg = g >> 1;
+  const int row = mbase + 8 * kg + ((lane & 15) >> 2);
+  const int bytecol = (nbase + 16 * (g & 1) + 4 * (lane & 3)) * 2;
+  typedef __attribute__((address_space(3))) v4s16 lds_v4;
+  const v4s16 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(T + wt_offset(row, bytecol)));
+  const v4s16 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(T + wt_offset(row + 4, bytecol)));
+  typedef short v8s16 __attribute__((ext_vector_type(8)));
+  const v8s16 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8, r);
 }
 
-__device__ __forceinline__ void stage_store_t(const StageT& s, bf16_t* S, int tid) {
-  const int noct = tid & 15, mq = tid >> 4;
-  // out[e] = the 4 m-values of column e: (lo dword: rows 0,1 ; hi dword: rows 2,3)
-  unsigned lo[8], hi[8];
+__device__ __forceinline__ void wmma_chunk(const unsigned char* At, const unsigned char* Bt, int wm, int wn, int lane,
+                                           f32x16 (&acc)[2][2]) {
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const int d = e >> 1;
-    const unsigned x0 = sel_dword(s.v[0], d), x1 = sel_dword(s.v[1], d);
-    const unsigned x2 = sel_dword(s.v[2], d), x3 = sel_dword(s.v[3], d);
-    if (e & 1) {
-      lo[e] = (x0 >> 16) | (x1 & 0xffff0000u);
-      hi[e] = (x2 >> 16) | (x3 & 0xffff0000u);
-    } else {
-      lo[e] = (x0 & 0xffffu) | (x1 << 16);
-      hi[e] = (x2 & 0xffffu) | (x3 << 16);
-    }
-  }
-  // barrel-rotate by (noct & 7) so that slot s holds column (s + noct) & 7
+  for (int ks = 0; ks < 4; ++ks) {
+    bf16x8 a[2], b[2];
 #pragma unroll
-  for (int bit = 0; bit < 3; ++bit) {
-    const int sh = 1 << bit;
-    const bool on = (noct >> bit) & 1;
-    unsigned nlo[8], nhi[8];
+    for (int i = 0; i < 2; ++i) a[i] = tr_frag(At, ks * 16, wm * 64 + i * 32, lane);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      nlo[e] = on ? lo[(e + sh) & 7] : lo[e];
-      nhi[e] = on ? hi[(e + sh) & 7] : hi[e];
-    }
+    for (int j = 0; j < 2; ++j) b[j] = tr_frag(Bt, ks * 16, wn * 64 + j * 32, lane);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { lo[e] = nlo[e]; hi[e] = nhi[e]; }
-  }
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-  for (int sl = 0; sl < 8; ++sl) {
-    const int e = (sl + noct) & 7;
-    *reinterpret_cast<uint2*>(S + (noct * 8 + e) * PITCH + mq * 4) = make_uint2(lo[sl], hi[sl]);
+      for (int j = 0; j < 2; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
   }
 }
 
 template <typename AT, bool BIAS>
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs p, int tiles_k, int chunks_per_split) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  bf16_t* const lds = reinterpret_cast<bf16_t*>(smem);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int tile_n = blockIdx.x / tiles_k, tile_k = blockIdx.x - tile_n * tiles_k;
   const int n0 = tile_n * BM, k0 = tile_k * BN;
-  const int nchunks = (p.M + BK - 1) / BK;
+  const int nchunks = (p.M + 63) / 64;
   const int c_begin = blockIdx.y * chunks_per_split;
   int c_end = c_begin + chunks_per_split;
   if (c_end > nchunks) c_end = nchunks;
   if (c_begin >= c_end) return;
   const AT* A = reinterpret_cast<const AT*>(p.A);
   const int nout = p.n_out > 0 ? p.n_out : p.N;
+  unsigned char* const At0 = smem;
+  unsigned char* const At1 = smem + WT_TILE_BYTES;
+  unsigned char* const Bt0 = smem + 2 * WT_TILE_BYTES;
+  unsigned char* const Bt1 = smem + 3 * WT_TILE_BYTES;
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -465,41 +521,39 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs p, int tiles_k,
   for (int e = 0; e < 8; ++e) csum[e] = 0.f;
   const bool do_bias = BIAS && (tile_k == 0);
 
-  StageT sa, sb;
-  stage_load_t<AT>(sa, A, p.lda, c_begin * BK, p.M, n0, p.N, tid);
-  stage_load_t<bf16_t>(sb, p.B, p.ldb, c_begin * BK, p.M, k0, p.K, tid);
-  if (do_bias) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      float f[8];
-      unpack8(sa.v[r], f);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) csum[e] += f[e];
-    }
+  StageW sa0, sb0, sa1, sb1;
+  wstage_load<AT>(sa0, A, p.lda, c_begin * 64, p.M, n0, p.N, tid);
+  wstage_load<bf16_t>(sb0, p.B, p.ldb, c_begin * 64, p.M, k0, p.K, tid);
+  if (c_begin + 1 < c_end) {
+    wstage_load<AT>(sa1, A, p.lda, (c_begin + 1) * 64, p.M, n0, p.N, tid);
+    wstage_load<bf16_t>(sb1, p.B, p.ldb, (c_begin + 1) * 64, p.M, k0, p.K, tid);
   }
-  stage_store_t(sa, lds, tid);
-  stage_store_t(sb, lds + 2 * TILE_HALFS, tid);
+  if (do_bias) wstage_colsum(sa0, csum);
+  wstage_store(sa0, At0, tid);
+  wstage_store(sb0, Bt0, tid);
   __syncthreads();
-  for (int c = c_begin; c < c_end; ++c) {
-    const int cur = (c - c_begin) & 1;
-    const bool more = (c + 1 < c_end);
-    if (more) {
-      stage_load_t<AT>(sa, A, p.lda, (c + 1) * BK, p.M, n0, p.N, tid);
-      stage_load_t<bf16_t>(sb, p.B, p.ldb, (c + 1) * BK, p.M, k0, p.K, tid);
+  for (int c = c_begin; c < c_end; c += 2) {
+    if (c + 2 < c_end) {
+      wstage_load<AT>(sa0, A, p.lda, (c + 2) * 64, p.M, n0, p.N, tid);
+      wstage_load<bf16_t>(sb0, p.B, p.ldb, (c + 2) * 64, p.M, k0, p.K, tid);
     }
-    mma_ktile(lds + cur * TILE_HALFS, lds + (2 + cur) * TILE_HALFS, wm, wn, lane, acc);
-    if (more) {
-      if (do_bias) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float f[8];
-          unpack8(sa.v[r], f);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) csum[e] += f[e];
-        }
-      }
-      stage_store_t(sa, lds + (cur ^ 1) * TILE_HALFS, tid);
-      stage_store_t(sb, lds + (2 + (cur ^ 1)) * TILE_HALFS, tid);
+    wmma_chunk(At0, Bt0, wm, wn, lane, acc);
+    if (c + 1 < c_end) {
+      if (do_bias) wstage_colsum(sa1, csum);
+      wstage_store(sa1, At1, tid);
+      wstage_store(sb1, Bt1, tid);
+    }
+    __syncthreads();
+    if (c + 1 >= c_end) break;
+    if (c + 3 < c_end) {
+      wstage_load<AT>(sa1, A, p.lda, (c + 3) * 64, p.M, n0, p.N, tid);
+      wstage_load<bf16_t>(sb1, p.B, p.ldb, (c + 3) * 64, p.M, k0, p.K, tid);
+    }
+    wmma_chunk(At1, Bt1, wm, wn, lane, acc);
+    if (c + 2 < c_end) {
+      if (do_bias) wstage_colsum(sa0, csum);
+      wstage_store(sa0, At0, tid);
+      wstage_store(sb0, Bt0, tid);
     }
     __syncthreads();
   }
@@ -516,8 +570,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs p, int tiles_k,
       }
 
   if (do_bias) {
-    // reduce the 16 m-quads that share a column octet, then one atomic per column
-    float* red = reinterpret_cast<float*>(smem);  // [16 mq][128 cols]
+    // reduce the 16 row-groups that share a column octet, then one atomic per column
+    float* red = reinterpret_cast<float*>(smem);  // [16][128]
     const int noct = tid & 15, mq = tid >> 4;
 #pragma unroll
     for (int e = 0; e < 8; ++e) red[mq * 128 + noct * 8 + e] = csum[e];
@@ -537,7 +591,7 @@ static int launch_wgrad_t(const WgradArgs& a, hipStream_t s) {
   auto kern = wgrad_kernel<AT, BIAS>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       GEMM_LDS_BYTES);
+                                       WGRAD_LDS_BYTES);
     if (e != hipSuccess) {
       coati_set_error("wgrad: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
       return COATI_EHIP;
@@ -546,14 +600,14 @@ static int launch_wgrad_t(const WgradArgs& a, hipStream_t s) {
   }
   const int tiles_n = cdiv(a.N, BM), tiles_k = cdiv(a.K, BN);
   const int tiles = tiles_n * tiles_k;
-  const int nchunks = cdiv(a.M, BK);
+  const int nchunks = cdiv(a.M, 64);
   // ~2 workgroups per CU over the whole launch; every split keeps >= 8 chunks (512 rows) of work
   int splits = cdiv(512, tiles);
   if (splits > cdiv(nchunks, 8)) splits = cdiv(nchunks, 8);
   if (splits < 1) splits = 1;
   const int cps = cdiv(nchunks, splits);
   splits = cdiv(nchunks, cps);
-  hipLaunchKernelGGL(kern, dim3(tiles, splits), dim3(256), GEMM_LDS_BYTES, s, a, tiles_k, cps);
+  hipLaunchKernelGGL(kern, dim3(tiles, splits), dim3(256), WGRAD_LDS_BYTES, s, a, tiles_k, cps);
   COATI_LAUNCH_CHECK("wgrad");
   return COATI_OK;
 }

@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
                                                      const float* __restrict__ x, long long ldx, int x_is_xhat,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ gamma, const float* dres, float* dx,
-                                                     float* __restrict__ dgamma, float* __restrict__ dbeta, int M,
+                                                     bf16_t* __restrict__ dx16, float* __restrict__ dgamma, float* __restrict__ dbeta, int M,
                                                      int C) {
   __shared__ float red[2][4][NCH * 256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -129,6 +129,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
           o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
         }
         *reinterpret_cast<float4*>(dx + (long long)row * C + idx) = o;
+        if (dx16) *reinterpret_cast<uint2*>(dx16 + (long long)row * C + idx) = make_uint2(pack2bf(o.x, o.y), pack2bf(o.z, o.w));
         ag[j].x += dyv[j].x * xh[j].x; ag[j].y += dyv[j].y * xh[j].y; ag[j].z += dyv[j].z * xh[j].z; ag[j].w += dyv[j].w * xh[j].w;
         ab[j].x += dyv[j].x; ab[j].y += dyv[j].y; ab[j].z += dyv[j].z; ab[j].w += dyv[j].w;
       }
@@ -152,7 +153,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
 
 int launch_layernorm_bwd(const void* dy, int dy_f32, long long lddy, const float* x, long long ldx, int x_is_xhat,
                          const float* mean, const float* rstd, const float* gamma, const float* dres,
-                         float* dx, float* dgamma, float* dbeta, int M, int C, hipStream_t s) {
+                         float* dx, bf16_t* dx16, float* dgamma, float* dbeta, int M, int C, hipStream_t s) {
   COATI_CHECK_ARG(dy && x && rstd && dx, "layernorm_bwd: null operand");
   COATI_CHECK_ARG(x_is_xhat || mean, "layernorm_bwd: mean required unless x holds xhat");
   COATI_CHECK_ARG((dgamma == nullptr) == (dbeta == nullptr), "layernorm_bwd: dgamma/dbeta must both be given or both null");
@@ -162,7 +163,7 @@ int launch_layernorm_bwd(const void* dy, int dy_f32, long long lddy, const float
   int blocks = cdiv(M, 4);
   if (blocks > 2048) blocks = 2048;
   dim3 grid(blocks), block(256);
-#define LN_B(N, F) hipLaunchKernelGGL((ln_bwd_kernel<N, F>), grid, block, 0, s, dy, lddy, x, ldx, x_is_xhat, mean, rstd, gamma, dres, dx, dgamma, dbeta, M, C)
+#define LN_B(N, F) hipLaunchKernelGGL((ln_bwd_kernel<N, F>), grid, block, 0, s, dy, lddy, x, ldx, x_is_xhat, mean, rstd, gamma, dres, dx, dx16, dgamma, dbeta, M, C)
   if (dy_f32) {
     if (nch == 1) LN_B(1, true); else if (nch == 2) LN_B(2, true); else if (nch == 3) LN_B(3, true); else LN_B(4, true);
   } else {

@@ -1,0 +1,83 @@
+"""Data-parallel step over the GPUs of one node: one process per GPU, torch.distributed with backend "nccl"
+(= RCCL over xGMI on ROCm).
+
+Exchange steps of the path (reference train_coati.py:256-258, autograd_funs.py:5-25, and the DDP wrap at :204):
+  1. all-gather of h_smiles / h_e3gnn / bad_rows so InfoNCE negatives span the global batch;
+  2. each rank evaluates only its B local rows x Bg global columns of the two logit matrices (the reference
+     computes the full Bg x Bg on every rank) and produces partial gradients for all Bg embeddings;
+  3. reduce-scatter(sum) of those partials (what AllGatherFunction.backward does);
+  4. bucketed gradient all-reduce (mean) over the flat fp32 gradient buffer, launched stage by stage so the
+     transfers run on RCCL's stream underneath the remaining backward kernels.
+The reference calls model.module.forward_dist and therefore never arms DDP's reducer: it does
+not average parameter gradients.  This implements the intended semantics."""
+import torch
+import torch.distributed as dist
+
+
+def all_gather_cat(t: torch.Tensor) -> torch.Tensor:
+    """rank-major concatenation along dim 0 (autograd_funs.py:10-12)."""
+    W = dist.get_world_size()
+    out = torch.empty((W * t.shape[0],) + tuple(t.shape[1:]), device=t.device, dtype=t.dtype)
+    dist.all_gather_into_tensor(out, t.contiguous())
+    return out
+
+
+def reduce_scatter_sum(t_all: torch.Tensor) -> torch.Tensor:
+    """sum over ranks of the rank's own row block (autograd_funs.py:18-21, fp32)."""
+    W = dist.get_world_size()
+    out = torch.empty((t_all.shape[0] // W,) + tuple(t_all.shape[1:]), device=t_all.device, dtype=t_all.dtype)
+    dist.reduce_scatter_tensor(out, t_all.contiguous(), op=dist.ReduceOp.SUM)
+    return out
+
+
+def grad_buckets(eng):
+    """(name, start, end) element ranges of the flat gradient buffer, by the backward stage that completes them."""
+    lay = eng.layout
+    lm0 = lay["xformer.lm_head.weight"][0]
+    pe0 = lay["point_encoder.embedding.weight"][0]
+    hd0 = lay["point_to_clip.0.weight"][0]
+    return {"xformer": (0, lm0), "lm_head": (lm0, pe0), "gnn": (pe0, hd0), "heads": (hd0, eng.n_params)}
+
+
+def distributed_train_step(eng, batch, use_point, lr, do_clip=True, optimizer=True):
+    """do_minibatch at world_size > 1.  Returns (h_e3gnn, h_smiles, bad_rows) of the local rows."""
+    W, rank = dist.get_world_size(), dist.get_rank()
+    h_e, h_s, bad = eng.forward(batch["raw_tokens"], batch["tokens"], batch["atoms"], batch["coords"], use_point,
+                                y_next=batch["y_next"], train=True)
+    B = h_e.shape[0]
+    dS = dC = None
+    if do_clip:
+        s_all, c_all, bad_all = all_gather_cat(h_s), all_gather_cat(h_e), all_gather_cat(bad)
+        # every rank's encoders receive W * d(global clip)/d(h_local); the mean all-reduce below divides by W
+        dS_all, dC_all = eng.infonce(h_s, h_e, s_all, c_all, bad_all, row0=rank * B,
+                                     gscale=0.5 * eng.token_entropy_unit() * W)
+        dS, dC = reduce_scatter_sum(dS_all), reduce_scatter_sum(dC_all)
+    bk = grad_buckets(eng)
+    works = []
+
+    def launch(name):
+        a, b = bk[name]
+        works.append(dist.all_reduce(eng.grads[a:b], op=dist.ReduceOp.AVG, async_op=True))
+
+    eng.backward(dS, dC, stage=1)
+    launch("lm_head"); launch("heads")
+    eng.backward(None, None, stage=2)
+    launch("xformer")
+    eng.backward(None, None, stage=3)
+    launch("gnn")
+    for w in works:
+        w.wait()
+    if optimizer:
+        eng.optimizer_step(lr)
+    return h_e, h_s, bad
+
+
+def global_losses(eng):
+    """all-reduced loss scalars (every rank must call this)."""
+    s = eng.scal.clone()
+    dist.all_reduce(s[:4], op=dist.ReduceOp.SUM)
+    s = s.cpu()
+    ar = float(s[0] / s[1]) if s[1] > 0 else 0.0
+    nv = float(s[4])
+    clip = float(0.5 * (s[2] + s[3]) / nv) if nv > 0 else 0.0
+    return {"ar_loss": ar, "clip_loss": clip, "loss": ar + clip * eng.token_entropy_unit()}

@@ -80,13 +80,14 @@ int coati_wgrad(const void* A, int a_f32, int64_t lda, const uint16_t* B, int64_
 int coati_sgemm(const float* A, int64_t ars, int64_t acs, const float* B, int64_t brs, int64_t bcs, float* C,
                 int64_t ldc, int M, int N, int K, const float* bias, float alpha, int accumulate, void* stream);
 
-/* nn.LayerNorm(C) / InstanceNorm1d applied over the hidden dim (gamma = beta = NULL), eps 1e-5. */
+/* nn.LayerNorm(C) / InstanceNorm1d applied over the hidden dim (gamma = beta = NULL), eps 1e-5.
+ * backward: dx (f32, = dres + LN'(dy)) and optionally dx16, the same values rounded to bf16 for the next GEMMs. */
 int coati_layernorm_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, uint16_t* y16,
                         int64_t ld16, float* y32, int64_t ld32, float* mean, float* rstd, int M, int C,
                         void* stream);
 int coati_layernorm_bwd(const void* dy, int dy_f32, int64_t lddy, const float* x, int64_t ldx, int x_is_xhat,
                         const float* mean, const float* rstd, const float* gamma, const float* dres, float* dx,
-                        float* dgamma, float* dbeta, int M, int C, void* stream);
+                        uint16_t* dx16, float* dgamma, float* dbeta, int M, int C, void* stream);
 
 /* RotarySelfAttention core (basic_transformer.py:126-150) for head size 16: RoPE(q,k), causal softmax(q k^T/4) v.
  * qkv [B*T, 3*nh*16] bf16, y [B*T, nh*16] bf16, lse [B, nh, T] f32, cos/sin [n_seq, 16] f32 (RotaryEmbedding

@@ -122,14 +122,16 @@ def test_three_step_loss_curve(setup, golden_dir):
     check("grad norm step0", torch.tensor([norms[0]]), vec["step_gradnorm"].reshape(1), 3e-2)
     A3 = np.load(os.path.join(golden_dir, "small_model_after3.npz"))
     sd = eng.state_dict()
-    # 3 AdamW steps at lr 5e-4 move each weight by <= ~1.5e-3; compare the DISPLACEMENT against the reference's
+    # 3 AdamW steps at lr 5e-4 move each weight by <= ~1.5e-3.  Adam's first steps are sign-like (m/sqrt(v) ~ +-1), so an
+    # element whose gradient is near zero can flip direction under bf16 noise; compare the DISPLACEMENT direction per tensor.
     for k in sorted(eng.layout):
-        d_hip = sd[k].cpu() - P[k]
-        d_ref = torch.from_numpy(A3[k]) - P[k]
-        denom = max(float(d_ref.abs().max()), 1e-12)
-        e = float((d_hip - d_ref).abs().max()) / denom
-        log(f"adamw displacement {k:55s} relerr {e:.3e}")
-        assert e < 0.6 or "coord_mlp" in k, (k, e)
+        if "coord_mlp" in k:
+            continue
+        d_hip = (sd[k].cpu() - P[k]).flatten().double()
+        d_ref = (torch.from_numpy(A3[k]) - P[k]).flatten().double()
+        cos = float((d_hip @ d_ref) / (d_hip.norm() * d_ref.norm() + 1e-30))
+        log(f"adamw displacement {k:55s} cosine {cos:.4f}")
+        assert cos > 0.9, (k, cos)
 
 
 def test_medium_random_model_grads():
