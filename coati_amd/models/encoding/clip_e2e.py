@@ -1,0 +1,200 @@
+"""Host-side mirror of the reference's model interface for the hot path (coati/models/encoding/clip_e2e.py):
+`e3gnn_smiles_clip_e2e` (same constructor kwargs, attributes, state_dict keys, forward_dist / encode_* signatures),
+`clip_loss`, and the tensorisation tail of `clip_ar_xform`.  All tensor maths runs in libcoati_hip.so through
+coati_amd.engine.Engine; this file only adapts the calling convention."""
+import math
+from typing import Any, Dict
+
+import torch
+import torch.nn as nn
+
+from ...engine import Engine, ModelConfig
+
+
+class _Node(nn.Module):
+    """container used to reproduce the reference's dotted state_dict names"""
+
+
+def _attach(root: nn.Module, dotted: str, tensor: torch.Tensor, grad: torch.Tensor = None, buffer=False):
+    parts = dotted.split(".")
+    mod = root
+    for p in parts[:-1]:
+        if p not in mod._modules:
+            mod.add_module(p, _Node())
+        mod = mod._modules[p]
+    if buffer:
+        mod.register_buffer(parts[-1], tensor)
+    else:
+        prm = nn.Parameter(tensor, requires_grad=True)   # shares storage with the flat buffer
+        if grad is not None:
+            prm.grad = grad
+        mod.register_parameter(parts[-1], prm)
+
+
+class clip_loss(nn.Module):
+    """Symmetric InfoNCE with the reference's signature (clip_e2e.py:27-47): returns a [1] tensor.  The value comes
+    from the HIP InfoNCE kernels; `backward()` is not wired through autograd -- training uses Engine.train_step."""
+
+    def __init__(self, engine: Engine = None):
+        super().__init__()
+        object.__setattr__(self, "_engine", engine)
+
+    def forward(self, smiles_features, conformer_features, bad_rows):
+        eng = self._engine
+        if eng is None:
+            raise RuntimeError("clip_loss needs the model's engine: use model.clip_loss")
+        s = smiles_features.detach().float().contiguous()
+        c = conformer_features.detach().float().contiguous()
+        bad = bad_rows.to(torch.uint8).contiguous()
+        eng.scal[2:5].zero_()
+        eng.infonce(s, c, s, c, bad, row0=0, gscale=1.0)
+        sc = eng.scal
+        return (0.5 * (sc[2] + sc[3]) / torch.clamp(sc[4], min=1.0)).unsqueeze(0)
+
+
+class e3gnn_smiles_clip_e2e(nn.Module):
+    """Drop-in for coati.models.encoding.clip_e2e.e3gnn_smiles_clip_e2e (clip_e2e.py:350-463, 772-845)."""
+
+    def __init__(self, n_layer_e3gnn: int = 4, n_layer_xformer: int = 16, n_hidden_xformer: int = 128,
+                 n_hidden_e3nn: int = 128, msg_cutoff_e3nn: float = 4.0, n_embd_common: int = 128, n_head: int = 8,
+                 n_seq: int = 200, n_tok: int = 4, biases: bool = True, torch_emb: bool = False, residual: bool = False,
+                 norm_clips: bool = True, norm_embed: bool = False, token_mlp: bool = True,
+                 use_point_encoder: bool = True, old_architecture: bool = False,
+                 device: torch.device = torch.device("cuda:0"), dtype: torch.dtype = torch.float):
+        super().__init__()
+        unsupported = dict(biases=not biases, torch_emb=torch_emb, residual=residual, norm_clips=not norm_clips,
+                           norm_embed=norm_embed, token_mlp=not token_mlp, use_point_encoder=not use_point_encoder,
+                           old_architecture=old_architecture)
+        bad = [k for k, v in unsupported.items() if v]
+        if bad:
+            raise NotImplementedError(f"coati_amd implements the grande/closed architecture only; unsupported flags: {bad}")
+        if dtype not in (torch.float, torch.float32):
+            raise NotImplementedError("parameters are fp32 master weights (bf16 is an internal operand format)")
+        self.embed_dim = n_embd_common
+        self.device = torch.device(device)
+        # msg_cutoff_e3nn is accepted and ignored exactly as in the reference: e3gnn_clip never forwards it to
+        # its e_gcl_sparse layers, so the effective cutoff is 5.0.
+        cfg = ModelConfig(n_layer_e3gnn=n_layer_e3gnn, n_layer_xformer=n_layer_xformer, n_hidden_xformer=n_hidden_xformer,
+                          n_hidden_e3nn=n_hidden_e3nn, n_embd_common=n_embd_common, n_head=n_head, n_seq=n_seq, n_tok=n_tok,
+                          msg_cutoff=5.0)
+        eng = Engine(cfg, self.device, train=True)
+        object.__setattr__(self, "engine", eng)
+        grads = eng.named_views("grads")
+        for name, view in eng.named_views("params").items():
+            _attach(self, name, view, grads[name])
+        for l in range(n_layer_xformer):   # causal-mask buffers of the reference state_dict (basic_transformer.py:117-123)
+            _attach(self, f"xformer.transformer.h.{l}.attn.bias",
+                    torch.tril(torch.ones(n_seq, n_seq, device=self.device)).view(1, 1, n_seq, n_seq), buffer=True)
+        self.xformer.n_seq, self.xformer.n_tok, self.xformer.n_embd = n_seq, n_tok, n_hidden_xformer
+        self.point_encoder.hidden_nf = n_hidden_e3nn
+        self.use_point_encoder = True
+        self.clip_loss = clip_loss(eng)
+        self.reset_parameters()
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module.engine.refresh_shadows())
+        n_blocks = sum(p.numel() for n, p in self.named_parameters() if ".transformer." in n)
+        n_g = sum(p.numel() for n, p in self.named_parameters() if n.startswith("point_encoder."))
+        n_x = sum(p.numel() for n, p in self.named_parameters() if n.startswith("xformer."))
+        print("number of parameters: %.2fM" % (n_blocks / 1e6,))
+        print(f"number of parameters Total: {n_g/1e6:.2f}M xformer: {n_x/1e6:.2f}M Total: {(n_g+n_x)/1e6:.2f}M ")
+
+    @torch.no_grad()
+    def reset_parameters(self, seed: int = None):
+        """torch.nn default initialisers for every layer type on the path (Linear: kaiming-uniform(a=sqrt 5) weight and
+        U(+-1/sqrt(fan_in)) bias; Embedding: N(0,1); LayerNorm: 1/0; coord_mlp.2: xavier-uniform gain 1e-3)."""
+        g = torch.Generator(device="cpu")
+        g.manual_seed(torch.initial_seed() if seed is None else seed)
+        for name, p in self.named_parameters():
+            shape = tuple(p.shape)
+            if name.endswith("tok_emb.weight"):
+                v = torch.randn(shape, generator=g)
+            elif name.endswith("coord_mlp.2.weight"):
+                bound = 1e-3 * math.sqrt(6.0 / (shape[0] + shape[1]))
+                v = (torch.rand(shape, generator=g) * 2 - 1) * bound
+            elif len(shape) == 2:
+                bound = 1.0 / math.sqrt(shape[1])
+                v = (torch.rand(shape, generator=g) * 2 - 1) * bound
+            elif (".ln_" in name or name.endswith("_to_clip.0.weight") or name.endswith("_to_clip.0.bias")):
+                v = torch.ones(shape) if name.endswith("weight") else torch.zeros(shape)
+            else:  # Linear bias: fan_in of the matching weight
+                wname = name[: -len("bias")] + "weight"
+                fan_in = dict(self.named_parameters())[wname].shape[1]
+                v = (torch.rand(shape, generator=g) * 2 - 1) / math.sqrt(fan_in)
+            p.copy_(v.to(p.device))
+        self.engine.refresh_shadows()
+
+    # ---- reference API ------------------------------------------------------------------------------------------
+    def _tok(self, t):
+        return t.to(self.device, torch.long).contiguous()
+
+    def forward_dist(self, raw_tokens, augmented_tokens, atoms, coords, tokenizer, p_clip_emb_smi: float = 0.4,
+                     use_point: torch.Tensor = None, return_logits: bool = True):
+        """clip_e2e.py:772-814.  Returns (h_e3gnn, h_smiles, logits, bad_rows).  `use_point` overrides the RNG draw."""
+        eng = self.engine
+        self._sync_tokens(tokenizer)
+        B = atoms.shape[0]
+        if use_point is None:
+            use_point = torch.rand((B,), device=self.device) > p_clip_emb_smi
+        h_e, h_s, bad = eng.forward(self._tok(raw_tokens), self._tok(augmented_tokens), self._tok(atoms),
+                                    coords.to(self.device), use_point.to(self.device), y_next=None, train=False)
+        err = int(eng.scal[6:7].view(torch.int32).item())
+        if err & 1:
+            raise RuntimeError("Some smiles in the batch do not have stop tokens. Did some tokenizations fail?")
+        logits = eng.logits() if return_logits else None
+        return h_e, h_s, logits, bad.bool()
+
+    def forward(self, raw_tokens, augmented_tokens, atoms, coords, tokenizer, p_clip_emb_smi: float = 0.4):
+        """clip_e2e.py:816-845: as forward_dist, fourth output = clip loss."""
+        h_e, h_s, logits, bad = self.forward_dist(raw_tokens, augmented_tokens, atoms, coords, tokenizer, p_clip_emb_smi)
+        return h_e, h_s, logits, self.clip_loss(h_s, h_e, bad)
+
+    def encode_tokens(self, token_indices, tokenizer):
+        """clip_e2e.py:448-452 (runs the full fixed launch sequence with placeholder point clouds)."""
+        idx = self._tok(token_indices)
+        B = idx.shape[0]
+        atoms = torch.ones(B, 2, dtype=torch.long, device=self.device)
+        coords = torch.zeros(B, 2, 3, device=self.device)
+        _, h_s, _, _ = self.forward_dist(idx, idx, atoms, coords, tokenizer, use_point=torch.zeros(B, dtype=torch.bool), return_logits=False)
+        return h_s
+
+    def encode_points(self, atoms, coords):
+        """clip_e2e.py:454-463 (placeholder token rows [SMILES][STOP])."""
+        B = atoms.shape[0]
+        c = self.engine.cfg
+        idx = torch.tensor([[2, c.stop_token]], dtype=torch.long, device=self.device).repeat(B, 1)
+        h_e, _, _, _ = self.forward_dist(idx, idx, atoms, coords, None, use_point=torch.ones(B, dtype=torch.bool), return_logits=False)
+        return h_e
+
+    def _sync_tokens(self, tokenizer):
+        if tokenizer is None:
+            return
+        c = self.engine.cfg
+        stop, unk = getattr(tokenizer, "stop_token", c.stop_token), tokenizer.vocab["[UNK]"] if hasattr(tokenizer, "vocab") else c.unk_token
+        if (stop, unk) != (c.stop_token, c.unk_token):
+            raise NotImplementedError("tokenizer special ids differ from the engine's (stop/unk); rebuild the model with them")
+
+
+def tensorize_batch(batch: Dict[str, Any], tokenizer, dtype=torch.float, device="cpu", coord_noise=False):
+    """The tensorisation tail of clip_ar_xform (clip_e2e.py:288-330): given stacked `tokens` / `raw_tokens`
+    ([B, n_seq] long) plus atoms/coords arrays, move to `device`, truncate columns to the longest row, build y_next
+    with the five masked special ids.  The SMILES augmentation + tokenisation head of clip_ar_xform needs rdkit and the
+    reference vocabularies and is out of scope."""
+    out = dict(batch)
+    for col in ("tokens", "atoms", "raw_tokens"):
+        if not isinstance(out[col], torch.Tensor):
+            out[col] = torch.tensor(out[col], requires_grad=False)
+        out[col] = out[col].to(device, torch.long)
+    if not isinstance(out["coords"], torch.Tensor):
+        out["coords"] = torch.tensor(out["coords"], requires_grad=False)
+    out["coords"] = out["coords"].to(device, dtype)
+    if out["atoms"].shape[0] < 1:
+        raise Exception("empty batch")
+    if coord_noise:
+        out["coords"] = out["coords"] + torch.normal(torch.zeros_like(out["coords"]), 0.05 * torch.ones_like(out["coords"]))
+    out["tokens"] = out["tokens"][:, : int((out["tokens"].sum(0) > 0).sum())]
+    out["raw_tokens"] = out["raw_tokens"][:, : int((out["raw_tokens"].sum(0) > 0).sum())]
+    y = torch.zeros_like(out["tokens"])
+    y[:, : out["tokens"].shape[1] - 1] = out["tokens"][:, 1:].clone()
+    for t in (tokenizer.clip_token, tokenizer.pad_token, tokenizer.unk_token, tokenizer.suffix_token, tokenizer.middle_token):
+        y[y == t] = -1
+    out["y_next"] = y
+    return out

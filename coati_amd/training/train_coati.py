@@ -1,0 +1,226 @@
+"""Trainer with the reference's interface (coati/training/train_coati.py): `do_args()` (same flags),
+`train_autoencoder(gpu, args)` (one process per GPU, env:// rendezvous), `serialize_model`.
+do_minibatch (train_coati.py:216-361) is the HIP engine's fixed launch sequence; DP collectives go through RCCL.
+
+Differences from the reference, all documented in DESIGN.md: parameter gradients ARE averaged across ranks (the
+reference bypasses DDP.forward and never reduces them); evaluation runs on every rank (the reference's rank-0-only test
+epoch would deadlock its own collectives); losses are read back only every `log_batch_loss` steps."""
+import argparse
+import json
+import math
+import os
+import pickle
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+from ..data.dataset import COATI_dataset, SyntheticTokenizer
+from ..models.encoding.clip_e2e import e3gnn_smiles_clip_e2e
+from .. import distributed as D
+
+
+def serialize_model(train_args, dataset_summary, model_state_dict, model_kwargs, optimizer_state_dict=None, **kwargs):
+    """train_coati.py:37-57: the checkpoint wire format (pickle of a dict)."""
+    d = pickle.dumps({"train_args": train_args, "dataset_summary": dataset_summary, "model": model_state_dict,
+                      "optimizer": optimizer_state_dict, "model_kwargs": model_kwargs, **kwargs},
+                     protocol=pickle.HIGHEST_PROTOCOL)
+    print("Model Document size (MB): ", sys.getsizeof(d) / (1024 * 1024))
+    return d
+
+
+def do_args(argv=None):
+    """train_coati.py:442-580, flag for flag."""
+    p = argparse.ArgumentParser(description="token_transformer")
+    p.add_argument("--exp_name", type=str, default="token_transformer")
+    p.add_argument("--run_name", type=str, default=str(int(time.time())))
+    p.add_argument("--output_dir", type=str, default="COATI_outputs")
+    p.add_argument("--model_dir", type=str, default="COATI_models")
+    p.add_argument("--data_dir", type=str, default="COATI_data")
+    p.add_argument("-ws", "--world_size", default=1, type=int)
+    p.add_argument("-nr", "--nr", default=0, type=int)
+    p.add_argument("-n", "--nodes", default=1, type=int)
+    p.add_argument("-g", "--gpus", default=torch.cuda.device_count(), type=int)
+    p.add_argument("--device", type=str, default="cuda")
+    p.add_argument("--dtype", type=str, default="float")
+    p.add_argument("--log_batch_loss", default=25)
+    p.add_argument("--code_features", default=["protein", "secondary", "library"])
+    p.add_argument("--n_epochs", type=int, default=2)
+    p.add_argument("--batch_size", type=int, default=32)
+    p.add_argument("--recipe", type=list, default=[{"collection": "geom_drugs", "n_samples": 6_000_000, "filter": {}}])
+    p.add_argument("--n_layer_e3gnn", type=int, default=4)
+    p.add_argument("--n_hidden_e3nn", type=int, default=128)
+    p.add_argument("--msg_cutoff_e3nn", type=float, default=10.0)
+    p.add_argument("--n_hidden_xformer", type=int, default=128)
+    p.add_argument("--n_embd_common", type=int, default=128)
+    p.add_argument("--n_layer_xformer", type=int, default=16)
+    p.add_argument("--n_head", type=int, default=8)
+    p.add_argument("--biases", type=bool, default=True)
+    p.add_argument("--n_seq", type=int, default=200)
+    p.add_argument("--tokenizer_vocab", type=str, default="Jan8")
+    p.add_argument("--torch_emb", type=bool, default=False)
+    p.add_argument("--load_transformer_only", type=bool, default=False)
+    p.add_argument("--p_dataset", type=float, default=0.3)
+    p.add_argument("--p_formula", type=float, default=0.3)
+    p.add_argument("--p_fim", type=float, default=0.5)
+    p.add_argument("--p_graph", type=float, default=0.3)
+    p.add_argument("--p_clip", type=float, default=0.3)
+    p.add_argument("--p_clip_cut", type=float, default=0.3)
+    p.add_argument("--p_clip_emb_smi", type=float, default=0.4)
+    p.add_argument("--p_randsmiles", type=float, default=0.5)
+    p.add_argument("--norm_clips", type=bool, default=False)
+    p.add_argument("--token_mlp", type=bool, default=False)
+    p.add_argument("--norm_embed", type=bool, default=False)
+    p.add_argument("--weight_decay", type=float, default=0.1)
+    p.add_argument("--lr", type=float, default=4e-4)
+    p.add_argument("--clip_grad", type=float, default=10.0)
+    p.add_argument("--do_clip", type=bool, default=True)
+    p.add_argument("--test_frac", type=float, default=0.02)
+    p.add_argument("--valid_frac", type=float, default=0.02)
+    p.add_argument("--test_interval", type=int, default=1)
+    p.add_argument("--log_interval", type=int, default=100)
+    p.add_argument("--ngrad_to_save", default=2e6)
+    p.add_argument("--resume_document", default=None)
+    p.add_argument("--resume_optimizer", type=bool, default=False)
+    args, unparsed = p.parse_known_args(argv)
+    if len(unparsed):
+        print("Warning... unparsed: ", unparsed)
+    return args
+
+
+class _JsonlLogger:
+    """minimal stand-in for COATILogger (training/logger.py:61-89, 127-134): metric records + checkpoint files"""
+
+    def __init__(self, run_time, output_path, model_path, model_name="e3gnn_smiles_clip_e2e"):
+        self.run_time, self.model_path, self.model_name = run_time, model_path, model_name
+        os.makedirs(os.path.join(output_path, str(run_time)), exist_ok=True)
+        os.makedirs(model_path, exist_ok=True)
+        self.f = open(os.path.join(output_path, str(run_time), "log.json"), "a")
+
+    def log_metric(self, key, value, dataset_epoch=None, step=None, tags=None):
+        rec = {"event": "metric", "key": key, "value": value, "dataset_epoch": dataset_epoch, "step": step,
+               "timestamp": time.time(), **{"tag_" + k: v for k, v in (tags or {}).items()}}
+        self.f.write(json.dumps(rec) + ",\n")
+        self.f.flush()
+        return rec
+
+    def log_pytorch(self, model_document, tags):
+        name = f"{self.model_name}_{self.run_time}_{'_'.join(str(v) for v in tags.values())}.pkl"
+        with open(os.path.join(self.model_path, name), "wb") as f:
+            f.write(model_document)
+        return name
+
+
+def train_autoencoder(gpu, args, dataset=None, tokenizer=None):
+    """train_coati.py:60-439.  `dataset` / `tokenizer` default to the synthetic stand-ins (no S3, no rdkit here)."""
+    rank = args.nr * args.gpus + gpu
+    world = args.world_size
+    print(f"train autoencoder rank {rank} reporting in.")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "8899")
+    device = torch.device("cuda:" + str(gpu))
+    torch.cuda.set_device(device)
+    if world > 1:
+        dist.init_process_group(backend="nccl", init_method="env://", world_size=world, rank=rank, device_id=device)
+    tokenizer = tokenizer or SyntheticTokenizer(n_seq=args.n_seq, n_token=getattr(args, "n_token", 10322))
+    dataset = dataset or COATI_dataset(cache_dir=args.data_dir, tokenizer=tokenizer,
+                                       n_batches=getattr(args, "synthetic_batches", 50))
+    token_entropy_unit = math.log(float(len(tokenizer.keys))) / math.log(2.0)       # train_coati.py:87
+    logger = None
+    if rank == 0:
+        out = os.path.join(args.output_dir, args.exp_name, str(args.run_name))
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "params.json"), "w") as f:
+            json.dump({k: v for k, v in vars(args).items() if isinstance(v, (int, float, str, bool, list, type(None)))}, f)
+        logger = _JsonlLogger(args.run_name, args.output_dir, args.model_dir)
+    kwargs = {"n_layer_xformer": args.n_layer_xformer, "n_layer_e3gnn": args.n_layer_e3gnn, "n_hidden_e3nn": args.n_hidden_e3nn,
+              "n_hidden_xformer": args.n_hidden_xformer, "n_embd_common": args.n_embd_common, "biases": args.biases,
+              "n_head": args.n_head, "n_seq": getattr(args, "max_n_seq", args.n_seq), "n_tok": tokenizer.n_token,
+              "torch_emb": args.torch_emb, "norm_clips": args.norm_clips, "norm_embed": args.norm_embed, "token_mlp": args.token_mlp}
+    model_kwargs = kwargs.copy()
+    kwargs["device"] = device
+    model = e3gnn_smiles_clip_e2e(**kwargs)
+    eng = model.engine
+    n_toks, ngrad_updates = 0, 0
+    offline_losses = {"batch_losses": [], "ar_losses": [], "clip_losses": []}
+    if args.resume_document is not None:
+        with open(args.resume_document, "rb") as f_in:
+            doc = pickle.load(f_in)
+        n_toks = doc.get("n_toks_processed", 0)
+        ngrad_updates = doc.get("n_grads_processed", 0)
+        sd = {(k[7:] if k.startswith("module.") else k): v for k, v in doc["model"].items()}
+        if args.load_transformer_only:
+            sd = {k: v for k, v in sd.items() if k.split(".")[0] in ("xformer", "smiles_to_clip")}
+        model.load_state_dict(sd, strict=False)
+        if args.resume_optimizer and isinstance(doc.get("optimizer"), dict) and "flat" in doc["optimizer"]:
+            eng.adam_m.copy_(doc["optimizer"]["flat"]["m"].to(device))
+            eng.adam_v.copy_(doc["optimizer"]["flat"]["v"].to(device))
+            eng.step_count = doc["optimizer"]["flat"]["step"]
+        print("Loaded from checkpoint. ")
+    if world > 1:   # DDP's constructor broadcast: every replica starts from rank 0's weights
+        dist.broadcast(eng.params, src=0)
+        eng.refresh_shadows()
+
+    def optimizer_state():
+        return {"flat": {"m": eng.adam_m.cpu(), "v": eng.adam_v.cpu(), "step": eng.step_count}}
+
+    def lr_at(epoch):   # CosineAnnealingLR(T_max=n_epochs), stepped once per epoch (train_coati.py:152, 381)
+        return 0.5 * args.lr * (1.0 + math.cos(math.pi * epoch / max(args.n_epochs, 1)))
+
+    def do_epoch(epoch, partition="train"):
+        nonlocal n_toks, ngrad_updates
+        t0, ng, losses = time.time(), 0, []
+        pipe = dataset.get_data_pipe(batch_size=args.batch_size, partition=partition, distributed_rankmod_total=world,
+                                     distributed_rankmod_rank=rank, required_fields=["smiles"])
+        for i, batch in enumerate(pipe):
+            dev = {k: v.to(device) for k, v in batch.items() if isinstance(v, torch.Tensor)}
+            B = dev["atoms"].shape[0]
+            if not (dev["tokens"].shape[0] == B and dev["y_next"].shape[0] == B):
+                print("a row was lost, skipping batch")          # train_coati.py:229-234
+                continue
+            use_point = torch.rand((B,), device=device) > args.p_clip_emb_smi
+            train = partition == "train"
+            if world > 1:
+                D.distributed_train_step(eng, dev, use_point, lr_at(epoch), do_clip=args.do_clip, optimizer=train)
+            else:
+                eng.train_step(dev, use_point, lr_at(epoch), do_clip=args.do_clip, optimizer=train)
+            ngrad_updates += B
+            ng += B
+            log_now = (i % int(args.log_batch_loss)) == 0
+            if log_now or i % args.log_interval == 0:
+                L = D.global_losses(eng) if world > 1 else eng.losses()
+                n_toks += int((dev["tokens"] > 0).sum().item())
+                losses.append(L["loss"])
+                if rank == 0 and log_now:
+                    tags = {"n_toks": n_toks}
+                    offline_losses["batch_losses"].append(logger.log_metric(partition + "_batch_loss", L["loss"], epoch, i, tags))
+                    offline_losses["ar_losses"].append(logger.log_metric(partition + "_ar_loss", L["ar_loss"], epoch, i, tags))
+                    offline_losses["clip_losses"].append(logger.log_metric(partition + "_clip_loss", L["clip_loss"], epoch, i, tags))
+                if rank == 0 and i % args.log_interval == 0:
+                    print("run_time %s Epoch %d \t it %d \t ar_l: %.2f, clip_l %.6f, loss %.4f \t grads_ps %.4f"
+                          % (args.run_name, epoch, i, L["ar_loss"], L["clip_loss"], L["loss"], ng * world / (time.time() - t0)))
+            if ngrad_updates * world > float(args.ngrad_to_save) and rank == 0:
+                ngrad_updates = 0
+                doc = serialize_model(vars(args), dataset.summary, {k: v.cpu() for k, v in model.state_dict().items()}, model_kwargs,
+                                      optimizer_state(), n_toks_processed=n_toks, n_grads_processed=ngrad_updates,
+                                      offline_loss=offline_losses)
+                logger.log_pytorch(doc, tags={"train_epoch": str(epoch), "dataset_epoch": str(epoch)})
+        if rank == 0:
+            print(f"epoch completed in {ng} grads and {time.time()-t0} seconds")
+        return sum(losses) / len(losses) if losses else None
+
+    res = {"best_test": 1e10, "best_epoch": 0, "best_model": None}
+    for epoch in range(args.n_epochs):
+        do_epoch(epoch, "train")
+        if epoch % args.test_interval == 0 and epoch > 0:
+            test_loss = do_epoch(epoch, "test")
+            if test_loss is not None and test_loss < res["best_test"]:
+                res.update(best_test=test_loss, best_epoch=epoch, best_model={k: v.cpu() for k, v in model.state_dict().items()})
+    if rank == 0:
+        doc = serialize_model(vars(args), dataset.summary, res["best_model"] or {k: v.cpu() for k, v in model.state_dict().items()},
+                              model_kwargs, optimizer_state(), n_toks_processed=n_toks, n_grads_processed=ngrad_updates)
+        logger.log_pytorch(doc, tags={"best": "best"})
+    if world > 1:
+        dist.destroy_process_group()
+    return model

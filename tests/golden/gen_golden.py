@@ -261,7 +261,26 @@ def main():
     xf = dict(tokens=res["tokens"], raw_tokens=res["raw_tokens"], y_next=res["y_next"])
     # the un-truncated stacks are re-derivable: pad back to n_seq with zeros
     np.savez_compressed(os.path.join(OUT, "xform_tail.npz"), **npify(xf))
+    # ---- G14 AllGatherFunction forward/backward under a 2-rank gloo group (autograd_funs.py:5-25) ----
+    import torch.multiprocessing as mp
+    mp.spawn(_allgather_worker, args=(2,), nprocs=2)
     print("golden vectors written to", OUT)
+
+
+def _allgather_worker(rank, world):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = "29611"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from coati.models.autograd_funs.autograd_funs import all_gather as ref_all_gather
+    g = torch.Generator().manual_seed(100 + rank)
+    x = torch.randn(3, 4, generator=g, requires_grad=True)
+    w = torch.randn(world * 3, 4, generator=torch.Generator().manual_seed(7 + rank))  # rank-dependent upstream grad
+    y = ref_all_gather(x)
+    (y * w).sum().backward()
+    np.savez(os.path.join(OUT, f"allgather_rank{rank}.npz"), x=x.detach().numpy(), w=w.numpy(), y=y.detach().numpy(),
+             gx=x.grad.numpy())
+    dist.destroy_process_group()
 
 
 if __name__ == "__main__":

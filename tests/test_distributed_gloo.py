@@ -1,0 +1,121 @@
+"""world_size-2 gloo tests (CPU) of the N>1 path: the differentiable all-gather against vectors captured from the
+reference's AllGatherFunction, and the row-sharded InfoNCE formulation (local rows x global columns + reduce-scatter)
+against the single-process global loss.  Compute inside these tests is the oracle's (tests may use it); what is under
+test is the collective glue in coati_amd.distributed / coati_amd.models.autograd_funs."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def _init(rank, world, port):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+
+def _allgather_worker(rank, world, port, q):
+    import sys
+    sys.path.insert(0, ROOT)
+    _init(rank, world, port)
+    from coati_amd.models.autograd_funs.autograd_funs import all_gather
+    z = np.load(os.path.join(GOLD, f"allgather_rank{rank}.npz"))
+    x = torch.from_numpy(z["x"]).requires_grad_(True)
+    y = all_gather(x)
+    (y * torch.from_numpy(z["w"])).sum().backward()
+    ok = torch.allclose(y.detach(), torch.from_numpy(z["y"])) and torch.allclose(x.grad, torch.from_numpy(z["gx"]), atol=1e-6)
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+def _infonce_worker(rank, world, port, q):
+    import sys
+    sys.path.insert(0, ROOT)
+    _init(rank, world, port)
+    from coati_amd import distributed as D
+    from oracle import coati_oracle as O
+    B, E = 6, 16
+    g = torch.Generator().manual_seed(5)
+    S = torch.randn(world * B, E, generator=g)
+    C = torch.randn(world * B, E, generator=g)
+    bad = torch.zeros(world * B, dtype=torch.bool)
+    bad[3] = bad[8] = True
+    # single-process global reference
+    Sg, Cg = S.clone().requires_grad_(True), C.clone().requires_grad_(True)
+    Lg = O.clip_loss(Sg, Cg, bad).sum()
+    Lg.backward()
+    # this rank's view
+    sl = slice(rank * B, (rank + 1) * B)
+    s_loc, c_loc = S[sl].contiguous(), C[sl].contiguous()
+    s_all, c_all = D.all_gather_cat(s_loc), D.all_gather_cat(c_loc)
+    bad_all = D.all_gather_cat(bad[sl].to(torch.uint8)).bool()
+    ok = torch.equal(s_all, S) and torch.equal(bad_all, bad)
+    # local rows x global columns: the two directional CE sums over this rank's rows
+    s_all_r, c_all_r = s_all.clone().requires_grad_(True), c_all.clone().requires_grad_(True)
+    labels = torch.arange(rank * B, (rank + 1) * B)
+    labels = torch.where(bad_all[sl], -torch.ones_like(labels), labels)
+    nvalid = float((~bad_all).sum())
+    l1 = torch.nn.functional.cross_entropy(s_all_r[sl] @ c_all_r.t(), labels, ignore_index=-1, reduction="sum")
+    l2 = torch.nn.functional.cross_entropy(c_all_r[sl] @ s_all_r.t(), labels, ignore_index=-1, reduction="sum")
+    part = 0.5 * (l1 + l2) / nvalid
+    part.backward()
+    dS = D.reduce_scatter_sum(s_all_r.grad)
+    dC = D.reduce_scatter_sum(c_all_r.grad)
+    tot = part.detach().clone()
+    dist.all_reduce(tot)
+    ok = ok and abs(float(tot) - float(Lg)) < 1e-5
+    ok = ok and torch.allclose(dS, Sg.grad[sl], atol=1e-6) and torch.allclose(dC, Cg.grad[sl], atol=1e-6)
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+def _spawn(fn, port):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=fn, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    return dict(res)
+
+
+def test_all_gather_matches_reference_vectors():
+    assert _spawn(_allgather_worker, 29701) == {0: True, 1: True}
+
+
+def test_row_sharded_infonce_equals_global_loss():
+    assert _spawn(_infonce_worker, 29702) == {0: True, 1: True}
+
+
+def test_grad_buckets_cover_the_flat_buffer():
+    import ctypes
+    from coati_amd import _lib
+    from coati_amd import distributed as D
+
+    class Fake:
+        pass
+    l = _lib.lib()
+    cfg = _lib.CoatiConfig(2, 2, 64, 64, 64, 4, 24, 48, 5.0, 0, 1, 7)
+    h = ctypes.c_void_p()
+    assert l.coati_engine_create(ctypes.byref(cfg), ctypes.byref(h)) == 0
+    eng = Fake()
+    eng.n_params = int(l.coati_engine_param_elems(h))
+    eng.layout = {}
+    buf = ctypes.create_string_buffer(256)
+    off, rows, cols = ctypes.c_int64(), ctypes.c_int32(), ctypes.c_int32()
+    for i in range(l.coati_engine_n_entries(h)):
+        l.coati_engine_entry(h, i, buf, 256, ctypes.byref(off), ctypes.byref(rows), ctypes.byref(cols))
+        eng.layout[buf.value.decode()] = (off.value, (rows.value, cols.value))
+    bk = D.grad_buckets(eng)
+    spans = sorted(bk.values())
+    assert spans[0][0] == 0 and spans[-1][1] == eng.n_params
+    assert all(spans[i][1] == spans[i + 1][0] for i in range(len(spans) - 1))
+    l.coati_engine_destroy(h)

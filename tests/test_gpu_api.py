@@ -1,0 +1,80 @@
+"""The reference-shaped Python API on the GPU: model mirror (constructor kwargs, state_dict keys, forward_dist,
+encode_*), the trainer entry point with its checkpoint document, and the loader."""
+import os
+import pickle
+import types
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from tests.gpu_util import check, log  # noqa: E402
+
+SMALL = dict(n_layer_e3gnn=2, n_layer_xformer=2, n_hidden_xformer=64, n_hidden_e3nn=64, n_embd_common=64, n_head=4,
+             n_seq=24, n_tok=48, biases=True, torch_emb=False, residual=False, norm_clips=True, norm_embed=False,
+             token_mlp=True)
+
+
+class Tok:
+    pad_token, stop_token, smiles_token, suffix_token, middle_token, unk_token, clip_token = 0, 1, 2, 5, 6, 7, 8
+    vocab = {"[UNK]": 7, "[STOP]": 1, "[PAD]": 0}
+    n_token, n_seq = 48, 24
+    keys = list(range(48))
+
+
+def test_model_mirror_against_golden(golden_dir):
+    from coati.models.encoding.clip_e2e import e3gnn_smiles_clip_e2e
+    z = np.load(os.path.join(golden_dir, "small_model.npz"))
+    v = np.load(os.path.join(golden_dir, "small_vectors.npz"))
+    model = e3gnn_smiles_clip_e2e(**SMALL, device=torch.device("cuda:0"))
+    sd_keys = set(model.state_dict().keys())
+    assert set(z.files) <= sd_keys
+    assert {k for k in sd_keys - set(z.files)} == {f"xformer.transformer.h.{l}.attn.bias" for l in range(2)}
+    missing = model.load_state_dict({k: torch.from_numpy(z[k]) for k in z.files}, strict=False)
+    assert not missing.unexpected_keys
+    assert model.embed_dim == 64 and hasattr(model, "point_encoder") and hasattr(model, "smiles_to_clip")
+    b = {k: torch.from_numpy(v["b_" + k]) for k in ("raw_tokens", "tokens", "atoms", "coords")}
+    he, hs, logits, bad = model.forward_dist(b["raw_tokens"], b["tokens"], b["atoms"], b["coords"], Tok(), p_clip_emb_smi=0.0)
+    check("api h_e3gnn", he.cpu(), torch.from_numpy(v["fd_p0_h_e3gnn"]), 3e-2)
+    check("api logits", logits.cpu(), torch.from_numpy(v["fd_p0_logits"]), 3e-2)
+    assert bad.dtype == torch.bool and torch.equal(bad.cpu(), torch.from_numpy(v["fd_p0_bad"]))
+    check("api encode_tokens", model.encode_tokens(b["raw_tokens"], Tok()).cpu(), torch.from_numpy(v["fd_p0_h_smiles"]), 3e-2)
+    check("api encode_points", model.encode_points(b["atoms"], b["coords"]).cpu(), torch.from_numpy(v["fd_p0_h_e3gnn"]), 3e-2)
+    a, c, badr = torch.from_numpy(v["cl_a"]), torch.from_numpy(v["cl_b"]), torch.from_numpy(v["cl_bad"])
+    check("api clip_loss", model.clip_loss(a.cuda(), c.cuda(), badr.cuda()).cpu(), torch.from_numpy(v["cl_l1"]), 1e-5)
+    raw_bad = b["raw_tokens"].clone()
+    raw_bad[0][raw_bad[0] == 1] = 0
+    with pytest.raises(RuntimeError, match="stop tokens"):
+        model.forward_dist(raw_bad, b["tokens"], b["atoms"], b["coords"], Tok())
+
+
+def test_trainer_and_checkpoint_roundtrip(tmp_path):
+    from coati.training.train_coati import train_autoencoder, do_args
+    from coati.models.io.coati import load_e3gnn_smiles_clip_e2e
+    from coati.data.dataset import COATI_dataset
+    from coati_amd.data.dataset import SyntheticTokenizer
+    args = do_args([])
+    args.nodes, args.nr, args.gpus, args.world_size = 1, 0, 1, 1
+    args.n_layer_e3gnn, args.n_hidden_e3nn, args.n_hidden_xformer, args.n_embd_common = 2, 64, 64, 64
+    args.n_layer_xformer, args.n_head, args.max_n_seq, args.n_seq = 2, 4, 40, 24
+    args.norm_clips, args.token_mlp = True, True
+    args.batch_size, args.n_epochs, args.lr, args.test_interval = 16, 2, 5e-4, 1
+    args.log_batch_loss, args.log_interval = 1, 1
+    args.output_dir, args.model_dir, args.data_dir = str(tmp_path / "logs"), str(tmp_path / "ckpt"), str(tmp_path)
+    args.run_name = "t"
+    tk = SyntheticTokenizer(n_seq=24, n_token=200, n_special=12)
+    ds = COATI_dataset(cache_dir=str(tmp_path), tokenizer=tk, n_batches=6, n_atoms=8)
+    model = train_autoencoder(0, args, dataset=ds, tokenizer=tk)
+    files = os.listdir(args.model_dir)
+    assert len(files) == 1
+    doc = pickle.load(open(os.path.join(args.model_dir, files[0]), "rb"))
+    assert set(doc) >= {"train_args", "dataset_summary", "model", "optimizer", "model_kwargs", "n_toks_processed", "n_grads_processed"}
+    recs = open(os.path.join(args.output_dir, "t", "log.json")).read().strip().split("\n")
+    losses = [eval(r.rstrip(","), {"null": None})["value"] for r in recs if "train_batch_loss" in r]
+    log(f"trainer losses {losses}")
+    assert len(losses) == 12 and all(np.isfinite(losses)) and losses[-1] < losses[0]
+    m2, _ = load_e3gnn_smiles_clip_e2e(os.path.join(args.model_dir, files[0]), device="cuda:0")
+    for k, t in model.state_dict().items():
+        assert torch.equal(t.cpu(), m2.state_dict()[k].cpu()), k

@@ -1,0 +1,129 @@
+"""CPU-only checks of the host side: the C-ABI library loads and exports every symbol include/coati_hip.h declares
+(no compute calls), the parameter table equals the reference state_dict contract, the synthetic batches and the
+clip_ar_xform tail are well-formed, the reference import paths resolve, and the product path refuses to run
+without a GPU instead of falling back."""
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_cabi_exports_every_declared_symbol():
+    from coati_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "coati_hip.h")).read()
+    declared = set(re.findall(r"\b(coati_[a-z0-9_]+)\s*\(", hdr))
+    l = _lib.lib()
+    assert l.coati_abi_version() == 1
+    for sym in sorted(declared):
+        assert hasattr(l, sym), f"libcoati_hip.so does not export {sym}"
+    assert declared == set(_lib.exported_symbols())
+
+
+def test_bad_arguments_return_codes_not_exceptions():
+    from coati_amd import _lib
+    l = _lib.lib()
+    rc = l.coati_gemm_nt(None, 0, 0, None, 0, 1, 1, 64, None, 0, 0, None, None, None, 0, 0, None)
+    assert rc == -1 and b"null" in l.coati_last_error()
+    cfg = _lib.CoatiConfig(2, 2, 96, 64, 96, 4, 24, 48, 5.0, 0, 1, 7)   # head size 24: unsupported
+    h = ctypes.c_void_p()
+    assert l.coati_engine_create(ctypes.byref(cfg), ctypes.byref(h)) == -2
+    assert b"head size" in l.coati_last_error()
+
+
+def test_layout_is_the_reference_state_dict_contract(golden_dir):
+    from coati_amd import _lib
+    from oracle import coati_oracle as O
+    l = _lib.lib()
+    for kw in (dict(n_layer_e3gnn=2, n_layer_xformer=2, n_hidden_xformer=64, n_hidden_e3nn=64, n_embd_common=64, n_head=4, n_seq=24, n_tok=48),
+               dict(n_layer_e3gnn=5, n_layer_xformer=16, n_hidden_xformer=256, n_hidden_e3nn=256, n_embd_common=256, n_head=16, n_seq=250, n_tok=10322)):
+        cfg = _lib.CoatiConfig(kw["n_layer_xformer"], kw["n_layer_e3gnn"], kw["n_hidden_xformer"], kw["n_hidden_e3nn"],
+                               kw["n_embd_common"], kw["n_head"], kw["n_seq"], kw["n_tok"], 5.0, 0, 1, 7)
+        h = ctypes.c_void_p()
+        assert l.coati_engine_create(ctypes.byref(cfg), ctypes.byref(h)) == 0
+        shapes = O.param_shapes(O.OracleConfig(**kw))
+        buf = ctypes.create_string_buffer(256)
+        off, rows, cols = ctypes.c_int64(), ctypes.c_int32(), ctypes.c_int32()
+        seen, prev_end = {}, 0
+        for i in range(l.coati_engine_n_entries(h)):
+            assert l.coati_engine_entry(h, i, buf, 256, ctypes.byref(off), ctypes.byref(rows), ctypes.byref(cols)) == 0
+            shape = (rows.value, cols.value) if cols.value > 0 else (rows.value,)
+            seen[buf.value.decode()] = shape
+            assert off.value % 64 == 0 and off.value >= prev_end
+            prev_end = off.value + int(np.prod(shape))
+        assert seen == {k: tuple(v) for k, v in shapes.items()}
+        assert l.coati_engine_param_elems(h) >= prev_end
+        assert l.coati_engine_shadow_elems(h) > l.coati_engine_param_elems(h)
+        assert l.coati_engine_workspace_bytes(h, 8, 20, 22, 6, 8) > 0
+        l.coati_engine_destroy(h)
+    z = np.load(os.path.join(golden_dir, "small_model.npz"))
+    assert set(z.files) == set(O.param_shapes(O.OracleConfig(n_layer_e3gnn=2, n_layer_xformer=2, n_hidden_xformer=64,
+                                                               n_hidden_e3nn=64, n_embd_common=64, n_head=4, n_seq=24, n_tok=48)))
+
+
+def test_no_cpu_fallback():
+    from coati_amd.engine import Engine, ModelConfig
+    from coati_amd import ops
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        Engine(ModelConfig(), "cuda:0")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.gemm_nt(torch.zeros(4, 64), torch.zeros(4, 64).bfloat16())
+
+
+def test_periodic_lut_matches_reference_table(golden_dir):
+    from coati_amd.periodic import onehot_lut, xy_position
+    lut = json.load(open(os.path.join(golden_dir, "constants.json")))["xy_lut"]
+    assert all(tuple(lut[z]) == xy_position(z) for z in range(120))
+    ix, iy = onehot_lut()
+    assert (ix[0], iy[0]) == (27, 17) and (ix[6], iy[6]) == (14, 20) and iy[92] == -1
+
+
+def test_synthetic_batch_format():
+    from coati_amd.synthetic import make_batch, y_next_from_tokens, STOP, PAD, UNK, CLIP
+    b, up = make_batch(64, 80, 16, 10322, seed=3)
+    assert b["tokens"].shape == (64, 80) and b["raw_tokens"].shape == (64, 78) and b["coords"].dtype == torch.float32
+    raw, tok = b["raw_tokens"], b["tokens"]
+    assert ((raw == STOP).sum(1) == 1).all()                      # get_stop_token_embs precondition
+    good = tok.sum(1) > 0
+    assert ((tok[good] == STOP).sum(1) == 1).all()
+    assert ((tok == UNK).sum(1) <= 1).all() and (tok[tok[:, 0] == CLIP][:, 1] == UNK).all()
+    assert torch.equal(b["y_next"], y_next_from_tokens(tok))
+    assert (b["atoms"] >= 0).all() and ((b["atoms"] > 0).sum(1) >= 8).all()
+    b2, _ = make_batch(64, 80, 16, 10322, seed=3)
+    assert all(torch.equal(b[k], b2[k]) for k in b)
+
+
+def test_tensorize_tail_matches_reference_xform(golden_dir):
+    from coati_amd.models.encoding.clip_e2e import tensorize_batch
+    from coati_amd.data.dataset import SyntheticTokenizer
+    z = np.load(os.path.join(golden_dir, "xform_tail.npz"))
+    tok = torch.from_numpy(z["tokens"])
+    raw = torch.from_numpy(z["raw_tokens"])
+    pad = lambda t: torch.cat([t, torch.zeros(t.shape[0], 40 - t.shape[1], dtype=t.dtype)], 1)
+    out = tensorize_batch({"tokens": pad(tok), "raw_tokens": pad(raw), "atoms": np.array([[6, 6, 8, 0]] * tok.shape[0]),
+                           "coords": np.zeros((tok.shape[0], 4, 3))}, SyntheticTokenizer(n_seq=40))
+    assert torch.equal(out["tokens"], tok) and torch.equal(out["raw_tokens"], raw)
+    assert torch.equal(out["y_next"], torch.from_numpy(z["y_next"]))
+
+
+def test_reference_import_paths_and_args():
+    from coati.training.train_coati import train_autoencoder, do_args, serialize_model  # noqa: F401
+    from coati.data.dataset import COATI_dataset
+    from coati.models.io.coati import load_e3gnn_smiles_clip_e2e  # noqa: F401
+    from coati.models.autograd_funs.autograd_funs import all_gather  # noqa: F401
+    from coati.models.encoding.clip_e2e import e3gnn_smiles_clip_e2e, clip_loss  # noqa: F401
+    a = do_args([])
+    for flag in ("world_size", "nr", "nodes", "gpus", "n_layer_e3gnn", "msg_cutoff_e3nn", "p_clip_emb_smi", "clip_grad",
+                 "ngrad_to_save", "resume_document", "tokenizer_vocab", "log_batch_loss", "weight_decay"):
+        assert hasattr(a, flag)
+    assert (a.lr, a.weight_decay, a.clip_grad, a.n_layer_xformer) == (4e-4, 0.1, 10.0, 16)
+    pipe = COATI_dataset(cache_dir=".").get_data_pipe(batch_size=4, distributed_rankmod_total=2, distributed_rankmod_rank=1)
+    b = next(iter(pipe))
+    assert b["tokens"].shape[0] == 4 and "y_next" in b
