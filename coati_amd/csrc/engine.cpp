@@ -704,10 +704,10 @@ int coati_engine_infonce(coati_engine* e, const float* S_loc, const float* C_loc
   COATI_CHECK_SHAPE(B > 0 && Bg >= B && row0 >= 0 && row0 + B <= Bg, "engine_infonce: bad row range");
   hipStream_t s = (hipStream_t)stream;
   const int E = e->cfg.n_embd_common;
+  COATI_CHECK_ARG(e->have_fwd, "engine_infonce: needs the workspace of a forward call");
   // logits scratch lives in the (now idle) backward scratch of the decoder pass: [B, Bg] f32 x 2
   COATI_CHECK_SHAPE((size_t)2 * B * Bg * sizeof(float) <= (size_t)e->B * (e->T1 > e->T2 ? e->T1 : e->T2) * 4 * e->cfg.n_hidden_xformer * sizeof(bf16_t),
                     "engine_infonce: Bg=%d too large for the logits scratch", Bg);
-  COATI_CHECK_ARG(e->have_fwd && B == e->B, "engine_infonce: call forward first");
   float* L1 = reinterpret_cast<float*>(e->dh4);
   float* L2 = L1 + (size_t)B * Bg;
   COATI_TRY(launch_count_valid(bad_all, Bg, scal + 4, scal + 7, s));
