@@ -1,19 +1,26 @@
 // Causal rotary self-attention for head size 16 (reference basic_transformer.py:83-100, 126-154),
-// forward and backward, one 64-lane wave per (batch row, head).
+// forward and backward.  One 64-lane wave per (batch row, head); a workgroup = 4 waves = 4 adjacent heads of
+// one batch row, so the workgroup consumes whole 128-B lines of the [B*T, 3C] qkv matrix.
 //
-// Head size 16 = exactly one K step of v_mfma_f32_32x32x16_bf16, so the kernels are softmax / LDS bound,
-// not MFMA bound.  Everything a (b, head) problem needs (T <= 256 tokens x 16 dims) sits in LDS:
+// Head size 16 = exactly one K step of v_mfma_f32_32x32x16_bf16, so the kernels are softmax / LDS / latency
+// bound, not MFMA bound.  Everything a (b, head) problem needs (T <= 256 tokens x 16 dims) sits in LDS as
+// ROW-MAJOR [T][16] bf16 images:
 //   * q, k are rotated (RoPE, fp32 maths) while being staged and rounded to bf16 once;
 //   * scores are computed TRANSPOSED (S^T = K Q^T) so each lane owns one query column and the softmax
 //     row statistics are lane-local (+ one cross-half shuffle);
 //   * P^T leaves the MFMA accumulator in exactly the layout the next MFMA wants as its B operand, provided
-//     the A operand (V^T, K^T, ...) is read with the same key permutation -- no cross-lane traffic for P;
-//   * the [T,T] score matrix is never materialised; the backward recomputes P from the saved log-sum-exp.
-// Layout: qkv [B*T, 3C] bf16 (q | k | v, head h at columns h*16..h*16+15), y / dy [B*T, C], lse [B, nh, T].
+//     the A operand (V^T, K^T, ...) is read with the same key permutation.  That permuted, transposed A
+//     fragment comes straight out of the row-major image with two ds_read_b64_tr_b16 (the gfx950 LDS
+//     transpose read: a 16-lane group fetches a 4-row x 16-col block, lane i receives column i);
+//   * the [T,T] score matrix is never materialised; the backward recomputes P from the saved log-sum-exp
+//     in two kernels (dQ; dK+dV) -- no atomics, deterministic, ~90 / ~130 registers each.
+// Layout: qkv [B*T, 3C] bf16 (q | k | v, head h at columns h*16..h*16+15), y / dy [B*T, C], lse, D [B, nh, T].
 #include "kernels.h"
 
 #define HS 16
 #define SCALE 0.25f   // 1/sqrt(16)
+typedef short v4s16a __attribute__((ext_vector_type(4)));
+typedef short v8s16a __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ void load16(const bf16_t* p, float* x) {
   const uint4 a = *reinterpret_cast<const uint4*>(p), b = *reinterpret_cast<const uint4*>(p + 8);
@@ -33,37 +40,18 @@ __device__ __forceinline__ void load_cs(const float* tab, int t, float* c) {
   c[0] = a.x; c[1] = a.y; c[2] = a.z; c[3] = a.w; c[4] = b.x; c[5] = b.y; c[6] = b.z; c[7] = b.w;
 }
 
-// stage one [T,16] operand: optional RoPE, row-major image (pitch 16) and/or transposed image (pitch tp)
-template <bool ROPE>
-__device__ __forceinline__ void stage16(const bf16_t* src, long long stride, int T, int Tp, const float* cos_t,
-                                        const float* sin_t, bf16_t* rm, bf16_t* tr, int tp, int lane) {
-  for (int t = lane; t < Tp; t += 64) {
-    float x[16];
-    if (t < T) {
-      load16(src + (long long)t * stride, x);
-      if (ROPE) {
-        float cs[8], sn[8];
-        load_cs(cos_t, t, cs);
-        load_cs(sin_t, t, sn);
-        rope16(x, cs, sn);
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < 16; ++i) x[i] = 0.f;
-    }
-    const uint4 lo = pack8(x), hi = pack8(x + 8);
-    if (rm) {
-      *reinterpret_cast<uint4*>(rm + t * HS) = lo;
-      *reinterpret_cast<uint4*>(rm + t * HS + 8) = hi;
-    }
-    if (tr) {
-      const unsigned w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        tr[(2 * i) * tp + t] = (bf16_t)(w[i] & 0xffffu);
-        tr[(2 * i + 1) * tp + t] = (bf16_t)(w[i] >> 16);
-      }
-    }
+// Cooperative staging of one operand for the 4 heads of a workgroup: rows t < T, 128 contiguous bytes per row
+// (4 heads x 16 dims bf16); 8 consecutive threads fetch one row -> fully coalesced 16-B loads.  Chunk c of a row lands in
+// head (c >> 1)'s row-major image at dims (c & 1) * 8.  Rows [T, Tp) are zero-filled.  q and k arrive already rotated
+// (the QKV GEMM applies RoPE in its epilogue).
+__device__ __forceinline__ void stage4(const bf16_t* src, long long stride, int T, int Tp, unsigned char* smem,
+                                       size_t per_wave_bytes, int image, int heads_here, int tid) {
+  for (int task = tid; task < Tp * 8; task += 256) {
+    const int t = task >> 3, c = task & 7, w = c >> 1;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (t < T && w < heads_here) v = *reinterpret_cast<const uint4*>(src + (long long)t * stride + c * 8);
+    bf16_t* img = reinterpret_cast<bf16_t*>(smem + (size_t)w * per_wave_bytes) + (size_t)image * Tp * HS;
+    *reinterpret_cast<uint4*>(img + t * HS + (c & 1) * 8) = v;
   }
 }
 
@@ -71,15 +59,16 @@ __device__ __forceinline__ void stage16(const bf16_t* src, long long stride, int
 __device__ __forceinline__ bf16x8 rfrag(const bf16_t* rm, int blk, int lane) {
   return *reinterpret_cast<const bf16x8*>(rm + (blk * 32 + (lane & 31)) * HS + (lane >> 5) * 8);
 }
-// A fragment of a transposed [16, tp] image with the accumulator's key permutation:
-// lane (d = lane&31, h = lane>>5), slot j <-> column base + 4h + (j&3) + 8*(j>>2); rows d >= 16 are zero.
-__device__ __forceinline__ bf16x8 tfrag(const bf16_t* tr, int tp, int base, int lane) {
-  const int d = lane & 31, h = lane >> 5;
-  const bf16_t* p = tr + (d & 15) * tp + base + 4 * h;
-  uint2 lo = *reinterpret_cast<const uint2*>(p), hi = *reinterpret_cast<const uint2*>(p + 8);
-  if (d >= 16) { lo = make_uint2(0, 0); hi = make_uint2(0, 0); }
-  const uint4 u = make_uint4(lo.x, lo.y, hi.x, hi.y);
-  return __builtin_bit_cast(bf16x8, u);
+// A fragment X^T[d][row] with the accumulator's row permutation, read from the row-major image with the LDS
+// transpose read: lane (d = lane&31, h = lane>>5), slot j <-> row base + 4h + (j&3) + 8*(j>>2); d >= 16 -> zero.
+__device__ __forceinline__ bf16x8 tfrag(const bf16_t* rm, int base, int lane) {
+  typedef __attribute__((address_space(3))) v4s16a lds_v4;
+  const bf16_t* p = rm + (base + 4 * (lane >> 5) + ((lane & 15) >> 2)) * HS + 4 * (lane & 3);
+  v4s16a lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)p);
+  v4s16a hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(p + 8 * HS));
+  if ((lane & 31) >= 16) { lo = (v4s16a){0, 0, 0, 0}; hi = (v4s16a){0, 0, 0, 0}; }
+  const v8s16a r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8, r);
 }
 __device__ __forceinline__ bf16x8 pfrag(const float* p) {  // 8 accumulator values -> bf16 B fragment
   const uint4 u = pack8(p);
@@ -94,22 +83,25 @@ __device__ __forceinline__ f32x16 zero16() {
 __device__ __forceinline__ int arow(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ y,
-                                                      float* __restrict__ lse, const float* __restrict__ cos_t,
-                                                      const float* __restrict__ sin_t, int T, int n_head) {
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ y,
+                                                       float* __restrict__ lse, int T, int n_head, int quads) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int lane = threadIdx.x;
-  const int b = blockIdx.x / n_head, hh = blockIdx.x - b * n_head;
-  const int C = n_head * HS, Tp = (T + 31) & ~31, tp = Tp + 8;
-  bf16_t* Qs = reinterpret_cast<bf16_t*>(smem);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.x / quads, hq = blockIdx.x - b * quads;
+  const int hh = hq * 4 + wave;
+  const int heads_here = (n_head - hq * 4) < 4 ? (n_head - hq * 4) : 4;
+  const int C = n_head * HS, Tp = (T + 31) & ~31;
+  const size_t pw = (size_t)3 * Tp * HS * 2;
+  bf16_t* Qs = reinterpret_cast<bf16_t*>(smem + (size_t)wave * pw);
   bf16_t* Ks = Qs + Tp * HS;
-  bf16_t* Vt = Ks + Tp * HS;
+  bf16_t* Vs = Ks + Tp * HS;
   const long long stride = 3LL * C;
-  const bf16_t* base = qkv + (long long)b * T * stride + hh * HS;
-  stage16<true>(base, stride, T, Tp, cos_t, sin_t, Qs, nullptr, 0, lane);
-  stage16<true>(base + C, stride, T, Tp, cos_t, sin_t, Ks, nullptr, 0, lane);
-  stage16<false>(base + 2 * C, stride, T, Tp, nullptr, nullptr, nullptr, Vt, tp, lane);
+  const bf16_t* base = qkv + (long long)b * T * stride + hq * 4 * HS;
+  stage4(base, stride, T, Tp, smem, pw, 0, heads_here, threadIdx.x);
+  stage4(base + C, stride, T, Tp, smem, pw, 1, heads_here, threadIdx.x);
+  stage4(base + 2 * C, stride, T, Tp, smem, pw, 2, heads_here, threadIdx.x);
   __syncthreads();
+  if (hh >= n_head) return;
 
   const int nblk = Tp >> 5, half = lane >> 5;
   for (int qb = 0; qb < nblk; ++qb) {
@@ -140,9 +132,9 @@ __global__ __launch_bounds__(64) void attn_fwd_kernel(const bf16_t* __restrict__
       l_run = l_run * alpha + lsum;
       m_run = m_new;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) o[r] *= alpha;
-      o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tfrag(Vt, tp, kb * 32, lane), pfrag(p), o, 0, 0, 0);
-      o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tfrag(Vt, tp, kb * 32 + 16, lane), pfrag(p + 8), o, 0, 0, 0);
+      for (int r = 0; r < 8; ++r) o[r] *= alpha;   // only d < 16 (regs 0..7) is live
+      o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tfrag(Vs, kb * 32, lane), pfrag(p), o, 0, 0, 0);
+      o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tfrag(Vs, kb * 32 + 16, lane), pfrag(p + 8), o, 0, 0, 0);
     }
     if (q < T) {
       const float inv = 1.0f / l_run;
@@ -154,20 +146,31 @@ __global__ __launch_bounds__(64) void attn_fwd_kernel(const bf16_t* __restrict__
   }
 }
 
-int launch_attn_fwd(const bf16_t* qkv, bf16_t* y, float* lse, const float* cos_t, const float* sin_t, int B, int T,
-                    int n_head, hipStream_t s) {
-  COATI_CHECK_ARG(qkv && y && lse && cos_t && sin_t, "attn_fwd: null operand");
+int launch_attn_fwd(const bf16_t* qkv, bf16_t* y, float* lse, int B, int T, int n_head, hipStream_t s) {
+  COATI_CHECK_ARG(qkv && y && lse, "attn_fwd: null operand");
   COATI_CHECK_SHAPE(B > 0 && T > 0 && T <= 256 && n_head > 0, "attn_fwd: unsupported shape B=%d T=%d nh=%d", B, T, n_head);
   const int Tp = (T + 31) & ~31;
-  const size_t lds = (size_t)(2 * Tp * HS + HS * (Tp + 8)) * 2;
-  hipLaunchKernelGGL(attn_fwd_kernel, dim3(B * n_head), dim3(64), lds, s, qkv, y, lse, cos_t, sin_t, T, n_head);
+  const size_t lds = (size_t)4 * 3 * Tp * HS * 2;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    if (e != hipSuccess) {
+      coati_set_error("attn_fwd: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+      return COATI_EHIP;
+    }
+    attr_set = true;
+  }
+  const int quads = cdiv(n_head, 4);
+  hipLaunchKernelGGL(attn_fwd_kernel, dim3(B * quads), dim3(256), lds, s, qkv, y, lse, T, n_head, quads);
   COATI_LAUNCH_CHECK("attn_fwd");
   return COATI_OK;
 }
 
 // ---------------------------------------------------------------------------------------------------
-// backward.  Sweep 1 (per query block): dQ.  Sweep 2 (per key block): dK, dV.  Both recompute P from lse.
-// dS = P * (dP - D) * scale with D[q] = sum_d dO[q,d] O[q,d].  No atomics: fully deterministic.
+// backward.  dS = P * (dP - D) * scale with D[q] = sum_d dO[q,d] O[q,d].
+//   kernel 1 (per query block): dQ^T[d][q] = sum_keys K^T[d][key] dS^T[key][q]          (also writes D)
+//   kernel 2 (per key block)  : dK^T[d][key] = sum_q Q^T[d][q] dS[q][key],  dV^T[d][key] = sum_q dO^T[d][q] P[q][key]
 // ---------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void store_grad_cols(bf16_t* dst, const f32x16& g, int half, bool rope_inv, const float* cos_t,
                                                 const float* sin_t, int t) {
@@ -176,62 +179,67 @@ __device__ __forceinline__ void store_grad_cols(bf16_t* dst, const f32x16& g, in
 #pragma unroll
   for (int j = 0; j < 4; ++j) { a[j] = g[j]; c[j] = g[4 + j]; }
   if (rope_inv) {
+    const float4 cs = *reinterpret_cast<const float4*>(cos_t + t * HS + 4 * half);
+    const float4 sn = *reinterpret_cast<const float4*>(sin_t + t * HS + 4 * half);
+    const float csv[4] = {cs.x, cs.y, cs.z, cs.w}, snv[4] = {sn.x, sn.y, sn.z, sn.w};
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const float cs = cos_t[t * HS + 4 * half + j], sn = sin_t[t * HS + 4 * half + j];
       const float ga = a[j], gc = c[j];
-      a[j] = ga * cs + gc * sn;
-      c[j] = gc * cs - ga * sn;
+      a[j] = ga * csv[j] + gc * snv[j];
+      c[j] = gc * csv[j] - ga * snv[j];
     }
   }
   *reinterpret_cast<uint2*>(dst + 4 * half) = make_uint2(pack2bf(a[0], a[1]), pack2bf(a[2], a[3]));
   *reinterpret_cast<uint2*>(dst + 8 + 4 * half) = make_uint2(pack2bf(c[0], c[1]), pack2bf(c[2], c[3]));
 }
 
-__global__ __launch_bounds__(64) void attn_bwd_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ y,
-                                                      const bf16_t* __restrict__ dy, const float* __restrict__ lse,
-                                                      bf16_t* __restrict__ dqkv, const float* __restrict__ cos_t,
-                                                      const float* __restrict__ sin_t, int T, int n_head) {
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ y,
+                                                          const bf16_t* __restrict__ dy, const float* __restrict__ lse,
+                                                          float* __restrict__ Dout, bf16_t* __restrict__ dqkv,
+                                                          const float* __restrict__ cos_t, const float* __restrict__ sin_t,
+                                                          int T, int n_head, int quads) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int lane = threadIdx.x;
-  const int b = blockIdx.x / n_head, hh = blockIdx.x - b * n_head;
-  const int C = n_head * HS, Tp = (T + 31) & ~31, tp = Tp + 8;
-  bf16_t* Qs = reinterpret_cast<bf16_t*>(smem);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.x / quads, hq = blockIdx.x - b * quads;
+  const int hh = hq * 4 + wave;
+  const int heads_here = (n_head - hq * 4) < 4 ? (n_head - hq * 4) : 4;
+  const int C = n_head * HS, Tp = (T + 31) & ~31;
+  const size_t pw = (size_t)4 * Tp * HS * 2 + (size_t)2 * Tp * 4;
+  unsigned char* my = smem + (size_t)wave * pw;
+  bf16_t* Qs = reinterpret_cast<bf16_t*>(my);
   bf16_t* Ks = Qs + Tp * HS;
   bf16_t* Vs = Ks + Tp * HS;
-  bf16_t* Gs = Vs + Tp * HS;          // dO row-major
-  bf16_t* Qt = Gs + Tp * HS;
-  bf16_t* Kt = Qt + HS * tp;
-  bf16_t* Gt = Kt + HS * tp;          // dO transposed
-  float* Ls = reinterpret_cast<float*>(Gt + HS * tp);
+  bf16_t* Gs = Vs + Tp * HS;
+  float* Ls = reinterpret_cast<float*>(Gs + Tp * HS);
   float* Ds = Ls + Tp;
   const long long stride = 3LL * C;
-  const bf16_t* base = qkv + (long long)b * T * stride + hh * HS;
+  const bf16_t* qbase = qkv + (long long)b * T * stride + hq * 4 * HS;
+  stage4(qbase, stride, T, Tp, smem, pw, 0, heads_here, threadIdx.x);
+  stage4(qbase + C, stride, T, Tp, smem, pw, 1, heads_here, threadIdx.x);
+  stage4(qbase + 2 * C, stride, T, Tp, smem, pw, 2, heads_here, threadIdx.x);
+  stage4(dy + (long long)b * T * C + hq * 4 * HS, (long long)C, T, Tp, smem, pw, 3, heads_here, threadIdx.x);
+  __syncthreads();
+  if (hh >= n_head) return;
   const bf16_t* ybase = y + (long long)b * T * C + hh * HS;
-  const bf16_t* gbase = dy + (long long)b * T * C + hh * HS;
-  stage16<true>(base, stride, T, Tp, cos_t, sin_t, Qs, Qt, tp, lane);
-  stage16<true>(base + C, stride, T, Tp, cos_t, sin_t, Ks, Kt, tp, lane);
-  stage16<false>(base + 2 * C, stride, T, Tp, nullptr, nullptr, Vs, nullptr, 0, lane);
-  stage16<false>(gbase, (long long)C, T, Tp, nullptr, nullptr, Gs, Gt, tp, lane);
   for (int t = lane; t < Tp; t += 64) {
     float d = 0.f, l = INFINITY;
     if (t < T) {
       float o[16], g[16];
       load16(ybase + (long long)t * C, o);
-      load16(gbase + (long long)t * C, g);
+      load16(Gs + t * HS, g);
 #pragma unroll
       for (int i = 0; i < 16; ++i) d += o[i] * g[i];
       l = lse[((long long)b * n_head + hh) * T + t];
+      Dout[((long long)b * n_head + hh) * T + t] = d;
     }
     Ds[t] = d;
     Ls[t] = l;
   }
-  __syncthreads();
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  __builtin_amdgcn_wave_barrier();
 
   const int nblk = Tp >> 5, half = lane >> 5;
   bf16_t* const dbase = dqkv + (long long)b * T * stride + hh * HS;
-
-  // ---- sweep 1: dQ^T[d][q] = sum_keys K^T[d][key] dS^T[key][q] -------------------------------------
   for (int qb = 0; qb < nblk; ++qb) {
     const bf16x8 qf = rfrag(Qs, qb, lane), gf = rfrag(Gs, qb, lane);
     const int q = qb * 32 + (lane & 31);
@@ -247,13 +255,49 @@ __global__ __launch_bounds__(64) void attn_bwd_kernel(const bf16_t* __restrict__
         const float p = (key <= q) ? __expf(s[r] * SCALE - lq) : 0.f;
         ds[r] = p * (dp[r] - dq_) * SCALE;
       }
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tfrag(Kt, tp, kb * 32, lane), pfrag(ds), acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tfrag(Kt, tp, kb * 32 + 16, lane), pfrag(ds + 8), acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tfrag(Ks, kb * 32, lane), pfrag(ds), acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tfrag(Ks, kb * 32 + 16, lane), pfrag(ds + 8), acc, 0, 0, 0);
     }
     if (q < T) store_grad_cols(dbase + (long long)q * stride, acc, half, true, cos_t, sin_t, q);
   }
+}
 
-  // ---- sweep 2: dK^T[d][key] = sum_q Q^T[d][q] dS[q][key],  dV^T[d][key] = sum_q dO^T[d][q] P[q][key] ---
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dy,
+                                                           const float* __restrict__ lse, const float* __restrict__ Din,
+                                                           bf16_t* __restrict__ dqkv, const float* __restrict__ cos_t,
+                                                           const float* __restrict__ sin_t, int T, int n_head, int quads) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.x / quads, hq = blockIdx.x - b * quads;
+  const int hh = hq * 4 + wave;
+  const int heads_here = (n_head - hq * 4) < 4 ? (n_head - hq * 4) : 4;
+  const int C = n_head * HS, Tp = (T + 31) & ~31;
+  const size_t pw = (size_t)4 * Tp * HS * 2 + (size_t)2 * Tp * 4;
+  unsigned char* my = smem + (size_t)wave * pw;
+  bf16_t* Qs = reinterpret_cast<bf16_t*>(my);
+  bf16_t* Ks = Qs + Tp * HS;
+  bf16_t* Vs = Ks + Tp * HS;
+  bf16_t* Gs = Vs + Tp * HS;
+  float* Ls = reinterpret_cast<float*>(Gs + Tp * HS);
+  float* Ds = Ls + Tp;
+  const long long stride = 3LL * C;
+  const bf16_t* qbase = qkv + (long long)b * T * stride + hq * 4 * HS;
+  stage4(qbase, stride, T, Tp, smem, pw, 0, heads_here, threadIdx.x);
+  stage4(qbase + C, stride, T, Tp, smem, pw, 1, heads_here, threadIdx.x);
+  stage4(qbase + 2 * C, stride, T, Tp, smem, pw, 2, heads_here, threadIdx.x);
+  stage4(dy + (long long)b * T * C + hq * 4 * HS, (long long)C, T, Tp, smem, pw, 3, heads_here, threadIdx.x);
+  __syncthreads();
+  if (hh >= n_head) return;
+  for (int t = lane; t < Tp; t += 64) {
+    const long long o = ((long long)b * n_head + hh) * T + t;
+    Ls[t] = (t < T) ? lse[o] : INFINITY;
+    Ds[t] = (t < T) ? Din[o] : 0.f;
+  }
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  __builtin_amdgcn_wave_barrier();
+
+  const int nblk = Tp >> 5, half = lane >> 5;
+  bf16_t* const dbase = dqkv + (long long)b * T * stride + hh * HS;
   for (int kb = 0; kb < nblk; ++kb) {
     const bf16x8 kf = rfrag(Ks, kb, lane), vf = rfrag(Vs, kb, lane);
     const int key = kb * 32 + (lane & 31);
@@ -275,10 +319,10 @@ __global__ __launch_bounds__(64) void attn_bwd_kernel(const bf16_t* __restrict__
           ds[r] = p[r] * (dp[r] - dvv[j]) * SCALE;
         }
       }
-      dv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tfrag(Gt, tp, qb * 32, lane), pfrag(p), dv, 0, 0, 0);
-      dv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tfrag(Gt, tp, qb * 32 + 16, lane), pfrag(p + 8), dv, 0, 0, 0);
-      dk = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tfrag(Qt, tp, qb * 32, lane), pfrag(ds), dk, 0, 0, 0);
-      dk = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tfrag(Qt, tp, qb * 32 + 16, lane), pfrag(ds + 8), dk, 0, 0, 0);
+      dv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tfrag(Gs, qb * 32, lane), pfrag(p), dv, 0, 0, 0);
+      dv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tfrag(Gs, qb * 32 + 16, lane), pfrag(p + 8), dv, 0, 0, 0);
+      dk = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tfrag(Qs, qb * 32, lane), pfrag(ds), dk, 0, 0, 0);
+      dk = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tfrag(Qs, qb * 32 + 16, lane), pfrag(ds + 8), dk, 0, 0, 0);
     }
     if (key < T) {
       store_grad_cols(dbase + (long long)key * stride + C, dk, half, true, cos_t, sin_t, key);
@@ -287,23 +331,30 @@ __global__ __launch_bounds__(64) void attn_bwd_kernel(const bf16_t* __restrict__
   }
 }
 
-int launch_attn_bwd(const bf16_t* qkv, const bf16_t* y, const bf16_t* dy, const float* lse, bf16_t* dqkv,
-                    const float* cos_t, const float* sin_t, int B, int T, int n_head, hipStream_t s) {
-  COATI_CHECK_ARG(qkv && y && dy && lse && dqkv && cos_t && sin_t, "attn_bwd: null operand");
+int launch_attn_bwd(const bf16_t* qkv, const bf16_t* y, const bf16_t* dy, const float* lse, float* dscratch,
+                    bf16_t* dqkv, const float* cos_t, const float* sin_t, int B, int T, int n_head, hipStream_t s) {
+  COATI_CHECK_ARG(qkv && y && dy && lse && dscratch && dqkv && cos_t && sin_t, "attn_bwd: null operand");
   COATI_CHECK_SHAPE(B > 0 && T > 0 && T <= 256 && n_head > 0, "attn_bwd: unsupported shape B=%d T=%d nh=%d", B, T, n_head);
   const int Tp = (T + 31) & ~31;
-  const size_t lds = (size_t)(4 * Tp * HS + 3 * HS * (Tp + 8)) * 2 + (size_t)2 * Tp * 4;
+  const size_t lds = (size_t)4 * (4 * Tp * HS * 2 + 2 * Tp * 4);
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-    if (e != hipSuccess) {
-      coati_set_error("attn_bwd: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+    hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e1 != hipSuccess || e2 != hipSuccess) {
+      coati_set_error("attn_bwd: hipFuncSetAttribute failed");
       return COATI_EHIP;
     }
     attr_set = true;
   }
-  hipLaunchKernelGGL(attn_bwd_kernel, dim3(B * n_head), dim3(64), lds, s, qkv, y, dy, lse, dqkv, cos_t, sin_t, T, n_head);
-  COATI_LAUNCH_CHECK("attn_bwd");
+  const int quads = cdiv(n_head, 4);
+  hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(B * quads), dim3(256), lds, s, qkv, y, dy, lse, dscratch, dqkv, cos_t,
+                     sin_t, T, n_head, quads);
+  COATI_LAUNCH_CHECK("attn_bwd_dq");
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(B * quads), dim3(256), lds, s, qkv, dy, lse, dscratch, dqkv, cos_t,
+                     sin_t, T, n_head, quads);
+  COATI_LAUNCH_CHECK("attn_bwd_dkv");
   return COATI_OK;
 }

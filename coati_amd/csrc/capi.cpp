@@ -65,13 +65,20 @@ int coati_layernorm_bwd(const void* dy, int dy_f32, int64_t lddy, const float* x
   return launch_layernorm_bwd(dy, dy_f32, lddy, x, ldx, x_is_xhat, mean, rstd, gamma, dres, dx, dx16, dgamma, dbeta, M, C, S_(stream));
 }
 
-int coati_attn_fwd(const uint16_t* qkv, uint16_t* y, float* lse, const float* cos_t, const float* sin_t, int B, int T,
-                   int n_head, void* stream) {
-  return launch_attn_fwd(qkv, y, lse, cos_t, sin_t, B, T, n_head, S_(stream));
+int coati_attn_fwd(const uint16_t* qkv, uint16_t* y, float* lse, int B, int T, int n_head, void* stream) {
+  return launch_attn_fwd(qkv, y, lse, B, T, n_head, S_(stream));
 }
-int coati_attn_bwd(const uint16_t* qkv, const uint16_t* y, const uint16_t* dy, const float* lse, uint16_t* dqkv,
+int coati_gemm_qkv_rope(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw, const float* bias, int M, int C,
+                        uint16_t* qkv, int64_t ldc, const float* cos_t, const float* sin_t, int T, void* stream) {
+  GemmArgs a;
+  memset(&a, 0, sizeof(a));
+  a.A = A; a.lda = lda; a.B = W; a.ldb = ldw; a.M = M; a.N = 3 * C; a.K = C; a.C = qkv; a.ldc = ldc; a.bias = bias;
+  a.rope_cos = cos_t; a.rope_sin = sin_t; a.rope_T = T; a.rope_C = C;
+  return launch_gemm_nt(a, 0, EPI_QKV_ROPE, S_(stream));
+}
+int coati_attn_bwd(const uint16_t* qkv, const uint16_t* y, const uint16_t* dy, const float* lse, float* dscratch, uint16_t* dqkv,
                    const float* cos_t, const float* sin_t, int B, int T, int n_head, void* stream) {
-  return launch_attn_bwd(qkv, y, dy, lse, dqkv, cos_t, sin_t, B, T, n_head, S_(stream));
+  return launch_attn_bwd(qkv, y, dy, lse, dscratch, dqkv, cos_t, sin_t, B, T, n_head, S_(stream));
 }
 
 int coati_embed_fwd(const int64_t* idx, const float* table, const float* injection, int unk_token, float* x, int B,

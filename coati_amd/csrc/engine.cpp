@@ -125,6 +125,7 @@ struct coati_engine {
   bf16_t *DX16, *g_DO16;
   float *dcliptok, *dptok, *dstok, *dsa, *dsb, *dhe, *dhs, *dhs_ln, *dhstop, *dhp_ln, *dhpoint;
   bf16_t *dh4, *da, *dyb, *dqkv;
+  float* attnD;
   float *g_DH, *g_DO;
   bf16_t *g_do2, *g_dtd, *g_du, *g_dmi, *g_ds2, *g_dpre1, *g_dP;
   float* opt_partial;
@@ -345,6 +346,7 @@ size_t carve(coati_engine* e, Arena& ar, int B, int T1, int T2, int A, int Bg) {
   e->g_DO16 = ar.take<bf16_t>(BA * H);
   e->dh4 = ar.take<bf16_t>(Mmax * 4 * C); e->da = ar.take<bf16_t>(Mmax * C); e->dyb = ar.take<bf16_t>(Mmax * C);
   e->dqkv = ar.take<bf16_t>(Mmax * 3 * C);
+  e->attnD = ar.take<float>(Mmax * c.n_head);
   e->dcliptok = ar.take<float>((size_t)B * E); e->dptok = ar.take<float>((size_t)B * E); e->dstok = ar.take<float>((size_t)B * E);
   e->dsa = ar.take<float>((size_t)B * E); e->dsb = ar.take<float>((size_t)B * E);
   e->dhe = ar.take<float>((size_t)B * E); e->dhs = ar.take<float>((size_t)B * E);
@@ -372,10 +374,18 @@ int xformer_fwd(coati_engine* e, XPass& p, const float* injection, hipStream_t s
       ProfScope ps(e, SITE_LN_FWD, 0, s);
       COATI_TRY(launch_layernorm_fwd(p.x[l], C, e->P + w.ln1w, e->P + w.ln1b, p.a1[l], C, nullptr, 0, p.mean1[l], p.rstd1[l], M, C, s));
     }
-    COATI_TRY(gemm(e, SITE_QKV_FWD, p.a1[l], 0, C, e->S + w.attnw, C, M, 3 * C, C, p.qkv[l], 3 * C, e->P + w.attnb, EPI_BF16, nullptr, nullptr, 0, s));
+    {
+      // QKV projection with RoPE applied to the q,k blocks in the epilogue (saved qkv holds the ROTATED q,k)
+      GemmArgs a;
+      memset(&a, 0, sizeof(a));
+      a.A = p.a1[l]; a.lda = C; a.B = e->S + w.attnw; a.ldb = C; a.M = M; a.N = 3 * C; a.K = C; a.C = p.qkv[l]; a.ldc = 3 * C;
+      a.bias = e->P + w.attnb; a.rope_cos = e->cos_t; a.rope_sin = e->sin_t; a.rope_T = p.T; a.rope_C = C;
+      ProfScope ps(e, SITE_QKV_FWD, 2.0 * M * 3 * C * C, s);
+      COATI_TRY(launch_gemm_nt(a, 0, EPI_QKV_ROPE, s));
+    }
     {
       ProfScope ps(e, SITE_ATTN_FWD, 4.0 * p.B * (double)p.T * p.T * C, s);
-      COATI_TRY(launch_attn_fwd(p.qkv[l], p.y[l], p.lse[l], e->cos_t, e->sin_t, p.B, p.T, c.n_head, s));
+      COATI_TRY(launch_attn_fwd(p.qkv[l], p.y[l], p.lse[l], p.B, p.T, c.n_head, s));
     }
     COATI_TRY(gemm(e, SITE_PROJ_FWD, p.y[l], 0, C, e->S + w.projw, C, M, C, C, p.xmid[l], C, e->P + w.projb, EPI_RES_F32, p.x[l], nullptr, C, s));
     {
@@ -415,7 +425,7 @@ int xformer_bwd(coati_engine* e, XPass& p, const void* dyf, int dyf_f32, float* 
     COATI_TRY(wgrad(e, SITE_XF_WGRAD, e->DX16, 0, C, p.y[l], C, M, C, C, e->G + w.projw, C, e->G + w.projb, 0, s));
     {
       ProfScope ps(e, SITE_ATTN_BWD, 10.0 * p.B * (double)p.T * p.T * C, s);
-      COATI_TRY(launch_attn_bwd(p.qkv[l], p.y[l], e->dyb, p.lse[l], e->dqkv, e->cos_t, e->sin_t, p.B, p.T, c.n_head, s));
+      COATI_TRY(launch_attn_bwd(p.qkv[l], p.y[l], e->dyb, p.lse[l], e->attnD, e->dqkv, e->cos_t, e->sin_t, p.B, p.T, c.n_head, s));
     }
     COATI_TRY(gemm(e, SITE_QKV_DGRAD, e->dqkv, 0, 3 * C, e->S + w.attnT, 3 * C, M, C, 3 * C, e->da, C, nullptr, EPI_BF16, nullptr, nullptr, 0, s));
     COATI_TRY(wgrad(e, SITE_XF_WGRAD, e->dqkv, 0, 3 * C, p.a1[l], C, M, 3 * C, C, e->G + w.attnw, C, e->G + w.attnb, 0, s));

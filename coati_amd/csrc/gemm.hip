@@ -125,7 +125,7 @@ __device__ __forceinline__ void epilogue8(const GemmArgs& p, int row, int col0, 
     if (rowok && (threadIdx.x & 15) == 0) p.partial[(long long)row * tiles_n + tile_n] = make_float2(mx, sm);
     return;
   }
-  if (!rowok) return;
+  if (!rowok && EPI != EPI_QKV_ROPE) return;
   const int nst = p.n_store > N ? p.n_store : N;
   if (col0 >= nst) return;
   const long long off = (long long)row * p.ldc + col0;
@@ -168,6 +168,19 @@ __device__ __forceinline__ void epilogue8(const GemmArgs& p, int row, int col0, 
   if (EPI == EPI_BF16) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] = v[e];
+  } else if (EPI == EPI_QKV_ROPE) {
+    // head size 16: this lane holds dims (col0 & 8) .. +7 of one head, the partner lane (lane ^ 1) the other half.
+    // RotaryEmbedding.rotary_embed (basic_transformer.py:83-100): y_i = x_i c_i - x_{i+8} s_i ; y_{i+8} = x_{i+8} c_i + x_i s_i
+    const bool hi_half = (col0 & 8) != 0;
+    const int t = row % p.rope_T;
+    const bool rot = col0 < 2 * p.rope_C;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float other = __shfl_xor(v[e], 1, 64);
+      const float c = p.rope_cos[t * 16 + e], s_ = p.rope_sin[t * 16 + e];
+      const float r = hi_half ? (v[e] * c + other * s_) : (v[e] * c - other * s_);
+      o[e] = rot ? r : v[e];
+    }
   } else if (EPI == EPI_GELU || EPI == EPI_SILU) {
     bf16_t* X = reinterpret_cast<bf16_t*>(p.aux_out);
     if (full) {
@@ -222,6 +235,7 @@ __device__ __forceinline__ void epilogue8(const GemmArgs& p, int row, int col0, 
       o[e] = v[e] * dsilu_f(pre);
     }
   }
+  if (!rowok) return;
   bf16_t* C = reinterpret_cast<bf16_t*>(p.C);
   if (col0 + 8 <= nst) {
     if (!full) {
@@ -373,6 +387,7 @@ int launch_gemm_nt(const GemmArgs& a, int a_f32, int epi, hipStream_t s) {
   if (epi == EPI_DGELU || epi == EPI_DSILU) COATI_CHECK_ARG(a.aux_in && a.ld_aux % 8 == 0, "gemm_nt: aux_in missing");
   if (epi == EPI_CE_PARTIAL) COATI_CHECK_ARG(a.partial, "gemm_nt: partial buffer missing");
   if (epi == EPI_CE_BWD) COATI_CHECK_ARG(a.lse && a.target && a.scal, "gemm_nt: CE operands missing");
+  if (epi == EPI_QKV_ROPE) COATI_CHECK_ARG(a.rope_cos && a.rope_sin && a.rope_T > 0 && a.rope_C > 0 && a.N % 16 == 0 && a.rope_C % 16 == 0, "gemm_nt: rope operands missing");
   if (epi == EPI_EDGE_DPRE) COATI_CHECK_ARG(a.P && a.d2 && a.w1c && a.b1 && a.natom > 0 && a.ldp % 8 == 0, "gemm_nt: edge operands missing");
 #define NT_CASE(E)                                                                  \
   case E:                                                                           \
@@ -393,6 +408,7 @@ int launch_gemm_nt(const GemmArgs& a, int a_f32, int epi, hipStream_t s) {
     NT_CASE_B16(EPI_CE_PARTIAL)
     NT_CASE_B16(EPI_CE_BWD)
     NT_CASE_B16(EPI_EDGE_DPRE)
+    NT_CASE_B16(EPI_QKV_ROPE)
     default:
       coati_set_error("gemm_nt: unknown epilogue %d", epi);
       return COATI_EARG;

@@ -18,7 +18,8 @@ enum CoatiEpi {
   EPI_CE_PARTIAL = 8,  // per (row, 128-col tile): (max, sum exp(v-max)) -> partial[row][tile]
   EPI_CE_BWD = 9,      // C(bf16) = (exp(acc - lse[row]) - [col==target[row]]) / count   (0 if target<0)
   EPI_EDGE_DPRE = 10,  // GNN: C(bf16) = acc * SiLU'(Pa[bj] + Pb[bk] + d2*w1c + b1)
-  EPI_COUNT = 11
+  EPI_QKV_ROPE = 11,   // C(bf16) = RoPE(acc + bias) on the q and k column blocks (cols < 2*rope_C), plain on v
+  EPI_COUNT = 12
 };
 
 struct GemmArgs {
@@ -48,6 +49,11 @@ struct GemmArgs {
   const float* b1;
   int natom;
   int H;
+  // rotary epilogue: row m is token t = m % rope_T; tables [n_seq, 16] f32 (head size 16)
+  const float* rope_cos;
+  const float* rope_sin;
+  int rope_T;
+  int rope_C;
 };
 
 int launch_gemm_nt(const GemmArgs& a, int a_f32, int epi, hipStream_t s);
@@ -88,9 +94,8 @@ int launch_layernorm_bwd(const void* dy, int dy_f32, long long lddy, const float
 // ------------------------------------------------------------------------------------------------
 // attention, head size 16 (attention.hip)
 // ------------------------------------------------------------------------------------------------
-int launch_attn_fwd(const bf16_t* qkv, bf16_t* y, float* lse, const float* cos, const float* sin, int B, int T,
-                    int n_head, hipStream_t s);
-int launch_attn_bwd(const bf16_t* qkv, const bf16_t* y, const bf16_t* dy, const float* lse, bf16_t* dqkv,
+int launch_attn_fwd(const bf16_t* qkv, bf16_t* y, float* lse, int B, int T, int n_head, hipStream_t s);
+int launch_attn_bwd(const bf16_t* qkv, const bf16_t* y, const bf16_t* dy, const float* lse, float* dscratch, bf16_t* dqkv,
                     const float* cos, const float* sin, int B, int T, int n_head, hipStream_t s);
 
 // ------------------------------------------------------------------------------------------------

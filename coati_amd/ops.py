@@ -105,18 +105,30 @@ def rope_tables(n_seq, head_size=16, base=10000.0, device="cuda"):
     return emb.cos().contiguous().to(device), emb.sin().contiguous().to(device)
 
 
-def attn_fwd(qkv, B, T, n_head, cos, sin):
+def gemm_qkv_rope(A, W, bias, T, cos, sin):
+    """qkv = [RoPE(q) | RoPE(k) | v] of A @ W^T + bias (rows are (b, t) with t = row % T)."""
+    _need_cuda(A, W)
+    M, C = A.shape
+    out = torch.empty(M, 3 * C, device=A.device, dtype=BF16)
+    _lib.call("coati_gemm_qkv_rope", ptr(A), A.stride(0), ptr(W), W.stride(0), ptr(bias), M, C, ptr(out), 3 * C, ptr(cos),
+              ptr(sin), T, stream())
+    return out
+
+
+def attn_fwd(qkv, B, T, n_head):
+    """causal attention on already-rotated q,k (head size 16)"""
     _need_cuda(qkv)
     C = n_head * 16
     y = torch.empty(B * T, C, device=qkv.device, dtype=BF16)
     lse = torch.empty(B, n_head, T, device=qkv.device, dtype=torch.float32)
-    _lib.call("coati_attn_fwd", ptr(qkv), ptr(y), ptr(lse), ptr(cos), ptr(sin), B, T, n_head, stream())
+    _lib.call("coati_attn_fwd", ptr(qkv), ptr(y), ptr(lse), B, T, n_head, stream())
     return y, lse
 
 
 def attn_bwd(qkv, y, dy, lse, B, T, n_head, cos, sin):
     dqkv = torch.empty_like(qkv)
-    _lib.call("coati_attn_bwd", ptr(qkv), ptr(y), ptr(dy), ptr(lse), ptr(dqkv), ptr(cos), ptr(sin), B, T, n_head, stream())
+    dscratch = torch.empty(B, n_head, T, device=qkv.device, dtype=torch.float32)
+    _lib.call("coati_attn_bwd", ptr(qkv), ptr(y), ptr(dy), ptr(lse), ptr(dscratch), ptr(dqkv), ptr(cos), ptr(sin), B, T, n_head, stream())
     return dqkv
 
 

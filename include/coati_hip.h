@@ -89,12 +89,17 @@ int coati_layernorm_bwd(const void* dy, int dy_f32, int64_t lddy, const float* x
                         const float* mean, const float* rstd, const float* gamma, const float* dres, float* dx,
                         uint16_t* dx16, float* dgamma, float* dbeta, int M, int C, void* stream);
 
-/* RotarySelfAttention core (basic_transformer.py:126-150) for head size 16: RoPE(q,k), causal softmax(q k^T/4) v.
+/* QKV projection with the rotary embedding fused into the epilogue (basic_transformer.py:133-144, 83-100):
+ * qkv[M, 3C] (bf16) = [RoPE(q) | RoPE(k) | v] of A W^T + bias; row m is token position m % T; head size 16. */
+int coati_gemm_qkv_rope(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw, const float* bias, int M, int C,
+                        uint16_t* qkv, int64_t ldc, const float* cos_t, const float* sin_t, int T, void* stream);
+
+/* RotarySelfAttention core (basic_transformer.py:145-150) for head size 16 on ALREADY ROTATED q,k: causal softmax(q k^T/4) v.
+ * The backward returns gradients w.r.t. the un-rotated q,k (it applies the transposed rotation), i.e. w.r.t. A W^T + bias.
  * qkv [B*T, 3*nh*16] bf16, y [B*T, nh*16] bf16, lse [B, nh, T] f32, cos/sin [n_seq, 16] f32 (RotaryEmbedding
- * tables, basic_transformer.py:57-69). */
-int coati_attn_fwd(const uint16_t* qkv, uint16_t* y, float* lse, const float* cos_t, const float* sin_t, int B,
-                   int T, int n_head, void* stream);
-int coati_attn_bwd(const uint16_t* qkv, const uint16_t* y, const uint16_t* dy, const float* lse, uint16_t* dqkv,
+ * tables, basic_transformer.py:57-69).  dscratch: [B, nh, T] f32 scratch (row sums of dO*O) for the backward. */
+int coati_attn_fwd(const uint16_t* qkv, uint16_t* y, float* lse, int B, int T, int n_head, void* stream);
+int coati_attn_bwd(const uint16_t* qkv, const uint16_t* y, const uint16_t* dy, const float* lse, float* dscratch, uint16_t* dqkv,
                    const float* cos_t, const float* sin_t, int B, int T, int n_head, void* stream);
 
 /* token embedding gather with [UNK]-slot injection (basic_transformer.py:80-81, smiles_xformer.py:444-448) */

@@ -52,9 +52,9 @@ for (N, K, f32) in [(768, 256, False), (256, 256, True), (1024, 256, False), (25
 B, T, nh = 1024, 80, 16
 qkv = torch.randn(B*T, 768, device=dev).bfloat16()
 cos, sin = ops.rope_tables(250, 16, device=dev)
-y, lse = ops.attn_fwd(qkv, B, T, nh, cos, sin)
+y, lse = ops.attn_fwd(qkv, B, T, nh)
 dy = torch.randn(B*T, 256, device=dev).bfloat16()
-row("attn fwd", timeit(lambda: ops.attn_fwd(qkv, B, T, nh, cos, sin)), 4.0*B*T*T*256, B*T*1024*2)
+row("attn fwd", timeit(lambda: ops.attn_fwd(qkv, B, T, nh)), 4.0*B*T*T*256, B*T*1024*2)
 row("attn bwd", timeit(lambda: ops.attn_bwd(qkv, y, dy, lse, B, T, nh, cos, sin)), 10.0*B*T*T*256, B*T*2560*2)
 x = torch.randn(B*T, 256, device=dev); g = torch.ones(256, device=dev); b = torch.zeros(256, device=dev)
 y16, _, mean, rstd = ops.layernorm_fwd(x, g, b)
