@@ -78,7 +78,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    # COATI_FORCE_DIST=1 runs the collective path even at world size 1 (single-GPU smoke test of the RCCL calls)
+    dist_on = world > 1 or (os.environ.get("COATI_FORCE_DIST") == "1" and "RANK" in os.environ)
+    if dist_on:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
@@ -108,13 +110,13 @@ def main():
     up = up_cpu.to(dev)
 
     def step():
-        if world > 1:
+        if dist_on:
             D.distributed_train_step(eng, batch, up, lr=5e-4)
         else:
             eng.train_step(batch, up, lr=5e-4)
 
     def sync():
-        if world > 1:
+        if dist_on:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -129,11 +131,11 @@ def main():
     dt = time.perf_counter() - t0
     site_ms, site_n, site_flops = eng.prof_collect()
     eng.prof_select(-1)
-    if world > 1:
+    if dist_on:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t)
-    losses = D.global_losses(eng) if world > 1 else eng.losses()
+    losses = D.global_losses(eng) if dist_on else eng.losses()
 
     if args.all_sites and rank == 0:
         rows = []
@@ -179,7 +181,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(batch_cpu, up_cpu, args.cpu_mols)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist_on:
         torch.distributed.destroy_process_group()
 
 

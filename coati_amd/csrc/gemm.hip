@@ -9,6 +9,7 @@
 // 72 halfs (144 B): 16 consecutive rows then hit 16 distinct 16-B slots of the 256-B bank row, so the
 // ds_read_b128 fragment reads are conflict-free without an XOR swizzle.  The accumulator tile is
 // transposed through LDS so the epilogue works on 8 consecutive columns per lane (16-B stores).
+#include <stdlib.h>
 #include "kernels.h"
 
 #define BM 128
@@ -91,166 +92,10 @@ __device__ __forceinline__ void mma_ktile(const bf16_t* As, const bf16_t* Bs, in
   }
 }
 
-// C/D fragment of v_mfma_f32_32x32x16: lane holds col = lane&31, rows (r&3) + 8*(r>>2) + 4*(lane>>5)
-__device__ __forceinline__ int frag_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
-
-// ---- epilogue on 8 consecutive columns of one row ----------------------------------------------------
-template <int EPI>
-__device__ __forceinline__ void epilogue8(const GemmArgs& p, int row, int col0, float (&v)[8], bool rowok,
-                                          int tile_n, int tiles_n) {
-  const int N = p.N;
-  if (p.bias != nullptr) {
-    if (col0 + 8 <= N) {
-      const float4 b0 = *reinterpret_cast<const float4*>(p.bias + col0), b1 = *reinterpret_cast<const float4*>(p.bias + col0 + 4);
-      v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
-    } else {
-      for (int e = 0; e < 8; ++e)
-        if (col0 + e < N) v[e] += p.bias[col0 + e];
-    }
-  }
-  if (EPI == EPI_CE_PARTIAL) {
-    // every lane of the 16-lane group that shares this row takes part in the shuffles
-    float mx = -INFINITY;
-#pragma unroll
-    for (int e = 0; e < 8; ++e)
-      if (col0 + e < N) mx = fmaxf(mx, v[e]);
-#pragma unroll
-    for (int o = 1; o < 16; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-    float sm = 0.f;
-#pragma unroll
-    for (int e = 0; e < 8; ++e)
-      if (col0 + e < N) sm += __expf(v[e] - mx);
-#pragma unroll
-    for (int o = 1; o < 16; o <<= 1) sm += __shfl_xor(sm, o, 64);
-    if (rowok && (threadIdx.x & 15) == 0) p.partial[(long long)row * tiles_n + tile_n] = make_float2(mx, sm);
-    return;
-  }
-  if (!rowok && EPI != EPI_QKV_ROPE) return;
-  const int nst = p.n_store > N ? p.n_store : N;
-  if (col0 >= nst) return;
-  const long long off = (long long)row * p.ldc + col0;
-  const long long aoff = (long long)row * p.ld_aux + col0;
-  const bool full = (col0 + 8 <= N);
-
-  if (EPI == EPI_F32 || EPI == EPI_RES_F32 || EPI == EPI_ACC_F32) {
-    float* C = reinterpret_cast<float*>(p.C);
-    if (full) {
-      float4 o0 = make_float4(v[0], v[1], v[2], v[3]), o1 = make_float4(v[4], v[5], v[6], v[7]);
-      if (EPI == EPI_RES_F32) {
-        const float* R = reinterpret_cast<const float*>(p.aux_in);
-        const float4 r0 = *reinterpret_cast<const float4*>(R + aoff), r1 = *reinterpret_cast<const float4*>(R + aoff + 4);
-        o0.x += r0.x; o0.y += r0.y; o0.z += r0.z; o0.w += r0.w;
-        o1.x += r1.x; o1.y += r1.y; o1.z += r1.z; o1.w += r1.w;
-      }
-      if (EPI == EPI_ACC_F32) {
-        const float4 r0 = *reinterpret_cast<const float4*>(C + off), r1 = *reinterpret_cast<const float4*>(C + off + 4);
-        o0.x += r0.x; o0.y += r0.y; o0.z += r0.z; o0.w += r0.w;
-        o1.x += r1.x; o1.y += r1.y; o1.z += r1.z; o1.w += r1.w;
-      }
-      *reinterpret_cast<float4*>(C + off) = o0;
-      *reinterpret_cast<float4*>(C + off + 4) = o1;
-    } else {
-      for (int e = 0; e < 8; ++e) {
-        if (col0 + e >= nst) break;
-        float o = (col0 + e < N) ? v[e] : 0.f;
-        if (col0 + e < N) {
-          if (EPI == EPI_RES_F32) o += reinterpret_cast<const float*>(p.aux_in)[aoff + e];
-          if (EPI == EPI_ACC_F32) o += C[off + e];
-        }
-        C[off + e] = o;
-      }
-    }
-    return;
-  }
-
-  // bf16 outputs
-  float o[8];
-  if (EPI == EPI_BF16) {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = v[e];
-  } else if (EPI == EPI_QKV_ROPE) {
-    // head size 16: this lane holds dims (col0 & 8) .. +7 of one head, the partner lane (lane ^ 1) the other half.
-    // RotaryEmbedding.rotary_embed (basic_transformer.py:83-100): y_i = x_i c_i - x_{i+8} s_i ; y_{i+8} = x_{i+8} c_i + x_i s_i
-    const bool hi_half = (col0 & 8) != 0;
-    const int t = row % p.rope_T;
-    const bool rot = col0 < 2 * p.rope_C;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const float other = __shfl_xor(v[e], 1, 64);
-      const float c = p.rope_cos[t * 16 + e], s_ = p.rope_sin[t * 16 + e];
-      const float r = hi_half ? (v[e] * c + other * s_) : (v[e] * c - other * s_);
-      o[e] = rot ? r : v[e];
-    }
-  } else if (EPI == EPI_GELU || EPI == EPI_SILU) {
-    bf16_t* X = reinterpret_cast<bf16_t*>(p.aux_out);
-    if (full) {
-      *reinterpret_cast<uint4*>(X + aoff) = pack8(v);
-    } else {
-      for (int e = 0; e < 8 && col0 + e < N; ++e) X[aoff + e] = f2bf(v[e]);
-    }
-#pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = (EPI == EPI_GELU) ? gelu_f(v[e]) : silu_f(v[e]);
-  } else if (EPI == EPI_DGELU || EPI == EPI_DSILU) {
-    const bf16_t* X = reinterpret_cast<const bf16_t*>(p.aux_in);
-    float x[8];
-    if (full) {
-      unpack8(*reinterpret_cast<const uint4*>(X + aoff), x);
-    } else {
-      for (int e = 0; e < 8; ++e) x[e] = (col0 + e < N) ? bf2f(X[aoff + e]) : 0.f;
-    }
-#pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = v[e] * ((EPI == EPI_DGELU) ? dgelu_f(x[e]) : dsilu_f(x[e]));
-  } else if (EPI == EPI_CE_BWD) {
-    const long long tgt = p.target[row];
-    const float cnt = p.scal[1];
-    const float inv = (tgt >= 0 && cnt > 0.f) ? 1.0f / cnt : 0.f;
-    const float l = p.lse[row];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      float pr = __expf(v[e] - l);
-      if ((long long)(col0 + e) == tgt) pr -= 1.0f;
-      o[e] = pr * inv;
-    }
-  } else if (EPI == EPI_EDGE_DPRE) {
-    const int A = p.natom, H = p.H;
-    const int bj = row / A, b = row / (A * A), k = row - bj * A;
-    const bf16_t* Pa = p.P + (long long)bj * p.ldp + col0;
-    const bf16_t* Pb = p.P + (long long)(b * A + k) * p.ldp + H + col0;
-    const float d2 = p.d2[row];
-    float pa[8], pb[8];
-    if (full) {
-      unpack8(*reinterpret_cast<const uint4*>(Pa), pa);
-      unpack8(*reinterpret_cast<const uint4*>(Pb), pb);
-    } else {
-      for (int e = 0; e < 8; ++e) {
-        pa[e] = (col0 + e < N) ? bf2f(Pa[e]) : 0.f;
-        pb[e] = (col0 + e < N) ? bf2f(Pb[e]) : 0.f;
-      }
-    }
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int c = col0 + e;
-      float pre = 0.f;
-      if (c < N) pre = pa[e] + pb[e] + d2 * p.w1c[(long long)c * p.w1c_stride] + p.b1[c];
-      o[e] = v[e] * dsilu_f(pre);
-    }
-  }
-  if (!rowok) return;
-  bf16_t* C = reinterpret_cast<bf16_t*>(p.C);
-  if (col0 + 8 <= nst) {
-    if (!full) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e)
-        if (col0 + e >= N) o[e] = 0.f;
-    }
-    *reinterpret_cast<uint4*>(C + off) = pack8(o);
-  } else {
-    for (int e = 0; e < 8 && col0 + e < nst; ++e) C[off + e] = (col0 + e < N) ? f2bf(o[e]) : (bf16_t)0;
-  }
-}
+#include "gemm_epi.h"
 
 // ---- NT GEMM kernel -------------------------------------------------------------------------------------
-template <typename AT, typename STAGE_A, int EPI>
+template <typename AT, typename STAGE_A, int EPI, bool PF2>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   bf16_t* const lds = reinterpret_cast<bf16_t*>(smem);
@@ -271,7 +116,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int nk = p.K / BK;
-  if constexpr (sizeof(AT) == 2) {
+  if constexpr (PF2) {
   // Two register stage sets -> two k-tiles of global loads in flight per workgroup (prefetch distance 2): with K = 256
     // (4 k-tiles) the MFMA work per tile (~0.2 us) is far shorter than the memory latency it has to cover.
     STAGE_A sa0, sa1;
@@ -355,10 +200,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
   }
 }
 
-template <typename AT, typename STAGE_A, int EPI>
+template <typename AT, typename STAGE_A, int EPI, bool PF2>
 static int launch_nt_t(const GemmArgs& a, hipStream_t s) {
   static bool attr_set = false;
-  auto kern = gemm_nt_kernel<AT, STAGE_A, EPI>;
+  auto kern = gemm_nt_kernel<AT, STAGE_A, EPI, PF2>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        GEMM_LDS_BYTES);
@@ -389,13 +234,14 @@ int launch_gemm_nt(const GemmArgs& a, int a_f32, int epi, hipStream_t s) {
   if (epi == EPI_CE_BWD) COATI_CHECK_ARG(a.lse && a.target && a.scal, "gemm_nt: CE operands missing");
   if (epi == EPI_QKV_ROPE) COATI_CHECK_ARG(a.rope_cos && a.rope_sin && a.rope_T > 0 && a.rope_C > 0 && a.N % 16 == 0 && a.rope_C % 16 == 0, "gemm_nt: rope operands missing");
   if (epi == EPI_EDGE_DPRE) COATI_CHECK_ARG(a.P && a.d2 && a.w1c && a.b1 && a.natom > 0 && a.ldp % 8 == 0, "gemm_nt: edge operands missing");
+  static const bool pf1 = getenv("COATI_PF2") == nullptr;   // distance-1 prefetch measured equal-or-better (fewer VGPRs)
 #define NT_CASE(E)                                                                  \
   case E:                                                                           \
-    return a_f32 ? launch_nt_t<float, StageF32, E>(a, s) : launch_nt_t<bf16_t, StageB16, E>(a, s);
+    return a_f32 ? launch_nt_t<float, StageF32, E, false>(a, s) : (pf1 ? launch_nt_t<bf16_t, StageB16, E, false>(a, s) : launch_nt_t<bf16_t, StageB16, E, true>(a, s));
 #define NT_CASE_B16(E)                                                              \
   case E:                                                                           \
     COATI_CHECK_ARG(!a_f32, "gemm_nt: epilogue %d has no f32-A variant", (int)E);   \
-    return launch_nt_t<bf16_t, StageB16, E>(a, s);
+    return pf1 ? launch_nt_t<bf16_t, StageB16, E, false>(a, s) : launch_nt_t<bf16_t, StageB16, E, true>(a, s);
   switch (epi) {
     NT_CASE(EPI_BF16)
     NT_CASE(EPI_F32)
@@ -507,14 +353,19 @@ __device__ __forceinline__ void wmma_chunk(const unsigned char* At, const unsign
 }
 
 template <typename AT, bool BIAS>
-__global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs p, int tiles_k, int chunks_per_split) {
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs p, int tiles_k, int chunks_per_split, int n_splits) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int tile_n = blockIdx.x / tiles_k, tile_k = blockIdx.x - tile_n * tiles_k;
+  // 1-D grid, XCD-aware: all output tiles of one M-split run back to back on the same XCD, so the split's A / B slabs
+  // are fetched from HBM once and re-read by the other tiles out of that XCD's L2.
+  const int tiles = gridDim.x / n_splits;
+  const int wg = xcd_swizzle(blockIdx.x, gridDim.x);
+  const int split = wg / tiles, tile = wg - split * tiles;
+  const int tile_n = tile / tiles_k, tile_k = tile - tile_n * tiles_k;
   const int n0 = tile_n * BM, k0 = tile_k * BN;
   const int nchunks = (p.M + 63) / 64;
-  const int c_begin = blockIdx.y * chunks_per_split;
+  const int c_begin = split * chunks_per_split;
   int c_end = c_begin + chunks_per_split;
   if (c_end > nchunks) c_end = nchunks;
   if (c_begin >= c_end) return;
@@ -618,12 +469,13 @@ static int launch_wgrad_t(const WgradArgs& a, hipStream_t s) {
   const int tiles = tiles_n * tiles_k;
   const int nchunks = cdiv(a.M, 64);
   // ~2 workgroups per CU over the whole launch; every split keeps >= 8 chunks (512 rows) of work
-  int splits = cdiv(512, tiles);
+  // 2 workgroups per CU x 256 CUs = 512 resident slots: never launch a partial second round
+  int splits = 512 / tiles;
   if (splits > cdiv(nchunks, 8)) splits = cdiv(nchunks, 8);
   if (splits < 1) splits = 1;
   const int cps = cdiv(nchunks, splits);
   splits = cdiv(nchunks, cps);
-  hipLaunchKernelGGL(kern, dim3(tiles, splits), dim3(256), WGRAD_LDS_BYTES, s, a, tiles_k, cps);
+  hipLaunchKernelGGL(kern, dim3(tiles * splits), dim3(256), WGRAD_LDS_BYTES, s, a, tiles_k, cps, splits);
   COATI_LAUNCH_CHECK("wgrad");
   return COATI_OK;
 }

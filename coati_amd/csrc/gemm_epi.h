@@ -1,0 +1,162 @@
+// Fused GEMM epilogues on "8 consecutive columns of one output row" (shared by gemm.hip and gemm_rb.hip).
+#pragma once
+#include "kernels.h"
+
+// C/D fragment of v_mfma_f32_32x32x16: lane holds col = lane&31, rows (r&3) + 8*(r>>2) + 4*(lane>>5)
+__device__ __forceinline__ int frag_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+// ---- epilogue on 8 consecutive columns of one row ----------------------------------------------------
+template <int EPI, int ROPE_PARTNER = 1>
+__device__ __forceinline__ void epilogue8(const GemmArgs& p, int row, int col0, float (&v)[8], bool rowok,
+                                          int tile_n, int tiles_n) {
+  const int N = p.N;
+  if (p.bias != nullptr) {
+    if (col0 + 8 <= N) {
+      const float4 b0 = *reinterpret_cast<const float4*>(p.bias + col0), b1 = *reinterpret_cast<const float4*>(p.bias + col0 + 4);
+      v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+    } else {
+      for (int e = 0; e < 8; ++e)
+        if (col0 + e < N) v[e] += p.bias[col0 + e];
+    }
+  }
+  if (EPI == EPI_CE_PARTIAL) {
+    // every lane of the 16-lane group that shares this row takes part in the shuffles
+    float mx = -INFINITY;
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      if (col0 + e < N) mx = fmaxf(mx, v[e]);
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    float sm = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      if (col0 + e < N) sm += __expf(v[e] - mx);
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) sm += __shfl_xor(sm, o, 64);
+    if (rowok && (threadIdx.x & 15) == 0) p.partial[(long long)row * tiles_n + tile_n] = make_float2(mx, sm);
+    return;
+  }
+  if (!rowok && EPI != EPI_QKV_ROPE) return;
+  const int nst = p.n_store > N ? p.n_store : N;
+  if (col0 >= nst) return;
+  const long long off = (long long)row * p.ldc + col0;
+  const long long aoff = (long long)row * p.ld_aux + col0;
+  const bool full = (col0 + 8 <= N);
+
+  if (EPI == EPI_F32 || EPI == EPI_RES_F32 || EPI == EPI_ACC_F32) {
+    float* C = reinterpret_cast<float*>(p.C);
+    if (full) {
+      float4 o0 = make_float4(v[0], v[1], v[2], v[3]), o1 = make_float4(v[4], v[5], v[6], v[7]);
+      if (EPI == EPI_RES_F32) {
+        const float* R = reinterpret_cast<const float*>(p.aux_in);
+        const float4 r0 = *reinterpret_cast<const float4*>(R + aoff), r1 = *reinterpret_cast<const float4*>(R + aoff + 4);
+        o0.x += r0.x; o0.y += r0.y; o0.z += r0.z; o0.w += r0.w;
+        o1.x += r1.x; o1.y += r1.y; o1.z += r1.z; o1.w += r1.w;
+      }
+      if (EPI == EPI_ACC_F32) {
+        const float4 r0 = *reinterpret_cast<const float4*>(C + off), r1 = *reinterpret_cast<const float4*>(C + off + 4);
+        o0.x += r0.x; o0.y += r0.y; o0.z += r0.z; o0.w += r0.w;
+        o1.x += r1.x; o1.y += r1.y; o1.z += r1.z; o1.w += r1.w;
+      }
+      *reinterpret_cast<float4*>(C + off) = o0;
+      *reinterpret_cast<float4*>(C + off + 4) = o1;
+    } else {
+      for (int e = 0; e < 8; ++e) {
+        if (col0 + e >= nst) break;
+        float o = (col0 + e < N) ? v[e] : 0.f;
+        if (col0 + e < N) {
+          if (EPI == EPI_RES_F32) o += reinterpret_cast<const float*>(p.aux_in)[aoff + e];
+          if (EPI == EPI_ACC_F32) o += C[off + e];
+        }
+        C[off + e] = o;
+      }
+    }
+    return;
+  }
+
+  // bf16 outputs
+  float o[8];
+  if (EPI == EPI_BF16) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = v[e];
+  } else if (EPI == EPI_QKV_ROPE) {
+    // head size 16: this lane holds dims (col0 & 8) .. +7 of one head, the partner lane (lane ^ 1) the other half.
+    // RotaryEmbedding.rotary_embed (basic_transformer.py:83-100): y_i = x_i c_i - x_{i+8} s_i ; y_{i+8} = x_{i+8} c_i + x_i s_i
+    const bool hi_half = (col0 & 8) != 0;
+    const int t = row % p.rope_T;
+    const bool rot = col0 < 2 * p.rope_C;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float other = __shfl_xor(v[e], ROPE_PARTNER, 64);
+      const float c = p.rope_cos[t * 16 + e], s_ = p.rope_sin[t * 16 + e];
+      const float r = hi_half ? (v[e] * c + other * s_) : (v[e] * c - other * s_);
+      o[e] = rot ? r : v[e];
+    }
+  } else if (EPI == EPI_GELU || EPI == EPI_SILU) {
+    bf16_t* X = reinterpret_cast<bf16_t*>(p.aux_out);
+    if (full) {
+      *reinterpret_cast<uint4*>(X + aoff) = pack8(v);
+    } else {
+      for (int e = 0; e < 8 && col0 + e < N; ++e) X[aoff + e] = f2bf(v[e]);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (EPI == EPI_GELU) ? gelu_f(v[e]) : silu_f(v[e]);
+  } else if (EPI == EPI_DGELU || EPI == EPI_DSILU) {
+    const bf16_t* X = reinterpret_cast<const bf16_t*>(p.aux_in);
+    float x[8];
+    if (full) {
+      unpack8(*reinterpret_cast<const uint4*>(X + aoff), x);
+    } else {
+      for (int e = 0; e < 8; ++e) x[e] = (col0 + e < N) ? bf2f(X[aoff + e]) : 0.f;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = v[e] * ((EPI == EPI_DGELU) ? dgelu_f(x[e]) : dsilu_f(x[e]));
+  } else if (EPI == EPI_CE_BWD) {
+    const long long tgt = p.target[row];
+    const float cnt = p.scal[1];
+    const float inv = (tgt >= 0 && cnt > 0.f) ? 1.0f / cnt : 0.f;
+    const float l = p.lse[row];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float pr = __expf(v[e] - l);
+      if ((long long)(col0 + e) == tgt) pr -= 1.0f;
+      o[e] = pr * inv;
+    }
+  } else if (EPI == EPI_EDGE_DPRE) {
+    const int A = p.natom, H = p.H;
+    const int bj = row / A, b = row / (A * A), k = row - bj * A;
+    const bf16_t* Pa = p.P + (long long)bj * p.ldp + col0;
+    const bf16_t* Pb = p.P + (long long)(b * A + k) * p.ldp + H + col0;
+    const float d2 = p.d2[row];
+    float pa[8], pb[8];
+    if (full) {
+      unpack8(*reinterpret_cast<const uint4*>(Pa), pa);
+      unpack8(*reinterpret_cast<const uint4*>(Pb), pb);
+    } else {
+      for (int e = 0; e < 8; ++e) {
+        pa[e] = (col0 + e < N) ? bf2f(Pa[e]) : 0.f;
+        pb[e] = (col0 + e < N) ? bf2f(Pb[e]) : 0.f;
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int c = col0 + e;
+      float pre = 0.f;
+      if (c < N) pre = pa[e] + pb[e] + d2 * p.w1c[(long long)c * p.w1c_stride] + p.b1[c];
+      o[e] = v[e] * dsilu_f(pre);
+    }
+  }
+  if (!rowok) return;
+  bf16_t* C = reinterpret_cast<bf16_t*>(p.C);
+  if (col0 + 8 <= nst) {
+    if (!full) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if (col0 + e >= N) o[e] = 0.f;
+    }
+    *reinterpret_cast<uint4*>(C + off) = pack8(o);
+  } else {
+    for (int e = 0; e < 8 && col0 + e < nst; ++e) C[off + e] = (col0 + e < N) ? f2bf(o[e]) : (bf16_t)0;
+  }
+}
+
