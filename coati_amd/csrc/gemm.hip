@@ -31,39 +31,43 @@ __device__ __forceinline__ int xcd_swizzle(int bid, int nwg) {
 struct StageB16 { uint4 v[4]; };
 struct StageF32 { float4 v[8]; };
 
+template <int NT>
 __device__ __forceinline__ void stage_load(StageB16& s, const bf16_t* base, long long ld, int row0, int rows,
                                            int k0, int tid) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int c = tid + 256 * i, row = c >> 3, kc = (c & 7) * 8;
+  for (int i = 0; i < 1024 / NT; ++i) {
+    const int c = tid + NT * i, row = c >> 3, kc = (c & 7) * 8;
     const int g = row0 + row;
     const int gc = g < rows ? g : rows - 1;   // always a valid address; out-of-range rows are zeroed by select
     const uint4 t = *reinterpret_cast<const uint4*>(base + (long long)gc * ld + k0 + kc);
     s.v[i] = (g < rows) ? t : make_uint4(0, 0, 0, 0);
   }
 }
+template <int NT>
 __device__ __forceinline__ void stage_store(const StageB16& s, bf16_t* S, int tid) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int c = tid + 256 * i, row = c >> 3, kc = (c & 7) * 8;
+  for (int i = 0; i < 1024 / NT; ++i) {
+    const int c = tid + NT * i, row = c >> 3, kc = (c & 7) * 8;
     *reinterpret_cast<uint4*>(S + row * PITCH + kc) = s.v[i];
   }
 }
+template <int NT>
 __device__ __forceinline__ void stage_load(StageF32& s, const float* base, long long ld, int row0, int rows,
                                            int k0, int tid) {
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int c = tid + 256 * i, row = c >> 4, kc = (c & 15) * 4;
+  for (int i = 0; i < 2048 / NT; ++i) {
+    const int c = tid + NT * i, row = c >> 4, kc = (c & 15) * 4;
     const int g = row0 + row;
     const int gc = g < rows ? g : rows - 1;
     const float4 t = *reinterpret_cast<const float4*>(base + (long long)gc * ld + k0 + kc);
     s.v[i] = (g < rows) ? t : make_float4(0.f, 0.f, 0.f, 0.f);
   }
 }
+template <int NT>
 __device__ __forceinline__ void stage_store(const StageF32& s, bf16_t* S, int tid) {
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int c = tid + 256 * i, row = c >> 4, kc = (c & 15) * 4;
+  for (int i = 0; i < 2048 / NT; ++i) {
+    const int c = tid + NT * i, row = c >> 4, kc = (c & 15) * 4;
     uint2 u;
     u.x = pack2bf(s.v[i].x, s.v[i].y);
     u.y = pack2bf(s.v[i].z, s.v[i].w);
@@ -72,20 +76,21 @@ __device__ __forceinline__ void stage_store(const StageF32& s, bf16_t* S, int ti
 }
 
 // ---- MFMA over one staged k-tile: each wave owns a 64x64 sub-tile ----------------------------------
+template <int MI>
 __device__ __forceinline__ void mma_ktile(const bf16_t* As, const bf16_t* Bs, int wm, int wn, int lane,
-                                          f32x16 (&acc)[2][2]) {
+                                          f32x16 (&acc)[MI][2]) {
   const int r = lane & 31, kg = (lane >> 5) * 8;
 #pragma unroll
   for (int ks = 0; ks < BK / 16; ++ks) {
-    bf16x8 a[2], b[2];
+    bf16x8 a[MI], b[2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-      a[i] = *reinterpret_cast<const bf16x8*>(As + (wm * 64 + i * 32 + r) * PITCH + ks * 16 + kg);
+    for (int i = 0; i < MI; ++i)
+      a[i] = *reinterpret_cast<const bf16x8*>(As + (wm * 32 * MI + i * 32 + r) * PITCH + ks * 16 + kg);
 #pragma unroll
     for (int j = 0; j < 2; ++j)
       b[j] = *reinterpret_cast<const bf16x8*>(Bs + (wn * 64 + j * 32 + r) * PITCH + ks * 16 + kg);
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
       for (int j = 0; j < 2; ++j)
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
@@ -95,8 +100,11 @@ __device__ __forceinline__ void mma_ktile(const bf16_t* As, const bf16_t* Bs, in
 #include "gemm_epi.h"
 
 // ---- NT GEMM kernel -------------------------------------------------------------------------------------
-template <typename AT, typename STAGE_A, int EPI, bool PF2>
-__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
+// WAVES = 4: each wave owns 64x64 of the 128x128 tile (2x2 MFMA tiles); WAVES = 8: 32x64 per wave (1x2).  The 8-wave
+// form doubles the resident waves per CU (LDS still allows 2 workgroups) and halves the per-thread epilogue work.
+template <typename AT, typename STAGE_A, int EPI, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, 2) void gemm_nt_kernel(GemmArgs p) {
+  constexpr int NT = 64 * WAVES, MI = 8 / WAVES;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   bf16_t* const lds = reinterpret_cast<bf16_t*>(smem);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -107,91 +115,50 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const AT* A = reinterpret_cast<const AT*>(p.A);
 
-  f32x16 acc[2][2];
+  f32x16 acc[MI][2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  // register-staged double buffer: the loads of k-tile kt+1 are issued before the MFMAs of k-tile kt
   const int nk = p.K / BK;
-  if constexpr (PF2) {
-  // Two register stage sets -> two k-tiles of global loads in flight per workgroup (prefetch distance 2): with K = 256
-    // (4 k-tiles) the MFMA work per tile (~0.2 us) is far shorter than the memory latency it has to cover.
-    STAGE_A sa0, sa1;
-    StageB16 sb0, sb1;
-    stage_load(sa0, A, p.lda, m0, p.M, 0, tid);
-    stage_load(sb0, p.B, p.ldb, n0, p.N, 0, tid);
-    if (nk > 1) {
-      stage_load(sa1, A, p.lda, m0, p.M, BK, tid);
-      stage_load(sb1, p.B, p.ldb, n0, p.N, BK, tid);
+  STAGE_A sa;
+  StageB16 sb;
+  stage_load<NT>(sa, A, p.lda, m0, p.M, 0, tid);
+  stage_load<NT>(sb, p.B, p.ldb, n0, p.N, 0, tid);
+  stage_store<NT>(sa, lds, tid);
+  stage_store<NT>(sb, lds + 2 * TILE_HALFS, tid);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) {
+      stage_load<NT>(sa, A, p.lda, m0, p.M, (kt + 1) * BK, tid);
+      stage_load<NT>(sb, p.B, p.ldb, n0, p.N, (kt + 1) * BK, tid);
     }
-    stage_store(sa0, lds, tid);
-    stage_store(sb0, lds + 2 * TILE_HALFS, tid);
+    mma_ktile<MI>(lds + cur * TILE_HALFS, lds + (2 + cur) * TILE_HALFS, wm, wn, lane, acc);
+    if (kt + 1 < nk) {
+      stage_store<NT>(sa, lds + (cur ^ 1) * TILE_HALFS, tid);
+      stage_store<NT>(sb, lds + (2 + (cur ^ 1)) * TILE_HALFS, tid);
+    }
     __syncthreads();
-    for (int kt = 0; kt < nk; kt += 2) {
-      // even tile kt lives in LDS buffer 0; set 0 is free again
-      if (kt + 2 < nk) {
-        stage_load(sa0, A, p.lda, m0, p.M, (kt + 2) * BK, tid);
-        stage_load(sb0, p.B, p.ldb, n0, p.N, (kt + 2) * BK, tid);
-      }
-      mma_ktile(lds, lds + 2 * TILE_HALFS, wm, wn, lane, acc);
-      if (kt + 1 < nk) {
-        stage_store(sa1, lds + TILE_HALFS, tid);
-        stage_store(sb1, lds + 3 * TILE_HALFS, tid);
-      }
-      __syncthreads();
-      if (kt + 1 >= nk) break;
-      // odd tile kt+1 lives in LDS buffer 1; set 1 is free again
-      if (kt + 3 < nk) {
-        stage_load(sa1, A, p.lda, m0, p.M, (kt + 3) * BK, tid);
-        stage_load(sb1, p.B, p.ldb, n0, p.N, (kt + 3) * BK, tid);
-      }
-      mma_ktile(lds + TILE_HALFS, lds + 3 * TILE_HALFS, wm, wn, lane, acc);
-      if (kt + 2 < nk) {
-        stage_store(sa0, lds, tid);
-        stage_store(sb0, lds + 2 * TILE_HALFS, tid);
-      }
-      __syncthreads();
-    }
-  } else {
-    // f32 A: the staging registers of a second set do not fit; plain distance-1 prefetch
-    STAGE_A sa;
-    StageB16 sb;
-    stage_load(sa, A, p.lda, m0, p.M, 0, tid);
-    stage_load(sb, p.B, p.ldb, n0, p.N, 0, tid);
-    stage_store(sa, lds, tid);
-    stage_store(sb, lds + 2 * TILE_HALFS, tid);
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-      const int cur = kt & 1;
-      if (kt + 1 < nk) {
-        stage_load(sa, A, p.lda, m0, p.M, (kt + 1) * BK, tid);
-        stage_load(sb, p.B, p.ldb, n0, p.N, (kt + 1) * BK, tid);
-      }
-      mma_ktile(lds + cur * TILE_HALFS, lds + (2 + cur) * TILE_HALFS, wm, wn, lane, acc);
-      if (kt + 1 < nk) {
-        stage_store(sa, lds + (cur ^ 1) * TILE_HALFS, tid);
-        stage_store(sb, lds + (2 + (cur ^ 1)) * TILE_HALFS, tid);
-      }
-      __syncthreads();
-    }
   }
 
   // accumulators -> LDS (fp32) -> row-contiguous epilogue
   float* Cs = reinterpret_cast<float*>(smem);
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r)
-        Cs[(wm * 64 + i * 32 + frag_row(r, lane)) * CPITCH + wn * 64 + j * 32 + (lane & 31)] = acc[i][j][r];
+        Cs[(wm * 32 * MI + i * 32 + frag_row(r, lane)) * CPITCH + wn * 64 + j * 32 + (lane & 31)] = acc[i][j][r];
   __syncthreads();
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int task = tid + 256 * i, r = task >> 4, cg = task & 15;
+  for (int i = 0; i < 2048 / NT; ++i) {
+    const int task = tid + NT * i, r = task >> 4, cg = task & 15;
     float v[8];
     const float4 c0 = *reinterpret_cast<const float4*>(Cs + r * CPITCH + cg * 8);
     const float4 c1 = *reinterpret_cast<const float4*>(Cs + r * CPITCH + cg * 8 + 4);
@@ -200,10 +167,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
   }
 }
 
-template <typename AT, typename STAGE_A, int EPI, bool PF2>
+template <typename AT, typename STAGE_A, int EPI, int WAVES>
 static int launch_nt_t(const GemmArgs& a, hipStream_t s) {
   static bool attr_set = false;
-  auto kern = gemm_nt_kernel<AT, STAGE_A, EPI, PF2>;
+  auto kern = gemm_nt_kernel<AT, STAGE_A, EPI, WAVES>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        GEMM_LDS_BYTES);
@@ -214,7 +181,7 @@ static int launch_nt_t(const GemmArgs& a, hipStream_t s) {
     attr_set = true;
   }
   const int tiles = cdiv(a.M, BM) * cdiv(a.N, BN);
-  hipLaunchKernelGGL(kern, dim3(tiles), dim3(256), GEMM_LDS_BYTES, s, a);
+  hipLaunchKernelGGL(kern, dim3(tiles), dim3(64 * WAVES), GEMM_LDS_BYTES, s, a);
   COATI_LAUNCH_CHECK("gemm_nt");
   return COATI_OK;
 }
@@ -234,14 +201,14 @@ int launch_gemm_nt(const GemmArgs& a, int a_f32, int epi, hipStream_t s) {
   if (epi == EPI_CE_BWD) COATI_CHECK_ARG(a.lse && a.target && a.scal, "gemm_nt: CE operands missing");
   if (epi == EPI_QKV_ROPE) COATI_CHECK_ARG(a.rope_cos && a.rope_sin && a.rope_T > 0 && a.rope_C > 0 && a.N % 16 == 0 && a.rope_C % 16 == 0, "gemm_nt: rope operands missing");
   if (epi == EPI_EDGE_DPRE) COATI_CHECK_ARG(a.P && a.d2 && a.w1c && a.b1 && a.natom > 0 && a.ldp % 8 == 0, "gemm_nt: edge operands missing");
-  static const bool pf1 = getenv("COATI_PF2") == nullptr;   // distance-1 prefetch measured equal-or-better (fewer VGPRs)
+  static const bool w4 = getenv("COATI_GEMM_W4") != nullptr;   // A/B switch: 4-wave instead of 8-wave workgroups
 #define NT_CASE(E)                                                                  \
   case E:                                                                           \
-    return a_f32 ? launch_nt_t<float, StageF32, E, false>(a, s) : (pf1 ? launch_nt_t<bf16_t, StageB16, E, false>(a, s) : launch_nt_t<bf16_t, StageB16, E, true>(a, s));
+    return a_f32 ? launch_nt_t<float, StageF32, E, 4>(a, s) : (w4 ? launch_nt_t<bf16_t, StageB16, E, 4>(a, s) : launch_nt_t<bf16_t, StageB16, E, 8>(a, s));
 #define NT_CASE_B16(E)                                                              \
   case E:                                                                           \
     COATI_CHECK_ARG(!a_f32, "gemm_nt: epilogue %d has no f32-A variant", (int)E);   \
-    return pf1 ? launch_nt_t<bf16_t, StageB16, E, false>(a, s) : launch_nt_t<bf16_t, StageB16, E, true>(a, s);
+    return w4 ? launch_nt_t<bf16_t, StageB16, E, 4>(a, s) : launch_nt_t<bf16_t, StageB16, E, 8>(a, s);
   switch (epi) {
     NT_CASE(EPI_BF16)
     NT_CASE(EPI_F32)
@@ -493,12 +460,15 @@ int launch_wgrad(const WgradArgs& a, int a_f32, hipStream_t s) {
 // exact-f32 MFMA GEMM with generic strides (small problems: heads, InfoNCE logits and their grads)
 // =================================================================================================
 #define SPITCH 65
+#define SBK 32
+// 64x64 tile per 256-thread workgroup (one 32x32 MFMA tile per wave), BK = 32, register-prefetched double-buffered
+// LDS: the next k-tile's (generic-stride) loads are in flight while the current one feeds 16 MFMAs per wave.
 __global__ __launch_bounds__(256) void sgemm_kernel(const float* __restrict__ A, long long ars, long long acs,
                                                     const float* __restrict__ B, long long brs, long long bcs,
                                                     float* __restrict__ C, long long ldc, int M, int N, int K,
                                                     const float* __restrict__ bias, float alpha, int accumulate) {
-  __shared__ float As[16 * SPITCH];
-  __shared__ float Bs[16 * SPITCH];
+  __shared__ float As[2][SBK * SPITCH];
+  __shared__ float Bs[2][SBK * SPITCH];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
@@ -506,27 +476,48 @@ __global__ __launch_bounds__(256) void sgemm_kernel(const float* __restrict__ A,
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   const bool a_kfast = (acs == 1), b_kfast = (brs == 1);
-  for (int k0 = 0; k0 < K; k0 += 16) {
+  float ra[8], rb[8];
+  auto load_tile = [&](int k0) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 8; ++i) {
       const int id = tid + 256 * i;
       int m, k;
-      if (a_kfast) { k = id & 15; m = id >> 4; } else { m = id & 63; k = id >> 6; }
+      if (a_kfast) { k = id & 31; m = id >> 5; } else { m = id & 63; k = id >> 6; }
       const int gm = m0 + m, gk = k0 + k;
-      As[k * SPITCH + m] = (gm < M && gk < K) ? A[gm * ars + gk * acs] : 0.f;
+      ra[i] = (gm < M && gk < K) ? A[gm * ars + gk * acs] : 0.f;
       int n, kb;
-      if (b_kfast) { kb = id & 15; n = id >> 4; } else { n = id & 63; kb = id >> 6; }
+      if (b_kfast) { kb = id & 31; n = id >> 5; } else { n = id & 63; kb = id >> 6; }
       const int gn = n0 + n, gkb = k0 + kb;
-      Bs[kb * SPITCH + n] = (gn < N && gkb < K) ? B[gkb * brs + gn * bcs] : 0.f;
+      rb[i] = (gn < N && gkb < K) ? B[gkb * brs + gn * bcs] : 0.f;
     }
-    __syncthreads();
+  };
+  auto store_tile = [&](int buf) {
 #pragma unroll
-    for (int kk = 0; kk < 8; ++kk) {
+    for (int i = 0; i < 8; ++i) {
+      const int id = tid + 256 * i;
+      int m, k;
+      if (a_kfast) { k = id & 31; m = id >> 5; } else { m = id & 63; k = id >> 6; }
+      As[buf][k * SPITCH + m] = ra[i];
+      int n, kb;
+      if (b_kfast) { kb = id & 31; n = id >> 5; } else { n = id & 63; kb = id >> 6; }
+      Bs[buf][kb * SPITCH + n] = rb[i];
+    }
+  };
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+  const int nk = (K + SBK - 1) / SBK;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) load_tile((kt + 1) * SBK);
+#pragma unroll
+    for (int kk = 0; kk < SBK / 2; ++kk) {
       const int k = 2 * kk + (lane >> 5);
-      const float a = As[k * SPITCH + wm * 32 + (lane & 31)];
-      const float b = Bs[k * SPITCH + wn * 32 + (lane & 31)];
+      const float a = As[cur][k * SPITCH + wm * 32 + (lane & 31)];
+      const float b = Bs[cur][k * SPITCH + wn * 32 + (lane & 31)];
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
     }
+    if (kt + 1 < nk) store_tile(cur ^ 1);
     __syncthreads();
   }
 #pragma unroll
