@@ -251,15 +251,15 @@ __device__ __forceinline__ unsigned wt_offset(int row, int bytecol) {
   return (unsigned)(row * WT_ROW_BYTES + ((((bytecol >> 6) ^ (row & 3)) << 6) | (bytecol & 63)));
 }
 
-template <typename AT>
+template <typename AT, int NT>
 __device__ __forceinline__ void wstage_load(StageW& s, const AT* base, long long ld, int m0, int m_end, int c0,
                                             int ncols, int tid) {
   const int col = c0 + (tid & 15) * 8;
   const bool colok = col < ncols;
   const int colc = colok ? col : 0;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int m = m0 + (tid >> 4) + 16 * i;
+  for (int i = 0; i < 1024 / NT; ++i) {
+    const int m = m0 + (tid >> 4) + (NT / 16) * i;
     const int mc = m < m_end ? m : m_end - 1;
     uint4 t;
     if constexpr (sizeof(AT) == 2) {
@@ -272,16 +272,18 @@ __device__ __forceinline__ void wstage_load(StageW& s, const AT* base, long long
     s.v[i] = (m < m_end && colok) ? t : make_uint4(0, 0, 0, 0);
   }
 }
+template <int NT>
 __device__ __forceinline__ void wstage_store(const StageW& s, unsigned char* T, int tid) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = (tid >> 4) + 16 * i;
+  for (int i = 0; i < 1024 / NT; ++i) {
+    const int row = (tid >> 4) + (NT / 16) * i;
     *reinterpret_cast<uint4*>(T + wt_offset(row, (tid & 15) * 16)) = s.v[i];
   }
 }
+template <int NT>
 __device__ __forceinline__ void wstage_colsum(const StageW& s, float (&csum)[8]) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < 1024 / NT; ++i) {
     float f[8];
     unpack8(s.v[i], f);
 #pragma unroll
@@ -302,25 +304,27 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* T, int mbase, int
   return __builtin_bit_cast(bf16x8, r);
 }
 
+template <int MI>
 __device__ __forceinline__ void wmma_chunk(const unsigned char* At, const unsigned char* Bt, int wm, int wn, int lane,
-                                           f32x16 (&acc)[2][2]) {
+                                           f32x16 (&acc)[MI][2]) {
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) {
-    bf16x8 a[2], b[2];
+    bf16x8 a[MI], b[2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) a[i] = tr_frag(At, ks * 16, wm * 64 + i * 32, lane);
+    for (int i = 0; i < MI; ++i) a[i] = tr_frag(At, ks * 16, wm * 32 * MI + i * 32, lane);
 #pragma unroll
     for (int j = 0; j < 2; ++j) b[j] = tr_frag(Bt, ks * 16, wn * 64 + j * 32, lane);
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
       for (int j = 0; j < 2; ++j)
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
   }
 }
 
-template <typename AT, bool BIAS>
-__global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs p, int tiles_k, int chunks_per_split, int n_splits) {
+template <typename AT, bool BIAS, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, 2) void wgrad_kernel(WgradArgs p, int tiles_k, int chunks_per_split, int n_splits) {
+  constexpr int NT = 64 * WAVES, MI = 8 / WAVES;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -343,9 +347,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs p, int tiles_k,
   unsigned char* const Bt0 = smem + 2 * WT_TILE_BYTES;
   unsigned char* const Bt1 = smem + 3 * WT_TILE_BYTES;
 
-  f32x16 acc[2][2];
+  f32x16 acc[MI][2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -356,56 +360,56 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs p, int tiles_k,
   const bool do_bias = BIAS && (tile_k == 0);
 
   StageW sa0, sb0, sa1, sb1;
-  wstage_load<AT>(sa0, A, p.lda, c_begin * 64, p.M, n0, p.N, tid);
-  wstage_load<bf16_t>(sb0, p.B, p.ldb, c_begin * 64, p.M, k0, p.K, tid);
+  wstage_load<AT, NT>(sa0, A, p.lda, c_begin * 64, p.M, n0, p.N, tid);
+  wstage_load<bf16_t, NT>(sb0, p.B, p.ldb, c_begin * 64, p.M, k0, p.K, tid);
   if (c_begin + 1 < c_end) {
-    wstage_load<AT>(sa1, A, p.lda, (c_begin + 1) * 64, p.M, n0, p.N, tid);
-    wstage_load<bf16_t>(sb1, p.B, p.ldb, (c_begin + 1) * 64, p.M, k0, p.K, tid);
+    wstage_load<AT, NT>(sa1, A, p.lda, (c_begin + 1) * 64, p.M, n0, p.N, tid);
+    wstage_load<bf16_t, NT>(sb1, p.B, p.ldb, (c_begin + 1) * 64, p.M, k0, p.K, tid);
   }
-  if (do_bias) wstage_colsum(sa0, csum);
-  wstage_store(sa0, At0, tid);
-  wstage_store(sb0, Bt0, tid);
+  if (do_bias) wstage_colsum<NT>(sa0, csum);
+  wstage_store<NT>(sa0, At0, tid);
+  wstage_store<NT>(sb0, Bt0, tid);
   __syncthreads();
   for (int c = c_begin; c < c_end; c += 2) {
     if (c + 2 < c_end) {
-      wstage_load<AT>(sa0, A, p.lda, (c + 2) * 64, p.M, n0, p.N, tid);
-      wstage_load<bf16_t>(sb0, p.B, p.ldb, (c + 2) * 64, p.M, k0, p.K, tid);
+      wstage_load<AT, NT>(sa0, A, p.lda, (c + 2) * 64, p.M, n0, p.N, tid);
+      wstage_load<bf16_t, NT>(sb0, p.B, p.ldb, (c + 2) * 64, p.M, k0, p.K, tid);
     }
-    wmma_chunk(At0, Bt0, wm, wn, lane, acc);
+    wmma_chunk<MI>(At0, Bt0, wm, wn, lane, acc);
     if (c + 1 < c_end) {
-      if (do_bias) wstage_colsum(sa1, csum);
-      wstage_store(sa1, At1, tid);
-      wstage_store(sb1, Bt1, tid);
+      if (do_bias) wstage_colsum<NT>(sa1, csum);
+      wstage_store<NT>(sa1, At1, tid);
+      wstage_store<NT>(sb1, Bt1, tid);
     }
     __syncthreads();
     if (c + 1 >= c_end) break;
     if (c + 3 < c_end) {
-      wstage_load<AT>(sa1, A, p.lda, (c + 3) * 64, p.M, n0, p.N, tid);
-      wstage_load<bf16_t>(sb1, p.B, p.ldb, (c + 3) * 64, p.M, k0, p.K, tid);
+      wstage_load<AT, NT>(sa1, A, p.lda, (c + 3) * 64, p.M, n0, p.N, tid);
+      wstage_load<bf16_t, NT>(sb1, p.B, p.ldb, (c + 3) * 64, p.M, k0, p.K, tid);
     }
-    wmma_chunk(At1, Bt1, wm, wn, lane, acc);
+    wmma_chunk<MI>(At1, Bt1, wm, wn, lane, acc);
     if (c + 2 < c_end) {
-      if (do_bias) wstage_colsum(sa0, csum);
-      wstage_store(sa0, At0, tid);
-      wstage_store(sb0, Bt0, tid);
+      if (do_bias) wstage_colsum<NT>(sa0, csum);
+      wstage_store<NT>(sa0, At0, tid);
+      wstage_store<NT>(sb0, Bt0, tid);
     }
     __syncthreads();
   }
 
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int n = n0 + wm * 64 + i * 32 + frag_row(r, lane);
+        const int n = n0 + wm * 32 * MI + i * 32 + frag_row(r, lane);
         const int k = k0 + wn * 64 + j * 32 + (lane & 31);
         if (n < nout && k < p.K) atomicAdd(p.dW + (long long)n * p.ldw + k, acc[i][j][r]);
       }
 
   if (do_bias) {
     // reduce the 16 row-groups that share a column octet, then one atomic per column
-    float* red = reinterpret_cast<float*>(smem);  // [16][128]
+    float* red = reinterpret_cast<float*>(smem);  // [NT/16][128]
     const int noct = tid & 15, mq = tid >> 4;
 #pragma unroll
     for (int e = 0; e < 8; ++e) red[mq * 128 + noct * 8 + e] = csum[e];
@@ -413,7 +417,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs p, int tiles_k,
     if (tid < 128) {
       float t = 0.f;
 #pragma unroll
-      for (int q = 0; q < 16; ++q) t += red[q * 128 + tid];
+      for (int q = 0; q < NT / 16; ++q) t += red[q * 128 + tid];
       if (n0 + tid < nout) atomicAdd(p.dbias + n0 + tid, t);
     }
   }
@@ -422,7 +426,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs p, int tiles_k,
 template <typename AT, bool BIAS>
 static int launch_wgrad_t(const WgradArgs& a, hipStream_t s) {
   static bool attr_set = false;
-  auto kern = wgrad_kernel<AT, BIAS>;
+  constexpr int WAVES = 4;   // measured: 8 waves is no faster without bias and slower with the bias column sums
+  auto kern = wgrad_kernel<AT, BIAS, WAVES>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        WGRAD_LDS_BYTES);
@@ -442,7 +447,7 @@ static int launch_wgrad_t(const WgradArgs& a, hipStream_t s) {
   if (splits < 1) splits = 1;
   const int cps = cdiv(nchunks, splits);
   splits = cdiv(nchunks, cps);
-  hipLaunchKernelGGL(kern, dim3(tiles * splits), dim3(256), WGRAD_LDS_BYTES, s, a, tiles_k, cps, splits);
+  hipLaunchKernelGGL(kern, dim3(tiles * splits), dim3(64 * WAVES), WGRAD_LDS_BYTES, s, a, tiles_k, cps, splits);
   COATI_LAUNCH_CHECK("wgrad");
   return COATI_OK;
 }
