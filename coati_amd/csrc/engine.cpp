@@ -129,6 +129,12 @@ struct coati_engine {
   float *g_DH, *g_DO;
   bf16_t *g_do2, *g_dtd, *g_du, *g_dmi, *g_ds2, *g_dpre1, *g_dP;
   float* opt_partial;
+  ShadowJob* d_jobs = nullptr;
+  int* d_tile_start = nullptr;
+  std::vector<ShadowJob> jobs;
+  std::vector<int> tile_start;
+  int n_job_tiles = 0;
+  bool jobs_uploaded = false;
   // profiling
   int prof_site = -1;
   std::vector<hipEvent_t> ev;
@@ -232,6 +238,32 @@ void build_layout(coati_engine* e) {
   }
   e->gd0T = add_shadow(e, (int64_t)H * H);
   e->gd3T = add_shadow(e, (int64_t)H * H);
+
+  // job table of the one-launch shadow refresh
+  auto job = [&](int64_t src, int ld_src, int64_t dst, int ld_dst, int rows, int cols, int transpose) {
+    e->tile_start.push_back(e->n_job_tiles);
+    e->jobs.push_back({src, dst, ld_src, ld_dst, rows, cols, transpose});
+    e->n_job_tiles += ((rows + 31) / 32) * ((cols + 31) / 32);
+  };
+  for (const XLayerP& w : e->xl) {
+    job(w.attnw, C, w.attnT, 3 * C, 3 * C, C, 1);
+    job(w.projw, C, w.projT, C, C, C, 1);
+    job(w.fc1w, C, w.fc1T, 4 * C, 4 * C, C, 1);
+    job(w.fc2w, 4 * C, w.fc2T, C, C, 4 * C, 1);
+  }
+  job(e->lmhead, C, e->lmheadT, e->Vpad, V, C, 1);
+  for (const GLayerP& w : e->gl) {
+    // W1 is [H, 2H+1]: receiver block W1a = cols [0,H), sender block W1b = cols [H,2H)
+    job(w.e0w, 2 * H + 1, w.w1ab, H, H, H, 0);
+    job(w.e0w + H, 2 * H + 1, w.w1ab + (int64_t)H * H, H, H, H, 0);
+    job(w.e0w, 2 * H + 1, w.w1abT, 2 * H, H, H, 1);          // W1abT [H][2H]: T[k][n] = W1ab[n][k]
+    job(w.e0w + H, 2 * H + 1, w.w1abT + H, 2 * H, H, H, 1);
+    job(w.e3w, H, w.e3T, H, H, H, 1);
+    job(w.n0w, 2 * H, w.n0T, H, H, 2 * H, 1);
+    job(w.n3w, H, w.n3T, H, H, H, 1);
+  }
+  job(e->gd0w, H, e->gd0T, H, H, H, 1);
+  job(e->gd3w, H, e->gd3T, H, H, H, 1);
 }
 
 // ---- profiling wrapper ---------------------------------------------------------------------------------
@@ -357,6 +389,12 @@ size_t carve(coati_engine* e, Arena& ar, int B, int T1, int T2, int A, int Bg) {
   e->g_dmi = ar.take<bf16_t>(BA * H); e->g_ds2 = ar.take<bf16_t>(Me * H); e->g_dpre1 = ar.take<bf16_t>(Me * H);
   e->g_dP = ar.take<bf16_t>(BA * 2 * H);
   e->opt_partial = ar.take<float>(1024);
+  {
+    ShadowJob* dj = ar.take<ShadowJob>(e->jobs.size());
+    int* dt = ar.take<int>(e->tile_start.size());
+    if (dj != e->d_jobs || dt != e->d_tile_start) e->jobs_uploaded = false;
+    e->d_jobs = dj; e->d_tile_start = dt;
+  }
   return (ar.off + 255) & ~(size_t)255;
 }
 
@@ -597,35 +635,33 @@ int coati_engine_bind(coati_engine* e, float* params, float* grads, float* adam_
   return COATI_OK;
 }
 
-int coati_engine_refresh_shadows(coati_engine* e, void* stream) {
+static int refresh_shadows_impl(coati_engine* e, void* stream, bool natural_done) {
   COATI_CHECK_ARG(e && e->P && e->S, "refresh_shadows: engine not bound");
   hipStream_t s = (hipStream_t)stream;
   const coati_config& c = e->cfg;
   const int C = c.n_hidden_xformer, H = c.n_hidden_e3nn;
   ProfScope ps(e, SITE_OPTIM, 0, s);
-  COATI_TRY(launch_cast_bf16(e->P, e->S, e->n_params, s));
-  for (const XLayerP& w : e->xl) {
-    COATI_TRY(launch_transpose_cast(e->P + w.attnw, C, e->S + w.attnT, 3 * C, 3 * C, C, s));
-    COATI_TRY(launch_transpose_cast(e->P + w.projw, C, e->S + w.projT, C, C, C, s));
-    COATI_TRY(launch_transpose_cast(e->P + w.fc1w, C, e->S + w.fc1T, 4 * C, 4 * C, C, s));
-    COATI_TRY(launch_transpose_cast(e->P + w.fc2w, 4 * C, e->S + w.fc2T, C, C, 4 * C, s));
+  if (!natural_done) COATI_TRY(launch_cast_bf16(e->P, e->S, e->n_params, s));
+  if (e->d_jobs != nullptr) {
+    if (!e->jobs_uploaded) {
+      if (hipMemcpyAsync(e->d_jobs, e->jobs.data(), e->jobs.size() * sizeof(ShadowJob), hipMemcpyHostToDevice, s) != hipSuccess ||
+          hipMemcpyAsync(e->d_tile_start, e->tile_start.data(), e->tile_start.size() * sizeof(int), hipMemcpyHostToDevice, s) != hipSuccess) {
+        coati_set_error("refresh_shadows: job table upload failed");
+        return COATI_EHIP;
+      }
+      e->jobs_uploaded = true;
+    }
+    return launch_shadow_jobs(e->d_jobs, e->d_tile_start, (int)e->jobs.size(), e->n_job_tiles, e->P, e->S, s);
   }
-  COATI_TRY(launch_transpose_cast(e->P + e->lmhead, C, e->S + e->lmheadT, e->Vpad, c.n_tok, C, s));
-  for (const GLayerP& w : e->gl) {
-    // W1 is [H, 2H+1]: receiver block W1a = cols [0,H), sender block W1b = cols [H,2H)
-    COATI_TRY(launch_pack_rows_cast(e->P + w.e0w, 2 * H + 1, e->S + w.w1ab, H, H, H, s));
-    COATI_TRY(launch_pack_rows_cast(e->P + w.e0w + H, 2 * H + 1, e->S + w.w1ab + (int64_t)H * H, H, H, H, s));
-    // W1abT [H][2H]: T[k][n] = W1ab[n][k]
-    COATI_TRY(launch_transpose_cast(e->P + w.e0w, 2 * H + 1, e->S + w.w1abT, 2 * H, H, H, s));
-    COATI_TRY(launch_transpose_cast(e->P + w.e0w + H, 2 * H + 1, e->S + w.w1abT + H, 2 * H, H, H, s));
-    COATI_TRY(launch_transpose_cast(e->P + w.e3w, H, e->S + w.e3T, H, H, H, s));
-    COATI_TRY(launch_transpose_cast(e->P + w.n0w, 2 * H, e->S + w.n0T, H, H, 2 * H, s));
-    COATI_TRY(launch_transpose_cast(e->P + w.n3w, H, e->S + w.n3T, H, H, H, s));
+  // no workspace yet (first refresh after loading weights): one launch per matrix
+  for (const ShadowJob& j : e->jobs) {
+    if (j.transpose) COATI_TRY(launch_transpose_cast(e->P + j.src_off, j.ld_src, e->S + j.dst_off, j.ld_dst, j.rows, j.cols, s));
+    else COATI_TRY(launch_pack_rows_cast(e->P + j.src_off, j.ld_src, e->S + j.dst_off, j.ld_dst, j.rows, j.cols, s));
   }
-  COATI_TRY(launch_transpose_cast(e->P + e->gd0w, H, e->S + e->gd0T, H, H, H, s));
-  COATI_TRY(launch_transpose_cast(e->P + e->gd3w, H, e->S + e->gd3T, H, H, H, s));
   return COATI_OK;
 }
+
+int coati_engine_refresh_shadows(coati_engine* e, void* stream) { return refresh_shadows_impl(e, stream, false); }
 
 int coati_engine_forward(coati_engine* e, void* workspace, int64_t workspace_bytes, int B, int T1, int T2, int A,
                          const int64_t* raw_tokens, const int64_t* tokens, const int64_t* y_next,
@@ -798,9 +834,9 @@ int coati_engine_optimizer_step(coati_engine* e, float lr, float beta1, float be
   {
     ProfScope ps(e, SITE_OPTIM, 0, s);
     COATI_TRY(launch_grad_sqnorm(e->G, e->n_params, e->opt_partial, 1024, scal + 5, max_norm, scal + 8, s));
-    COATI_TRY(launch_adamw(e->P, e->G, e->Mo, e->Vo, nullptr, e->n_params, lr, beta1, beta2, eps, weight_decay, step, scal + 8, 1.f, s));
+    COATI_TRY(launch_adamw(e->P, e->G, e->Mo, e->Vo, e->S, e->n_params, lr, beta1, beta2, eps, weight_decay, step, scal + 8, 1.f, s));
   }
-  return coati_engine_refresh_shadows(e, stream);
+  return refresh_shadows_impl(e, stream, true);
 }
 
 int coati_engine_prof_select(coati_engine* e, int site) {

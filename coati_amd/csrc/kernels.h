@@ -172,3 +172,11 @@ int launch_transpose_cast(const float* src, long long ld_src, bf16_t* dst, long 
                           hipStream_t s);
 int launch_pack_rows_cast(const float* src, long long ld_src, bf16_t* dst, long long ld_dst, int rows, int cols,
                           hipStream_t s);
+
+// one-launch rebuild of the transposed / packed bf16 weight shadows (optim.hip); jobs + prefix tile counts live on the device
+struct ShadowJob {
+  long long src_off, dst_off;   // element offsets into the f32 parameter buffer / the bf16 shadow buffer
+  int ld_src, ld_dst, rows, cols, transpose;
+};
+int launch_shadow_jobs(const ShadowJob* jobs, const int* tile_start, int n_jobs, int n_tiles, const float* P, bf16_t* S,
+                       hipStream_t s);

@@ -129,3 +129,48 @@ int launch_pack_rows_cast(const float* src, long long ld_src, bf16_t* dst, long 
   COATI_LAUNCH_CHECK("pack_rows_cast");
   return COATI_OK;
 }
+
+// ---- batched transposes: one launch for every transposed / packed bf16 weight shadow ----------------------------
+// Each job: dst[c * ld_dst + r] = bf16(src[r * ld_src + c]) (transpose) or dst[r * ld_dst + c] = bf16(src[r * ld_src + c]).
+// blockIdx.x walks the concatenated 32x32 tile lists of all jobs (prefix sums in tile_start).
+__global__ __launch_bounds__(256) void shadow_jobs_kernel(const ShadowJob* __restrict__ jobs, const int* __restrict__ tile_start,
+                                                          int n_jobs, const float* __restrict__ P, bf16_t* __restrict__ S) {
+  __shared__ float tile[32][33];
+  int lo = 0, hi = n_jobs - 1;
+  const int b = blockIdx.x;
+  while (lo < hi) {   // last job whose first tile <= b
+    const int mid = (lo + hi + 1) >> 1;
+    if (tile_start[mid] <= b) lo = mid; else hi = mid - 1;
+  }
+  const ShadowJob j = jobs[lo];
+  const int t = b - tile_start[lo];
+  const int tiles_c = (j.cols + 31) >> 5;
+  const int r0 = (t / tiles_c) * 32, c0 = (t % tiles_c) * 32;
+  const float* src = P + j.src_off;
+  bf16_t* dst = S + j.dst_off;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  if (j.transpose) {
+    for (int i = ty; i < 32; i += 8) {
+      const int r = r0 + i, c = c0 + tx;
+      tile[i][tx] = (r < j.rows && c < j.cols) ? src[(long long)r * j.ld_src + c] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+      const int c = c0 + i, r = r0 + tx;
+      if (c < j.cols && r < j.rows) dst[(long long)c * j.ld_dst + r] = f2bf(tile[tx][i]);
+    }
+  } else {
+    for (int i = ty; i < 32; i += 8) {
+      const int r = r0 + i, c = c0 + tx;
+      if (r < j.rows && c < j.cols) dst[(long long)r * j.ld_dst + c] = f2bf(src[(long long)r * j.ld_src + c]);
+    }
+  }
+}
+
+int launch_shadow_jobs(const ShadowJob* jobs, const int* tile_start, int n_jobs, int n_tiles, const float* P, bf16_t* S,
+                       hipStream_t s) {
+  COATI_CHECK_ARG(jobs && tile_start && P && S && n_jobs > 0 && n_tiles > 0, "shadow_jobs: bad argument");
+  hipLaunchKernelGGL(shadow_jobs_kernel, dim3(n_tiles), dim3(256), 0, s, jobs, tile_start, n_jobs, P, S);
+  COATI_LAUNCH_CHECK("shadow_jobs");
+  return COATI_OK;
+}
