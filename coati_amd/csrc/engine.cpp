@@ -135,6 +135,10 @@ struct coati_engine {
   std::vector<int> tile_start;
   int n_job_tiles = 0;
   bool jobs_uploaded = false;
+  // side stream: the point encoder (independent of the transformer passes) runs concurrently with them
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  bool overlap = true;
   // profiling
   int prof_site = -1;
   std::vector<hipEvent_t> ev;
@@ -578,6 +582,34 @@ int head_linear_bwd(coati_engine* e, const float* dY, const float* X, int64_t w_
   return COATI_OK;
 }
 
+int ensure_side(coati_engine* e) {
+  if (e->side) return COATI_OK;
+  if (hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming) != hipSuccess) {
+    coati_set_error("engine: could not create the side stream");
+    return COATI_EHIP;
+  }
+  return COATI_OK;
+}
+// side waits for everything enqueued on main so far
+int fork_side(coati_engine* e, hipStream_t main) {
+  COATI_TRY(ensure_side(e));
+  if (hipEventRecord(e->ev_fork, main) != hipSuccess || hipStreamWaitEvent(e->side, e->ev_fork, 0) != hipSuccess) {
+    coati_set_error("engine: fork failed");
+    return COATI_EHIP;
+  }
+  return COATI_OK;
+}
+// main waits for everything enqueued on side so far
+int join_side(coati_engine* e, hipStream_t main) {
+  if (hipEventRecord(e->ev_join, e->side) != hipSuccess || hipStreamWaitEvent(main, e->ev_join, 0) != hipSuccess) {
+    coati_set_error("engine: join failed");
+    return COATI_EHIP;
+  }
+  return COATI_OK;
+}
+
 }  // namespace
 
 // =====================================================================================================
@@ -603,6 +635,9 @@ int coati_engine_create(const coati_config* cfg, coati_engine** out) {
 void coati_engine_destroy(coati_engine* e) {
   if (!e) return;
   for (auto ev : e->ev) hipEventDestroy(ev);
+  if (e->ev_fork) hipEventDestroy(e->ev_fork);
+  if (e->ev_join) hipEventDestroy(e->ev_join);
+  if (e->side) hipStreamDestroy(e->side);
   delete e;
 }
 
@@ -697,12 +732,20 @@ int coati_engine_forward(coati_engine* e, void* workspace, int64_t workspace_byt
     HIPCHK(hipMemsetD32Async((hipDeviceptr_t)e->ones, 0x3f800000, B, s));
   }
 
-  // ---- point encoder + point_to_clip (clip_e2e.py:454-461) ----
-  COATI_TRY(gnn_fwd(e, e->atoms, coords, s));
+  // ---- point encoder (clip_e2e.py:454-461): on the side stream, concurrent with the encoder pass ----
+  const bool ovl = e->overlap && e->prof_site < 0;
+  if (ovl) {
+    COATI_TRY(fork_side(e, s));
+    COATI_TRY(gnn_fwd(e, e->atoms, coords, e->side));
+  } else {
+    COATI_TRY(gnn_fwd(e, e->atoms, coords, s));
+  }
+  // ---- encoder pass (clip_e2e.py:448-452) ----
+  COATI_TRY(xformer_fwd(e, e->p1, nullptr, s));
+  if (ovl) COATI_TRY(join_side(e, s));
   COATI_TRY(launch_layernorm_fwd(e->hpoint, H, e->P + e->p2c_lnw, e->P + e->p2c_lnb, nullptr, 0, e->hp_ln, H, e->hp_mean, e->hp_rstd, B, H, s));
   COATI_TRY(launch_sgemm(e->hp_ln, H, 1, e->P + e->p2c_w, 1, H, e->h_e3gnn, E, B, E, H, e->P + e->p2c_b, 1.f, 0, s));
-  // ---- encoder pass + smiles_to_clip (clip_e2e.py:448-452) ----
-  COATI_TRY(xformer_fwd(e, e->p1, nullptr, s));
+  // ---- smiles_to_clip ----
   COATI_TRY(launch_find_stop(e->p1.idx, c.stop_token, e->stop_pos, e->err_flag, B, T1, s));
   COATI_TRY(launch_gather_rows(e->p1.xf32, e->stop_pos, e->hstop, B, T1, C, s));
   COATI_TRY(launch_layernorm_fwd(e->hstop, C, e->P + e->s2c_lnw, e->P + e->s2c_lnb, nullptr, 0, e->hs_ln, C, e->hs_mean, e->hs_rstd, B, C, s));
@@ -812,6 +855,12 @@ int coati_engine_backward(coati_engine* e, const float* dh_smiles, const float* 
     COATI_TRY(head_linear_bwd(e, e->dhe, e->hp_ln, e->p2c_w, e->p2c_b, e->dhp_ln, B, E, H, s));
     COATI_TRY(launch_layernorm_bwd(e->dhp_ln, 1, H, e->hpoint, H, 0, e->hp_mean, e->hp_rstd, e->P + e->p2c_lnw, nullptr, e->dhpoint, nullptr, e->G + e->p2c_lnw, e->G + e->p2c_lnb, B, H, s));
   }
+  const bool ovl_bwd = (stage == 0) && e->overlap && e->prof_site < 0;
+  if (ovl_bwd) {
+    // the point-encoder backward only needs dhpoint (ready here) and writes its own gradient slice: side stream
+    COATI_TRY(fork_side(e, s));
+    COATI_TRY(gnn_bwd(e, e->dhpoint, e->side));
+  }
   if (stage == 0 || stage == 2) {
     // ---- encoder pass: gradient enters at the [STOP] rows of ln_f's output ----
     float* dxf = reinterpret_cast<float*>(e->dh4);  // [M1, C] f32 scratch (dh4 is idle here: 4C bf16 >= C f32)
@@ -820,7 +869,9 @@ int coati_engine_backward(coati_engine* e, const float* dh_smiles, const float* 
     // xformer_bwd consumes dyf in its first kernel (ln_f backward) before dh4 is rewritten
     COATI_TRY(xformer_bwd(e, e->p1, dxf, 1, nullptr, s));
   }
-  if (stage == 0 || stage == 3) {
+  if (ovl_bwd) {
+    COATI_TRY(join_side(e, s));
+  } else if (stage == 0 || stage == 3) {
     COATI_TRY(gnn_bwd(e, e->dhpoint, s));
   }
   return COATI_OK;
