@@ -26,7 +26,7 @@ _SIGS = {
     "coati_wgrad": [P, I, L, P, L, I, I, I, P, L, P, I, P],
     "coati_sgemm": [P, L, L, P, L, L, P, L, I, I, I, P, F, I, P],
     "coati_layernorm_fwd": [P, L, P, P, P, L, P, L, P, P, I, I, P],
-    "coati_layernorm_bwd": [P, I, L, P, L, I, P, P, P, P, P, P, P, P, I, I, P],
+    "coati_layernorm_bwd": [P, I, L, P, L, I, P, P, P, P, P, P, P, P, P, I, I, P],
     "coati_attn_fwd": [P, P, P, I, I, I, P],
     "coati_gemm_qkv_rope": [P, L, P, L, P, I, I, P, L, P, P, I, P],
     "coati_attn_bwd": [P, P, P, P, P, P, P, P, I, I, I, P],

@@ -61,8 +61,8 @@ int coati_layernorm_fwd(const float* x, int64_t ldx, const float* gamma, const f
 }
 int coati_layernorm_bwd(const void* dy, int dy_f32, int64_t lddy, const float* x, int64_t ldx, int x_is_xhat,
                         const float* mean, const float* rstd, const float* gamma, const float* dres, float* dx,
-                        uint16_t* dx16, float* dgamma, float* dbeta, int M, int C, void* stream) {
-  return launch_layernorm_bwd(dy, dy_f32, lddy, x, ldx, x_is_xhat, mean, rstd, gamma, dres, dx, dx16, dgamma, dbeta, M, C, S_(stream));
+                        uint16_t* dx16, float* dgamma, float* dbeta, float* partial, int M, int C, void* stream) {
+  return launch_layernorm_bwd(dy, dy_f32, lddy, x, ldx, x_is_xhat, mean, rstd, gamma, dres, dx, dx16, dgamma, dbeta, partial, M, C, S_(stream));
 }
 
 int coati_attn_fwd(const uint16_t* qkv, uint16_t* y, float* lse, int B, int T, int n_head, void* stream) {

@@ -129,6 +129,7 @@ struct coati_engine {
   float *g_DH, *g_DO;
   bf16_t *g_do2, *g_dtd, *g_du, *g_dmi, *g_ds2, *g_dpre1, *g_dP;
   float* opt_partial;
+  float* ln_partial;
   ShadowJob* d_jobs = nullptr;
   int* d_tile_start = nullptr;
   std::vector<ShadowJob> jobs;
@@ -393,6 +394,7 @@ size_t carve(coati_engine* e, Arena& ar, int B, int T1, int T2, int A, int Bg) {
   e->g_dmi = ar.take<bf16_t>(BA * H); e->g_ds2 = ar.take<bf16_t>(Me * H); e->g_dpre1 = ar.take<bf16_t>(Me * H);
   e->g_dP = ar.take<bf16_t>(BA * 2 * H);
   e->opt_partial = ar.take<float>(1024);
+  e->ln_partial = ar.take<float>((size_t)COATI_LN_PARTIAL_ROWS * 2 * (C > H ? C : H));
   {
     ShadowJob* dj = ar.take<ShadowJob>(e->jobs.size());
     int* dt = ar.take<int>(e->tile_start.size());
@@ -448,7 +450,7 @@ int xformer_bwd(coati_engine* e, XPass& p, const void* dyf, int dyf_f32, float* 
   float* DX = e->DX;
   {
     ProfScope ps(e, SITE_LN_BWD, 0, s);
-    COATI_TRY(launch_layernorm_bwd(dyf, dyf_f32, C, p.x[L], C, 0, p.meanf, p.rstdf, e->P + e->lnfw, nullptr, DX, e->DX16, e->G + e->lnfw, e->G + e->lnfb, M, C, s));
+    COATI_TRY(launch_layernorm_bwd(dyf, dyf_f32, C, p.x[L], C, 0, p.meanf, p.rstdf, e->P + e->lnfw, nullptr, DX, e->DX16, e->G + e->lnfw, e->G + e->lnfb, e->ln_partial, M, C, s));
   }
   for (int l = L - 1; l >= 0; --l) {
     const XLayerP& w = e->xl[l];
@@ -460,7 +462,7 @@ int xformer_bwd(coati_engine* e, XPass& p, const void* dyf, int dyf_f32, float* 
     COATI_TRY(wgrad(e, SITE_XF_WGRAD, e->dh4, 0, 4 * C, p.a2[l], C, M, 4 * C, C, e->G + w.fc1w, C, e->G + w.fc1b, 0, s));
     {
       ProfScope ps(e, SITE_LN_BWD, 0, s);
-      COATI_TRY(launch_layernorm_bwd(e->da, 0, C, p.xmid[l], C, 0, p.mean2[l], p.rstd2[l], e->P + w.ln2w, DX, DX, e->DX16, e->G + w.ln2w, e->G + w.ln2b, M, C, s));
+      COATI_TRY(launch_layernorm_bwd(e->da, 0, C, p.xmid[l], C, 0, p.mean2[l], p.rstd2[l], e->P + w.ln2w, DX, DX, e->DX16, e->G + w.ln2w, e->G + w.ln2b, e->ln_partial, M, C, s));
     }
     // xmid = x[l] + y Wp^T + bp
     COATI_TRY(gemm(e, SITE_PROJ_DGRAD, e->DX16, 0, C, e->S + w.projT, C, M, C, C, e->dyb, C, nullptr, EPI_BF16, nullptr, nullptr, 0, s));
@@ -473,7 +475,7 @@ int xformer_bwd(coati_engine* e, XPass& p, const void* dyf, int dyf_f32, float* 
     COATI_TRY(wgrad(e, SITE_XF_WGRAD, e->dqkv, 0, 3 * C, p.a1[l], C, M, 3 * C, C, e->G + w.attnw, C, e->G + w.attnb, 0, s));
     {
       ProfScope ps(e, SITE_LN_BWD, 0, s);
-      COATI_TRY(launch_layernorm_bwd(e->da, 0, C, p.x[l], C, 0, p.mean1[l], p.rstd1[l], e->P + w.ln1w, DX, DX, e->DX16, e->G + w.ln1w, e->G + w.ln1b, M, C, s));
+      COATI_TRY(launch_layernorm_bwd(e->da, 0, C, p.x[l], C, 0, p.mean1[l], p.rstd1[l], e->P + w.ln1w, DX, DX, e->DX16, e->G + w.ln1w, e->G + w.ln1b, e->ln_partial, M, C, s));
     }
   }
   ProfScope ps(e, SITE_EMBED, 0, s);
@@ -532,7 +534,7 @@ int gnn_bwd(coati_engine* e, const float* dhpoint, hipStream_t s) {
     const GLayerP& w = e->gl[l];
     {
       ProfScope ps(e, SITE_GNN_ELEMWISE, 0, s);
-      COATI_TRY(launch_layernorm_bwd(DH, 1, H, e->g_h32[l + 1], H, 1, nullptr, e->g_rstd[l + 1], nullptr, nullptr, DO, e->g_DO16, nullptr, nullptr, BA, H, s));
+      COATI_TRY(launch_layernorm_bwd(DH, 1, H, e->g_h32[l + 1], H, 1, nullptr, e->g_rstd[l + 1], nullptr, nullptr, DO, e->g_DO16, nullptr, nullptr, e->ln_partial, BA, H, s));
     }
     // o = h + t W4^T + b4
     COATI_TRY(gemm(e, SITE_GNN_NODE_GEMM, e->g_DO16, 0, H, e->S + w.n3T, H, BA, H, H, e->g_du, H, nullptr, EPI_DSILU, e->g_upre[l], nullptr, H, s));
@@ -566,7 +568,7 @@ int gnn_bwd(coati_engine* e, const float* dhpoint, hipStream_t s) {
   }
   {
     ProfScope ps(e, SITE_GNN_ELEMWISE, 0, s);
-    COATI_TRY(launch_layernorm_bwd(DH, 1, H, e->g_h32[0], H, 1, nullptr, e->g_rstd[0], nullptr, nullptr, DO, nullptr, nullptr, nullptr, BA, H, s));
+    COATI_TRY(launch_layernorm_bwd(DH, 1, H, e->g_h32[0], H, 1, nullptr, e->g_rstd[0], nullptr, nullptr, DO, nullptr, nullptr, nullptr, e->ln_partial, BA, H, s));
     COATI_TRY(launch_gnn_embed_bwd(e->atoms, e->lut_ix, e->lut_iy, DO, e->G + e->gembw, e->G + e->gembb, BA, H, s));
   }
   return COATI_OK;
@@ -851,9 +853,9 @@ int coati_engine_backward(coati_engine* e, const float* dh_smiles, const float* 
     COATI_TRY(launch_silu_bwd(e->h_smiles, e->dsb, e->dhs, (long long)B * E, 1, s));
     // smiles_to_clip / point_to_clip: Linear then LayerNorm backward
     COATI_TRY(head_linear_bwd(e, e->dhs, e->hs_ln, e->s2c_w, e->s2c_b, e->dhs_ln, B, E, C, s));
-    COATI_TRY(launch_layernorm_bwd(e->dhs_ln, 1, C, e->hstop, C, 0, e->hs_mean, e->hs_rstd, e->P + e->s2c_lnw, nullptr, e->dhstop, nullptr, e->G + e->s2c_lnw, e->G + e->s2c_lnb, B, C, s));
+    COATI_TRY(launch_layernorm_bwd(e->dhs_ln, 1, C, e->hstop, C, 0, e->hs_mean, e->hs_rstd, e->P + e->s2c_lnw, nullptr, e->dhstop, nullptr, e->G + e->s2c_lnw, e->G + e->s2c_lnb, e->ln_partial, B, C, s));
     COATI_TRY(head_linear_bwd(e, e->dhe, e->hp_ln, e->p2c_w, e->p2c_b, e->dhp_ln, B, E, H, s));
-    COATI_TRY(launch_layernorm_bwd(e->dhp_ln, 1, H, e->hpoint, H, 0, e->hp_mean, e->hp_rstd, e->P + e->p2c_lnw, nullptr, e->dhpoint, nullptr, e->G + e->p2c_lnw, e->G + e->p2c_lnb, B, H, s));
+    COATI_TRY(launch_layernorm_bwd(e->dhp_ln, 1, H, e->hpoint, H, 0, e->hp_mean, e->hp_rstd, e->P + e->p2c_lnw, nullptr, e->dhpoint, nullptr, e->G + e->p2c_lnw, e->G + e->p2c_lnb, e->ln_partial, B, H, s));
   }
   const bool ovl_bwd = (stage == 0) && e->overlap && e->prof_site < 0;
   if (ovl_bwd) {

@@ -89,7 +89,9 @@ int launch_layernorm_fwd(const float* x, long long ldx, const float* gamma, cons
 // xhat is recomputed from (x, mean, rstd) or, if x_is_xhat, x already holds xhat (affine-free norms).
 int launch_layernorm_bwd(const void* dy, int dy_f32, long long lddy, const float* x, long long ldx, int x_is_xhat,
                          const float* mean, const float* rstd, const float* gamma, const float* dres,
-                         float* dx, bf16_t* dx16, float* dgamma, float* dbeta, int M, int C, hipStream_t s);
+                         float* dx, bf16_t* dx16, float* dgamma, float* dbeta, float* partial, int M, int C, hipStream_t s);
+// partial: optional [2048, 2C] f32 scratch -> deterministic two-stage dgamma/dbeta reduction (else fp32 atomics)
+#define COATI_LN_PARTIAL_ROWS 2048
 
 // ------------------------------------------------------------------------------------------------
 // attention, head size 16 (attention.hip)

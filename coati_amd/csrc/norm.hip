@@ -76,8 +76,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
                                                      const float* __restrict__ x, long long ldx, int x_is_xhat,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ gamma, const float* dres, float* dx,
-                                                     bf16_t* __restrict__ dx16, float* __restrict__ dgamma, float* __restrict__ dbeta, int M,
-                                                     int C) {
+                                                     bf16_t* __restrict__ dx16, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                     float* __restrict__ partial, int M, int C) {
   __shared__ float red[2][4][NCH * 256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float4 ag[NCH], ab[NCH];
@@ -146,14 +146,42 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
   for (int c = threadIdx.x; c < C; c += 256) {
     const float g = red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c];
     const float b = red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c];
-    atomicAdd(dgamma + c, g);
-    atomicAdd(dbeta + c, b);
+    if (partial) {   // stage 1 of the deterministic two-stage reduction: one row of [gamma | beta] sums per workgroup
+      partial[(long long)blockIdx.x * 2 * C + c] = g;
+      partial[(long long)blockIdx.x * 2 * C + C + c] = b;
+    } else {         // thousands of workgroups hammering 2C addresses: ~45 us of serialised L2 atomics at C = 256
+      atomicAdd(dgamma + c, g);
+      atomicAdd(dbeta + c, b);
+    }
+  }
+}
+
+// stage 2: column sums of partial[nblk][2C] added into dgamma | dbeta.  grid (2C/64, 32 row chunks): 32 atomics per column
+// instead of one per stage-1 workgroup.
+__global__ __launch_bounds__(256) void ln_bwd_finish_kernel(const float* __restrict__ partial, int nblk, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta, int C) {
+  __shared__ float red[4][64];
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
+  const int per = (nblk + gridDim.y - 1) / gridDim.y;
+  const int r0 = blockIdx.y * per;
+  int r1 = r0 + per;
+  if (r1 > nblk) r1 = nblk;
+  float acc = 0.f;
+  if (col < 2 * C) {
+#pragma unroll 4
+    for (int r = r0 + rg; r < r1; r += 4) acc += partial[(long long)r * 2 * C + col];
+  }
+  red[rg][threadIdx.x & 63] = acc;
+  __syncthreads();
+  if (rg == 0 && col < 2 * C) {
+    const float t = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    atomicAdd(col < C ? dgamma + col : dbeta + (col - C), t);
   }
 }
 
 int launch_layernorm_bwd(const void* dy, int dy_f32, long long lddy, const float* x, long long ldx, int x_is_xhat,
                          const float* mean, const float* rstd, const float* gamma, const float* dres,
-                         float* dx, bf16_t* dx16, float* dgamma, float* dbeta, int M, int C, hipStream_t s) {
+                         float* dx, bf16_t* dx16, float* dgamma, float* dbeta, float* partial, int M, int C, hipStream_t s) {
   COATI_CHECK_ARG(dy && x && rstd && dx, "layernorm_bwd: null operand");
   COATI_CHECK_ARG(x_is_xhat || mean, "layernorm_bwd: mean required unless x holds xhat");
   COATI_CHECK_ARG((dgamma == nullptr) == (dbeta == nullptr), "layernorm_bwd: dgamma/dbeta must both be given or both null");
@@ -163,7 +191,7 @@ int launch_layernorm_bwd(const void* dy, int dy_f32, long long lddy, const float
   int blocks = cdiv(M, 4);
   if (blocks > 2048) blocks = 2048;
   dim3 grid(blocks), block(256);
-#define LN_B(N, F) hipLaunchKernelGGL((ln_bwd_kernel<N, F>), grid, block, 0, s, dy, lddy, x, ldx, x_is_xhat, mean, rstd, gamma, dres, dx, dx16, dgamma, dbeta, M, C)
+#define LN_B(N, F) hipLaunchKernelGGL((ln_bwd_kernel<N, F>), grid, block, 0, s, dy, lddy, x, ldx, x_is_xhat, mean, rstd, gamma, dres, dx, dx16, dgamma, dbeta, partial, M, C)
   if (dy_f32) {
     if (nch == 1) LN_B(1, true); else if (nch == 2) LN_B(2, true); else if (nch == 3) LN_B(3, true); else LN_B(4, true);
   } else {
@@ -171,5 +199,9 @@ int launch_layernorm_bwd(const void* dy, int dy_f32, long long lddy, const float
   }
 #undef LN_B
   COATI_LAUNCH_CHECK("layernorm_bwd");
+  if (dgamma && partial) {
+    hipLaunchKernelGGL(ln_bwd_finish_kernel, dim3(cdiv(2 * C, 64), 32), dim3(256), 0, s, partial, blocks, dgamma, dbeta, C);
+    COATI_LAUNCH_CHECK("layernorm_bwd(finish)");
+  }
   return COATI_OK;
 }

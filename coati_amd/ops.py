@@ -83,15 +83,17 @@ def layernorm_fwd(x, gamma=None, beta=None, want16=True, want32=False):
     return y16, y32, mean, rstd
 
 
-def layernorm_bwd(dy, x, mean, rstd, gamma=None, dres=None, x_is_xhat=False, want_affine_grads=True, want16=False):
+def layernorm_bwd(dy, x, mean, rstd, gamma=None, dres=None, x_is_xhat=False, want_affine_grads=True, want16=False,
+                  two_stage=True):
     _need_cuda(dy, x)
     M, C = x.shape
     dx = torch.empty(M, C, device=x.device, dtype=torch.float32)
     dg = torch.zeros(C, device=x.device, dtype=torch.float32) if (gamma is not None and want_affine_grads) else None
     db = torch.zeros(C, device=x.device, dtype=torch.float32) if dg is not None else None
     dx16 = torch.empty(M, C, device=x.device, dtype=BF16) if want16 else None
+    partial = torch.empty(2048, 2 * C, device=x.device, dtype=torch.float32) if (dg is not None and two_stage) else None
     _lib.call("coati_layernorm_bwd", ptr(dy), 1 if dy.dtype == torch.float32 else 0, dy.stride(0), ptr(x), x.stride(0),
-              1 if x_is_xhat else 0, ptr(mean), ptr(rstd), ptr(gamma), ptr(dres), ptr(dx), ptr(dx16), ptr(dg), ptr(db), M, C, stream())
+              1 if x_is_xhat else 0, ptr(mean), ptr(rstd), ptr(gamma), ptr(dres), ptr(dx), ptr(dx16), ptr(dg), ptr(db), ptr(partial), M, C, stream())
     return (dx, dg, db, dx16) if want16 else (dx, dg, db)
 
 

@@ -81,13 +81,15 @@ int coati_sgemm(const float* A, int64_t ars, int64_t acs, const float* B, int64_
                 int64_t ldc, int M, int N, int K, const float* bias, float alpha, int accumulate, void* stream);
 
 /* nn.LayerNorm(C) / InstanceNorm1d applied over the hidden dim (gamma = beta = NULL), eps 1e-5.
- * backward: dx (f32, = dres + LN'(dy)) and optionally dx16, the same values rounded to bf16 for the next GEMMs. */
+ * backward: dx (f32, = dres + LN'(dy)) and optionally dx16, the same values rounded to bf16 for the next GEMMs;
+ * dgamma/dbeta are ADDED to.  partial: optional [2048, 2C] f32 scratch -> deterministic two-stage reduction of the affine
+ * gradients (without it they are accumulated with fp32 atomics, ~2x slower at C = 256). */
 int coati_layernorm_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, uint16_t* y16,
                         int64_t ld16, float* y32, int64_t ld32, float* mean, float* rstd, int M, int C,
                         void* stream);
 int coati_layernorm_bwd(const void* dy, int dy_f32, int64_t lddy, const float* x, int64_t ldx, int x_is_xhat,
                         const float* mean, const float* rstd, const float* gamma, const float* dres, float* dx,
-                        uint16_t* dx16, float* dgamma, float* dbeta, int M, int C, void* stream);
+                        uint16_t* dx16, float* dgamma, float* dbeta, float* partial, int M, int C, void* stream);
 
 /* QKV projection with the rotary embedding fused into the epilogue (basic_transformer.py:133-144, 83-100):
  * qkv[M, 3C] (bf16) = [RoPE(q) | RoPE(k) | v] of A W^T + bias; row m is token position m % T; head size 16. */

@@ -60,3 +60,5 @@ x = torch.randn(B*T, 256, device=dev); g = torch.ones(256, device=dev); b = torc
 y16, _, mean, rstd = ops.layernorm_fwd(x, g, b)
 row("ln fwd", timeit(lambda: ops.layernorm_fwd(x, g, b)), 0, B*T*256*6)
 row("ln bwd", timeit(lambda: ops.layernorm_bwd(dy, x, mean, rstd, g, dres=x)), 0, B*T*256*14)
+row("ln bwd (no dgamma/dbeta)", timeit(lambda: ops.layernorm_bwd(dy, x, mean, rstd, g, dres=x, want_affine_grads=False)), 0, B*T*256*14)
+row("ln bwd (no dres)", timeit(lambda: ops.layernorm_bwd(dy, x, mean, rstd, g)), 0, B*T*256*10)
