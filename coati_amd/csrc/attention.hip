@@ -19,6 +19,8 @@
 
 #define HS 16
 #define SCALE 0.25f   // 1/sqrt(16)
+#define SCALE_LOG2E 0.36067376022224085f   // SCALE * log2(e): softmax exponentials go straight to v_exp_f32 (2^x)
+#define LOG2E 1.4426950408889634f
 typedef short v4s16a __attribute__((ext_vector_type(4)));
 typedef short v8s16a __attribute__((ext_vector_type(8)));
 
@@ -64,9 +66,10 @@ __device__ __forceinline__ bf16x8 rfrag(const bf16_t* rm, int blk, int lane) {
 __device__ __forceinline__ bf16x8 tfrag(const bf16_t* rm, int base, int lane) {
   typedef __attribute__((address_space(3))) v4s16a lds_v4;
   const bf16_t* p = rm + (base + 4 * (lane >> 5) + ((lane & 15) >> 2)) * HS + 4 * (lane & 3);
-  v4s16a lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)p);
-  v4s16a hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(p + 8 * HS));
-  if ((lane & 31) >= 16) { lo = (v4s16a){0, 0, 0, 0}; hi = (v4s16a){0, 0, 0, 0}; }
+  const v4s16a lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)p);
+  const v4s16a hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(p + 8 * HS));
+  // lanes with d >= 16 feed don't-care rows of the A operand: MFMA output rows are independent and rows 16..31 of the
+  // result (accumulator registers 8..15) are never read, so no masking is needed.
   const v8s16a r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
   return __builtin_bit_cast(bf16x8, r);
 }
@@ -111,21 +114,31 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
     f32x16 o = zero16();
     for (int kb = 0; kb <= qb; ++kb) {
       f32x16 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rfrag(Ks, kb, lane), qf, zero16(), 0, 0, 0);
+      // running max / sum are kept on the RAW scores (the scale is positive); exp(x*scale) = 2^(x*scale*log2e)
       float p[16];
       float mloc = -INFINITY;
+      if (kb == qb) {   // only the diagonal block needs the causal mask
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = kb * 32 + arow(r, lane);
-        p[r] = (key <= q) ? s[r] * SCALE : -INFINITY;
-        mloc = fmaxf(mloc, p[r]);
+        for (int r = 0; r < 16; ++r) {
+          const int key = kb * 32 + arow(r, lane);
+          p[r] = (key <= q) ? s[r] : -INFINITY;
+          mloc = fmaxf(mloc, p[r]);
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          p[r] = s[r];
+          mloc = fmaxf(mloc, p[r]);
+        }
       }
       mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
       const float m_new = fmaxf(m_run, mloc);
-      const float alpha = __expf(m_run - m_new);
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * SCALE_LOG2E);
+      const float mc = m_new * SCALE_LOG2E;
       float lsum = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        p[r] = __expf(p[r] - m_new);
+        p[r] = __builtin_amdgcn_exp2f(fmaf(p[r], SCALE_LOG2E, -mc));
         lsum += p[r];
       }
       lsum += __shfl_xor(lsum, 32, 64);
@@ -141,7 +154,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
       bf16_t* yr = y + ((long long)b * T + q) * C + hh * HS + 4 * half;
       *reinterpret_cast<uint2*>(yr) = make_uint2(pack2bf(o[0] * inv, o[1] * inv), pack2bf(o[2] * inv, o[3] * inv));
       *reinterpret_cast<uint2*>(yr + 8) = make_uint2(pack2bf(o[4] * inv, o[5] * inv), pack2bf(o[6] * inv, o[7] * inv));
-      if (half == 0) lse[((long long)b * n_head + hh) * T + q] = m_run + __logf(l_run);
+      if (half == 0) lse[((long long)b * n_head + hh) * T + q] = m_run * SCALE + __logf(l_run);
     }
   }
 }
@@ -243,7 +256,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
   for (int qb = 0; qb < nblk; ++qb) {
     const bf16x8 qf = rfrag(Qs, qb, lane), gf = rfrag(Gs, qb, lane);
     const int q = qb * 32 + (lane & 31);
-    const float lq = Ls[q], dq_ = Ds[q];
+    const float lq = Ls[q] * LOG2E, dq_ = Ds[q];
     f32x16 acc = zero16();
     for (int kb = 0; kb <= qb; ++kb) {
       const f32x16 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rfrag(Ks, kb, lane), qf, zero16(), 0, 0, 0);
@@ -251,8 +264,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
       float ds[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int key = kb * 32 + arow(r, lane);
-        const float p = (key <= q) ? __expf(s[r] * SCALE - lq) : 0.f;
+        float p = __builtin_amdgcn_exp2f(fmaf(s[r], SCALE_LOG2E, -lq));
+        if (kb == qb && kb * 32 + arow(r, lane) > q) p = 0.f;
         ds[r] = p * (dp[r] - dq_) * SCALE;
       }
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tfrag(Ks, kb * 32, lane), pfrag(ds), acc, 0, 0, 0);
@@ -311,11 +324,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
         const int q0 = qb * 32 + 8 * g4 + 4 * half;
         const float4 l4 = *reinterpret_cast<const float4*>(Ls + q0);
         const float4 d4 = *reinterpret_cast<const float4*>(Ds + q0);
-        const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dvv[4] = {d4.x, d4.y, d4.z, d4.w};
+        const float lv[4] = {l4.x * LOG2E, l4.y * LOG2E, l4.z * LOG2E, l4.w * LOG2E}, dvv[4] = {d4.x, d4.y, d4.z, d4.w};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int r = g4 * 4 + j, q = q0 + j;
-          p[r] = (key <= q) ? __expf(s[r] * SCALE - lv[j]) : 0.f;
+          p[r] = __builtin_amdgcn_exp2f(fmaf(s[r], SCALE_LOG2E, -lv[j]));
+          if (qb == kb && key > q) p[r] = 0.f;
           ds[r] = p[r] * (dp[r] - dvv[j]) * SCALE;
         }
       }
