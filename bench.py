@@ -69,7 +69,7 @@ def main():
     ap.add_argument("--batch", type=int, default=1024, help="molecules per GPU (BASELINE.json configs[1])")
     ap.add_argument("--seq", type=int, default=80)
     ap.add_argument("--atoms", type=int, default=16)
-    ap.add_argument("--roofline-site", type=str, default="fc1_fwd")
+    ap.add_argument("--roofline-site", type=str, default="xf_wgrad", help="engine launch site timed for the roofline entry (default: the dominant one)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-mols", type=int, default=32)
     ap.add_argument("--all-sites", action="store_true", help="extra: per-site kernel time table on stderr")
