@@ -201,6 +201,10 @@ int launch_gemm_nt(const GemmArgs& a, int a_f32, int epi, hipStream_t s) {
   if (epi == EPI_CE_BWD) COATI_CHECK_ARG(a.lse && a.target && a.scal, "gemm_nt: CE operands missing");
   if (epi == EPI_QKV_ROPE) COATI_CHECK_ARG(a.rope_cos && a.rope_sin && a.rope_T > 0 && a.rope_C > 0 && a.N % 16 == 0 && a.rope_C % 16 == 0, "gemm_nt: rope operands missing");
   if (epi == EPI_EDGE_DPRE) COATI_CHECK_ARG(a.P && a.d2 && a.w1c && a.b1 && a.natom > 0 && a.ldp % 8 == 0, "gemm_nt: edge operands missing");
+  {
+    static const bool no_rb = getenv("COATI_NO_RB") != nullptr;   // A/B switch for benchmarking
+    if (!no_rb && gemm_rb256_supported(a, a_f32, epi)) return launch_gemm_rb256(a, epi, s);
+  }
   static const bool w4 = getenv("COATI_GEMM_W4") != nullptr;   // A/B switch: 4-wave instead of 8-wave workgroups
 #define NT_CASE(E)                                                                  \
   case E:                                                                           \
