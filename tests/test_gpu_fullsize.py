@@ -1,0 +1,89 @@
+"""BASELINE.json full-size configuration (grande_closed, B=1024, T=80, A=16, V=10322) through size-independent
+properties -- the oracle cannot run this size in seconds:
+  * batch-row permutation equivariance of forward_dist and invariance of both losses;
+  * the analytic gradient of the whole step against a central finite difference of the engine's own loss along the
+    gradient direction (checks the complete backward at full size: <g, d> = dL/d eps);
+  * a small move against the gradient lowers the loss; the optimiser's clip-norm equals the gradient buffer's norm."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from tests.gpu_util import log  # noqa: E402
+
+DEV = "cuda:0"
+GRANDE = dict(n_layer_e3gnn=5, n_layer_xformer=16, n_hidden_xformer=256, n_hidden_e3nn=256, n_embd_common=256,
+              n_head=16, n_seq=250, n_tok=10322)
+
+
+@pytest.fixture(scope="module")
+def big():
+    from coati_amd.engine import Engine, ModelConfig
+    from coati_amd.synthetic import make_batch
+    eng = Engine(ModelConfig(**GRANDE), DEV)
+    g = torch.Generator().manual_seed(0)
+    with torch.no_grad():
+        for name, (off, shape) in eng.layout.items():
+            v = eng.view(name)
+            if len(shape) == 2:
+                v.copy_((torch.randn(shape, generator=g) * (0.03 if "tok_emb" not in name else 1.0)).to(DEV))
+            elif (".ln_" in name and name.endswith("weight")) or name.endswith("clip.0.weight"):
+                v.fill_(1.0)
+            else:
+                v.copy_((0.01 * torch.randn(shape, generator=g)).to(DEV))
+    eng.refresh_shadows()
+    batch, up = make_batch(1024, 80, 16, GRANDE["n_tok"], seed=77)
+    return eng, {k: v.to(DEV) for k, v in batch.items()}, up.to(DEV)
+
+
+def total_loss(eng, batch, up):
+    h_e, h_s, bad = eng.forward(batch["raw_tokens"], batch["tokens"], batch["atoms"], batch["coords"], up,
+                                y_next=batch["y_next"], train=False)
+    eng.infonce(h_s, h_e, h_s, h_e, bad, row0=0, gscale=1.0)
+    return eng.losses(), h_e.clone(), h_s.clone()
+
+
+def test_batch_permutation(big):
+    eng, batch, up = big
+    L0, he0, hs0 = total_loss(eng, batch, up)
+    perm = torch.randperm(1024, generator=torch.Generator().manual_seed(1)).to(DEV)
+    pb = {k: v[perm].contiguous() for k, v in batch.items()}
+    L1, he1, hs1 = total_loss(eng, pb, up[perm].contiguous())
+    assert torch.equal(he1, he0[perm]) and torch.equal(hs1, hs0[perm])          # per-molecule maths is row-independent
+    assert abs(L1["ar_loss"] - L0["ar_loss"]) < 2e-5 * abs(L0["ar_loss"])        # sums re-associate (fp32 atomics)
+    assert abs(L1["clip_loss"] - L0["clip_loss"]) < 2e-5 * abs(L0["clip_loss"])
+    log(f"fullsize permutation: ar {L0['ar_loss']:.6f}/{L1['ar_loss']:.6f} clip {L0['clip_loss']:.6f}/{L1['clip_loss']:.6f}")
+
+
+def test_gradient_matches_finite_difference_and_step_descends(big):
+    eng, batch, up = big
+    p0 = eng.params.clone()
+    eng.train_step(batch, up, lr=0.0, optimizer=False)
+    L = eng.losses()
+    g = eng.grads.clone()
+    assert torch.isfinite(g).all()
+    gn = float(g.double().norm())
+    assert gn > 0 and math.isfinite(gn)
+    d = g / gn
+    eps = 0.25 / gn                     # moves the loss by ~0.5 in total, far above the bf16 noise of the forward
+    vals = []
+    for sgn in (+1.0, -1.0):
+        eng.params.copy_(p0 + sgn * eps * d)
+        eng.refresh_shadows()
+        vals.append(total_loss(eng, batch, up)[0]["loss"])
+    fd = (vals[0] - vals[1]) / (2 * eps)
+    log(f"fullsize directional derivative: analytic {gn:.4f}  finite-difference {fd:.4f}  loss {L['loss']:.4f}")
+    assert abs(fd - gn) < 0.08 * gn, (fd, gn)
+    assert vals[1] < L["loss"] < vals[0]       # a small move against / along the gradient lowers / raises the loss
+    # the optimiser kernel's pre-clip norm equals the norm of the gradient buffer (lr = 0: parameters unchanged)
+    eng.params.copy_(p0)
+    eng.refresh_shadows()
+    eng.adam_m.zero_(); eng.adam_v.zero_(); eng.step_count = 0
+    eng.train_step(batch, up, lr=0.0)
+    Ls = eng.losses()
+    log(f"fullsize step: loss {Ls['loss']:.4f}, grad norm {Ls['grad_norm']:.3f}")
+    assert abs(Ls["grad_norm"] - gn) < 1e-3 * gn
+    assert torch.equal(eng.params, p0)
+    eng.adam_m.zero_(); eng.adam_v.zero_(); eng.step_count = 0
