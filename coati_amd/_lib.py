@@ -41,6 +41,11 @@ _SIGS = {
     "coati_gnn_edge_pre": [P, L, P, P, L, P, P, I, I, I, P],
     "coati_gnn_edge_reduce": [P, P, P, L, I, I, I, P],
     "coati_infonce_rows": [P, L, I, I, I, P, P, P, F, P],
+    "coati_count_valid": [P, I, P, P, P],
+    "coati_colsum2": [P, P, P, P, I, I, P],
+    "coati_standardize": [P, P, P, P, P, P, I, I, P],
+    "coati_barlow_dc": [P, P, F, P, I, P],
+    "coati_standardize_bwd": [P, P, P, P, P, P, F, P, I, I, P],
     "coati_grad_sqnorm": [P, L, P, I, P, F, P, P],
     "coati_adamw": [P, P, P, P, P, L, F, F, F, F, F, I, P, F, P],
     "coati_engine_create": [POINTER(CoatiConfig), POINTER(c_void_p)],

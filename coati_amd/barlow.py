@@ -1,0 +1,48 @@
+"""Barlow-Twins contrastive head (BASELINE.json configs[3] `barlow_closed`) on the HIP kernels.
+
+The reference repository holds no Barlow code (only checkpoint names), so this follows the Barlow-Twins formulation;
+parity is UNPINNED and the only check is the oracle's own restatement (oracle.barlow_loss).  Exchange pattern at
+world size > 1: all-reduce of the per-dimension batch statistics (2 x 2E floats), of the E x E
+cross-correlation matrix, and of the 2 x 2E backward statistics -- no embedding all-gather is needed."""
+import torch
+import torch.distributed as dist
+
+from . import _lib
+from .ops import ptr, stream, sgemm
+
+
+def barlow_head(h_s: torch.Tensor, h_e: torch.Tensor, bad: torch.Tensor, lam: float = 5e-3, gscale: float = 1.0,
+                distributed: bool = False):
+    """Returns (loss[1] on device, dL/dh_s, dL/dh_e); gradients are multiplied by gscale."""
+    B, E = h_s.shape
+    dev = h_s.device
+    f32 = dict(device=dev, dtype=torch.float32)
+    bad = bad.to(torch.uint8).contiguous()
+    cnt = torch.zeros(2, **f32)
+    _lib.call("coati_count_valid", ptr(bad), B, ptr(cnt[0:1]), ptr(cnt[1:2]), stream())
+    stats = torch.empty(2, 2 * E, **f32)
+    _lib.call("coati_colsum2", ptr(h_s), None, ptr(bad), ptr(stats[0]), B, E, stream())
+    _lib.call("coati_colsum2", ptr(h_e), None, ptr(bad), ptr(stats[1]), B, E, stream())
+    if distributed:
+        dist.all_reduce(stats)
+        dist.all_reduce(cnt[0:1])
+    zs, ze = torch.empty(B, E, **f32), torch.empty(B, E, **f32)
+    rs = torch.empty(2, E, **f32)
+    _lib.call("coati_standardize", ptr(h_s), ptr(bad), ptr(stats[0]), ptr(cnt), ptr(zs), ptr(rs[0]), B, E, stream())
+    _lib.call("coati_standardize", ptr(h_e), ptr(bad), ptr(stats[1]), ptr(cnt), ptr(ze), ptr(rs[1]), B, E, stream())
+    C = sgemm(zs, ze, trans_a=True)                      # [E,E] raw cross-correlation of the local rows
+    if distributed:
+        dist.all_reduce(C)
+    loss = torch.zeros(1, **f32)
+    _lib.call("coati_barlow_dc", ptr(C), ptr(cnt), float(lam), ptr(loss), E, stream())   # C -> G = dL/dC / n
+    dzs = sgemm(ze, C, trans_b=True)                     # dL/dzs~ = Ze~ G^T
+    dze = sgemm(zs, C)                                   # dL/dze~ = Zs~ G
+    m = torch.empty(2, 2 * E, **f32)
+    _lib.call("coati_colsum2", ptr(dzs), ptr(zs), ptr(bad), ptr(m[0]), B, E, stream())
+    _lib.call("coati_colsum2", ptr(dze), ptr(ze), ptr(bad), ptr(m[1]), B, E, stream())
+    if distributed:
+        dist.all_reduce(m)
+    dS, dC = torch.empty(B, E, **f32), torch.empty(B, E, **f32)
+    _lib.call("coati_standardize_bwd", ptr(dzs), ptr(zs), ptr(bad), ptr(rs[0]), ptr(m[0]), ptr(cnt), float(gscale), ptr(dS), B, E, stream())
+    _lib.call("coati_standardize_bwd", ptr(dze), ptr(ze), ptr(bad), ptr(rs[1]), ptr(m[1]), ptr(cnt), float(gscale), ptr(dC), B, E, stream())
+    return loss, dS, dC

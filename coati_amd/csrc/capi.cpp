@@ -122,6 +122,24 @@ int coati_infonce_rows(float* logits, int64_t ld, int R, int N, int label0, cons
   return launch_infonce_rows(logits, ld, R, N, label0, bad, loss_sum, inv_count, gscale, S_(stream));
 }
 
+int coati_count_valid(const uint8_t* bad, int n, float* count, float* inv, void* stream) {
+  return launch_count_valid(bad, n, count, inv, S_(stream));
+}
+int coati_colsum2(const float* a, const float* b2, const uint8_t* bad, float* out, int B, int E, void* stream) {
+  return launch_colsum2(a, b2, bad, out, B, E, S_(stream));
+}
+int coati_standardize(const float* z, const uint8_t* bad, const float* stats, const float* count, float* zt, float* rsigma,
+                      int B, int E, void* stream) {
+  return launch_standardize(z, bad, stats, count, zt, rsigma, B, E, S_(stream));
+}
+int coati_barlow_dc(float* C, const float* count, float lam, float* loss, int E, void* stream) {
+  return launch_barlow_dc(C, count, lam, loss, E, S_(stream));
+}
+int coati_standardize_bwd(const float* dzt, const float* zt, const uint8_t* bad, const float* rsigma, const float* m,
+                          const float* count, float scale, float* dz, int B, int E, void* stream) {
+  return launch_standardize_bwd(dzt, zt, bad, rsigma, m, count, scale, dz, B, E, S_(stream));
+}
+
 int coati_grad_sqnorm(const float* g, int64_t n, float* partial, int n_partial, float* out_norm, float max_norm,
                       float* out_coef, void* stream) {
   return launch_grad_sqnorm(g, n, partial, n_partial, out_norm, max_norm, out_coef, S_(stream));

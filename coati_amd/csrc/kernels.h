@@ -163,6 +163,13 @@ int launch_axpy(const float* x, float* y, float alpha, long long n, hipStream_t 
 int launch_infonce_rows(float* logits, long long ld, int R, int N, int label0, const unsigned char* bad,
                         float* loss_sum, const float* inv_count, float gscale, hipStream_t s);
 int launch_count_valid(const unsigned char* bad, int n, float* out_count, float* out_inv, hipStream_t s);
+// Barlow-Twins head pieces (loss.hip)
+int launch_colsum2(const float* a, const float* b2, const unsigned char* bad, float* out, int B, int E, hipStream_t s);
+int launch_standardize(const float* z, const unsigned char* bad, const float* stats, const float* count, float* zt, float* rsigma,
+                       int B, int E, hipStream_t s);
+int launch_barlow_dc(float* C, const float* count, float lam, float* loss, int E, hipStream_t s);
+int launch_standardize_bwd(const float* dzt, const float* zt, const unsigned char* bad, const float* rsigma, const float* m,
+                           const float* count, float scale, float* dz, int B, int E, hipStream_t s);
 
 // ------------------------------------------------------------------------------------------------
 // optimiser (optim.hip)

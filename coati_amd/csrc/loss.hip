@@ -124,3 +124,104 @@ int launch_count_valid(const unsigned char* bad, int n, float* out_count, float*
   COATI_LAUNCH_CHECK("count_valid");
   return COATI_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Barlow-Twins head over the two [B,E] embeddings (BASELINE.json configs[3]; the reference holds no Barlow code, so this
+// follows the Barlow-Twins formulation and is PARITY UNPINNED -- see oracle.barlow_loss):
+//   z~ = keep * (z - mu) / sqrt(var + eps) per embedding dim over the valid rows of the GLOBAL batch (biased variance),
+//   C = Za~^T Zb~ / n,  L = sum_i (1 - C_ii)^2 + lambda * sum_{i != j} C_ij^2.
+// Column statistics and C are small ([2E], [E,E]) and are what a multi-GPU run all-reduces.
+// ---------------------------------------------------------------------------------------------------------------------
+// out[c] = sum_b keep[b] a[b,c] ; out[E + c] = sum_b keep[b] a[b,c] * (b2 ? b2[b,c] : a[b,c]).  Deterministic (no atomics).
+__global__ __launch_bounds__(256) void colsum2_kernel(const float* __restrict__ a, const float* __restrict__ b2,
+                                                      const unsigned char* __restrict__ bad, float* __restrict__ out, int B, int E) {
+  __shared__ float red[2][4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
+  float s1 = 0.f, s2 = 0.f;
+  if (c < E)
+    for (int r = rg; r < B; r += 4) {
+      if (bad[r]) continue;
+      const float x = a[(long long)r * E + c];
+      s1 += x;
+      s2 += x * (b2 ? b2[(long long)r * E + c] : x);
+    }
+  red[0][rg][threadIdx.x & 63] = s1;
+  red[1][rg][threadIdx.x & 63] = s2;
+  __syncthreads();
+  if (rg == 0 && c < E) {
+    const int t = threadIdx.x;
+    out[c] = red[0][0][t] + red[0][1][t] + red[0][2][t] + red[0][3][t];
+    out[E + c] = red[1][0][t] + red[1][1][t] + red[1][2][t] + red[1][3][t];
+  }
+}
+int launch_colsum2(const float* a, const float* b2, const unsigned char* bad, float* out, int B, int E, hipStream_t s) {
+  COATI_CHECK_ARG(a && bad && out, "colsum2: null operand");
+  hipLaunchKernelGGL(colsum2_kernel, dim3(cdiv(E, 64)), dim3(256), 0, s, a, b2, bad, out, B, E);
+  COATI_LAUNCH_CHECK("colsum2");
+  return COATI_OK;
+}
+
+// stats = [sum | sumsq] over the global valid rows, count[0] = n.  zt = keep (z - mu) * rsigma ; rsigma[c] written.
+__global__ void standardize_kernel(const float* __restrict__ z, const unsigned char* __restrict__ bad, const float* __restrict__ stats,
+                                   const float* __restrict__ count, float* __restrict__ zt, float* __restrict__ rsigma, int B, int E) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)B * E) return;
+  const int c = (int)(i % E), r = (int)(i / E);
+  const float n = fmaxf(count[0], 1.f);
+  const float mu = stats[c] / n;
+  const float var = fmaxf(stats[E + c] / n - mu * mu, 0.f);
+  const float rs = 1.0f / sqrtf(var + 1e-5f);
+  if (r == 0) rsigma[c] = rs;
+  zt[i] = bad[r] ? 0.f : (z[i] - mu) * rs;
+}
+int launch_standardize(const float* z, const unsigned char* bad, const float* stats, const float* count, float* zt, float* rsigma,
+                       int B, int E, hipStream_t s) {
+  COATI_CHECK_ARG(z && bad && stats && count && zt && rsigma, "standardize: null operand");
+  hipLaunchKernelGGL(standardize_kernel, dim3(cdiv((long long)B * E, 256)), dim3(256), 0, s, z, bad, stats, count, zt, rsigma, B, E);
+  COATI_LAUNCH_CHECK("standardize");
+  return COATI_OK;
+}
+
+// C holds the raw Za~^T Zb~ (already summed over ranks); in place -> G = dL/dC / n (so that dZ~ = Z~ G needs no further scaling);
+// loss[0] = L.
+__global__ __launch_bounds__(256) void barlow_dc_kernel(float* __restrict__ C, const float* __restrict__ count, float lam,
+                                                        float* __restrict__ loss, int E) {
+  __shared__ float red[4];
+  const float n = fmaxf(count[0], 1.f);
+  float acc = 0.f;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < (long long)E * E; i += (long long)gridDim.x * 256) {
+    const int r = (int)(i / E), c = (int)(i % E);
+    const float v = C[i] / n;
+    float g;
+    if (r == c) { acc += (1.f - v) * (1.f - v); g = -2.f * (1.f - v); } else { acc += lam * v * v; g = 2.f * lam * v; }
+    C[i] = g / n;
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(loss, red[0] + red[1] + red[2] + red[3]);
+}
+int launch_barlow_dc(float* C, const float* count, float lam, float* loss, int E, hipStream_t s) {
+  COATI_CHECK_ARG(C && count && loss, "barlow_dc: null operand");
+  hipLaunchKernelGGL(barlow_dc_kernel, dim3(64), dim3(256), 0, s, C, count, lam, loss, E);
+  COATI_LAUNCH_CHECK("barlow_dc");
+  return COATI_OK;
+}
+
+// dz = keep * rsigma * (dzt - m1 - zt * m2) * scale, with m = [sum keep dzt | sum keep dzt zt] / n (batch-norm backward)
+__global__ void standardize_bwd_kernel(const float* __restrict__ dzt, const float* __restrict__ zt, const unsigned char* __restrict__ bad,
+                                       const float* __restrict__ rsigma, const float* __restrict__ m, const float* __restrict__ count,
+                                       float scale, float* __restrict__ dz, int B, int E) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)B * E) return;
+  const int c = (int)(i % E), r = (int)(i / E);
+  const float n = fmaxf(count[0], 1.f);
+  dz[i] = bad[r] ? 0.f : scale * rsigma[c] * (dzt[i] - m[c] / n - zt[i] * (m[E + c] / n));
+}
+int launch_standardize_bwd(const float* dzt, const float* zt, const unsigned char* bad, const float* rsigma, const float* m,
+                           const float* count, float scale, float* dz, int B, int E, hipStream_t s) {
+  COATI_CHECK_ARG(dzt && zt && bad && rsigma && m && count && dz, "standardize_bwd: null operand");
+  hipLaunchKernelGGL(standardize_bwd_kernel, dim3(cdiv((long long)B * E, 256)), dim3(256), 0, s, dzt, zt, bad, rsigma, m, count, scale, dz, B, E);
+  COATI_LAUNCH_CHECK("standardize_bwd");
+  return COATI_OK;
+}

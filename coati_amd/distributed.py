@@ -39,14 +39,18 @@ def grad_buckets(eng):
     return {"xformer": (0, lm0), "lm_head": (lm0, pe0), "gnn": (pe0, hd0), "heads": (hd0, eng.n_params)}
 
 
-def distributed_train_step(eng, batch, use_point, lr, do_clip=True, optimizer=True):
-    """do_minibatch at world_size > 1.  Returns (h_e3gnn, h_smiles, bad_rows) of the local rows."""
+def distributed_train_step(eng, batch, use_point, lr, do_clip=True, optimizer=True, head="infonce"):
+    """do_minibatch at world_size > 1.  Returns (h_e3gnn, h_smiles, bad_rows) of the local rows.
+    head="barlow": Barlow-Twins head instead of InfoNCE (statistics / E x E matrix all-reduced, no embedding gather)."""
     W, rank = dist.get_world_size(), dist.get_rank()
     h_e, h_s, bad = eng.forward(batch["raw_tokens"], batch["tokens"], batch["atoms"], batch["coords"], use_point,
                                 y_next=batch["y_next"], train=True)
     B = h_e.shape[0]
     dS = dC = None
-    if do_clip:
+    if do_clip and head == "barlow":
+        from .barlow import barlow_head
+        eng.barlow_loss, dS, dC = barlow_head(h_s, h_e, bad, gscale=eng.token_entropy_unit() * W, distributed=True)
+    elif do_clip:
         s_all, c_all, bad_all = all_gather_cat(h_s), all_gather_cat(h_e), all_gather_cat(bad)
         # every rank's encoders receive W * d(global clip)/d(h_local); the mean all-reduce below divides by W
         dS_all, dC_all = eng.infonce(h_s, h_e, s_all, c_all, bad_all, row0=rank * B,

@@ -169,12 +169,17 @@ class Engine:
     def token_entropy_unit(self):
         return math.log(float(self.cfg.n_tok)) / math.log(2.0)
 
-    def train_step(self, batch, use_point, lr, do_clip=True, clip_weight=None, optimizer=True):
-        """One single-GPU do_minibatch (train_coati.py:216-277).  Losses stay on the device in self.scal."""
+    def train_step(self, batch, use_point, lr, do_clip=True, clip_weight=None, optimizer=True, head="infonce"):
+        """One single-GPU do_minibatch (train_coati.py:216-277).  Losses stay on the device in self.scal.
+        head: "infonce" (clip_e2e.py:27-47) or "barlow" (BASELINE configs[3]; parity unpinned, see barlow.py)."""
         h_e, h_s, bad = self.forward(batch["raw_tokens"], batch["tokens"], batch["atoms"], batch["coords"], use_point,
                                      y_next=batch["y_next"], train=True)
         dS = dC = None
-        if do_clip:
+        if do_clip and head == "barlow":
+            from .barlow import barlow_head
+            w = self.token_entropy_unit() if clip_weight is None else clip_weight
+            self.barlow_loss, dS, dC = barlow_head(h_s, h_e, bad, gscale=w)
+        elif do_clip:
             w = self.token_entropy_unit() if clip_weight is None else clip_weight
             dS, dC = self.infonce(h_s, h_e, h_s, h_e, bad, row0=0, gscale=0.5 * w)
         self.backward(dS, dC, 0)

@@ -131,6 +131,21 @@ int coati_gnn_edge_reduce(const uint16_t* s2, const float* w, uint16_t* mi, int6
 int coati_infonce_rows(float* logits, int64_t ld, int R, int N, int label0, const uint8_t* bad, float* loss_sum,
                        const float* inv_count, float gscale, void* stream);
 
+/* Barlow-Twins head (BASELINE.json configs[3]; no reference implementation exists -> parity unpinned).  The host
+ * (coati_amd/barlow.py) strings these together and all-reduces the small statistics / the ExE matrix across ranks:
+ *   coati_count_valid: count[0] = #rows with bad == 0, inv[0] = 1/count
+ *   coati_colsum2:     out[0:E] = sum_b keep a ; out[E:2E] = sum_b keep a*(b2 ? b2 : a)
+ *   coati_standardize: zt = keep (z - mu)/sqrt(var + 1e-5), rsigma written
+ *   coati_barlow_dc:   C (raw Za~^T Zb~) -> dL/dC / n in place, loss[0] += L
+ *   coati_standardize_bwd: batch-norm style backward of the standardisation, times `scale` */
+int coati_count_valid(const uint8_t* bad, int n, float* count, float* inv, void* stream);
+int coati_colsum2(const float* a, const float* b2, const uint8_t* bad, float* out, int B, int E, void* stream);
+int coati_standardize(const float* z, const uint8_t* bad, const float* stats, const float* count, float* zt, float* rsigma,
+                      int B, int E, void* stream);
+int coati_barlow_dc(float* C, const float* count, float lam, float* loss, int E, void* stream);
+int coati_standardize_bwd(const float* dzt, const float* zt, const uint8_t* bad, const float* rsigma, const float* m,
+                          const float* count, float scale, float* dz, int B, int E, void* stream);
+
 /* clip_grad_norm_ + AdamW over flat buffers (train_coati.py:145-151, 276-277) */
 int coati_grad_sqnorm(const float* g, int64_t n, float* partial, int n_partial, float* out_norm, float max_norm,
                       float* out_coef, void* stream);

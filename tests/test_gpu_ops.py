@@ -223,3 +223,37 @@ def test_gemm_qkv_rope(ops, B, T, nh):
     q, k = O.rotary_embed(q, k, c_, s_)
     ref = torch.cat([q.transpose(1, 2).reshape(B * T, C), k.transpose(1, 2).reshape(B * T, C), v.reshape(B * T, C)], 1)
     check(f"qkv rope B{B} T{T}", out.float().cpu(), ref, TB)
+
+
+def test_barlow_head_vs_oracle():
+    """Barlow-Twins head (parity UNPINNED: no reference code) against the oracle's own restatement + autograd."""
+    from oracle import coati_oracle as O
+    from coati_amd.barlow import barlow_head
+    g = torch.Generator().manual_seed(9)
+    B, E = 200, 64
+    a = torch.randn(B, E, generator=g) * 2 + 0.5
+    b = 0.7 * a + 0.5 * torch.randn(B, E, generator=g)
+    bad = torch.zeros(B, dtype=torch.bool)
+    bad[[3, 77, 150]] = True
+    ar, br = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = O.barlow_loss(ar, br, bad)
+    ref.sum().backward()
+    loss, dS, dC = barlow_head(a.to(DEV), b.to(DEV), bad.to(DEV), lam=5e-3, gscale=1.0)
+    check("barlow loss", loss.cpu(), ref.detach(), 2e-5)
+    check("barlow d/da", dS.cpu(), ar.grad, 1e-4)
+    check("barlow d/db", dC.cpu(), br.grad, 1e-4)
+    assert float(dS[3].abs().max()) == 0.0
+
+
+def test_barlow_train_step_runs():
+    from coati_amd.engine import Engine, ModelConfig
+    from coati_amd.synthetic import make_batch
+    kw = dict(n_layer_e3gnn=1, n_layer_xformer=2, n_hidden_xformer=64, n_hidden_e3nn=64, n_embd_common=64, n_head=4, n_seq=32, n_tok=64)
+    from oracle import coati_oracle as O
+    eng = Engine(ModelConfig(**kw), DEV)
+    eng.load_state_dict(O.init_params(O.OracleConfig(**kw), seed=4))
+    batch, up = make_batch(16, 20, 6, 64, seed=2, n_special=12, min_len=4)
+    dev = {k: v.to(DEV) for k, v in batch.items()}
+    eng.train_step(dev, up.to(DEV), lr=1e-3, head="barlow")
+    L = eng.losses()
+    assert torch.isfinite(eng.grads).all() and L["grad_norm"] > 0 and float(eng.barlow_loss) > 0
