@@ -206,7 +206,7 @@ __device__ __forceinline__ void store_grad_cols(bf16_t* dst, const f32x16& g, in
   *reinterpret_cast<uint2*>(dst + 8 + 4 * half) = make_uint2(pack2bf(c[0], c[1]), pack2bf(c[2], c[3]));
 }
 
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ y,
+__global__ __launch_bounds__(256, 4) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ y,
                                                           const bf16_t* __restrict__ dy, const float* __restrict__ lse,
                                                           float* __restrict__ Dout, bf16_t* __restrict__ dqkv,
                                                           const float* __restrict__ cos_t, const float* __restrict__ sin_t,
@@ -275,7 +275,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
   }
 }
 
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dy,
+__global__ __launch_bounds__(256, 3) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dy,
                                                            const float* __restrict__ lse, const float* __restrict__ Din,
                                                            bf16_t* __restrict__ dqkv, const float* __restrict__ cos_t,
                                                            const float* __restrict__ sin_t, int T, int n_head, int quads) {
