@@ -3,9 +3,10 @@
 // one batch row, so the workgroup consumes whole 128-B lines of the [B*T, 3C] qkv matrix.
 //
 // Head size 16 = exactly one K step of v_mfma_f32_32x32x16_bf16, so the kernels are softmax / LDS / latency
-// bound, not MFMA bound.  Everything a (b, head) problem needs (T <= 256 tokens x 16 dims) sits in LDS as
-// ROW-MAJOR [T][16] bf16 images:
-//   * q, k are rotated (RoPE, fp32 maths) while being staged and rounded to bf16 once;
+// bound, not MFMA bound.  The operands a kernel sweeps over (T <= 256 tokens x 16 dims: K,V in the forward and dQ
+// kernels, Q,dO in the dK/dV kernel) sit in LDS as ROW-MAJOR [T][16] bf16 images; the operand that is fixed for a
+// 32-row block is read from global memory straight into an MFMA fragment, so a workgroup needs only 2 images per head:
+//   * q, k arrive already rotated (the QKV GEMM applies RoPE in its epilogue); dq, dk are rotated back on store;
 //   * scores are computed TRANSPOSED (S^T = K Q^T) so each lane owns one query column and the softmax
 //     row statistics are lane-local (+ one cross-half shuffle);
 //   * P^T leaves the MFMA accumulator in exactly the layout the next MFMA wants as its B operand, provided
@@ -61,6 +62,15 @@ __device__ __forceinline__ void stage4(const bf16_t* src, long long stride, int 
 __device__ __forceinline__ bf16x8 rfrag(const bf16_t* rm, int blk, int lane) {
   return *reinterpret_cast<const bf16x8*>(rm + (blk * 32 + (lane & 31)) * HS + (lane >> 5) * 8);
 }
+// The same fragment straight from global memory (rows >= T read as zero): for the operand that is needed for ONE
+// 32-row block only, so it never occupies LDS.
+__device__ __forceinline__ bf16x8 gfrag(const bf16_t* src, long long stride, int blk, int T, int lane) {
+  const int row = blk * 32 + (lane & 31);
+  const int rc = row < T ? row : T - 1;
+  uint4 u = *reinterpret_cast<const uint4*>(src + (long long)rc * stride + (lane >> 5) * 8);
+  if (row >= T) u = make_uint4(0, 0, 0, 0);
+  return __builtin_bit_cast(bf16x8, u);
+}
 // A fragment X^T[d][row] with the accumulator's row permutation, read from the row-major image with the LDS
 // transpose read: lane (d = lane&31, h = lane>>5), slot j <-> row base + 4h + (j&3) + 8*(j>>2); d >= 16 -> zero.
 __device__ __forceinline__ bf16x8 tfrag(const bf16_t* rm, int base, int lane) {
@@ -94,21 +104,20 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
   const int hh = hq * 4 + wave;
   const int heads_here = (n_head - hq * 4) < 4 ? (n_head - hq * 4) : 4;
   const int C = n_head * HS, Tp = (T + 31) & ~31;
-  const size_t pw = (size_t)3 * Tp * HS * 2;
-  bf16_t* Qs = reinterpret_cast<bf16_t*>(smem + (size_t)wave * pw);
-  bf16_t* Ks = Qs + Tp * HS;
+  const size_t pw = (size_t)2 * Tp * HS * 2;
+  bf16_t* Ks = reinterpret_cast<bf16_t*>(smem + (size_t)wave * pw);
   bf16_t* Vs = Ks + Tp * HS;
   const long long stride = 3LL * C;
   const bf16_t* base = qkv + (long long)b * T * stride + hq * 4 * HS;
-  stage4(base, stride, T, Tp, smem, pw, 0, heads_here, threadIdx.x);
-  stage4(base + C, stride, T, Tp, smem, pw, 1, heads_here, threadIdx.x);
-  stage4(base + 2 * C, stride, T, Tp, smem, pw, 2, heads_here, threadIdx.x);
+  stage4(base + C, stride, T, Tp, smem, pw, 0, heads_here, threadIdx.x);
+  stage4(base + 2 * C, stride, T, Tp, smem, pw, 1, heads_here, threadIdx.x);
   __syncthreads();
   if (hh >= n_head) return;
+  const bf16_t* qsrc = qkv + (long long)b * T * stride + hh * HS;
 
   const int nblk = Tp >> 5, half = lane >> 5;
   for (int qb = 0; qb < nblk; ++qb) {
-    const bf16x8 qf = rfrag(Qs, qb, lane);
+    const bf16x8 qf = gfrag(qsrc, stride, qb, T, lane);
     const int q = qb * 32 + (lane & 31);
     float m_run = -INFINITY, l_run = 0.f;
     f32x16 o = zero16();
@@ -163,7 +172,7 @@ int launch_attn_fwd(const bf16_t* qkv, bf16_t* y, float* lse, int B, int T, int 
   COATI_CHECK_ARG(qkv && y && lse, "attn_fwd: null operand");
   COATI_CHECK_SHAPE(B > 0 && T > 0 && T <= 256 && n_head > 0, "attn_fwd: unsupported shape B=%d T=%d nh=%d", B, T, n_head);
   const int Tp = (T + 31) & ~31;
-  const size_t lds = (size_t)4 * 3 * Tp * HS * 2;
+  const size_t lds = (size_t)4 * 2 * Tp * HS * 2;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel),
@@ -217,46 +226,37 @@ __global__ __launch_bounds__(256, 4) void attn_bwd_dq_kernel(const bf16_t* __res
   const int hh = hq * 4 + wave;
   const int heads_here = (n_head - hq * 4) < 4 ? (n_head - hq * 4) : 4;
   const int C = n_head * HS, Tp = (T + 31) & ~31;
-  const size_t pw = (size_t)4 * Tp * HS * 2 + (size_t)2 * Tp * 4;
-  unsigned char* my = smem + (size_t)wave * pw;
-  bf16_t* Qs = reinterpret_cast<bf16_t*>(my);
-  bf16_t* Ks = Qs + Tp * HS;
+  const size_t pw = (size_t)2 * Tp * HS * 2;
+  bf16_t* Ks = reinterpret_cast<bf16_t*>(smem + (size_t)wave * pw);
   bf16_t* Vs = Ks + Tp * HS;
-  bf16_t* Gs = Vs + Tp * HS;
-  float* Ls = reinterpret_cast<float*>(Gs + Tp * HS);
-  float* Ds = Ls + Tp;
   const long long stride = 3LL * C;
   const bf16_t* qbase = qkv + (long long)b * T * stride + hq * 4 * HS;
-  stage4(qbase, stride, T, Tp, smem, pw, 0, heads_here, threadIdx.x);
-  stage4(qbase + C, stride, T, Tp, smem, pw, 1, heads_here, threadIdx.x);
-  stage4(qbase + 2 * C, stride, T, Tp, smem, pw, 2, heads_here, threadIdx.x);
-  stage4(dy + (long long)b * T * C + hq * 4 * HS, (long long)C, T, Tp, smem, pw, 3, heads_here, threadIdx.x);
+  stage4(qbase + C, stride, T, Tp, smem, pw, 0, heads_here, threadIdx.x);
+  stage4(qbase + 2 * C, stride, T, Tp, smem, pw, 1, heads_here, threadIdx.x);
   __syncthreads();
   if (hh >= n_head) return;
   const bf16_t* ybase = y + (long long)b * T * C + hh * HS;
-  for (int t = lane; t < Tp; t += 64) {
-    float d = 0.f, l = INFINITY;
-    if (t < T) {
-      float o[16], g[16];
-      load16(ybase + (long long)t * C, o);
-      load16(Gs + t * HS, g);
-#pragma unroll
-      for (int i = 0; i < 16; ++i) d += o[i] * g[i];
-      l = lse[((long long)b * n_head + hh) * T + t];
-      Dout[((long long)b * n_head + hh) * T + t] = d;
-    }
-    Ds[t] = d;
-    Ls[t] = l;
-  }
-  __builtin_amdgcn_s_waitcnt(0xc07f);
-  __builtin_amdgcn_wave_barrier();
+  const bf16_t* qsrc = qkv + (long long)b * T * stride + hh * HS;
+  const bf16_t* gsrc = dy + (long long)b * T * C + hh * HS;
+  const long long sbase = ((long long)b * n_head + hh) * T;
 
   const int nblk = Tp >> 5, half = lane >> 5;
   bf16_t* const dbase = dqkv + (long long)b * T * stride + hh * HS;
   for (int qb = 0; qb < nblk; ++qb) {
-    const bf16x8 qf = rfrag(Qs, qb, lane), gf = rfrag(Gs, qb, lane);
+    const bf16x8 qf = gfrag(qsrc, stride, qb, T, lane), gf = gfrag(gsrc, (long long)C, qb, T, lane);
     const int q = qb * 32 + (lane & 31);
-    const float lq = Ls[q] * LOG2E, dq_ = Ds[q];
+    // D[q] = sum_d dO[q,d] O[q,d]: this lane holds dims half*8..+7 of dO[q] in gf; the partner half-wave adds the rest
+    float lq = INFINITY, dq_ = 0.f;
+    if (q < T) {
+      float o8[8], g8[8];
+      unpack8(*reinterpret_cast<const uint4*>(ybase + (long long)q * C + half * 8), o8);
+      unpack8(__builtin_bit_cast(uint4, gf), g8);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) dq_ += o8[i] * g8[i];
+      lq = lse[sbase + q] * LOG2E;
+    }
+    dq_ += __shfl_xor(dq_, 32, 64);
+    if (q < T && half == 0) Dout[sbase + q] = dq_;
     f32x16 acc = zero16();
     for (int kb = 0; kb <= qb; ++kb) {
       const f32x16 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rfrag(Ks, kb, lane), qf, zero16(), 0, 0, 0);
@@ -285,22 +285,19 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_kernel(const bf16_t* __re
   const int hh = hq * 4 + wave;
   const int heads_here = (n_head - hq * 4) < 4 ? (n_head - hq * 4) : 4;
   const int C = n_head * HS, Tp = (T + 31) & ~31;
-  const size_t pw = (size_t)4 * Tp * HS * 2 + (size_t)2 * Tp * 4;
+  const size_t pw = (size_t)2 * Tp * HS * 2 + (size_t)2 * Tp * 4;
   unsigned char* my = smem + (size_t)wave * pw;
   bf16_t* Qs = reinterpret_cast<bf16_t*>(my);
-  bf16_t* Ks = Qs + Tp * HS;
-  bf16_t* Vs = Ks + Tp * HS;
-  bf16_t* Gs = Vs + Tp * HS;
+  bf16_t* Gs = Qs + Tp * HS;
   float* Ls = reinterpret_cast<float*>(Gs + Tp * HS);
   float* Ds = Ls + Tp;
   const long long stride = 3LL * C;
   const bf16_t* qbase = qkv + (long long)b * T * stride + hq * 4 * HS;
   stage4(qbase, stride, T, Tp, smem, pw, 0, heads_here, threadIdx.x);
-  stage4(qbase + C, stride, T, Tp, smem, pw, 1, heads_here, threadIdx.x);
-  stage4(qbase + 2 * C, stride, T, Tp, smem, pw, 2, heads_here, threadIdx.x);
-  stage4(dy + (long long)b * T * C + hq * 4 * HS, (long long)C, T, Tp, smem, pw, 3, heads_here, threadIdx.x);
+  stage4(dy + (long long)b * T * C + hq * 4 * HS, (long long)C, T, Tp, smem, pw, 1, heads_here, threadIdx.x);
   __syncthreads();
   if (hh >= n_head) return;
+  const bf16_t* ksrc = qkv + (long long)b * T * stride + C + hh * HS;
   for (int t = lane; t < Tp; t += 64) {
     const long long o = ((long long)b * n_head + hh) * T + t;
     Ls[t] = (t < T) ? lse[o] : INFINITY;
@@ -312,7 +309,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_kernel(const bf16_t* __re
   const int nblk = Tp >> 5, half = lane >> 5;
   bf16_t* const dbase = dqkv + (long long)b * T * stride + hh * HS;
   for (int kb = 0; kb < nblk; ++kb) {
-    const bf16x8 kf = rfrag(Ks, kb, lane), vf = rfrag(Vs, kb, lane);
+    const bf16x8 kf = gfrag(ksrc, stride, kb, T, lane), vf = gfrag(ksrc + C, stride, kb, T, lane);
     const int key = kb * 32 + (lane & 31);
     f32x16 dk = zero16(), dv = zero16();
     for (int qb = kb; qb < nblk; ++qb) {
@@ -350,7 +347,7 @@ int launch_attn_bwd(const bf16_t* qkv, const bf16_t* y, const bf16_t* dy, const 
   COATI_CHECK_ARG(qkv && y && dy && lse && dscratch && dqkv && cos_t && sin_t, "attn_bwd: null operand");
   COATI_CHECK_SHAPE(B > 0 && T > 0 && T <= 256 && n_head > 0, "attn_bwd: unsupported shape B=%d T=%d nh=%d", B, T, n_head);
   const int Tp = (T + 31) & ~31;
-  const size_t lds = (size_t)4 * (4 * Tp * HS * 2 + 2 * Tp * 4);
+  const size_t lds = (size_t)4 * (2 * Tp * HS * 2 + 2 * Tp * 4);   // dK/dV kernel (the dQ kernel uses less)
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel),
@@ -364,7 +361,7 @@ int launch_attn_bwd(const bf16_t* qkv, const bf16_t* y, const bf16_t* dy, const 
     attr_set = true;
   }
   const int quads = cdiv(n_head, 4);
-  hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(B * quads), dim3(256), lds, s, qkv, y, dy, lse, dscratch, dqkv, cos_t,
+  hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(B * quads), dim3(256), (size_t)4 * 2 * Tp * HS * 2, s, qkv, y, dy, lse, dscratch, dqkv, cos_t,
                      sin_t, T, n_head, quads);
   COATI_LAUNCH_CHECK("attn_bwd_dq");
   hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(B * quads), dim3(256), lds, s, qkv, dy, lse, dscratch, dqkv, cos_t,
