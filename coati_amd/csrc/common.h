@@ -72,23 +72,28 @@ __device__ __forceinline__ uint4 pack8(const float* v) {
 }
 
 // ---- activations (fp32 math) --------------------------------------------------------------------
-// NewGELU, tanh form (reference basic_transformer.py:12-28).  tanh(u) = 1 - 2/(1 + exp(2u)) on the hardware exp unit
-// (v_exp_f32); absolute error < 2e-7, saturates cleanly for |u| large (exp -> inf => 1, exp -> 0 => -1).
-__device__ __forceinline__ float fast_tanh(float u) { return 1.0f - 2.0f / (1.0f + __expf(2.0f * u)); }
+// The hardware transcendental unit does the exponentials (v_exp_f32 = 2^x) and the reciprocals (v_rcp_f32, 1 ulp): an
+// IEEE `a / b` expands to ~10 VALU instructions, which made the GELU epilogues VALU-bound.  sigmoid saturates cleanly:
+// 2^(+big) = inf -> rcp = 0 ; 2^(-big) = 0 -> 1.
+#define COATI_LOG2E 1.4426950408889634f
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float sigmoid_f(float x) { return fast_rcp(1.0f + __builtin_amdgcn_exp2f(-COATI_LOG2E * x)); }
+// NewGELU, tanh form (reference basic_transformer.py:12-28): 0.5 x (1 + tanh(u)) = x * sigmoid(2u),
+// u = sqrt(2/pi) (x + 0.044715 x^3)
 __device__ __forceinline__ float gelu_f(float x) {
-  const float k = 0.7978845608028654f;  // sqrt(2/pi)
-  float u = k * (x + 0.044715f * x * x * x);
-  return 0.5f * x * (1.0f + fast_tanh(u));
+  const float k2 = 2.0f * 0.7978845608028654f;
+  const float z = k2 * fmaf(0.044715f * x * x, x, x);
+  return x * sigmoid_f(z);
 }
+// d/dx [x s(z)] = s + x s (1 - s) z',  z' = 2 sqrt(2/pi) (1 + 3 * 0.044715 x^2)
 __device__ __forceinline__ float dgelu_f(float x) {
-  const float k = 0.7978845608028654f;
-  float x2 = x * x;
-  float u = k * (x + 0.044715f * x * x2);
-  float t = fast_tanh(u);
-  float du = k * (1.0f + 3.0f * 0.044715f * x2);
-  return 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * du;
+  const float k2 = 2.0f * 0.7978845608028654f;
+  const float x2 = x * x;
+  const float z = k2 * fmaf(0.044715f * x2, x, x);
+  const float s = sigmoid_f(z);
+  const float zp = k2 * fmaf(3.0f * 0.044715f, x2, 1.0f);
+  return fmaf(x * s * (1.0f - s), zp, s);
 }
-__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
 __device__ __forceinline__ float silu_f(float x) { return x * sigmoid_f(x); }
 __device__ __forceinline__ float dsilu_f(float x) {
   float s = sigmoid_f(x);

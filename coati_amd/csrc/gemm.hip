@@ -273,7 +273,9 @@ __device__ __forceinline__ void wstage_load(StageW& s, const AT* base, long long
       const float4 f1 = *reinterpret_cast<const float4*>(base + (long long)mc * ld + colc + 4);
       t = make_uint4(pack2bf(f0.x, f0.y), pack2bf(f0.z, f0.w), pack2bf(f1.x, f1.y), pack2bf(f1.z, f1.w));
     }
-    s.v[i] = (m < m_end && colok) ? t : make_uint4(0, 0, 0, 0);
+    // zero-fill by masking, not by select: a select lets the compiler predicate the load itself (one exec branch per load)
+    const unsigned keep = (m < m_end && colok) ? 0xffffffffu : 0u;
+    s.v[i] = make_uint4(t.x & keep, t.y & keep, t.z & keep, t.w & keep);
   }
 }
 template <int NT>
@@ -366,19 +368,17 @@ __global__ __launch_bounds__(64 * WAVES, 2) void wgrad_kernel(WgradArgs p, int t
   StageW sa0, sb0, sa1, sb1;
   wstage_load<AT, NT>(sa0, A, p.lda, c_begin * 64, p.M, n0, p.N, tid);
   wstage_load<bf16_t, NT>(sb0, p.B, p.ldb, c_begin * 64, p.M, k0, p.K, tid);
-  if (c_begin + 1 < c_end) {
-    wstage_load<AT, NT>(sa1, A, p.lda, (c_begin + 1) * 64, p.M, n0, p.N, tid);
-    wstage_load<bf16_t, NT>(sb1, p.B, p.ldb, (c_begin + 1) * 64, p.M, k0, p.K, tid);
-  }
+  // every prefetch below is issued UNCONDITIONALLY (rows past the end are clamped and zero-filled by wstage_load): a
+  // branch around the loads would make the compiler wait for vmcnt(0) at the join and kill the two-deep prefetch
+  wstage_load<AT, NT>(sa1, A, p.lda, (c_begin + 1) * 64, p.M, n0, p.N, tid);
+  wstage_load<bf16_t, NT>(sb1, p.B, p.ldb, (c_begin + 1) * 64, p.M, k0, p.K, tid);
   if (do_bias) wstage_colsum<NT>(sa0, csum);
   wstage_store<NT>(sa0, At0, tid);
   wstage_store<NT>(sb0, Bt0, tid);
   __syncthreads();
   for (int c = c_begin; c < c_end; c += 2) {
-    if (c + 2 < c_end) {
-      wstage_load<AT, NT>(sa0, A, p.lda, (c + 2) * 64, p.M, n0, p.N, tid);
-      wstage_load<bf16_t, NT>(sb0, p.B, p.ldb, (c + 2) * 64, p.M, k0, p.K, tid);
-    }
+    wstage_load<AT, NT>(sa0, A, p.lda, (c + 2) * 64, p.M, n0, p.N, tid);
+    wstage_load<bf16_t, NT>(sb0, p.B, p.ldb, (c + 2) * 64, p.M, k0, p.K, tid);
     wmma_chunk<MI>(At0, Bt0, wm, wn, lane, acc);
     if (c + 1 < c_end) {
       if (do_bias) wstage_colsum<NT>(sa1, csum);
@@ -387,10 +387,8 @@ __global__ __launch_bounds__(64 * WAVES, 2) void wgrad_kernel(WgradArgs p, int t
     }
     __syncthreads();
     if (c + 1 >= c_end) break;
-    if (c + 3 < c_end) {
-      wstage_load<AT, NT>(sa1, A, p.lda, (c + 3) * 64, p.M, n0, p.N, tid);
-      wstage_load<bf16_t, NT>(sb1, p.B, p.ldb, (c + 3) * 64, p.M, k0, p.K, tid);
-    }
+    wstage_load<AT, NT>(sa1, A, p.lda, (c + 3) * 64, p.M, n0, p.N, tid);
+    wstage_load<bf16_t, NT>(sb1, p.B, p.ldb, (c + 3) * 64, p.M, k0, p.K, tid);
     wmma_chunk<MI>(At1, Bt1, wm, wn, lane, acc);
     if (c + 2 < c_end) {
       if (do_bias) wstage_colsum<NT>(sa0, csum);

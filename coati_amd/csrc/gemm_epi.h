@@ -8,7 +8,9 @@ __device__ __forceinline__ int frag_row(int r, int lane) { return (r & 3) + 8 * 
 // ---- epilogue on 8 consecutive columns of one row ----------------------------------------------------
 template <int EPI, int ROPE_PARTNER = 1>
 __device__ __forceinline__ void epilogue8(const GemmArgs& p, int row, int col0, float (&v)[8], bool rowok,
-                                          int tile_n, int tiles_n) {
+                                          int tile_n, int tiles_n, const float* rope_row = nullptr) {
+  // rope_row: optional [8 cos | 8 sin] of this row's token position, pre-staged by the caller (LDS) instead of the
+  // global tables
   const int N = p.N;
   if (p.bias != nullptr) {
     if (col0 + 8 <= N) {
@@ -88,7 +90,8 @@ __device__ __forceinline__ void epilogue8(const GemmArgs& p, int row, int col0, 
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const float other = __shfl_xor(v[e], ROPE_PARTNER, 64);
-      const float c = p.rope_cos[t * 16 + e], s_ = p.rope_sin[t * 16 + e];
+      const float c = rope_row ? rope_row[e] : p.rope_cos[t * 16 + e];
+      const float s_ = rope_row ? rope_row[8 + e] : p.rope_sin[t * 16 + e];
       const float r = hi_half ? (v[e] * c + other * s_) : (v[e] * c - other * s_);
       o[e] = rot ? r : v[e];
     }

@@ -7,25 +7,39 @@
 //   * each wave keeps its 32 x 256 slab of A as 16 MFMA A-fragments in registers (A is read from HBM exactly once);
 //   * the weight tile [64 cols][256] streams through a double-buffered LDS image (rows padded to 528 B: conflict-free
 //     ds_read_b128), the next tile's loads in flight behind the current tile's 32 MFMAs per wave, one barrier per tile;
-//   * every wave transposes its 32 x 64 accumulator block through a PRIVATE LDS region (no workgroup barrier) and runs
-//     the fused epilogue (gemm_epi.h) on 8 consecutive columns per lane: 128-B row segments, 16-B stores;
+//     the MFMA loop reads its weight fragments RB_PD - 1 k-steps ahead (explicit software pipeline);
+//   * the bias is folded into the accumulator initialisation (next tile's two values prefetched with the weights), and
+//     the rotary tables of the wave's 32 rows are staged in LDS once: the epilogue issues no global loads;
+//   * every wave transposes its 32 x 64 accumulator block, 16 rows at a time, through a PRIVATE LDS region (no
+//     workgroup barrier) and runs the fused epilogue (gemm_epi.h) on 8 consecutive columns per lane: 128-B row
+//     segments, 16-B stores;
 //   * W waves per workgroup is chosen on the host so that the grid is a whole number of 256-CU rounds.
+// Probe with the phase ablations that led to this shape: tools/probes/rb_probe.hip.
 #include "gemm_epi.h"
 
 #define RB_K 256
 #define RB_BN 64
-#define RB_PITCH 264                      // halfs per LDS row of the weight tile (528 B)
-#define RB_TILE_HALFS (RB_BN * RB_PITCH)  // 33,792 B per tile
+#define RB_TILE_HALFS (RB_BN * RB_K)      // 32 KiB per tile: [64 cols][256 k], unpadded, chunk-swizzled
 #define RB_EPITCH 68                      // floats per row of the per-wave transpose region
-#define RB_EFLOATS (32 * RB_EPITCH)       // 8,704 B per wave
+#define RB_EFLOATS (16 * RB_EPITCH)       // 4,352 B per wave: 16 rows x 64 columns
+#define RB_ROPE_FLOATS (32 * 16)          // 2 KiB per wave: [32 rows][8 cos | 8 sin]
 #define RB_MAX_W 10
+#ifndef RB_PD
+#define RB_PD 3                           // LDS read pipeline depth of the MFMA loop
+#endif
+
+template <typename F>
+__device__ __forceinline__ void rb_call_restrict(F&& f, int j, const bf16_t* __restrict__ cur, bf16_t* __restrict__ nxt) {
+  f(j, cur, nxt);
+}
 
 template <int EPI>
 __global__ __launch_bounds__(64 * RB_MAX_W) void gemm_rb256_kernel(GemmArgs p, int W) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   bf16_t* const Bs = reinterpret_cast<bf16_t*>(smem);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, NT = blockDim.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   float* const Es = reinterpret_cast<float*>(smem + 2 * RB_TILE_HALFS * 2) + wave * RB_EFLOATS;
+  float* const Rs = reinterpret_cast<float*>(smem + 2 * RB_TILE_HALFS * 2) + W * RB_EFLOATS + wave * RB_ROPE_FLOATS;
   const int m0 = (blockIdx.x * W + wave) * 32;
   const int fr = lane & 31, fk = (lane >> 5) * 8;
 
@@ -37,68 +51,120 @@ __global__ __launch_bounds__(64 * RB_MAX_W) void gemm_rb256_kernel(GemmArgs p, i
 #pragma unroll
     for (int ks = 0; ks < 16; ++ks) af[ks] = *reinterpret_cast<const bf16x8*>(ap + ks * 16);
   }
+  if (EPI == EPI_QKV_ROPE) {
+    // lane -> (row = lane >> 1, cos | sin): 8 floats each
+    const int r = lane >> 1, t = (m0 + r) % p.rope_T;
+    const float* src = ((lane & 1) ? p.rope_sin : p.rope_cos) + t * 16;
+    const float4 x0 = *reinterpret_cast<const float4*>(src), x1 = *reinterpret_cast<const float4*>(src + 4);
+    *reinterpret_cast<float4*>(Rs + r * 16 + (lane & 1) * 8) = x0;
+    *reinterpret_cast<float4*>(Rs + r * 16 + (lane & 1) * 8 + 4) = x1;
+  }
 
   const int ntiles = (p.N + RB_BN - 1) / RB_BN;
-  uint4 st[4];   // weight-tile staging: 2048 16-B chunks over NT threads (NT >= 512 -> at most 4 each)
-  auto load_tile = [&](int n0) {
+  // Weight tiles go HBM/L2 -> LDS directly (global_load_lds_dwordx4: no staging registers, no ds_write).  One wave
+  // instruction fills 1 KiB = two 512-B tile rows in lane order, so rows are unpadded and the 16-B chunk c of tile row r
+  // is stored at chunk position c ^ (r & 31): the 32 lanes of a fragment read (same k chunk, 32 different rows) then
+  // hit 32 different 16-B columns (conflict-free ds_read_b128).  The swizzle is applied on the GLOBAL side: the lane
+  // that writes position q of row r fetches chunk q ^ (r & 31).  Weight rows >= N are clamped to row N-1 (their output
+  // columns are never stored).
+  typedef __attribute__((address_space(3))) void lds_void;
+  typedef __attribute__((address_space(1))) const void gbl_void;
+  auto load_tile = [&](int n0, bf16_t* S) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int c = tid + NT * i;
-      if (c < 2048) {
-        const int row = c >> 5, kc = (c & 31) * 8;
-        const int g = n0 + row;
-        const int gc = g < p.N ? g : p.N - 1;
-        const uint4 t = *reinterpret_cast<const uint4*>(p.B + (long long)gc * p.ldb + kc);
-        st[i] = (g < p.N) ? t : make_uint4(0, 0, 0, 0);
+      const int k = wave + W * i;            // wave-uniform: which 1-KiB piece (two rows) of the tile
+      if (k < 32) {
+        const int r = 2 * k + (lane >> 5), q = lane & 31;
+        const int g = n0 + r, gc = g < p.N ? g : p.N - 1;
+        const bf16_t* src = p.B + (long long)gc * p.ldb + ((q ^ (r & 31)) * 8);
+        __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(S + k * 512), 16, 0, 0);
       }
     }
   };
-  auto store_tile = [&](bf16_t* S) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int c = tid + NT * i;
-      if (c < 2048) *reinterpret_cast<uint4*>(S + (c >> 5) * RB_PITCH + (c & 31) * 8) = st[i];
-    }
-  };
-  load_tile(0);
-  store_tile(Bs);
+  auto bias_at = [&](int col) { return p.bias[col < p.N ? col : p.N - 1]; };
+  const bool has_bias = p.bias != nullptr;
+  GemmArgs q = p;
+  q.bias = nullptr;   // folded into the accumulator initialisation below
+
+  load_tile(0, Bs);
+  float bz0 = 0.f, bz1 = 0.f, bn0 = 0.f, bn1 = 0.f;
+  if (has_bias) { bz0 = bias_at(fr); bz1 = bias_at(32 + fr); }
+  __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0)
   __syncthreads();
 
-  for (int j = 0; j < ntiles; ++j) {
-    const bf16_t* cur = Bs + (j & 1) * RB_TILE_HALFS;
-    if (j + 1 < ntiles) load_tile((j + 1) * RB_BN);
+  const int sw = fr & 31, hk = lane >> 5;
+  auto tile = [&](int j, const bf16_t* cur, bf16_t* nxt) {
+    // prefetch for tile j + 1 (past the last tile: a clamped, unused re-read of the last rows).  Every wave finished
+    // reading that buffer before the barrier that ended the previous iteration.
+    load_tile((j + 1) * RB_BN, nxt);
+    if (has_bias) { bn0 = bias_at((j + 1) * RB_BN + fr); bn1 = bias_at((j + 1) * RB_BN + 32 + fr); }
     f32x16 acc0, acc1;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+    for (int r = 0; r < 16; ++r) { acc0[r] = bz0; acc1[r] = bz1; }
+    {
+      const bf16_t* wp0 = cur + fr * RB_K;
+      const bf16_t* wp1 = wp0 + 32 * RB_K;
+      bf16x8 wa[RB_PD], wb[RB_PD];
 #pragma unroll
-    for (int ks = 0; ks < 16; ++ks) {
-      const bf16x8 w0 = *reinterpret_cast<const bf16x8*>(cur + fr * RB_PITCH + ks * 16 + fk);
-      const bf16x8 w1 = *reinterpret_cast<const bf16x8*>(cur + (32 + fr) * RB_PITCH + ks * 16 + fk);
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks], w0, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks], w1, acc1, 0, 0, 0);
-    }
-    // wave-private transpose: accumulator (lane = column, registers = rows) -> rows of 64 contiguous columns
+      for (int d = 0; d < RB_PD - 1; ++d) {
+        wa[d] = *reinterpret_cast<const bf16x8*>(wp0 + (((2 * d + hk) ^ sw) * 8));
+        wb[d] = *reinterpret_cast<const bf16x8*>(wp1 + (((2 * d + hk) ^ sw) * 8));
+      }
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      Es[row * RB_EPITCH + fr] = acc0[r];
-      Es[row * RB_EPITCH + 32 + fr] = acc1[r];
+      for (int ks = 0; ks < 16; ++ks) {
+        if (ks + RB_PD - 1 < 16) {
+          const int kn = ks + RB_PD - 1;
+          wa[kn % RB_PD] = *reinterpret_cast<const bf16x8*>(wp0 + (((2 * kn + hk) ^ sw) * 8));
+          wb[kn % RB_PD] = *reinterpret_cast<const bf16x8*>(wp1 + (((2 * kn + hk) ^ sw) * 8));
+        }
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks], wa[ks % RB_PD], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks], wb[ks % RB_PD], acc1, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);   // keep the reads ahead of the MFMAs (the scheduler sinks them otherwise)
+      }
     }
-    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0)
-    __builtin_amdgcn_wave_barrier();
+    // The next tile had the whole MFMA phase to land.  Waiting HERE -- before this tile's stores are issued -- lets the
+    // stores stay in flight across the barrier and through the next MFMA phase (vmcnt completes in order).
+    __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0)
+    // wave-private transpose, rows 0-15 then 16-31 of the slab (accumulator registers 0-7 / 8-15):
+    // (lane = column, registers = rows) -> rows of 64 contiguous columns
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int task = lane + 64 * i, row = task >> 3, cg = task & 7;
-      float v[8];
-      const float4 c0 = *reinterpret_cast<const float4*>(Es + row * RB_EPITCH + cg * 8);
-      const float4 c1 = *reinterpret_cast<const float4*>(Es + row * RB_EPITCH + cg * 8 + 4);
-      v[0] = c0.x; v[1] = c0.y; v[2] = c0.z; v[3] = c0.w; v[4] = c1.x; v[5] = c1.y; v[6] = c1.z; v[7] = c1.w;
-      epilogue8<EPI>(p, m0 + row, j * RB_BN + cg * 8, v, (m0 + row) < p.M, 0, 1);
+    for (int hf = 0; hf < 2; ++hf) {
+#pragma unroll
+      for (int rr = 0; rr < 8; ++rr) {
+        const int r = hf * 8 + rr;
+        const int row = (rr & 3) + 8 * (rr >> 2) + 4 * (lane >> 5);   // 0..15 within this half
+        Es[row * RB_EPITCH + fr] = acc0[r];
+        Es[row * RB_EPITCH + 32 + fr] = acc1[r];
+      }
+      __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0)
+      __builtin_amdgcn_wave_barrier();
+      auto task = [&](int i) {
+        const int t = lane + 64 * i, rl = t >> 3, cg = t & 7;
+        const int row = hf * 16 + rl;
+        float v[8];
+        const float4 c0 = *reinterpret_cast<const float4*>(Es + rl * RB_EPITCH + cg * 8);
+        const float4 c1 = *reinterpret_cast<const float4*>(Es + rl * RB_EPITCH + cg * 8 + 4);
+        v[0] = c0.x; v[1] = c0.y; v[2] = c0.z; v[3] = c0.w; v[4] = c1.x; v[5] = c1.y; v[6] = c1.z; v[7] = c1.w;
+        epilogue8<EPI>(q, m0 + row, j * RB_BN + cg * 8, v, (m0 + row) < p.M, 0, 1, EPI == EPI_QKV_ROPE ? Rs + row * 16 : nullptr);
+      };
+      // light epilogues run both tasks interleaved; the heavy ones (activation maths, extra operands) one after the
+      // other, or their temporaries spill (the kernel lives at the 168-VGPR limit of 3 waves per SIMD)
+      if constexpr (EPI == EPI_BF16 || EPI == EPI_F32) {
+        task(0);
+        task(1);
+      } else {
+#pragma nounroll
+        for (int i = 0; i < 2; ++i) task(i);
+      }
+      __builtin_amdgcn_wave_barrier();      // the next writes to Es stay behind these reads
     }
-    __builtin_amdgcn_wave_barrier();      // the next tile's writes to Es stay behind these reads
-    if (j + 1 < ntiles) store_tile(Bs + ((j + 1) & 1) * RB_TILE_HALFS);
     __syncthreads();
-  }
+    bz0 = bn0; bz1 = bn1;
+  };
+  // cur / nxt reach the tile body as __restrict__ parameters (rb_call_restrict): the compiler waits for every pending
+  // global_load_lds before an LDS read it cannot prove disjoint from the DMA's target
+  for (int j = 0; j < ntiles; ++j)
+    rb_call_restrict(tile, j, Bs + (j & 1) * RB_TILE_HALFS, Bs + ((j + 1) & 1) * RB_TILE_HALFS);
 }
 
 static int rb_waves(int M) {
@@ -123,7 +189,7 @@ template <int EPI>
 static int launch_rb_t(const GemmArgs& a, hipStream_t s) {
   static bool attr_set = false;
   auto kern = gemm_rb256_kernel<EPI>;
-  const size_t lds_max = (size_t)2 * RB_TILE_HALFS * 2 + (size_t)RB_MAX_W * RB_EFLOATS * 4;
+  const size_t lds_max = (size_t)2 * RB_TILE_HALFS * 2 + (size_t)RB_MAX_W * (RB_EFLOATS + RB_ROPE_FLOATS) * 4;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
     if (e != hipSuccess) {
@@ -134,7 +200,7 @@ static int launch_rb_t(const GemmArgs& a, hipStream_t s) {
   }
   const int W = rb_waves(a.M);
   const int blocks = cdiv(cdiv(a.M, 32), W);
-  const size_t lds = (size_t)2 * RB_TILE_HALFS * 2 + (size_t)W * RB_EFLOATS * 4;
+  const size_t lds = (size_t)2 * RB_TILE_HALFS * 2 + (size_t)W * (RB_EFLOATS + (EPI == EPI_QKV_ROPE ? RB_ROPE_FLOATS : 0)) * 4;
   hipLaunchKernelGGL(kern, dim3(blocks), dim3(64 * W), lds, s, a, W);
   COATI_LAUNCH_CHECK("gemm_rb256");
   return COATI_OK;

@@ -1,26 +1,14 @@
 """Micro-benchmark of the GEMM family at the shapes of the grande step (run on the GPU box)."""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import torch
 from coati_amd import ops
 
 dev = "cuda:0"
 M = 81920
 
-def timeit(fn, reps=20):
-    for _ in range(3):
-        fn()
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
-        fn()
-    e1.record()
-    torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / reps * 1e3  # us
-
-def row(name, us, flops, bytes_):
-    print(f"{name:44s} {us:8.1f} us  {flops/us/1e6:7.1f} TFLOP/s  {bytes_/us/1e6:6.2f} TB/s", flush=True)
+from gemm_bench_util import timeit, row
 
 torch.manual_seed(0)
 for (N, K) in [(768, 256), (256, 256), (1024, 256), (256, 1024), (256, 768), (1024, 1024)]:
