@@ -8,9 +8,11 @@ __device__ __forceinline__ int frag_row(int r, int lane) { return (r & 3) + 8 * 
 // ---- epilogue on 8 consecutive columns of one row ----------------------------------------------------
 template <int EPI, int ROPE_PARTNER = 1>
 __device__ __forceinline__ void epilogue8(const GemmArgs& p, int row, int col0, float (&v)[8], bool rowok,
-                                          int tile_n, int tiles_n, const float* rope_row = nullptr) {
-  // rope_row: optional [8 cos | 8 sin] of this row's token position, pre-staged by the caller (LDS) instead of the
-  // global tables
+                                          int tile_n, int tiles_n, const void* staged = nullptr) {
+  // staged: optional operand the caller pre-staged (in LDS) so that the epilogue issues no global load for it:
+  //   EPI_QKV_ROPE       -> float[16] = [8 cos | 8 sin] of this row's token position (instead of the global tables)
+  //   EPI_DGELU / DSILU  -> uint4 = the 8 saved pre-activations aux_in[row, col0..col0+7]
+  const float* rope_row = (EPI == EPI_QKV_ROPE) ? reinterpret_cast<const float*>(staged) : nullptr;
   const int N = p.N;
   if (p.bias != nullptr) {
     if (col0 + 8 <= N) {
@@ -107,7 +109,9 @@ __device__ __forceinline__ void epilogue8(const GemmArgs& p, int row, int col0, 
   } else if (EPI == EPI_DGELU || EPI == EPI_DSILU) {
     const bf16_t* X = reinterpret_cast<const bf16_t*>(p.aux_in);
     float x[8];
-    if (full) {
+    if (staged) {
+      unpack8(*reinterpret_cast<const uint4*>(staged), x);
+    } else if (full) {
       unpack8(*reinterpret_cast<const uint4*>(X + aoff), x);
     } else {
       for (int e = 0; e < 8; ++e) x[e] = (col0 + e < N) ? bf2f(X[aoff + e]) : 0.f;

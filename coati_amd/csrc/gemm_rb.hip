@@ -15,6 +15,7 @@
 //     segments, 16-B stores;
 //   * W waves per workgroup is chosen on the host so that the grid is a whole number of 256-CU rounds.
 // Probe with the phase ablations that led to this shape: tools/probes/rb_probe.hip.
+#include <cstdlib>
 #include "gemm_epi.h"
 
 #define RB_K 256
@@ -23,6 +24,7 @@
 #define RB_EPITCH 68                      // floats per row of the per-wave transpose region
 #define RB_EFLOATS (16 * RB_EPITCH)       // 4,352 B per wave: 16 rows x 64 columns
 #define RB_ROPE_FLOATS (32 * 16)          // 2 KiB per wave: [32 rows][8 cos | 8 sin]
+#define RB_AUX_BYTES 4096                 // per wave: the 32 x 64 bf16 block of saved pre-activations of the current tile
 #define RB_MAX_W 10
 #ifndef RB_PD
 #define RB_PD 3                           // LDS read pipeline depth of the MFMA loop
@@ -40,6 +42,8 @@ __global__ __launch_bounds__(64 * RB_MAX_W) void gemm_rb256_kernel(GemmArgs p, i
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   float* const Es = reinterpret_cast<float*>(smem + 2 * RB_TILE_HALFS * 2) + wave * RB_EFLOATS;
   float* const Rs = reinterpret_cast<float*>(smem + 2 * RB_TILE_HALFS * 2) + W * RB_EFLOATS + wave * RB_ROPE_FLOATS;
+  unsigned char* const Xs = smem + 2 * RB_TILE_HALFS * 2 + (size_t)W * RB_EFLOATS * 4 + wave * RB_AUX_BYTES;   // DGELU / DSILU
+  constexpr bool AUX = (EPI == EPI_DGELU || EPI == EPI_DSILU);
   const int m0 = (blockIdx.x * W + wave) * 32;
   const int fr = lane & 31, fk = (lane >> 5) * 8;
 
@@ -81,6 +85,18 @@ __global__ __launch_bounds__(64 * RB_MAX_W) void gemm_rb256_kernel(GemmArgs p, i
       }
     }
   };
+  // saved pre-activations of this wave's 32 x 64 output block, DMA'd in epilogue-task order (task = lane + 64 i <->
+  // row (task >> 3), columns (task & 7) * 8 .. +7): the epilogue reads its 16 B back with one ds_read_b128.  The block
+  // is consumed after the MFMA phase of the same tile, behind the same vmcnt(0) as the next weight tile.
+  auto load_aux = [&](int n0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int t = lane + 64 * i, row = m0 + (t >> 3), col = n0 + (t & 7) * 8;
+      const int rc = row < p.M ? row : p.M - 1, cc = col + 8 <= p.N ? col : 0;
+      const bf16_t* src = reinterpret_cast<const bf16_t*>(p.aux_in) + (long long)rc * p.ld_aux + cc;
+      __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(Xs + i * 1024), 16, 0, 0);
+    }
+  };
   auto bias_at = [&](int col) { return p.bias[col < p.N ? col : p.N - 1]; };
   const bool has_bias = p.bias != nullptr;
   GemmArgs q = p;
@@ -97,6 +113,7 @@ __global__ __launch_bounds__(64 * RB_MAX_W) void gemm_rb256_kernel(GemmArgs p, i
     // prefetch for tile j + 1 (past the last tile: a clamped, unused re-read of the last rows).  Every wave finished
     // reading that buffer before the barrier that ended the previous iteration.
     load_tile((j + 1) * RB_BN, nxt);
+    if constexpr (AUX) load_aux(j * RB_BN);
     if (has_bias) { bn0 = bias_at((j + 1) * RB_BN + fr); bn1 = bias_at((j + 1) * RB_BN + 32 + fr); }
     f32x16 acc0, acc1;
 #pragma unroll
@@ -145,7 +162,10 @@ __global__ __launch_bounds__(64 * RB_MAX_W) void gemm_rb256_kernel(GemmArgs p, i
         const float4 c0 = *reinterpret_cast<const float4*>(Es + rl * RB_EPITCH + cg * 8);
         const float4 c1 = *reinterpret_cast<const float4*>(Es + rl * RB_EPITCH + cg * 8 + 4);
         v[0] = c0.x; v[1] = c0.y; v[2] = c0.z; v[3] = c0.w; v[4] = c1.x; v[5] = c1.y; v[6] = c1.z; v[7] = c1.w;
-        epilogue8<EPI>(q, m0 + row, j * RB_BN + cg * 8, v, (m0 + row) < p.M, 0, 1, EPI == EPI_QKV_ROPE ? Rs + row * 16 : nullptr);
+        const void* staged = nullptr;
+        if constexpr (EPI == EPI_QKV_ROPE) staged = Rs + row * 16;
+        if constexpr (AUX) staged = Xs + (size_t)(lane + 64 * (2 * hf + i)) * 16;
+        epilogue8<EPI>(q, m0 + row, j * RB_BN + cg * 8, v, (m0 + row) < p.M, 0, 1, staged);
       };
       // light epilogues run both tasks interleaved; the heavy ones (activation maths, extra operands) one after the
       // other, or their temporaries spill (the kernel lives at the 168-VGPR limit of 3 waves per SIMD)
@@ -177,19 +197,21 @@ static int rb_waves(int M) {
 
 // true when (a, epi) can run on the row-block kernel
 bool gemm_rb256_supported(const GemmArgs& a, int a_f32, int epi) {
+  // COATI_RB_EXCLUDE (A/B switch for tuning): bit 1 = N < 512, bit 2 = epilogues with extra row-major operands
+  static const int excl = getenv("COATI_RB_EXCLUDE") ? atoi(getenv("COATI_RB_EXCLUDE")) : 0;
   if (a_f32 || a.K != RB_K || epi == EPI_CE_PARTIAL) return false;
   if (a.N % 16 != 0 && epi != EPI_CE_BWD) return false;
-  if (a.N < 512) return false;   // measured: with only 2-4 column tiles the tiled kernel is as fast or faster
-  // epilogues that read or write extra row-major operands (f32 residuals, saved pre-activations): tiled kernel wins
-  if (epi == EPI_RES_F32 || epi == EPI_ACC_F32 || epi == EPI_F32 || epi == EPI_DGELU || epi == EPI_DSILU || epi == EPI_EDGE_DPRE) return false;
-  return rb_waves(a.M) >= 8;   // staging assumes >= 512 threads; smaller problems run on the tiled kernel
+  if (rb_waves(a.M) < 8) return false;   // small problems run on the tiled kernel
+  if ((excl & 1) && a.N < 512) return false;
+  if ((excl & 2) && (epi == EPI_RES_F32 || epi == EPI_ACC_F32 || epi == EPI_F32 || epi == EPI_DGELU || epi == EPI_DSILU || epi == EPI_EDGE_DPRE)) return false;
+  return true;
 }
 
 template <int EPI>
 static int launch_rb_t(const GemmArgs& a, hipStream_t s) {
   static bool attr_set = false;
   auto kern = gemm_rb256_kernel<EPI>;
-  const size_t lds_max = (size_t)2 * RB_TILE_HALFS * 2 + (size_t)RB_MAX_W * (RB_EFLOATS + RB_ROPE_FLOATS) * 4;
+  const size_t lds_max = (size_t)2 * RB_TILE_HALFS * 2 + (size_t)RB_MAX_W * (RB_EFLOATS * 4 + RB_AUX_BYTES);
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
     if (e != hipSuccess) {
@@ -200,7 +222,7 @@ static int launch_rb_t(const GemmArgs& a, hipStream_t s) {
   }
   const int W = rb_waves(a.M);
   const int blocks = cdiv(cdiv(a.M, 32), W);
-  const size_t lds = (size_t)2 * RB_TILE_HALFS * 2 + (size_t)W * (RB_EFLOATS + (EPI == EPI_QKV_ROPE ? RB_ROPE_FLOATS : 0)) * 4;
+  const size_t lds = (size_t)2 * RB_TILE_HALFS * 2 + (size_t)W * (RB_EFLOATS * 4 + (EPI == EPI_QKV_ROPE ? RB_ROPE_FLOATS * 4 : (EPI == EPI_DGELU || EPI == EPI_DSILU) ? RB_AUX_BYTES : 0));
   hipLaunchKernelGGL(kern, dim3(blocks), dim3(64 * W), lds, s, a, W);
   COATI_LAUNCH_CHECK("gemm_rb256");
   return COATI_OK;
