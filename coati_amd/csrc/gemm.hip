@@ -38,17 +38,19 @@ __device__ __forceinline__ void stage_load(StageB16& s, const bf16_t* base, long
   for (int i = 0; i < 1024 / NT; ++i) {
     const int c = tid + NT * i, row = c >> 3, kc = (c & 7) * 8;
     const int g = row0 + row;
-    const int gc = g < rows ? g : rows - 1;   // always a valid address; out-of-range rows are zeroed by select
-    const uint4 t = *reinterpret_cast<const uint4*>(base + (long long)gc * ld + k0 + kc);
-    s.v[i] = (g < rows) ? t : make_uint4(0, 0, 0, 0);
+    const int gc = g < rows ? g : rows - 1;   // always a valid address; out-of-range rows are zeroed in stage_store
+    s.v[i] = *reinterpret_cast<const uint4*>(base + (long long)gc * ld + k0 + kc);
   }
 }
+// The loaded registers are not touched between the load and this store (a select or mask right after the load makes the
+// compiler wait for the load on the spot, or predicate it behind an exec branch): rows >= `rows` are zeroed here.
 template <int NT>
-__device__ __forceinline__ void stage_store(const StageB16& s, bf16_t* S, int tid) {
+__device__ __forceinline__ void stage_store(const StageB16& s, bf16_t* S, int row0, int rows, int tid) {
 #pragma unroll
   for (int i = 0; i < 1024 / NT; ++i) {
     const int c = tid + NT * i, row = c >> 3, kc = (c & 7) * 8;
-    *reinterpret_cast<uint4*>(S + row * PITCH + kc) = s.v[i];
+    const unsigned keep = (row0 + row) < rows ? 0xffffffffu : 0u;
+    *reinterpret_cast<uint4*>(S + row * PITCH + kc) = make_uint4(s.v[i].x & keep, s.v[i].y & keep, s.v[i].z & keep, s.v[i].w & keep);
   }
 }
 template <int NT>
@@ -59,18 +61,18 @@ __device__ __forceinline__ void stage_load(StageF32& s, const float* base, long 
     const int c = tid + NT * i, row = c >> 4, kc = (c & 15) * 4;
     const int g = row0 + row;
     const int gc = g < rows ? g : rows - 1;
-    const float4 t = *reinterpret_cast<const float4*>(base + (long long)gc * ld + k0 + kc);
-    s.v[i] = (g < rows) ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+    s.v[i] = *reinterpret_cast<const float4*>(base + (long long)gc * ld + k0 + kc);
   }
 }
 template <int NT>
-__device__ __forceinline__ void stage_store(const StageF32& s, bf16_t* S, int tid) {
+__device__ __forceinline__ void stage_store(const StageF32& s, bf16_t* S, int row0, int rows, int tid) {
 #pragma unroll
   for (int i = 0; i < 2048 / NT; ++i) {
     const int c = tid + NT * i, row = c >> 4, kc = (c & 15) * 4;
+    const unsigned keep = (row0 + row) < rows ? 0xffffffffu : 0u;
     uint2 u;
-    u.x = pack2bf(s.v[i].x, s.v[i].y);
-    u.y = pack2bf(s.v[i].z, s.v[i].w);
+    u.x = pack2bf(s.v[i].x, s.v[i].y) & keep;
+    u.y = pack2bf(s.v[i].z, s.v[i].w) & keep;
     *reinterpret_cast<uint2*>(S + row * PITCH + kc) = u;
   }
 }
@@ -123,27 +125,62 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_nt_kernel(GemmArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  // register-staged double buffer: the loads of k-tile kt+1 are issued before the MFMAs of k-tile kt
+  // Two LDS buffers + two register stage sets: the loads of k-tile kt+2 are issued before the MFMAs of k-tile kt and
+  // are written to LDS one iteration later, so two k-tiles (64 KB per workgroup) are in flight.  All loads are
+  // unconditional (k offsets past the end are clamped to the last k-tile and never stored): no branch, no vmcnt(0).
   const int nk = p.K / BK;
-  STAGE_A sa;
-  StageB16 sb;
-  stage_load<NT>(sa, A, p.lda, m0, p.M, 0, tid);
-  stage_load<NT>(sb, p.B, p.ldb, n0, p.N, 0, tid);
-  stage_store<NT>(sa, lds, tid);
-  stage_store<NT>(sb, lds + 2 * TILE_HALFS, tid);
-  __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) {
-      stage_load<NT>(sa, A, p.lda, m0, p.M, (kt + 1) * BK, tid);
-      stage_load<NT>(sb, p.B, p.ldb, n0, p.N, (kt + 1) * BK, tid);
-    }
-    mma_ktile<MI>(lds + cur * TILE_HALFS, lds + (2 + cur) * TILE_HALFS, wm, wn, lane, acc);
-    if (kt + 1 < nk) {
-      stage_store<NT>(sa, lds + (cur ^ 1) * TILE_HALFS, tid);
-      stage_store<NT>(sb, lds + (2 + (cur ^ 1)) * TILE_HALFS, tid);
-    }
+  auto kofs = [&](int kt) { return (kt < nk ? kt : nk - 1) * BK; };
+  if constexpr (sizeof(AT) == 2) {
+    STAGE_A sa0, sa1;
+    StageB16 sb0, sb1;
+    stage_load<NT>(sa0, A, p.lda, m0, p.M, 0, tid);
+    stage_load<NT>(sb0, p.B, p.ldb, n0, p.N, 0, tid);
+    stage_load<NT>(sa1, A, p.lda, m0, p.M, kofs(1), tid);
+    stage_load<NT>(sb1, p.B, p.ldb, n0, p.N, kofs(1), tid);
+    stage_store<NT>(sa0, lds, m0, p.M, tid);
+    stage_store<NT>(sb0, lds + 2 * TILE_HALFS, n0, p.N, tid);
     __syncthreads();
+    for (int kt = 0; kt < nk; kt += 2) {
+      // even k-tile: LDS buffer 0; stage set 0 is free -> prefetch kt + 2; stage set 1 (kt + 1) goes to buffer 1
+      stage_load<NT>(sa0, A, p.lda, m0, p.M, kofs(kt + 2), tid);
+      stage_load<NT>(sb0, p.B, p.ldb, n0, p.N, kofs(kt + 2), tid);
+      mma_ktile<MI>(lds, lds + 2 * TILE_HALFS, wm, wn, lane, acc);
+      if (kt + 1 < nk) {
+        stage_store<NT>(sa1, lds + TILE_HALFS, m0, p.M, tid);
+        stage_store<NT>(sb1, lds + 3 * TILE_HALFS, n0, p.N, tid);
+      }
+      __syncthreads();
+      if (kt + 1 >= nk) break;
+      // odd k-tile: LDS buffer 1; prefetch kt + 3 into stage set 1; stage set 0 (kt + 2) goes to buffer 0
+      stage_load<NT>(sa1, A, p.lda, m0, p.M, kofs(kt + 3), tid);
+      stage_load<NT>(sb1, p.B, p.ldb, n0, p.N, kofs(kt + 3), tid);
+      mma_ktile<MI>(lds + TILE_HALFS, lds + 3 * TILE_HALFS, wm, wn, lane, acc);
+      if (kt + 2 < nk) {
+        stage_store<NT>(sa0, lds, m0, p.M, tid);
+        stage_store<NT>(sb0, lds + 2 * TILE_HALFS, n0, p.N, tid);
+      }
+      __syncthreads();
+    }
+  } else {
+    // f32 A (twice the staging registers): one stage set, prefetch distance 1
+    STAGE_A sa;
+    StageB16 sb;
+    stage_load<NT>(sa, A, p.lda, m0, p.M, 0, tid);
+    stage_load<NT>(sb, p.B, p.ldb, n0, p.N, 0, tid);
+    stage_store<NT>(sa, lds, m0, p.M, tid);
+    stage_store<NT>(sb, lds + 2 * TILE_HALFS, n0, p.N, tid);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+      const int cur = kt & 1;
+      stage_load<NT>(sa, A, p.lda, m0, p.M, kofs(kt + 1), tid);
+      stage_load<NT>(sb, p.B, p.ldb, n0, p.N, kofs(kt + 1), tid);
+      mma_ktile<MI>(lds + cur * TILE_HALFS, lds + (2 + cur) * TILE_HALFS, wm, wn, lane, acc);
+      if (kt + 1 < nk) {
+        stage_store<NT>(sa, lds + (cur ^ 1) * TILE_HALFS, m0, p.M, tid);
+        stage_store<NT>(sb, lds + (2 + (cur ^ 1)) * TILE_HALFS, n0, p.N, tid);
+      }
+      __syncthreads();
+    }
   }
 
   // accumulators -> LDS (fp32) -> row-contiguous epilogue
