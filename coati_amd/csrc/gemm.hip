@@ -117,13 +117,19 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_nt_kernel(GemmArgs p) {
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const AT* A = reinterpret_cast<const AT*>(p.A);
 
+  // the bias is folded into the accumulator initialisation (lane = output column): no bias loads in the epilogue
   f32x16 acc[MI][2];
+  GemmArgs q = p;
+  q.bias = nullptr;
 #pragma unroll
-  for (int i = 0; i < MI; ++i)
+  for (int j = 0; j < 2; ++j) {
+    const int col = n0 + wn * 64 + j * 32 + (lane & 31);
+    const float b = (p.bias != nullptr) ? p.bias[col < p.N ? col : p.N - 1] : 0.f;
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = b;
+  }
 
   // Two LDS buffers + two register stage sets: the loads of k-tile kt+2 are issued before the MFMAs of k-tile kt and
   // are written to LDS one iteration later, so two k-tiles (64 KB per workgroup) are in flight.  All loads are
@@ -193,14 +199,36 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_nt_kernel(GemmArgs p) {
       for (int r = 0; r < 16; ++r)
         Cs[(wm * 32 * MI + i * 32 + frag_row(r, lane)) * CPITCH + wn * 64 + j * 32 + (lane & 31)] = acc[i][j][r];
   __syncthreads();
+  // extra row-major operands of the epilogue (f32 residual / accumulate target, saved pre-activations): all tasks' loads
+  // are issued first, so their latency is paid once per workgroup instead of once per task
+  constexpr int TASKS = 2048 / NT;
+  constexpr bool PRE_F32 = (EPI == EPI_RES_F32 || EPI == EPI_ACC_F32);
+  constexpr bool PRE_B16 = (EPI == EPI_DGELU || EPI == EPI_DSILU);
+  EpiPre pre[TASKS];
 #pragma unroll
-  for (int i = 0; i < 2048 / NT; ++i) {
+  for (int i = 0; i < TASKS; ++i) {
+    const int task = tid + NT * i, r = task >> 4, cg = task & 15;
+    const int row = m0 + r, col0 = n0 + cg * 8;
+    pre[i].have = (PRE_F32 || PRE_B16) && row < p.M && col0 + 8 <= p.N;
+    if (pre[i].have) {
+      if constexpr (PRE_F32) {
+        const float* src = (EPI == EPI_RES_F32) ? reinterpret_cast<const float*>(p.aux_in) + (long long)row * p.ld_aux + col0
+                                                : reinterpret_cast<const float*>(p.C) + (long long)row * p.ldc + col0;
+        pre[i].f0 = *reinterpret_cast<const float4*>(src);
+        pre[i].f1 = *reinterpret_cast<const float4*>(src + 4);
+      }
+      if constexpr (PRE_B16)
+        pre[i].h = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(p.aux_in) + (long long)row * p.ld_aux + col0);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < TASKS; ++i) {
     const int task = tid + NT * i, r = task >> 4, cg = task & 15;
     float v[8];
     const float4 c0 = *reinterpret_cast<const float4*>(Cs + r * CPITCH + cg * 8);
     const float4 c1 = *reinterpret_cast<const float4*>(Cs + r * CPITCH + cg * 8 + 4);
     v[0] = c0.x; v[1] = c0.y; v[2] = c0.z; v[3] = c0.w; v[4] = c1.x; v[5] = c1.y; v[6] = c1.z; v[7] = c1.w;
-    epilogue8<EPI>(p, m0 + r, n0 + cg * 8, v, (m0 + r) < p.M, tile_n, tiles_n);
+    epilogue8<EPI>(q, m0 + r, n0 + cg * 8, v, (m0 + r) < p.M, tile_n, tiles_n, nullptr, &pre[i]);
   }
 }
 

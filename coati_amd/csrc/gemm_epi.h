@@ -6,12 +6,20 @@
 __device__ __forceinline__ int frag_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
 // ---- epilogue on 8 consecutive columns of one row ----------------------------------------------------
+// register-resident pre-loaded extra operand of one task (tiled kernel): see `staged` below for the meaning per epilogue
+struct EpiPre {
+  float4 f0, f1;
+  uint4 h;
+  bool have;
+};
+
 template <int EPI, int ROPE_PARTNER = 1>
 __device__ __forceinline__ void epilogue8(const GemmArgs& p, int row, int col0, float (&v)[8], bool rowok,
-                                          int tile_n, int tiles_n, const void* staged = nullptr) {
+                                          int tile_n, int tiles_n, const void* staged = nullptr, const EpiPre* pre = nullptr) {
   // staged: optional operand the caller pre-staged (in LDS) so that the epilogue issues no global load for it:
   //   EPI_QKV_ROPE       -> float[16] = [8 cos | 8 sin] of this row's token position (instead of the global tables)
   //   EPI_DGELU / DSILU  -> uint4 = the 8 saved pre-activations aux_in[row, col0..col0+7]
+  //   EPI_RES_F32        -> float4[2] = aux_in[row, col0..col0+7];   EPI_ACC_F32 -> float4[2] = C[row, col0..col0+7]
   const float* rope_row = (EPI == EPI_QKV_ROPE) ? reinterpret_cast<const float*>(staged) : nullptr;
   const int N = p.N;
   if (p.bias != nullptr) {
@@ -53,12 +61,16 @@ __device__ __forceinline__ void epilogue8(const GemmArgs& p, int row, int col0, 
       float4 o0 = make_float4(v[0], v[1], v[2], v[3]), o1 = make_float4(v[4], v[5], v[6], v[7]);
       if (EPI == EPI_RES_F32) {
         const float* R = reinterpret_cast<const float*>(p.aux_in);
-        const float4 r0 = *reinterpret_cast<const float4*>(R + aoff), r1 = *reinterpret_cast<const float4*>(R + aoff + 4);
+        float4 r0, r1;
+        if (pre && pre->have) { r0 = pre->f0; r1 = pre->f1; }
+        else { r0 = *reinterpret_cast<const float4*>(R + aoff); r1 = *reinterpret_cast<const float4*>(R + aoff + 4); }
         o0.x += r0.x; o0.y += r0.y; o0.z += r0.z; o0.w += r0.w;
         o1.x += r1.x; o1.y += r1.y; o1.z += r1.z; o1.w += r1.w;
       }
       if (EPI == EPI_ACC_F32) {
-        const float4 r0 = *reinterpret_cast<const float4*>(C + off), r1 = *reinterpret_cast<const float4*>(C + off + 4);
+        float4 r0, r1;
+        if (pre && pre->have) { r0 = pre->f0; r1 = pre->f1; }
+        else { r0 = *reinterpret_cast<const float4*>(C + off); r1 = *reinterpret_cast<const float4*>(C + off + 4); }
         o0.x += r0.x; o0.y += r0.y; o0.z += r0.z; o0.w += r0.w;
         o1.x += r1.x; o1.y += r1.y; o1.z += r1.z; o1.w += r1.w;
       }
@@ -109,7 +121,9 @@ __device__ __forceinline__ void epilogue8(const GemmArgs& p, int row, int col0, 
   } else if (EPI == EPI_DGELU || EPI == EPI_DSILU) {
     const bf16_t* X = reinterpret_cast<const bf16_t*>(p.aux_in);
     float x[8];
-    if (staged) {
+    if (pre && pre->have) {
+      unpack8(pre->h, x);
+    } else if (staged) {
       unpack8(*reinterpret_cast<const uint4*>(staged), x);
     } else if (full) {
       unpack8(*reinterpret_cast<const uint4*>(X + aoff), x);
