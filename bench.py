@@ -8,7 +8,13 @@ backward, clip-norm, AdamW, DP collectives) on the grande_closed configuration, 
 
 Prints ONE JSON line on rank 0 (contract in the task statement): whole-job molecules/s with inputs resident in HBM,
 plus `roofline` (dominant kernel, timed live with HIP events on the launch stream) and, at N=1, `cpu_baseline`
-(the oracle's fp32 CPU step on a bounded sample of the same workload, on this box's host cores)."""
+(the oracle's fp32 CPU step on a bounded sample of the same workload, on this box's host cores).
+
+roofline: the dominant launch site is the transformer weight-gradient kernel (`xf_wgrad`, 128 launches per step).  Its
+arithmetic intensity N*K/(N+K) = 128..205 flop/B is below the MI355X ridge (2.5 PFLOP/s / 8 TB/s = 312 flop/B), so the
+bound is HBM: achieved = algorithmic bytes per launch (both bf16 activation operands once + the f32 gradient
+read-modify-write) / average launch time.  `traffic` is the measured HBM bytes per launch of that
+kernel (rocprofv3 PMC passes of this same command, profiles/r01_pmc_summary.json), null if that file is absent."""
 import argparse
 import json
 import os
@@ -132,6 +138,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     site_ms, site_n, site_flops = eng.prof_collect()
+    site_bytes = eng.prof_last_bytes()
     eng.prof_select(-1)
     if dist_on:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -146,18 +153,37 @@ def main():
             step()
             torch.cuda.synchronize()
             ms, n, fl = eng.prof_collect()
-            rows.append((ms, s, n, fl))
+            rows.append((ms, s, n, fl, eng.prof_last_bytes()))
         eng.prof_select(-1)
         tot = sum(r[0] for r in rows)
-        for ms, s, n, fl in sorted(rows, reverse=True):
+        for ms, s, n, fl, by in sorted(rows, reverse=True):
             tf = (fl * n / (ms * 1e-3) / 1e12) if ms > 0 and fl > 0 else 0.0
-            print(f"  site {s:16s} {ms:8.3f} ms/step  {100 * ms / max(tot, 1e-9):5.1f}%  launches {n:4d}  {tf:7.1f} TFLOP/s", file=sys.stderr)
+            tb = (by * n / (ms * 1e-3) / 1e12) if ms > 0 and by > 0 else 0.0
+            print(f"  site {s:16s} {ms:8.3f} ms/step  {100 * ms / max(tot, 1e-9):5.1f}%  launches {n:4d}  {tf:7.1f} TFLOP/s  {tb:5.2f} TB/s (algorithmic)", file=sys.stderr)
         print(f"  sum of sites {tot:.3f} ms/step", file=sys.stderr)
 
     if rank == 0:
         mols = args.batch * world * args.steps
         avg_ms = site_ms / max(site_n, 1)
-        achieved = (site_flops / (avg_ms * 1e-3) / 1e12) if avg_ms > 0 else 0.0
+        tflops = (site_flops / (avg_ms * 1e-3) / 1e12) if avg_ms > 0 else 0.0
+        gbs = (site_bytes / (avg_ms * 1e-3) / 1e9) if avg_ms > 0 else 0.0
+        # bound by arithmetic intensity against the ridge point (dense bf16 MFMA peak / HBM peak)
+        ridge = PEAK_BF16_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9)
+        hbm_bound = site_bytes > 0 and (site_flops / site_bytes) < ridge
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")) as f:
+                traffic = json.load(f).get(args.roofline_site, {}).get("hbm_bytes_per_launch")
+        except (OSError, ValueError):
+            pass
+        if hbm_bound:
+            roof = {"bound": "hbm", "kernel": args.roofline_site, "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                    "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": traffic, "avg_launch_ms": round(avg_ms, 5), "launches": site_n,
+                    "bytes_per_launch": site_bytes, "flops_per_launch": site_flops, "tflops": round(tflops, 1)}
+        else:
+            roof = {"bound": "mfma", "kernel": args.roofline_site, "achieved": round(tflops, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(tflops / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "avg_launch_ms": round(avg_ms, 5), "launches": site_n,
+                    "bytes_per_launch": site_bytes, "flops_per_launch": site_flops}
         out = {
             "metric": "molecules/sec (contrastive+AR train step), " + ("grande_closed" if args.head == "infonce" else "barlow_closed"),
             "value": round(mols / dt, 2),
@@ -176,9 +202,7 @@ def main():
                                    f"fp32 accumulate + fp32 master weights, random-init weights",
                        "global_batch": args.batch * world, "seq_len": args.seq, "parallelism": f"dp{world}"},
             "loss": {k: round(v, 4) for k, v in losses.items() if k in ("ar_loss", "clip_loss", "loss")},
-            "roofline": {"bound": "mfma", "kernel": args.roofline_site, "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
-                         "avg_launch_ms": round(avg_ms, 5), "launches": site_n, "flops_per_launch": site_flops},
+            "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(batch_cpu, up_cpu, args.cpu_mols)

@@ -145,6 +145,8 @@ struct coati_engine {
   std::vector<hipEvent_t> ev;
   int ev_used = 0;
   double prof_flops = 0.0;
+  double prof_last_bytes = 0.0;   // per launch, of the last prof_collect
+  double prof_bytes = 0.0;   // algorithmic HBM bytes (operands read once, results written once) of the selected site
 };
 
 namespace {
@@ -276,11 +278,12 @@ struct ProfScope {
   coati_engine* e;
   hipStream_t s;
   bool on;
-  ProfScope(coati_engine* e_, int site, double flops, hipStream_t s_) : e(e_), s(s_), on(false) {
+  ProfScope(coati_engine* e_, int site, double flops, hipStream_t s_, double bytes = 0.0) : e(e_), s(s_), on(false) {
     if (e->prof_site == site && e->ev_used + 2 <= (int)e->ev.size()) {
       on = true;
       hipEventRecord(e->ev[e->ev_used], s);
       e->prof_flops += flops;
+      e->prof_bytes += bytes;
     }
   }
   ~ProfScope() {
@@ -299,7 +302,12 @@ int gemm(coati_engine* e, int site, const void* A, int a_f32, int64_t lda, const
   memset(&a, 0, sizeof(a));
   a.A = A; a.lda = lda; a.B = Bm; a.ldb = ldb; a.M = M; a.N = N; a.K = K; a.C = Cm; a.ldc = ldc; a.bias = bias;
   a.aux_in = aux_in; a.aux_out = aux_out; a.ld_aux = ld_aux;
-  ProfScope ps(e, site, 2.0 * M * N * K, s);
+  // algorithmic bytes: A once, weights once, every output / extra operand once
+  const bool out32 = (epi == EPI_F32 || epi == EPI_RES_F32 || epi == EPI_ACC_F32);
+  double bytes = (double)M * K * (a_f32 ? 4 : 2) + (double)N * K * 2 + (double)M * N * (out32 ? 4 : 2);
+  if (epi == EPI_RES_F32 || epi == EPI_ACC_F32) bytes += (double)M * N * 4;
+  if (epi == EPI_GELU || epi == EPI_SILU || epi == EPI_DGELU || epi == EPI_DSILU) bytes += (double)M * N * 2;
+  ProfScope ps(e, site, 2.0 * M * N * K, s, bytes);
   return launch_gemm_nt(a, a_f32, epi, s);
 }
 int wgrad(coati_engine* e, int site, const void* A, int a_f32, int64_t lda, const bf16_t* Bm, int64_t ldb, int M,
@@ -307,7 +315,8 @@ int wgrad(coati_engine* e, int site, const void* A, int a_f32, int64_t lda, cons
   WgradArgs a;
   a.A = A; a.lda = lda; a.B = Bm; a.ldb = ldb; a.M = M; a.N = N; a.K = K; a.dW = dW; a.ldw = ldw; a.dbias = dbias;
   a.n_out = n_out;
-  ProfScope ps(e, site, 2.0 * M * N * K, s);
+  // algorithmic bytes: both activation operands once + the f32 gradient read-modify-write
+  ProfScope ps(e, site, 2.0 * M * N * K, s, (double)M * N * (a_f32 ? 4 : 2) + (double)M * K * 2 + (double)N * K * 8);
   return launch_wgrad(a, a_f32, s);
 }
 
@@ -415,7 +424,7 @@ int xformer_fwd(coati_engine* e, XPass& p, const float* injection, hipStream_t s
   for (int l = 0; l < L; ++l) {
     const XLayerP& w = e->xl[l];
     {
-      ProfScope ps(e, SITE_LN_FWD, 0, s);
+      ProfScope ps(e, SITE_LN_FWD, 0, s, (double)M * C * 6 + (double)M * 8);
       COATI_TRY(launch_layernorm_fwd(p.x[l], C, e->P + w.ln1w, e->P + w.ln1b, p.a1[l], C, nullptr, 0, p.mean1[l], p.rstd1[l], M, C, s));
     }
     {
@@ -424,22 +433,22 @@ int xformer_fwd(coati_engine* e, XPass& p, const float* injection, hipStream_t s
       memset(&a, 0, sizeof(a));
       a.A = p.a1[l]; a.lda = C; a.B = e->S + w.attnw; a.ldb = C; a.M = M; a.N = 3 * C; a.K = C; a.C = p.qkv[l]; a.ldc = 3 * C;
       a.bias = e->P + w.attnb; a.rope_cos = e->cos_t; a.rope_sin = e->sin_t; a.rope_T = p.T; a.rope_C = C;
-      ProfScope ps(e, SITE_QKV_FWD, 2.0 * M * 3 * C * C, s);
+      ProfScope ps(e, SITE_QKV_FWD, 2.0 * M * 3 * C * C, s, (double)M * C * 2 + 3.0 * C * C * 2 + (double)M * 3 * C * 2);
       COATI_TRY(launch_gemm_nt(a, 0, EPI_QKV_ROPE, s));
     }
     {
-      ProfScope ps(e, SITE_ATTN_FWD, 4.0 * p.B * (double)p.T * p.T * C, s);
+      ProfScope ps(e, SITE_ATTN_FWD, 4.0 * p.B * (double)p.T * p.T * C, s, (double)M * 4 * C * 2 + (double)M * c.n_head * 4);   // qkv in, y + lse out
       COATI_TRY(launch_attn_fwd(p.qkv[l], p.y[l], p.lse[l], p.B, p.T, c.n_head, s));
     }
     COATI_TRY(gemm(e, SITE_PROJ_FWD, p.y[l], 0, C, e->S + w.projw, C, M, C, C, p.xmid[l], C, e->P + w.projb, EPI_RES_F32, p.x[l], nullptr, C, s));
     {
-      ProfScope ps(e, SITE_LN_FWD, 0, s);
+      ProfScope ps(e, SITE_LN_FWD, 0, s, (double)M * C * 6 + (double)M * 8);
       COATI_TRY(launch_layernorm_fwd(p.xmid[l], C, e->P + w.ln2w, e->P + w.ln2b, p.a2[l], C, nullptr, 0, p.mean2[l], p.rstd2[l], M, C, s));
     }
     COATI_TRY(gemm(e, SITE_FC1_FWD, p.a2[l], 0, C, e->S + w.fc1w, C, M, 4 * C, C, p.g[l], 4 * C, e->P + w.fc1b, EPI_GELU, nullptr, p.hpre[l], 4 * C, s));
     COATI_TRY(gemm(e, SITE_FC2_FWD, p.g[l], 0, 4 * C, e->S + w.fc2w, 4 * C, M, C, 4 * C, p.x[l + 1], C, e->P + w.fc2b, EPI_RES_F32, p.xmid[l], nullptr, C, s));
   }
-  ProfScope ps(e, SITE_LN_FWD, 0, s);
+  ProfScope ps(e, SITE_LN_FWD, 0, s, (double)M * C * 10 + (double)M * 8);
   return launch_layernorm_fwd(p.x[L], C, e->P + e->lnfw, e->P + e->lnfb, p.af, C, p.xf32, C, p.meanf, p.rstdf, M, C, s);
 }
 
@@ -449,7 +458,7 @@ int xformer_bwd(coati_engine* e, XPass& p, const void* dyf, int dyf_f32, float* 
   const int C = c.n_hidden_xformer, L = c.n_layer_xformer, M = p.M;
   float* DX = e->DX;
   {
-    ProfScope ps(e, SITE_LN_BWD, 0, s);
+    ProfScope ps(e, SITE_LN_BWD, 0, s, (double)M * C * ((dyf_f32 ? 4 : 2) + 4 + 4 + 2));
     COATI_TRY(launch_layernorm_bwd(dyf, dyf_f32, C, p.x[L], C, 0, p.meanf, p.rstdf, e->P + e->lnfw, nullptr, DX, e->DX16, e->G + e->lnfw, e->G + e->lnfb, e->ln_partial, M, C, s));
   }
   for (int l = L - 1; l >= 0; --l) {
@@ -461,20 +470,20 @@ int xformer_bwd(coati_engine* e, XPass& p, const void* dyf, int dyf_f32, float* 
     COATI_TRY(gemm(e, SITE_FC1_DGRAD, e->dh4, 0, 4 * C, e->S + w.fc1T, 4 * C, M, C, 4 * C, e->da, C, nullptr, EPI_BF16, nullptr, nullptr, 0, s));
     COATI_TRY(wgrad(e, SITE_XF_WGRAD, e->dh4, 0, 4 * C, p.a2[l], C, M, 4 * C, C, e->G + w.fc1w, C, e->G + w.fc1b, 0, s));
     {
-      ProfScope ps(e, SITE_LN_BWD, 0, s);
+      ProfScope ps(e, SITE_LN_BWD, 0, s, (double)M * C * (2 + 4 + 4 + 4 + 2));   // dy16, x, dres in; dx, dx16 out
       COATI_TRY(launch_layernorm_bwd(e->da, 0, C, p.xmid[l], C, 0, p.mean2[l], p.rstd2[l], e->P + w.ln2w, DX, DX, e->DX16, e->G + w.ln2w, e->G + w.ln2b, e->ln_partial, M, C, s));
     }
     // xmid = x[l] + y Wp^T + bp
     COATI_TRY(gemm(e, SITE_PROJ_DGRAD, e->DX16, 0, C, e->S + w.projT, C, M, C, C, e->dyb, C, nullptr, EPI_BF16, nullptr, nullptr, 0, s));
     COATI_TRY(wgrad(e, SITE_XF_WGRAD, e->DX16, 0, C, p.y[l], C, M, C, C, e->G + w.projw, C, e->G + w.projb, 0, s));
     {
-      ProfScope ps(e, SITE_ATTN_BWD, 10.0 * p.B * (double)p.T * p.T * C, s);
+      ProfScope ps(e, SITE_ATTN_BWD, 10.0 * p.B * (double)p.T * p.T * C, s, (double)M * 8 * C * 2 + (double)M * c.n_head * 8);   // qkv, y, dy in; dqkv out
       COATI_TRY(launch_attn_bwd(p.qkv[l], p.y[l], e->dyb, p.lse[l], e->attnD, e->dqkv, e->cos_t, e->sin_t, p.B, p.T, c.n_head, s));
     }
     COATI_TRY(gemm(e, SITE_QKV_DGRAD, e->dqkv, 0, 3 * C, e->S + w.attnT, 3 * C, M, C, 3 * C, e->da, C, nullptr, EPI_BF16, nullptr, nullptr, 0, s));
     COATI_TRY(wgrad(e, SITE_XF_WGRAD, e->dqkv, 0, 3 * C, p.a1[l], C, M, 3 * C, C, e->G + w.attnw, C, e->G + w.attnb, 0, s));
     {
-      ProfScope ps(e, SITE_LN_BWD, 0, s);
+      ProfScope ps(e, SITE_LN_BWD, 0, s, (double)M * C * (2 + 4 + 4 + 4 + 2));   // dy16, x, dres in; dx, dx16 out
       COATI_TRY(launch_layernorm_bwd(e->da, 0, C, p.x[l], C, 0, p.mean1[l], p.rstd1[l], e->P + w.ln1w, DX, DX, e->DX16, e->G + w.ln1w, e->G + w.ln1b, e->ln_partial, M, C, s));
     }
   }
@@ -553,7 +562,7 @@ int gnn_bwd(coati_engine* e, const float* dhpoint, hipStream_t s) {
       a.A = e->g_ds2; a.lda = H; a.B = e->S + w.e3T; a.ldb = H; a.M = Me; a.N = H; a.K = H; a.C = e->g_dpre1; a.ldc = H;
       a.P = e->g_P[l]; a.ldp = 2 * H; a.d2 = e->g_d2; a.w1c = e->P + w.e0w + 2 * H; a.w1c_stride = 2 * H + 1;
       a.b1 = e->P + w.e0b; a.natom = A; a.H = H;
-      ProfScope ps(e, SITE_GNN_EDGE_GEMM, 2.0 * Me * H * H, s);
+      ProfScope ps(e, SITE_GNN_EDGE_GEMM, 2.0 * Me * H * H, s, (double)Me * H * 4 + (double)H * H * 2);
       COATI_TRY(launch_gemm_nt(a, 0, EPI_EDGE_DPRE, s));
     }
     COATI_TRY(wgrad(e, SITE_GNN_WGRAD, e->g_ds2, 0, H, e->g_e1[l], H, Me, H, H, e->G + w.e3w, H, e->G + w.e3b, 0, s));
@@ -768,7 +777,7 @@ int coati_engine_forward(coati_engine* e, void* workspace, int64_t workspace_byt
     memset(&a, 0, sizeof(a));
     a.A = e->p2.af; a.lda = C; a.B = e->S + e->lmhead; a.ldb = C; a.M = M2; a.N = c.n_tok; a.K = C; a.partial = e->ce_partial;
     {
-      ProfScope ps(e, SITE_LMHEAD_FWD, 2.0 * M2 * c.n_tok * C, s);
+      ProfScope ps(e, SITE_LMHEAD_FWD, 2.0 * M2 * c.n_tok * C, s, (double)M2 * C * 2 + (double)c.n_tok * C * 2);   // logits never leave the chip
       COATI_TRY(launch_gemm_nt(a, 0, EPI_CE_PARTIAL, s));
     }
     COATI_TRY(launch_ce_finish(e->ce_partial, tiles_v, e->p2.af, C, e->S + e->lmhead, C, e->y_next, e->ce_lse, scal, M2, C, c.n_tok, s));
@@ -830,7 +839,7 @@ int coati_engine_backward(coati_engine* e, const float* dh_smiles, const float* 
       memset(&a, 0, sizeof(a));
       a.A = e->p2.af; a.lda = C; a.B = e->S + e->lmhead; a.ldb = C; a.M = M2; a.N = c.n_tok; a.K = C;
       a.C = e->dlogits; a.ldc = e->Vpad; a.n_store = e->Vpad; a.lse = e->ce_lse; a.target = e->y_next; a.scal = e->scal;
-      ProfScope ps(e, SITE_LMHEAD_DLOGITS, 2.0 * M2 * c.n_tok * C, s);
+      ProfScope ps(e, SITE_LMHEAD_DLOGITS, 2.0 * M2 * c.n_tok * C, s, (double)M2 * C * 2 + (double)c.n_tok * C * 2 + (double)M2 * e->Vpad * 2);
       COATI_TRY(launch_gemm_nt(a, 0, EPI_CE_BWD, s));
     }
     COATI_TRY(gemm(e, SITE_LMHEAD_DGRAD, e->dlogits, 0, e->Vpad, e->S + e->lmheadT, e->Vpad, M2, C, e->Vpad, e->da, C, nullptr, EPI_BF16, nullptr, nullptr, 0, s));
@@ -906,6 +915,7 @@ int coati_engine_prof_select(coati_engine* e, int site) {
   e->prof_site = site;
   e->ev_used = 0;
   e->prof_flops = 0.0;
+  e->prof_bytes = 0.0;
   return COATI_OK;
 }
 
@@ -924,8 +934,16 @@ int coati_engine_prof_collect(coati_engine* e, double* total_ms, int64_t* launch
   *total_ms = tot;
   *launches = e->ev_used / 2;
   if (flops_per_launch) *flops_per_launch = e->ev_used ? e->prof_flops / (e->ev_used / 2) : 0.0;
+  e->prof_last_bytes = e->ev_used ? e->prof_bytes / (e->ev_used / 2) : 0.0;
   e->ev_used = 0;
   e->prof_flops = 0.0;
+  e->prof_bytes = 0.0;
+  return COATI_OK;
+}
+
+int coati_engine_prof_last_bytes(coati_engine* e, double* bytes_per_launch) {
+  COATI_CHECK_ARG(e && bytes_per_launch, "prof_last_bytes: null argument");
+  *bytes_per_launch = e->prof_last_bytes;
   return COATI_OK;
 }
 

@@ -211,3 +211,9 @@ class Engine:
         ms, n, fl = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double()
         _lib.check(self.l.coati_engine_prof_collect(self.h, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl)), "prof_collect")
         return ms.value, n.value, fl.value
+
+    def prof_last_bytes(self):
+        """Algorithmic HBM bytes per launch of the site returned by the last prof_collect()."""
+        b = ctypes.c_double()
+        _lib.check(self.l.coati_engine_prof_last_bytes(self.h, ctypes.byref(b)), "prof_last_bytes")
+        return b.value

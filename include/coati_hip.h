@@ -219,6 +219,8 @@ int coati_engine_optimizer_step(coati_engine* e, float lr, float beta1, float be
 /* per-site kernel timing with HIP events on the launch stream (bench.py roofline leg) */
 int coati_engine_prof_select(coati_engine* e, int site);              /* -1 disables */
 int coati_engine_prof_collect(coati_engine* e, double* total_ms, int64_t* launches, double* flops_per_launch);
+/* algorithmic HBM bytes per launch (operands read once, results written once) of the site collected last */
+int coati_engine_prof_last_bytes(coati_engine* e, double* bytes_per_launch);
 int coati_engine_site_count(void);
 const char* coati_engine_site_name(int site);
 
