@@ -103,7 +103,9 @@ __device__ __forceinline__ void epilogue8(const GemmArgs& p, int row, int col0, 
     const bool rot = col0 < 2 * p.rope_C;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const float other = __shfl_xor(v[e], ROPE_PARTNER, 64);
+      // partner lane = lane ^ 1: a DPP quad permutation (one VALU op), not a ds_bpermute through the LDS pipe
+      const float other = (ROPE_PARTNER == 1) ? __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v[e]), 0xB1, 0xF, 0xF, true))
+                                              : __shfl_xor(v[e], ROPE_PARTNER, 64);
       const float c = rope_row ? rope_row[e] : p.rope_cos[t * 16 + e];
       const float s_ = rope_row ? rope_row[8 + e] : p.rope_sin[t * 16 + e];
       const float r = hi_half ? (v[e] * c + other * s_) : (v[e] * c - other * s_);
