@@ -266,11 +266,13 @@ __global__ __launch_bounds__(256, 4) void attn_bwd_dq_kernel(const bf16_t* __res
       for (int r = 0; r < 16; ++r) {
         float p = __builtin_amdgcn_exp2f(fmaf(s[r], SCALE_LOG2E, -lq));
         if (kb == qb && kb * 32 + arow(r, lane) > q) p = 0.f;
-        ds[r] = p * (dp[r] - dq_) * SCALE;
+        ds[r] = p * (dp[r] - dq_);   // the softmax scale is applied once to the finished dQ block
       }
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tfrag(Ks, kb * 32, lane), pfrag(ds), acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tfrag(Ks, kb * 32 + 16, lane), pfrag(ds + 8), acc, 0, 0, 0);
     }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) acc[r] *= SCALE;
     if (q < T) store_grad_cols(dbase + (long long)q * stride, acc, half, true, cos_t, sin_t, q);
   }
 }
@@ -327,7 +329,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_kernel(const bf16_t* __re
           const int r = g4 * 4 + j, q = q0 + j;
           p[r] = __builtin_amdgcn_exp2f(fmaf(s[r], SCALE_LOG2E, -lv[j]));
           if (qb == kb && key > q) p[r] = 0.f;
-          ds[r] = p[r] * (dp[r] - dvv[j]) * SCALE;
+          ds[r] = p[r] * (dp[r] - dvv[j]);   // scale applied once to the finished dK block
         }
       }
       dv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tfrag(Gs, qb * 32, lane), pfrag(p), dv, 0, 0, 0);
@@ -335,6 +337,8 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_kernel(const bf16_t* __re
       dk = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tfrag(Qs, qb * 32, lane), pfrag(ds), dk, 0, 0, 0);
       dk = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tfrag(Qs, qb * 32 + 16, lane), pfrag(ds + 8), dk, 0, 0, 0);
     }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) dk[r] *= SCALE;
     if (key < T) {
       store_grad_cols(dbase + (long long)key * stride + C, dk, half, true, cos_t, sin_t, key);
       store_grad_cols(dbase + (long long)key * stride + 2 * C, dv, half, false, cos_t, sin_t, key);
