@@ -95,6 +95,47 @@ __device__ __forceinline__ f32x16 zero16() {
 }
 __device__ __forceinline__ int arow(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
+// ---- output path: results leave the workgroup as whole 128-B row segments --------------------------------------
+// An accumulator block holds, per lane, 2 x 4 dims of ONE row; storing that directly is 8-B granules scattered over 32
+// rows per instruction (address-coalescer / partial-line bound: it cost ~40 of the 78 us of the dK/dV kernel).  Each
+// wave instead drops its head's 32 x 16 block into a workgroup-shared LDS tile [32 rows][4 heads x 16 dims] (row pitch
+// 144 B), and after a barrier the 256 threads store the tile as 16-B chunks, 8 lanes per 128-B row.
+#define OT_PITCH 144                       // bytes per row of the output tile
+#define OT_BYTES (32 * OT_PITCH)
+__device__ __forceinline__ void tile_put(unsigned char* tile, int wave, int lane, const float (&a)[4], const float (&c)[4]) {
+  unsigned char* row = tile + (lane & 31) * OT_PITCH + wave * 32 + (lane >> 5) * 8;   // dims 4*half.. and 8+4*half..
+  *reinterpret_cast<uint2*>(row) = make_uint2(pack2bf(a[0], a[1]), pack2bf(a[2], a[3]));
+  *reinterpret_cast<uint2*>(row + 16) = make_uint2(pack2bf(c[0], c[1]), pack2bf(c[2], c[3]));
+}
+// gradient block (lane = token row, regs 0..3 / 4..7 = dims 4*half+j / 8+4*half+j) -> tile, with the inverse rotation
+__device__ __forceinline__ void tile_put_grad(unsigned char* tile, int wave, int lane, const f32x16& g, bool rope_inv,
+                                              const float* cos_t, const float* sin_t, int t) {
+  const int half = lane >> 5;
+  float a[4], c[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { a[j] = g[j]; c[j] = g[4 + j]; }
+  if (rope_inv) {
+    const float4 cs = *reinterpret_cast<const float4*>(cos_t + t * HS + 4 * half);
+    const float4 sn = *reinterpret_cast<const float4*>(sin_t + t * HS + 4 * half);
+    const float csv[4] = {cs.x, cs.y, cs.z, cs.w}, snv[4] = {sn.x, sn.y, sn.z, sn.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float ga = a[j], gc = c[j];
+      a[j] = ga * csv[j] + gc * snv[j];
+      c[j] = gc * csv[j] - ga * snv[j];
+    }
+  }
+  tile_put(tile, wave, lane, a, c);
+}
+// cooperative store of one tile: thread -> (row = tid >> 3, 16-B chunk = tid & 7); dst points at (row 0, first head)
+__device__ __forceinline__ void tile_store(const unsigned char* tile, bf16_t* dst, long long stride, int row0, int T,
+                                           int heads_here, int tid) {
+  const int row = tid >> 3, ch = tid & 7;
+  if (row0 + row < T && (ch >> 1) < heads_here)
+    *reinterpret_cast<uint4*>(dst + (long long)(row0 + row) * stride + ch * 8) =
+        *reinterpret_cast<const uint4*>(tile + row * OT_PITCH + ch * 16);
+}
+
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ y,
                                                        float* __restrict__ lse, int T, int n_head, int quads) {
@@ -112,59 +153,63 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
   stage4(base + C, stride, T, Tp, smem, pw, 0, heads_here, threadIdx.x);
   stage4(base + 2 * C, stride, T, Tp, smem, pw, 1, heads_here, threadIdx.x);
   __syncthreads();
-  if (hh >= n_head) return;
-  const bf16_t* qsrc = qkv + (long long)b * T * stride + hh * HS;
+  const bool active = hh < n_head;   // inactive waves of a partial quad only take part in the barriers
+  unsigned char* const otile = smem + 4 * pw;
+  bf16_t* const ydst = y + (long long)b * T * C + hq * 4 * HS;
+  const bf16_t* qsrc = qkv + (long long)b * T * stride + (active ? hh : 0) * HS;
 
   const int nblk = Tp >> 5, half = lane >> 5;
   for (int qb = 0; qb < nblk; ++qb) {
-    const bf16x8 qf = gfrag(qsrc, stride, qb, T, lane);
     const int q = qb * 32 + (lane & 31);
-    float m_run = -INFINITY, l_run = 0.f;
-    f32x16 o = zero16();
-    for (int kb = 0; kb <= qb; ++kb) {
-      f32x16 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rfrag(Ks, kb, lane), qf, zero16(), 0, 0, 0);
-      // running max / sum are kept on the RAW scores (the scale is positive); exp(x*scale) = 2^(x*scale*log2e)
-      float p[16];
-      float mloc = -INFINITY;
-      if (kb == qb) {   // only the diagonal block needs the causal mask
+    if (active) {
+      const bf16x8 qf = gfrag(qsrc, stride, qb, T, lane);
+      float m_run = -INFINITY, l_run = 0.f;
+      f32x16 o = zero16();
+      for (int kb = 0; kb <= qb; ++kb) {
+        f32x16 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rfrag(Ks, kb, lane), qf, zero16(), 0, 0, 0);
+        // running max / sum are kept on the RAW scores (the scale is positive); exp(x*scale) = 2^(x*scale*log2e)
+        float p[16];
+        float mloc = -INFINITY;
+        if (kb == qb) {   // only the diagonal block needs the causal mask
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int key = kb * 32 + arow(r, lane);
+            p[r] = (key <= q) ? s[r] : -INFINITY;
+            mloc = fmaxf(mloc, p[r]);
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            p[r] = s[r];
+            mloc = fmaxf(mloc, p[r]);
+          }
+        }
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+        const float m_new = fmaxf(m_run, mloc);
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * SCALE_LOG2E);
+        const float mc = m_new * SCALE_LOG2E;
+        float lsum = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int key = kb * 32 + arow(r, lane);
-          p[r] = (key <= q) ? s[r] : -INFINITY;
-          mloc = fmaxf(mloc, p[r]);
+          p[r] = __builtin_amdgcn_exp2f(fmaf(p[r], SCALE_LOG2E, -mc));
+          lsum += p[r];
         }
-      } else {
+        lsum += __shfl_xor(lsum, 32, 64);
+        l_run = l_run * alpha + lsum;
+        m_run = m_new;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          p[r] = s[r];
-          mloc = fmaxf(mloc, p[r]);
-        }
+        for (int r = 0; r < 8; ++r) o[r] *= alpha;   // only d < 16 (regs 0..7) is live
+        o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tfrag(Vs, kb * 32, lane), pfrag(p), o, 0, 0, 0);
+        o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tfrag(Vs, kb * 32 + 16, lane), pfrag(p + 8), o, 0, 0, 0);
       }
-      mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
-      const float m_new = fmaxf(m_run, mloc);
-      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * SCALE_LOG2E);
-      const float mc = m_new * SCALE_LOG2E;
-      float lsum = 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        p[r] = __builtin_amdgcn_exp2f(fmaf(p[r], SCALE_LOG2E, -mc));
-        lsum += p[r];
-      }
-      lsum += __shfl_xor(lsum, 32, 64);
-      l_run = l_run * alpha + lsum;
-      m_run = m_new;
-#pragma unroll
-      for (int r = 0; r < 8; ++r) o[r] *= alpha;   // only d < 16 (regs 0..7) is live
-      o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tfrag(Vs, kb * 32, lane), pfrag(p), o, 0, 0, 0);
-      o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tfrag(Vs, kb * 32 + 16, lane), pfrag(p + 8), o, 0, 0, 0);
-    }
-    if (q < T) {
       const float inv = 1.0f / l_run;
-      bf16_t* yr = y + ((long long)b * T + q) * C + hh * HS + 4 * half;
-      *reinterpret_cast<uint2*>(yr) = make_uint2(pack2bf(o[0] * inv, o[1] * inv), pack2bf(o[2] * inv, o[3] * inv));
-      *reinterpret_cast<uint2*>(yr + 8) = make_uint2(pack2bf(o[4] * inv, o[5] * inv), pack2bf(o[6] * inv, o[7] * inv));
-      if (half == 0) lse[((long long)b * n_head + hh) * T + q] = m_run * SCALE + __logf(l_run);
+      const float a[4] = {o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv}, c[4] = {o[4] * inv, o[5] * inv, o[6] * inv, o[7] * inv};
+      tile_put(otile, wave, lane, a, c);
+      if (q < T && half == 0) lse[((long long)b * n_head + hh) * T + q] = m_run * SCALE + __logf(l_run);
     }
+    __syncthreads();
+    tile_store(otile, ydst, C, qb * 32, T, heads_here, threadIdx.x);
+    __syncthreads();
   }
 }
 
@@ -172,7 +217,7 @@ int launch_attn_fwd(const bf16_t* qkv, bf16_t* y, float* lse, int B, int T, int 
   COATI_CHECK_ARG(qkv && y && lse, "attn_fwd: null operand");
   COATI_CHECK_SHAPE(B > 0 && T > 0 && T <= 256 && n_head > 0, "attn_fwd: unsupported shape B=%d T=%d nh=%d", B, T, n_head);
   const int Tp = (T + 31) & ~31;
-  const size_t lds = (size_t)4 * 2 * Tp * HS * 2;
+  const size_t lds = (size_t)4 * 2 * Tp * HS * 2 + OT_BYTES;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel),
@@ -194,27 +239,6 @@ int launch_attn_fwd(const bf16_t* qkv, bf16_t* y, float* lse, int B, int T, int 
 //   kernel 1 (per query block): dQ^T[d][q] = sum_keys K^T[d][key] dS^T[key][q]          (also writes D)
 //   kernel 2 (per key block)  : dK^T[d][key] = sum_q Q^T[d][q] dS[q][key],  dV^T[d][key] = sum_q dO^T[d][q] P[q][key]
 // ---------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void store_grad_cols(bf16_t* dst, const f32x16& g, int half, bool rope_inv, const float* cos_t,
-                                                const float* sin_t, int t) {
-  // lane holds dims d = 4*half + j (regs 0..3) and 8 + 4*half + j (regs 4..7): the RoPE pairs (d, d+8)
-  float a[4], c[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) { a[j] = g[j]; c[j] = g[4 + j]; }
-  if (rope_inv) {
-    const float4 cs = *reinterpret_cast<const float4*>(cos_t + t * HS + 4 * half);
-    const float4 sn = *reinterpret_cast<const float4*>(sin_t + t * HS + 4 * half);
-    const float csv[4] = {cs.x, cs.y, cs.z, cs.w}, snv[4] = {sn.x, sn.y, sn.z, sn.w};
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float ga = a[j], gc = c[j];
-      a[j] = ga * csv[j] + gc * snv[j];
-      c[j] = gc * csv[j] - ga * snv[j];
-    }
-  }
-  *reinterpret_cast<uint2*>(dst + 4 * half) = make_uint2(pack2bf(a[0], a[1]), pack2bf(a[2], a[3]));
-  *reinterpret_cast<uint2*>(dst + 8 + 4 * half) = make_uint2(pack2bf(c[0], c[1]), pack2bf(c[2], c[3]));
-}
-
 __global__ __launch_bounds__(256, 4) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ y,
                                                           const bf16_t* __restrict__ dy, const float* __restrict__ lse,
                                                           float* __restrict__ Dout, bf16_t* __restrict__ dqkv,
@@ -234,46 +258,53 @@ __global__ __launch_bounds__(256, 4) void attn_bwd_dq_kernel(const bf16_t* __res
   stage4(qbase + C, stride, T, Tp, smem, pw, 0, heads_here, threadIdx.x);
   stage4(qbase + 2 * C, stride, T, Tp, smem, pw, 1, heads_here, threadIdx.x);
   __syncthreads();
-  if (hh >= n_head) return;
-  const bf16_t* ybase = y + (long long)b * T * C + hh * HS;
-  const bf16_t* qsrc = qkv + (long long)b * T * stride + hh * HS;
-  const bf16_t* gsrc = dy + (long long)b * T * C + hh * HS;
-  const long long sbase = ((long long)b * n_head + hh) * T;
+  const bool active = hh < n_head;
+  const int hc = active ? hh : 0;
+  unsigned char* const otile = smem + 4 * pw;
+  const bf16_t* ybase = y + (long long)b * T * C + hc * HS;
+  const bf16_t* qsrc = qkv + (long long)b * T * stride + hc * HS;
+  const bf16_t* gsrc = dy + (long long)b * T * C + hc * HS;
+  const long long sbase = ((long long)b * n_head + hc) * T;
 
   const int nblk = Tp >> 5, half = lane >> 5;
-  bf16_t* const dbase = dqkv + (long long)b * T * stride + hh * HS;
+  bf16_t* const dbase = dqkv + (long long)b * T * stride + hq * 4 * HS;
   for (int qb = 0; qb < nblk; ++qb) {
-    const bf16x8 qf = gfrag(qsrc, stride, qb, T, lane), gf = gfrag(gsrc, (long long)C, qb, T, lane);
     const int q = qb * 32 + (lane & 31);
-    // D[q] = sum_d dO[q,d] O[q,d]: this lane holds dims half*8..+7 of dO[q] in gf; the partner half-wave adds the rest
-    float lq = INFINITY, dq_ = 0.f;
-    if (q < T) {
-      float o8[8], g8[8];
-      unpack8(*reinterpret_cast<const uint4*>(ybase + (long long)q * C + half * 8), o8);
-      unpack8(__builtin_bit_cast(uint4, gf), g8);
+    if (active) {
+      const bf16x8 qf = gfrag(qsrc, stride, qb, T, lane), gf = gfrag(gsrc, (long long)C, qb, T, lane);
+      // D[q] = sum_d dO[q,d] O[q,d]: this lane holds dims half*8..+7 of dO[q] in gf; the partner half-wave adds the rest
+      float lq = INFINITY, dq_ = 0.f;
+      if (q < T) {
+        float o8[8], g8[8];
+        unpack8(*reinterpret_cast<const uint4*>(ybase + (long long)q * C + half * 8), o8);
+        unpack8(__builtin_bit_cast(uint4, gf), g8);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) dq_ += o8[i] * g8[i];
-      lq = lse[sbase + q] * LOG2E;
-    }
-    dq_ += __shfl_xor(dq_, 32, 64);
-    if (q < T && half == 0) Dout[sbase + q] = dq_;
-    f32x16 acc = zero16();
-    for (int kb = 0; kb <= qb; ++kb) {
-      const f32x16 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rfrag(Ks, kb, lane), qf, zero16(), 0, 0, 0);
-      const f32x16 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rfrag(Vs, kb, lane), gf, zero16(), 0, 0, 0);
-      float ds[16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float p = __builtin_amdgcn_exp2f(fmaf(s[r], SCALE_LOG2E, -lq));
-        if (kb == qb && kb * 32 + arow(r, lane) > q) p = 0.f;
-        ds[r] = p * (dp[r] - dq_);   // the softmax scale is applied once to the finished dQ block
+        for (int i = 0; i < 8; ++i) dq_ += o8[i] * g8[i];
+        lq = lse[sbase + q] * LOG2E;
       }
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tfrag(Ks, kb * 32, lane), pfrag(ds), acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tfrag(Ks, kb * 32 + 16, lane), pfrag(ds + 8), acc, 0, 0, 0);
-    }
+      dq_ += __shfl_xor(dq_, 32, 64);
+      if (q < T && half == 0) Dout[sbase + q] = dq_;
+      f32x16 acc = zero16();
+      for (int kb = 0; kb <= qb; ++kb) {
+        const f32x16 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rfrag(Ks, kb, lane), qf, zero16(), 0, 0, 0);
+        const f32x16 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rfrag(Vs, kb, lane), gf, zero16(), 0, 0, 0);
+        float ds[16];
 #pragma unroll
-    for (int r = 0; r < 8; ++r) acc[r] *= SCALE;
-    if (q < T) store_grad_cols(dbase + (long long)q * stride, acc, half, true, cos_t, sin_t, q);
+        for (int r = 0; r < 16; ++r) {
+          float p = __builtin_amdgcn_exp2f(fmaf(s[r], SCALE_LOG2E, -lq));
+          if (kb == qb && kb * 32 + arow(r, lane) > q) p = 0.f;
+          ds[r] = p * (dp[r] - dq_);   // the softmax scale is applied once to the finished dQ block
+        }
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tfrag(Ks, kb * 32, lane), pfrag(ds), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tfrag(Ks, kb * 32 + 16, lane), pfrag(ds + 8), acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 8; ++r) acc[r] *= SCALE;
+      tile_put_grad(otile, wave, lane, acc, true, cos_t, sin_t, q < T ? q : 0);
+    }
+    __syncthreads();
+    tile_store(otile, dbase, stride, qb * 32, T, heads_here, threadIdx.x);
+    __syncthreads();
   }
 }
 
@@ -298,10 +329,12 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_kernel(const bf16_t* __re
   stage4(qbase, stride, T, Tp, smem, pw, 0, heads_here, threadIdx.x);
   stage4(dy + (long long)b * T * C + hq * 4 * HS, (long long)C, T, Tp, smem, pw, 1, heads_here, threadIdx.x);
   __syncthreads();
-  if (hh >= n_head) return;
-  const bf16_t* ksrc = qkv + (long long)b * T * stride + C + hh * HS;
+  const bool active = hh < n_head;
+  const int hc = active ? hh : 0;
+  unsigned char* const otile = smem + 4 * pw;   // two tiles: dK, dV
+  const bf16_t* ksrc = qkv + (long long)b * T * stride + C + hc * HS;
   for (int t = lane; t < Tp; t += 64) {
-    const long long o = ((long long)b * n_head + hh) * T + t;
+    const long long o = ((long long)b * n_head + hc) * T + t;
     Ls[t] = (t < T) ? lse[o] : INFINITY;
     Ds[t] = (t < T) ? Din[o] : 0.f;
   }
@@ -309,40 +342,44 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_kernel(const bf16_t* __re
   __builtin_amdgcn_wave_barrier();
 
   const int nblk = Tp >> 5, half = lane >> 5;
-  bf16_t* const dbase = dqkv + (long long)b * T * stride + hh * HS;
+  bf16_t* const dbase = dqkv + (long long)b * T * stride + hq * 4 * HS;
   for (int kb = 0; kb < nblk; ++kb) {
-    const bf16x8 kf = gfrag(ksrc, stride, kb, T, lane), vf = gfrag(ksrc + C, stride, kb, T, lane);
     const int key = kb * 32 + (lane & 31);
-    f32x16 dk = zero16(), dv = zero16();
-    for (int qb = kb; qb < nblk; ++qb) {
-      const f32x16 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rfrag(Qs, qb, lane), kf, zero16(), 0, 0, 0);
-      const f32x16 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rfrag(Gs, qb, lane), vf, zero16(), 0, 0, 0);
-      float p[16], ds[16];
+    if (active) {
+      const bf16x8 kf = gfrag(ksrc, stride, kb, T, lane), vf = gfrag(ksrc + C, stride, kb, T, lane);
+      f32x16 dk = zero16(), dv = zero16();
+      for (int qb = kb; qb < nblk; ++qb) {
+        const f32x16 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rfrag(Qs, qb, lane), kf, zero16(), 0, 0, 0);
+        const f32x16 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rfrag(Gs, qb, lane), vf, zero16(), 0, 0, 0);
+        float p[16], ds[16];
 #pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        const int q0 = qb * 32 + 8 * g4 + 4 * half;
-        const float4 l4 = *reinterpret_cast<const float4*>(Ls + q0);
-        const float4 d4 = *reinterpret_cast<const float4*>(Ds + q0);
-        const float lv[4] = {l4.x * LOG2E, l4.y * LOG2E, l4.z * LOG2E, l4.w * LOG2E}, dvv[4] = {d4.x, d4.y, d4.z, d4.w};
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const int q0 = qb * 32 + 8 * g4 + 4 * half;
+          const float4 l4 = *reinterpret_cast<const float4*>(Ls + q0);
+          const float4 d4 = *reinterpret_cast<const float4*>(Ds + q0);
+          const float lv[4] = {l4.x * LOG2E, l4.y * LOG2E, l4.z * LOG2E, l4.w * LOG2E}, dvv[4] = {d4.x, d4.y, d4.z, d4.w};
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int r = g4 * 4 + j, q = q0 + j;
-          p[r] = __builtin_amdgcn_exp2f(fmaf(s[r], SCALE_LOG2E, -lv[j]));
-          if (qb == kb && key > q) p[r] = 0.f;
-          ds[r] = p[r] * (dp[r] - dvv[j]);   // scale applied once to the finished dK block
+          for (int j = 0; j < 4; ++j) {
+            const int r = g4 * 4 + j, q = q0 + j;
+            p[r] = __builtin_amdgcn_exp2f(fmaf(s[r], SCALE_LOG2E, -lv[j]));
+            if (qb == kb && key > q) p[r] = 0.f;
+            ds[r] = p[r] * (dp[r] - dvv[j]);   // scale applied once to the finished dK block
+          }
         }
+        dv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tfrag(Gs, qb * 32, lane), pfrag(p), dv, 0, 0, 0);
+        dv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tfrag(Gs, qb * 32 + 16, lane), pfrag(p + 8), dv, 0, 0, 0);
+        dk = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tfrag(Qs, qb * 32, lane), pfrag(ds), dk, 0, 0, 0);
+        dk = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tfrag(Qs, qb * 32 + 16, lane), pfrag(ds + 8), dk, 0, 0, 0);
       }
-      dv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tfrag(Gs, qb * 32, lane), pfrag(p), dv, 0, 0, 0);
-      dv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tfrag(Gs, qb * 32 + 16, lane), pfrag(p + 8), dv, 0, 0, 0);
-      dk = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tfrag(Qs, qb * 32, lane), pfrag(ds), dk, 0, 0, 0);
-      dk = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tfrag(Qs, qb * 32 + 16, lane), pfrag(ds + 8), dk, 0, 0, 0);
-    }
 #pragma unroll
-    for (int r = 0; r < 8; ++r) dk[r] *= SCALE;
-    if (key < T) {
-      store_grad_cols(dbase + (long long)key * stride + C, dk, half, true, cos_t, sin_t, key);
-      store_grad_cols(dbase + (long long)key * stride + 2 * C, dv, half, false, cos_t, sin_t, key);
+      for (int r = 0; r < 8; ++r) dk[r] *= SCALE;
+      tile_put_grad(otile, wave, lane, dk, true, cos_t, sin_t, key < T ? key : 0);
+      tile_put_grad(otile + OT_BYTES, wave, lane, dv, false, cos_t, sin_t, 0);
     }
+    __syncthreads();
+    tile_store(otile, dbase + C, stride, kb * 32, T, heads_here, threadIdx.x);
+    tile_store(otile + OT_BYTES, dbase + 2 * C, stride, kb * 32, T, heads_here, threadIdx.x);
+    __syncthreads();
   }
 }
 
@@ -351,7 +388,7 @@ int launch_attn_bwd(const bf16_t* qkv, const bf16_t* y, const bf16_t* dy, const 
   COATI_CHECK_ARG(qkv && y && dy && lse && dscratch && dqkv && cos_t && sin_t, "attn_bwd: null operand");
   COATI_CHECK_SHAPE(B > 0 && T > 0 && T <= 256 && n_head > 0, "attn_bwd: unsupported shape B=%d T=%d nh=%d", B, T, n_head);
   const int Tp = (T + 31) & ~31;
-  const size_t lds = (size_t)4 * (2 * Tp * HS * 2 + 2 * Tp * 4);   // dK/dV kernel (the dQ kernel uses less)
+  const size_t lds = (size_t)4 * (2 * Tp * HS * 2 + 2 * Tp * 4) + 2 * OT_BYTES;   // dK/dV kernel (the dQ kernel uses less)
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel),
@@ -365,7 +402,7 @@ int launch_attn_bwd(const bf16_t* qkv, const bf16_t* y, const bf16_t* dy, const 
     attr_set = true;
   }
   const int quads = cdiv(n_head, 4);
-  hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(B * quads), dim3(256), (size_t)4 * 2 * Tp * HS * 2, s, qkv, y, dy, lse, dscratch, dqkv, cos_t,
+  hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(B * quads), dim3(256), (size_t)4 * 2 * Tp * HS * 2 + OT_BYTES, s, qkv, y, dy, lse, dscratch, dqkv, cos_t,
                      sin_t, T, n_head, quads);
   COATI_LAUNCH_CHECK("attn_bwd_dq");
   hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(B * quads), dim3(256), lds, s, qkv, dy, lse, dscratch, dqkv, cos_t,
