@@ -19,6 +19,7 @@ __device__ __forceinline__ void epilogue8(const GemmArgs& p, int row, int col0, 
   // staged: optional operand the caller pre-staged (in LDS) so that the epilogue issues no global load for it:
   //   EPI_QKV_ROPE       -> float[16] = [8 cos | 8 sin] of this row's token position (instead of the global tables)
   //   EPI_DGELU / DSILU  -> uint4 = the 8 saved pre-activations aux_in[row, col0..col0+7]
+  //   EPI_EDGE_DPRE      -> float[8 + ...]: staged[e] = w1c of column col0+e, staged[64 + e] = b1 of column col0+e
   //   EPI_RES_F32        -> float4[2] = aux_in[row, col0..col0+7];   EPI_ACC_F32 -> float4[2] = C[row, col0..col0+7]
   const float* rope_row = (EPI == EPI_QKV_ROPE) ? reinterpret_cast<const float*>(staged) : nullptr;
   const int N = p.N;
@@ -165,7 +166,12 @@ __device__ __forceinline__ void epilogue8(const GemmArgs& p, int row, int col0, 
     for (int e = 0; e < 8; ++e) {
       const int c = col0 + e;
       float pre = 0.f;
-      if (c < N) pre = pa[e] + pb[e] + d2 * p.w1c[(long long)c * p.w1c_stride] + p.b1[c];
+      if (c < N) {
+        const float* st = reinterpret_cast<const float*>(staged);
+        const float wc = st ? st[e] : p.w1c[(long long)c * p.w1c_stride];
+        const float bc = st ? st[64 + e] : p.b1[c];
+        pre = pa[e] + pb[e] + d2 * wc + bc;
+      }
       o[e] = v[e] * dsilu_f(pre);
     }
   }

@@ -44,6 +44,7 @@ __global__ __launch_bounds__(64 * RB_MAX_W) void gemm_rb256_kernel(GemmArgs p, i
   float* const Rs = reinterpret_cast<float*>(smem + 2 * RB_TILE_HALFS * 2) + W * RB_EFLOATS + wave * RB_ROPE_FLOATS;
   unsigned char* const Xs = smem + 2 * RB_TILE_HALFS * 2 + (size_t)W * RB_EFLOATS * 4 + wave * RB_AUX_BYTES;   // DGELU / DSILU
   constexpr bool AUX = (EPI == EPI_DGELU || EPI == EPI_DSILU);
+  constexpr bool EDGE = (EPI == EPI_EDGE_DPRE);   // per-column constants of the tile staged in Rs: [64 w1c | 64 b1]
   const int m0 = (blockIdx.x * W + wave) * 32;
   const int fr = lane & 31, fk = (lane >> 5) * 8;
 
@@ -115,6 +116,12 @@ __global__ __launch_bounds__(64 * RB_MAX_W) void gemm_rb256_kernel(GemmArgs p, i
     load_tile((j + 1) * RB_BN, nxt);
     if constexpr (AUX) load_aux(j * RB_BN);
     if (has_bias) { bn0 = bias_at((j + 1) * RB_BN + fr); bn1 = bias_at((j + 1) * RB_BN + 32 + fr); }
+    float ew = 0.f, eb = 0.f;
+    if constexpr (EDGE) {   // lane = column of this tile (clamped); written to LDS after the MFMA phase
+      const int c = j * RB_BN + lane, cc = c < p.N ? c : p.N - 1;
+      ew = p.w1c[(long long)cc * p.w1c_stride];
+      eb = p.b1[cc];
+    }
     f32x16 acc0, acc1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc0[r] = bz0; acc1[r] = bz1; }
@@ -142,6 +149,7 @@ __global__ __launch_bounds__(64 * RB_MAX_W) void gemm_rb256_kernel(GemmArgs p, i
     // The next tile had the whole MFMA phase to land.  Waiting HERE -- before this tile's stores are issued -- lets the
     // stores stay in flight across the barrier and through the next MFMA phase (vmcnt completes in order).
     __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0)
+    if constexpr (EDGE) { Rs[lane] = ew; Rs[64 + lane] = eb; }   // read back after the lgkmcnt(0) + wave barrier below
     // wave-private transpose, rows 0-15 then 16-31 of the slab (accumulator registers 0-7 / 8-15):
     // (lane = column, registers = rows) -> rows of 64 contiguous columns
 #pragma unroll
@@ -165,6 +173,7 @@ __global__ __launch_bounds__(64 * RB_MAX_W) void gemm_rb256_kernel(GemmArgs p, i
         const void* staged = nullptr;
         if constexpr (EPI == EPI_QKV_ROPE) staged = Rs + row * 16;
         if constexpr (AUX) staged = Xs + (size_t)(lane + 64 * (2 * hf + i)) * 16;
+        if constexpr (EDGE) staged = Rs + cg * 8;
         epilogue8<EPI>(q, m0 + row, j * RB_BN + cg * 8, v, (m0 + row) < p.M, 0, 1, staged);
       };
       // light epilogues run both tasks interleaved; the heavy ones (activation maths, extra operands) one after the
@@ -222,7 +231,7 @@ static int launch_rb_t(const GemmArgs& a, hipStream_t s) {
   }
   const int W = rb_waves(a.M);
   const int blocks = cdiv(cdiv(a.M, 32), W);
-  const size_t lds = (size_t)2 * RB_TILE_HALFS * 2 + (size_t)W * (RB_EFLOATS * 4 + (EPI == EPI_QKV_ROPE ? RB_ROPE_FLOATS * 4 : (EPI == EPI_DGELU || EPI == EPI_DSILU) ? RB_AUX_BYTES : 0));
+  const size_t lds = (size_t)2 * RB_TILE_HALFS * 2 + (size_t)W * (RB_EFLOATS * 4 + ((EPI == EPI_QKV_ROPE || EPI == EPI_EDGE_DPRE) ? RB_ROPE_FLOATS * 4 : (EPI == EPI_DGELU || EPI == EPI_DSILU) ? RB_AUX_BYTES : 0));
   hipLaunchKernelGGL(kern, dim3(blocks), dim3(64 * W), lds, s, a, W);
   COATI_LAUNCH_CHECK("gemm_rb256");
   return COATI_OK;
