@@ -540,7 +540,7 @@ int launch_wgrad(const WgradArgs& a, int a_f32, hipStream_t s) {
 __global__ __launch_bounds__(256) void sgemm_kernel(const float* __restrict__ A, long long ars, long long acs,
                                                     const float* __restrict__ B, long long brs, long long bcs,
                                                     float* __restrict__ C, long long ldc, int M, int N, int K,
-                                                    const float* __restrict__ bias, float alpha, int accumulate) {
+                                                    const float* __restrict__ bias, float alpha, int accumulate, int ksplit) {
   __shared__ float As[2][SBK * SPITCH];
   __shared__ float Bs[2][SBK * SPITCH];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -577,13 +577,17 @@ __global__ __launch_bounds__(256) void sgemm_kernel(const float* __restrict__ A,
       Bs[buf][kb * SPITCH + n] = rb[i];
     }
   };
-  load_tile(0);
+  // split-K (gridDim.z > 1, accumulate only): this workgroup reduces k in [kbeg, kend) and adds with atomics
+  const int kbeg = blockIdx.z * ksplit;
+  const int kend_ = kbeg + ksplit < K ? kbeg + ksplit : K;
+  K = kend_;
+  load_tile(kbeg);
   store_tile(0);
   __syncthreads();
-  const int nk = (K + SBK - 1) / SBK;
+  const int nk = (kend_ - kbeg + SBK - 1) / SBK;
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
-    if (kt + 1 < nk) load_tile((kt + 1) * SBK);
+    if (kt + 1 < nk) load_tile(kbeg + (kt + 1) * SBK);
 #pragma unroll
     for (int kk = 0; kk < SBK / 2; ++kk) {
       const int k = 2 * kk + (lane >> 5);
@@ -599,9 +603,10 @@ __global__ __launch_bounds__(256) void sgemm_kernel(const float* __restrict__ A,
     const int m = m0 + wm * 32 + frag_row(r, lane), n = n0 + wn * 32 + (lane & 31);
     if (m < M && n < N) {
       float v = alpha * acc[r];
-      if (bias) v += bias[n];
+      if (bias && blockIdx.z == 0) v += bias[n];
       float* c = C + (long long)m * ldc + n;
-      *c = accumulate ? (*c + v) : v;
+      if (gridDim.z > 1) atomicAdd(c, v);
+      else *c = accumulate ? (*c + v) : v;
     }
   }
 }
@@ -611,8 +616,18 @@ int launch_sgemm(const float* A, long long ars, long long acs, const float* B, l
                  hipStream_t s) {
   COATI_CHECK_ARG(A && B && C, "sgemm: null operand");
   COATI_CHECK_SHAPE(M > 0 && N > 0 && K > 0, "sgemm: empty problem");
-  hipLaunchKernelGGL(sgemm_kernel, dim3(cdiv(N, 64), cdiv(M, 64)), dim3(256), 0, s, A, ars, acs, B, brs, bcs, C, ldc,
-                     M, N, K, bias, alpha, accumulate);
+  // few output tiles + a long reduction (the head weight / bias gradients: K = batch): split K over gridDim.z
+  const int tiles = cdiv(N, 64) * cdiv(M, 64);
+  int splits = 1;
+  if (accumulate && K >= 256 && tiles < 128) {
+    splits = 256 / tiles;
+    if (splits > K / 64) splits = K / 64;
+    if (splits < 1) splits = 1;
+  }
+  int ksplit = cdiv(cdiv(K, splits), SBK) * SBK;
+  splits = cdiv(K, ksplit);
+  hipLaunchKernelGGL(sgemm_kernel, dim3(cdiv(N, 64), cdiv(M, 64), splits), dim3(256), 0, s, A, ars, acs, B, brs, bcs, C, ldc,
+                     M, N, K, bias, alpha, accumulate, ksplit);
   COATI_LAUNCH_CHECK("sgemm");
   return COATI_OK;
 }
