@@ -69,37 +69,49 @@ int launch_gnn_embed(const long long* atoms, const int* lut_ix, const int* lut_i
 }
 
 // dW[:, i] = sum over atoms whose one-hot has bit i of de[atom, :]; db = sum over all atoms.
-// grid (29, chunks): block x handles one-hot index x (28 = the bias); deterministic inside a chunk.
+// One pass over de: a workgroup owns a chunk of atoms, thread = channel, the 28 + 1 partial sums per channel live in LDS
+// ([29][H] floats, own column per thread -> no LDS atomics needed); the flush walks dW in memory order so consecutive
+// lanes add to consecutive addresses.
 __global__ __launch_bounds__(256) void gnn_embed_bwd_kernel(const long long* __restrict__ atoms, const int* __restrict__ lut_ix,
                                                             const int* __restrict__ lut_iy, const float* __restrict__ de,
                                                             float* __restrict__ dW, float* __restrict__ db, int BA, int H,
                                                             int rows_per_chunk) {
-  const int i = blockIdx.x;
-  const int r0 = blockIdx.y * rows_per_chunk;
+  extern __shared__ float acc[];   // [29][H]
+  for (int i = threadIdx.x; i < 29 * H; i += blockDim.x) acc[i] = 0.f;
+  __syncthreads();
+  const int r0 = blockIdx.x * rows_per_chunk;
   int r1 = r0 + rows_per_chunk;
   if (r1 > BA) r1 = BA;
-  for (int c = threadIdx.x; c < H; c += 256) {
-    float acc = 0.f;
+  for (int c = threadIdx.x; c < H; c += blockDim.x) {
+    float bsum = 0.f;
     for (int row = r0; row < r1; ++row) {
-      bool hit = (i == 28);
-      if (!hit) {
-        long long z = atoms[row];
-        if (z < 0) z = 0;
-        if (z > 119) z = 119;
-        hit = (lut_ix[z] == i) || (lut_iy[z] == i);
-      }
-      if (hit) acc += de[(long long)row * H + c];
+      long long z = atoms[row];
+      if (z < 0) z = 0;
+      if (z > 119) z = 119;
+      const int ix = lut_ix[z], iy = lut_iy[z];
+      const float v = de[(long long)row * H + c];
+      bsum += v;
+      acc[ix * H + c] += v;
+      if (iy != ix) acc[iy * H + c] += v;
     }
-    if (i == 28) atomicAdd(db + c, acc); else atomicAdd(dW + c * 28 + i, acc);
+    acc[28 * H + c] = bsum;
   }
+  __syncthreads();
+  for (int f = threadIdx.x; f < 28 * H; f += blockDim.x) {   // f = c * 28 + i: the memory order of dW [H][28]
+    const int c = f / 28, i = f - c * 28;
+    const float v = acc[i * H + c];
+    if (v != 0.f) atomicAdd(dW + f, v);
+  }
+  for (int c = threadIdx.x; c < H; c += blockDim.x) atomicAdd(db + c, acc[28 * H + c]);
 }
 
 int launch_gnn_embed_bwd(const long long* atoms, const int* lut_ix, const int* lut_iy, const float* de,
                          float* dW, float* db, int BA, int H, hipStream_t s) {
   COATI_CHECK_ARG(atoms && lut_ix && lut_iy && de && dW && db, "gnn_embed_bwd: null operand");
-  const int chunks = BA >= 4096 ? 32 : (BA >= 256 ? 8 : 1);
+  COATI_CHECK_SHAPE((size_t)29 * H * 4 <= 64 * 1024, "gnn_embed_bwd: H=%d too wide for the LDS accumulator", H);
+  const int chunks = BA >= 4096 ? 128 : (BA >= 256 ? 8 : 1);
   const int rpc = cdiv(BA, chunks);
-  hipLaunchKernelGGL(gnn_embed_bwd_kernel, dim3(29, cdiv(BA, rpc)), dim3(256), 0, s, atoms, lut_ix, lut_iy, de, dW, db, BA, H, rpc);
+  hipLaunchKernelGGL(gnn_embed_bwd_kernel, dim3(cdiv(BA, rpc)), dim3(256), (size_t)29 * H * 4, s, atoms, lut_ix, lut_iy, de, dW, db, BA, H, rpc);
   COATI_LAUNCH_CHECK("gnn_embed_bwd");
   return COATI_OK;
 }
