@@ -167,3 +167,39 @@ def test_medium_random_model_grads():
         if e > TOL_GRAD_SIM:
             bad.append((e, k))
     assert not bad, sorted(bad, reverse=True)[:8]
+
+
+def test_tall_closed_shape_vs_oracle():
+    """BASELINE.json configs[0] shape (d=256, nh=16 -> head size 16, batch 64, seq_len 128, 16-atom clouds) at reduced
+    depth (2 + 2 layers) and vocabulary so the oracle finishes in seconds: four 32-token attention blocks, the
+    row-block K=256 GEMMs at a ragged M (not a multiple of 320 rows), lm_head tiles with a partial last tile."""
+    from oracle import coati_oracle as O
+    from coati_amd.engine import Engine, ModelConfig
+    from coati_amd.synthetic import make_batch
+    kw = dict(n_layer_e3gnn=2, n_layer_xformer=2, n_hidden_xformer=256, n_hidden_e3nn=256, n_embd_common=256, n_head=16,
+              n_seq=250, n_tok=1003)
+    ocfg = O.OracleConfig(**kw)
+    P = O.init_params(ocfg, seed=11)
+    eng = Engine(ModelConfig(**kw), DEV)
+    eng.load_state_dict(P)
+    batch, up = make_batch(64, 128, 16, 1003, seed=7, n_special=12, p_bad=0.05, min_len=20)
+    db = {k: v.to(DEV) for k, v in batch.items()}
+    eng.train_step(db, up.to(DEV), lr=1e-3, optimizer=False)
+    L = eng.losses()
+    Pg = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    with O.sim_bf16():
+        loss, ar, cl, _ = O.step_loss(Pg, ocfg, batch, up)
+    loss.backward()
+    log(f"tall losses hip {L} oracle ar {float(ar):.6f} clip {float(cl):.6f}")
+    check("tall ar", torch.tensor([L["ar_loss"]]), ar.detach().reshape(1), 5e-3)
+    check("tall clip", torch.tensor([L["clip_loss"]]), cl.detach().reshape(1), 5e-3)
+    grads = eng.named_views("grads")
+    bad = []
+    for k in sorted(eng.layout):
+        ref = Pg[k].grad if Pg[k].grad is not None else torch.zeros_like(P[k])
+        scale = max(float(ref.abs().max()), 1e-30)
+        e = float((grads[k].cpu() - ref).abs().max()) / scale if float(ref.abs().max()) > 0 else float(grads[k].abs().max())
+        log(f"tall grad {k:60s} relerr {e:.3e} scale {scale:.3e}")
+        if e > TOL_GRAD_SIM:
+            bad.append((e, k))
+    assert not bad, sorted(bad, reverse=True)[:8]
