@@ -36,6 +36,8 @@ _SIGS = {
     "coati_gather_rows": [P, P, P, I, I, I, P],
     "coati_scatter_rows_add": [P, P, P, I, I, I, P],
     "coati_bad_rows": [P, P, I, I, P],
+    "coati_batch_ncols": [P, I, I, P, P],
+    "coati_batch_tail": [P, I, I, I, P, P, P, I, P],
     "coati_gnn_embed": [P, P, P, P, P, P, P, L, P, P, I, I, P],
     "coati_gnn_geom": [P, P, F, P, P, I, I, P],
     "coati_gnn_edge_pre": [P, L, P, P, L, P, P, I, I, I, P],

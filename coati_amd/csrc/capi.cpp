@@ -101,6 +101,14 @@ int coati_scatter_rows_add(const float* dout, const int32_t* pos, float* dx, int
 int coati_bad_rows(const int64_t* tokens, uint8_t* bad, int B, int T, void* stream) {
   return launch_bad_rows(LL(tokens), bad, B, T, S_(stream));
 }
+int coati_batch_ncols(const int64_t* tokens, int B, int n_seq, int32_t* ncols, void* stream) {
+  return launch_batch_ncols(LL(tokens), B, n_seq, ncols, S_(stream));
+}
+int coati_batch_tail(const int64_t* tokens, int B, int n_seq, int ncol, int64_t* tokens_out, int64_t* y_next_out,
+                     const int64_t* masked_ids, int n_masked, void* stream) {
+  return launch_batch_tail(LL(tokens), B, n_seq, ncol, reinterpret_cast<long long*>(tokens_out),
+                           reinterpret_cast<long long*>(y_next_out), LL(masked_ids), n_masked, S_(stream));
+}
 
 int coati_gnn_embed(const int64_t* atoms, const int32_t* lut_ix, const int32_t* lut_iy, const float* W, const float* b,
                     float* h32, uint16_t* h16, int64_t ld16, float* rstd, float* mask, int BA, int H, void* stream) {

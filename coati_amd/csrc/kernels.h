@@ -117,6 +117,10 @@ int launch_gather_rows(const float* x, const int* pos, float* out, int B, int T,
 int launch_scatter_rows_add(const float* dout, const int* pos, float* dx, int B, int T, int C, hipStream_t s);
 // bad[b] = sum_t tokens[b,t] < 1
 int launch_bad_rows(const long long* tokens, unsigned char* bad, int B, int T, hipStream_t s);
+// batch tail (batch.hip)
+int launch_batch_ncols(const long long* tok, int B, int S, int* ncols, hipStream_t s);
+int launch_batch_tail(const long long* tok, int B, int S, int ncol, long long* tok_out, long long* y_out,
+                      const long long* masked, int n_masked, hipStream_t s);
 
 // ------------------------------------------------------------------------------------------------
 // fused lm_head cross-entropy pieces (lmhead.hip)

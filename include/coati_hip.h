@@ -115,6 +115,13 @@ int coati_gather_rows(const float* x, const int32_t* pos, float* out, int B, int
 int coati_scatter_rows_add(const float* dout, const int32_t* pos, float* dx, int B, int T, int C, void* stream);
 int coati_bad_rows(const int64_t* tokens, uint8_t* bad, int B, int T, void* stream);
 
+/* batch tail of clip_ar_xform on the device (clip_e2e.py:312-329).
+   ncols[0] = (tokens.sum(0) > 0).sum();  batch_tail: tokens_out = tokens[:, :ncol] (contiguous), and if y_next_out:
+   y_next_out[:, t] = tokens[:, t+1] (0 in the last column) with every id in masked_ids replaced by -1 */
+int coati_batch_ncols(const int64_t* tokens, int B, int n_seq, int32_t* ncols, void* stream);
+int coati_batch_tail(const int64_t* tokens, int B, int n_seq, int ncol, int64_t* tokens_out, int64_t* y_next_out,
+                     const int64_t* masked_ids, int n_masked, void* stream);
+
 /* E(3)-GNN pieces (e3gnn_clip.py:108-137, e_gcl_sparse.py) -- see csrc/gnn.hip for the dense-edge formulation */
 int coati_gnn_embed(const int64_t* atoms, const int32_t* lut_ix, const int32_t* lut_iy, const float* W,
                     const float* b, float* h32, uint16_t* h16, int64_t ld16, float* rstd, float* mask, int BA,

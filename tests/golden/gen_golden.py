@@ -261,6 +261,26 @@ def main():
     xf = dict(tokens=res["tokens"], raw_tokens=res["raw_tokens"], y_next=res["y_next"])
     # the un-truncated stacks are re-derivable: pad back to n_seq with zeros
     np.savez_compressed(os.path.join(OUT, "xform_tail.npz"), **npify(xf))
+    # ---- n2: stack_batch (data/batch_pipe.py:9-72) on seeded ragged rows, incl. a row without atoms and a row whose
+    # coords arrive flat (the "snowflake" branch) -------------------------------------------------------------
+    from coati.data.batch_pipe import stack_batch as ref_stack, get_mod_from_str as ref_mod
+    rng = np.random.RandomState(11)
+    rows = []
+    for i, na in enumerate([5, 9, 0, 3, 12, 7]):
+        r = {"smiles": f"mol{i}", "source_collection": "x"}
+        if na > 0:
+            r["atoms"] = rng.randint(1, 18, size=(na,)).astype(np.int64)
+            r["coords"] = rng.randn(na, 3)
+        rows.append(r)
+    rows[3]["coords"] = rows[3]["coords"].reshape(-1)      # flat coords -> the except branch
+    sb = ref_stack([dict(r) for r in rows])
+    sbv = dict(atoms=sb["atoms"], coords=sb["coords"], smiles=np.array([str(x) for x in sb["smiles"]]),
+               mods=np.array([ref_mod(r["smiles"], 8) for r in rows], dtype=np.int64))
+    for i, r in enumerate(rows):
+        if "atoms" in r:
+            sbv[f"row{i}_atoms"] = r["atoms"]
+            sbv[f"row{i}_coords"] = r["coords"]
+    np.savez_compressed(os.path.join(OUT, "stack_batch.npz"), **sbv)
     # ---- G14 AllGatherFunction forward/backward under a 2-rank gloo group (autograd_funs.py:5-25) ----
     import torch.multiprocessing as mp
     mp.spawn(_allgather_worker, args=(2,), nprocs=2)

@@ -78,3 +78,42 @@ def test_trainer_and_checkpoint_roundtrip(tmp_path):
     m2, _ = load_e3gnn_smiles_clip_e2e(os.path.join(args.model_dir, files[0]), device="cuda:0")
     for k, t in model.state_dict().items():
         assert torch.equal(t.cpu(), m2.state_dict()[k].cpu()), k
+
+
+DEV = "cuda:0"
+
+
+def test_device_batch_tail_matches_reference_golden(golden_dir):
+    """truncate + y_next on the device (coati_batch_ncols / coati_batch_tail) against the reference's own
+    clip_ar_xform output (tests/golden/xform_tail.npz) and against the host mirror on a synthetic batch."""
+    import numpy as np
+    from coati_amd.data.batch_pipe import device_tail
+    from coati_amd.models.encoding.clip_e2e import tensorize_batch
+    g = np.load(os.path.join(golden_dir, "xform_tail.npz"))
+
+    class Tk:  # ids of the 'mar' vocabulary used by the golden generator (tests/golden/constants.json)
+        pad_token, clip_token, unk_token, suffix_token, middle_token = 0, 8, 7, 5, 6
+
+    n_seq = 40
+    tok = torch.zeros(g["tokens"].shape[0], n_seq, dtype=torch.long)
+    raw = torch.zeros_like(tok)
+    tok[:, : g["tokens"].shape[1]] = torch.from_numpy(g["tokens"])
+    raw[:, : g["raw_tokens"].shape[1]] = torch.from_numpy(g["raw_tokens"])
+    t, r, y = device_tail(tok.to(DEV), raw.to(DEV), Tk)
+    assert torch.equal(t.cpu(), torch.from_numpy(g["tokens"]))
+    assert torch.equal(r.cpu(), torch.from_numpy(g["raw_tokens"]))
+    assert torch.equal(y.cpu(), torch.from_numpy(g["y_next"]))
+    # larger seeded batch: device tail == host mirror (bit-exact integer work)
+    gen = torch.Generator().manual_seed(3)
+    B, S = 257, 250
+    lens = torch.randint(3, 90, (B,), generator=gen)
+    tok = torch.zeros(B, S, dtype=torch.long)
+    raw = torch.zeros(B, S, dtype=torch.long)
+    for b in range(B):
+        tok[b, : lens[b]] = torch.randint(0, 300, (int(lens[b]),), generator=gen)
+        raw[b, : max(int(lens[b]) - 2, 1)] = torch.randint(1, 300, (max(int(lens[b]) - 2, 1),), generator=gen)
+    tok[:, 0] = 8
+    host = tensorize_batch({"tokens": tok.clone(), "raw_tokens": raw.clone(), "atoms": torch.zeros(B, 4, dtype=torch.long),
+                            "coords": torch.zeros(B, 4, 3)}, Tk, device="cpu")
+    t, r, y = device_tail(tok.to(DEV), raw.to(DEV), Tk)
+    assert torch.equal(t.cpu(), host["tokens"]) and torch.equal(r.cpu(), host["raw_tokens"]) and torch.equal(y.cpu(), host["y_next"])

@@ -127,3 +127,27 @@ def test_reference_import_paths_and_args():
     pipe = COATI_dataset(cache_dir=".").get_data_pipe(batch_size=4, distributed_rankmod_total=2, distributed_rankmod_rank=1)
     b = next(iter(pipe))
     assert b["tokens"].shape[0] == 4 and "y_next" in b
+
+
+def test_stack_batch_matches_reference_golden(golden_dir):
+    """the host mirror of coati/data/batch_pipe.py:stack_batch against vectors produced by the reference
+    itself (ragged atom counts, a molecule without atoms, flat coordinates)."""
+    import numpy as np
+    from coati_amd.data.batch_pipe import stack_batch, get_mod_from_str, shard_rows
+    g = np.load(os.path.join(golden_dir, "stack_batch.npz"), allow_pickle=False)
+    rows = []
+    for i, smi in enumerate(g["smiles"]):
+        r = {"smiles": str(smi), "source_collection": "x"}
+        if f"row{i}_atoms" in g.files:
+            r["atoms"] = g[f"row{i}_atoms"]
+            r["coords"] = g[f"row{i}_coords"]
+        rows.append(r)
+    out = stack_batch(rows)
+    assert out["atoms"].shape == g["atoms"].shape and out["coords"].shape == g["coords"].shape
+    assert np.array_equal(out["atoms"], g["atoms"])
+    assert np.array_equal(out["coords"], g["coords"])
+    assert [str(x) for x in out["smiles"]] == [str(x) for x in g["smiles"]]
+    assert [get_mod_from_str(r["smiles"], 8) for r in rows] == list(g["mods"])
+    # the per-rank filter partitions the rows
+    parts = [shard_rows(rows, r, 2) for r in range(2)]
+    assert sum(len(p) for p in parts) == len(rows)
