@@ -36,6 +36,12 @@ _SIGS = {
     "coati_gather_rows": [P, P, P, I, I, I, P],
     "coati_scatter_rows_add": [P, P, P, I, I, I, P],
     "coati_bad_rows": [P, P, I, I, P],
+    "coati_silu": [P, P, L, P],
+    "coati_attn_decode": [P, P, P, I, I, I, I, P],
+    "coati_topk_sample": [P, L, I, I, I, F, P, P, P, I, I, P],
+    "coati_engine_decode_begin": [P, P, L, I, I],
+    "coati_engine_decode_step": [P, P, P, P, L, P],
+    "coati_engine_decode_pos": [P],
     "coati_batch_ncols": [P, I, I, P, P],
     "coati_batch_tail": [P, I, I, I, P, P, P, I, P],
     "coati_gnn_embed": [P, P, P, P, P, P, P, L, P, P, I, I, P],
@@ -91,6 +97,8 @@ def lib():
         getattr(l, name).restype = c_int64
     l.coati_engine_workspace_bytes.argtypes = [P, I, I, I, I, I]
     l.coati_engine_workspace_bytes.restype = c_int64
+    l.coati_engine_decode_workspace_bytes.argtypes = [P, I, I]
+    l.coati_engine_decode_workspace_bytes.restype = c_int64
     l.coati_engine_n_entries.argtypes = [P]
     l.coati_engine_n_entries.restype = c_int
     l.coati_engine_site_count.restype = c_int
@@ -103,7 +111,7 @@ def lib():
 def exported_symbols():
     return sorted(list(_SIGS) + ["coati_last_error", "coati_abi_version", "coati_engine_destroy",
                                  "coati_engine_param_elems", "coati_engine_shadow_elems",
-                                 "coati_engine_workspace_bytes", "coati_engine_n_entries",
+                                 "coati_engine_workspace_bytes", "coati_engine_decode_workspace_bytes", "coati_engine_n_entries",
                                  "coati_engine_site_count", "coati_engine_site_name"])
 
 

@@ -101,6 +101,14 @@ int coati_scatter_rows_add(const float* dout, const int32_t* pos, float* dx, int
 int coati_bad_rows(const int64_t* tokens, uint8_t* bad, int B, int T, void* stream) {
   return launch_bad_rows(LL(tokens), bad, B, T, S_(stream));
 }
+int coati_silu(const float* x, float* y, int64_t n, void* stream) { return launch_silu_fwd(x, y, n, S_(stream)); }
+int coati_attn_decode(const uint16_t* qkv, uint16_t* cache, uint16_t* y, int B, int n_head, int Tmax, int pos, void* stream) {
+  return launch_attn_decode(qkv, cache, y, B, n_head, Tmax, pos, S_(stream));
+}
+int coati_topk_sample(const float* logits, int64_t ldl, int B, int V, int k, float inv_temp, const float* u,
+                      int64_t* tokens_out, int32_t* stopped, int stop_token, int pad_token, void* stream) {
+  return launch_topk_sample(logits, ldl, B, V, k, inv_temp, u, reinterpret_cast<long long*>(tokens_out), stopped, stop_token, pad_token, S_(stream));
+}
 int coati_batch_ncols(const int64_t* tokens, int B, int n_seq, int32_t* ncols, void* stream) {
   return launch_batch_ncols(LL(tokens), B, n_seq, ncols, S_(stream));
 }

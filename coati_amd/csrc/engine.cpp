@@ -146,6 +146,14 @@ struct coati_engine {
   int ev_used = 0;
   double prof_flops = 0.0;
   double prof_last_bytes = 0.0;   // per launch, of the last prof_collect
+  // ---- inference decode (KV cache) ----
+  struct Decode {
+    bool active = false;
+    int B = 0, Tmax = 0, pos = 0;
+    bf16_t* cache = nullptr;   // [L][B][nh][Tmax][k16|v16]
+    float *x = nullptr, *xmid = nullptr, *xn = nullptr, *mean = nullptr, *rstd = nullptr;
+    bf16_t *a = nullptr, *qkv = nullptr, *y = nullptr, *hpre = nullptr, *g = nullptr, *af = nullptr;
+  } dec;
   double prof_bytes = 0.0;   // algorithmic HBM bytes (operands read once, results written once) of the selected site
 };
 
@@ -274,6 +282,7 @@ void build_layout(coati_engine* e) {
 }
 
 // ---- profiling wrapper ---------------------------------------------------------------------------------
+constexpr int SITE_NONE = -2;   // launches outside the training step (never timed)
 struct ProfScope {
   coati_engine* e;
   hipStream_t s;
@@ -949,5 +958,88 @@ int coati_engine_prof_last_bytes(coati_engine* e, double* bytes_per_launch) {
 
 int coati_engine_site_count(void) { return SITE_COUNT; }
 const char* coati_engine_site_name(int site) { return (site >= 0 && site < SITE_COUNT) ? kSiteNames[site] : ""; }
+
+}  // extern "C"
+
+// ---- inference: KV-cached decode (reference smiles_xformer.py:272-351 + xformer_blocks) ----------------
+namespace {
+size_t decode_carve(coati_engine* e, Arena& ar, int B, int Tmax) {
+  const coati_config& c = e->cfg;
+  const size_t C = c.n_hidden_xformer, L = c.n_layer_xformer;
+  auto& d = e->dec;
+  d.cache = ar.take<bf16_t>(L * B * (size_t)c.n_head * Tmax * 32);
+  d.x = ar.take<float>(B * C); d.xmid = ar.take<float>(B * C); d.xn = ar.take<float>(B * C);
+  d.mean = ar.take<float>(B); d.rstd = ar.take<float>(B);
+  d.a = ar.take<bf16_t>(B * C); d.qkv = ar.take<bf16_t>(B * 3 * C); d.y = ar.take<bf16_t>(B * C);
+  d.hpre = ar.take<bf16_t>(B * 4 * C); d.g = ar.take<bf16_t>(B * 4 * C); d.af = ar.take<bf16_t>(B * C);
+  return (ar.off + 255) & ~(size_t)255;
+}
+}  // namespace
+
+extern "C" {
+
+int64_t coati_engine_decode_workspace_bytes(coati_engine* e, int B, int Tmax) {
+  if (!e || B <= 0 || Tmax <= 0) return 0;
+  Arena ar{nullptr, 0, 0, true};
+  coati_engine::Decode keep = e->dec;
+  const size_t n = decode_carve(e, ar, B, Tmax);
+  e->dec = keep;
+  return (int64_t)n;
+}
+
+int coati_engine_decode_begin(coati_engine* e, void* workspace, int64_t ws_bytes, int B, int Tmax) {
+  COATI_CHECK_ARG(e && workspace && e->P && e->S, "decode_begin: engine not bound / null workspace");
+  COATI_CHECK_SHAPE(B > 0 && Tmax > 0 && Tmax <= e->cfg.n_seq && Tmax <= 256, "decode_begin: bad shape B=%d Tmax=%d (n_seq=%d)", B, Tmax, e->cfg.n_seq);
+  COATI_CHECK_SHAPE(e->cfg.n_hidden_xformer == e->cfg.n_head * 16, "decode: head size must be 16");
+  COATI_CHECK_SHAPE(ws_bytes >= coati_engine_decode_workspace_bytes(e, B, Tmax), "decode_begin: workspace too small");
+  Arena ar{reinterpret_cast<char*>(workspace), 0, (size_t)ws_bytes, false};
+  decode_carve(e, ar, B, Tmax);
+  e->dec.active = true;
+  e->dec.B = B; e->dec.Tmax = Tmax; e->dec.pos = 0;
+  return COATI_OK;
+}
+
+int coati_engine_decode_pos(coati_engine* e) { return (e && e->dec.active) ? e->dec.pos : -1; }
+
+// One position for every sequence: tokens[B] (ids; rows equal to the [UNK] id take their embedding from injection[B, C]
+// when it is given, smiles_xformer.py:444-448).  logits (optional) [B, n_tok] f32, row stride ldl.
+int coati_engine_decode_step(coati_engine* e, const int64_t* tokens, const float* injection, float* logits, int64_t ldl,
+                             void* stream) {
+  COATI_CHECK_ARG(e && e->dec.active && tokens, "decode_step: no decode session / null tokens");
+  auto& d = e->dec;
+  COATI_CHECK_SHAPE(d.pos < d.Tmax, "decode_step: the cache is full (pos=%d, Tmax=%d)", d.pos, d.Tmax);
+  COATI_CHECK_ARG(!logits || ldl >= e->cfg.n_tok, "decode_step: ldl too small");
+  hipStream_t s = (hipStream_t)stream;
+  const coati_config& c = e->cfg;
+  const int C = c.n_hidden_xformer, L = c.n_layer_xformer, B = d.B;
+  COATI_TRY(launch_embed_fwd(reinterpret_cast<const long long*>(tokens), e->P + e->tok_emb, injection, c.unk_token, d.x, B, 1, C, c.n_tok, s));
+  float* x = d.x;
+  float* xm = d.xmid;
+  for (int l = 0; l < L; ++l) {
+    const XLayerP& w = e->xl[l];
+    COATI_TRY(launch_layernorm_fwd(x, C, e->P + w.ln1w, e->P + w.ln1b, d.a, C, nullptr, 0, d.mean, d.rstd, B, C, s));
+    {
+      // every row sits at token position pos: rope tables offset to that row, period 1
+      GemmArgs a;
+      memset(&a, 0, sizeof(a));
+      a.A = d.a; a.lda = C; a.B = e->S + w.attnw; a.ldb = C; a.M = B; a.N = 3 * C; a.K = C; a.C = d.qkv; a.ldc = 3 * C;
+      a.bias = e->P + w.attnb; a.rope_cos = e->cos_t + (size_t)d.pos * 16; a.rope_sin = e->sin_t + (size_t)d.pos * 16;
+      a.rope_T = 1; a.rope_C = C;
+      COATI_TRY(launch_gemm_nt(a, 0, EPI_QKV_ROPE, s));
+    }
+    bf16_t* cache_l = d.cache + (size_t)l * B * c.n_head * d.Tmax * 32;
+    COATI_TRY(launch_attn_decode(d.qkv, cache_l, d.y, B, c.n_head, d.Tmax, d.pos, s));
+    COATI_TRY(gemm(e, SITE_NONE, d.y, 0, C, e->S + w.projw, C, B, C, C, xm, C, e->P + w.projb, EPI_RES_F32, x, nullptr, C, s));
+    COATI_TRY(launch_layernorm_fwd(xm, C, e->P + w.ln2w, e->P + w.ln2b, d.a, C, nullptr, 0, d.mean, d.rstd, B, C, s));
+    COATI_TRY(gemm(e, SITE_NONE, d.a, 0, C, e->S + w.fc1w, C, B, 4 * C, C, d.g, 4 * C, e->P + w.fc1b, EPI_GELU, nullptr, d.hpre, 4 * C, s));
+    COATI_TRY(gemm(e, SITE_NONE, d.g, 0, 4 * C, e->S + w.fc2w, 4 * C, B, C, 4 * C, x, C, e->P + w.fc2b, EPI_RES_F32, xm, nullptr, C, s));
+  }
+  d.pos += 1;
+  if (logits) {
+    COATI_TRY(launch_layernorm_fwd(x, C, e->P + e->lnfw, e->P + e->lnfb, d.af, C, nullptr, 0, d.mean, d.rstd, B, C, s));
+    COATI_TRY(gemm(e, SITE_NONE, d.af, 0, C, e->S + e->lmhead, C, B, c.n_tok, C, logits, ldl, nullptr, EPI_F32, nullptr, nullptr, 0, s));
+  }
+  return COATI_OK;
+}
 
 }  // extern "C"

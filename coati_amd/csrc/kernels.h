@@ -117,6 +117,10 @@ int launch_gather_rows(const float* x, const int* pos, float* out, int B, int T,
 int launch_scatter_rows_add(const float* dout, const int* pos, float* dx, int B, int T, int C, hipStream_t s);
 // bad[b] = sum_t tokens[b,t] < 1
 int launch_bad_rows(const long long* tokens, unsigned char* bad, int B, int T, hipStream_t s);
+// inference decode (decode.hip)
+int launch_attn_decode(const bf16_t* qkv, bf16_t* cache, bf16_t* y, int B, int n_head, int Tmax, int pos, hipStream_t s);
+int launch_topk_sample(const float* logits, long long ldl, int B, int V, int k, float inv_temp, const float* u,
+                       long long* tok_out, int* stopped, int stop_token, int pad_token, hipStream_t s);
 // batch tail (batch.hip)
 int launch_batch_ncols(const long long* tok, int B, int S, int* ncols, hipStream_t s);
 int launch_batch_tail(const long long* tok, int B, int S, int ncol, long long* tok_out, long long* y_out,

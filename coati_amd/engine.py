@@ -199,6 +199,70 @@ class Engine:
         return {"ar_loss": ar, "clip_loss": clip, "loss": ar + clip * self.token_entropy_unit(),
                 "grad_norm": float(s[SCAL_GRADNORM]), "n_targets": float(s[SCAL_AR_COUNT]), "n_valid": nv}
 
+
+    # ---- inference: KV-cached decode ---------------------------------------------------------------
+    def decode_begin(self, B, Tmax=None):
+        """Start a generation session for B sequences of at most Tmax positions (default n_seq)."""
+        Tmax = int(Tmax or self.cfg.n_seq)
+        n = int(self.l.coati_engine_decode_workspace_bytes(self.h, int(B), Tmax))
+        if n <= 0:
+            raise RuntimeError("decode_begin: bad shape")
+        self._dec_ws = torch.empty(n, dtype=torch.uint8, device=self.device)
+        self._dec_B = int(B)
+        _lib.check(self.l.coati_engine_decode_begin(self.h, ctypes.c_void_p(self._dec_ws.data_ptr()), n, int(B), Tmax), "decode_begin")
+
+    def decode_step(self, tokens, injection=None, want_logits=True):
+        """Append one position: tokens [B] int64 (rows equal to the [UNK] id read `injection` [B, C] instead of the
+        embedding table).  Returns logits [B, n_tok] f32 or None."""
+        B = self._dec_B
+        tokens = tokens.to(self.device, torch.long).contiguous()
+        assert tokens.shape == (B,)
+        inj = None
+        if injection is not None:
+            inj = injection.to(self.device, torch.float32).contiguous()
+            assert inj.shape == (B, self.cfg.n_hidden_xformer)
+        logits = torch.empty(B, self.cfg.n_tok, device=self.device, dtype=torch.float32) if want_logits else None
+        _lib.check(self.l.coati_engine_decode_step(self.h, ptr(tokens), ptr(inj), ptr(logits), self.cfg.n_tok, stream()), "decode_step")
+        return logits
+
+    def generate_top_k_with_inj_batch(self, prefix, stop_token, pad_token=0, inv_temp=1.0, k=50, inj_token=None,
+                                      inj_payload=None, as_tensor=False, generator=None):
+        """RotarySmilesTransformer.generate_top_k_with_inj_batch (smiles_xformer.py:272-351) on the KV-cached decode
+        path: same arguments, same stopping rules (stopped rows emit pad_token, rows that never stop get a final
+        stop_token), sampling = softmax(top-k logits * inv_temp) drawn with uniforms from `generator`."""
+        prefix = [int(t) for t in prefix]
+        B = int(inj_payload.shape[0])
+        if inj_token is not None and int(inj_token) != self.cfg.unk_token:
+            raise NotImplementedError("the injection slot must be the engine's [UNK] id")
+        n_seq = self.cfg.n_seq
+        self.decode_begin(B, n_seq)
+        dev = self.device
+        logits = None
+        for i, t in enumerate(prefix):
+            tok = torch.full((B,), t, dtype=torch.long, device=dev)
+            logits = self.decode_step(tok, inj_payload if (inj_token is not None and t == int(inj_token)) else None,
+                                      want_logits=(i == len(prefix) - 1))
+        stopped = torch.zeros(B, dtype=torch.int32, device=dev)
+        generated = []
+        idx = 0
+        while idx < n_seq - len(prefix):
+            u = torch.rand(B, device=dev, generator=generator) if k > 1 else torch.zeros(B, device=dev)
+            nxt = torch.empty(B, dtype=torch.long, device=dev)
+            _lib.call("coati_topk_sample", ptr(logits), self.cfg.n_tok, B, self.cfg.n_tok, int(k), float(inv_temp), ptr(u),
+                      ptr(nxt), ptr(stopped), int(stop_token), int(pad_token), stream())
+            generated.append(nxt)
+            idx += 1
+            if int(stopped.sum().item()) >= B or idx >= n_seq - len(prefix):
+                break
+            logits = self.decode_step(nxt)
+        gen = torch.stack(generated, dim=1)
+        not_stopped = stopped == 0
+        if bool(not_stopped.any()):
+            gen[not_stopped, -1] = int(stop_token)
+        if as_tensor:
+            return torch.cat([torch.tensor(prefix, dtype=torch.long, device=dev).unsqueeze(0).repeat(B, 1), gen], dim=1)
+        return [prefix + row for row in gen.tolist()]
+
     # ---- profiling ---------------------------------------------------------------------------------------------
     def site_names(self):
         return [self.l.coati_engine_site_name(i).decode() for i in range(self.l.coati_engine_site_count())]

@@ -86,6 +86,8 @@ class e3gnn_smiles_clip_e2e(nn.Module):
             _attach(self, f"xformer.transformer.h.{l}.attn.bias",
                     torch.tril(torch.ones(n_seq, n_seq, device=self.device)).view(1, 1, n_seq, n_seq), buffer=True)
         self.xformer.n_seq, self.xformer.n_tok, self.xformer.n_embd = n_seq, n_tok, n_hidden_xformer
+        # generation entry point of the reference's RotarySmilesTransformer (smiles_xformer.py:272-351), KV-cached here
+        object.__setattr__(self.xformer, "generate_top_k_with_inj_batch", eng.generate_top_k_with_inj_batch)
         self.point_encoder.hidden_nf = n_hidden_e3nn
         self.use_point_encoder = True
         self.clip_loss = clip_loss(eng)
@@ -163,6 +165,42 @@ class e3gnn_smiles_clip_e2e(nn.Module):
         idx = torch.tensor([[2, c.stop_token]], dtype=torch.long, device=self.device).repeat(B, 1)
         h_e, _, _, _ = self.forward_dist(idx, idx, atoms, coords, None, use_point=torch.ones(B, dtype=torch.bool), return_logits=False)
         return h_e
+
+    def special_tokens_from_clip(self, h_clip):
+        """point_clip_to_special_tokens = SiLU -> Linear (clip_e2e.py:432-435) on [B, E] embeddings (HIP silu + f32 GEMM)."""
+        from ... import _lib, ops
+        h = h_clip.to(self.device, torch.float32).contiguous()
+        a = torch.empty_like(h)
+        _lib.call("coati_silu", ops.ptr(h), ops.ptr(a), h.numel(), ops.stream())
+        lin = self.point_clip_to_special_tokens._modules["1"]
+        return ops.sgemm(a, lin.weight.detach(), trans_b=True, bias=lin.bias.detach())
+
+    @torch.no_grad()
+    def hclip_to_2d_batch(self, h_clip, tokenizer, fill_in_from: str = "[SMILES]", noise_scale: float = 0.0,
+                          inv_temp: float = 2, k: int = 100, do_suffix=False, keep_special: bool = False,
+                          return_tokens: bool = False, generator=None):
+        """clip_e2e.py:544-588: decode a batch of clip embeddings into token sequences (and SMILES when the tokenizer
+        can decode).  Prefix "[CLIP][UNK]" + fill_in_from (+ "[SUFFIX][MIDDLE]"), the [UNK] slot carries the
+        special-token embedding of h_clip; generation = top-k sampling on the KV-cached decode path."""
+        self._sync_tokens(tokenizer)
+        assert fill_in_from in ("[SMILES]", "[GRAPH]")
+        if noise_scale > 0:
+            h_clip = h_clip + noise_scale * torch.randn_like(h_clip)
+        h_token = self.special_tokens_from_clip(h_clip)
+        if hasattr(tokenizer, "tokenize_text"):
+            prefix = tokenizer.tokenize_text("[CLIP][UNK]" + fill_in_from + ("[SUFFIX][MIDDLE]" if do_suffix else ""), pad=False)
+        else:
+            names = ["clip_token", "unk_token", "smiles_token" if fill_in_from == "[SMILES]" else "graph_token"]
+            names += ["suffix_token", "middle_token"] if do_suffix else []
+            prefix = [int(getattr(tokenizer, n)) for n in names]
+        generation = self.engine.generate_top_k_with_inj_batch(prefix=prefix, stop_token=tokenizer.stop_token, inv_temp=inv_temp,
+                                                               k=k, pad_token=tokenizer.pad_token, inj_token=tokenizer.unk_token,
+                                                               inj_payload=h_token, generator=generator)
+        if hasattr(tokenizer, "decode"):
+            smiles_list = [tokenizer.decode(t, special=keep_special) for t in generation]
+        else:
+            smiles_list = generation
+        return (smiles_list, generation) if return_tokens else smiles_list
 
     def _sync_tokens(self, tokenizer):
         if tokenizer is None:

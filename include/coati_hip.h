@@ -122,6 +122,16 @@ int coati_batch_ncols(const int64_t* tokens, int B, int n_seq, int32_t* ncols, v
 int coati_batch_tail(const int64_t* tokens, int B, int n_seq, int ncol, int64_t* tokens_out, int64_t* y_next_out,
                      const int64_t* masked_ids, int n_masked, void* stream);
 
+/* y = x * sigmoid(x), f32 (point_clip_to_special_tokens = SiLU -> Linear, clip_e2e.py:432-435) */
+int coati_silu(const float* x, float* y, int64_t n, void* stream);
+
+/* decode-time operators: one query per (sequence, head) against the KV cache [B, nh, Tmax, k16|v16] (appends position
+   pos first), and top-k sampling: token = inds[multinomial(softmax(topk(logits, k) * inv_temp))] with the caller's
+   uniforms u[B]; rows flagged in stopped[] emit pad_token, rows drawing stop_token get flagged (smiles_xformer.py:305-324) */
+int coati_attn_decode(const uint16_t* qkv, uint16_t* cache, uint16_t* y, int B, int n_head, int Tmax, int pos, void* stream);
+int coati_topk_sample(const float* logits, int64_t ldl, int B, int V, int k, float inv_temp, const float* u,
+                      int64_t* tokens_out, int32_t* stopped, int stop_token, int pad_token, void* stream);
+
 /* E(3)-GNN pieces (e3gnn_clip.py:108-137, e_gcl_sparse.py) -- see csrc/gnn.hip for the dense-edge formulation */
 int coati_gnn_embed(const int64_t* atoms, const int32_t* lut_ix, const int32_t* lut_iy, const float* W,
                     const float* b, float* h32, uint16_t* h16, int64_t ld16, float* rstd, float* mask, int BA,
@@ -229,6 +239,17 @@ int coati_engine_prof_collect(coati_engine* e, double* total_ms, int64_t* launch
 /* algorithmic HBM bytes per launch (operands read once, results written once) of the site collected last */
 int coati_engine_prof_last_bytes(coati_engine* e, double* bytes_per_launch);
 int coati_engine_site_count(void);
+
+/* ---- inference decode: KV-cached generation, one position per call -------------------------------
+   replaces RotarySmilesTransformer.generate_top_k_with_inj_batch's per-token full-prefix recompute
+   (smiles_xformer.py:272-351).  workspace: caller-owned device memory (KV cache [L,B,nh,Tmax,32] bf16 + per-step
+   activations).  decode_step consumes tokens[B]; rows equal to the [UNK] id read injection[B, C] instead of the
+   embedding table (smiles_xformer.py:444-448); logits [B, n_tok] f32 (optional). */
+int64_t coati_engine_decode_workspace_bytes(coati_engine* e, int B, int Tmax);
+int coati_engine_decode_begin(coati_engine* e, void* workspace, int64_t ws_bytes, int B, int Tmax);
+int coati_engine_decode_step(coati_engine* e, const int64_t* tokens, const float* injection, float* logits, int64_t ldl,
+                             void* stream);
+int coati_engine_decode_pos(coati_engine* e);
 const char* coati_engine_site_name(int site);
 
 #ifdef __cplusplus

@@ -244,6 +244,20 @@ def main():
     # a second step-grad pin with large gradients so that clip_grad_norm actually clips
     out.update(teu=np.array(teu))
 
+    # ---- n3: greedy generation with clip injection (smiles_xformer.py:272-351) with the weights of
+    # small_model_after3.npz; teacher-forced logits of the generated sequences (xformer_blocks :202-213) ------------
+    with torch.no_grad():
+        gg = torch.Generator().manual_seed(77)
+        payload = torch.randn(6, 64, generator=gg)
+        prefix = [Tok.clip_token, Tok.unk_token, Tok.smiles_token]
+        gen = model.xformer.generate_top_k_with_inj_batch(prefix=prefix, stop_token=Tok.stop_token, pad_token=Tok.pad_token,
+                                                          inv_temp=1, k=1, inj_token=Tok.unk_token, inj_payload=payload,
+                                                          as_tensor=True)
+        xg = model.xformer.emb(gen)
+        xg[:, 1, :] = payload
+        lg = model.xformer.xformer_blocks(xg, apply_norm=True, output_logits=True)
+        out.update(gen_payload=payload, gen_tokens=gen, gen_logits=lg)
+
     np.savez_compressed(os.path.join(OUT, "small_vectors.npz"), **npify(out))
 
     # ---- G15 clip_ar_xform tail (tokenizer 'mar', CanonSmiles stubbed to identity) -----------
