@@ -221,9 +221,11 @@ class Engine:
         if injection is not None:
             inj = injection.to(self.device, torch.float32).contiguous()
             assert inj.shape == (B, self.cfg.n_hidden_xformer)
-        logits = torch.empty(B, self.cfg.n_tok, device=self.device, dtype=torch.float32) if want_logits else None
-        _lib.check(self.l.coati_engine_decode_step(self.h, ptr(tokens), ptr(inj), ptr(logits), self.cfg.n_tok, stream()), "decode_step")
-        return logits
+        V = self.cfg.n_tok
+        ld = (V + 7) // 8 * 8          # f32 rows 16-B aligned for the GEMM epilogue's float4 stores
+        logits = torch.empty(B, ld, device=self.device, dtype=torch.float32) if want_logits else None
+        _lib.check(self.l.coati_engine_decode_step(self.h, ptr(tokens), ptr(inj), ptr(logits), ld, stream()), "decode_step")
+        return logits[:, :V] if want_logits else None
 
     def generate_top_k_with_inj_batch(self, prefix, stop_token, pad_token=0, inv_temp=1.0, k=50, inj_token=None,
                                       inj_payload=None, as_tensor=False, generator=None):
@@ -248,7 +250,7 @@ class Engine:
         while idx < n_seq - len(prefix):
             u = torch.rand(B, device=dev, generator=generator) if k > 1 else torch.zeros(B, device=dev)
             nxt = torch.empty(B, dtype=torch.long, device=dev)
-            _lib.call("coati_topk_sample", ptr(logits), self.cfg.n_tok, B, self.cfg.n_tok, int(k), float(inv_temp), ptr(u),
+            _lib.call("coati_topk_sample", ptr(logits), logits.stride(0), B, self.cfg.n_tok, int(k), float(inv_temp), ptr(u),
                       ptr(nxt), ptr(stopped), int(stop_token), int(pad_token), stream())
             generated.append(nxt)
             idx += 1
