@@ -99,6 +99,16 @@ def lib():
     l.coati_engine_workspace_bytes.restype = c_int64
     l.coati_engine_decode_workspace_bytes.argtypes = [P, I, I]
     l.coati_engine_decode_workspace_bytes.restype = c_int64
+    l.coati_tokenizer_create.argtypes = [P, P, I, P, P, I, P]
+    l.coati_tokenizer_create.restype = c_int
+    l.coati_tokenizer_destroy.argtypes = [P]
+    l.coati_tokenizer_destroy.restype = None
+    l.coati_tokenizer_encode.argtypes = [P, c_char_p, c_int64, P, I]
+    l.coati_tokenizer_encode.restype = c_int64
+    l.coati_tokenizer_pieces.argtypes = [P, c_char_p, c_int64, P, P, P, I]
+    l.coati_tokenizer_pieces.restype = c_int64
+    l.coati_tokenizer_encode_batch.argtypes = [P, P, I, I, P, P, I]
+    l.coati_tokenizer_encode_batch.restype = c_int
     l.coati_engine_n_entries.argtypes = [P]
     l.coati_engine_n_entries.restype = c_int
     l.coati_engine_site_count.restype = c_int
@@ -112,6 +122,8 @@ def exported_symbols():
     return sorted(list(_SIGS) + ["coati_last_error", "coati_abi_version", "coati_engine_destroy",
                                  "coati_engine_param_elems", "coati_engine_shadow_elems",
                                  "coati_engine_workspace_bytes", "coati_engine_decode_workspace_bytes", "coati_engine_n_entries",
+                                 "coati_tokenizer_create", "coati_tokenizer_destroy", "coati_tokenizer_encode",
+                                 "coati_tokenizer_pieces", "coati_tokenizer_encode_batch",
                                  "coati_engine_site_count", "coati_engine_site_name"])
 
 

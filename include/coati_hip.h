@@ -252,6 +252,22 @@ int coati_engine_decode_step(coati_engine* e, const int64_t* tokens, const float
 int coati_engine_decode_pos(coati_engine* e);
 const char* coati_engine_site_name(int site);
 
+/* ---- host-side trie tokenizer (reference tokenizers/trie.py:39-214, trie_tokenizer.py:48-109) ---------
+   special[i] has id special_ids[i] (null: i), smiles[j] has id smiles_ids[j] (null: n_special + j).
+   Leftmost-longest matching, special tokens first. */
+typedef struct coati_tokenizer coati_tokenizer;
+int coati_tokenizer_create(const char* const* special, const int32_t* special_ids, int n_special, const char* const* smiles,
+                           const int32_t* smiles_ids, int n_smiles, coati_tokenizer** out);
+void coati_tokenizer_destroy(coati_tokenizer* tk);
+/* token count (may exceed cap; nothing past cap is written) or -(1 + byte offset) of the first piece with no id */
+long long coati_tokenizer_encode(const coati_tokenizer* tk, const char* text, long long n_bytes, int32_t* ids_out, int cap);
+/* pre_tokenize: byte ranges [begin, end) and ids (-1 = not in the vocabulary) of the pieces; returns their number */
+long long coati_tokenizer_pieces(const coati_tokenizer* tk, const char* text, long long n_bytes, int64_t* begin, int64_t* end,
+                                 int32_t* id, int cap);
+/* rows -> out[n_rows, n_seq] int64 zero-padded, len[i] = tokens / -1 unknown piece / -2 longer than n_seq; threaded */
+int coati_tokenizer_encode_batch(const coati_tokenizer* tk, const char* const* rows, int n_rows, int n_seq, int64_t* out,
+                                 int32_t* len, int n_threads);
+
 #ifdef __cplusplus
 }
 #endif

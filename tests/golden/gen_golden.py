@@ -295,6 +295,49 @@ def main():
             sbv[f"row{i}_atoms"] = r["atoms"]
             sbv[f"row{i}_coords"] = r["coords"]
     np.savez_compressed(os.path.join(OUT, "stack_batch.npz"), **sbv)
+    # ---- n4: Trie / TrieTokenizer (tokenizers/trie.py, trie_tokenizer.py) on a synthetic SMILES-like vocabulary and on
+    # random small vocabularies (overlapping words, out-of-vocabulary characters, multi-byte characters) -------------
+    from coati.models.encoding.tokenizers.trie import Trie as RefTrie
+    from coati.models.encoding.tokenizers.trie_tokenizer import TrieTokenizer as RefTok
+    import io
+    import contextlib
+    rnd = random.Random(42)
+    spec = ["[PAD]", "[STOP]", "[SMILES]", "[GRAPH]", "[FORMULA]", "[SUFFIX]", "[MIDDLE]", "[UNK]", "[CLIP]", "[SET]",
+            "[ELM5]", "[ELM", "[E"]
+    smi_vocab = ["C", "c", "N", "n", "O", "o", "(", ")", "=", "#", "1", "2", "Cl", "Br", "c1ccccc1", "C(=O)", "CC", "[nH]",
+                 "[C@@H]", "[C@H]", "N(C)", "c1", "cc", "[NH3+]", "S", "F", "OC", "C(=O)O", "%10", "\u00e9"]
+    rt = RefTok(n_seq=32, smiles_tokens=smi_vocab, special_tokens=spec)
+    texts = ["[SMILES]c1ccccc1[STOP]", "[SMILES]CC(=O)OC[STOP]", "[CLIP][UNK][SMILES]C[C@@H](N)C(=O)O[STOP]",
+             "[SMILES]BrCCl[SUFFIX]N(C)[MIDDLE]c1cc[nH]c1[STOP]", "[SMILES]C\u00e9C[STOP]", "[SMILES]CxC[STOP]", "", "[ELM5][ELM[E[",
+             "[SMILES]" + "C" * 40 + "[STOP]", "[SMILES]C%10C[NH3+][STOP]"]
+    for _ in range(40):
+        texts.append("".join(rnd.choice(spec + smi_vocab + ["x", "[", "]"]) for _ in range(rnd.randint(0, 9))))
+    tcases = []
+    for t in texts:
+        with contextlib.redirect_stdout(io.StringIO()):
+            try:
+                r = ["ok", rt.tokenize_text(t, pad=True)]
+            except KeyError as e:
+                r = ["KeyError", str(e)]
+            except Exception as e:
+                r = ["Exception", str(e.args)]
+        tcases.append(dict(text=t, pieces=rt.pre_tokenize(t), result=r))
+    bs, bad = rt.batch_smiles(["c1ccccc1", "CxC", "CC(=O)O", "C" * 40, "N(C)C"], skip_failed=True)
+    okc = [c for c in tcases if c["result"][0] == "ok" and c["text"]][:6]
+    dec = [rt.decode(c["result"][1], special=sp) for c in okc for sp in (True, False)]
+    scases = []
+    for trial in range(120):
+        alpha = rnd.choice(["ab", "abc", "CNO()=c1", "ab\u00e9\u53cb", "[]EL"])
+        words = sorted({"".join(rnd.choice(alpha) for _ in range(rnd.randint(1, 5))) for _ in range(rnd.randint(1, 10))})
+        tr = RefTrie()
+        for w in words:
+            tr.add(w)
+        for _ in range(4):
+            t = "".join(rnd.choice(alpha + "xyz") for _ in range(rnd.randint(0, 14)))
+            scases.append(dict(words=words, text=t, split=tr.split(t)))
+    with open(os.path.join(OUT, "tokenizer.json"), "w") as f:
+        json.dump(dict(special=spec, smiles=smi_vocab, n_seq=32, cases=tcases, batch_tokens=bs.tolist(), batch_bad=bad,
+                       decoded=dec, trie_cases=scases), f)
     # ---- G14 AllGatherFunction forward/backward under a 2-rank gloo group (autograd_funs.py:5-25) ----
     import torch.multiprocessing as mp
     mp.spawn(_allgather_worker, args=(2,), nprocs=2)
