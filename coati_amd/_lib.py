@@ -83,6 +83,9 @@ def lib():
         _build.build()
     if not os.path.exists(path):
         raise RuntimeError(f"coati_amd: {path} is missing and could not be built; there is no CPU fallback")
+    # torch first: its wheel carries its own ROCm runtime; loading this library before torch would bind it to the system
+    # libamdhip64 and leave the process with two HIP runtimes (one of which then reports "no ROCm-capable device")
+    import torch  # noqa: F401
     l = ctypes.CDLL(path)
     l.coati_last_error.restype = c_char_p
     l.coati_abi_version.restype = c_int
