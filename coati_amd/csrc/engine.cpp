@@ -140,6 +140,7 @@ struct coati_engine {
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool overlap = true;
+  bool gnn_bwd_done = false;   // staged backward: stage 2 already ran the point-encoder backward on the side stream
   // profiling
   int prof_site = -1;
   std::vector<hipEvent_t> ev;
@@ -875,7 +876,10 @@ int coati_engine_backward(coati_engine* e, const float* dh_smiles, const float* 
     COATI_TRY(head_linear_bwd(e, e->dhe, e->hp_ln, e->p2c_w, e->p2c_b, e->dhp_ln, B, E, H, s));
     COATI_TRY(launch_layernorm_bwd(e->dhp_ln, 1, H, e->hpoint, H, 0, e->hp_mean, e->hp_rstd, e->P + e->p2c_lnw, nullptr, e->dhpoint, nullptr, e->G + e->p2c_lnw, e->G + e->p2c_lnb, e->ln_partial, B, H, s));
   }
-  const bool ovl_bwd = (stage == 0) && e->overlap && e->prof_site < 0;
+  // whole backward (stage 0) or the encoder stage of the staged (multi-GPU) backward: the point-encoder backward runs on
+  // the side stream underneath the encoder pass; stage 3 then has nothing left to do
+  const bool ovl_bwd = (stage == 0 || stage == 2) && e->overlap && e->prof_site < 0;
+  if (stage == 0 || stage == 1) e->gnn_bwd_done = false;
   if (ovl_bwd) {
     // the point-encoder backward only needs dhpoint (ready here) and writes its own gradient slice: side stream
     COATI_TRY(fork_side(e, s));
@@ -891,8 +895,10 @@ int coati_engine_backward(coati_engine* e, const float* dh_smiles, const float* 
   }
   if (ovl_bwd) {
     COATI_TRY(join_side(e, s));
-  } else if (stage == 0 || stage == 3) {
+    e->gnn_bwd_done = true;
+  } else if ((stage == 0 || stage == 3) && !e->gnn_bwd_done) {
     COATI_TRY(gnn_bwd(e, e->dhpoint, s));
+    e->gnn_bwd_done = true;
   }
   return COATI_OK;
 }
