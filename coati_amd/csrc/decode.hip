@@ -96,61 +96,114 @@ int launch_attn_decode(const bf16_t* qkv, bf16_t* cache, bf16_t* y, int B, int n
 
 // ---- top-k sampling (smiles_xformer.py:305-313) -----------------------------------------------------------------------
 //   logits_topk, inds = topk(logits[b], k);  probs = softmax(logits_topk * inv_temp);  token = inds[multinomial(probs)]
-// One workgroup per row; the row lives in LDS; k rounds of a block-wide arg-max (ties -> the lower index, like a stable
-// descending sort), then an inverse-CDF draw with the caller's uniform u[b] in [0, 1).  stopped rows emit pad_token;
-// a row that draws stop_token is marked stopped (reference :314-324).
+// One workgroup per row, the row's order-preserving integer keys in LDS.  The k-th largest key is found with a 4-pass
+// radix select (8 bits per pass, one histogram bin per thread), the <= TOPK_MAX survivors are compacted (ties at the
+// threshold in index order), sorted (value descending, index ascending -- the order of a stable descending sort) and
+// sampled by inverse CDF with the caller's uniform u[b] in [0, 1).  stopped rows emit pad_token; a row that draws
+// stop_token is marked stopped (reference :314-324).  Integer/compare work on a 40-KB row: ~10 us per row-block.
 #define TOPK_MAX 128
+__device__ __forceinline__ unsigned f2key(float f) {   // larger float <-> larger unsigned (NaN sorts high, like torch)
+  const unsigned u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key2f(unsigned k) {
+  return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+
 __global__ __launch_bounds__(256) void topk_sample_kernel(const float* __restrict__ logits, long long ldl, int V, int k,
                                                           float inv_temp, const float* __restrict__ u,
                                                           long long* __restrict__ tok_out, int* __restrict__ stopped,
                                                           int stop_token, int pad_token) {
-  extern __shared__ float row[];   // [V]
-  __shared__ float wv[4];
-  __shared__ int wi[4];
-  __shared__ float top_v[TOPK_MAX];
+  extern __shared__ unsigned keys[];   // [V]
+  __shared__ int hist[256];
+  __shared__ unsigned s_prefix;
+  __shared__ int s_need, s_ngt, s_neq;
+  __shared__ unsigned top_k[TOPK_MAX];
   __shared__ int top_i[TOPK_MAX];
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.x, tid = threadIdx.x;
   if (stopped && stopped[b]) {
     if (tid == 0) tok_out[b] = pad_token;
     return;
   }
-  for (int i = tid; i < V; i += 256) row[i] = logits[(long long)b * ldl + i];
+  for (int i = tid; i < V; i += 256) keys[i] = f2key(logits[(long long)b * ldl + i]);
+  if (tid == 0) { s_prefix = 0u; s_need = k; }
   __syncthreads();
-  for (int r = 0; r < k; ++r) {
-    float bv = -INFINITY;
-    int bi = 0x7fffffff;
+  // radix select of the k-th largest key: after pass p the top 8*(p+1) bits of the threshold are known
+  for (int pass = 0; pass < 4; ++pass) {
+    const int shift = 24 - 8 * pass;
+    const unsigned mask = pass == 0 ? 0u : (0xffffffffu << (shift + 8));
+    hist[tid] = 0;
+    __syncthreads();
+    const unsigned prefix = s_prefix;
     for (int i = tid; i < V; i += 256) {
-      const float v = row[i];
-      if (v > bv || (v == bv && i < bi)) { bv = v; bi = i; }
+      const unsigned key = keys[i];
+      if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255], 1);
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const float ov = __shfl_xor(bv, o, 64);
-      const int oi = __shfl_xor(bi, o, 64);
-      if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-    }
-    if (lane == 0) { wv[wave] = bv; wi[wave] = bi; }
     __syncthreads();
     if (tid == 0) {
-      float v = wv[0];
-      int i = wi[0];
-      for (int w = 1; w < 4; ++w)
-        if (wv[w] > v || (wv[w] == v && wi[w] < i)) { v = wv[w]; i = wi[w]; }
-      top_v[r] = v;
-      top_i[r] = i;
-      if (i >= 0 && i < V) row[i] = -INFINITY;
+      int need = s_need, bin = 255;
+      for (; bin > 0; --bin) {
+        if (hist[bin] >= need) break;
+        need -= hist[bin];
+      }
+      s_need = need;                              // rank of the threshold inside its bin
+      s_prefix = prefix | ((unsigned)bin << shift);
     }
     __syncthreads();
   }
+  const unsigned tau = s_prefix;                  // the k-th largest key; s_need = how many keys == tau belong to the top k
+  if (tid == 0) { s_ngt = 0; s_neq = 0; }
+  __syncthreads();
+  // survivors: every key > tau (any order), then the first s_need keys == tau in index order
+  for (int i = tid; i < V; i += 256) {
+    if (keys[i] > tau) {
+      const int slot = atomicAdd(&s_ngt, 1);
+      top_k[slot] = keys[i];
+      top_i[slot] = i;
+    }
+  }
+  __syncthreads();
+  {
+    // the first s_need keys == tau in INDEX order: threads own contiguous index segments, exclusive scan of their counts
+    const int seg = (V + 255) / 256, i0 = tid * seg, i1 = (i0 + seg < V) ? i0 + seg : V;
+    int cnt = 0;
+    for (int i = i0; i < i1; ++i) cnt += (keys[i] == tau) ? 1 : 0;
+    hist[tid] = cnt;
+    __syncthreads();
+    int before = 0;
+    for (int t = 0; t < tid; ++t) before += hist[t];
+    const int base = s_ngt, need = s_need;
+    if (cnt > 0 && before < need) {
+      int pos = before;
+      for (int i = i0; i < i1 && pos < need; ++i)
+        if (keys[i] == tau) { top_k[base + pos] = tau; top_i[base + pos] = i; ++pos; }
+    }
+  }
+  __syncthreads();
+  // sort the k survivors: key descending, index ascending (rank by counting; k <= 128)
+  unsigned myk = 0;
+  int myi = 0, rank = 0;
+  if (tid < k) {
+    myk = top_k[tid];
+    myi = top_i[tid];
+    for (int j = 0; j < k; ++j) {
+      const unsigned kj = top_k[j];
+      const int ij = top_i[j];
+      rank += (kj > myk || (kj == myk && ij < myi)) ? 1 : 0;
+    }
+  }
+  __syncthreads();
+  if (tid < k) { top_k[rank] = myk; top_i[rank] = myi; }
+  __syncthreads();
   if (tid == 0) {
-    const float mx = top_v[0] * inv_temp;
+    const float mx = key2f(top_k[0]) * inv_temp;
     float z = 0.f;
-    for (int r = 0; r < k; ++r) z += __expf(top_v[r] * inv_temp - mx);
+    for (int r = 0; r < k; ++r) z += __expf(key2f(top_k[r]) * inv_temp - mx);
     const float target = (u ? u[b] : 0.f) * z;
     float c = 0.f;
     int pick = k - 1;
     for (int r = 0; r < k; ++r) {
-      c += __expf(top_v[r] * inv_temp - mx);
+      c += __expf(key2f(top_k[r]) * inv_temp - mx);
       if (target < c) { pick = r; break; }
     }
     const int tok = top_i[pick];
