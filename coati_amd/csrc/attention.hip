@@ -14,7 +14,8 @@
 //     fragment comes straight out of the row-major image with two ds_read_b64_tr_b16 (the gfx950 LDS
 //     transpose read: a 16-lane group fetches a 4-row x 16-col block, lane i receives column i);
 //   * the [T,T] score matrix is never materialised; the backward recomputes P from the saved log-sum-exp
-//     in two kernels (dQ; dK+dV) -- no atomics, deterministic, ~90 / ~130 registers each.
+//     in two kernels (dQ; dK+dV) -- no atomics, deterministic;
+//   * results leave a workgroup as whole 128-B row segments through a shared LDS tile (tile_put / tile_store).
 // Layout: qkv [B*T, 3C] bf16 (q | k | v, head h at columns h*16..h*16+15), y / dy [B*T, C], lse, D [B, nh, T].
 #include "kernels.h"
 
@@ -24,24 +25,6 @@
 #define LOG2E 1.4426950408889634f
 typedef short v4s16a __attribute__((ext_vector_type(4)));
 typedef short v8s16a __attribute__((ext_vector_type(8)));
-
-__device__ __forceinline__ void load16(const bf16_t* p, float* x) {
-  const uint4 a = *reinterpret_cast<const uint4*>(p), b = *reinterpret_cast<const uint4*>(p + 8);
-  unpack8(a, x);
-  unpack8(b, x + 8);
-}
-__device__ __forceinline__ void rope16(float* x, const float* cs, const float* sn) {
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const float a = x[i], b = x[i + 8];
-    x[i] = a * cs[i] - b * sn[i];
-    x[i + 8] = b * cs[i] + a * sn[i];
-  }
-}
-__device__ __forceinline__ void load_cs(const float* tab, int t, float* c) {
-  const float4 a = *reinterpret_cast<const float4*>(tab + t * HS), b = *reinterpret_cast<const float4*>(tab + t * HS + 4);
-  c[0] = a.x; c[1] = a.y; c[2] = a.z; c[3] = a.w; c[4] = b.x; c[5] = b.y; c[6] = b.z; c[7] = b.w;
-}
 
 // Cooperative staging of one operand for the 4 heads of a workgroup: rows t < T, 128 contiguous bytes per row
 // (4 heads x 16 dims bf16); 8 consecutive threads fetch one row -> fully coalesced 16-B loads.  Chunk c of a row lands in

@@ -4,8 +4,10 @@
 //   wgrad_tn  dW[N,K] += A[M,N]^T * B[M,K] (+ column sums of A)       (all weight/bias gradients)
 //   sgemm     exact-f32 MFMA (v_mfma_f32_32x32x2_f32), generic strides (contrastive head, [B,256] maths)
 //
-// Tiling: 128x128 output tile per 256-thread workgroup (4 waves as 2x2, each 64x64 = 2x2 MFMA tiles),
-// BK = 64, register-staged global->LDS double buffer (one barrier per k-tile).  LDS rows are padded to
+//   (every GEMM with K = 256 runs on the row-block kernel of gemm_rb.hip instead: launch_gemm_nt dispatches)
+//
+// Tiling: 128x128 output tile per workgroup (8 waves, each 32x64 = 1x2 MFMA tiles; 4 waves x 64x64 for f32 A),
+// BK = 64, two LDS buffers + two register stage sets (one barrier per k-tile).  LDS rows are padded to
 // 72 halfs (144 B): 16 consecutive rows then hit 16 distinct 16-B slots of the 256-B bank row, so the
 // ds_read_b128 fragment reads are conflict-free without an XOR swizzle.  The accumulator tile is
 // transposed through LDS so the epilogue works on 8 consecutive columns per lane (16-B stores).
