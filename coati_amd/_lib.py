@@ -38,6 +38,10 @@ _SIGS = {
     "coati_bad_rows": [P, P, I, I, P],
     "coati_silu": [P, P, L, P],
     "coati_attn_decode": [P, P, P, I, I, I, I, P],
+    "coati_attn_decode_hs": [P, P, P, I, I, I, I, I, P],
+    "coati_attn_fwd_hs": [P, P, P, I, I, I, I, P],
+    "coati_attn_bwd_hs": [P, P, P, P, P, P, P, P, I, I, I, I, P],
+    "coati_gemm_qkv_rope_hs": [P, L, P, L, P, I, I, P, L, P, P, I, I, P],
     "coati_topk_sample": [P, L, I, I, I, F, P, P, P, I, I, P],
     "coati_engine_decode_begin": [P, P, L, I, I],
     "coati_engine_decode_step": [P, P, P, P, L, P],

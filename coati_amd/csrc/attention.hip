@@ -1,5 +1,6 @@
-// Causal rotary self-attention for head size 16 (reference basic_transformer.py:83-100, 126-154),
-// forward and backward.  One 64-lane wave per (batch row, head); a workgroup = 4 waves = 4 adjacent heads of
+// Causal rotary self-attention for head size 16 (grande / "closed": d=256, 16 heads) and 32 (the COATI2-size
+// transformer: d=512, 16 heads) -- reference basic_transformer.py:83-100, 126-154 -- forward and backward; every
+// function is a template on HS.  One 64-lane wave per (batch row, head); a workgroup = 4 waves = 4 adjacent heads of
 // one batch row, so the workgroup consumes whole 128-B lines of the [B*T, 3C] qkv matrix.
 //
 // Head size 16 = exactly one K step of v_mfma_f32_32x32x16_bf16, so the kernels are softmax / LDS / latency
@@ -16,49 +17,55 @@
 //   * the [T,T] score matrix is never materialised; the backward recomputes P from the saved log-sum-exp
 //     in two kernels (dQ; dK+dV) -- no atomics, deterministic;
 //   * results leave a workgroup as whole 128-B row segments through a shared LDS tile (tile_put / tile_store).
-// Layout: qkv [B*T, 3C] bf16 (q | k | v, head h at columns h*16..h*16+15), y / dy [B*T, C], lse, D [B, nh, T].
+// Layout: qkv [B*T, 3C] bf16 (q | k | v, head h at columns h*HS..h*HS+HS-1), y / dy [B*T, C], lse, D [B, nh, T].
 #include "kernels.h"
 
-#define HS 16
-#define SCALE 0.25f   // 1/sqrt(16)
-#define SCALE_LOG2E 0.36067376022224085f   // SCALE * log2(e): softmax exponentials go straight to v_exp_f32 (2^x)
 #define LOG2E 1.4426950408889634f
+// 1/sqrt(HS) and its product with log2(e): softmax exponentials go straight to v_exp_f32 (2^x)
+template <int HS> __device__ __forceinline__ constexpr float att_scale() { return HS == 16 ? 0.25f : 0.17677669529663687f; }
+template <int HS> __device__ __forceinline__ constexpr float att_scale_log2e() { return HS == 16 ? 0.36067376022224085f : 0.25503486588225905f; }
 typedef short v4s16a __attribute__((ext_vector_type(4)));
 typedef short v8s16a __attribute__((ext_vector_type(8)));
 
-// Cooperative staging of one operand for the 4 heads of a workgroup: rows t < T, 128 contiguous bytes per row
-// (4 heads x 16 dims bf16); 8 consecutive threads fetch one row -> fully coalesced 16-B loads.  Chunk c of a row lands in
-// head (c >> 1)'s row-major image at dims (c & 1) * 8.  Rows [T, Tp) are zero-filled.  q and k arrive already rotated
+// Cooperative staging of one operand for the 4 heads of a workgroup: rows t < T, 4 * HS contiguous bf16 per row (128 /
+// 256 B); HS/2 consecutive threads fetch one row -> fully coalesced 16-B loads.  Chunk c of a row lands in head
+// c / (HS/8)'s row-major image at dims (c % (HS/8)) * 8.  Rows [T, Tp) are zero-filled.  q and k arrive already rotated
 // (the QKV GEMM applies RoPE in its epilogue).
+template <int HS>
 __device__ __forceinline__ void stage4(const bf16_t* src, long long stride, int T, int Tp, unsigned char* smem,
                                        size_t per_wave_bytes, int image, int heads_here, int tid) {
-  for (int task = tid; task < Tp * 8; task += 256) {
-    const int t = task >> 3, c = task & 7, w = c >> 1;
+  constexpr int CPR = HS / 2, CPH = HS / 8;   // 16-B chunks per row / per head
+  for (int task = tid; task < Tp * CPR; task += 256) {
+    const int t = task / CPR, c = task - t * CPR, w = c / CPH;
     uint4 v = make_uint4(0, 0, 0, 0);
     if (t < T && w < heads_here) v = *reinterpret_cast<const uint4*>(src + (long long)t * stride + c * 8);
     bf16_t* img = reinterpret_cast<bf16_t*>(smem + (size_t)w * per_wave_bytes) + (size_t)image * Tp * HS;
-    *reinterpret_cast<uint4*>(img + t * HS + (c & 1) * 8) = v;
+    *reinterpret_cast<uint4*>(img + t * HS + (c - w * CPH) * 8) = v;
   }
 }
 
-// A/B fragment of a row-major [*,16] image: lane (r = lane&31, half = lane>>5) -> row blk*32+r, dims half*8..+7
-__device__ __forceinline__ bf16x8 rfrag(const bf16_t* rm, int blk, int lane) {
-  return *reinterpret_cast<const bf16x8*>(rm + (blk * 32 + (lane & 31)) * HS + (lane >> 5) * 8);
+// A/B fragment of a row-major [*,HS] image for reduction step ks (16 dims each):
+// lane (r = lane&31, half = lane>>5) -> row blk*32+r, dims ks*16 + half*8..+7
+template <int HS>
+__device__ __forceinline__ bf16x8 rfrag(const bf16_t* rm, int blk, int ks, int lane) {
+  return *reinterpret_cast<const bf16x8*>(rm + (blk * 32 + (lane & 31)) * HS + ks * 16 + (lane >> 5) * 8);
 }
 // The same fragment straight from global memory (rows >= T read as zero): for the operand that is needed for ONE
 // 32-row block only, so it never occupies LDS.
-__device__ __forceinline__ bf16x8 gfrag(const bf16_t* src, long long stride, int blk, int T, int lane) {
+__device__ __forceinline__ bf16x8 gfrag(const bf16_t* src, long long stride, int blk, int ks, int T, int lane) {
   const int row = blk * 32 + (lane & 31);
   const int rc = row < T ? row : T - 1;
-  uint4 u = *reinterpret_cast<const uint4*>(src + (long long)rc * stride + (lane >> 5) * 8);
+  uint4 u = *reinterpret_cast<const uint4*>(src + (long long)rc * stride + ks * 16 + (lane >> 5) * 8);
   if (row >= T) u = make_uint4(0, 0, 0, 0);
   return __builtin_bit_cast(bf16x8, u);
 }
 // A fragment X^T[d][row] with the accumulator's row permutation, read from the row-major image with the LDS
-// transpose read: lane (d = lane&31, h = lane>>5), slot j <-> row base + 4h + (j&3) + 8*(j>>2); d >= 16 -> zero.
+// transpose read: lane (d = lane&31, h = lane>>5), slot j <-> row base + 4h + (j&3) + 8*(j>>2).  HS = 16: lanes with
+// d >= 16 feed don't-care rows; HS = 32: the second 16-lane group of each half reads dims 16..31.
+template <int HS>
 __device__ __forceinline__ bf16x8 tfrag(const bf16_t* rm, int base, int lane) {
   typedef __attribute__((address_space(3))) v4s16a lds_v4;
-  const bf16_t* p = rm + (base + 4 * (lane >> 5) + ((lane & 15) >> 2)) * HS + 4 * (lane & 3);
+  const bf16_t* p = rm + (base + 4 * (lane >> 5) + ((lane & 15) >> 2)) * HS + 4 * (lane & 3) + (HS == 32 ? 16 * ((lane >> 4) & 1) : 0);
   const v4s16a lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)p);
   const v4s16a hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(p + 8 * HS));
   // lanes with d >= 16 feed don't-care rows of the A operand: MFMA output rows are independent and rows 16..31 of the
@@ -83,45 +90,69 @@ __device__ __forceinline__ int arow(int r, int lane) { return (r & 3) + 8 * (r >
 // rows per instruction (address-coalescer / partial-line bound: it cost ~40 of the 78 us of the dK/dV kernel).  Each
 // wave instead drops its head's 32 x 16 block into a workgroup-shared LDS tile [32 rows][4 heads x 16 dims] (row pitch
 // 144 B), and after a barrier the 256 threads store the tile as 16-B chunks, 8 lanes per 128-B row.
-#define OT_PITCH 144                       // bytes per row of the output tile
-#define OT_BYTES (32 * OT_PITCH)
-__device__ __forceinline__ void tile_put(unsigned char* tile, int wave, int lane, const float (&a)[4], const float (&c)[4]) {
-  unsigned char* row = tile + (lane & 31) * OT_PITCH + wave * 32 + (lane >> 5) * 8;   // dims 4*half.. and 8+4*half..
-  *reinterpret_cast<uint2*>(row) = make_uint2(pack2bf(a[0], a[1]), pack2bf(a[2], a[3]));
-  *reinterpret_cast<uint2*>(row + 16) = make_uint2(pack2bf(c[0], c[1]), pack2bf(c[2], c[3]));
+template <int HS> __host__ __device__ __forceinline__ constexpr int ot_pitch() { return 4 * HS * 2 + 16; }   // bytes per tile row (144 / 272)
+template <int HS> __host__ __device__ __forceinline__ constexpr int ot_bytes() { return 32 * ot_pitch<HS>(); }
+// v[0 .. HS/2): the lane's live accumulator registers of one row; register group g (4 regs) = dims 8g + 4*half .. +3
+template <int HS>
+__device__ __forceinline__ void tile_put(unsigned char* tile, int wave, int lane, const float* v) {
+  unsigned char* row = tile + (lane & 31) * ot_pitch<HS>() + wave * HS * 2 + (lane >> 5) * 8;
+#pragma unroll
+  for (int g = 0; g < HS / 8; ++g)
+    *reinterpret_cast<uint2*>(row + 16 * g) = make_uint2(pack2bf(v[4 * g], v[4 * g + 1]), pack2bf(v[4 * g + 2], v[4 * g + 3]));
 }
-// gradient block (lane = token row, regs 0..3 / 4..7 = dims 4*half+j / 8+4*half+j) -> tile, with the inverse rotation
+// gradient block (lane = token row, register group g = dims 8g + 4*half + j) -> tile, with the inverse rotation of the
+// RoPE pairs (d, d + HS/2) = register groups (g, g + HS/16)
+template <int HS>
 __device__ __forceinline__ void tile_put_grad(unsigned char* tile, int wave, int lane, const f32x16& g, bool rope_inv,
                                               const float* cos_t, const float* sin_t, int t) {
   const int half = lane >> 5;
-  float a[4], c[4];
+  float v[HS / 2];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) { a[j] = g[j]; c[j] = g[4 + j]; }
+  for (int j = 0; j < HS / 2; ++j) v[j] = g[j];
   if (rope_inv) {
-    const float4 cs = *reinterpret_cast<const float4*>(cos_t + t * HS + 4 * half);
-    const float4 sn = *reinterpret_cast<const float4*>(sin_t + t * HS + 4 * half);
-    const float csv[4] = {cs.x, cs.y, cs.z, cs.w}, snv[4] = {sn.x, sn.y, sn.z, sn.w};
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float ga = a[j], gc = c[j];
-      a[j] = ga * csv[j] + gc * snv[j];
-      c[j] = gc * csv[j] - ga * snv[j];
+    for (int gq = 0; gq < HS / 16; ++gq) {   // pair (group gq, group gq + HS/16): dims 8gq + 4half + j and + HS/2
+      const float4 cs = *reinterpret_cast<const float4*>(cos_t + t * HS + 8 * gq + 4 * half);
+      const float4 sn = *reinterpret_cast<const float4*>(sin_t + t * HS + 8 * gq + 4 * half);
+      const float csv[4] = {cs.x, cs.y, cs.z, cs.w}, snv[4] = {sn.x, sn.y, sn.z, sn.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float ga = v[4 * gq + j], gc = v[4 * (gq + HS / 16) + j];
+        v[4 * gq + j] = ga * csv[j] + gc * snv[j];
+        v[4 * (gq + HS / 16) + j] = gc * csv[j] - ga * snv[j];
+      }
     }
   }
-  tile_put(tile, wave, lane, a, c);
+  tile_put<HS>(tile, wave, lane, v);
 }
-// cooperative store of one tile: thread -> (row = tid >> 3, 16-B chunk = tid & 7); dst points at (row 0, first head)
+// cooperative store of one tile: task -> (row, 16-B chunk); dst points at (row 0, first head of the quad)
+template <int HS>
 __device__ __forceinline__ void tile_store(const unsigned char* tile, bf16_t* dst, long long stride, int row0, int T,
                                            int heads_here, int tid) {
-  const int row = tid >> 3, ch = tid & 7;
-  if (row0 + row < T && (ch >> 1) < heads_here)
-    *reinterpret_cast<uint4*>(dst + (long long)(row0 + row) * stride + ch * 8) =
-        *reinterpret_cast<const uint4*>(tile + row * OT_PITCH + ch * 16);
+  constexpr int CPR = HS / 2, CPH = HS / 8;
+#pragma unroll
+  for (int task = tid; task < 32 * CPR; task += 256) {
+    const int row = task / CPR, ch = task - row * CPR;
+    if (row0 + row < T && ch / CPH < heads_here)
+      *reinterpret_cast<uint4*>(dst + (long long)(row0 + row) * stride + ch * 8) =
+          *reinterpret_cast<const uint4*>(tile + row * ot_pitch<HS>() + ch * 16);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------
+// S^T block (keys x queries) = sum over the HS/16 reduction steps
+template <int HS>
+__device__ __forceinline__ f32x16 score_block(const bf16_t* Xs, int blk, const bf16x8 (&f)[HS / 16], int lane) {
+  f32x16 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rfrag<HS>(Xs, blk, 0, lane), f[0], zero16(), 0, 0, 0);
+  if constexpr (HS == 32) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rfrag<HS>(Xs, blk, 1, lane), f[1], s, 0, 0, 0);
+  return s;
+}
+
+template <int HS>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ y,
                                                        float* __restrict__ lse, int T, int n_head, int quads) {
+  constexpr int NK = HS / 16, LIVE = HS / 2;
+  constexpr float SCALE = att_scale<HS>(), SCALE_LOG2E = att_scale_log2e<HS>();
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int b = blockIdx.x / quads, hq = blockIdx.x - b * quads;
@@ -133,8 +164,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
   bf16_t* Vs = Ks + Tp * HS;
   const long long stride = 3LL * C;
   const bf16_t* base = qkv + (long long)b * T * stride + hq * 4 * HS;
-  stage4(base + C, stride, T, Tp, smem, pw, 0, heads_here, threadIdx.x);
-  stage4(base + 2 * C, stride, T, Tp, smem, pw, 1, heads_here, threadIdx.x);
+  stage4<HS>(base + C, stride, T, Tp, smem, pw, 0, heads_here, threadIdx.x);
+  stage4<HS>(base + 2 * C, stride, T, Tp, smem, pw, 1, heads_here, threadIdx.x);
   __syncthreads();
   const bool active = hh < n_head;   // inactive waves of a partial quad only take part in the barriers
   unsigned char* const otile = smem + 4 * pw;
@@ -145,11 +176,13 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
   for (int qb = 0; qb < nblk; ++qb) {
     const int q = qb * 32 + (lane & 31);
     if (active) {
-      const bf16x8 qf = gfrag(qsrc, stride, qb, T, lane);
+      bf16x8 qf[NK];
+#pragma unroll
+      for (int ks = 0; ks < NK; ++ks) qf[ks] = gfrag(qsrc, stride, qb, ks, T, lane);
       float m_run = -INFINITY, l_run = 0.f;
       f32x16 o = zero16();
       for (int kb = 0; kb <= qb; ++kb) {
-        f32x16 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rfrag(Ks, kb, lane), qf, zero16(), 0, 0, 0);
+        f32x16 s = score_block<HS>(Ks, kb, qf, lane);
         // running max / sum are kept on the RAW scores (the scale is positive); exp(x*scale) = 2^(x*scale*log2e)
         float p[16];
         float mloc = -INFINITY;
@@ -181,30 +214,31 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
         l_run = l_run * alpha + lsum;
         m_run = m_new;
 #pragma unroll
-        for (int r = 0; r < 8; ++r) o[r] *= alpha;   // only d < 16 (regs 0..7) is live
-        o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tfrag(Vs, kb * 32, lane), pfrag(p), o, 0, 0, 0);
-        o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tfrag(Vs, kb * 32 + 16, lane), pfrag(p + 8), o, 0, 0, 0);
+        for (int r = 0; r < LIVE; ++r) o[r] *= alpha;   // only d < HS is live (regs 0..HS/2-1)
+        o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tfrag<HS>(Vs, kb * 32, lane), pfrag(p), o, 0, 0, 0);
+        o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tfrag<HS>(Vs, kb * 32 + 16, lane), pfrag(p + 8), o, 0, 0, 0);
       }
       const float inv = 1.0f / l_run;
-      const float a[4] = {o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv}, c[4] = {o[4] * inv, o[5] * inv, o[6] * inv, o[7] * inv};
-      tile_put(otile, wave, lane, a, c);
+      float v[LIVE];
+#pragma unroll
+      for (int r = 0; r < LIVE; ++r) v[r] = o[r] * inv;
+      tile_put<HS>(otile, wave, lane, v);
       if (q < T && half == 0) lse[((long long)b * n_head + hh) * T + q] = m_run * SCALE + __logf(l_run);
     }
     __syncthreads();
-    tile_store(otile, ydst, C, qb * 32, T, heads_here, threadIdx.x);
+    tile_store<HS>(otile, ydst, C, qb * 32, T, heads_here, threadIdx.x);
     __syncthreads();
   }
 }
 
-int launch_attn_fwd(const bf16_t* qkv, bf16_t* y, float* lse, int B, int T, int n_head, hipStream_t s) {
-  COATI_CHECK_ARG(qkv && y && lse, "attn_fwd: null operand");
-  COATI_CHECK_SHAPE(B > 0 && T > 0 && T <= 256 && n_head > 0, "attn_fwd: unsupported shape B=%d T=%d nh=%d", B, T, n_head);
+template <int HS>
+static int launch_attn_fwd_t(const bf16_t* qkv, bf16_t* y, float* lse, int B, int T, int n_head, hipStream_t s) {
   const int Tp = (T + 31) & ~31;
-  const size_t lds = (size_t)4 * 2 * Tp * HS * 2 + OT_BYTES;
+  const size_t lds = (size_t)4 * 2 * Tp * HS * 2 + ot_bytes<HS>();
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<HS>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) {
       coati_set_error("attn_fwd: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
       return COATI_EHIP;
@@ -212,9 +246,16 @@ int launch_attn_fwd(const bf16_t* qkv, bf16_t* y, float* lse, int B, int T, int 
     attr_set = true;
   }
   const int quads = cdiv(n_head, 4);
-  hipLaunchKernelGGL(attn_fwd_kernel, dim3(B * quads), dim3(256), lds, s, qkv, y, lse, T, n_head, quads);
+  hipLaunchKernelGGL(attn_fwd_kernel<HS>, dim3(B * quads), dim3(256), lds, s, qkv, y, lse, T, n_head, quads);
   COATI_LAUNCH_CHECK("attn_fwd");
   return COATI_OK;
+}
+
+int launch_attn_fwd(const bf16_t* qkv, bf16_t* y, float* lse, int B, int T, int n_head, int head_size, hipStream_t s) {
+  COATI_CHECK_ARG(qkv && y && lse, "attn_fwd: null operand");
+  COATI_CHECK_SHAPE(B > 0 && T > 0 && T <= 256 && n_head > 0 && (head_size == 16 || head_size == 32),
+                    "attn_fwd: unsupported shape B=%d T=%d nh=%d hs=%d", B, T, n_head, head_size);
+  return head_size == 16 ? launch_attn_fwd_t<16>(qkv, y, lse, B, T, n_head, s) : launch_attn_fwd_t<32>(qkv, y, lse, B, T, n_head, s);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -222,11 +263,14 @@ int launch_attn_fwd(const bf16_t* qkv, bf16_t* y, float* lse, int B, int T, int 
 //   kernel 1 (per query block): dQ^T[d][q] = sum_keys K^T[d][key] dS^T[key][q]          (also writes D)
 //   kernel 2 (per key block)  : dK^T[d][key] = sum_q Q^T[d][q] dS[q][key],  dV^T[d][key] = sum_q dO^T[d][q] P[q][key]
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 4) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ y,
+template <int HS>
+__global__ __launch_bounds__(256, HS == 16 ? 4 : 2) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ y,
                                                           const bf16_t* __restrict__ dy, const float* __restrict__ lse,
                                                           float* __restrict__ Dout, bf16_t* __restrict__ dqkv,
                                                           const float* __restrict__ cos_t, const float* __restrict__ sin_t,
                                                           int T, int n_head, int quads) {
+  constexpr int NK = HS / 16, LIVE = HS / 2;
+  constexpr float SCALE = att_scale<HS>(), SCALE_LOG2E = att_scale_log2e<HS>();
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int b = blockIdx.x / quads, hq = blockIdx.x - b * quads;
@@ -238,8 +282,8 @@ __global__ __launch_bounds__(256, 4) void attn_bwd_dq_kernel(const bf16_t* __res
   bf16_t* Vs = Ks + Tp * HS;
   const long long stride = 3LL * C;
   const bf16_t* qbase = qkv + (long long)b * T * stride + hq * 4 * HS;
-  stage4(qbase + C, stride, T, Tp, smem, pw, 0, heads_here, threadIdx.x);
-  stage4(qbase + 2 * C, stride, T, Tp, smem, pw, 1, heads_here, threadIdx.x);
+  stage4<HS>(qbase + C, stride, T, Tp, smem, pw, 0, heads_here, threadIdx.x);
+  stage4<HS>(qbase + 2 * C, stride, T, Tp, smem, pw, 1, heads_here, threadIdx.x);
   __syncthreads();
   const bool active = hh < n_head;
   const int hc = active ? hh : 0;
@@ -254,23 +298,32 @@ __global__ __launch_bounds__(256, 4) void attn_bwd_dq_kernel(const bf16_t* __res
   for (int qb = 0; qb < nblk; ++qb) {
     const int q = qb * 32 + (lane & 31);
     if (active) {
-      const bf16x8 qf = gfrag(qsrc, stride, qb, T, lane), gf = gfrag(gsrc, (long long)C, qb, T, lane);
-      // D[q] = sum_d dO[q,d] O[q,d]: this lane holds dims half*8..+7 of dO[q] in gf; the partner half-wave adds the rest
+      bf16x8 qf[NK], gf[NK];
+#pragma unroll
+      for (int ks = 0; ks < NK; ++ks) {
+        qf[ks] = gfrag(qsrc, stride, qb, ks, T, lane);
+        gf[ks] = gfrag(gsrc, (long long)C, qb, ks, T, lane);
+      }
+      // D[q] = sum_d dO[q,d] O[q,d]: this lane holds dims ks*16 + half*8..+7 of dO[q] in gf; the partner half-wave adds
+      // the rest
       float lq = INFINITY, dq_ = 0.f;
       if (q < T) {
-        float o8[8], g8[8];
-        unpack8(*reinterpret_cast<const uint4*>(ybase + (long long)q * C + half * 8), o8);
-        unpack8(__builtin_bit_cast(uint4, gf), g8);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) dq_ += o8[i] * g8[i];
+        for (int ks = 0; ks < NK; ++ks) {
+          float o8[8], g8[8];
+          unpack8(*reinterpret_cast<const uint4*>(ybase + (long long)q * C + ks * 16 + half * 8), o8);
+          unpack8(__builtin_bit_cast(uint4, gf[ks]), g8);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) dq_ += o8[i] * g8[i];
+        }
         lq = lse[sbase + q] * LOG2E;
       }
       dq_ += __shfl_xor(dq_, 32, 64);
       if (q < T && half == 0) Dout[sbase + q] = dq_;
       f32x16 acc = zero16();
       for (int kb = 0; kb <= qb; ++kb) {
-        const f32x16 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rfrag(Ks, kb, lane), qf, zero16(), 0, 0, 0);
-        const f32x16 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rfrag(Vs, kb, lane), gf, zero16(), 0, 0, 0);
+        const f32x16 s = score_block<HS>(Ks, kb, qf, lane);
+        const f32x16 dp = score_block<HS>(Vs, kb, gf, lane);
         float ds[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -278,23 +331,26 @@ __global__ __launch_bounds__(256, 4) void attn_bwd_dq_kernel(const bf16_t* __res
           if (kb == qb && kb * 32 + arow(r, lane) > q) p = 0.f;
           ds[r] = p * (dp[r] - dq_);   // the softmax scale is applied once to the finished dQ block
         }
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tfrag(Ks, kb * 32, lane), pfrag(ds), acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tfrag(Ks, kb * 32 + 16, lane), pfrag(ds + 8), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tfrag<HS>(Ks, kb * 32, lane), pfrag(ds), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tfrag<HS>(Ks, kb * 32 + 16, lane), pfrag(ds + 8), acc, 0, 0, 0);
       }
 #pragma unroll
-      for (int r = 0; r < 8; ++r) acc[r] *= SCALE;
-      tile_put_grad(otile, wave, lane, acc, true, cos_t, sin_t, q < T ? q : 0);
+      for (int r = 0; r < LIVE; ++r) acc[r] *= SCALE;
+      tile_put_grad<HS>(otile, wave, lane, acc, true, cos_t, sin_t, q < T ? q : 0);
     }
     __syncthreads();
-    tile_store(otile, dbase, stride, qb * 32, T, heads_here, threadIdx.x);
+    tile_store<HS>(otile, dbase, stride, qb * 32, T, heads_here, threadIdx.x);
     __syncthreads();
   }
 }
 
-__global__ __launch_bounds__(256, 3) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dy,
+template <int HS>
+__global__ __launch_bounds__(256, HS == 16 ? 3 : 2) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dy,
                                                            const float* __restrict__ lse, const float* __restrict__ Din,
                                                            bf16_t* __restrict__ dqkv, const float* __restrict__ cos_t,
                                                            const float* __restrict__ sin_t, int T, int n_head, int quads) {
+  constexpr int NK = HS / 16, LIVE = HS / 2;
+  constexpr float SCALE = att_scale<HS>(), SCALE_LOG2E = att_scale_log2e<HS>();
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int b = blockIdx.x / quads, hq = blockIdx.x - b * quads;
@@ -309,8 +365,8 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_kernel(const bf16_t* __re
   float* Ds = Ls + Tp;
   const long long stride = 3LL * C;
   const bf16_t* qbase = qkv + (long long)b * T * stride + hq * 4 * HS;
-  stage4(qbase, stride, T, Tp, smem, pw, 0, heads_here, threadIdx.x);
-  stage4(dy + (long long)b * T * C + hq * 4 * HS, (long long)C, T, Tp, smem, pw, 1, heads_here, threadIdx.x);
+  stage4<HS>(qbase, stride, T, Tp, smem, pw, 0, heads_here, threadIdx.x);
+  stage4<HS>(dy + (long long)b * T * C + hq * 4 * HS, (long long)C, T, Tp, smem, pw, 1, heads_here, threadIdx.x);
   __syncthreads();
   const bool active = hh < n_head;
   const int hc = active ? hh : 0;
@@ -329,11 +385,16 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_kernel(const bf16_t* __re
   for (int kb = 0; kb < nblk; ++kb) {
     const int key = kb * 32 + (lane & 31);
     if (active) {
-      const bf16x8 kf = gfrag(ksrc, stride, kb, T, lane), vf = gfrag(ksrc + C, stride, kb, T, lane);
+      bf16x8 kf[NK], vf[NK];
+#pragma unroll
+      for (int ks = 0; ks < NK; ++ks) {
+        kf[ks] = gfrag(ksrc, stride, kb, ks, T, lane);
+        vf[ks] = gfrag(ksrc + C, stride, kb, ks, T, lane);
+      }
       f32x16 dk = zero16(), dv = zero16();
       for (int qb = kb; qb < nblk; ++qb) {
-        const f32x16 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rfrag(Qs, qb, lane), kf, zero16(), 0, 0, 0);
-        const f32x16 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rfrag(Gs, qb, lane), vf, zero16(), 0, 0, 0);
+        const f32x16 s = score_block<HS>(Qs, qb, kf, lane);
+        const f32x16 dp = score_block<HS>(Gs, qb, vf, lane);
         float p[16], ds[16];
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
@@ -349,34 +410,34 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_kernel(const bf16_t* __re
             ds[r] = p[r] * (dp[r] - dvv[j]);   // scale applied once to the finished dK block
           }
         }
-        dv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tfrag(Gs, qb * 32, lane), pfrag(p), dv, 0, 0, 0);
-        dv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tfrag(Gs, qb * 32 + 16, lane), pfrag(p + 8), dv, 0, 0, 0);
-        dk = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tfrag(Qs, qb * 32, lane), pfrag(ds), dk, 0, 0, 0);
-        dk = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tfrag(Qs, qb * 32 + 16, lane), pfrag(ds + 8), dk, 0, 0, 0);
+        dv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tfrag<HS>(Gs, qb * 32, lane), pfrag(p), dv, 0, 0, 0);
+        dv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tfrag<HS>(Gs, qb * 32 + 16, lane), pfrag(p + 8), dv, 0, 0, 0);
+        dk = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tfrag<HS>(Qs, qb * 32, lane), pfrag(ds), dk, 0, 0, 0);
+        dk = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tfrag<HS>(Qs, qb * 32 + 16, lane), pfrag(ds + 8), dk, 0, 0, 0);
       }
 #pragma unroll
-      for (int r = 0; r < 8; ++r) dk[r] *= SCALE;
-      tile_put_grad(otile, wave, lane, dk, true, cos_t, sin_t, key < T ? key : 0);
-      tile_put_grad(otile + OT_BYTES, wave, lane, dv, false, cos_t, sin_t, 0);
+      for (int r = 0; r < LIVE; ++r) dk[r] *= SCALE;
+      tile_put_grad<HS>(otile, wave, lane, dk, true, cos_t, sin_t, key < T ? key : 0);
+      tile_put_grad<HS>(otile + ot_bytes<HS>(), wave, lane, dv, false, cos_t, sin_t, 0);
     }
     __syncthreads();
-    tile_store(otile, dbase + C, stride, kb * 32, T, heads_here, threadIdx.x);
-    tile_store(otile + OT_BYTES, dbase + 2 * C, stride, kb * 32, T, heads_here, threadIdx.x);
+    tile_store<HS>(otile, dbase + C, stride, kb * 32, T, heads_here, threadIdx.x);
+    tile_store<HS>(otile + ot_bytes<HS>(), dbase + 2 * C, stride, kb * 32, T, heads_here, threadIdx.x);
     __syncthreads();
   }
 }
 
-int launch_attn_bwd(const bf16_t* qkv, const bf16_t* y, const bf16_t* dy, const float* lse, float* dscratch,
-                    bf16_t* dqkv, const float* cos_t, const float* sin_t, int B, int T, int n_head, hipStream_t s) {
-  COATI_CHECK_ARG(qkv && y && dy && lse && dscratch && dqkv && cos_t && sin_t, "attn_bwd: null operand");
-  COATI_CHECK_SHAPE(B > 0 && T > 0 && T <= 256 && n_head > 0, "attn_bwd: unsupported shape B=%d T=%d nh=%d", B, T, n_head);
+template <int HS>
+static int launch_attn_bwd_t(const bf16_t* qkv, const bf16_t* y, const bf16_t* dy, const float* lse, float* dscratch,
+                             bf16_t* dqkv, const float* cos_t, const float* sin_t, int B, int T, int n_head, hipStream_t s) {
   const int Tp = (T + 31) & ~31;
-  const size_t lds = (size_t)4 * (2 * Tp * HS * 2 + 2 * Tp * 4) + 2 * OT_BYTES;   // dK/dV kernel (the dQ kernel uses less)
+  const size_t lds_dq = (size_t)4 * 2 * Tp * HS * 2 + ot_bytes<HS>();
+  const size_t lds_dkv = (size_t)4 * (2 * Tp * HS * 2 + 2 * Tp * 4) + 2 * ot_bytes<HS>();
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel),
+    hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel<HS>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_kernel),
+    hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_kernel<HS>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e1 != hipSuccess || e2 != hipSuccess) {
       coati_set_error("attn_bwd: hipFuncSetAttribute failed");
@@ -385,11 +446,20 @@ int launch_attn_bwd(const bf16_t* qkv, const bf16_t* y, const bf16_t* dy, const 
     attr_set = true;
   }
   const int quads = cdiv(n_head, 4);
-  hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(B * quads), dim3(256), (size_t)4 * 2 * Tp * HS * 2 + OT_BYTES, s, qkv, y, dy, lse, dscratch, dqkv, cos_t,
+  hipLaunchKernelGGL(attn_bwd_dq_kernel<HS>, dim3(B * quads), dim3(256), lds_dq, s, qkv, y, dy, lse, dscratch, dqkv, cos_t,
                      sin_t, T, n_head, quads);
   COATI_LAUNCH_CHECK("attn_bwd_dq");
-  hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(B * quads), dim3(256), lds, s, qkv, dy, lse, dscratch, dqkv, cos_t,
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel<HS>, dim3(B * quads), dim3(256), lds_dkv, s, qkv, dy, lse, dscratch, dqkv, cos_t,
                      sin_t, T, n_head, quads);
   COATI_LAUNCH_CHECK("attn_bwd_dkv");
   return COATI_OK;
+}
+
+int launch_attn_bwd(const bf16_t* qkv, const bf16_t* y, const bf16_t* dy, const float* lse, float* dscratch,
+                    bf16_t* dqkv, const float* cos_t, const float* sin_t, int B, int T, int n_head, int head_size, hipStream_t s) {
+  COATI_CHECK_ARG(qkv && y && dy && lse && dscratch && dqkv && cos_t && sin_t, "attn_bwd: null operand");
+  COATI_CHECK_SHAPE(B > 0 && T > 0 && T <= 256 && n_head > 0 && (head_size == 16 || head_size == 32),
+                    "attn_bwd: unsupported shape B=%d T=%d nh=%d hs=%d", B, T, n_head, head_size);
+  return head_size == 16 ? launch_attn_bwd_t<16>(qkv, y, dy, lse, dscratch, dqkv, cos_t, sin_t, B, T, n_head, s)
+                         : launch_attn_bwd_t<32>(qkv, y, dy, lse, dscratch, dqkv, cos_t, sin_t, B, T, n_head, s);
 }

@@ -66,19 +66,34 @@ int coati_layernorm_bwd(const void* dy, int dy_f32, int64_t lddy, const float* x
 }
 
 int coati_attn_fwd(const uint16_t* qkv, uint16_t* y, float* lse, int B, int T, int n_head, void* stream) {
-  return launch_attn_fwd(qkv, y, lse, B, T, n_head, S_(stream));
+  return launch_attn_fwd(qkv, y, lse, B, T, n_head, 16, S_(stream));
+}
+int coati_attn_fwd_hs(const uint16_t* qkv, uint16_t* y, float* lse, int B, int T, int n_head, int head_size, void* stream) {
+  return launch_attn_fwd(qkv, y, lse, B, T, n_head, head_size, S_(stream));
 }
 int coati_gemm_qkv_rope(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw, const float* bias, int M, int C,
                         uint16_t* qkv, int64_t ldc, const float* cos_t, const float* sin_t, int T, void* stream) {
   GemmArgs a;
   memset(&a, 0, sizeof(a));
   a.A = A; a.lda = lda; a.B = W; a.ldb = ldw; a.M = M; a.N = 3 * C; a.K = C; a.C = qkv; a.ldc = ldc; a.bias = bias;
-  a.rope_cos = cos_t; a.rope_sin = sin_t; a.rope_T = T; a.rope_C = C;
+  a.rope_cos = cos_t; a.rope_sin = sin_t; a.rope_T = T; a.rope_C = C; a.rope_hs = 16;
+  return launch_gemm_nt(a, 0, EPI_QKV_ROPE, S_(stream));
+}
+int coati_gemm_qkv_rope_hs(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw, const float* bias, int M, int C,
+                           uint16_t* qkv, int64_t ldc, const float* cos_t, const float* sin_t, int T, int head_size, void* stream) {
+  GemmArgs a;
+  memset(&a, 0, sizeof(a));
+  a.A = A; a.lda = lda; a.B = W; a.ldb = ldw; a.M = M; a.N = 3 * C; a.K = C; a.C = qkv; a.ldc = ldc; a.bias = bias;
+  a.rope_cos = cos_t; a.rope_sin = sin_t; a.rope_T = T; a.rope_C = C; a.rope_hs = head_size;
   return launch_gemm_nt(a, 0, EPI_QKV_ROPE, S_(stream));
 }
 int coati_attn_bwd(const uint16_t* qkv, const uint16_t* y, const uint16_t* dy, const float* lse, float* dscratch, uint16_t* dqkv,
                    const float* cos_t, const float* sin_t, int B, int T, int n_head, void* stream) {
-  return launch_attn_bwd(qkv, y, dy, lse, dscratch, dqkv, cos_t, sin_t, B, T, n_head, S_(stream));
+  return launch_attn_bwd(qkv, y, dy, lse, dscratch, dqkv, cos_t, sin_t, B, T, n_head, 16, S_(stream));
+}
+int coati_attn_bwd_hs(const uint16_t* qkv, const uint16_t* y, const uint16_t* dy, const float* lse, float* dscratch, uint16_t* dqkv,
+                      const float* cos_t, const float* sin_t, int B, int T, int n_head, int head_size, void* stream) {
+  return launch_attn_bwd(qkv, y, dy, lse, dscratch, dqkv, cos_t, sin_t, B, T, n_head, head_size, S_(stream));
 }
 
 int coati_embed_fwd(const int64_t* idx, const float* table, const float* injection, int unk_token, float* x, int B,
@@ -103,7 +118,10 @@ int coati_bad_rows(const int64_t* tokens, uint8_t* bad, int B, int T, void* stre
 }
 int coati_silu(const float* x, float* y, int64_t n, void* stream) { return launch_silu_fwd(x, y, n, S_(stream)); }
 int coati_attn_decode(const uint16_t* qkv, uint16_t* cache, uint16_t* y, int B, int n_head, int Tmax, int pos, void* stream) {
-  return launch_attn_decode(qkv, cache, y, B, n_head, Tmax, pos, S_(stream));
+  return launch_attn_decode(qkv, cache, y, B, n_head, 16, Tmax, pos, S_(stream));
+}
+int coati_attn_decode_hs(const uint16_t* qkv, uint16_t* cache, uint16_t* y, int B, int n_head, int head_size, int Tmax, int pos, void* stream) {
+  return launch_attn_decode(qkv, cache, y, B, n_head, head_size, Tmax, pos, S_(stream));
 }
 int coati_topk_sample(const float* logits, int64_t ldl, int B, int V, int k, float inv_temp, const float* u,
                       int64_t* tokens_out, int32_t* stopped, int stop_token, int pad_token, void* stream) {

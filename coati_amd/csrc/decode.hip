@@ -2,20 +2,21 @@
 // head size 16, and top-k sampling of the next token (reference smiles_xformer.py:272-351 recomputes the whole prefix
 // for every generated token; here the rotated keys and the values of earlier positions live in an HBM cache).
 //
-// Cache layout: [B][n_head][Tmax][k16 | v16] bf16 -> one (b, head) sequence is a contiguous run of 64-B records, a wave
-// streams it with one 64-B record per lane per pass.  HBM-bound: 64 B per cached token per head per step.
+// Cache layout: [B][n_head][Tmax][k | v] bf16 (head size 16 or 32) -> one (b, head) sequence is a contiguous run of
+// 64 / 128-B records, a wave streams it with one record per lane per pass.  HBM-bound: 4 * hs bytes per cached token
+// per head per step.
 #include "kernels.h"
 
-#define DHS 16
 
-__device__ __forceinline__ void load_bf16x16(const bf16_t* p, float* x) {
-  const uint4 a = *reinterpret_cast<const uint4*>(p), b = *reinterpret_cast<const uint4*>(p + 8);
-  unpack8(a, x);
-  unpack8(b, x + 8);
+template <int N>
+__device__ __forceinline__ void load_bf16(const bf16_t* p, float* x) {
+#pragma unroll
+  for (int i = 0; i < N / 8; ++i) unpack8(*reinterpret_cast<const uint4*>(p + 8 * i), x + 8 * i);
 }
 
 // qkv: [B, 3C] bf16 of the new token (q, k already rotated by the QKV GEMM epilogue); y: [B, C] bf16.
 // One wave per (b, head).  Appends (k, v) at position pos, attends to positions 0..pos.
+template <int DHS>
 __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ cache,
                                                           bf16_t* __restrict__ y, int B, int n_head, int Tmax, int pos) {
   const int lane = threadIdx.x & 63;
@@ -25,13 +26,14 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
   const int C = n_head * DHS;
   const bf16_t* row = qkv + (long long)b * 3 * C + h * DHS;
   float q[DHS], kn[DHS], vn[DHS];
-  load_bf16x16(row, q);
-  load_bf16x16(row + C, kn);
-  load_bf16x16(row + 2 * C, vn);
-  bf16_t* seq = cache + ((long long)item * Tmax) * 32;
-  if (lane < 4) {   // append the new record: 4 x 16 B
-    const bf16_t* src = (lane < 2) ? row + C + lane * 8 : row + 2 * C + (lane - 2) * 8;
-    *reinterpret_cast<uint4*>(seq + (long long)pos * 32 + lane * 8) = *reinterpret_cast<const uint4*>(src);
+  constexpr int REC = 2 * DHS, CH = DHS / 8;   // record = [k | v] halfs; 16-B chunks per operand
+  load_bf16<DHS>(row, q);
+  load_bf16<DHS>(row + C, kn);
+  load_bf16<DHS>(row + 2 * C, vn);
+  bf16_t* seq = cache + ((long long)item * Tmax) * REC;
+  if (lane < 2 * CH) {   // append the new record
+    const bf16_t* src = (lane < CH) ? row + C + lane * 8 : row + 2 * C + (lane - CH) * 8;
+    *reinterpret_cast<uint4*>(seq + (long long)pos * REC + lane * 8) = *reinterpret_cast<const uint4*>(src);
   }
   // scores of this lane's keys (t = lane, lane + 64, ...); the newest key comes from registers, not from the cache
   float m = -INFINITY;
@@ -47,13 +49,13 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
 #pragma unroll
         for (int d = 0; d < DHS; ++d) { k[d] = kn[d]; kv[i][d] = vn[d]; }
       } else {
-        load_bf16x16(seq + (long long)t * 32, k);
-        load_bf16x16(seq + (long long)t * 32 + 16, kv[i]);
+        load_bf16<DHS>(seq + (long long)t * REC, k);
+        load_bf16<DHS>(seq + (long long)t * REC + DHS, kv[i]);
       }
       float s = 0.f;
 #pragma unroll
       for (int d = 0; d < DHS; ++d) s += q[d] * k[d];
-      sc[i] = s * 0.25f;   // 1 / sqrt(16)
+      sc[i] = s * (DHS == 16 ? 0.25f : 0.17677669529663687f);   // 1 / sqrt(hs)
       m = fmaxf(m, sc[i]);
     } else {
 #pragma unroll
@@ -76,20 +78,20 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
 #pragma unroll
   for (int d = 0; d < DHS; ++d) acc[d] = wave_sum(acc[d]) * inv;
   if (lane == 0) {
-    uint4 o0, o1;
-    o0.x = pack2bf(acc[0], acc[1]); o0.y = pack2bf(acc[2], acc[3]); o0.z = pack2bf(acc[4], acc[5]); o0.w = pack2bf(acc[6], acc[7]);
-    o1.x = pack2bf(acc[8], acc[9]); o1.y = pack2bf(acc[10], acc[11]); o1.z = pack2bf(acc[12], acc[13]); o1.w = pack2bf(acc[14], acc[15]);
     bf16_t* dst = y + (long long)b * C + h * DHS;
-    *reinterpret_cast<uint4*>(dst) = o0;
-    *reinterpret_cast<uint4*>(dst + 8) = o1;
+#pragma unroll
+    for (int i = 0; i < DHS / 8; ++i) *reinterpret_cast<uint4*>(dst + 8 * i) = pack8(acc + 8 * i);
   }
 }
 
-int launch_attn_decode(const bf16_t* qkv, bf16_t* cache, bf16_t* y, int B, int n_head, int Tmax, int pos, hipStream_t s) {
+int launch_attn_decode(const bf16_t* qkv, bf16_t* cache, bf16_t* y, int B, int n_head, int head_size, int Tmax, int pos, hipStream_t s) {
   COATI_CHECK_ARG(qkv && cache && y, "attn_decode: null operand");
-  COATI_CHECK_SHAPE(B > 0 && n_head > 0 && Tmax > 0 && Tmax <= 256 && pos >= 0 && pos < Tmax,
-                    "attn_decode: unsupported shape B=%d nh=%d Tmax=%d pos=%d", B, n_head, Tmax, pos);
-  hipLaunchKernelGGL(attn_decode_kernel, dim3(cdiv(B * n_head, 4)), dim3(256), 0, s, qkv, cache, y, B, n_head, Tmax, pos);
+  COATI_CHECK_SHAPE(B > 0 && n_head > 0 && Tmax > 0 && Tmax <= 256 && pos >= 0 && pos < Tmax && (head_size == 16 || head_size == 32),
+                    "attn_decode: unsupported shape B=%d nh=%d hs=%d Tmax=%d pos=%d", B, n_head, head_size, Tmax, pos);
+  if (head_size == 16)
+    hipLaunchKernelGGL(attn_decode_kernel<16>, dim3(cdiv(B * n_head, 4)), dim3(256), 0, s, qkv, cache, y, B, n_head, Tmax, pos);
+  else
+    hipLaunchKernelGGL(attn_decode_kernel<32>, dim3(cdiv(B * n_head, 4)), dim3(256), 0, s, qkv, cache, y, B, n_head, Tmax, pos);
   COATI_LAUNCH_CHECK("attn_decode");
   return COATI_OK;
 }

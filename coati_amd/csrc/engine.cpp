@@ -442,13 +442,13 @@ int xformer_fwd(coati_engine* e, XPass& p, const float* injection, hipStream_t s
       GemmArgs a;
       memset(&a, 0, sizeof(a));
       a.A = p.a1[l]; a.lda = C; a.B = e->S + w.attnw; a.ldb = C; a.M = M; a.N = 3 * C; a.K = C; a.C = p.qkv[l]; a.ldc = 3 * C;
-      a.bias = e->P + w.attnb; a.rope_cos = e->cos_t; a.rope_sin = e->sin_t; a.rope_T = p.T; a.rope_C = C;
+      a.bias = e->P + w.attnb; a.rope_cos = e->cos_t; a.rope_sin = e->sin_t; a.rope_T = p.T; a.rope_C = C; a.rope_hs = C / c.n_head;
       ProfScope ps(e, SITE_QKV_FWD, 2.0 * M * 3 * C * C, s, (double)M * C * 2 + 3.0 * C * C * 2 + (double)M * 3 * C * 2);
       COATI_TRY(launch_gemm_nt(a, 0, EPI_QKV_ROPE, s));
     }
     {
       ProfScope ps(e, SITE_ATTN_FWD, 4.0 * p.B * (double)p.T * p.T * C, s, (double)M * 4 * C * 2 + (double)M * c.n_head * 4);   // qkv in, y + lse out
-      COATI_TRY(launch_attn_fwd(p.qkv[l], p.y[l], p.lse[l], p.B, p.T, c.n_head, s));
+      COATI_TRY(launch_attn_fwd(p.qkv[l], p.y[l], p.lse[l], p.B, p.T, c.n_head, C / c.n_head, s));
     }
     COATI_TRY(gemm(e, SITE_PROJ_FWD, p.y[l], 0, C, e->S + w.projw, C, M, C, C, p.xmid[l], C, e->P + w.projb, EPI_RES_F32, p.x[l], nullptr, C, s));
     {
@@ -488,7 +488,7 @@ int xformer_bwd(coati_engine* e, XPass& p, const void* dyf, int dyf_f32, float* 
     COATI_TRY(wgrad(e, SITE_XF_WGRAD, e->DX16, 0, C, p.y[l], C, M, C, C, e->G + w.projw, C, e->G + w.projb, 0, s));
     {
       ProfScope ps(e, SITE_ATTN_BWD, 10.0 * p.B * (double)p.T * p.T * C, s, (double)M * 8 * C * 2 + (double)M * c.n_head * 8);   // qkv, y, dy in; dqkv out
-      COATI_TRY(launch_attn_bwd(p.qkv[l], p.y[l], e->dyb, p.lse[l], e->attnD, e->dqkv, e->cos_t, e->sin_t, p.B, p.T, c.n_head, s));
+      COATI_TRY(launch_attn_bwd(p.qkv[l], p.y[l], e->dyb, p.lse[l], e->attnD, e->dqkv, e->cos_t, e->sin_t, p.B, p.T, c.n_head, C / c.n_head, s));
     }
     COATI_TRY(gemm(e, SITE_QKV_DGRAD, e->dqkv, 0, 3 * C, e->S + w.attnT, 3 * C, M, C, 3 * C, e->da, C, nullptr, EPI_BF16, nullptr, nullptr, 0, s));
     COATI_TRY(wgrad(e, SITE_XF_WGRAD, e->dqkv, 0, 3 * C, p.a1[l], C, M, 3 * C, C, e->G + w.attnw, C, e->G + w.attnb, 0, s));
@@ -641,7 +641,7 @@ extern "C" {
 int coati_engine_create(const coati_config* cfg, coati_engine** out) {
   COATI_CHECK_ARG(cfg && out, "engine_create: null argument");
   const int C = cfg->n_hidden_xformer, H = cfg->n_hidden_e3nn, E = cfg->n_embd_common;
-  COATI_CHECK_SHAPE(cfg->n_head > 0 && C == cfg->n_head * 16, "engine_create: head size must be 16 (C=%d, n_head=%d)", C, cfg->n_head);
+  COATI_CHECK_SHAPE(cfg->n_head > 0 && (C == cfg->n_head * 16 || C == cfg->n_head * 32), "engine_create: head size must be 16 or 32 (C=%d, n_head=%d)", C, cfg->n_head);
   COATI_CHECK_SHAPE(C % 64 == 0 && H % 64 == 0 && C <= 1024 && H <= 1024, "engine_create: C=%d and H=%d must be multiples of 64 (<=1024)", C, H);
   COATI_CHECK_SHAPE(E == C, "engine_create: n_embd_common (%d) must equal n_hidden_xformer (%d)", E, C);
   COATI_CHECK_SHAPE(cfg->n_seq > 0 && cfg->n_seq <= 256 && cfg->n_tok > 8, "engine_create: n_seq must be <= 256");
@@ -973,7 +973,7 @@ size_t decode_carve(coati_engine* e, Arena& ar, int B, int Tmax) {
   const coati_config& c = e->cfg;
   const size_t C = c.n_hidden_xformer, L = c.n_layer_xformer;
   auto& d = e->dec;
-  d.cache = ar.take<bf16_t>(L * B * (size_t)c.n_head * Tmax * 32);
+  d.cache = ar.take<bf16_t>(L * B * (size_t)C * Tmax * 2);   // [L][B][nh][Tmax][k | v]
   d.x = ar.take<float>(B * C); d.xmid = ar.take<float>(B * C); d.xn = ar.take<float>(B * C);
   d.mean = ar.take<float>(B); d.rstd = ar.take<float>(B);
   d.a = ar.take<bf16_t>(B * C); d.qkv = ar.take<bf16_t>(B * 3 * C); d.y = ar.take<bf16_t>(B * C);
@@ -996,7 +996,6 @@ int64_t coati_engine_decode_workspace_bytes(coati_engine* e, int B, int Tmax) {
 int coati_engine_decode_begin(coati_engine* e, void* workspace, int64_t ws_bytes, int B, int Tmax) {
   COATI_CHECK_ARG(e && workspace && e->P && e->S, "decode_begin: engine not bound / null workspace");
   COATI_CHECK_SHAPE(B > 0 && Tmax > 0 && Tmax <= e->cfg.n_seq && Tmax <= 256, "decode_begin: bad shape B=%d Tmax=%d (n_seq=%d)", B, Tmax, e->cfg.n_seq);
-  COATI_CHECK_SHAPE(e->cfg.n_hidden_xformer == e->cfg.n_head * 16, "decode: head size must be 16");
   COATI_CHECK_SHAPE(ws_bytes >= coati_engine_decode_workspace_bytes(e, B, Tmax), "decode_begin: workspace too small");
   Arena ar{reinterpret_cast<char*>(workspace), 0, (size_t)ws_bytes, false};
   decode_carve(e, ar, B, Tmax);
@@ -1029,12 +1028,13 @@ int coati_engine_decode_step(coati_engine* e, const int64_t* tokens, const float
       GemmArgs a;
       memset(&a, 0, sizeof(a));
       a.A = d.a; a.lda = C; a.B = e->S + w.attnw; a.ldb = C; a.M = B; a.N = 3 * C; a.K = C; a.C = d.qkv; a.ldc = 3 * C;
-      a.bias = e->P + w.attnb; a.rope_cos = e->cos_t + (size_t)d.pos * 16; a.rope_sin = e->sin_t + (size_t)d.pos * 16;
+      a.bias = e->P + w.attnb; a.rope_hs = C / c.n_head;
+      a.rope_cos = e->cos_t + (size_t)d.pos * a.rope_hs; a.rope_sin = e->sin_t + (size_t)d.pos * a.rope_hs;
       a.rope_T = 1; a.rope_C = C;
       COATI_TRY(launch_gemm_nt(a, 0, EPI_QKV_ROPE, s));
     }
-    bf16_t* cache_l = d.cache + (size_t)l * B * c.n_head * d.Tmax * 32;
-    COATI_TRY(launch_attn_decode(d.qkv, cache_l, d.y, B, c.n_head, d.Tmax, d.pos, s));
+    bf16_t* cache_l = d.cache + (size_t)l * B * C * d.Tmax * 2;
+    COATI_TRY(launch_attn_decode(d.qkv, cache_l, d.y, B, c.n_head, C / c.n_head, d.Tmax, d.pos, s));
     COATI_TRY(gemm(e, SITE_NONE, d.y, 0, C, e->S + w.projw, C, B, C, C, xm, C, e->P + w.projb, EPI_RES_F32, x, nullptr, C, s));
     COATI_TRY(launch_layernorm_fwd(xm, C, e->P + w.ln2w, e->P + w.ln2b, d.a, C, nullptr, 0, d.mean, d.rstd, B, C, s));
     COATI_TRY(gemm(e, SITE_NONE, d.a, 0, C, e->S + w.fc1w, C, B, 4 * C, C, d.g, 4 * C, e->P + w.fc1b, EPI_GELU, nullptr, d.hpre, 4 * C, s));

@@ -266,7 +266,7 @@ int launch_gemm_nt(const GemmArgs& a, int a_f32, int epi, hipStream_t s) {
   if (epi == EPI_DGELU || epi == EPI_DSILU) COATI_CHECK_ARG(a.aux_in && a.ld_aux % 8 == 0, "gemm_nt: aux_in missing");
   if (epi == EPI_CE_PARTIAL) COATI_CHECK_ARG(a.partial, "gemm_nt: partial buffer missing");
   if (epi == EPI_CE_BWD) COATI_CHECK_ARG(a.lse && a.target && a.scal, "gemm_nt: CE operands missing");
-  if (epi == EPI_QKV_ROPE) COATI_CHECK_ARG(a.rope_cos && a.rope_sin && a.rope_T > 0 && a.rope_C > 0 && a.N % 16 == 0 && a.rope_C % 16 == 0, "gemm_nt: rope operands missing");
+  if (epi == EPI_QKV_ROPE) COATI_CHECK_ARG(a.rope_cos && a.rope_sin && a.rope_T > 0 && a.rope_C > 0 && a.N % 16 == 0 && a.rope_C % 16 == 0 && (a.rope_hs == 0 || a.rope_hs == 16 || a.rope_hs == 32) && (a.rope_hs != 32 || a.rope_C % 32 == 0), "gemm_nt: rope operands missing / unsupported head size");
   if (epi == EPI_EDGE_DPRE) COATI_CHECK_ARG(a.P && a.d2 && a.w1c && a.b1 && a.natom > 0 && a.ldp % 8 == 0, "gemm_nt: edge operands missing");
   {
     static const bool no_rb = getenv("COATI_NO_RB") != nullptr;   // A/B switch for benchmarking

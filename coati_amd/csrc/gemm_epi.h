@@ -97,18 +97,22 @@ __device__ __forceinline__ void epilogue8(const GemmArgs& p, int row, int col0, 
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] = v[e];
   } else if (EPI == EPI_QKV_ROPE) {
-    // head size 16: this lane holds dims (col0 & 8) .. +7 of one head, the partner lane (lane ^ 1) the other half.
-    // RotaryEmbedding.rotary_embed (basic_transformer.py:83-100): y_i = x_i c_i - x_{i+8} s_i ; y_{i+8} = x_{i+8} c_i + x_i s_i
-    const bool hi_half = (col0 & 8) != 0;
+    // This lane holds 8 consecutive dims of one head; the RoPE partner (d +- hs/2) sits in lane ^ 1 (head size 16) or
+    // lane ^ 2 (head size 32): a DPP quad permutation (one VALU op), not a ds_bpermute through the LDS pipe.
+    // RotaryEmbedding.rotary_embed (basic_transformer.py:83-100): y_i = x_i c_i - x_{i+h} s_i ; y_{i+h} = x_{i+h} c_i + x_i s_i
+    const bool hs32 = p.rope_hs == 32;
+    const bool hi_half = (col0 & (hs32 ? 16 : 8)) != 0;
     const int t = row % p.rope_T;
     const bool rot = col0 < 2 * p.rope_C;
+    const int tab = hs32 ? t * 32 + (col0 & 8) : t * 16;   // tables are [n_seq, hs] with entries i and i + hs/2 equal
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      // partner lane = lane ^ 1: a DPP quad permutation (one VALU op), not a ds_bpermute through the LDS pipe
-      const float other = (ROPE_PARTNER == 1) ? __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v[e]), 0xB1, 0xF, 0xF, true))
-                                              : __shfl_xor(v[e], ROPE_PARTNER, 64);
-      const float c = rope_row ? rope_row[e] : p.rope_cos[t * 16 + e];
-      const float s_ = rope_row ? rope_row[8 + e] : p.rope_sin[t * 16 + e];
+      const int vi = __builtin_bit_cast(int, v[e]);
+      const float o1 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, vi, 0xB1, 0xF, 0xF, true));   // lane ^ 1
+      const float o2 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, vi, 0x4E, 0xF, 0xF, true));   // lane ^ 2
+      const float other = (ROPE_PARTNER != 1) ? __shfl_xor(v[e], hs32 ? 2 * ROPE_PARTNER : ROPE_PARTNER, 64) : (hs32 ? o2 : o1);
+      const float c = rope_row ? rope_row[e] : p.rope_cos[tab + e];
+      const float s_ = rope_row ? rope_row[8 + e] : p.rope_sin[tab + e];
       const float r = hi_half ? (v[e] * c + other * s_) : (v[e] * c - other * s_);
       o[e] = rot ? r : v[e];
     }

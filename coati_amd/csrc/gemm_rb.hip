@@ -209,6 +209,7 @@ bool gemm_rb256_supported(const GemmArgs& a, int a_f32, int epi) {
   // COATI_RB_EXCLUDE (A/B switch for tuning): bit 1 = N < 512, bit 2 = epilogues with extra row-major operands
   static const int excl = getenv("COATI_RB_EXCLUDE") ? atoi(getenv("COATI_RB_EXCLUDE")) : 0;
   if (a_f32 || a.K != RB_K || epi == EPI_CE_PARTIAL) return false;
+  if (epi == EPI_QKV_ROPE && a.rope_hs == 32) return false;   // the staged rotary rows are laid out for head size 16
   if (a.N % 16 != 0 && epi != EPI_CE_BWD) return false;
   if (rb_waves(a.M) < 8) return false;   // small problems run on the tiled kernel
   if ((excl & 1) && a.N < 512) return false;

@@ -49,11 +49,12 @@ struct GemmArgs {
   const float* b1;
   int natom;
   int H;
-  // rotary epilogue: row m is token t = m % rope_T; tables [n_seq, 16] f32 (head size 16)
+  // rotary epilogue: row m is token t = m % rope_T; tables [n_seq, rope_hs] f32; head size rope_hs = 16 or 32 (0 -> 16)
   const float* rope_cos;
   const float* rope_sin;
   int rope_T;
   int rope_C;
+  int rope_hs;
 };
 
 int launch_gemm_nt(const GemmArgs& a, int a_f32, int epi, hipStream_t s);
@@ -99,9 +100,9 @@ int launch_layernorm_bwd(const void* dy, int dy_f32, long long lddy, const float
 // ------------------------------------------------------------------------------------------------
 // attention, head size 16 (attention.hip)
 // ------------------------------------------------------------------------------------------------
-int launch_attn_fwd(const bf16_t* qkv, bf16_t* y, float* lse, int B, int T, int n_head, hipStream_t s);
+int launch_attn_fwd(const bf16_t* qkv, bf16_t* y, float* lse, int B, int T, int n_head, int head_size, hipStream_t s);
 int launch_attn_bwd(const bf16_t* qkv, const bf16_t* y, const bf16_t* dy, const float* lse, float* dscratch, bf16_t* dqkv,
-                    const float* cos, const float* sin, int B, int T, int n_head, hipStream_t s);
+                    const float* cos, const float* sin, int B, int T, int n_head, int head_size, hipStream_t s);
 
 // ------------------------------------------------------------------------------------------------
 // embedding / token kernels (embed.hip)
@@ -118,7 +119,7 @@ int launch_scatter_rows_add(const float* dout, const int* pos, float* dx, int B,
 // bad[b] = sum_t tokens[b,t] < 1
 int launch_bad_rows(const long long* tokens, unsigned char* bad, int B, int T, hipStream_t s);
 // inference decode (decode.hip)
-int launch_attn_decode(const bf16_t* qkv, bf16_t* cache, bf16_t* y, int B, int n_head, int Tmax, int pos, hipStream_t s);
+int launch_attn_decode(const bf16_t* qkv, bf16_t* cache, bf16_t* y, int B, int n_head, int head_size, int Tmax, int pos, hipStream_t s);
 int launch_topk_sample(const float* logits, long long ldl, int B, int V, int k, float inv_temp, const float* u,
                        long long* tok_out, int* stopped, int stop_token, int pad_token, hipStream_t s);
 // batch tail (batch.hip)

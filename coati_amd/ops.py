@@ -107,30 +107,30 @@ def rope_tables(n_seq, head_size=16, base=10000.0, device="cuda"):
     return emb.cos().contiguous().to(device), emb.sin().contiguous().to(device)
 
 
-def gemm_qkv_rope(A, W, bias, T, cos, sin):
-    """qkv = [RoPE(q) | RoPE(k) | v] of A @ W^T + bias (rows are (b, t) with t = row % T)."""
+def gemm_qkv_rope(A, W, bias, T, cos, sin, hs=16):
+    """qkv = [RoPE(q) | RoPE(k) | v] of A @ W^T + bias (rows are (b, t) with t = row % T); head size hs = 16 or 32."""
     _need_cuda(A, W)
     M, C = A.shape
     out = torch.empty(M, 3 * C, device=A.device, dtype=BF16)
-    _lib.call("coati_gemm_qkv_rope", ptr(A), A.stride(0), ptr(W), W.stride(0), ptr(bias), M, C, ptr(out), 3 * C, ptr(cos),
-              ptr(sin), T, stream())
+    _lib.call("coati_gemm_qkv_rope_hs", ptr(A), A.stride(0), ptr(W), W.stride(0), ptr(bias), M, C, ptr(out), 3 * C, ptr(cos),
+              ptr(sin), T, hs, stream())
     return out
 
 
-def attn_fwd(qkv, B, T, n_head):
-    """causal attention on already-rotated q,k (head size 16)"""
+def attn_fwd(qkv, B, T, n_head, hs=16):
+    """causal attention on already-rotated q,k (head size 16 or 32)"""
     _need_cuda(qkv)
-    C = n_head * 16
+    C = n_head * hs
     y = torch.empty(B * T, C, device=qkv.device, dtype=BF16)
     lse = torch.empty(B, n_head, T, device=qkv.device, dtype=torch.float32)
-    _lib.call("coati_attn_fwd", ptr(qkv), ptr(y), ptr(lse), B, T, n_head, stream())
+    _lib.call("coati_attn_fwd_hs", ptr(qkv), ptr(y), ptr(lse), B, T, n_head, hs, stream())
     return y, lse
 
 
-def attn_bwd(qkv, y, dy, lse, B, T, n_head, cos, sin):
+def attn_bwd(qkv, y, dy, lse, B, T, n_head, cos, sin, hs=16):
     dqkv = torch.empty_like(qkv)
     dscratch = torch.empty(B, n_head, T, device=qkv.device, dtype=torch.float32)
-    _lib.call("coati_attn_bwd", ptr(qkv), ptr(y), ptr(dy), ptr(lse), ptr(dscratch), ptr(dqkv), ptr(cos), ptr(sin), B, T, n_head, stream())
+    _lib.call("coati_attn_bwd_hs", ptr(qkv), ptr(y), ptr(dy), ptr(lse), ptr(dscratch), ptr(dqkv), ptr(cos), ptr(sin), B, T, n_head, hs, stream())
     return dqkv
 
 

@@ -103,6 +103,17 @@ int coati_gemm_qkv_rope(const uint16_t* A, int64_t lda, const uint16_t* W, int64
 int coati_attn_fwd(const uint16_t* qkv, uint16_t* y, float* lse, int B, int T, int n_head, void* stream);
 int coati_attn_bwd(const uint16_t* qkv, const uint16_t* y, const uint16_t* dy, const float* lse, float* dscratch, uint16_t* dqkv,
                    const float* cos_t, const float* sin_t, int B, int T, int n_head, void* stream);
+/* head-size-generic variants (head_size = 16 or 32; the un-suffixed entry points are head size 16): qkv / cache / rope
+   tables as above with 16 replaced by head_size (rope tables [n_seq, head_size]) */
+int coati_attn_fwd_hs(const uint16_t* qkv, uint16_t* y, float* lse, int B, int T, int n_head, int head_size, void* stream);
+int coati_attn_bwd_hs(const uint16_t* qkv, const uint16_t* y, const uint16_t* dy, const float* lse, float* dscratch,
+                      uint16_t* dqkv, const float* cos_t, const float* sin_t, int B, int T, int n_head, int head_size,
+                      void* stream);
+int coati_gemm_qkv_rope_hs(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw, const float* bias, int M, int C,
+                           uint16_t* qkv, int64_t ldc, const float* cos_t, const float* sin_t, int T, int head_size,
+                           void* stream);
+int coati_attn_decode_hs(const uint16_t* qkv, uint16_t* cache, uint16_t* y, int B, int n_head, int head_size, int Tmax,
+                         int pos, void* stream);
 
 /* token embedding gather with [UNK]-slot injection (basic_transformer.py:80-81, smiles_xformer.py:444-448) */
 int coati_embed_fwd(const int64_t* idx, const float* table, const float* injection, int unk_token, float* x,

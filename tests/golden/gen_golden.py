@@ -258,6 +258,24 @@ def main():
         lg = model.xformer.xformer_blocks(xg, apply_norm=True, output_logits=True)
         out.update(gen_payload=payload, gen_tokens=gen, gen_logits=lg)
 
+    # ---- head size 32 (the COATI2-size transformer shape: n_embd / n_head = 32): RotaryBlock forward + input gradient
+    cfg32 = types.SimpleNamespace(n_embd=128, n_head=4, n_seq=24, biases=True)
+    g32 = torch.Generator().manual_seed(321)
+    emb32 = ref_bt.RotaryEmbedding(n_seq=24, n_embd=128, n_tok=48, n_head=4)
+    blk32 = ref_bt.RotaryBlock(cfg32)
+    with torch.no_grad():
+        for prm in blk32.parameters():
+            prm.copy_(torch.randn(prm.shape, generator=g32) * (0.15 if prm.dim() == 2 else 0.3) + (1.0 if prm.dim() == 1 and prm.shape[0] == 128 and False else 0.0))
+    x32 = torch.randn(3, 17, 128, generator=g32).requires_grad_(True)
+    y32 = blk32(x32, emb32)
+    a32 = blk32.attn(blk32.ln_1(x32), emb32)
+    gy = torch.randn(y32.shape, generator=g32)
+    (y32 * gy).sum().backward()
+    hs32 = {"hs32_" + k.replace(".", "__"): v for k, v in blk32.state_dict().items() if k != "attn.bias"}
+    hs32.update(hs32_x=x32.detach(), hs32_y=y32, hs32_attn=a32, hs32_gy=gy, hs32_dx=x32.grad,
+                hs32_cos=emb32.cos_cached, hs32_sin=emb32.sin_cached)
+    out.update(hs32)
+
     np.savez_compressed(os.path.join(OUT, "small_vectors.npz"), **npify(out))
 
     # ---- G15 clip_ar_xform tail (tokenizer 'mar', CanonSmiles stubbed to identity) -----------

@@ -236,3 +236,54 @@ def test_staged_backward_equals_whole_backward():
         a, b = whole[off:off + n], eng.grads[off:off + n]
         scale = max(float(a.abs().max()), 1e-20)
         assert float((a - b).abs().max()) <= 1e-5 * scale + 1e-12, (name, float((a - b).abs().max()), scale)
+
+
+def test_head_size_32_model_grads_and_decode():
+    """The COATI2-size transformer shape (n_embd / n_head = 32): a full training step against
+    the oracle (pinned at head size 32 by tests/test_oracle_golden.py::test_block_head_size_32), and the KV-cached decode
+    path against the engine's own full-sequence logits."""
+    from oracle import coati_oracle as O
+    from coati_amd.engine import Engine, ModelConfig
+    from coati_amd.synthetic import make_batch
+    kw = dict(n_layer_e3gnn=1, n_layer_xformer=2, n_hidden_xformer=128, n_hidden_e3nn=128, n_embd_common=128, n_head=4,
+              n_seq=64, n_tok=300)
+    ocfg = O.OracleConfig(**kw)
+    P = O.init_params(ocfg, seed=4)
+    eng = Engine(ModelConfig(**kw), DEV)
+    eng.load_state_dict(P)
+    batch, up = make_batch(20, 40, 10, 300, seed=6, n_special=12, p_bad=0.1, min_len=6)
+    db = {k: v.to(DEV) for k, v in batch.items()}
+    eng.train_step(db, up.to(DEV), lr=1e-3, optimizer=False)
+    L = eng.losses()
+    Pg = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    with O.sim_bf16():
+        loss, ar, cl, _ = O.step_loss(Pg, ocfg, batch, up)
+    loss.backward()
+    check("hs32 ar", torch.tensor([L["ar_loss"]]), ar.detach().reshape(1), 5e-3)
+    check("hs32 clip", torch.tensor([L["clip_loss"]]), cl.detach().reshape(1), 5e-3)
+    grads = eng.named_views("grads")
+    bad = []
+    for k in sorted(eng.layout):
+        ref = Pg[k].grad if Pg[k].grad is not None else torch.zeros_like(P[k])
+        scale = max(float(ref.abs().max()), 1e-30)
+        e = float((grads[k].cpu() - ref).abs().max()) / scale if float(ref.abs().max()) > 0 else float(grads[k].abs().max())
+        log(f"hs32 grad {k:60s} relerr {e:.3e} scale {scale:.3e}")
+        if e > TOL_GRAD_SIM:
+            bad.append((e, k))
+    assert not bad, sorted(bad, reverse=True)[:8]
+    # decode: feed the decoder tokens position by position, compare with the full-sequence logits of the same engine
+    eng.forward(db["raw_tokens"], db["tokens"], db["atoms"], db["coords"], up.to(DEV), y_next=None, train=False)
+    full = eng.logits().clone()                      # [B, T2, V]
+    B, T2 = db["tokens"].shape
+    inj = torch.zeros(B, 128, device=DEV)            # rows with an [UNK] slot were injected with cliptok in the full pass
+    has_unk = (db["tokens"] == 7).any(1)
+    rows = (~has_unk).nonzero().flatten()            # compare rows without injection (their embeddings are table rows)
+    assert rows.numel() > 0
+    eng.decode_begin(B, T2)
+    worst = 0.0
+    for t in range(T2):
+        lg = eng.decode_step(db["tokens"][:, t].contiguous(), inj)
+        ref = full[rows, t]
+        worst = max(worst, float((lg[rows] - ref).abs().max()) / max(float(ref.abs().max()), 1e-6))
+    log(f"hs32 decode vs full forward: worst relative error {worst:.3e}")
+    assert worst < 2e-2

@@ -121,37 +121,38 @@ def test_layernorm(ops, M, C, affine):
         check(f"ln bwd xhat {M}x{C}", dx, xr.grad, 2e-5)
 
 
-@pytest.mark.parametrize("B,T,nh", [(3, 12, 4), (5, 80, 16), (2, 250, 4), (4, 33, 2)])
-def test_attention(ops, B, T, nh):
+@pytest.mark.parametrize("B,T,nh,hs", [(3, 12, 4, 16), (5, 80, 16, 16), (2, 250, 4, 16), (4, 33, 2, 16),
+                                        (3, 12, 4, 32), (3, 80, 16, 32), (2, 250, 3, 32), (4, 33, 2, 32)])
+def test_attention(ops, B, T, nh, hs):
     from oracle import coati_oracle as O
-    C = nh * 16
+    C = nh * hs
     g = torch.Generator().manual_seed(T)
     qkv = rbf(torch.randn(B * T, 3 * C, generator=g)).to(DEV)
     dy = rbf(torch.randn(B * T, C, generator=g)).to(DEV)
-    cos, sin = ops.rope_tables(256, 16, device=DEV)
+    cos, sin = ops.rope_tables(256, hs, device=DEV)
     # reference (fp32 torch), oracle functions restate basic_transformer.py:126-150.  The HIP attention takes q,k already
     # rotated and rounded to bf16 (the QKV GEMM epilogue does that); its backward returns gradients w.r.t. the raw q,k.
     qr = qkv.cpu().clone().requires_grad_(True)
     q, k, v = qr.view(B, T, 3 * C).split(C, dim=2)
-    q = q.view(B, T, nh, 16).transpose(1, 2)
-    k = k.view(B, T, nh, 16).transpose(1, 2)
-    v = v.view(B, T, nh, 16).transpose(1, 2)
-    c_, s_ = O.rope_tables(256, 16)
+    q = q.view(B, T, nh, hs).transpose(1, 2)
+    k = k.view(B, T, nh, hs).transpose(1, 2)
+    v = v.view(B, T, nh, hs).transpose(1, 2)
+    c_, s_ = O.rope_tables(256, hs)
     q, k = O.rotary_embed(q, k, c_, s_)
     q = q + (rbf(q) - q).detach()          # straight-through bf16 rounding of the rotated operands
     k = k + (rbf(k) - k).detach()
     qkv_rot = torch.cat([q.transpose(1, 2).reshape(B * T, C), k.transpose(1, 2).reshape(B * T, C), qkv.cpu()[:, 2 * C:]], 1)
     qkv_dev = qkv_rot.detach().to(DEV).bfloat16()
-    y, lse = ops.attn_fwd(qkv_dev, B, T, nh)
-    att = (q @ k.transpose(-2, -1)) * 0.25
+    y, lse = ops.attn_fwd(qkv_dev, B, T, nh, hs)
+    att = (q @ k.transpose(-2, -1)) * (1.0 / hs ** 0.5)
     att = att.masked_fill(~torch.tril(torch.ones(T, T, dtype=torch.bool)), float("-inf"))
     lse_ref = torch.logsumexp(att, -1)
     yr = (torch.softmax(att, -1) @ v).transpose(1, 2).reshape(B * T, C)
-    check(f"attn fwd y B{B} T{T}", y.float().cpu(), yr, 1.2e-2)
+    check(f"attn fwd y B{B} T{T} hs{hs}", y.float().cpu(), yr, 1.2e-2)
     check(f"attn fwd lse B{B} T{T}", lse.cpu(), lse_ref, 5e-3)
     yr.backward(dy.cpu())
-    dqkv = ops.attn_bwd(qkv_dev, y, dy.bfloat16(), lse, B, T, nh, cos, sin)
-    check(f"attn bwd dq B{B} T{T}", dqkv[:, :C].float().cpu(), qr.grad[:, :C], 2e-2)
+    dqkv = ops.attn_bwd(qkv_dev, y, dy.bfloat16(), lse, B, T, nh, cos, sin, hs)
+    check(f"attn bwd dq B{B} T{T} hs{hs}", dqkv[:, :C].float().cpu(), qr.grad[:, :C], 2e-2)
     check(f"attn bwd dk B{B} T{T}", dqkv[:, C:2 * C].float().cpu(), qr.grad[:, C:2 * C], 2e-2)
     check(f"attn bwd dv B{B} T{T}", dqkv[:, 2 * C:].float().cpu(), qr.grad[:, 2 * C:], 2e-2)
 
@@ -205,24 +206,24 @@ def test_lmhead_ce(ops, M, V, K):
     assert float(d[:, V:].float().abs().max()) == 0.0 if d.shape[1] > V else True
 
 
-@pytest.mark.parametrize("B,T,nh", [(3, 12, 4), (7, 80, 16)])
-def test_gemm_qkv_rope(ops, B, T, nh):
+@pytest.mark.parametrize("B,T,nh,hs", [(3, 12, 4, 16), (7, 80, 16, 16), (3, 20, 4, 32), (1024, 80, 16, 32), (5, 33, 8, 32)])
+def test_gemm_qkv_rope(ops, B, T, nh, hs):
     from oracle import coati_oracle as O
-    C = nh * 16
+    C = nh * hs
     g = torch.Generator().manual_seed(B)
     A = rbf(torch.randn(B * T, C, generator=g))
     W = rbf(torch.randn(3 * C, C, generator=g) / math.sqrt(C))
     bias = torch.randn(3 * C, generator=g)
-    cos, sin = ops.rope_tables(128, 16, device=DEV)
-    out = ops.gemm_qkv_rope(A.to(DEV).bfloat16(), W.to(DEV).bfloat16(), bias.to(DEV), T, cos, sin)
+    cos, sin = ops.rope_tables(128, hs, device=DEV)
+    out = ops.gemm_qkv_rope(A.to(DEV).bfloat16(), W.to(DEV).bfloat16(), bias.to(DEV), T, cos, sin, hs)
     ref = A @ W.t() + bias
     q, k, v = ref.view(B, T, 3 * C).split(C, dim=2)
-    q = q.view(B, T, nh, 16).transpose(1, 2)
-    k = k.view(B, T, nh, 16).transpose(1, 2)
-    c_, s_ = O.rope_tables(128, 16)
+    q = q.view(B, T, nh, hs).transpose(1, 2)
+    k = k.view(B, T, nh, hs).transpose(1, 2)
+    c_, s_ = O.rope_tables(128, hs)
     q, k = O.rotary_embed(q, k, c_, s_)
     ref = torch.cat([q.transpose(1, 2).reshape(B * T, C), k.transpose(1, 2).reshape(B * T, C), v.reshape(B * T, C)], 1)
-    check(f"qkv rope B{B} T{T}", out.float().cpu(), ref, TB)
+    check(f"qkv rope B{B} T{T} hs{hs}", out.float().cpu(), ref, TB)
 
 
 def test_barlow_head_vs_oracle():

@@ -226,3 +226,20 @@ def test_sim_bf16_is_close_to_fp32(vec, small):
     with O.sim_bf16():
         l16, *_ = O.step_loss(P, cfg, b, use_point)
     assert abs(float(l32) - float(l16)) < 3e-2 * abs(float(l32))
+
+
+def test_block_head_size_32(vec):
+    """The COATI2-size transformer shape (n_embd / n_head = 32): the oracle's RotaryBlock restatement against the
+    reference's RotaryBlock (forward, attention output, rope tables, input gradient)."""
+    P = {k[len("hs32_"):].replace("__", "."): v for k, v in vec.items() if k.startswith("hs32_") and "__" in k}
+    P = {"b." + k: v for k, v in P.items()}
+    cos, sin = O.rope_tables(24, 32)
+    close(cos, vec["hs32_cos"][:24], name="cos32")
+    close(sin, vec["hs32_sin"][:24], name="sin32")
+    x = vec["hs32_x"].clone().requires_grad_(True)
+    a1 = torch.nn.functional.layer_norm(x, (128,), P["b.ln_1.weight"], P["b.ln_1.bias"], 1e-5)
+    close(O.attention(a1, P, "b.attn.", 4, cos, sin), vec["hs32_attn"], name="attn32")
+    y = O.block(x, P, "b.", 4, cos, sin)
+    close(y, vec["hs32_y"], name="block32")
+    (y * vec["hs32_gy"]).sum().backward()
+    close(x.grad, vec["hs32_dx"], name="dx32")
