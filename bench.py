@@ -29,6 +29,10 @@ if ROOT not in sys.path:
 
 GRANDE = dict(n_layer_e3gnn=5, n_layer_xformer=16, n_hidden_xformer=256, n_hidden_e3nn=256, n_embd_common=256,
               n_head=16, n_seq=250, n_tok=10322)          # examples/training/train_grande.py:17-35, vocab may_closedparen
+# SURVEY 8(d) config 5 shape (COATI2-size transformer: d=512, 16 heads of size 32, 12 layers, vocabulary coati2_12_12;
+# the point encoder is the E(3)-GNN at h=512 -- the chiral-aware encoder and fp8 have no reference code: parity unpinned)
+COATI2_SHAPE = dict(n_layer_e3gnn=5, n_layer_xformer=12, n_hidden_xformer=512, n_hidden_e3nn=512, n_embd_common=512,
+                    n_head=16, n_seq=250, n_tok=4266)
 PEAK_BF16_TFLOPS = 2500.0    # dense bf16 MFMA, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
 
@@ -79,6 +83,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-mols", type=int, default=32)
     ap.add_argument("--all-sites", action="store_true", help="extra: per-site kernel time table on stderr")
+    ap.add_argument("--config", choices=["grande_closed", "coati2_shape"], default="grande_closed",
+                    help="grande_closed = the headline workload; coati2_shape = d=512 / head size 32 / 12 layers (bf16, extra)")
     ap.add_argument("--head", choices=["infonce", "barlow"], default="infonce",
                     help="contrastive head: infonce = grande_closed (the headline metric); barlow = barlow_closed (configs[3])")
     args = ap.parse_args()
@@ -100,7 +106,8 @@ def main():
     from coati_amd.synthetic import make_batch
     from coati_amd import distributed as D
 
-    eng = Engine(ModelConfig(**GRANDE), dev)
+    MODEL = GRANDE if args.config == "grande_closed" else COATI2_SHAPE
+    eng = Engine(ModelConfig(**MODEL), dev)
     # random-init weights of the grande architecture (no network for checkpoints): N(0, 0.02)-style init
     g = torch.Generator(device="cpu").manual_seed(0)
     with torch.no_grad():
@@ -113,7 +120,7 @@ def main():
             else:
                 v.zero_()
     eng.refresh_shadows()
-    batch_cpu, up_cpu = make_batch(args.batch, args.seq, args.atoms, GRANDE["n_tok"], seed=1234 + rank)
+    batch_cpu, up_cpu = make_batch(args.batch, args.seq, args.atoms, MODEL["n_tok"], seed=1234 + rank)
     batch = {k: v.to(dev) for k, v in batch_cpu.items()}
     up = up_cpu.to(dev)
 
@@ -172,6 +179,8 @@ def main():
         hbm_bound = site_bytes > 0 and (site_flops / site_bytes) < ridge
         traffic = None
         try:
+            if args.config != "grande_closed":
+                raise OSError("PMC summary was collected for the grande_closed shapes only")
             with open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")) as f:
                 traffic = json.load(f).get(args.roofline_site, {}).get("hbm_bytes_per_launch")
         except (OSError, ValueError):
@@ -185,7 +194,7 @@ def main():
                     "frac": round(tflops / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "avg_launch_ms": round(avg_ms, 5), "launches": site_n,
                     "bytes_per_launch": site_bytes, "flops_per_launch": site_flops}
         out = {
-            "metric": "molecules/sec (contrastive+AR train step), " + ("grande_closed" if args.head == "infonce" else "barlow_closed"),
+            "metric": "molecules/sec (contrastive+AR train step), " + (args.config if args.config != "grande_closed" else ("grande_closed" if args.head == "infonce" else "barlow_closed")),
             "value": round(mols / dt, 2),
             "unit": "molecules/s",
             "n_gpus": world,
@@ -197,14 +206,15 @@ def main():
             "vs_baseline": None,
             "dtype": "bf16",
             "data": "synthetic",
-            "config": {"workload": f"grande_closed d=256 L=16 nh=16 + E3GNN h=256x5, V=10322, batch {args.batch}/GPU, "
+            "config": {"workload": (f"grande_closed d=256 L=16 nh=16 + E3GNN h=256x5, V=10322" if args.config == "grande_closed" else
+                                    f"coati2_shape d=512 L=12 nh=16 (head size 32) + E3GNN h=512x5, V=4266 (parity unpinned)") + f", batch {args.batch}/GPU, "
                                    f"seq_len {args.seq}, {args.atoms}-atom point clouds, InfoNCE + AR loss, bf16 MFMA operands / "
                                    f"fp32 accumulate + fp32 master weights, random-init weights",
                        "global_batch": args.batch * world, "seq_len": args.seq, "parallelism": f"dp{world}"},
             "loss": {k: round(v, 4) for k, v in losses.items() if k in ("ar_loss", "clip_loss", "loss")},
             "roofline": roof,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.config == "grande_closed":
             out["cpu_baseline"] = cpu_baseline(batch_cpu, up_cpu, args.cpu_mols)
         print(json.dumps(out), flush=True)
     if dist_on:
