@@ -727,7 +727,7 @@ int coati_engine_forward(coati_engine* e, void* workspace, int64_t workspace_byt
   COATI_CHECK_ARG(workspace && raw_tokens && tokens && atoms && coords && use_point && scal, "engine_forward: null argument");
   COATI_CHECK_ARG(!train || (e->G && y_next), "engine_forward: training needs grads and y_next");
   const coati_config& c = e->cfg;
-  COATI_CHECK_SHAPE(B > 0 && T1 > 0 && T2 > 0 && A > 1 && T1 <= c.n_seq && T2 <= c.n_seq,
+  COATI_CHECK_SHAPE(B > 0 && T1 > 0 && T2 > 0 && A > 0 && T1 <= c.n_seq && T2 <= c.n_seq,
                     "engine_forward: unsupported shape B=%d T1=%d T2=%d A=%d (n_seq=%d)", B, T1, T2, A, c.n_seq);
   hipStream_t s = (hipStream_t)stream;
   const int C = c.n_hidden_xformer, H = c.n_hidden_e3nn, E = c.n_embd_common;
