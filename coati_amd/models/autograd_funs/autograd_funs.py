@@ -1,27 +1,26 @@
-"""Differentiable all-gather with the reference's interface (coati/models/autograd_funs/autograd_funs.py:5-25):
-forward = all_gather + rank-major cat, backward = reduce_scatter(sum) of the fp32 gradient chunks.
-Pure torch.distributed (RCCL on the GPUs, gloo in the CPU tests); one collective each way instead of the
-reference's per-rank tensor list."""
+"""Differentiable all-gather behind the reference's import path and names (coati/models/autograd_funs/
+autograd_funs.py:5-25).  The collectives themselves live in coati_amd.distributed (one all_gather_into_tensor forward,
+one reduce_scatter_tensor backward -- RCCL on the GPUs, gloo in the CPU tests); this module only adapts them to
+torch.autograd so that code written against the reference (`from coati.models.autograd_funs.autograd_funs import
+all_gather`) keeps working."""
 import torch
-import torch.distributed as dist
+
+from ...distributed import all_gather_cat, reduce_scatter_sum
 
 
 class AllGatherFunction(torch.autograd.Function):
+    """forward: rows of every rank, rank-major; backward: this rank's row block of the summed gradient (fp32 on the
+    wire unless `reduce_dtype` says otherwise, cast back to the incoming gradient's dtype)."""
+
     @staticmethod
     def forward(ctx, tensor: torch.Tensor, reduce_dtype: torch.dtype = torch.float32):
-        ctx.reduce_dtype = reduce_dtype
-        W = dist.get_world_size()
-        out = torch.empty((W * tensor.shape[0],) + tuple(tensor.shape[1:]), dtype=tensor.dtype, device=tensor.device)
-        dist.all_gather_into_tensor(out, tensor.contiguous())
-        return out
+        ctx.wire_dtype = reduce_dtype
+        return all_gather_cat(tensor)
 
     @staticmethod
     def backward(ctx, grad_output: torch.Tensor):
-        W = dist.get_world_size()
-        g = grad_output.to(ctx.reduce_dtype).contiguous()
-        out = torch.empty((g.shape[0] // W,) + tuple(g.shape[1:]), dtype=g.dtype, device=g.device)
-        dist.reduce_scatter_tensor(out, g, op=dist.ReduceOp.SUM)
-        return out.to(grad_output.dtype), None
+        local = reduce_scatter_sum(grad_output.to(ctx.wire_dtype))
+        return local.to(grad_output.dtype), None
 
 
 def all_gather(tensor):
