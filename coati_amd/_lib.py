@@ -46,6 +46,8 @@ _SIGS = {
     "coati_engine_decode_begin": [P, P, L, I, I],
     "coati_engine_decode_step": [P, P, P, P, L, P],
     "coati_engine_decode_pos": [P],
+    "coati_engine_decode_graph_build": [P, P],
+    "coati_engine_decode_graph_step": [P, P, P, P, P, P],
     "coati_batch_ncols": [P, I, I, P, P],
     "coati_batch_tail": [P, I, I, I, P, P, P, I, P],
     "coati_gnn_embed": [P, P, P, P, P, P, P, L, P, P, I, I, P],

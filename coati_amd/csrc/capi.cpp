@@ -118,10 +118,10 @@ int coati_bad_rows(const int64_t* tokens, uint8_t* bad, int B, int T, void* stre
 }
 int coati_silu(const float* x, float* y, int64_t n, void* stream) { return launch_silu_fwd(x, y, n, S_(stream)); }
 int coati_attn_decode(const uint16_t* qkv, uint16_t* cache, uint16_t* y, int B, int n_head, int Tmax, int pos, void* stream) {
-  return launch_attn_decode(qkv, cache, y, B, n_head, 16, Tmax, pos, S_(stream));
+  return launch_attn_decode(qkv, cache, y, B, n_head, 16, Tmax, pos, nullptr, S_(stream));
 }
 int coati_attn_decode_hs(const uint16_t* qkv, uint16_t* cache, uint16_t* y, int B, int n_head, int head_size, int Tmax, int pos, void* stream) {
-  return launch_attn_decode(qkv, cache, y, B, n_head, head_size, Tmax, pos, S_(stream));
+  return launch_attn_decode(qkv, cache, y, B, n_head, head_size, Tmax, pos, nullptr, S_(stream));
 }
 int coati_topk_sample(const float* logits, int64_t ldl, int B, int V, int k, float inv_temp, const float* u,
                       int64_t* tokens_out, int32_t* stopped, int stop_token, int pad_token, void* stream) {

@@ -18,7 +18,9 @@ __device__ __forceinline__ void load_bf16(const bf16_t* p, float* x) {
 // One wave per (b, head).  Appends (k, v) at position pos, attends to positions 0..pos.
 template <int DHS>
 __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ cache,
-                                                          bf16_t* __restrict__ y, int B, int n_head, int Tmax, int pos) {
+                                                          bf16_t* __restrict__ y, int B, int n_head, int Tmax, int pos_arg,
+                                                          const int* __restrict__ pos_dev) {
+  const int pos = pos_dev ? *pos_dev : pos_arg;
   const int lane = threadIdx.x & 63;
   const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (item >= B * n_head) return;
@@ -84,14 +86,23 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
   }
 }
 
-int launch_attn_decode(const bf16_t* qkv, bf16_t* cache, bf16_t* y, int B, int n_head, int head_size, int Tmax, int pos, hipStream_t s) {
+__global__ void add_int_kernel(int* x, int v, int set) { *x = set ? v : *x + v; }
+// set != 0: *x = v; else *x += v   (the decode position lives in device memory for graph replay)
+int launch_add_int(int* x, int v, int set, hipStream_t s) {
+  hipLaunchKernelGGL(add_int_kernel, dim3(1), dim3(1), 0, s, x, v, set);
+  COATI_LAUNCH_CHECK("add_int");
+  return COATI_OK;
+}
+
+int launch_attn_decode(const bf16_t* qkv, bf16_t* cache, bf16_t* y, int B, int n_head, int head_size, int Tmax, int pos,
+                       const int* pos_dev, hipStream_t s) {
   COATI_CHECK_ARG(qkv && cache && y, "attn_decode: null operand");
   COATI_CHECK_SHAPE(B > 0 && n_head > 0 && Tmax > 0 && Tmax <= 256 && pos >= 0 && pos < Tmax && (head_size == 16 || head_size == 32),
                     "attn_decode: unsupported shape B=%d nh=%d hs=%d Tmax=%d pos=%d", B, n_head, head_size, Tmax, pos);
   if (head_size == 16)
-    hipLaunchKernelGGL(attn_decode_kernel<16>, dim3(cdiv(B * n_head, 4)), dim3(256), 0, s, qkv, cache, y, B, n_head, Tmax, pos);
+    hipLaunchKernelGGL(attn_decode_kernel<16>, dim3(cdiv(B * n_head, 4)), dim3(256), 0, s, qkv, cache, y, B, n_head, Tmax, pos, pos_dev);
   else
-    hipLaunchKernelGGL(attn_decode_kernel<32>, dim3(cdiv(B * n_head, 4)), dim3(256), 0, s, qkv, cache, y, B, n_head, Tmax, pos);
+    hipLaunchKernelGGL(attn_decode_kernel<32>, dim3(cdiv(B * n_head, 4)), dim3(256), 0, s, qkv, cache, y, B, n_head, Tmax, pos, pos_dev);
   COATI_LAUNCH_CHECK("attn_decode");
   return COATI_OK;
 }

@@ -154,6 +154,13 @@ struct coati_engine {
     bf16_t* cache = nullptr;   // [L][B][nh][Tmax][k16|v16]
     float *x = nullptr, *xmid = nullptr, *xn = nullptr, *mean = nullptr, *rstd = nullptr;
     bf16_t *a = nullptr, *qkv = nullptr, *y = nullptr, *hpre = nullptr, *g = nullptr, *af = nullptr;
+    // graph replay: position, input tokens / injection and logits live at fixed device addresses
+    int* pos_dev = nullptr;
+    long long* tok_dev = nullptr;
+    float* inj_dev = nullptr;
+    float* logits_dev = nullptr;
+    int64_t ldl = 0;
+    hipGraphExec_t graph[2] = {nullptr, nullptr};   // [0] tokens only, [1] tokens + injection
   } dec;
   double prof_bytes = 0.0;   // algorithmic HBM bytes (operands read once, results written once) of the selected site
 };
@@ -655,6 +662,8 @@ int coati_engine_create(const coati_config* cfg, coati_engine** out) {
 
 void coati_engine_destroy(coati_engine* e) {
   if (!e) return;
+  for (auto& g : e->dec.graph)
+    if (g) hipGraphExecDestroy(g);
   for (auto ev : e->ev) hipEventDestroy(ev);
   if (e->ev_fork) hipEventDestroy(e->ev_fork);
   if (e->ev_join) hipEventDestroy(e->ev_join);
@@ -967,6 +976,8 @@ const char* coati_engine_site_name(int site) { return (site >= 0 && site < SITE_
 
 }  // extern "C"
 
+namespace { void decode_drop_graphs(coati_engine* e); }
+
 // ---- inference: KV-cached decode (reference smiles_xformer.py:272-351 + xformer_blocks) ----------------
 namespace {
 size_t decode_carve(coati_engine* e, Arena& ar, int B, int Tmax) {
@@ -978,6 +989,11 @@ size_t decode_carve(coati_engine* e, Arena& ar, int B, int Tmax) {
   d.mean = ar.take<float>(B); d.rstd = ar.take<float>(B);
   d.a = ar.take<bf16_t>(B * C); d.qkv = ar.take<bf16_t>(B * 3 * C); d.y = ar.take<bf16_t>(B * C);
   d.hpre = ar.take<bf16_t>(B * 4 * C); d.g = ar.take<bf16_t>(B * 4 * C); d.af = ar.take<bf16_t>(B * C);
+  d.pos_dev = ar.take<int>(4);
+  d.tok_dev = ar.take<long long>(B);
+  d.inj_dev = ar.take<float>(B * C);
+  d.ldl = ((int64_t)c.n_tok + 7) / 8 * 8;
+  d.logits_dev = ar.take<float>((size_t)B * d.ldl);
   return (ar.off + 255) & ~(size_t)255;
 }
 }  // namespace
@@ -997,6 +1013,7 @@ int coati_engine_decode_begin(coati_engine* e, void* workspace, int64_t ws_bytes
   COATI_CHECK_ARG(e && workspace && e->P && e->S, "decode_begin: engine not bound / null workspace");
   COATI_CHECK_SHAPE(B > 0 && Tmax > 0 && Tmax <= e->cfg.n_seq && Tmax <= 256, "decode_begin: bad shape B=%d Tmax=%d (n_seq=%d)", B, Tmax, e->cfg.n_seq);
   COATI_CHECK_SHAPE(ws_bytes >= coati_engine_decode_workspace_bytes(e, B, Tmax), "decode_begin: workspace too small");
+  decode_drop_graphs(e);   // a captured graph bakes the previous session's buffer addresses in
   Arena ar{reinterpret_cast<char*>(workspace), 0, (size_t)ws_bytes, false};
   decode_carve(e, ar, B, Tmax);
   e->dec.active = true;
@@ -1006,6 +1023,59 @@ int coati_engine_decode_begin(coati_engine* e, void* workspace, int64_t ws_bytes
 
 int coati_engine_decode_pos(coati_engine* e) { return (e && e->dec.active) ? e->dec.pos : -1; }
 
+}  // extern "C"
+
+namespace {
+// Enqueue one decode position.  graph_mode: the position comes from device memory (d.pos_dev) so that the very same
+// launch sequence can be replayed from a captured graph, and the sequence ends by incrementing it.
+int decode_enqueue(coati_engine* e, const long long* tokens, const float* injection, float* logits, int64_t ldl,
+                   bool graph_mode, hipStream_t s) {
+  auto& d = e->dec;
+  const coati_config& c = e->cfg;
+  const int C = c.n_hidden_xformer, L = c.n_layer_xformer, B = d.B, hs = C / c.n_head;
+  COATI_TRY(launch_embed_fwd(tokens, e->P + e->tok_emb, injection, c.unk_token, d.x, B, 1, C, c.n_tok, s));
+  float* x = d.x;
+  float* xm = d.xmid;
+  for (int l = 0; l < L; ++l) {
+    const XLayerP& w = e->xl[l];
+    COATI_TRY(launch_layernorm_fwd(x, C, e->P + w.ln1w, e->P + w.ln1b, d.a, C, nullptr, 0, d.mean, d.rstd, B, C, s));
+    {
+      GemmArgs a;
+      memset(&a, 0, sizeof(a));
+      a.A = d.a; a.lda = C; a.B = e->S + w.attnw; a.ldb = C; a.M = B; a.N = 3 * C; a.K = C; a.C = d.qkv; a.ldc = 3 * C;
+      a.bias = e->P + w.attnb; a.rope_hs = hs; a.rope_T = 1; a.rope_C = C;
+      if (graph_mode) {   // every row sits at token position *pos_dev
+        a.rope_cos = e->cos_t; a.rope_sin = e->sin_t; a.rope_pos = d.pos_dev;
+      } else {            // every row sits at token position pos: tables offset to that row, period 1
+        a.rope_cos = e->cos_t + (size_t)d.pos * hs; a.rope_sin = e->sin_t + (size_t)d.pos * hs;
+      }
+      COATI_TRY(launch_gemm_nt(a, 0, EPI_QKV_ROPE, s));
+    }
+    bf16_t* cache_l = d.cache + (size_t)l * B * C * d.Tmax * 2;
+    COATI_TRY(launch_attn_decode(d.qkv, cache_l, d.y, B, c.n_head, hs, d.Tmax, d.pos, graph_mode ? d.pos_dev : nullptr, s));
+    COATI_TRY(gemm(e, SITE_NONE, d.y, 0, C, e->S + w.projw, C, B, C, C, xm, C, e->P + w.projb, EPI_RES_F32, x, nullptr, C, s));
+    COATI_TRY(launch_layernorm_fwd(xm, C, e->P + w.ln2w, e->P + w.ln2b, d.a, C, nullptr, 0, d.mean, d.rstd, B, C, s));
+    COATI_TRY(gemm(e, SITE_NONE, d.a, 0, C, e->S + w.fc1w, C, B, 4 * C, C, d.g, 4 * C, e->P + w.fc1b, EPI_GELU, nullptr, d.hpre, 4 * C, s));
+    COATI_TRY(gemm(e, SITE_NONE, d.g, 0, 4 * C, e->S + w.fc2w, 4 * C, B, C, 4 * C, x, C, e->P + w.fc2b, EPI_RES_F32, xm, nullptr, C, s));
+  }
+  if (logits) {
+    COATI_TRY(launch_layernorm_fwd(x, C, e->P + e->lnfw, e->P + e->lnfb, d.af, C, nullptr, 0, d.mean, d.rstd, B, C, s));
+    COATI_TRY(gemm(e, SITE_NONE, d.af, 0, C, e->S + e->lmhead, C, B, c.n_tok, C, logits, ldl, nullptr, EPI_F32, nullptr, nullptr, 0, s));
+  }
+  if (graph_mode) COATI_TRY(launch_add_int(d.pos_dev, 1, 0, s));
+  return COATI_OK;
+}
+
+void decode_drop_graphs(coati_engine* e) {
+  for (auto& g : e->dec.graph) {
+    if (g) hipGraphExecDestroy(g);
+    g = nullptr;
+  }
+}
+}  // namespace
+
+extern "C" {
+
 // One position for every sequence: tokens[B] (ids; rows equal to the [UNK] id take their embedding from injection[B, C]
 // when it is given, smiles_xformer.py:444-448).  logits (optional) [B, n_tok] f32, row stride ldl.
 int coati_engine_decode_step(coati_engine* e, const int64_t* tokens, const float* injection, float* logits, int64_t ldl,
@@ -1014,37 +1084,61 @@ int coati_engine_decode_step(coati_engine* e, const int64_t* tokens, const float
   auto& d = e->dec;
   COATI_CHECK_SHAPE(d.pos < d.Tmax, "decode_step: the cache is full (pos=%d, Tmax=%d)", d.pos, d.Tmax);
   COATI_CHECK_ARG(!logits || ldl >= e->cfg.n_tok, "decode_step: ldl too small");
-  hipStream_t s = (hipStream_t)stream;
-  const coati_config& c = e->cfg;
-  const int C = c.n_hidden_xformer, L = c.n_layer_xformer, B = d.B;
-  COATI_TRY(launch_embed_fwd(reinterpret_cast<const long long*>(tokens), e->P + e->tok_emb, injection, c.unk_token, d.x, B, 1, C, c.n_tok, s));
-  float* x = d.x;
-  float* xm = d.xmid;
-  for (int l = 0; l < L; ++l) {
-    const XLayerP& w = e->xl[l];
-    COATI_TRY(launch_layernorm_fwd(x, C, e->P + w.ln1w, e->P + w.ln1b, d.a, C, nullptr, 0, d.mean, d.rstd, B, C, s));
-    {
-      // every row sits at token position pos: rope tables offset to that row, period 1
-      GemmArgs a;
-      memset(&a, 0, sizeof(a));
-      a.A = d.a; a.lda = C; a.B = e->S + w.attnw; a.ldb = C; a.M = B; a.N = 3 * C; a.K = C; a.C = d.qkv; a.ldc = 3 * C;
-      a.bias = e->P + w.attnb; a.rope_hs = C / c.n_head;
-      a.rope_cos = e->cos_t + (size_t)d.pos * a.rope_hs; a.rope_sin = e->sin_t + (size_t)d.pos * a.rope_hs;
-      a.rope_T = 1; a.rope_C = C;
-      COATI_TRY(launch_gemm_nt(a, 0, EPI_QKV_ROPE, s));
-    }
-    bf16_t* cache_l = d.cache + (size_t)l * B * C * d.Tmax * 2;
-    COATI_TRY(launch_attn_decode(d.qkv, cache_l, d.y, B, c.n_head, C / c.n_head, d.Tmax, d.pos, s));
-    COATI_TRY(gemm(e, SITE_NONE, d.y, 0, C, e->S + w.projw, C, B, C, C, xm, C, e->P + w.projb, EPI_RES_F32, x, nullptr, C, s));
-    COATI_TRY(launch_layernorm_fwd(xm, C, e->P + w.ln2w, e->P + w.ln2b, d.a, C, nullptr, 0, d.mean, d.rstd, B, C, s));
-    COATI_TRY(gemm(e, SITE_NONE, d.a, 0, C, e->S + w.fc1w, C, B, 4 * C, C, d.g, 4 * C, e->P + w.fc1b, EPI_GELU, nullptr, d.hpre, 4 * C, s));
-    COATI_TRY(gemm(e, SITE_NONE, d.g, 0, 4 * C, e->S + w.fc2w, 4 * C, B, C, 4 * C, x, C, e->P + w.fc2b, EPI_RES_F32, xm, nullptr, C, s));
-  }
+  COATI_TRY(decode_enqueue(e, reinterpret_cast<const long long*>(tokens), injection, logits, ldl, false, (hipStream_t)stream));
   d.pos += 1;
-  if (logits) {
-    COATI_TRY(launch_layernorm_fwd(x, C, e->P + e->lnfw, e->P + e->lnfb, d.af, C, nullptr, 0, d.mean, d.rstd, B, C, s));
-    COATI_TRY(gemm(e, SITE_NONE, d.af, 0, C, e->S + e->lmhead, C, B, c.n_tok, C, logits, ldl, nullptr, EPI_F32, nullptr, nullptr, 0, s));
+  return COATI_OK;
+}
+
+// Capture the decode step (embedding .. logits + position increment, ~115 launches) into two HIP graphs (without / with
+// the [UNK]-slot injection).  The launch-bound small-batch step then costs one hipGraphLaunch.  Call after decode_begin;
+// a dry, un-captured step runs first so that every one-time kernel attribute is set outside the capture (it writes the
+// cache slot of the CURRENT position, which the next real step overwrites).
+int coati_engine_decode_graph_build(coati_engine* e, void* stream) {
+  COATI_CHECK_ARG(e && e->dec.active, "decode_graph_build: no decode session");
+  auto& d = e->dec;
+  hipStream_t s = (hipStream_t)stream;
+  COATI_CHECK_ARG(s != nullptr, "decode_graph_build: graph capture needs an explicit (non-default) stream");
+  decode_drop_graphs(e);
+  HIPCHK(hipMemsetAsync(d.tok_dev, 0, sizeof(long long) * d.B, s));
+  HIPCHK(hipMemsetAsync(d.inj_dev, 0, sizeof(float) * d.B * e->cfg.n_hidden_xformer, s));
+  COATI_TRY(decode_enqueue(e, d.tok_dev, d.inj_dev, d.logits_dev, d.ldl, false, s));
+  HIPCHK(hipStreamSynchronize(s));
+  for (int v = 0; v < 2; ++v) {
+    hipGraph_t g = nullptr;
+    HIPCHK(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
+    const int rc = decode_enqueue(e, d.tok_dev, v ? d.inj_dev : nullptr, d.logits_dev, d.ldl, true, s);
+    hipError_t ee = hipStreamEndCapture(s, &g);
+    if (rc != COATI_OK) { if (g) hipGraphDestroy(g); return rc; }
+    if (ee != hipSuccess || !g) {
+      coati_set_error("decode_graph_build: capture failed: %s", hipGetErrorString(ee));
+      return COATI_EHIP;
+    }
+    ee = hipGraphInstantiate(&d.graph[v], g, nullptr, nullptr, 0);
+    hipGraphDestroy(g);
+    if (ee != hipSuccess) {
+      coati_set_error("decode_graph_build: hipGraphInstantiate failed: %s", hipGetErrorString(ee));
+      return COATI_EHIP;
+    }
   }
+  return COATI_OK;
+}
+
+// Replay: tokens[B] / injection[B, C] are copied to the graph's fixed input buffers, the graph runs one position and
+// leaves the logits in the session's own buffer (*logits_out, row stride *ldl_out; valid until the next step).
+int coati_engine_decode_graph_step(coati_engine* e, const int64_t* tokens, const float* injection, float** logits_out,
+                                   int64_t* ldl_out, void* stream) {
+  COATI_CHECK_ARG(e && e->dec.active && tokens && logits_out && ldl_out, "decode_graph_step: no decode session / null argument");
+  auto& d = e->dec;
+  COATI_CHECK_ARG(d.graph[0] && d.graph[1], "decode_graph_step: call coati_engine_decode_graph_build first");
+  COATI_CHECK_SHAPE(d.pos < d.Tmax, "decode_graph_step: the cache is full (pos=%d, Tmax=%d)", d.pos, d.Tmax);
+  hipStream_t s = (hipStream_t)stream;
+  HIPCHK(hipMemcpyAsync(d.tok_dev, tokens, sizeof(long long) * d.B, hipMemcpyDeviceToDevice, s));
+  if (injection) HIPCHK(hipMemcpyAsync(d.inj_dev, injection, sizeof(float) * d.B * e->cfg.n_hidden_xformer, hipMemcpyDeviceToDevice, s));
+  COATI_TRY(launch_add_int(d.pos_dev, d.pos, 1, s));   // keeps the device position in step with the host's (eager steps may have run)
+  HIPCHK(hipGraphLaunch(d.graph[injection ? 1 : 0], s));
+  d.pos += 1;
+  *logits_out = d.logits_dev;
+  *ldl_out = d.ldl;
   return COATI_OK;
 }
 

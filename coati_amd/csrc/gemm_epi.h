@@ -102,7 +102,7 @@ __device__ __forceinline__ void epilogue8(const GemmArgs& p, int row, int col0, 
     // RotaryEmbedding.rotary_embed (basic_transformer.py:83-100): y_i = x_i c_i - x_{i+h} s_i ; y_{i+h} = x_{i+h} c_i + x_i s_i
     const bool hs32 = p.rope_hs == 32;
     const bool hi_half = (col0 & (hs32 ? 16 : 8)) != 0;
-    const int t = row % p.rope_T;
+    const int t = p.rope_pos ? *p.rope_pos : row % p.rope_T;
     const bool rot = col0 < 2 * p.rope_C;
     const int tab = hs32 ? t * 32 + (col0 & 8) : t * 16;   // tables are [n_seq, hs] with entries i and i + hs/2 equal
 #pragma unroll

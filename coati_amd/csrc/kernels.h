@@ -55,6 +55,7 @@ struct GemmArgs {
   int rope_T;
   int rope_C;
   int rope_hs;
+  const int* rope_pos;   // decode: when set, EVERY row sits at token position *rope_pos (device memory; graph replay)
 };
 
 int launch_gemm_nt(const GemmArgs& a, int a_f32, int epi, hipStream_t s);
@@ -119,7 +120,10 @@ int launch_scatter_rows_add(const float* dout, const int* pos, float* dx, int B,
 // bad[b] = sum_t tokens[b,t] < 1
 int launch_bad_rows(const long long* tokens, unsigned char* bad, int B, int T, hipStream_t s);
 // inference decode (decode.hip)
-int launch_attn_decode(const bf16_t* qkv, bf16_t* cache, bf16_t* y, int B, int n_head, int head_size, int Tmax, int pos, hipStream_t s);
+// pos_dev: optional device pointer holding the position (overrides pos): lets a captured graph be replayed step after step
+int launch_attn_decode(const bf16_t* qkv, bf16_t* cache, bf16_t* y, int B, int n_head, int head_size, int Tmax, int pos,
+                       const int* pos_dev, hipStream_t s);
+int launch_add_int(int* x, int v, int set, hipStream_t s);
 int launch_topk_sample(const float* logits, long long ldl, int B, int V, int k, float inv_temp, const float* u,
                        long long* tok_out, int* stopped, int stop_token, int pad_token, hipStream_t s);
 // batch tail (batch.hip)

@@ -211,9 +211,11 @@ class Engine:
         self._dec_B = int(B)
         _lib.check(self.l.coati_engine_decode_begin(self.h, ctypes.c_void_p(self._dec_ws.data_ptr()), n, int(B), Tmax), "decode_begin")
 
-    def decode_step(self, tokens, injection=None, want_logits=True):
+    def decode_step(self, tokens, injection=None, want_logits=True, graph=False):
         """Append one position: tokens [B] int64 (rows equal to the [UNK] id read `injection` [B, C] instead of the
-        embedding table).  Returns logits [B, n_tok] f32 or None."""
+        embedding table).  Returns logits [B, n_tok] f32 or None.  graph=True replays the captured HIP graph
+        (decode_graph_build first; must run on a non-default stream); the logits are then a view into the session's
+        buffer, valid until the next step."""
         B = self._dec_B
         tokens = tokens.to(self.device, torch.long).contiguous()
         assert tokens.shape == (B,)
@@ -222,13 +224,34 @@ class Engine:
             inj = injection.to(self.device, torch.float32).contiguous()
             assert inj.shape == (B, self.cfg.n_hidden_xformer)
         V = self.cfg.n_tok
+        if graph:
+            lp, ld = ctypes.c_void_p(), ctypes.c_int64()
+            _lib.check(self.l.coati_engine_decode_graph_step(self.h, ptr(tokens), ptr(inj), ctypes.byref(lp), ctypes.byref(ld), stream()),
+                       "decode_graph_step")
+            off = lp.value - self._dec_ws.data_ptr()
+            return self._dec_ws[off: off + B * ld.value * 4].view(torch.float32).view(B, ld.value)[:, :V]
         ld = (V + 7) // 8 * 8          # f32 rows 16-B aligned for the GEMM epilogue's float4 stores
         logits = torch.empty(B, ld, device=self.device, dtype=torch.float32) if want_logits else None
         _lib.check(self.l.coati_engine_decode_step(self.h, ptr(tokens), ptr(inj), ptr(logits), ld, stream()), "decode_step")
         return logits[:, :V] if want_logits else None
 
+    def decode_graph_build(self):
+        """Capture the decode step into HIP graphs (call inside `with torch.cuda.stream(side_stream)`)."""
+        _lib.check(self.l.coati_engine_decode_graph_build(self.h, stream()), "decode_graph_build")
+
     def generate_top_k_with_inj_batch(self, prefix, stop_token, pad_token=0, inv_temp=1.0, k=50, inj_token=None,
-                                      inj_payload=None, as_tensor=False, generator=None):
+                                      inj_payload=None, as_tensor=False, generator=None, use_graph=False):
+        """See _generate; runs on a private stream so that the decode step can be replayed from a captured HIP graph
+        (use_graph=True).  Measured: replay == eager (the step is bound by the ~6 us device-side cost of each of its ~115
+        dependent kernels, not by host launch overhead), so eager is the default."""
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(side):
+            out = self._generate(prefix, stop_token, pad_token, inv_temp, k, inj_token, inj_payload, as_tensor, generator, use_graph)
+        torch.cuda.current_stream(self.device).wait_stream(side)
+        return out
+
+    def _generate(self, prefix, stop_token, pad_token, inv_temp, k, inj_token, inj_payload, as_tensor, generator, use_graph):
         """RotarySmilesTransformer.generate_top_k_with_inj_batch (smiles_xformer.py:272-351) on the KV-cached decode
         path: same arguments, same stopping rules (stopped rows emit pad_token, rows that never stop get a final
         stop_token), sampling = softmax(top-k logits * inv_temp) drawn with uniforms from `generator`."""
@@ -238,12 +261,14 @@ class Engine:
             raise NotImplementedError("the injection slot must be the engine's [UNK] id")
         n_seq = self.cfg.n_seq
         self.decode_begin(B, n_seq)
+        if use_graph:
+            self.decode_graph_build()
         dev = self.device
         logits = None
         for i, t in enumerate(prefix):
             tok = torch.full((B,), t, dtype=torch.long, device=dev)
             logits = self.decode_step(tok, inj_payload if (inj_token is not None and t == int(inj_token)) else None,
-                                      want_logits=(i == len(prefix) - 1))
+                                      want_logits=(i == len(prefix) - 1), graph=use_graph)
         stopped = torch.zeros(B, dtype=torch.int32, device=dev)
         generated = []
         idx = 0
@@ -256,7 +281,7 @@ class Engine:
             idx += 1
             if int(stopped.sum().item()) >= B or idx >= n_seq - len(prefix):
                 break
-            logits = self.decode_step(nxt)
+            logits = self.decode_step(nxt, graph=use_graph)
         gen = torch.stack(generated, dim=1)
         not_stopped = stopped == 0
         if bool(not_stopped.any()):

@@ -261,6 +261,13 @@ int coati_engine_decode_begin(coati_engine* e, void* workspace, int64_t ws_bytes
 int coati_engine_decode_step(coati_engine* e, const int64_t* tokens, const float* injection, float* logits, int64_t ldl,
                              void* stream);
 int coati_engine_decode_pos(coati_engine* e);
+/* the same step captured into HIP graphs (one hipGraphLaunch instead of ~115 kernel launches; pays off at small batch).
+   graph_build: after decode_begin, on an explicit stream.  graph_step: tokens[B] / injection[B, C] (device) are copied
+   into the session's fixed input buffers; *logits_out points at the session's logits [B, n_tok] (row stride *ldl_out),
+   valid until the next step.  Eager and graph steps may be mixed. */
+int coati_engine_decode_graph_build(coati_engine* e, void* stream);
+int coati_engine_decode_graph_step(coati_engine* e, const int64_t* tokens, const float* injection, float** logits_out,
+                                   int64_t* ldl_out, void* stream);
 const char* coati_engine_site_name(int site);
 
 /* ---- host-side trie tokenizer (reference tokenizers/trie.py:39-214, trie_tokenizer.py:48-109) ---------

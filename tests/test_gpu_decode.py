@@ -118,3 +118,24 @@ def test_model_api_hclip_to_2d_batch():
     assert len(toks) == 5 and all(len(t) <= 24 for t in toks)
     assert all(t[:3] == [tk.clip_token, tk.unk_token, tk.smiles_token] for t in toks)
     assert all(tk.stop_token in t for t in toks)
+
+
+def test_graph_replay_equals_eager_decode(small_engine):
+    """The captured-HIP-graph decode step (one hipGraphLaunch per position) produces the same logits as the eager launch
+    sequence, position after position, including the [UNK]-slot injection; eager and graph steps can be mixed."""
+    eng, g = small_engine
+    toks = torch.from_numpy(g["gen_tokens"]).to(DEV)
+    payload = torch.from_numpy(g["gen_payload"]).to(DEV)
+    B, T = toks.shape
+    eng.decode_begin(B, T)
+    eager = [eng.decode_step(toks[:, t].contiguous(), payload if t == 1 else None).clone() for t in range(T)]
+    side = torch.cuda.Stream(device=DEV)
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        eng.decode_begin(B, T)
+        eng.decode_graph_build()
+        for t in range(T):
+            use_graph = t != 5                      # one eager step in the middle: positions stay in step
+            lg = eng.decode_step(toks[:, t].contiguous(), payload if t == 1 else None, graph=use_graph)
+            assert torch.equal(lg, eager[t]), t
+    torch.cuda.current_stream().wait_stream(side)

@@ -28,6 +28,16 @@ for t in range(T):
     torch.cuda.synchronize(); times.append(time.perf_counter() - t0)
 print(f"B={B}: decode step at pos 1 / 40 / 79: {times[1]*1e3:.3f} / {times[40]*1e3:.3f} / {times[79]*1e3:.3f} ms; "
       f"{B * (T - 1) / sum(times[1:]):.0f} tokens/s over {T} positions (logits [B, 10322] f32 every step)")
+side = torch.cuda.Stream()
+with torch.cuda.stream(side):
+    eng.decode_begin(B, T)
+    eng.decode_graph_build()
+    gt = []
+    for t in range(T):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        lg = eng.decode_step(tok, graph=True)
+        torch.cuda.synchronize(); gt.append(time.perf_counter() - t0)
+print(f"B={B}: graph-replayed decode step at pos 1 / 40 / 79: {gt[1]*1e3:.3f} / {gt[40]*1e3:.3f} / {gt[79]*1e3:.3f} ms; {B * (T - 1) / sum(gt[1:]):.0f} tokens/s")
 payload = torch.randn(B, 256, device=dev)
 torch.cuda.synchronize(); t0 = time.perf_counter()
 out = eng.generate_top_k_with_inj_batch(prefix=[8, 7, 2], stop_token=1, pad_token=0, inv_temp=2.0, k=100, inj_token=7,
