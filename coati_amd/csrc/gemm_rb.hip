@@ -19,13 +19,15 @@
 #include "gemm_epi.h"
 
 #define RB_K 256
-#define RB_BN 64
-#define RB_TILE_HALFS (RB_BN * RB_K)      // 32 KiB per tile: [64 cols][256 k], unpadded, chunk-swizzled
-#define RB_EPITCH 68                      // floats per row of the per-wave transpose region
-#define RB_EFLOATS (16 * RB_EPITCH)       // 4,352 B per wave: 16 rows x 64 columns
+// Two shapes of the same kernel (template BN, MAXW):
+//   BN = 64, up to 10 waves, ONE workgroup per CU  -- fewest barriers (default);
+//   BN = 32, 5 waves, TWO workgroups per CU        -- the two workgroups' MFMA / epilogue phases interleave
+//                                                     (COATI_RB_SPLIT=1; A/B in DESIGN.md).
+#define RB_EFLOATS_MAX (16 * 68)          // per-wave transpose region, floats (16 rows x (BN + 4))
 #define RB_ROPE_FLOATS (32 * 16)          // 2 KiB per wave: [32 rows][8 cos | 8 sin]
 #define RB_AUX_BYTES 4096                 // per wave: the 32 x 64 bf16 block of saved pre-activations of the current tile
 #define RB_MAX_W 10
+#define RB_SPLIT_W 5
 #ifndef RB_PD
 #define RB_PD 3                           // LDS read pipeline depth of the MFMA loop
 #endif
@@ -35,8 +37,14 @@ __device__ __forceinline__ void rb_call_restrict(F&& f, int j, const bf16_t* __r
   f(j, cur, nxt);
 }
 
-template <int EPI>
-__global__ __launch_bounds__(64 * RB_MAX_W) void gemm_rb256_kernel(GemmArgs p, int W) {
+template <int EPI, int RB_BN, int MAXW>
+__global__ __launch_bounds__(64 * MAXW, 640 / (64 * MAXW)) void gemm_rb256_kernel(GemmArgs p, int W) {
+  constexpr int NACC = RB_BN / 32;                 // 32-column accumulator blocks per wave per tile
+  constexpr int RB_TILE_HALFS = RB_BN * RB_K;      // [BN cols][256 k] bf16, unpadded, chunk-swizzled
+  constexpr int RB_EPITCH = RB_BN + 4;             // floats per row of the per-wave transpose region
+  constexpr int RB_EFLOATS = 16 * RB_EPITCH;       // 16 rows x BN columns
+  constexpr int CGS = RB_BN / 8;                   // 8-column groups per row
+  constexpr int TPH = 16 * CGS / 64;               // epilogue tasks per lane per 16-row half (2 or 1)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   bf16_t* const Bs = reinterpret_cast<bf16_t*>(smem);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -78,7 +86,7 @@ __global__ __launch_bounds__(64 * RB_MAX_W) void gemm_rb256_kernel(GemmArgs p, i
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int k = wave + W * i;            // wave-uniform: which 1-KiB piece (two rows) of the tile
-      if (k < 32) {
+      if (k < RB_BN / 2) {
         const int r = 2 * k + (lane >> 5), q = lane & 31;
         const int g = n0 + r, gc = g < p.N ? g : p.N - 1;
         const bf16_t* src = p.B + (long long)gc * p.ldb + ((q ^ (r & 31)) * 8);
@@ -91,8 +99,8 @@ __global__ __launch_bounds__(64 * RB_MAX_W) void gemm_rb256_kernel(GemmArgs p, i
   // is consumed after the MFMA phase of the same tile, behind the same vmcnt(0) as the next weight tile.
   auto load_aux = [&](int n0) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int t = lane + 64 * i, row = m0 + (t >> 3), col = n0 + (t & 7) * 8;
+    for (int i = 0; i < 2 * TPH; ++i) {
+      const int t = lane + 64 * i, row = m0 + t / CGS, col = n0 + (t % CGS) * 8;
       const int rc = row < p.M ? row : p.M - 1, cc = col + 8 <= p.N ? col : 0;
       const bf16_t* src = reinterpret_cast<const bf16_t*>(p.aux_in) + (long long)rc * p.ld_aux + cc;
       __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(Xs + i * 1024), 16, 0, 0);
@@ -104,8 +112,9 @@ __global__ __launch_bounds__(64 * RB_MAX_W) void gemm_rb256_kernel(GemmArgs p, i
   q.bias = nullptr;   // folded into the accumulator initialisation below
 
   load_tile(0, Bs);
-  float bz0 = 0.f, bz1 = 0.f, bn0 = 0.f, bn1 = 0.f;
-  if (has_bias) { bz0 = bias_at(fr); bz1 = bias_at(32 + fr); }
+  float bz[NACC], bn[NACC];
+#pragma unroll
+  for (int a = 0; a < NACC; ++a) { bz[a] = has_bias ? bias_at(32 * a + fr) : 0.f; bn[a] = 0.f; }
   __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0)
   __syncthreads();
 
@@ -115,41 +124,46 @@ __global__ __launch_bounds__(64 * RB_MAX_W) void gemm_rb256_kernel(GemmArgs p, i
     // reading that buffer before the barrier that ended the previous iteration.
     load_tile((j + 1) * RB_BN, nxt);
     if constexpr (AUX) load_aux(j * RB_BN);
-    if (has_bias) { bn0 = bias_at((j + 1) * RB_BN + fr); bn1 = bias_at((j + 1) * RB_BN + 32 + fr); }
+    if (has_bias) {
+#pragma unroll
+      for (int a = 0; a < NACC; ++a) bn[a] = bias_at((j + 1) * RB_BN + 32 * a + fr);
+    }
     float ew = 0.f, eb = 0.f;
     if constexpr (EDGE) {   // lane = column of this tile (clamped); written to LDS after the MFMA phase
-      const int c = j * RB_BN + lane, cc = c < p.N ? c : p.N - 1;
+      const int c = j * RB_BN + (lane % RB_BN), cc = c < p.N ? c : p.N - 1;
       ew = p.w1c[(long long)cc * p.w1c_stride];
       eb = p.b1[cc];
     }
-    f32x16 acc0, acc1;
+    f32x16 acc[NACC];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { acc0[r] = bz0; acc1[r] = bz1; }
+    for (int a = 0; a < NACC; ++a)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][r] = bz[a];
     {
-      const bf16_t* wp0 = cur + fr * RB_K;
-      const bf16_t* wp1 = wp0 + 32 * RB_K;
-      bf16x8 wa[RB_PD], wb[RB_PD];
+      const bf16_t* wp = cur + fr * RB_K;
+      bf16x8 wf[RB_PD][NACC];
 #pragma unroll
-      for (int d = 0; d < RB_PD - 1; ++d) {
-        wa[d] = *reinterpret_cast<const bf16x8*>(wp0 + (((2 * d + hk) ^ sw) * 8));
-        wb[d] = *reinterpret_cast<const bf16x8*>(wp1 + (((2 * d + hk) ^ sw) * 8));
-      }
+      for (int d = 0; d < RB_PD - 1; ++d)
+#pragma unroll
+        for (int a = 0; a < NACC; ++a) wf[d][a] = *reinterpret_cast<const bf16x8*>(wp + a * 32 * RB_K + (((2 * d + hk) ^ sw) * 8));
 #pragma unroll
       for (int ks = 0; ks < 16; ++ks) {
         if (ks + RB_PD - 1 < 16) {
           const int kn = ks + RB_PD - 1;
-          wa[kn % RB_PD] = *reinterpret_cast<const bf16x8*>(wp0 + (((2 * kn + hk) ^ sw) * 8));
-          wb[kn % RB_PD] = *reinterpret_cast<const bf16x8*>(wp1 + (((2 * kn + hk) ^ sw) * 8));
+#pragma unroll
+          for (int a = 0; a < NACC; ++a) wf[kn % RB_PD][a] = *reinterpret_cast<const bf16x8*>(wp + a * 32 * RB_K + (((2 * kn + hk) ^ sw) * 8));
         }
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks], wa[ks % RB_PD], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks], wb[ks % RB_PD], acc1, 0, 0, 0);
+#pragma unroll
+        for (int a = 0; a < NACC; ++a) acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks], wf[ks % RB_PD][a], acc[a], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);   // keep the reads ahead of the MFMAs (the scheduler sinks them otherwise)
       }
     }
     // The next tile had the whole MFMA phase to land.  Waiting HERE -- before this tile's stores are issued -- lets the
     // stores stay in flight across the barrier and through the next MFMA phase (vmcnt completes in order).
     __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0)
-    if constexpr (EDGE) { Rs[lane] = ew; Rs[64 + lane] = eb; }   // read back after the lgkmcnt(0) + wave barrier below
+    if constexpr (EDGE) {   // read back after the lgkmcnt(0) + wave barrier below
+      if (lane < RB_BN) { Rs[lane] = ew; Rs[64 + lane] = eb; }
+    }
     // wave-private transpose, rows 0-15 then 16-31 of the slab (accumulator registers 0-7 / 8-15):
     // (lane = column, registers = rows) -> rows of 64 contiguous columns
 #pragma unroll
@@ -158,13 +172,13 @@ __global__ __launch_bounds__(64 * RB_MAX_W) void gemm_rb256_kernel(GemmArgs p, i
       for (int rr = 0; rr < 8; ++rr) {
         const int r = hf * 8 + rr;
         const int row = (rr & 3) + 8 * (rr >> 2) + 4 * (lane >> 5);   // 0..15 within this half
-        Es[row * RB_EPITCH + fr] = acc0[r];
-        Es[row * RB_EPITCH + 32 + fr] = acc1[r];
+#pragma unroll
+        for (int a = 0; a < NACC; ++a) Es[row * RB_EPITCH + 32 * a + fr] = acc[a][r];
       }
       __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0)
       __builtin_amdgcn_wave_barrier();
       auto task = [&](int i) {
-        const int t = lane + 64 * i, rl = t >> 3, cg = t & 7;
+        const int t = lane + 64 * i, rl = t / CGS, cg = t % CGS;
         const int row = hf * 16 + rl;
         float v[8];
         const float4 c0 = *reinterpret_cast<const float4*>(Es + rl * RB_EPITCH + cg * 8);
@@ -172,23 +186,26 @@ __global__ __launch_bounds__(64 * RB_MAX_W) void gemm_rb256_kernel(GemmArgs p, i
         v[0] = c0.x; v[1] = c0.y; v[2] = c0.z; v[3] = c0.w; v[4] = c1.x; v[5] = c1.y; v[6] = c1.z; v[7] = c1.w;
         const void* staged = nullptr;
         if constexpr (EPI == EPI_QKV_ROPE) staged = Rs + row * 16;
-        if constexpr (AUX) staged = Xs + (size_t)(lane + 64 * (2 * hf + i)) * 16;
+        if constexpr (AUX) staged = Xs + (size_t)(lane + 64 * (TPH * hf + i)) * 16;
         if constexpr (EDGE) staged = Rs + cg * 8;
         epilogue8<EPI>(q, m0 + row, j * RB_BN + cg * 8, v, (m0 + row) < p.M, 0, 1, staged);
       };
       // light epilogues run both tasks interleaved; the heavy ones (activation maths, extra operands) one after the
       // other, or their temporaries spill (the kernel lives at the 168-VGPR limit of 3 waves per SIMD)
-      if constexpr (EPI == EPI_BF16 || EPI == EPI_F32) {
+      if constexpr (TPH == 1) {
+        task(0);
+      } else if constexpr (EPI == EPI_BF16 || EPI == EPI_F32) {
         task(0);
         task(1);
       } else {
 #pragma nounroll
-        for (int i = 0; i < 2; ++i) task(i);
+        for (int i = 0; i < TPH; ++i) task(i);
       }
       __builtin_amdgcn_wave_barrier();      // the next writes to Es stay behind these reads
     }
     __syncthreads();
-    bz0 = bn0; bz1 = bn1;
+#pragma unroll
+    for (int a = 0; a < NACC; ++a) bz[a] = bn[a];
   };
   // cur / nxt reach the tile body as __restrict__ parameters (rb_call_restrict): the compiler waits for every pending
   // global_load_lds before an LDS read it cannot prove disjoint from the DMA's target
@@ -217,25 +234,35 @@ bool gemm_rb256_supported(const GemmArgs& a, int a_f32, int epi) {
   return true;
 }
 
-template <int EPI>
-static int launch_rb_t(const GemmArgs& a, hipStream_t s) {
+template <int EPI, int BN, int MAXW>
+static int launch_rb_shape(const GemmArgs& a, int W, hipStream_t s) {
   static bool attr_set = false;
-  auto kern = gemm_rb256_kernel<EPI>;
-  const size_t lds_max = (size_t)2 * RB_TILE_HALFS * 2 + (size_t)RB_MAX_W * (RB_EFLOATS * 4 + RB_AUX_BYTES);
+  auto kern = gemm_rb256_kernel<EPI, BN, MAXW>;
+  const size_t tile_bytes = (size_t)2 * BN * RB_K * 2;              // double-buffered weight tile
+  const size_t per_wave = (size_t)16 * (BN + 4) * 4 + ((EPI == EPI_QKV_ROPE || EPI == EPI_EDGE_DPRE) ? RB_ROPE_FLOATS * 4
+                                                       : (EPI == EPI_DGELU || EPI == EPI_DSILU) ? RB_AUX_BYTES : 0);
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)(tile_bytes + MAXW * per_wave));
     if (e != hipSuccess) {
       coati_set_error("gemm_rb256: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
       return COATI_EHIP;
     }
     attr_set = true;
   }
-  const int W = rb_waves(a.M);
   const int blocks = cdiv(cdiv(a.M, 32), W);
-  const size_t lds = (size_t)2 * RB_TILE_HALFS * 2 + (size_t)W * (RB_EFLOATS * 4 + ((EPI == EPI_QKV_ROPE || EPI == EPI_EDGE_DPRE) ? RB_ROPE_FLOATS * 4 : (EPI == EPI_DGELU || EPI == EPI_DSILU) ? RB_AUX_BYTES : 0));
-  hipLaunchKernelGGL(kern, dim3(blocks), dim3(64 * W), lds, s, a, W);
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(64 * W), tile_bytes + W * per_wave, s, a, W);
   COATI_LAUNCH_CHECK("gemm_rb256");
   return COATI_OK;
+}
+
+template <int EPI>
+static int launch_rb_t(const GemmArgs& a, hipStream_t s) {
+  // COATI_RB_SPLIT=1: two 5-wave workgroups per CU on 32-column tiles instead of one 10-wave workgroup on 64-column tiles
+  static const bool split = getenv("COATI_RB_SPLIT") != nullptr && atoi(getenv("COATI_RB_SPLIT")) != 0;
+  const int W = rb_waves(a.M);
+  if (split && W == RB_MAX_W) return launch_rb_shape<EPI, 32, RB_SPLIT_W>(a, RB_SPLIT_W, s);
+  return launch_rb_shape<EPI, 64, RB_MAX_W>(a, W, s);
 }
 
 int launch_gemm_rb256(const GemmArgs& a, int epi, hipStream_t s) {
