@@ -128,6 +128,8 @@ struct coati_engine {
   float* attnD;
   float *g_DH, *g_DO;
   bf16_t *g_do2, *g_dtd, *g_du, *g_dmi, *g_ds2, *g_dpre1, *g_dP;
+  float* nce = nullptr;
+  size_t nce_cap = 0;
   float* opt_partial;
   float* ln_partial;
   ShadowJob* d_jobs = nullptr;
@@ -370,7 +372,6 @@ size_t carve(coati_engine* e, Arena& ar, int B, int T1, int T2, int A, int Bg) {
   const int C = c.n_hidden_xformer, H = c.n_hidden_e3nn, E = c.n_embd_common, Lg = c.n_layer_e3gnn;
   const size_t Mmax = (size_t)B * (T1 > T2 ? T1 : T2), M2 = (size_t)B * T2;
   const size_t BA = (size_t)B * A, Me = BA * A;
-  (void)Bg;
   carve_pass(e, ar, e->p1, B, T1);
   carve_pass(e, ar, e->p2, B, T2);
   // heads
@@ -427,6 +428,11 @@ size_t carve(coati_engine* e, Arena& ar, int B, int T1, int T2, int A, int Bg) {
     if (dj != e->d_jobs || dt != e->d_tile_start) e->jobs_uploaded = false;
     e->d_jobs = dj; e->d_tile_start = dt;
   }
+  // LAST region: InfoNCE logits of the local rows against the GLOBAL batch, [B, Bg] f32 x 2 (Bg = world_size * B at
+  // workspace-sizing time).  coati_engine_forward does not know Bg: it hands this region whatever the caller's
+  // workspace holds beyond everything above.
+  e->nce_cap = (size_t)2 * B * (Bg > B ? Bg : B);
+  e->nce = ar.take<float>(e->nce_cap);
   return (ar.off + 255) & ~(size_t)255;
 }
 
@@ -743,6 +749,7 @@ int coati_engine_forward(coati_engine* e, void* workspace, int64_t workspace_byt
   Arena ar{reinterpret_cast<char*>(workspace), 0, (size_t)workspace_bytes, false};
   const size_t need = carve(e, ar, B, T1, T2, A, B);
   COATI_CHECK_ARG((int64_t)need <= workspace_bytes, "engine_forward: workspace too small (%zu > %lld)", need, (long long)workspace_bytes);
+  if (e->nce) e->nce_cap = ((size_t)workspace_bytes - (size_t)(reinterpret_cast<char*>(e->nce) - reinterpret_cast<char*>(workspace))) / sizeof(float);
   e->B = B; e->T1 = T1; e->T2 = T2; e->A = A;
   e->p1.idx = reinterpret_cast<const long long*>(raw_tokens);
   e->p2.idx = reinterpret_cast<const long long*>(tokens);
@@ -824,10 +831,14 @@ int coati_engine_infonce(coati_engine* e, const float* S_loc, const float* C_loc
   hipStream_t s = (hipStream_t)stream;
   const int E = e->cfg.n_embd_common;
   COATI_CHECK_ARG(e->have_fwd, "engine_infonce: needs the workspace of a forward call");
-  // logits scratch lives in the (now idle) backward scratch of the decoder pass: [B, Bg] f32 x 2
-  COATI_CHECK_SHAPE((size_t)2 * B * Bg * sizeof(float) <= (size_t)e->B * (e->T1 > e->T2 ? e->T1 : e->T2) * 4 * e->cfg.n_hidden_xformer * sizeof(bf16_t),
-                    "engine_infonce: Bg=%d too large for the logits scratch", Bg);
-  float* L1 = reinterpret_cast<float*>(e->dh4);
+  // logits scratch [B, Bg] f32 x 2: the dedicated region sized at workspace time (world_size * B columns), or -- for the
+  // stand-alone clip_loss API with another batch size -- the idle backward scratch of the decoder pass
+  const size_t need = (size_t)2 * B * Bg;
+  const size_t dh4_floats = (size_t)e->B * (e->T1 > e->T2 ? e->T1 : e->T2) * 4 * e->cfg.n_hidden_xformer * sizeof(bf16_t) / sizeof(float);
+  COATI_CHECK_SHAPE(need <= e->nce_cap || need <= dh4_floats,
+                    "engine_infonce: B=%d x Bg=%d does not fit the logits scratch (workspace was sized for Bg=%zu)", B, Bg,
+                    e->nce_cap / (2 * (size_t)(e->B > 0 ? e->B : 1)));
+  float* L1 = need <= e->nce_cap ? e->nce : reinterpret_cast<float*>(e->dh4);
   float* L2 = L1 + (size_t)B * Bg;
   COATI_TRY(launch_count_valid(bad_all, Bg, scal + 4, scal + 7, s));
   // L1 = S_loc C_all^T ; L2 = C_loc S_all^T     (clip_e2e.py:36-37, local rows only)

@@ -110,7 +110,15 @@ class Engine:
 
     # ---- step pieces ---------------------------------------------------------------------------------------
     def _ensure_workspace(self, B, T1, T2, A):
-        need = int(self.l.coati_engine_workspace_bytes(self.h, B, T1, T2, A, B))
+        # Bg = columns of the InfoNCE logits: the global batch when torch.distributed is up
+        world = 1
+        try:
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized():
+                world = dist.get_world_size()
+        except Exception:
+            world = 1
+        need = int(self.l.coati_engine_workspace_bytes(self.h, B, T1, T2, A, B * world))
         if self.workspace is None or self.workspace.numel() < need:
             self.workspace = None
             self.workspace = torch.empty(need, device=self.device, dtype=torch.uint8)
