@@ -18,6 +18,7 @@
 //     in two kernels (dQ; dK+dV) -- no atomics, deterministic;
 //   * results leave a workgroup as whole 128-B row segments through a shared LDS tile (tile_put / tile_store).
 // Layout: qkv [B*T, 3C] bf16 (q | k | v, head h at columns h*HS..h*HS+HS-1), y / dy [B*T, C], lse, D [B, nh, T].
+#include <cstdlib>
 #include "kernels.h"
 
 #define LOG2E 1.4426950408889634f
@@ -427,6 +428,183 @@ __global__ __launch_bounds__(256, HS == 16 ? 3 : 2) void attn_bwd_dkv_kernel(con
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Fused backward for T <= 32 * NB (NB <= 4): ONE sweep over the (key block, query block) pairs produces dK, dV and dQ.
+// S, dP and the exponentials are evaluated once per pair in the dK/dV orientation (lane = key); dS is then dropped as
+// bf16 into a wave-private [32 keys][32 queries] LDS tile and read back TRANSPOSED (ds_read_b64_tr_b16) as the B operand
+// of dQ^T += K^T dS^T.  dQ of all NB query blocks stays in registers until the end.  All four operands are staged once.
+// ---------------------------------------------------------------------------------------------------
+#define DST_PITCH 36   // halfs per row of the dS tile (72 B); the 4 wave-private tiles alias the two output tiles
+__device__ __forceinline__ bf16x8 dst_frag(const bf16_t* tile, int base, int lane) {   // B fragment: keys base.., column q
+  typedef __attribute__((address_space(3))) v4s16a lds_v4;
+  const bf16_t* p = tile + (base + 4 * (lane >> 5) + ((lane & 15) >> 2)) * DST_PITCH + 4 * (lane & 3) + 16 * ((lane >> 4) & 1);
+  const v4s16a lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)p);
+  const v4s16a hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(p + 8 * DST_PITCH));
+  const v8s16a r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8, r);
+}
+
+template <int HS, int NB>
+__global__ __launch_bounds__(256, (HS == 16 && NB <= 3) ? 3 : 2) void attn_bwd_fused_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ y,
+                                                             const bf16_t* __restrict__ dy, const float* __restrict__ lse,
+                                                             bf16_t* __restrict__ dqkv, const float* __restrict__ cos_t,
+                                                             const float* __restrict__ sin_t, int T, int n_head, int quads) {
+  constexpr int NK = HS / 16, LIVE = HS / 2, Tp = 32 * NB;
+  constexpr float SCALE = att_scale<HS>(), SCALE_LOG2E = att_scale_log2e<HS>();
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.x / quads, hq = blockIdx.x - b * quads;
+  const int hh = hq * 4 + wave;
+  const int heads_here = (n_head - hq * 4) < 4 ? (n_head - hq * 4) : 4;
+  const int C = n_head * HS;
+  constexpr size_t pw = (size_t)3 * Tp * HS * 2 + (size_t)2 * Tp * 4;
+  unsigned char* my = smem + (size_t)wave * pw;
+  bf16_t* Qs = reinterpret_cast<bf16_t*>(my);
+  bf16_t* Ks = Qs + Tp * HS;
+  bf16_t* Gs = Ks + Tp * HS;
+  float* Ls = reinterpret_cast<float*>(Gs + Tp * HS);
+  float* Ds = Ls + Tp;
+  const long long stride = 3LL * C;
+  const bf16_t* qbase = qkv + (long long)b * T * stride + hq * 4 * HS;
+  stage4<HS>(qbase, stride, T, Tp, smem, pw, 0, heads_here, threadIdx.x);
+  stage4<HS>(qbase + C, stride, T, Tp, smem, pw, 1, heads_here, threadIdx.x);
+  {  // dO image + D[t] = sum_d dO[t,d] O[t,d]: the thread that stages a 16-B chunk of dO also fetches the same chunk of O
+     // (same coalesced pattern, in flight together with the other staging loads); the HS/8 chunk lanes of a head then
+     // add up through DPP/shuffles
+    constexpr int CPR = HS / 2, CPH = HS / 8;
+    const bf16_t* gsrc = dy + (long long)b * T * C + hq * 4 * HS;
+    const bf16_t* osrc = y + (long long)b * T * C + hq * 4 * HS;
+#pragma unroll
+    for (int task = threadIdx.x; task < Tp * CPR; task += 256) {
+      const int t = task / CPR, c = task - t * CPR, w = c / CPH;
+      uint4 g = make_uint4(0, 0, 0, 0), o = make_uint4(0, 0, 0, 0);
+      if (t < T && w < heads_here) {
+        g = *reinterpret_cast<const uint4*>(gsrc + (long long)t * C + c * 8);
+        o = *reinterpret_cast<const uint4*>(osrc + (long long)t * C + c * 8);
+      }
+      unsigned char* hw = smem + (size_t)w * pw;
+      *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(hw) + (size_t)2 * Tp * HS + t * HS + (c - w * CPH) * 8) = g;
+      float g8[8], o8[8];
+      unpack8(g, g8);
+      unpack8(o, o8);
+      float d = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) d += g8[i] * o8[i];
+      d += __shfl_xor(d, 1, 64);
+      if constexpr (CPH == 4) d += __shfl_xor(d, 2, 64);
+      if ((c & (CPH - 1)) == 0) reinterpret_cast<float*>(hw + (size_t)3 * Tp * HS * 2)[Tp + t] = d;
+    }
+  }
+  __syncthreads();
+  const bool active = hh < n_head;
+  const int hc = active ? hh : 0;
+  unsigned char* const otile = smem + 4 * pw;   // two tiles (dK | dV, then dQ); during a sweep they hold the dS tiles
+  static_assert(4 * 32 * DST_PITCH * 2 <= 2 * ot_bytes<HS>(), "dS tiles must fit the output tiles");
+  bf16_t* const dsT = reinterpret_cast<bf16_t*>(otile) + wave * 32 * DST_PITCH;
+  const bf16_t* vsrc = qkv + (long long)b * T * stride + 2 * C + hc * HS;
+  // log-sum-exp of this head's rows, pre-multiplied by log2(e) (rows >= T: +inf -> p = 0)
+  for (int t = lane; t < Tp; t += 64) Ls[t] = (t < T) ? lse[((long long)b * n_head + hc) * T + t] * LOG2E : INFINITY;
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  __builtin_amdgcn_wave_barrier();
+
+  const int half = lane >> 5;
+  bf16_t* const dbase = dqkv + (long long)b * T * stride + hq * 4 * HS;
+  f32x16 dq[NB];
+#pragma unroll
+  for (int i = 0; i < NB; ++i) dq[i] = zero16();
+#pragma unroll
+  for (int kb = 0; kb < NB; ++kb) {
+    const int key = kb * 32 + (lane & 31);
+    if (active) {
+      bf16x8 kf[NK], vf[NK];
+#pragma unroll
+      for (int ks = 0; ks < NK; ++ks) {
+        kf[ks] = rfrag<HS>(Ks, kb, ks, lane);
+        vf[ks] = gfrag(vsrc, stride, kb, ks, T, lane);
+      }
+      const bf16x8 kt0 = tfrag<HS>(Ks, kb * 32, lane), kt1 = tfrag<HS>(Ks, kb * 32 + 16, lane);
+      f32x16 dk = zero16(), dv = zero16();
+#pragma unroll
+      for (int qb = kb; qb < NB; ++qb) {
+        const f32x16 s = score_block<HS>(Qs, qb, kf, lane);
+        const f32x16 dp = score_block<HS>(Gs, qb, vf, lane);
+        float p[16], ds[16];
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const int q0 = qb * 32 + 8 * g4 + 4 * half;
+          const float4 l4 = *reinterpret_cast<const float4*>(Ls + q0);
+          const float4 d4 = *reinterpret_cast<const float4*>(Ds + q0);
+          const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dvv[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int r = g4 * 4 + j, q = q0 + j;
+            p[r] = __builtin_amdgcn_exp2f(fmaf(s[r], SCALE_LOG2E, -lv[j]));
+            if (qb == kb && key > q) p[r] = 0.f;
+            ds[r] = p[r] * (dp[r] - dvv[j]);   // the softmax scale is applied once to the finished blocks
+          }
+          // dS tile: row = key (this lane), 4 consecutive queries 8*g4 + 4*half .. +3
+          *reinterpret_cast<uint2*>(dsT + (lane & 31) * DST_PITCH + 8 * g4 + 4 * half) =
+              make_uint2(pack2bf(ds[4 * g4], ds[4 * g4 + 1]), pack2bf(ds[4 * g4 + 2], ds[4 * g4 + 3]));
+        }
+        dv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tfrag<HS>(Gs, qb * 32, lane), pfrag(p), dv, 0, 0, 0);
+        dv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tfrag<HS>(Gs, qb * 32 + 16, lane), pfrag(p + 8), dv, 0, 0, 0);
+        dk = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tfrag<HS>(Qs, qb * 32, lane), pfrag(ds), dk, 0, 0, 0);
+        dk = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tfrag<HS>(Qs, qb * 32 + 16, lane), pfrag(ds + 8), dk, 0, 0, 0);
+        __builtin_amdgcn_s_waitcnt(0xc07f);   // the tile writes above are visible to the whole wave
+        __builtin_amdgcn_wave_barrier();
+        dq[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kt0, dst_frag(dsT, 0, lane), dq[qb], 0, 0, 0);
+        dq[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kt1, dst_frag(dsT, 16, lane), dq[qb], 0, 0, 0);
+        __builtin_amdgcn_wave_barrier();      // the next pair's tile writes stay behind these reads
+      }
+#pragma unroll
+      for (int r = 0; r < LIVE; ++r) dk[r] *= SCALE;
+      __syncthreads();   // every wave is done with its dS tile
+      tile_put_grad<HS>(otile, wave, lane, dk, true, cos_t, sin_t, key < T ? key : 0);
+      tile_put_grad<HS>(otile + ot_bytes<HS>(), wave, lane, dv, false, cos_t, sin_t, 0);
+    } else {
+      __syncthreads();
+    }
+    __syncthreads();
+    tile_store<HS>(otile, dbase + C, stride, kb * 32, T, heads_here, threadIdx.x);
+    tile_store<HS>(otile + ot_bytes<HS>(), dbase + 2 * C, stride, kb * 32, T, heads_here, threadIdx.x);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int qb = 0; qb < NB; ++qb) {
+    const int q = qb * 32 + (lane & 31);
+    if (active) {
+#pragma unroll
+      for (int r = 0; r < LIVE; ++r) dq[qb][r] *= SCALE;
+      tile_put_grad<HS>(otile, wave, lane, dq[qb], true, cos_t, sin_t, q < T ? q : 0);
+    }
+    __syncthreads();
+    tile_store<HS>(otile, dbase, stride, qb * 32, T, heads_here, threadIdx.x);
+    __syncthreads();
+  }
+}
+
+template <int HS, int NB>
+static int launch_attn_bwd_fused_t(const bf16_t* qkv, const bf16_t* y, const bf16_t* dy, const float* lse, bf16_t* dqkv,
+                                   const float* cos_t, const float* sin_t, int B, int T, int n_head, hipStream_t s) {
+  constexpr int Tp = 32 * NB;
+  const size_t lds = (size_t)4 * ((size_t)3 * Tp * HS * 2 + (size_t)2 * Tp * 4) + 2 * ot_bytes<HS>();
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_fused_kernel<HS, NB>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) {
+      coati_set_error("attn_bwd(fused): hipFuncSetAttribute failed");
+      return COATI_EHIP;
+    }
+    attr_set = true;
+  }
+  const int quads = cdiv(n_head, 4);
+  hipLaunchKernelGGL((attn_bwd_fused_kernel<HS, NB>), dim3(B * quads), dim3(256), lds, s, qkv, y, dy, lse, dqkv, cos_t, sin_t, T,
+                     n_head, quads);
+  COATI_LAUNCH_CHECK("attn_bwd_fused");
+  return COATI_OK;
+}
+
 template <int HS>
 static int launch_attn_bwd_t(const bf16_t* qkv, const bf16_t* y, const bf16_t* dy, const float* lse, float* dscratch,
                              bf16_t* dqkv, const float* cos_t, const float* sin_t, int B, int T, int n_head, hipStream_t s) {
@@ -460,6 +638,16 @@ int launch_attn_bwd(const bf16_t* qkv, const bf16_t* y, const bf16_t* dy, const 
   COATI_CHECK_ARG(qkv && y && dy && lse && dscratch && dqkv && cos_t && sin_t, "attn_bwd: null operand");
   COATI_CHECK_SHAPE(B > 0 && T > 0 && T <= 256 && n_head > 0 && (head_size == 16 || head_size == 32),
                     "attn_bwd: unsupported shape B=%d T=%d nh=%d hs=%d", B, T, n_head, head_size);
+  // T <= 128: the single-sweep kernel (grande: 120 vs 141 us); COATI_ATTN_FUSED_BWD=0 is the A/B switch back to the two
+  // kernels, which also serve longer sequences
+  static const bool fused = getenv("COATI_ATTN_FUSED_BWD") == nullptr || atoi(getenv("COATI_ATTN_FUSED_BWD")) != 0;
+  if (fused && T <= 128) {
+    const int nb = (T + 31) / 32;
+#define FUSED_CASE(H, N) if (head_size == H && nb == N) return launch_attn_bwd_fused_t<H, N>(qkv, y, dy, lse, dqkv, cos_t, sin_t, B, T, n_head, s);
+    FUSED_CASE(16, 1) FUSED_CASE(16, 2) FUSED_CASE(16, 3) FUSED_CASE(16, 4)
+    FUSED_CASE(32, 1) FUSED_CASE(32, 2) FUSED_CASE(32, 3) FUSED_CASE(32, 4)
+#undef FUSED_CASE
+  }
   return head_size == 16 ? launch_attn_bwd_t<16>(qkv, y, dy, lse, dscratch, dqkv, cos_t, sin_t, B, T, n_head, s)
                          : launch_attn_bwd_t<32>(qkv, y, dy, lse, dscratch, dqkv, cos_t, sin_t, B, T, n_head, s);
 }

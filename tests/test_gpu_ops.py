@@ -122,7 +122,8 @@ def test_layernorm(ops, M, C, affine):
 
 
 @pytest.mark.parametrize("B,T,nh,hs", [(3, 12, 4, 16), (5, 80, 16, 16), (2, 250, 4, 16), (4, 33, 2, 16),
-                                        (3, 12, 4, 32), (3, 80, 16, 32), (2, 250, 3, 32), (4, 33, 2, 32)])
+                                        (3, 12, 4, 32), (3, 80, 16, 32), (2, 250, 3, 32), (4, 33, 2, 32),
+                                        (2, 128, 5, 16), (2, 64, 6, 16), (2, 100, 3, 32), (2, 129, 5, 16)])
 def test_attention(ops, B, T, nh, hs):
     from oracle import coati_oracle as O
     C = nh * hs
