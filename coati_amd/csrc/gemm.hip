@@ -12,6 +12,7 @@
 // ds_read_b128 fragment reads are conflict-free without an XOR swizzle.  The accumulator tile is
 // transposed through LDS so the epilogue works on 8 consecutive columns per lane (16-B stores).
 #include <stdlib.h>
+#include <cstdlib>
 #include "kernels.h"
 
 #define BM 128
@@ -492,6 +493,291 @@ __global__ __launch_bounds__(64 * WAVES, 2) void wgrad_kernel(WgradArgs p, int t
   }
 }
 
+// =================================================================================================
+// wgrad, LDS-DMA variant (bf16 A).  One 512-thread workgroup per CU owns one 128 x 128 output tile and one slice of M:
+//   * operand rows go HBM/L2 -> LDS with global_load_lds_dwordx4 (no staging registers, no ds_write) into a ring of NS
+//     stages of 64 m-rows ([2 sub-chunks][A: 32 m x 128 n | B: 32 m x 128 k], 32 KiB).  One wave instruction fills
+//     1 KiB = 4 tile rows in lane order; the 64-B-chunk swizzle of the transpose reads is applied on the GLOBAL side
+//     (the lane that writes slot q of a row fetches chunk (q>>2 ^ row&3, q&3)).  NS - 1 stages are always in flight:
+//     per stage one s_waitcnt vmcnt(4 (NS - 2)) + one s_barrier (no fence: a fence would drain every DMA);
+//   * the 8 waves form two groups of 2 x 2 waves; group g multiplies sub-chunk g of every stage into its own copy of
+//     the tile, and at the end the groups swap halves through the (then idle) ring so that each wave adds up and
+//     commits half of its 64 x 64 block.  Two groups per tile instead of two workgroups per CU halve the fp32 atomics,
+//     the largest single cost of the register-staged kernel (ablation: streaming 30 us, MFMA phase +12, atomics +17 of
+//     62 us at 768 x 256);
+//   * rows past the end of the slice and columns past N / K are fetched from a 256-B page of zeros: no masking anywhere;
+//   * bias column sums are read back from the A sub-chunk in LDS (8 ds_read_b32 per thread) and spread evenly over the
+//     tiles_k workgroups that see the same A rows: workgroup tile_k takes the stages with stage % tiles_k == tile_k.
+// The DMA is issued from inline assembly so that the only vmcnt waits in the ring are the hand-placed ones (with the
+// builtin the compiler puts a vmcnt(0) in front of every ds_read_b64_tr_b16: its memory operand carries no alias
+// scope that would separate it from the DMA targets).
+// =================================================================================================
+#define WD_CH 64                                 // m rows per stage (two sub-chunks of 32)
+#define WD_HALF_BYTES (32 * WT_ROW_BYTES)        // one operand of one sub-chunk: 8 KiB
+#define WD_STAGE_BYTES (4 * WD_HALF_BYTES)       // 32 KiB
+struct WdFrags { bf16x8 a[2][2], b[2][2]; };
+__device__ __attribute__((aligned(256))) const uint4 wd_zero_page[16] = {};
+
+// One global_load_lds_dwordx4: lane i -> LDS byte address lds + 16 i (lds wave-uniform).  Per-lane 64-bit address ...
+__device__ __forceinline__ void wd_dma16(const void* g, unsigned lds) {
+  asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(lds) : "memory", "m0");
+}
+// ... or scalar base + 32-bit per-lane byte offset
+__device__ __forceinline__ void wd_dma16s(const void* base, unsigned off, unsigned lds) {
+  asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(base), "s"(lds) : "memory", "m0");
+}
+template <int S> struct WdSlot { static constexpr int value = S; };
+
+template <bool BIAS, int NS>
+__global__ __launch_bounds__(512, 1) void wgrad_dma_kernel(WgradArgs p, int tiles_k, int chunks_per_split, int n_splits) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2, wm = (wave >> 1) & 1, wn = wave & 1;
+  const int tiles = gridDim.x / n_splits;
+  const int wg = xcd_swizzle(blockIdx.x, gridDim.x);
+  const int split = wg / tiles, tile = wg - split * tiles;
+  const int tile_n = tile / tiles_k, tile_k = tile - tile_n * tiles_k;
+  const int n0 = tile_n * BM, k0 = tile_k * BN;
+  const int nchunks = (p.M + WD_CH - 1) / WD_CH;
+  const int c_begin = split * chunks_per_split;
+  int c_end = c_begin + chunks_per_split;
+  if (c_end > nchunks) c_end = nchunks;
+  if (c_begin >= c_end) return;
+  const int m_begin = c_begin * WD_CH;
+  const int m_end = c_end * WD_CH < p.M ? c_end * WD_CH : p.M;
+  const int nout = p.n_out > 0 ? p.n_out : p.N;
+  const bf16_t* A = reinterpret_cast<const bf16_t*>(p.A);
+
+  // DMA sources of this lane.  Piece (1 KiB = 4 rows) wave + 8 i of a stage, i = 0..3: sub-chunk i >> 1, operand i & 1,
+  // rows 4 wave .. +3; LDS slot (row & 3 = lane >> 4, 16-B chunk q = lane & 15) <- global chunk qg of that row.
+  const int rsub = lane >> 4, q = lane & 15;
+  const int qg = (((q >> 2) ^ rsub) << 2) | (q & 3);
+  const bool aok = n0 + qg * 8 < p.N, bok = k0 + qg * 8 < p.K;
+  const bf16_t* const zero = reinterpret_cast<const bf16_t*>(wd_zero_page) + q * 8;
+  const bool full_tile = n0 + BM <= p.N && k0 + BN <= p.K && 130LL * p.lda < (1LL << 30) && 130LL * p.ldb < (1LL << 30);
+  const unsigned offa = (unsigned)(((4 * wave + rsub) * (int)p.lda + qg * 8) * 2);   // byte offsets of this lane's row 0 chunk
+  const unsigned offb = (unsigned)(((4 * wave + rsub) * (int)p.ldb + qg * 8) * 2);
+  int cnext = c_begin;   // next stage to fetch
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[i][0][r] = 0.f; acc[i][1][r] = 0.f; }
+  }
+  // bias: thread -> columns 2 cp, 2 cp + 1 and rows 8 (wave & 3) .. +7 of its group's sub-chunk
+  float cs0 = 0.f, cs1 = 0.f;
+  const int cp = lane, rq = wave & 3;
+  int bias_ctr = (tile_k - c_begin % tiles_k + tiles_k) % tiles_k;   // stages until this workgroup's turn
+
+  // DMA of the next stage -> ring slot `slot` (this wave's 4 pieces).  Interior stages of full tiles take the fast path:
+  // scalar bases (advanced on the scalar unit) + constant per-lane byte offsets, no vector work at all; stages that touch
+  // the end of the slice and tiles that stick out of N / K select per lane between the row and the zero page.
+  typedef __attribute__((address_space(3))) unsigned char lds_u8;
+  const unsigned ldsw = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_u8*)smem) + wave * 1024;
+  const bf16_t* ab = A + n0 + (long long)c_begin * WD_CH * p.lda;     // row 0 of the next stage (scalar)
+  const bf16_t* bb = p.B + k0 + (long long)c_begin * WD_CH * p.ldb;
+  const long long ab_step = (long long)WD_CH * p.lda, bb_step = (long long)WD_CH * p.ldb;
+  const unsigned offa1 = offa + 64u * (unsigned)p.lda, offb1 = offb + 64u * (unsigned)p.ldb;
+  auto issue = [&](int slot) __attribute__((always_inline)) {
+    const unsigned S = ldsw + slot * WD_STAGE_BYTES;
+    if (full_tile && (cnext + 1) * WD_CH <= m_end) {
+      wd_dma16s(ab, offa, S);
+      wd_dma16s(bb, offb, S + WD_HALF_BYTES);
+      wd_dma16s(ab, offa1, S + 2 * WD_HALF_BYTES);
+      wd_dma16s(bb, offb1, S + 3 * WD_HALF_BYTES);
+    } else {
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub) {
+        const int m = cnext * WD_CH + 32 * sub + 4 * wave + rsub;
+        const bool ok = m < m_end;
+        wd_dma16((ok && aok) ? A + n0 + qg * 8 + (long long)m * p.lda : zero, S + (2 * sub) * WD_HALF_BYTES);
+        wd_dma16((ok && bok) ? p.B + k0 + qg * 8 + (long long)m * p.ldb : zero, S + (2 * sub + 1) * WD_HALF_BYTES);
+      }
+    }
+    ++cnext;
+    ab += ab_step;
+    bb += bb_step;
+  };
+  // fragments of the stage in ring slot `slot` (compile-time in the main loop: every address is lane constant + immediate)
+  auto fetch = [&](int slot, WdFrags& f) __attribute__((always_inline)) {
+    const unsigned char* At = smem + slot * WD_STAGE_BYTES + grp * 2 * WD_HALF_BYTES;
+    const unsigned char* Bt = At + WD_HALF_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) f.a[ks][i] = tr_frag(At, ks * 16, wm * 64 + i * 32, lane);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) f.b[ks][j] = tr_frag(Bt, ks * 16, wn * 64 + j * 32, lane);
+    }
+  };
+  auto mma = [&](const WdFrags& f) __attribute__((always_inline)) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[ks][i], f.b[ks][j], acc[i][j], 0, 0, 0);
+  };
+  // bias operands of this thread in the stage in ring slot `slot`: rows 8 rq .. +7, columns 2 cp, 2 cp + 1
+  typedef __bf16 v2bf __attribute__((ext_vector_type(2)));
+  // (1, 0) and (0, 1) selectors of v_dot2c_f32_bf16, kept in registers: as immediates the compiler turns both into the
+  // inline constant 1.0, which does not mean the same thing for a packed operand
+  unsigned sel_lo_u, sel_hi_u;
+  asm volatile("v_mov_b32 %0, 0x3f80\n\tv_mov_b32 %1, 0x3f800000" : "=v"(sel_lo_u), "=v"(sel_hi_u));
+  const v2bf sel_lo = __builtin_bit_cast(v2bf, sel_lo_u), sel_hi = __builtin_bit_cast(v2bf, sel_hi_u);
+  unsigned bu[8];
+#pragma unroll
+  for (int rr = 0; rr < 8; ++rr) bu[rr] = 0;
+  auto bias_read = [&](int slot) __attribute__((always_inline)) {
+    const unsigned char* At = smem + slot * WD_STAGE_BYTES + grp * 2 * WD_HALF_BYTES;
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) bu[rr] = *reinterpret_cast<const unsigned*>(At + wt_offset(rq * 8 + rr, cp * 4));
+  };
+  auto bias_add = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {
+      const v2bf u = __builtin_bit_cast(v2bf, bu[rr]);
+      cs0 = __builtin_amdgcn_fdot2_f32_bf16(u, sel_lo, cs0, false);
+      cs1 = __builtin_amdgcn_fdot2_f32_bf16(u, sel_hi, cs1, false);
+    }
+  };
+  constexpr int VM_KEEP = 4 * (NS - 2);   // DMAs that may stay in flight when the oldest stage is needed
+  constexpr int VM_WAIT = 0x0f70 | (VM_KEEP & 15) | ((VM_KEEP >> 4) << 14);
+
+  // Stage c is multiplied out of registers while the transpose reads of stage c + 1 are in flight: one step =
+  // [stage c + 1 has landed | barrier] -> DMA of stage c + NS into the slot of stage c (every wave finished reading it
+  // before the barrier) -> LDS reads of stage c + 1 interleaved with the MFMAs of stage c.  NS - 1 stages are in flight
+  // throughout.  The ring slot is a compile-time constant of each step (the loop is unrolled over slots x fragment
+  // sets), so a step is ~55 instructions per wave: with two waves per SIMD the instruction count per stage is on the
+  // critical path (every instruction shaved off the step showed up in the kernel time).
+#pragma unroll
+  for (int s0 = 0; s0 < NS - 1; ++s0) issue(s0);
+  __builtin_amdgcn_s_waitcnt(VM_WAIT);
+  __builtin_amdgcn_s_barrier();
+  issue(NS - 1);
+  WdFrags fa, fb;
+  fetch(0, fa);
+  if (BIAS) {   // bias operands of the first stage
+    if (bias_ctr == 0) {
+      bias_read(0);
+      bias_add();
+      bias_ctr = tiles_k;
+    }
+    --bias_ctr;
+  }
+  auto step = [&](auto slot_c, const WdFrags& cur, WdFrags& nxt) __attribute__((always_inline)) {
+    constexpr int SL = decltype(slot_c)::value, SN = (SL + 1) % NS;   // ring slots of stage c and stage c + 1
+    __builtin_amdgcn_s_waitcnt(VM_WAIT & 0xf0ff);   // + lgkmcnt(0): this wave's reads of stage c are complete
+    __builtin_amdgcn_s_barrier();
+    issue(SL);
+    // issue order: one MFMA (32 cycles in the matrix core, 4 to issue), then two of the transpose reads in its shadow --
+    // the matrix core never waits for the read phase of the next stage.  On this workgroup's bias turns the 8 x 2 bias
+    // operands of the thread are read in front of that block and added up behind it, when they have long arrived (the
+    // interleave is per basic block, so the block itself stays free of branches).
+    const bool turn = BIAS && bias_ctr == 0;
+    if (BIAS) bias_ctr = (bias_ctr == 0 ? tiles_k : bias_ctr) - 1;
+    if (turn) bias_read(SN);
+    fetch(SN, nxt);
+    mma(cur);
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // DS read
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (turn) bias_add();
+  };
+  static_assert(NS == 3 || NS == 4, "the main loop is unrolled for ring depths 3 and 4");
+  for (int c = c_begin;;) {
+    if constexpr (NS == 3) {
+      step(WdSlot<0>(), fa, fb); if (++c >= c_end) break;
+      step(WdSlot<1>(), fb, fa); if (++c >= c_end) break;
+      step(WdSlot<2>(), fa, fb); if (++c >= c_end) break;
+      step(WdSlot<0>(), fb, fa); if (++c >= c_end) break;
+      step(WdSlot<1>(), fa, fb); if (++c >= c_end) break;
+      step(WdSlot<2>(), fb, fa); if (++c >= c_end) break;
+    } else {
+      step(WdSlot<0>(), fa, fb); if (++c >= c_end) break;
+      step(WdSlot<1>(), fb, fa); if (++c >= c_end) break;
+      step(WdSlot<2>(), fa, fb); if (++c >= c_end) break;
+      step(WdSlot<3>(), fb, fa); if (++c >= c_end) break;
+    }
+  }
+  __builtin_amdgcn_s_waitcnt(0x0f70);   // the over-issued (zero-page) DMAs have landed: the ring is free
+  __builtin_amdgcn_s_barrier();
+
+  // the groups swap halves: wave w keeps block row (i == grp) of its 64 x 64 block and hands the other one to wave w ^ 4
+  float* const xch = reinterpret_cast<float*>(smem);
+  float* const bsum = xch + 8 * 2048;   // [8 waves][128 columns] bias partials (2 sub-chunks x 4 row quarters), behind the exchange buffer
+  {
+    float* mine = xch + wave * 2048 + lane;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mine[(j * 16 + r) * 64] = grp == 0 ? acc[1][j][r] : acc[0][j][r];
+    if (BIAS) {
+      bsum[wave * 128 + 2 * cp] = cs0;
+      bsum[wave * 128 + 2 * cp + 1] = cs1;
+    }
+  }
+  __syncthreads();
+  // the bias atomics go first: all workgroups of a tile row hit the same 128 addresses at the same time, and that
+  // serialised chain then runs in the L2 underneath the (much larger) tile commit below
+  if (BIAS && tid < 128) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) t += bsum[w * 128 + tid];
+    if (n0 + tid < nout) atomicAdd(p.dbias + n0 + tid, t);
+  }
+  {
+    const float* theirs = xch + (wave ^ 4) * 2048 + lane;
+    const int i = grp;
+    float v[2][16];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[j][r] = (grp == 0 ? acc[0][j][r] : acc[1][j][r]) + theirs[(j * 16 + r) * 64];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = n0 + wm * 64 + i * 32 + frag_row(r, lane);
+        const int k = k0 + wn * 64 + j * 32 + (lane & 31);
+        if (n < nout && k < p.K) atomicAdd(p.dW + (long long)n * p.ldw + k, v[j][r]);
+      }
+  }
+}
+
+template <bool BIAS, int NS>
+static int launch_wgrad_dma_t(const WgradArgs& a, hipStream_t s) {
+  static bool attr_set = false;
+  auto kern = wgrad_dma_kernel<BIAS, NS>;
+  constexpr int lds = NS * WD_STAGE_BYTES;
+  static_assert(lds >= 8 * 2048 * 4 + 8 * 128 * 4, "the ring doubles as the 64-KiB exchange buffer + the bias partials");
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) {
+      coati_set_error("wgrad(dma): hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+      return COATI_EHIP;
+    }
+    attr_set = true;
+  }
+  const int tiles_n = cdiv(a.N, BM), tiles_k = cdiv(a.K, BN);
+  const int tiles = tiles_n * tiles_k;
+  const int nchunks = cdiv(a.M, WD_CH);
+  static const int slot_env = getenv("COATI_WGRAD_SLOTS") ? atoi(getenv("COATI_WGRAD_SLOTS")) : 0;
+  const int slots = slot_env > 0 ? slot_env : 256;   // one workgroup per CU
+  int splits = slots / tiles;
+  if (splits > cdiv(nchunks, 4)) splits = cdiv(nchunks, 4);
+  if (splits < 1) splits = 1;
+  const int cps = cdiv(nchunks, splits);
+  splits = cdiv(nchunks, cps);
+  hipLaunchKernelGGL(kern, dim3(tiles * splits), dim3(512), lds, s, a, tiles_k, cps, splits);
+  COATI_LAUNCH_CHECK("wgrad_dma");
+  return COATI_OK;
+}
+
 template <typename AT, bool BIAS>
 static int launch_wgrad_t(const WgradArgs& a, hipStream_t s) {
   static bool attr_set = false;
@@ -529,6 +815,15 @@ int launch_wgrad(const WgradArgs& a, int a_f32, hipStream_t s) {
   COATI_CHECK_SHAPE(a.N % 8 == 0 && a.K % 8 == 0, "wgrad: N=%d and K=%d must be multiples of 8", a.N, a.K);
   COATI_CHECK_SHAPE(a.lda % 8 == 0 && a.ldb % 8 == 0, "wgrad: lda/ldb alignment");
   if (a_f32) return a.dbias ? launch_wgrad_t<float, true>(a, s) : launch_wgrad_t<float, false>(a, s);
+  // bf16 A: the LDS-DMA kernel (one 512-thread workgroup per CU) when the launch gives every CU a tile and a slice of at
+  // least 16 stages; otherwise (few rows: GNN node level; many tiles: lm_head) the register-staged kernel.
+  // COATI_WGRAD_DMA: ring depth 3..5, 0 = register-staged kernel everywhere (A/B switch).
+  static const int dma = getenv("COATI_WGRAD_DMA") ? atoi(getenv("COATI_WGRAD_DMA")) : 3;
+  const int tiles = cdiv(a.N, BM) * cdiv(a.K, BN);
+  if (dma >= 3 && tiles <= 32 && (long long)a.M >= 16LL * WD_CH * (256 / tiles)) {
+    if (dma == 3) return a.dbias ? launch_wgrad_dma_t<true, 3>(a, s) : launch_wgrad_dma_t<false, 3>(a, s);
+    return a.dbias ? launch_wgrad_dma_t<true, 4>(a, s) : launch_wgrad_dma_t<false, 4>(a, s);
+  }
   return a.dbias ? launch_wgrad_t<bf16_t, true>(a, s) : launch_wgrad_t<bf16_t, false>(a, s);
 }
 

@@ -27,7 +27,7 @@ for (N, K) in [(768, 256), (256, 256), (1024, 256), (256, 1024), (256, 768), (10
     row(f"nt gelu   N={N} K={K}", timeit(lambda: ops.gemm_nt(A, W, bias, ops.EPI_GELU, out=o16)), fl, M*K*2 + M*N*4)
     row(f"nt dgelu  N={N} K={K} (A f32)", timeit(lambda: ops.gemm_nt(A32, W, None, ops.EPI_DGELU, aux_in=pre, out=o16)), fl, M*K*4 + M*N*4)
     row(f"nt bf16   N={N} K={K} (A f32)", timeit(lambda: ops.gemm_nt(A32, W, None, ops.EPI_BF16, out=o16)), fl, M*K*4 + M*N*2)
-for (N, K, f32) in [(768, 256, False), (256, 256, True), (1024, 256, False), (256, 1024, True)]:
+for (N, K, f32) in [(768, 256, False), (256, 256, False), (1024, 256, False), (256, 1024, False), (256, 256, True), (256, 1024, True)]:
     A = torch.randn(M, N, device=dev)
     A = A if f32 else A.bfloat16()
     X = torch.randn(M, K, device=dev).bfloat16()
