@@ -599,16 +599,43 @@ __global__ __launch_bounds__(512, 1) void wgrad_dma_kernel(WgradArgs p, int tile
     ab += ab_step;
     bb += bb_step;
   };
-  // fragments of the stage in ring slot `slot` (compile-time in the main loop: every address is lane constant + immediate)
+  // fragments of the stage in ring slot `slot` (compile-time in the main loop): every transpose read is one of four
+  // per-lane LDS addresses (2 A blocks, 2 B blocks of this wave, incl. the group's sub-chunk) + an immediate
+  typedef __attribute__((address_space(3))) v4s16 lds_v4;
+  unsigned la[2], lb[2];
+  {
+    const int g = lane >> 4, kg = g >> 1, r0 = 8 * kg + ((lane & 15) >> 2), cb = (16 * (g & 1) + 4 * (lane & 3)) * 2;
+    const unsigned sub0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_u8*)smem) + grp * 2 * WD_HALF_BYTES;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      la[i] = sub0 + wt_offset(r0, (wm * 64 + i * 32) * 2 + cb);
+      lb[i] = sub0 + WD_HALF_BYTES + wt_offset(r0, (wn * 64 + i * 32) * 2 + cb);
+    }
+  }
+  auto frag_at = [&](unsigned addr) __attribute__((always_inline)) {
+    const v4s16 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(size_t)addr);
+    const v4s16 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(size_t)(addr + 4 * WT_ROW_BYTES));
+    typedef short v8s16 __attribute__((ext_vector_type(8)));
+    const v8s16 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, r);
+  };
+  // a second set 64 KiB up (opaque to the compiler) keeps the immediates of ring slots >= 2 inside the 16-bit offset field
+  unsigned lah[2], lbh[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    lah[i] = la[i] + 0x10000u;
+    lbh[i] = lb[i] + 0x10000u;
+    asm volatile("" : "+v"(lah[i]), "+v"(lbh[i]));
+  }
   auto fetch = [&](int slot, WdFrags& f) __attribute__((always_inline)) {
-    const unsigned char* At = smem + slot * WD_STAGE_BYTES + grp * 2 * WD_HALF_BYTES;
-    const unsigned char* Bt = At + WD_HALF_BYTES;
+    const bool high = slot * WD_STAGE_BYTES >= 0x10000;
+    const unsigned so = slot * WD_STAGE_BYTES - (high ? 0x10000u : 0u);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i) f.a[ks][i] = tr_frag(At, ks * 16, wm * 64 + i * 32, lane);
+      for (int i = 0; i < 2; ++i) f.a[ks][i] = frag_at((high ? lah[i] : la[i]) + so + ks * 16 * WT_ROW_BYTES);
 #pragma unroll
-      for (int j = 0; j < 2; ++j) f.b[ks][j] = tr_frag(Bt, ks * 16, wn * 64 + j * 32, lane);
+      for (int j = 0; j < 2; ++j) f.b[ks][j] = frag_at((high ? lbh[j] : lb[j]) + so + ks * 16 * WT_ROW_BYTES);
     }
   };
   auto mma = [&](const WdFrags& f) __attribute__((always_inline)) {
