@@ -272,6 +272,7 @@ int launch_gemm_nt(const GemmArgs& a, int a_f32, int epi, hipStream_t s) {
   {
     static const bool no_rb = getenv("COATI_NO_RB") != nullptr;   // A/B switch for benchmarking
     if (!no_rb && gemm_rb256_supported(a, a_f32, epi)) return launch_gemm_rb256(a, epi, s);
+    if (gemm_ring256_supported(a, a_f32, epi)) return launch_gemm_ring256(a, epi, s);
   }
   static const bool w4 = getenv("COATI_GEMM_W4") != nullptr;   // A/B switch: 4-wave instead of 8-wave workgroups
 #define NT_CASE(E)                                                                  \

@@ -1,0 +1,272 @@
+// Ring GEMM for N = 256: C[M,256] = A[M,K] * W[256,K]^T (+ bias, + f32 residual), bf16 operands, K % 64 == 0, K > 256.
+// These are the long-K products of the transformer (reference basic_transformer.py:103-123 MLP down-projection forward,
+// and the input gradients of c_fc / c_attn): M = 81 920 rows stream through once, the 256 x K weight sits in L2.
+//
+// One persistent 640-thread workgroup per CU walks over row blocks of 160 rows (grande: 512 blocks = exactly 2 per CU;
+// the 128-row tiles of the tiled kernel make 2.5 rounds there and lose a fifth of the machine in the last one).
+//   * the block's A rows and the weight rows go HBM/L2 -> LDS with global_load_lds_dwordx4 into a ring of 3 stages of
+//     64 k ([160 rows | 256 weight rows] x 128 B = 52 KiB); rows are unpadded, the 16-B chunk c of row r sits at chunk
+//     position c ^ ((r >> 1) & 7) (applied on the global side of the DMA) so that the 16 lanes of one LDS cycle of a
+//     fragment read (16 consecutive rows, same k chunk) hit 16 different 16-B columns;
+//   * the stream of stages is continuous ACROSS row blocks: the DMA pointer runs two stages ahead of the MFMA pointer, so
+//     while the waves write a block's results, the first stages of the next block are already landing;
+//   * 10 waves = 5 row groups x 2 column halves, 32 x 128 outputs per wave (4 accumulator blocks, 5 fragment reads per
+//     4 MFMAs);
+//   * results leave straight from the accumulator layout: for one register the 32 lanes of a half-wave hold 32
+//     consecutive columns of one row, i.e. one whole 128-B line of an f32 row (residual read + store) -- no LDS staging,
+//     so the ring can use all of the LDS.
+// The DMA is issued from inline assembly (see gemm.hip: the compiler then leaves the vmcnt bookkeeping of the ring to
+// the hand-placed waits).
+#include <cstdlib>
+#include "kernels.h"
+
+#define RG_BR 160                           // rows per block
+#define RG_BK 64                            // k per stage
+#define RG_WAVES 10
+#define RG_NS 3
+#define RG_A_BYTES (RG_BR * RG_BK * 2)      // 20 KiB
+#define RG_W_BYTES (256 * RG_BK * 2)        // 32 KiB
+#define RG_STAGE_BYTES (RG_A_BYTES + RG_W_BYTES)
+#define RG_LDS_BYTES (RG_NS * RG_STAGE_BYTES)   // 159,744 B
+
+__device__ __forceinline__ void rg_dma16(const void* g, unsigned lds) {   // per-lane 64-bit address
+  asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(lds) : "memory", "m0");
+}
+__device__ __forceinline__ void rg_dma16s(const void* base, unsigned off, unsigned lds) {   // scalar base + lane offset
+  asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(base), "s"(lds) : "memory", "m0");
+}
+__device__ __forceinline__ int rg_frag_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+// s_waitcnt vmcnt(n) for the values the ring uses (the count is an immediate); anything else waits for less
+__device__ __forceinline__ void rg_wait_vm(int n) {
+  if (n >= 63) __builtin_amdgcn_s_waitcnt(0xcf7f);        // vmcnt(63)
+  else if (n >= 38) __builtin_amdgcn_s_waitcnt(0x8f76);   // vmcnt(38)
+  else if (n >= 37) __builtin_amdgcn_s_waitcnt(0x8f75);   // vmcnt(37)
+  else if (n >= 6) __builtin_amdgcn_s_waitcnt(0x0f76);    // vmcnt(6)
+  else if (n >= 5) __builtin_amdgcn_s_waitcnt(0x0f75);    // vmcnt(5)
+  else __builtin_amdgcn_s_waitcnt(0x0f70);
+}
+
+template <int EPI>
+__global__ __launch_bounds__(64 * RG_WAVES, 1) void gemm_ring256_kernel(GemmArgs p, int nblocks) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  typedef __attribute__((address_space(3))) unsigned char lds_u8;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int G = gridDim.x, wg = blockIdx.x;
+  const int nk = p.K / RG_BK;
+  const int mine = (nblocks - wg + G - 1) / G;   // row blocks wg, wg + G, ...
+  if (mine <= 0) return;
+  const bf16_t* A = reinterpret_cast<const bf16_t*>(p.A);
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_u8*)smem);
+
+  // ---- DMA side.  Piece q (1 KiB = 8 rows x 128 B) of an operand: lane -> row 8 q + (lane >> 3), LDS chunk slot
+  // lane & 7, global chunk (lane & 7) ^ ((row >> 1) & 7).  A wave takes A pieces {wave, wave + 10} and weight pieces
+  // {wave, wave + 10, wave + 20 (, wave + 30 for waves 0 and 1)}: all of one parity, so one chunk permutation per lane.
+  const int lrow = lane >> 3;
+  const int cg = (lane & 7) ^ ((((wave & 1) << 2) + (lane >> 4)) & 7);
+  const unsigned offa = (unsigned)((lrow * (int)p.lda + cg * 8) * 2);
+  const unsigned offw = (unsigned)((lrow * (int)p.ldb + cg * 8) * 2);
+  const int nwp = wave < 2 ? 4 : 3;              // weight pieces of this wave
+  const int my_dmas = 2 + nwp;
+  // DMA pointer: all scalar, carried from stage to stage (the instruction count of a stage is on the critical path: the
+  // first version recomputed bases and the k rotation every stage and spent 7 scalar instructions per MFMA).
+  //   every block walks k from its own starting chunk (blk % nk): with a power-of-two row pitch all blocks would
+  //   otherwise read the same 128-B column of their rows at the same time, i.e. the same few HBM channels
+  int bi = 0, ki = 0;                            // block index (of mine), stages issued of that block
+  int kk = wg % nk;                              // k chunk of the next stage
+  int row0 = wg * RG_BR;
+  const bf16_t* pa = A + ((long long)row0 + 8 * wave) * p.lda;          // this wave's first A piece, k = 0
+  const long long a_p1 = 8LL * RG_WAVES * p.lda;                          // second A piece
+  const bf16_t* const pw = p.B + (long long)8 * wave * p.ldb;            // first weight piece, k = 0
+  const long long w_p = 8LL * RG_WAVES * p.ldb;                           // stride between this wave's weight pieces
+  unsigned sl = lds0 + wave * 1024;                                       // LDS address of piece `wave` of the next slot
+  auto issue = [&]() __attribute__((always_inline)) {
+    if (bi < mine) {
+      if (row0 + RG_BR <= p.M) {
+        const bf16_t* ab = pa + kk * RG_BK;
+        rg_dma16s(ab, offa, sl);
+        rg_dma16s(ab + a_p1, offa, sl + RG_WAVES * 1024);
+      } else {   // last block: rows past M re-read row M - 1 (their outputs are never stored)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          int r = row0 + (wave + RG_WAVES * i) * 8 + lrow;
+          r = r < p.M ? r : p.M - 1;
+          rg_dma16(A + (long long)r * p.lda + kk * RG_BK + cg * 8, sl + i * RG_WAVES * 1024);
+        }
+      }
+      const bf16_t* wb = pw + kk * RG_BK;
+      rg_dma16s(wb, offw, sl + RG_A_BYTES);
+      rg_dma16s(wb + w_p, offw, sl + RG_A_BYTES + RG_WAVES * 1024);
+      rg_dma16s(wb + 2 * w_p, offw, sl + RG_A_BYTES + 2 * RG_WAVES * 1024);
+      if (nwp == 4) rg_dma16s(wb + 3 * w_p, offw, sl + RG_A_BYTES + 3 * RG_WAVES * 1024);
+    }
+    kk = kk + 1 == nk ? 0 : kk + 1;
+    sl = sl + RG_STAGE_BYTES == lds0 + wave * 1024 + RG_NS * RG_STAGE_BYTES ? lds0 + wave * 1024 : sl + RG_STAGE_BYTES;
+    if (++ki == nk) {   // next block of this workgroup
+      ki = 0;
+      ++bi;
+      row0 += G * RG_BR;
+      pa += (long long)G * RG_BR * p.lda;
+      kk = (wg + bi * G) % nk;
+    }
+  };
+
+  // ---- MFMA side: lane (r = lane & 31, kg = lane >> 5) reads chunk (2 ks + kg) ^ ((r >> 1) & 7) of its rows
+  const int fr = lane & 31, kg = lane >> 5, swz = (fr >> 1) & 7;
+  unsigned xo[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) xo[ks] = (unsigned)(fr * 128 + (((2 * ks + kg) ^ swz) << 4));
+  const unsigned a_row = (unsigned)(wm * 32 * 128), w_row = (unsigned)(RG_A_BYTES + wn * 128 * 128);
+
+  f32x16 acc[4];
+  auto acc_init = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float b = p.bias != nullptr ? p.bias[wn * 128 + j * 32 + fr] : 0.f;   // lane = output column
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] = b;
+    }
+  };
+
+  const int total = mine * nk;
+  const int vm_keep = my_dmas * (RG_NS - 2);
+  issue();
+  issue();
+  acc_init();
+  int sc = 0, kc = 0, bc = 0;   // MFMA pointer: ring slot, k chunk, block index
+  int st_cnt = 0, st_age = 2;   // stores issued by the last write-out, stages since then
+  for (int s = 0; s < total; ++s) {
+    // stage s has landed (this wave's pieces; the barrier covers the others) and every wave is done with stage s - 1,
+    // whose slot the next DMA overwrites.  Near the end of the stream nothing is issued any more: wait for everything.
+    // After a block's write-out the stores are the youngest entries of the (in-order) vmcnt queue: for the next two
+    // stages the wait lets them -- `st_cnt` instructions -- stay in flight too instead of draining them.
+    if (s + RG_NS - 1 < total) {
+      rg_wait_vm(vm_keep + (st_age < 2 ? st_cnt : 0));
+    } else {
+      __builtin_amdgcn_s_waitcnt(0x0f70);
+    }
+    ++st_age;
+    __builtin_amdgcn_s_barrier();
+    issue();
+    const unsigned char* S = smem + sc * RG_STAGE_BYTES;
+    // two fragment sets: the 5 reads of k step ks + 1 are issued in the shadow of the 4 MFMAs of step ks (the LDS pipe
+    // is as busy as the matrix core here: 5 KiB of fragments per 4 MFMAs)
+    {
+      bf16x8 fa[2], fw[2][4];
+      fa[0] = *reinterpret_cast<const bf16x8*>(S + a_row + xo[0]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fw[0][j] = *reinterpret_cast<const bf16x8*>(S + w_row + j * 4096 + xo[0]);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const int cur = ks & 1, nxt = cur ^ 1;
+        if (ks < 3) {
+          fa[nxt] = *reinterpret_cast<const bf16x8*>(S + a_row + xo[ks + 1]);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) fw[nxt][j] = *reinterpret_cast<const bf16x8*>(S + w_row + j * 4096 + xo[ks + 1]);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur], fw[cur][j], acc[j], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x100, 5, 0);     // fragments of k step 0
+#pragma unroll
+      for (int ks = 0; ks < 3; ++ks) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#pragma unroll
+        for (int j = 1; j < 4; ++j) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+    }
+    sc = sc + 1 == RG_NS ? 0 : sc + 1;
+    if (++kc == nk) {
+      // the block is complete: write it out straight from the accumulator layout (the next block's first stages are in
+      // flight meanwhile)
+      const int row0 = (wg + bc * G) * RG_BR + wm * 32;
+      const int brow0 = (wg + bc * G) * RG_BR;
+      const bool full = brow0 + RG_BR <= p.M;   // uniform: no per-row guards (and no branches between the stores) inside
+      if (EPI == EPI_RES_F32) {
+        // all 64 residual loads of the wave are issued before the first add (rows past M re-read row M - 1)
+        const float* res = reinterpret_cast<const float*>(p.aux_in) + wn * 128 + fr;
+        float* out = reinterpret_cast<float*>(p.C) + wn * 128 + fr;
+        float x[16][4];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = row0 + rg_frag_row(r, lane), rc = (full || row < p.M) ? row : p.M - 1;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) x[r][j] = res[(long long)rc * p.ld_aux + j * 32];
+        }
+        if (full) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = row0 + rg_frag_row(r, lane);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) out[(long long)row * p.ldc + j * 32] = acc[j][r] + x[r][j];
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = row0 + rg_frag_row(r, lane);
+            if (row < p.M) {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) out[(long long)row * p.ldc + j * 32] = acc[j][r] + x[r][j];
+            }
+          }
+        }
+      } else {
+        // bf16: one 2-B store per element (64-B row segments).  Regrouping the columns into 128-B lines with ds_bpermute
+        // was measured slower (4 permutes per output dword: 73 vs 64 us at K = 1024).
+        bf16_t* out = reinterpret_cast<bf16_t*>(p.C) + wn * 128 + fr;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = row0 + rg_frag_row(r, lane);
+          if (full || row < p.M) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) out[(long long)row * p.ldc + j * 32] = f2bf(acc[j][r]);
+          }
+        }
+      }
+      st_cnt = full ? 64 : 0;   // a partial block skips stores: no credit
+      st_age = 0;
+      kc = 0;
+      ++bc;
+      acc_init();
+    }
+  }
+}
+
+bool gemm_ring256_supported(const GemmArgs& a, int a_f32, int epi) {
+  static const bool off = getenv("COATI_NO_RING") != nullptr;   // A/B switch
+  if (off || a_f32) return false;
+  if (epi != EPI_BF16 && epi != EPI_RES_F32) return false;
+  if (a.N != 256 || a.K % RG_BK != 0 || a.K < 512) return false;
+  if (a.M < 256 * RG_BR / 2) return false;                      // fewer than half the CUs busy: the tiled kernel spreads better
+  if (130LL * a.lda >= (1LL << 30) || 260LL * a.ldb >= (1LL << 30)) return false;
+  return true;
+}
+
+template <int EPI>
+static int launch_ring_t(const GemmArgs& a, hipStream_t s) {
+  static bool attr_set = false;
+  auto kern = gemm_ring256_kernel<EPI>;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, RG_LDS_BYTES);
+    if (e != hipSuccess) {
+      coati_set_error("gemm_ring: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+      return COATI_EHIP;
+    }
+    attr_set = true;
+  }
+  const int nblocks = cdiv(a.M, RG_BR);
+  const int grid = nblocks < 256 ? nblocks : 256;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * RG_WAVES), RG_LDS_BYTES, s, a, nblocks);
+  COATI_LAUNCH_CHECK("gemm_ring");
+  return COATI_OK;
+}
+
+int launch_gemm_ring256(const GemmArgs& a, int epi, hipStream_t s) {
+  return epi == EPI_RES_F32 ? launch_ring_t<EPI_RES_F32>(a, s) : launch_ring_t<EPI_BF16>(a, s);
+}

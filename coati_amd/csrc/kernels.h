@@ -62,6 +62,9 @@ int launch_gemm_nt(const GemmArgs& a, int a_f32, int epi, hipStream_t s);
 // row-block kernel for K = 256 (gemm_rb.hip); launch_gemm_nt dispatches to it when supported
 bool gemm_rb256_supported(const GemmArgs& a, int a_f32, int epi);
 int launch_gemm_rb256(const GemmArgs& a, int epi, hipStream_t s);
+// ring kernel for N = 256, long K (gemm_ring.hip)
+bool gemm_ring256_supported(const GemmArgs& a, int a_f32, int epi);
+int launch_gemm_ring256(const GemmArgs& a, int epi, hipStream_t s);
 
 // dW[N,K] (f32, atomic +=) = A[M,N]^T * B[M,K];  dbias[N] (atomic +=) = colsum(A) if non-null
 struct WgradArgs {

@@ -24,7 +24,9 @@ def gelu(x):
     return 0.5 * x * (1.0 + torch.tanh(math.sqrt(2.0 / math.pi) * (x + 0.044715 * x ** 3)))
 
 
-@pytest.mark.parametrize("M,N,K", [(300, 192, 256), (128, 768, 64), (1000, 130, 128), (64, 64, 1024), (2000, 192, 256), (1411, 1024, 256), (40000, 256, 256), (33000, 768, 256)])
+# the last three rows take the N = 256 ring kernel (bf16 / residual epilogues): full blocks, a ragged last block, K = 512
+@pytest.mark.parametrize("M,N,K", [(300, 192, 256), (128, 768, 64), (1000, 130, 128), (64, 64, 1024), (2000, 192, 256), (1411, 1024, 256), (40000, 256, 256), (33000, 768, 256),
+                                   (40960, 256, 1024), (30011, 256, 768), (24000, 256, 512)])
 def test_gemm_epilogues(ops, M, N, K):
     g = torch.Generator(device="cpu").manual_seed(M + N + K)
     A = rbf(torch.randn(M, K, generator=g)).to(DEV)
