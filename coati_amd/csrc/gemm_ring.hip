@@ -81,26 +81,37 @@ __global__ __launch_bounds__(64 * RG_WAVES, 1) void gemm_ring256_kernel(GemmArgs
   const bf16_t* const pw = p.B + (long long)8 * wave * p.ldb;            // first weight piece, k = 0
   const long long w_p = 8LL * RG_WAVES * p.ldb;                           // stride between this wave's weight pieces
   unsigned sl = lds0 + wave * 1024;                                       // LDS address of piece `wave` of the next slot
-  auto issue = [&]() __attribute__((always_inline)) {
+  // The DMAs of a stage are issued in three parts (A pieces | weight pieces 0, 1 | weight pieces 2, 3), spread over the
+  // k steps of the stage being multiplied, so that the requests reach the memory system as a steady stream instead of a
+  // burst behind every barrier.
+  auto issue_part = [&](int part) __attribute__((always_inline)) {
     if (bi < mine) {
-      if (row0 + RG_BR <= p.M) {
-        const bf16_t* ab = pa + kk * RG_BK;
-        rg_dma16s(ab, offa, sl);
-        rg_dma16s(ab + a_p1, offa, sl + RG_WAVES * 1024);
-      } else {   // last block: rows past M re-read row M - 1 (their outputs are never stored)
+      if (part == 0) {
+        if (row0 + RG_BR <= p.M) {
+          const bf16_t* ab = pa + kk * RG_BK;
+          rg_dma16s(ab, offa, sl);
+          rg_dma16s(ab + a_p1, offa, sl + RG_WAVES * 1024);
+        } else {   // last block: rows past M re-read row M - 1 (their outputs are never stored)
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          int r = row0 + (wave + RG_WAVES * i) * 8 + lrow;
-          r = r < p.M ? r : p.M - 1;
-          rg_dma16(A + (long long)r * p.lda + kk * RG_BK + cg * 8, sl + i * RG_WAVES * 1024);
+          for (int i = 0; i < 2; ++i) {
+            int r = row0 + (wave + RG_WAVES * i) * 8 + lrow;
+            r = r < p.M ? r : p.M - 1;
+            rg_dma16(A + (long long)r * p.lda + kk * RG_BK + cg * 8, sl + i * RG_WAVES * 1024);
+          }
+        }
+      } else {
+        const bf16_t* wb = pw + kk * RG_BK;
+        if (part == 1) {
+          rg_dma16s(wb, offw, sl + RG_A_BYTES);
+          rg_dma16s(wb + w_p, offw, sl + RG_A_BYTES + RG_WAVES * 1024);
+        } else {
+          rg_dma16s(wb + 2 * w_p, offw, sl + RG_A_BYTES + 2 * RG_WAVES * 1024);
+          if (nwp == 4) rg_dma16s(wb + 3 * w_p, offw, sl + RG_A_BYTES + 3 * RG_WAVES * 1024);
         }
       }
-      const bf16_t* wb = pw + kk * RG_BK;
-      rg_dma16s(wb, offw, sl + RG_A_BYTES);
-      rg_dma16s(wb + w_p, offw, sl + RG_A_BYTES + RG_WAVES * 1024);
-      rg_dma16s(wb + 2 * w_p, offw, sl + RG_A_BYTES + 2 * RG_WAVES * 1024);
-      if (nwp == 4) rg_dma16s(wb + 3 * w_p, offw, sl + RG_A_BYTES + 3 * RG_WAVES * 1024);
     }
+  };
+  auto issue_advance = [&]() __attribute__((always_inline)) {
     kk = kk + 1 == nk ? 0 : kk + 1;
     sl = sl + RG_STAGE_BYTES == lds0 + wave * 1024 + RG_NS * RG_STAGE_BYTES ? lds0 + wave * 1024 : sl + RG_STAGE_BYTES;
     if (++ki == nk) {   // next block of this workgroup
@@ -110,6 +121,12 @@ __global__ __launch_bounds__(64 * RG_WAVES, 1) void gemm_ring256_kernel(GemmArgs
       pa += (long long)G * RG_BR * p.lda;
       kk = (wg + bi * G) % nk;
     }
+  };
+  auto issue = [&]() __attribute__((always_inline)) {
+    issue_part(0);
+    issue_part(1);
+    issue_part(2);
+    issue_advance();
   };
 
   // ---- MFMA side: lane (r = lane & 31, kg = lane >> 5) reads chunk (2 ks + kg) ^ ((r >> 1) & 7) of its rows
@@ -148,10 +165,8 @@ __global__ __launch_bounds__(64 * RG_WAVES, 1) void gemm_ring256_kernel(GemmArgs
     }
     ++st_age;
     __builtin_amdgcn_s_barrier();
-    issue();
     const unsigned char* S = smem + sc * RG_STAGE_BYTES;
-    // two fragment sets: the 5 reads of k step ks + 1 are issued in the shadow of the 4 MFMAs of step ks (the LDS pipe
-    // is as busy as the matrix core here: 5 KiB of fragments per 4 MFMAs)
+    // two fragment sets: the 5 reads of k step ks + 1 are issued in the shadow of the 4 MFMAs of step ks
     {
       bf16x8 fa[2], fw[2][4];
       fa[0] = *reinterpret_cast<const bf16x8*>(S + a_row + xo[0]);
@@ -161,25 +176,24 @@ __global__ __launch_bounds__(64 * RG_WAVES, 1) void gemm_ring256_kernel(GemmArgs
       for (int ks = 0; ks < 4; ++ks) {
         const int cur = ks & 1, nxt = cur ^ 1;
         if (ks < 3) {
+          issue_part(ks);
           fa[nxt] = *reinterpret_cast<const bf16x8*>(S + a_row + xo[ks + 1]);
 #pragma unroll
           for (int j = 0; j < 4; ++j) fw[nxt][j] = *reinterpret_cast<const bf16x8*>(S + w_row + j * 4096 + xo[ks + 1]);
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur], fw[cur][j], acc[j], 0, 0, 0);
-      }
-      __builtin_amdgcn_sched_group_barrier(0x100, 5, 0);     // fragments of k step 0
-#pragma unroll
-      for (int ks = 0; ks < 3; ++ks) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-#pragma unroll
-        for (int j = 1; j < 4; ++j) {
+        if (ks < 3) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#pragma unroll
+          for (int j = 1; j < 4; ++j) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          }
         }
       }
-      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+      issue_advance();
     }
     sc = sc + 1 == RG_NS ? 0 : sc + 1;
     if (++kc == nk) {
