@@ -15,6 +15,6 @@ cp $(find $OUT/${TAG}_prof -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_benc
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_$c -- python $R/tools/prof_wgrad.py > /dev/null 2>&1
 done
-python $R/tools/pmc_to_json.py xf_wgrad wgrad_kernel $(find $OUT/${TAG}_pmc_FETCH_SIZE $OUT/${TAG}_pmc_WRITE_SIZE -name "*counter_collection.csv") > $OUT/${TAG}_pmc_summary.json
+python $R/tools/pmc_to_json.py xf_wgrad wgrad_dma_kernel $(find $OUT/${TAG}_pmc_FETCH_SIZE $OUT/${TAG}_pmc_WRITE_SIZE -name "*counter_collection.csv") > $OUT/${TAG}_pmc_summary.json
 python $R/tools/gemm_bench.py > $OUT/${TAG}_gemm_microbench.txt 2>&1
 tail -3 $OUT/${TAG}_bench.json; cat $OUT/${TAG}_pmc_summary.json; head -12 $OUT/${TAG}_bench_kernel_stats.csv
