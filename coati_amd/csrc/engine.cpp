@@ -132,6 +132,7 @@ struct coati_engine {
   size_t nce_cap = 0;
   float* opt_partial;
   float* ln_partial;
+  float* ln_part_x;   // [2L + 1][COATI_LN_PARTIAL_ROWS][2C]: deferred LayerNorm dgamma / dbeta partials of one transformer pass
   ShadowJob* d_jobs = nullptr;
   int* d_tile_start = nullptr;
   std::vector<ShadowJob> jobs;
@@ -422,6 +423,7 @@ size_t carve(coati_engine* e, Arena& ar, int B, int T1, int T2, int A, int Bg) {
   e->g_dP = ar.take<bf16_t>(BA * 2 * H);
   e->opt_partial = ar.take<float>(1024);
   e->ln_partial = ar.take<float>((size_t)COATI_LN_PARTIAL_ROWS * 2 * (C > H ? C : H));
+  e->ln_part_x = ar.take<float>((size_t)(2 * c.n_layer_xformer + 1) * COATI_LN_PARTIAL_ROWS * 2 * C);
   {
     ShadowJob* dj = ar.take<ShadowJob>(e->jobs.size());
     int* dt = ar.take<int>(e->tile_start.size());
@@ -480,9 +482,22 @@ int xformer_bwd(coati_engine* e, XPass& p, const void* dyf, int dyf_f32, float* 
   const coati_config& c = e->cfg;
   const int C = c.n_hidden_xformer, L = c.n_layer_xformer, M = p.M;
   float* DX = e->DX;
+  // the dgamma / dbeta partial sums of the pass's 2L + 1 LayerNorms are added up by ONE launch at the end
+  const bool defer = 2 * L + 1 <= COATI_LN_MAX_SLOTS;
+  const long long slot_stride = (long long)COATI_LN_PARTIAL_ROWS * 2 * C;
+  LnFinishBatch fin;
+  fin.n = 0;
+  int nblk = 0;
+  auto ln_bwd = [&](const void* dy, int dy_f32, const float* x, const float* mean, const float* rstd, const float* gamma,
+                    const float* dres, size_t goff, size_t boff) -> int {
+    if (!defer) return launch_layernorm_bwd(dy, dy_f32, C, x, C, 0, mean, rstd, gamma, dres, DX, e->DX16, e->G + goff, e->G + boff, e->ln_partial, M, C, s);
+    fin.dg_off[fin.n] = (long long)goff;
+    fin.db_off[fin.n] = (long long)boff;
+    return launch_layernorm_bwd_deferred(dy, dy_f32, C, x, C, 0, mean, rstd, gamma, dres, DX, e->DX16, e->ln_part_x + (fin.n++) * slot_stride, &nblk, M, C, s);
+  };
   {
     ProfScope ps(e, SITE_LN_BWD, 0, s, (double)M * C * ((dyf_f32 ? 4 : 2) + 4 + 4 + 2));
-    COATI_TRY(launch_layernorm_bwd(dyf, dyf_f32, C, p.x[L], C, 0, p.meanf, p.rstdf, e->P + e->lnfw, nullptr, DX, e->DX16, e->G + e->lnfw, e->G + e->lnfb, e->ln_partial, M, C, s));
+    COATI_TRY(ln_bwd(dyf, dyf_f32, p.x[L], p.meanf, p.rstdf, e->P + e->lnfw, nullptr, e->lnfw, e->lnfb));
   }
   for (int l = L - 1; l >= 0; --l) {
     const XLayerP& w = e->xl[l];
@@ -494,7 +509,7 @@ int xformer_bwd(coati_engine* e, XPass& p, const void* dyf, int dyf_f32, float* 
     COATI_TRY(wgrad(e, SITE_XF_WGRAD, e->dh4, 0, 4 * C, p.a2[l], C, M, 4 * C, C, e->G + w.fc1w, C, e->G + w.fc1b, 0, s));
     {
       ProfScope ps(e, SITE_LN_BWD, 0, s, (double)M * C * (2 + 4 + 4 + 4 + 2));   // dy16, x, dres in; dx, dx16 out
-      COATI_TRY(launch_layernorm_bwd(e->da, 0, C, p.xmid[l], C, 0, p.mean2[l], p.rstd2[l], e->P + w.ln2w, DX, DX, e->DX16, e->G + w.ln2w, e->G + w.ln2b, e->ln_partial, M, C, s));
+      COATI_TRY(ln_bwd(e->da, 0, p.xmid[l], p.mean2[l], p.rstd2[l], e->P + w.ln2w, DX, w.ln2w, w.ln2b));
     }
     // xmid = x[l] + y Wp^T + bp
     COATI_TRY(gemm(e, SITE_PROJ_DGRAD, e->DX16, 0, C, e->S + w.projT, C, M, C, C, e->dyb, C, nullptr, EPI_BF16, nullptr, nullptr, 0, s));
@@ -507,8 +522,12 @@ int xformer_bwd(coati_engine* e, XPass& p, const void* dyf, int dyf_f32, float* 
     COATI_TRY(wgrad(e, SITE_XF_WGRAD, e->dqkv, 0, 3 * C, p.a1[l], C, M, 3 * C, C, e->G + w.attnw, C, e->G + w.attnb, 0, s));
     {
       ProfScope ps(e, SITE_LN_BWD, 0, s, (double)M * C * (2 + 4 + 4 + 4 + 2));   // dy16, x, dres in; dx, dx16 out
-      COATI_TRY(launch_layernorm_bwd(e->da, 0, C, p.x[l], C, 0, p.mean1[l], p.rstd1[l], e->P + w.ln1w, DX, DX, e->DX16, e->G + w.ln1w, e->G + w.ln1b, e->ln_partial, M, C, s));
+      COATI_TRY(ln_bwd(e->da, 0, p.x[l], p.mean1[l], p.rstd1[l], e->P + w.ln1w, DX, w.ln1w, w.ln1b));
     }
+  }
+  if (defer) {
+    ProfScope ps(e, SITE_LN_BWD, 0, s, 0.0);
+    COATI_TRY(launch_ln_finish_batched(e->ln_part_x, slot_stride, nblk, e->G, fin, C, s));
   }
   ProfScope ps(e, SITE_EMBED, 0, s);
   return launch_embed_bwd(p.idx, DX, e->G + e->tok_emb, dinjection, c.unk_token, p.B, p.T, C, c.n_tok, s);

@@ -74,7 +74,10 @@ __global__ __launch_bounds__(64 * RG_WAVES, 1) void gemm_ring256_kernel(GemmArgs
   //   every block walks k from its own starting chunk (blk % nk): with a power-of-two row pitch all blocks would
   //   otherwise read the same 128-B column of their rows at the same time, i.e. the same few HBM channels
   int bi = 0, ki = 0;                            // block index (of mine), stages issued of that block
-  int kk = wg % nk;                              // k chunk of the next stage
+  // (only for the bf16-output products, i.e. the input gradients: the residual product is the forward fc2, whose rows
+  //  must not depend on where in the batch they sit -- the k order is part of the fp32 sum)
+  constexpr bool ROT = (EPI != EPI_RES_F32);
+  int kk = ROT ? wg % nk : 0;                    // k chunk of the next stage
   int row0 = wg * RG_BR;
   const bf16_t* pa = A + ((long long)row0 + 8 * wave) * p.lda;          // this wave's first A piece, k = 0
   const long long a_p1 = 8LL * RG_WAVES * p.lda;                          // second A piece
@@ -119,7 +122,7 @@ __global__ __launch_bounds__(64 * RG_WAVES, 1) void gemm_ring256_kernel(GemmArgs
       ++bi;
       row0 += G * RG_BR;
       pa += (long long)G * RG_BR * p.lda;
-      kk = (wg + bi * G) % nk;
+      kk = ROT ? (wg + bi * G) % nk : 0;
     }
   };
   auto issue = [&]() __attribute__((always_inline)) {

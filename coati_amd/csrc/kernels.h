@@ -99,6 +99,20 @@ int launch_layernorm_bwd(const void* dy, int dy_f32, long long lddy, const float
                          const float* mean, const float* rstd, const float* gamma, const float* dres,
                          float* dx, bf16_t* dx16, float* dgamma, float* dbeta, float* partial, int M, int C, hipStream_t s);
 // partial: optional [2048, 2C] f32 scratch -> deterministic two-stage dgamma/dbeta reduction (else fp32 atomics)
+// The same without the second stage: the per-workgroup [gamma | beta] partial sums stay in `partial` (COATI_LN_PARTIAL_ROWS x
+// 2C floats at most; *nblk_out rows are valid) until launch_ln_finish_batched adds them up -- one launch for all the
+// LayerNorms of a transformer pass instead of one 5-us launch each.
+int launch_layernorm_bwd_deferred(const void* dy, int dy_f32, long long lddy, const float* x, long long ldx, int x_is_xhat,
+                                  const float* mean, const float* rstd, const float* gamma, const float* dres, float* dx,
+                                  bf16_t* dx16, float* partial, int* nblk_out, int M, int C, hipStream_t s);
+#define COATI_LN_MAX_SLOTS 72
+struct LnFinishBatch {
+  int n;                                   // slots in use
+  long long dg_off[COATI_LN_MAX_SLOTS];    // offsets of dgamma / dbeta of slot i from the gradient base pointer
+  long long db_off[COATI_LN_MAX_SLOTS];
+};
+int launch_ln_finish_batched(const float* partial, long long slot_stride, int nblk, float* grad_base, const LnFinishBatch& b,
+                             int C, hipStream_t s);
 #define COATI_LN_PARTIAL_ROWS 2048
 
 // ------------------------------------------------------------------------------------------------

@@ -198,9 +198,9 @@ __global__ __launch_bounds__(256) void ln_bwd_finish_kernel(const float* __restr
   }
 }
 
-int launch_layernorm_bwd(const void* dy, int dy_f32, long long lddy, const float* x, long long ldx, int x_is_xhat,
+static int ln_bwd_stage1(const void* dy, int dy_f32, long long lddy, const float* x, long long ldx, int x_is_xhat,
                          const float* mean, const float* rstd, const float* gamma, const float* dres,
-                         float* dx, bf16_t* dx16, float* dgamma, float* dbeta, float* partial, int M, int C, hipStream_t s) {
+                         float* dx, bf16_t* dx16, float* dgamma, float* dbeta, float* partial, int M, int C, int* nblk_out, hipStream_t s) {
   COATI_CHECK_ARG(dy && x && rstd && dx, "layernorm_bwd: null operand");
   COATI_CHECK_ARG(x_is_xhat || mean, "layernorm_bwd: mean required unless x holds xhat");
   COATI_CHECK_ARG((dgamma == nullptr) == (dbeta == nullptr), "layernorm_bwd: dgamma/dbeta must both be given or both null");
@@ -218,9 +218,60 @@ int launch_layernorm_bwd(const void* dy, int dy_f32, long long lddy, const float
   }
 #undef LN_B
   COATI_LAUNCH_CHECK("layernorm_bwd");
+  if (nblk_out) *nblk_out = blocks;
+  return COATI_OK;
+}
+
+int launch_layernorm_bwd(const void* dy, int dy_f32, long long lddy, const float* x, long long ldx, int x_is_xhat,
+                         const float* mean, const float* rstd, const float* gamma, const float* dres,
+                         float* dx, bf16_t* dx16, float* dgamma, float* dbeta, float* partial, int M, int C, hipStream_t s) {
+  int blocks = 0;
+  const int rc = ln_bwd_stage1(dy, dy_f32, lddy, x, ldx, x_is_xhat, mean, rstd, gamma, dres, dx, dx16, dgamma, dbeta, partial, M, C, &blocks, s);
+  if (rc != COATI_OK) return rc;
   if (dgamma && partial) {
     hipLaunchKernelGGL(ln_bwd_finish_kernel, dim3(cdiv(2 * C, 64), 32), dim3(256), 0, s, partial, blocks, dgamma, dbeta, C);
     COATI_LAUNCH_CHECK("layernorm_bwd(finish)");
   }
+  return COATI_OK;
+}
+
+int launch_layernorm_bwd_deferred(const void* dy, int dy_f32, long long lddy, const float* x, long long ldx, int x_is_xhat,
+                                  const float* mean, const float* rstd, const float* gamma, const float* dres, float* dx,
+                                  bf16_t* dx16, float* partial, int* nblk_out, int M, int C, hipStream_t s) {
+  COATI_CHECK_ARG(partial && nblk_out, "layernorm_bwd_deferred: partial buffer missing");
+  // any non-null dgamma / dbeta selects the partial-sum path of the kernel; they are not written there
+  return ln_bwd_stage1(dy, dy_f32, lddy, x, ldx, x_is_xhat, mean, rstd, gamma, dres, dx, dx16, partial, partial, partial, M, C, nblk_out, s);
+}
+
+// stage 2 for a batch of LayerNorms: blockIdx.z = slot
+__global__ __launch_bounds__(256) void ln_bwd_finish_batched_kernel(const float* __restrict__ partial, long long slot_stride, int nblk,
+                                                                    float* __restrict__ grad_base, LnFinishBatch b, int C) {
+  __shared__ float red[4][64];
+  const int slot = blockIdx.z;
+  const float* ps = partial + (long long)slot * slot_stride;
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
+  const int per = (nblk + gridDim.y - 1) / gridDim.y;
+  const int r0 = blockIdx.y * per;
+  int r1 = r0 + per;
+  if (r1 > nblk) r1 = nblk;
+  float acc = 0.f;
+  if (col < 2 * C) {
+#pragma unroll 4
+    for (int r = r0 + rg; r < r1; r += 4) acc += ps[(long long)r * 2 * C + col];
+  }
+  red[rg][threadIdx.x & 63] = acc;
+  __syncthreads();
+  if (rg == 0 && col < 2 * C) {
+    const float t = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    atomicAdd(col < C ? grad_base + b.dg_off[slot] + col : grad_base + b.db_off[slot] + (col - C), t);
+  }
+}
+
+int launch_ln_finish_batched(const float* partial, long long slot_stride, int nblk, float* grad_base, const LnFinishBatch& b,
+                             int C, hipStream_t s) {
+  COATI_CHECK_ARG(partial && grad_base && b.n > 0 && b.n <= COATI_LN_MAX_SLOTS, "ln_finish_batched: bad batch");
+  hipLaunchKernelGGL(ln_bwd_finish_batched_kernel, dim3(cdiv(2 * C, 64), 32, b.n), dim3(256), 0, s, partial, slot_stride, nblk,
+                     grad_base, b, C);
+  COATI_LAUNCH_CHECK("ln_finish_batched");
   return COATI_OK;
 }
