@@ -12,7 +12,7 @@ extern "C" {
 int coati_gemm_nt(const void* A, int a_f32, int64_t lda, const uint16_t* B, int64_t ldb, int M, int N, int K,
                   void* C, int64_t ldc, int n_store, const float* bias, const void* aux_in, void* aux_out,
                   int64_t ld_aux, int epi, void* stream) {
-  COATI_CHECK_ARG(epi >= EPI_BF16 && epi <= EPI_ACC_F32, "coati_gemm_nt: epilogue %d is not a plain epilogue", epi);
+  COATI_CHECK_ARG((epi >= EPI_BF16 && epi <= EPI_ACC_F32) || epi == EPI_GELU_GRAD || epi == EPI_MUL_AUX, "coati_gemm_nt: epilogue %d is not a plain epilogue", epi);
   GemmArgs a;
   memset(&a, 0, sizeof(a));
   a.A = A; a.lda = lda; a.B = B; a.ldb = ldb; a.M = M; a.N = N; a.K = K; a.C = C; a.ldc = ldc; a.n_store = n_store;

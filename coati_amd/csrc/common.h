@@ -94,6 +94,16 @@ __device__ __forceinline__ float dgelu_f(float x) {
   const float zp = k2 * fmaf(3.0f * 0.044715f, x2, 1.0f);
   return fmaf(x * s * (1.0f - s), zp, s);
 }
+// both at once (one sigmoid): the forward MLP stores NewGELU' next to NewGELU, so the backward is a plain multiply
+__device__ __forceinline__ void gelu_and_grad_f(float x, float& h, float& d) {
+  const float k2 = 2.0f * 0.7978845608028654f;
+  const float x2 = x * x;
+  const float z = k2 * fmaf(0.044715f * x2, x, x);
+  const float s = sigmoid_f(z);
+  const float zp = k2 * fmaf(3.0f * 0.044715f, x2, 1.0f);
+  h = x * s;
+  d = fmaf(h * (1.0f - s), zp, s);
+}
 __device__ __forceinline__ float silu_f(float x) { return x * sigmoid_f(x); }
 __device__ __forceinline__ float dsilu_f(float x) {
   float s = sigmoid_f(x);

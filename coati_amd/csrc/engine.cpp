@@ -326,7 +326,7 @@ int gemm(coati_engine* e, int site, const void* A, int a_f32, int64_t lda, const
   const bool out32 = (epi == EPI_F32 || epi == EPI_RES_F32 || epi == EPI_ACC_F32);
   double bytes = (double)M * K * (a_f32 ? 4 : 2) + (double)N * K * 2 + (double)M * N * (out32 ? 4 : 2);
   if (epi == EPI_RES_F32 || epi == EPI_ACC_F32) bytes += (double)M * N * 4;
-  if (epi == EPI_GELU || epi == EPI_SILU || epi == EPI_DGELU || epi == EPI_DSILU) bytes += (double)M * N * 2;
+  if (epi == EPI_GELU || epi == EPI_SILU || epi == EPI_DGELU || epi == EPI_DSILU || epi == EPI_GELU_GRAD || epi == EPI_MUL_AUX) bytes += (double)M * N * 2;
   ProfScope ps(e, site, 2.0 * M * N * K, s, bytes);
   return launch_gemm_nt(a, a_f32, epi, s);
 }
@@ -470,7 +470,9 @@ int xformer_fwd(coati_engine* e, XPass& p, const float* injection, hipStream_t s
       ProfScope ps(e, SITE_LN_FWD, 0, s, (double)M * C * 6 + (double)M * 8);
       COATI_TRY(launch_layernorm_fwd(p.xmid[l], C, e->P + w.ln2w, e->P + w.ln2b, p.a2[l], C, nullptr, 0, p.mean2[l], p.rstd2[l], M, C, s));
     }
-    COATI_TRY(gemm(e, SITE_FC1_FWD, p.a2[l], 0, C, e->S + w.fc1w, C, M, 4 * C, C, p.g[l], 4 * C, e->P + w.fc1b, EPI_GELU, nullptr, p.hpre[l], 4 * C, s));
+    // hpre holds NewGELU'(pre-activation), not the pre-activation: the backward multiplies instead of re-evaluating the
+    // sigmoid (the activation epilogues are VALU-bound: 2 quarter-rate transcendentals per element)
+    COATI_TRY(gemm(e, SITE_FC1_FWD, p.a2[l], 0, C, e->S + w.fc1w, C, M, 4 * C, C, p.g[l], 4 * C, e->P + w.fc1b, EPI_GELU_GRAD, nullptr, p.hpre[l], 4 * C, s));
     COATI_TRY(gemm(e, SITE_FC2_FWD, p.g[l], 0, 4 * C, e->S + w.fc2w, 4 * C, M, C, 4 * C, p.x[l + 1], C, e->P + w.fc2b, EPI_RES_F32, p.xmid[l], nullptr, C, s));
   }
   ProfScope ps(e, SITE_LN_FWD, 0, s, (double)M * C * 10 + (double)M * 8);
@@ -502,7 +504,7 @@ int xformer_bwd(coati_engine* e, XPass& p, const void* dyf, int dyf_f32, float* 
   for (int l = L - 1; l >= 0; --l) {
     const XLayerP& w = e->xl[l];
     // x[l+1] = xmid + g W2^T + b2
-    COATI_TRY(gemm(e, SITE_FC2_DGRAD, e->DX16, 0, C, e->S + w.fc2T, C, M, 4 * C, C, e->dh4, 4 * C, nullptr, EPI_DGELU, p.hpre[l], nullptr, 4 * C, s));
+    COATI_TRY(gemm(e, SITE_FC2_DGRAD, e->DX16, 0, C, e->S + w.fc2T, C, M, 4 * C, C, e->dh4, 4 * C, nullptr, EPI_MUL_AUX, p.hpre[l], nullptr, 4 * C, s));
     COATI_TRY(wgrad(e, SITE_XF_WGRAD, e->DX16, 0, C, p.g[l], 4 * C, M, C, 4 * C, e->G + w.fc2w, 4 * C, e->G + w.fc2b, 0, s));
     // hpre = a2 W1^T + b1
     COATI_TRY(gemm(e, SITE_FC1_DGRAD, e->dh4, 0, 4 * C, e->S + w.fc1T, 4 * C, M, C, 4 * C, e->da, C, nullptr, EPI_BF16, nullptr, nullptr, 0, s));

@@ -206,7 +206,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_nt_kernel(GemmArgs p) {
   // are issued first, so their latency is paid once per workgroup instead of once per task
   constexpr int TASKS = 2048 / NT;
   constexpr bool PRE_F32 = (EPI == EPI_RES_F32 || EPI == EPI_ACC_F32);
-  constexpr bool PRE_B16 = (EPI == EPI_DGELU || EPI == EPI_DSILU);
+  constexpr bool PRE_B16 = (EPI == EPI_DGELU || EPI == EPI_DSILU || EPI == EPI_MUL_AUX);
   EpiPre pre[TASKS];
 #pragma unroll
   for (int i = 0; i < TASKS; ++i) {
@@ -263,8 +263,8 @@ int launch_gemm_nt(const GemmArgs& a, int a_f32, int epi, hipStream_t s) {
   if (epi != EPI_CE_PARTIAL)
     COATI_CHECK_SHAPE(a.ldc % (out_f32 ? 4 : 8) == 0, "gemm_nt: ldc=%lld alignment", a.ldc);
   if (epi == EPI_RES_F32) COATI_CHECK_ARG(a.aux_in && a.ld_aux % 4 == 0, "gemm_nt: residual missing/misaligned");
-  if (epi == EPI_GELU || epi == EPI_SILU) COATI_CHECK_ARG(a.aux_out && a.ld_aux % 8 == 0, "gemm_nt: aux_out missing");
-  if (epi == EPI_DGELU || epi == EPI_DSILU) COATI_CHECK_ARG(a.aux_in && a.ld_aux % 8 == 0, "gemm_nt: aux_in missing");
+  if (epi == EPI_GELU || epi == EPI_SILU || epi == EPI_GELU_GRAD) COATI_CHECK_ARG(a.aux_out && a.ld_aux % 8 == 0, "gemm_nt: aux_out missing");
+  if (epi == EPI_DGELU || epi == EPI_DSILU || epi == EPI_MUL_AUX) COATI_CHECK_ARG(a.aux_in && a.ld_aux % 8 == 0, "gemm_nt: aux_in missing");
   if (epi == EPI_CE_PARTIAL) COATI_CHECK_ARG(a.partial, "gemm_nt: partial buffer missing");
   if (epi == EPI_CE_BWD) COATI_CHECK_ARG(a.lse && a.target && a.scal, "gemm_nt: CE operands missing");
   if (epi == EPI_QKV_ROPE) COATI_CHECK_ARG(a.rope_cos && a.rope_sin && a.rope_T > 0 && a.rope_C > 0 && a.N % 16 == 0 && a.rope_C % 16 == 0 && (a.rope_hs == 0 || a.rope_hs == 16 || a.rope_hs == 32) && (a.rope_hs != 32 || a.rope_C % 32 == 0), "gemm_nt: rope operands missing / unsupported head size");
@@ -295,6 +295,8 @@ int launch_gemm_nt(const GemmArgs& a, int a_f32, int epi, hipStream_t s) {
     NT_CASE_B16(EPI_CE_BWD)
     NT_CASE_B16(EPI_EDGE_DPRE)
     NT_CASE_B16(EPI_QKV_ROPE)
+    NT_CASE_B16(EPI_GELU_GRAD)
+    NT_CASE_B16(EPI_MUL_AUX)
     default:
       coati_set_error("gemm_nt: unknown epilogue %d", epi);
       return COATI_EARG;

@@ -116,6 +116,16 @@ __device__ __forceinline__ void epilogue8(const GemmArgs& p, int row, int col0, 
       const float r = hi_half ? (v[e] * c + other * s_) : (v[e] * c - other * s_);
       o[e] = rot ? r : v[e];
     }
+  } else if (EPI == EPI_GELU_GRAD) {
+    bf16_t* X = reinterpret_cast<bf16_t*>(p.aux_out);
+    float d[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) gelu_and_grad_f(v[e], o[e], d[e]);
+    if (full) {
+      *reinterpret_cast<uint4*>(X + aoff) = pack8(d);
+    } else {
+      for (int e = 0; e < 8 && col0 + e < N; ++e) X[aoff + e] = f2bf(d[e]);
+    }
   } else if (EPI == EPI_GELU || EPI == EPI_SILU) {
     bf16_t* X = reinterpret_cast<bf16_t*>(p.aux_out);
     if (full) {
@@ -125,7 +135,7 @@ __device__ __forceinline__ void epilogue8(const GemmArgs& p, int row, int col0, 
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] = (EPI == EPI_GELU) ? gelu_f(v[e]) : silu_f(v[e]);
-  } else if (EPI == EPI_DGELU || EPI == EPI_DSILU) {
+  } else if (EPI == EPI_DGELU || EPI == EPI_DSILU || EPI == EPI_MUL_AUX) {
     const bf16_t* X = reinterpret_cast<const bf16_t*>(p.aux_in);
     float x[8];
     if (pre && pre->have) {
@@ -138,7 +148,7 @@ __device__ __forceinline__ void epilogue8(const GemmArgs& p, int row, int col0, 
       for (int e = 0; e < 8; ++e) x[e] = (col0 + e < N) ? bf2f(X[aoff + e]) : 0.f;
     }
 #pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = v[e] * ((EPI == EPI_DGELU) ? dgelu_f(x[e]) : dsilu_f(x[e]));
+    for (int e = 0; e < 8; ++e) o[e] = v[e] * ((EPI == EPI_MUL_AUX) ? x[e] : (EPI == EPI_DGELU) ? dgelu_f(x[e]) : dsilu_f(x[e]));
   } else if (EPI == EPI_CE_BWD) {
     const long long tgt = p.target[row];
     const float cnt = p.scal[1];

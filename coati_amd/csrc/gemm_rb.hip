@@ -51,7 +51,7 @@ __global__ __launch_bounds__(64 * MAXW, 640 / (64 * MAXW)) void gemm_rb256_kerne
   float* const Es = reinterpret_cast<float*>(smem + 2 * RB_TILE_HALFS * 2) + wave * RB_EFLOATS;
   float* const Rs = reinterpret_cast<float*>(smem + 2 * RB_TILE_HALFS * 2) + W * RB_EFLOATS + wave * RB_ROPE_FLOATS;
   unsigned char* const Xs = smem + 2 * RB_TILE_HALFS * 2 + (size_t)W * RB_EFLOATS * 4 + wave * RB_AUX_BYTES;   // DGELU / DSILU
-  constexpr bool AUX = (EPI == EPI_DGELU || EPI == EPI_DSILU);
+  constexpr bool AUX = (EPI == EPI_DGELU || EPI == EPI_DSILU || EPI == EPI_MUL_AUX);
   constexpr bool EDGE = (EPI == EPI_EDGE_DPRE);   // per-column constants of the tile staged in Rs: [64 w1c | 64 b1]
   const int m0 = (blockIdx.x * W + wave) * 32;
   const int fr = lane & 31, fk = (lane >> 5) * 8;
@@ -230,7 +230,7 @@ bool gemm_rb256_supported(const GemmArgs& a, int a_f32, int epi) {
   if (a.N % 16 != 0 && epi != EPI_CE_BWD) return false;
   if (rb_waves(a.M) < 8) return false;   // small problems run on the tiled kernel
   if ((excl & 1) && a.N < 512) return false;
-  if ((excl & 2) && (epi == EPI_RES_F32 || epi == EPI_ACC_F32 || epi == EPI_F32 || epi == EPI_DGELU || epi == EPI_DSILU || epi == EPI_EDGE_DPRE)) return false;
+  if ((excl & 2) && (epi == EPI_RES_F32 || epi == EPI_ACC_F32 || epi == EPI_F32 || epi == EPI_DGELU || epi == EPI_DSILU || epi == EPI_MUL_AUX || epi == EPI_EDGE_DPRE)) return false;
   return true;
 }
 
@@ -240,7 +240,7 @@ static int launch_rb_shape(const GemmArgs& a, int W, hipStream_t s) {
   auto kern = gemm_rb256_kernel<EPI, BN, MAXW>;
   const size_t tile_bytes = (size_t)2 * BN * RB_K * 2;              // double-buffered weight tile
   const size_t per_wave = (size_t)16 * (BN + 4) * 4 + ((EPI == EPI_QKV_ROPE || EPI == EPI_EDGE_DPRE) ? RB_ROPE_FLOATS * 4
-                                                       : (EPI == EPI_DGELU || EPI == EPI_DSILU) ? RB_AUX_BYTES : 0);
+                                                       : (EPI == EPI_DGELU || EPI == EPI_DSILU || EPI == EPI_MUL_AUX) ? RB_AUX_BYTES : 0);
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)(tile_bytes + MAXW * per_wave));
@@ -272,6 +272,8 @@ int launch_gemm_rb256(const GemmArgs& a, int epi, hipStream_t s) {
     case EPI_RES_F32: return launch_rb_t<EPI_RES_F32>(a, s);
     case EPI_GELU: return launch_rb_t<EPI_GELU>(a, s);
     case EPI_DGELU: return launch_rb_t<EPI_DGELU>(a, s);
+    case EPI_GELU_GRAD: return launch_rb_t<EPI_GELU_GRAD>(a, s);
+    case EPI_MUL_AUX: return launch_rb_t<EPI_MUL_AUX>(a, s);
     case EPI_SILU: return launch_rb_t<EPI_SILU>(a, s);
     case EPI_DSILU: return launch_rb_t<EPI_DSILU>(a, s);
     case EPI_ACC_F32: return launch_rb_t<EPI_ACC_F32>(a, s);

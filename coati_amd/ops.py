@@ -8,6 +8,7 @@ import torch
 from . import _lib
 
 EPI_BF16, EPI_F32, EPI_RES_F32, EPI_GELU, EPI_DGELU, EPI_SILU, EPI_DSILU, EPI_ACC_F32 = range(8)
+EPI_GELU_GRAD, EPI_MUL_AUX = 12, 13
 BF16 = torch.bfloat16
 
 
@@ -26,7 +27,7 @@ def _need_cuda(*ts):
 
 
 def gemm_nt(A, W, bias=None, epi=EPI_BF16, aux_in=None, out=None, n_store=0):
-    """C = epilogue(A @ W^T + bias).  A [M,K] bf16|f32, W [N,K] bf16.  Returns C or (C, pre) for GELU/SILU."""
+    """C = epilogue(A @ W^T + bias).  A [M,K] bf16|f32, W [N,K] bf16.  Returns C or (C, pre) for GELU/SILU, (C, NewGELU'(pre)) for GELU_GRAD."""
     _need_cuda(A, W)
     M, K = A.shape
     N = W.shape[0]
@@ -37,7 +38,7 @@ def gemm_nt(A, W, bias=None, epi=EPI_BF16, aux_in=None, out=None, n_store=0):
         out = torch.empty(M, ncol, device=A.device, dtype=torch.float32 if out_f32 else BF16)
     aux_out = None
     ld_aux = 0
-    if epi in (EPI_GELU, EPI_SILU):
+    if epi in (EPI_GELU, EPI_SILU, EPI_GELU_GRAD):
         aux_out = torch.empty(M, N, device=A.device, dtype=BF16)
         ld_aux = aux_out.stride(0)
     if aux_in is not None:

@@ -48,7 +48,10 @@ int coati_abi_version(void);
 /* epilogue selector of coati_gemm_nt (values of enum CoatiEpi in csrc/kernels.h) */
 enum {
   COATI_EPI_BF16 = 0, COATI_EPI_F32 = 1, COATI_EPI_RES_F32 = 2, COATI_EPI_GELU = 3, COATI_EPI_DGELU = 4,
-  COATI_EPI_SILU = 5, COATI_EPI_DSILU = 6, COATI_EPI_ACC_F32 = 7
+  COATI_EPI_SILU = 5, COATI_EPI_DSILU = 6, COATI_EPI_ACC_F32 = 7,
+  /* 8..11: internal to the engine (fused cross-entropy, GNN edge, QKV + RoPE) */
+  COATI_EPI_GELU_GRAD = 12,   /* aux_out = NewGELU'(acc + bias), C = NewGELU(acc + bias): the MLP forward as the engine runs it */
+  COATI_EPI_MUL_AUX = 13      /* C = acc * aux_in: its backward (input gradient of the activation) */
 };
 
 /* C[M,N] = epilogue(A[M,K] * B[N,K]^T + bias).  Replaces nn.Linear forward (F.linear) and its input-gradient,

@@ -60,6 +60,13 @@ def test_gemm_epilogues(ops, M, N, K):
         (dg,) = torch.autograd.grad(gelu(xg).sum(), xg)
         c = ops.gemm_nt(Ab, Wb, None, ops.EPI_DGELU, aux_in=x.bfloat16())
         check(f"gemm dgelu {M}x{N}x{K}", c.float(), (A @ W.t()) * dg, TB)
+        c = ops.gemm_nt(Ab, Wb, None, ops.EPI_MUL_AUX, aux_in=x.bfloat16())
+        check(f"gemm mul_aux {M}x{N}x{K}", c.float(), (A @ W.t()) * x, TB)
+        rg = ref.clone().requires_grad_(True)
+        (dref,) = torch.autograd.grad(gelu(rg).sum(), rg)
+        c, dact = ops.gemm_nt(Ab, Wb, bias, ops.EPI_GELU_GRAD)
+        check(f"gemm gelu_grad h {M}x{N}x{K}", c.float(), gelu(ref), TB)
+        check(f"gemm gelu_grad d {M}x{N}x{K}", dact.float(), dref, TB)
         (ds,) = torch.autograd.grad(torch.nn.functional.silu(xg).sum(), xg)
         c = ops.gemm_nt(A, Wb, None, ops.EPI_DSILU, aux_in=x.bfloat16())
         check(f"gemm dsilu(A f32) {M}x{N}x{K}", c.float(), (A @ W.t()) * ds, TB)
