@@ -94,15 +94,21 @@ __device__ __forceinline__ float dgelu_f(float x) {
   const float zp = k2 * fmaf(3.0f * 0.044715f, x2, 1.0f);
   return fmaf(x * s * (1.0f - s), zp, s);
 }
-// both at once (one sigmoid): the forward MLP stores NewGELU' next to NewGELU, so the backward is a plain multiply
-__device__ __forceinline__ void gelu_and_grad_f(float x, float& h, float& d) {
+// both at once (one sigmoid): the forward MLP stores NewGELU' next to NewGELU, so the backward is a plain multiply.
+// Two elements per call: everything but the two transcendentals is packed fp32 (v_pk_mul / v_pk_fma / v_pk_add, two
+// lanes' worth per issue slot) -- the activation epilogues are VALU-bound.
+typedef float coati_v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void gelu_and_grad_f2(coati_v2f x, coati_v2f& h, coati_v2f& d) {
   const float k2 = 2.0f * 0.7978845608028654f;
-  const float x2 = x * x;
-  const float z = k2 * fmaf(0.044715f * x2, x, x);
-  const float s = sigmoid_f(z);
-  const float zp = k2 * fmaf(3.0f * 0.044715f, x2, 1.0f);
+  const coati_v2f one = {1.0f, 1.0f};
+  const coati_v2f x2 = x * x;
+  const coati_v2f t = x * __builtin_elementwise_fma(coati_v2f{0.044715f, 0.044715f}, x2, one);    // x + 0.044715 x^3
+  const coati_v2f a = t * coati_v2f{-COATI_LOG2E * k2, -COATI_LOG2E * k2};                        // -log2(e) z
+  const coati_v2f den = coati_v2f{__builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y)} + one;
+  const coati_v2f s = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+  const coati_v2f zp = __builtin_elementwise_fma(coati_v2f{3.0f * 0.044715f * k2, 3.0f * 0.044715f * k2}, x2, coati_v2f{k2, k2});
   h = x * s;
-  d = fmaf(h * (1.0f - s), zp, s);
+  d = __builtin_elementwise_fma(h * (one - s), zp, s);
 }
 __device__ __forceinline__ float silu_f(float x) { return x * sigmoid_f(x); }
 __device__ __forceinline__ float dsilu_f(float x) {

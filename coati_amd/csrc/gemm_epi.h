@@ -120,7 +120,12 @@ __device__ __forceinline__ void epilogue8(const GemmArgs& p, int row, int col0, 
     bf16_t* X = reinterpret_cast<bf16_t*>(p.aux_out);
     float d[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) gelu_and_grad_f(v[e], o[e], d[e]);
+    for (int e = 0; e < 8; e += 2) {
+      coati_v2f hh, dd;
+      gelu_and_grad_f2(coati_v2f{v[e], v[e + 1]}, hh, dd);
+      o[e] = hh.x; o[e + 1] = hh.y;
+      d[e] = dd.x; d[e + 1] = dd.y;
+    }
     if (full) {
       *reinterpret_cast<uint4*>(X + aoff) = pack8(d);
     } else {
