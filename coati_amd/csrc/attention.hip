@@ -149,7 +149,9 @@ __device__ __forceinline__ f32x16 score_block(const bf16_t* Xs, int blk, const b
   return s;
 }
 
-template <int HS>
+// NB > 0: the sequence fits NB 32-row blocks and every loop bound is a compile-time constant (the staging loads of a
+// workgroup are then issued back to back instead of one load -> store round trip per iteration); NB = 0: any T <= 256.
+template <int HS, int NB>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ y,
                                                        float* __restrict__ lse, int T, int n_head, int quads) {
   constexpr int NK = HS / 16, LIVE = HS / 2;
@@ -159,7 +161,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
   const int b = blockIdx.x / quads, hq = blockIdx.x - b * quads;
   const int hh = hq * 4 + wave;
   const int heads_here = (n_head - hq * 4) < 4 ? (n_head - hq * 4) : 4;
-  const int C = n_head * HS, Tp = (T + 31) & ~31;
+  const int C = n_head * HS, Tp = NB ? 32 * NB : ((T + 31) & ~31);
   const size_t pw = (size_t)2 * Tp * HS * 2;
   bf16_t* Ks = reinterpret_cast<bf16_t*>(smem + (size_t)wave * pw);
   bf16_t* Vs = Ks + Tp * HS;
@@ -174,6 +176,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
   const bf16_t* qsrc = qkv + (long long)b * T * stride + (active ? hh : 0) * HS;
 
   const int nblk = Tp >> 5, half = lane >> 5;
+#pragma unroll
   for (int qb = 0; qb < nblk; ++qb) {
     const int q = qb * 32 + (lane & 31);
     if (active) {
@@ -232,13 +235,13 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
   }
 }
 
-template <int HS>
+template <int HS, int NB>
 static int launch_attn_fwd_t(const bf16_t* qkv, bf16_t* y, float* lse, int B, int T, int n_head, hipStream_t s) {
   const int Tp = (T + 31) & ~31;
   const size_t lds = (size_t)4 * 2 * Tp * HS * 2 + ot_bytes<HS>();
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<HS>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<HS, NB>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) {
       coati_set_error("attn_fwd: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
@@ -247,7 +250,7 @@ static int launch_attn_fwd_t(const bf16_t* qkv, bf16_t* y, float* lse, int B, in
     attr_set = true;
   }
   const int quads = cdiv(n_head, 4);
-  hipLaunchKernelGGL(attn_fwd_kernel<HS>, dim3(B * quads), dim3(256), lds, s, qkv, y, lse, T, n_head, quads);
+  hipLaunchKernelGGL((attn_fwd_kernel<HS, NB>), dim3(B * quads), dim3(256), lds, s, qkv, y, lse, T, n_head, quads);
   COATI_LAUNCH_CHECK("attn_fwd");
   return COATI_OK;
 }
@@ -256,7 +259,12 @@ int launch_attn_fwd(const bf16_t* qkv, bf16_t* y, float* lse, int B, int T, int 
   COATI_CHECK_ARG(qkv && y && lse, "attn_fwd: null operand");
   COATI_CHECK_SHAPE(B > 0 && T > 0 && T <= 256 && n_head > 0 && (head_size == 16 || head_size == 32),
                     "attn_fwd: unsupported shape B=%d T=%d nh=%d hs=%d", B, T, n_head, head_size);
-  return head_size == 16 ? launch_attn_fwd_t<16>(qkv, y, lse, B, T, n_head, s) : launch_attn_fwd_t<32>(qkv, y, lse, B, T, n_head, s);
+  const int nb = (T + 31) / 32;
+#define FWD_CASE(H, N) if (head_size == H && nb == N) return launch_attn_fwd_t<H, N>(qkv, y, lse, B, T, n_head, s);
+  FWD_CASE(16, 1) FWD_CASE(16, 2) FWD_CASE(16, 3) FWD_CASE(16, 4)
+  FWD_CASE(32, 1) FWD_CASE(32, 2) FWD_CASE(32, 3) FWD_CASE(32, 4)
+#undef FWD_CASE
+  return head_size == 16 ? launch_attn_fwd_t<16, 0>(qkv, y, lse, B, T, n_head, s) : launch_attn_fwd_t<32, 0>(qkv, y, lse, B, T, n_head, s);
 }
 
 // ---------------------------------------------------------------------------------------------------
