@@ -1,4 +1,4 @@
-// Ring GEMM for N = 256: C[M,256] = A[M,K] * W[256,K]^T (+ bias, + f32 residual), bf16 operands, K % 64 == 0, K > 256.
+// Ring GEMM for N = 256: C[M,256] = A[M,K] * W[256,K]^T (+ bias, + f32 residual), bf16 operands, K % 64 == 0, K >= 256.
 // These are the long-K products of the transformer (reference basic_transformer.py:103-123 MLP down-projection forward,
 // and the input gradients of c_fc / c_attn): M = 81 920 rows stream through once, the 256 x K weight sits in L2.
 //
@@ -76,7 +76,8 @@ __global__ __launch_bounds__(64 * RG_WAVES, 1) void gemm_ring256_kernel(GemmArgs
   int bi = 0, ki = 0;                            // block index (of mine), stages issued of that block
   // (only for the bf16-output products, i.e. the input gradients: the residual product is the forward fc2, whose rows
   //  must not depend on where in the batch they sit -- the k order is part of the fp32 sum)
-  constexpr bool ROT = (EPI != EPI_RES_F32);
+  //  K < 512 never rotates: no camping at a 512-B pitch, and the GNN's edge product -- a forward one -- has K = 256)
+  const bool ROT = (EPI != EPI_RES_F32) && nk >= 8;
   int kk = ROT ? wg % nk : 0;                    // k chunk of the next stage
   int row0 = wg * RG_BR;
   const bf16_t* pa = A + ((long long)row0 + 8 * wave) * p.lda;          // this wave's first A piece, k = 0
@@ -259,7 +260,7 @@ bool gemm_ring256_supported(const GemmArgs& a, int a_f32, int epi) {
   static const bool off = getenv("COATI_NO_RING") != nullptr;   // A/B switch
   if (off || a_f32) return false;
   if (epi != EPI_BF16 && epi != EPI_RES_F32) return false;
-  if (a.N != 256 || a.K % RG_BK != 0 || a.K < 512) return false;
+  if (a.N != 256 || a.K % RG_BK != 0 || a.K < 256) return false;
   if (a.M < 256 * RG_BR / 2) return false;                      // fewer than half the CUs busy: the tiled kernel spreads better
   if (130LL * a.lda >= (1LL << 30) || 260LL * a.ldb >= (1LL << 30)) return false;
   return true;
