@@ -852,7 +852,7 @@ int launch_wgrad(const WgradArgs& a, int a_f32, hipStream_t s) {
   // COATI_WGRAD_DMA: ring depth 3..5, 0 = register-staged kernel everywhere (A/B switch).
   static const int dma = getenv("COATI_WGRAD_DMA") ? atoi(getenv("COATI_WGRAD_DMA")) : 3;
   const int tiles = cdiv(a.N, BM) * cdiv(a.K, BN);
-  if (dma >= 3 && tiles <= 32 && (long long)a.M >= 16LL * WD_CH * (256 / tiles)) {
+  if (dma >= 3 && tiles <= 64 && (long long)a.M >= 16LL * WD_CH * (256 / tiles)) {
     if (dma == 3) return a.dbias ? launch_wgrad_dma_t<true, 3>(a, s) : launch_wgrad_dma_t<false, 3>(a, s);
     return a.dbias ? launch_wgrad_dma_t<true, 4>(a, s) : launch_wgrad_dma_t<false, 4>(a, s);
   }
