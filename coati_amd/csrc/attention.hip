@@ -516,6 +516,7 @@ __global__ __launch_bounds__(256, (HS == 16 && NB <= 3) ? 3 : 2) void attn_bwd_f
   __builtin_amdgcn_wave_barrier();
 
   const int half = lane >> 5;
+  const bool tail16 = T - (NB - 1) * 32 <= 16;
   bf16_t* const dbase = dqkv + (long long)b * T * stride + hq * 4 * HS;
   f32x16 dq[NB];
 #pragma unroll
@@ -537,8 +538,16 @@ __global__ __launch_bounds__(256, (HS == 16 && NB <= 3) ? 3 : 2) void attn_bwd_f
         const f32x16 s = score_block<HS>(Qs, qb, kf, lane);
         const f32x16 dp = score_block<HS>(Gs, qb, vf, lane);
         float p[16], ds[16];
+        // the last query block may hold <= 16 rows (T = 80: rows 64..79): register groups 2, 3 (queries 16..31 of the
+        // block) are then padding for every lane -- no exponentials, no tile writes, no second MFMA for them
+        const bool short_q = (qb == NB - 1) && tail16;
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
+          if (g4 >= 2 && short_q) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) p[g4 * 4 + j] = ds[g4 * 4 + j] = 0.f;
+            continue;
+          }
           const int q0 = qb * 32 + 8 * g4 + 4 * half;
           const float4 l4 = *reinterpret_cast<const float4*>(Ls + q0);
           const float4 d4 = *reinterpret_cast<const float4*>(Ds + q0);
@@ -555,9 +564,9 @@ __global__ __launch_bounds__(256, (HS == 16 && NB <= 3) ? 3 : 2) void attn_bwd_f
               make_uint2(pack2bf(ds[4 * g4], ds[4 * g4 + 1]), pack2bf(ds[4 * g4 + 2], ds[4 * g4 + 3]));
         }
         dv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tfrag<HS>(Gs, qb * 32, lane), pfrag(p), dv, 0, 0, 0);
-        dv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tfrag<HS>(Gs, qb * 32 + 16, lane), pfrag(p + 8), dv, 0, 0, 0);
+        if (!short_q) dv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tfrag<HS>(Gs, qb * 32 + 16, lane), pfrag(p + 8), dv, 0, 0, 0);
         dk = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tfrag<HS>(Qs, qb * 32, lane), pfrag(ds), dk, 0, 0, 0);
-        dk = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tfrag<HS>(Qs, qb * 32 + 16, lane), pfrag(ds + 8), dk, 0, 0, 0);
+        if (!short_q) dk = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tfrag<HS>(Qs, qb * 32 + 16, lane), pfrag(ds + 8), dk, 0, 0, 0);
         __builtin_amdgcn_s_waitcnt(0xc07f);   // the tile writes above are visible to the whole wave
         __builtin_amdgcn_wave_barrier();
         dq[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kt0, dst_frag(dsT, 0, lane), dq[qb], 0, 0, 0);
