@@ -144,6 +144,7 @@ struct coati_engine {
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool overlap = true;
   bool gnn_bwd_done = false;   // staged backward: stage 2 already ran the point-encoder backward on the side stream
+  bool gnn_side_pending = false;   // stage 4 forked it; stage 5 joins
   // profiling
   int prof_site = -1;
   std::vector<hipEvent_t> ev;
@@ -480,9 +481,11 @@ int xformer_fwd(coati_engine* e, XPass& p, const float* injection, hipStream_t s
 }
 
 // dyf: gradient w.r.t. ln_f output, bf16 (decoder pass) or f32 (encoder pass)
-int xformer_bwd(coati_engine* e, XPass& p, const void* dyf, int dyf_f32, float* dinjection, hipStream_t s) {
+// layers [l_lo, l_hi) only, descending; the ln_f backward belongs to l_hi == L, the embedding backward to l_lo == 0
+int xformer_bwd(coati_engine* e, XPass& p, const void* dyf, int dyf_f32, float* dinjection, hipStream_t s, int l_hi = -1, int l_lo = 0) {
   const coati_config& c = e->cfg;
   const int C = c.n_hidden_xformer, L = c.n_layer_xformer, M = p.M;
+  if (l_hi < 0) l_hi = L;
   float* DX = e->DX;
   // the dgamma / dbeta partial sums of the pass's 2L + 1 LayerNorms are added up by ONE launch at the end
   const bool defer = 2 * L + 1 <= COATI_LN_MAX_SLOTS;
@@ -497,11 +500,11 @@ int xformer_bwd(coati_engine* e, XPass& p, const void* dyf, int dyf_f32, float* 
     fin.db_off[fin.n] = (long long)boff;
     return launch_layernorm_bwd_deferred(dy, dy_f32, C, x, C, 0, mean, rstd, gamma, dres, DX, e->DX16, e->ln_part_x + (fin.n++) * slot_stride, &nblk, M, C, s);
   };
-  {
+  if (l_hi == L) {
     ProfScope ps(e, SITE_LN_BWD, 0, s, (double)M * C * ((dyf_f32 ? 4 : 2) + 4 + 4 + 2));
     COATI_TRY(ln_bwd(dyf, dyf_f32, p.x[L], p.meanf, p.rstdf, e->P + e->lnfw, nullptr, e->lnfw, e->lnfb));
   }
-  for (int l = L - 1; l >= 0; --l) {
+  for (int l = l_hi - 1; l >= l_lo; --l) {
     const XLayerP& w = e->xl[l];
     // x[l+1] = xmid + g W2^T + b2
     COATI_TRY(gemm(e, SITE_FC2_DGRAD, e->DX16, 0, C, e->S + w.fc2T, C, M, 4 * C, C, e->dh4, 4 * C, nullptr, EPI_MUL_AUX, p.hpre[l], nullptr, 4 * C, s));
@@ -528,10 +531,11 @@ int xformer_bwd(coati_engine* e, XPass& p, const void* dyf, int dyf_f32, float* 
       COATI_TRY(ln_bwd(e->da, 0, p.x[l], p.mean1[l], p.rstd1[l], e->P + w.ln1w, DX, w.ln1w, w.ln1b));
     }
   }
-  if (defer) {
+  if (defer && fin.n > 0) {
     ProfScope ps(e, SITE_LN_BWD, 0, s, 0.0);
     COATI_TRY(launch_ln_finish_batched(e->ln_part_x, slot_stride, nblk, e->G, fin, C, s));
   }
+  if (l_lo > 0) return COATI_OK;
   ProfScope ps(e, SITE_EMBED, 0, s);
   return launch_embed_bwd(p.idx, DX, e->G + e->tok_emb, dinjection, c.unk_token, p.B, p.T, C, c.n_tok, s);
 }
@@ -879,7 +883,7 @@ int coati_engine_infonce(coati_engine* e, const float* S_loc, const float* C_loc
 
 int coati_engine_backward(coati_engine* e, const float* dh_smiles, const float* dh_e3gnn, int stage, void* stream) {
   COATI_CHECK_ARG(e && e->have_fwd && e->G, "engine_backward: no forward / gradient buffer");
-  COATI_CHECK_ARG(stage >= 0 && stage <= 3, "engine_backward: bad stage");
+  COATI_CHECK_ARG(stage >= 0 && stage <= 5, "engine_backward: bad stage");
   hipStream_t s = (hipStream_t)stream;
   const coati_config& c = e->cfg;
   const int C = c.n_hidden_xformer, H = c.n_hidden_e3nn, E = c.n_embd_common, B = e->B;
@@ -920,24 +924,31 @@ int coati_engine_backward(coati_engine* e, const float* dh_smiles, const float* 
   }
   // whole backward (stage 0) or the encoder stage of the staged (multi-GPU) backward: the point-encoder backward runs on
   // the side stream underneath the encoder pass; stage 3 then has nothing left to do
-  const bool ovl_bwd = (stage == 0 || stage == 2) && e->overlap && e->prof_site < 0;
-  if (stage == 0 || stage == 1) e->gnn_bwd_done = false;
+  // stages 4 / 5 = the encoder stage in two halves (upper / lower half of the layers), so that the caller can start the
+  // all-reduce of the upper layers' finished gradients underneath the lower half
+  const int Lx = c.n_layer_xformer, Lmid = Lx / 2;
+  const bool ovl_bwd = (stage == 0 || stage == 2 || stage == 4) && e->overlap && e->prof_site < 0;
+  if (stage == 0 || stage == 1) { e->gnn_bwd_done = false; e->gnn_side_pending = false; }
   if (ovl_bwd) {
     // the point-encoder backward only needs dhpoint (ready here) and writes its own gradient slice: side stream
     COATI_TRY(fork_side(e, s));
     COATI_TRY(gnn_bwd(e, e->dhpoint, e->side));
   }
-  if (stage == 0 || stage == 2) {
+  if (stage == 0 || stage == 2 || stage == 4) {
     // ---- encoder pass: gradient enters at the [STOP] rows of ln_f's output ----
     float* dxf = reinterpret_cast<float*>(e->dh4);  // [M1, C] f32 scratch (dh4 is idle here: 4C bf16 >= C f32)
     HIPCHK(hipMemsetAsync(dxf, 0, (size_t)e->p1.M * C * sizeof(float), s));
     COATI_TRY(launch_scatter_rows_add(e->dhstop, e->stop_pos, dxf, B, e->T1, C, s));
     // xformer_bwd consumes dyf in its first kernel (ln_f backward) before dh4 is rewritten
-    COATI_TRY(xformer_bwd(e, e->p1, dxf, 1, nullptr, s));
+    COATI_TRY(xformer_bwd(e, e->p1, dxf, 1, nullptr, s, Lx, stage == 4 ? Lmid : 0));
   }
-  if (ovl_bwd) {
+  if (stage == 5) COATI_TRY(xformer_bwd(e, e->p1, nullptr, 1, nullptr, s, Lmid, 0));
+  if (ovl_bwd && stage == 4) {
+    e->gnn_side_pending = true;   // joined at the end of stage 5
+  } else if (ovl_bwd || (stage == 5 && e->gnn_side_pending)) {
     COATI_TRY(join_side(e, s));
     e->gnn_bwd_done = true;
+    e->gnn_side_pending = false;
   } else if ((stage == 0 || stage == 3) && !e->gnn_bwd_done) {
     COATI_TRY(gnn_bwd(e, e->dhpoint, s));
     e->gnn_bwd_done = true;

@@ -7,7 +7,8 @@ Exchange steps of the path (reference train_coati.py:256-258, autograd_funs.py:5
      computes the full Bg x Bg on every rank) and produces partial gradients for all Bg embeddings;
   3. reduce-scatter(sum) of those partials (what AllGatherFunction.backward does);
   4. bucketed gradient all-reduce (mean) over the flat fp32 gradient buffer, launched stage by stage so the
-     transfers run on RCCL's stream underneath the remaining backward kernels.
+     transfers run on RCCL's stream underneath the remaining backward kernels (the encoder stage is cut in two: the
+     upper layers' bucket travels underneath the lower half of that pass).
 The reference calls model.module.forward_dist and therefore never arms DDP's reducer: it does
 not average parameter gradients.  This implements the intended semantics."""
 import torch
@@ -36,7 +37,10 @@ def grad_buckets(eng):
     lm0 = lay["xformer.lm_head.weight"][0]
     pe0 = lay["point_encoder.embedding.weight"][0]
     hd0 = lay["point_to_clip.0.weight"][0]
-    return {"xformer": (0, lm0), "lm_head": (lm0, pe0), "gnn": (pe0, hd0), "heads": (hd0, eng.n_params)}
+    L = sum(1 for k in lay if k.startswith("xformer.transformer.h.") and k.endswith(".ln_1.weight"))
+    mid = lay[f"xformer.transformer.h.{L // 2}.ln_1.weight"][0]   # first entry of layer L/2: [0, mid) = embeddings + lower layers
+    return {"xformer_lo": (0, mid), "xformer_hi": (mid, lm0), "lm_head": (lm0, pe0), "gnn": (pe0, hd0),
+            "heads": (hd0, eng.n_params)}
 
 
 def distributed_train_step(eng, batch, use_point, lr, do_clip=True, optimizer=True, head="infonce"):
@@ -65,8 +69,12 @@ def distributed_train_step(eng, batch, use_point, lr, do_clip=True, optimizer=Tr
 
     eng.backward(dS, dC, stage=1)
     launch("lm_head"); launch("heads")
-    eng.backward(None, None, stage=2)
-    launch("xformer")
+    # the encoder stage in two halves: the upper layers' gradients (both passes are through them) travel underneath the
+    # lower half of the backward
+    eng.backward(None, None, stage=4)
+    launch("xformer_hi")
+    eng.backward(None, None, stage=5)
+    launch("xformer_lo")
     eng.backward(None, None, stage=3)
     launch("gnn")
     for w in works:

@@ -228,14 +228,16 @@ def test_staged_backward_equals_whole_backward():
     eng.grads.zero_()
     h_e, h_s, bad = eng.forward(db["raw_tokens"], db["tokens"], db["atoms"], db["coords"], up, y_next=db["y_next"], train=True)
     dS, dC = eng.infonce(h_s, h_e, h_s, h_e, bad, row0=0, gscale=0.5 * eng.token_entropy_unit())
-    for stage in (1, 2, 3):
-        eng.backward(dS if stage == 1 else None, dC if stage == 1 else None, stage)
-    torch.cuda.synchronize()
-    for name, (off, shape) in eng.layout.items():
-        n = int(np.prod(shape))
-        a, b = whole[off:off + n], eng.grads[off:off + n]
-        scale = max(float(a.abs().max()), 1e-20)
-        assert float((a - b).abs().max()) <= 1e-5 * scale + 1e-12, (name, float((a - b).abs().max()), scale)
+    for order in ((1, 2, 3), (1, 4, 5, 3)):   # 4, 5 = the encoder stage in two halves (what the data-parallel step runs)
+        eng.grads.zero_()
+        for stage in order:
+            eng.backward(dS if stage == 1 else None, dC if stage == 1 else None, stage)
+        torch.cuda.synchronize()
+        for name, (off, shape) in eng.layout.items():
+            n = int(np.prod(shape))
+            a, b = whole[off:off + n], eng.grads[off:off + n]
+            scale = max(float(a.abs().max()), 1e-20)
+            assert float((a - b).abs().max()) <= 1e-5 * scale + 1e-12, (order, name, float((a - b).abs().max()), scale)
 
 
 def test_head_size_32_model_grads_and_decode():
