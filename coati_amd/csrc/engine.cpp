@@ -389,7 +389,7 @@ size_t carve(coati_engine* e, Arena& ar, int B, int T1, int T2, int A, int Bg) {
   e->stop_pos = ar.take<int>(B);
   e->err_flag = ar.take<int>(4);
   // lm head
-  const int tiles_v = cdiv(c.n_tok, 128);
+  const int tiles_v = cdiv(c.n_tok, 64);   // one (max, sum) pair per 64 columns: either GEMM kernel fits
   e->ce_partial = ar.take<float2>(M2 * tiles_v);
   e->ce_lse = ar.take<float>(M2);
   e->dlogits = ar.take<bf16_t>(M2 * e->Vpad);
@@ -824,10 +824,12 @@ int coati_engine_forward(coati_engine* e, void* workspace, int64_t workspace_byt
   if (bad_rows) COATI_TRY(launch_bad_rows(e->p2.idx, bad_rows, B, T2, s));
   // ---- lm_head + AR cross-entropy, logits never materialised (smiles_xformer.py:453, train_coati.py:260-265) ----
   if (y_next) {
-    const int M2 = B * T2, tiles_v = cdiv(c.n_tok, 128);
+    const int M2 = B * T2;
     GemmArgs a;
     memset(&a, 0, sizeof(a));
     a.A = e->p2.af; a.lda = C; a.B = e->S + e->lmhead; a.ldb = C; a.M = M2; a.N = c.n_tok; a.K = C; a.partial = e->ce_partial;
+    a.partial_tile = 64;   // ce_partial is sized for 64-column entries: the row-block kernel may take the product
+    const int tiles_v = cdiv(c.n_tok, gemm_ce_tile_width(a));
     {
       ProfScope ps(e, SITE_LMHEAD_FWD, 2.0 * M2 * c.n_tok * C, s, (double)M2 * C * 2 + (double)c.n_tok * C * 2);   // logits never leave the chip
       COATI_TRY(launch_gemm_nt(a, 0, EPI_CE_PARTIAL, s));

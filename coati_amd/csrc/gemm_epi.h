@@ -13,7 +13,9 @@ struct EpiPre {
   bool have;
 };
 
-template <int EPI, int ROPE_PARTNER = 1>
+// CE_LANES: lanes that share one output row of the tile (EPI_CE_PARTIAL reduces across them): 16 for the 128-column
+// tiles of the tiled kernel, 8 for the 64-column tiles of the row-block kernel
+template <int EPI, int ROPE_PARTNER = 1, int CE_LANES = 16>
 __device__ __forceinline__ void epilogue8(const GemmArgs& p, int row, int col0, float (&v)[8], bool rowok,
                                           int tile_n, int tiles_n, const void* staged = nullptr, const EpiPre* pre = nullptr) {
   // staged: optional operand the caller pre-staged (in LDS) so that the epilogue issues no global load for it:
@@ -33,20 +35,20 @@ __device__ __forceinline__ void epilogue8(const GemmArgs& p, int row, int col0, 
     }
   }
   if (EPI == EPI_CE_PARTIAL) {
-    // every lane of the 16-lane group that shares this row takes part in the shuffles
+    // every lane of the CE_LANES-lane group that shares this row takes part in the shuffles
     float mx = -INFINITY;
 #pragma unroll
     for (int e = 0; e < 8; ++e)
       if (col0 + e < N) mx = fmaxf(mx, v[e]);
 #pragma unroll
-    for (int o = 1; o < 16; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    for (int o = 1; o < CE_LANES; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
     float sm = 0.f;
 #pragma unroll
     for (int e = 0; e < 8; ++e)
       if (col0 + e < N) sm += __expf(v[e] - mx);
 #pragma unroll
-    for (int o = 1; o < 16; o <<= 1) sm += __shfl_xor(sm, o, 64);
-    if (rowok && (threadIdx.x & 15) == 0) p.partial[(long long)row * tiles_n + tile_n] = make_float2(mx, sm);
+    for (int o = 1; o < CE_LANES; o <<= 1) sm += __shfl_xor(sm, o, 64);
+    if (rowok && (threadIdx.x & (CE_LANES - 1)) == 0) p.partial[(long long)row * tiles_n + tile_n] = make_float2(mx, sm);
     return;
   }
   if (!rowok && EPI != EPI_QKV_ROPE) return;

@@ -188,7 +188,7 @@ __global__ __launch_bounds__(64 * MAXW, 640 / (64 * MAXW)) void gemm_rb256_kerne
         if constexpr (EPI == EPI_QKV_ROPE) staged = Rs + row * 16;
         if constexpr (AUX) staged = Xs + (size_t)(lane + 64 * (TPH * hf + i)) * 16;
         if constexpr (EDGE) staged = Rs + cg * 8;
-        epilogue8<EPI>(q, m0 + row, j * RB_BN + cg * 8, v, (m0 + row) < p.M, 0, 1, staged);
+        epilogue8<EPI, 1, RB_BN / 8>(q, m0 + row, j * RB_BN + cg * 8, v, (m0 + row) < p.M, j, ntiles, staged);
       };
       // light epilogues run both tasks interleaved; the heavy ones (activation maths, extra operands) one after the
       // other, or their temporaries spill (the kernel lives at the 168-VGPR limit of 3 waves per SIMD)
@@ -221,11 +221,17 @@ static int rb_waves(int M) {
   return W;
 }
 
+int gemm_ce_tile_width(const GemmArgs& a) {
+  static const bool no_rb = getenv("COATI_NO_RB") != nullptr;
+  return (!no_rb && gemm_rb256_supported(a, 0, EPI_CE_PARTIAL)) ? 64 : 128;
+}
+
 // true when (a, epi) can run on the row-block kernel
 bool gemm_rb256_supported(const GemmArgs& a, int a_f32, int epi) {
   // COATI_RB_EXCLUDE (A/B switch for tuning): bit 1 = N < 512, bit 2 = epilogues with extra row-major operands
   static const int excl = getenv("COATI_RB_EXCLUDE") ? atoi(getenv("COATI_RB_EXCLUDE")) : 0;
-  if (a_f32 || a.K != RB_K || epi == EPI_CE_PARTIAL) return false;
+  if (a_f32 || a.K != RB_K) return false;
+  if (epi == EPI_CE_PARTIAL && a.partial_tile != 64) return false;   // the caller's partial buffer is laid out for 128-column tiles
   if (epi == EPI_QKV_ROPE && a.rope_hs == 32) return false;   // the staged rotary rows are laid out for head size 16
   if (a.N % 16 != 0 && epi != EPI_CE_BWD) return false;
   if (rb_waves(a.M) < 8) return false;   // small problems run on the tiled kernel
@@ -278,6 +284,7 @@ int launch_gemm_rb256(const GemmArgs& a, int epi, hipStream_t s) {
     case EPI_DSILU: return launch_rb_t<EPI_DSILU>(a, s);
     case EPI_ACC_F32: return launch_rb_t<EPI_ACC_F32>(a, s);
     case EPI_CE_BWD: return launch_rb_t<EPI_CE_BWD>(a, s);
+    case EPI_CE_PARTIAL: return launch_rb_t<EPI_CE_PARTIAL>(a, s);
     case EPI_EDGE_DPRE: return launch_rb_t<EPI_EDGE_DPRE>(a, s);
     case EPI_QKV_ROPE: return launch_rb_t<EPI_QKV_ROPE>(a, s);
     default:

@@ -42,6 +42,8 @@ struct GemmArgs {
   const long long* target;  // [M], -1 = ignore
   const float* scal;        // scal[1] = number of non-ignored targets
   float2* partial;          // [M, tiles_n]
+  int partial_tile;         // EPI_CE_PARTIAL: 0 / 128 = one entry per 128 columns (tiled kernel); 64 = the buffer holds one entry
+                            // per 64 columns, so the row-block kernel may be used (gemm_ce_tile_width tells which one ran)
   // GNN edge epilogue
   const bf16_t* P;          // [B*A, 2H] (Pa | Pb)
   long long ldp;
@@ -63,6 +65,8 @@ struct GemmArgs {
 int launch_gemm_nt(const GemmArgs& a, int a_f32, int epi, hipStream_t s);
 // row-block kernel for K = 256 (gemm_rb.hip); launch_gemm_nt dispatches to it when supported
 bool gemm_rb256_supported(const GemmArgs& a, int a_f32, int epi);
+// column width of the EPI_CE_PARTIAL entries launch_gemm_nt writes for these arguments (64 or 128)
+int gemm_ce_tile_width(const GemmArgs& a);
 int launch_gemm_rb256(const GemmArgs& a, int epi, hipStream_t s);
 // ring kernel for N = 256, long K (gemm_ring.hip)
 bool gemm_ring256_supported(const GemmArgs& a, int a_f32, int epi);
