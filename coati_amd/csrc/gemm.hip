@@ -799,7 +799,7 @@ static int launch_wgrad_dma_t(const WgradArgs& a, hipStream_t s) {
   const int tiles = tiles_n * tiles_k;
   const int nchunks = cdiv(a.M, WD_CH);
   static const int slot_env = getenv("COATI_WGRAD_SLOTS") ? atoi(getenv("COATI_WGRAD_SLOTS")) : 0;
-  const int slots = slot_env > 0 ? slot_env : 256;   // one workgroup per CU
+  const int slots = slot_env > 0 ? slot_env : (tiles > 128 ? 512 : 256);   // one workgroup per CU (two rounds when the tiles alone almost fill one)
   int splits = slots / tiles;
   if (splits > cdiv(nchunks, 4)) splits = cdiv(nchunks, 4);
   if (splits < 1) splits = 1;
@@ -852,7 +852,10 @@ int launch_wgrad(const WgradArgs& a, int a_f32, hipStream_t s) {
   // COATI_WGRAD_DMA: ring depth 3..5, 0 = register-staged kernel everywhere (A/B switch).
   static const int dma = getenv("COATI_WGRAD_DMA") ? atoi(getenv("COATI_WGRAD_DMA")) : 3;
   const int tiles = cdiv(a.N, BM) * cdiv(a.K, BN);
-  if (dma >= 3 && tiles <= 64 && (long long)a.M >= 16LL * WD_CH * (256 / tiles)) {
+  // tiles <= 64: one round of 256 workgroups; 129..256 tiles (lm_head: 162): two rounds of up to 512; in between the
+  // register-staged kernel's 512 half-CU slots fill the machine better
+  const bool fits = tiles <= 64 || (tiles > 128 && tiles <= 256);
+  if (dma >= 3 && fits && (long long)a.M >= 16LL * WD_CH * (256 / tiles > 0 ? 256 / tiles : 1)) {
     if (dma == 3) return a.dbias ? launch_wgrad_dma_t<true, 3>(a, s) : launch_wgrad_dma_t<false, 3>(a, s);
     return a.dbias ? launch_wgrad_dma_t<true, 4>(a, s) : launch_wgrad_dma_t<false, 4>(a, s);
   }

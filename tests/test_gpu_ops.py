@@ -72,11 +72,11 @@ def test_gemm_epilogues(ops, M, N, K):
         check(f"gemm dsilu(A f32) {M}x{N}x{K}", c.float(), (A @ W.t()) * ds, TB)
 
 
-# the last four rows are large enough for the LDS-DMA kernel (one workgroup per CU, >= 16 stages each): ragged M, tiles
-# sticking out of N / K, several k tiles (bias turns)
+# the last five rows are large enough for the LDS-DMA kernel (one workgroup per CU, >= 16 stages each): ragged M, tiles
+# sticking out of N / K, several k tiles (bias turns), > 128 tiles (two rounds, the lm_head regime)
 @pytest.mark.parametrize("M,N,K,f32", [(1000, 256, 128, False), (4099, 768, 256, False), (640, 64, 64, True), (3000, 136, 1024, True),
                                        (74451, 256, 256, False), (40001, 768, 256, False), (65555, 264, 136, False),
-                                       (50003, 256, 1024, False)])
+                                       (50003, 256, 1024, False), (9001, 2112, 1024, False)])
 def test_wgrad(ops, M, N, K, f32):
     g = torch.Generator().manual_seed(M)
     A = rbf(torch.randn(M, N, generator=g)).to(DEV)
