@@ -233,7 +233,7 @@ bool gemm_rb256_supported(const GemmArgs& a, int a_f32, int epi) {
   if (a_f32 || a.K != RB_K) return false;
   if (epi == EPI_CE_PARTIAL && a.partial_tile != 64) return false;   // the caller's partial buffer is laid out for 128-column tiles
   if (epi == EPI_QKV_ROPE && a.rope_hs == 32) return false;   // the staged rotary rows are laid out for head size 16
-  if (a.N % 16 != 0 && epi != EPI_CE_BWD) return false;
+  if (a.N % 16 != 0 && epi != EPI_CE_BWD && epi != EPI_CE_PARTIAL) return false;   // (those two write no N-wide rows)
   if (rb_waves(a.M) < 8) return false;   // small problems run on the tiled kernel
   if ((excl & 1) && a.N < 512) return false;
   if ((excl & 2) && (epi == EPI_RES_F32 || epi == EPI_ACC_F32 || epi == EPI_F32 || epi == EPI_DGELU || epi == EPI_DSILU || epi == EPI_MUL_AUX || epi == EPI_EDGE_DPRE)) return false;
