@@ -450,16 +450,21 @@ int xformer_fwd(coati_engine* e, XPass& p, const float* injection, hipStream_t s
   for (int l = 0; l < L; ++l) {
     const XLayerP& w = e->xl[l];
     {
-      ProfScope ps(e, SITE_LN_FWD, 0, s, (double)M * C * 6 + (double)M * 8);
-      COATI_TRY(launch_layernorm_fwd(p.x[l], C, e->P + w.ln1w, e->P + w.ln1b, p.a1[l], C, nullptr, 0, p.mean1[l], p.rstd1[l], M, C, s));
-    }
-    {
-      // QKV projection with RoPE applied to the q,k blocks in the epilogue (saved qkv holds the ROTATED q,k)
+      // QKV projection with RoPE applied to the q,k blocks in the epilogue (saved qkv holds the ROTATED q,k).  Where the
+      // row-block kernel takes the product, ln_1 is evaluated inside its operand load (x f32 in; a1, mean, rstd out): no
+      // LayerNorm launch, no second trip of the normalised rows through HBM
       GemmArgs a;
       memset(&a, 0, sizeof(a));
       a.A = p.a1[l]; a.lda = C; a.B = e->S + w.attnw; a.ldb = C; a.M = M; a.N = 3 * C; a.K = C; a.C = p.qkv[l]; a.ldc = 3 * C;
       a.bias = e->P + w.attnb; a.rope_cos = e->cos_t; a.rope_sin = e->sin_t; a.rope_T = p.T; a.rope_C = C; a.rope_hs = C / c.n_head;
-      ProfScope ps(e, SITE_QKV_FWD, 2.0 * M * 3 * C * C, s, (double)M * C * 2 + 3.0 * C * C * 2 + (double)M * 3 * C * 2);
+      const bool fuse = gemm_rb256_ln_fusable(a, EPI_QKV_ROPE);
+      if (fuse) {
+        a.ln_x = p.x[l]; a.ln_ldx = C; a.ln_gamma = e->P + w.ln1w; a.ln_beta = e->P + w.ln1b; a.ln_mean = p.mean1[l]; a.ln_rstd = p.rstd1[l];
+      } else {
+        ProfScope ps(e, SITE_LN_FWD, 0, s, (double)M * C * 6 + (double)M * 8);
+        COATI_TRY(launch_layernorm_fwd(p.x[l], C, e->P + w.ln1w, e->P + w.ln1b, p.a1[l], C, nullptr, 0, p.mean1[l], p.rstd1[l], M, C, s));
+      }
+      ProfScope ps(e, SITE_QKV_FWD, 2.0 * M * 3 * C * C, s, (double)M * C * (fuse ? 6 : 2) + 3.0 * C * C * 2 + (double)M * 3 * C * 2);
       COATI_TRY(launch_gemm_nt(a, 0, EPI_QKV_ROPE, s));
     }
     {
@@ -468,12 +473,23 @@ int xformer_fwd(coati_engine* e, XPass& p, const float* injection, hipStream_t s
     }
     COATI_TRY(gemm(e, SITE_PROJ_FWD, p.y[l], 0, C, e->S + w.projw, C, M, C, C, p.xmid[l], C, e->P + w.projb, EPI_RES_F32, p.x[l], nullptr, C, s));
     {
-      ProfScope ps(e, SITE_LN_FWD, 0, s, (double)M * C * 6 + (double)M * 8);
-      COATI_TRY(launch_layernorm_fwd(p.xmid[l], C, e->P + w.ln2w, e->P + w.ln2b, p.a2[l], C, nullptr, 0, p.mean2[l], p.rstd2[l], M, C, s));
+      // hpre holds NewGELU'(pre-activation), not the pre-activation: the backward multiplies instead of re-evaluating the
+      // sigmoid (the activation epilogues are VALU-bound: 2 quarter-rate transcendentals per element).  ln_2 is fused into
+      // the operand load like ln_1 above.
+      GemmArgs a;
+      memset(&a, 0, sizeof(a));
+      a.A = p.a2[l]; a.lda = C; a.B = e->S + w.fc1w; a.ldb = C; a.M = M; a.N = 4 * C; a.K = C; a.C = p.g[l]; a.ldc = 4 * C;
+      a.bias = e->P + w.fc1b; a.aux_out = p.hpre[l]; a.ld_aux = 4 * C;
+      const bool fuse = gemm_rb256_ln_fusable(a, EPI_GELU_GRAD);
+      if (fuse) {
+        a.ln_x = p.xmid[l]; a.ln_ldx = C; a.ln_gamma = e->P + w.ln2w; a.ln_beta = e->P + w.ln2b; a.ln_mean = p.mean2[l]; a.ln_rstd = p.rstd2[l];
+      } else {
+        ProfScope ps(e, SITE_LN_FWD, 0, s, (double)M * C * 6 + (double)M * 8);
+        COATI_TRY(launch_layernorm_fwd(p.xmid[l], C, e->P + w.ln2w, e->P + w.ln2b, p.a2[l], C, nullptr, 0, p.mean2[l], p.rstd2[l], M, C, s));
+      }
+      ProfScope ps(e, SITE_FC1_FWD, 2.0 * M * 4 * C * C, s, (double)M * C * (fuse ? 6 : 2) + 4.0 * C * C * 2 + (double)M * 4 * C * 4);
+      COATI_TRY(launch_gemm_nt(a, 0, EPI_GELU_GRAD, s));
     }
-    // hpre holds NewGELU'(pre-activation), not the pre-activation: the backward multiplies instead of re-evaluating the
-    // sigmoid (the activation epilogues are VALU-bound: 2 quarter-rate transcendentals per element)
-    COATI_TRY(gemm(e, SITE_FC1_FWD, p.a2[l], 0, C, e->S + w.fc1w, C, M, 4 * C, C, p.g[l], 4 * C, e->P + w.fc1b, EPI_GELU_GRAD, nullptr, p.hpre[l], 4 * C, s));
     COATI_TRY(gemm(e, SITE_FC2_FWD, p.g[l], 0, 4 * C, e->S + w.fc2w, 4 * C, M, C, 4 * C, p.x[l + 1], C, e->P + w.fc2b, EPI_RES_F32, p.xmid[l], nullptr, C, s));
   }
   ProfScope ps(e, SITE_LN_FWD, 0, s, (double)M * C * 10 + (double)M * 8);

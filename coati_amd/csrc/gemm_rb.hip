@@ -37,7 +37,7 @@ __device__ __forceinline__ void rb_call_restrict(F&& f, int j, const bf16_t* __r
   f(j, cur, nxt);
 }
 
-template <int EPI, int RB_BN, int MAXW>
+template <int EPI, int RB_BN, int MAXW, bool LN = false>
 __global__ __launch_bounds__(64 * MAXW, 640 / (64 * MAXW)) void gemm_rb256_kernel(GemmArgs p, int W) {
   constexpr int NACC = RB_BN / 32;                 // 32-column accumulator blocks per wave per tile
   constexpr int RB_TILE_HALFS = RB_BN * RB_K;      // [BN cols][256 k] bf16, unpadded, chunk-swizzled
@@ -58,11 +58,66 @@ __global__ __launch_bounds__(64 * MAXW, 640 / (64 * MAXW)) void gemm_rb256_kerne
 
   // resident A slab: A-operand fragments, lane (i = lane&31 -> row, kg = lane>>5) holds k = ks*16 + kg*8 .. +7
   bf16x8 af[16];
-  {
+  if constexpr (!LN) {
     const int rc = (m0 + fr) < p.M ? (m0 + fr) : p.M - 1;
     const bf16_t* ap = reinterpret_cast<const bf16_t*>(p.A) + (long long)rc * p.lda + fk;
 #pragma unroll
     for (int ks = 0; ks < 16; ++ks) af[ks] = *reinterpret_cast<const bf16x8*>(ap + ks * 16);
+  } else {
+    // LayerNorm fused into the slab load (reference basic_transformer.py:165-173: x + attn(ln_1(x)), ... mlp(ln_2(x))):
+    // the lane pair (fr, kg = 0 / 1) holds one f32 row of 256 = 2 x 16 chunks of 8; two-pass statistics in registers
+    // (same formulas as ln_fwd_kernel), normalised row -> bf16 fragments + the saved copy the weight gradient reads
+    const int row = m0 + fr, rc = row < p.M ? row : p.M - 1;
+    const float* xp = p.ln_x + (long long)rc * p.ln_ldx + fk;
+    float xf[16][8];
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+      const float4 x0 = *reinterpret_cast<const float4*>(xp + ks * 16), x1 = *reinterpret_cast<const float4*>(xp + ks * 16 + 4);
+      xf[ks][0] = x0.x; xf[ks][1] = x0.y; xf[ks][2] = x0.z; xf[ks][3] = x0.w;
+      xf[ks][4] = x1.x; xf[ks][5] = x1.y; xf[ks][6] = x1.z; xf[ks][7] = x1.w;
+    }
+    // gamma | beta go through the second weight-tile buffer (idle until the first tile prefetches into it): their loads are
+    // in flight together with the row loads, and the normalisation below reads them as LDS broadcasts
+    float* const GB = reinterpret_cast<float*>(Bs + RB_TILE_HALFS);
+    if (tid < 128) {
+      const float* src = tid < 64 ? p.ln_gamma + 4 * tid : p.ln_beta + 4 * (tid - 64);
+      *reinterpret_cast<float4*>(GB + 4 * tid) = *reinterpret_cast<const float4*>(src);
+    }
+    float sm = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) sm += xf[ks][i];
+    sm += __shfl_xor(sm, 32, 64);
+    const float mean = sm / (float)RB_K;
+    float q2 = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float d = xf[ks][i] - mean;
+        q2 += d * d;
+      }
+    q2 += __shfl_xor(q2, 32, 64);
+    const float rstd = 1.0f / sqrtf(q2 / (float)RB_K + 1e-5f);
+    if (lane < 32 && row < p.M) {
+      p.ln_mean[row] = mean;
+      p.ln_rstd[row] = rstd;
+    }
+    bf16_t* op = reinterpret_cast<bf16_t*>(const_cast<void*>(p.A)) + (long long)rc * p.lda + fk;
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+      const float4 g0 = *reinterpret_cast<const float4*>(GB + fk + ks * 16), g1 = *reinterpret_cast<const float4*>(GB + fk + ks * 16 + 4);
+      const float4 b0 = *reinterpret_cast<const float4*>(GB + RB_K + fk + ks * 16), b1 = *reinterpret_cast<const float4*>(GB + RB_K + fk + ks * 16 + 4);
+      const float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, bt[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+      float o[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) o[i] = (xf[ks][i] - mean) * rstd * g[i] + bt[i];
+      const uint4 u = pack8(o);
+      af[ks] = __builtin_bit_cast(bf16x8, u);
+      if (row < p.M) *reinterpret_cast<uint4*>(op + ks * 16) = u;
+    }
   }
   if (EPI == EPI_QKV_ROPE) {
     // lane -> (row = lane >> 1, cos | sin): 8 floats each
@@ -221,6 +276,14 @@ static int rb_waves(int M) {
   return W;
 }
 
+bool gemm_rb256_ln_fusable(const GemmArgs& a, int epi) {
+  static const bool off = getenv("COATI_NO_LN_FUSE") != nullptr || getenv("COATI_NO_RB") != nullptr;   // A/B switches
+  if (off || (epi != EPI_QKV_ROPE && epi != EPI_GELU_GRAD)) return false;
+  GemmArgs b = a;
+  b.ln_x = nullptr;
+  return gemm_rb256_supported(b, 0, epi) && a.K == RB_K;
+}
+
 int gemm_ce_tile_width(const GemmArgs& a) {
   static const bool no_rb = getenv("COATI_NO_RB") != nullptr;
   return (!no_rb && gemm_rb256_supported(a, 0, EPI_CE_PARTIAL)) ? 64 : 128;
@@ -240,10 +303,10 @@ bool gemm_rb256_supported(const GemmArgs& a, int a_f32, int epi) {
   return true;
 }
 
-template <int EPI, int BN, int MAXW>
+template <int EPI, int BN, int MAXW, bool LN = false>
 static int launch_rb_shape(const GemmArgs& a, int W, hipStream_t s) {
   static bool attr_set = false;
-  auto kern = gemm_rb256_kernel<EPI, BN, MAXW>;
+  auto kern = gemm_rb256_kernel<EPI, BN, MAXW, LN>;
   const size_t tile_bytes = (size_t)2 * BN * RB_K * 2;              // double-buffered weight tile
   const size_t per_wave = (size_t)16 * (BN + 4) * 4 + ((EPI == EPI_QKV_ROPE || EPI == EPI_EDGE_DPRE) ? RB_ROPE_FLOATS * 4
                                                        : (EPI == EPI_DGELU || EPI == EPI_DSILU || EPI == EPI_MUL_AUX) ? RB_AUX_BYTES : 0);
@@ -267,6 +330,13 @@ static int launch_rb_t(const GemmArgs& a, hipStream_t s) {
   // COATI_RB_SPLIT=1: two 5-wave workgroups per CU on 32-column tiles instead of one 10-wave workgroup on 64-column tiles
   static const bool split = getenv("COATI_RB_SPLIT") != nullptr && atoi(getenv("COATI_RB_SPLIT")) != 0;
   const int W = rb_waves(a.M);
+  if constexpr (EPI == EPI_QKV_ROPE || EPI == EPI_GELU_GRAD) {
+    if (a.ln_x != nullptr) return launch_rb_shape<EPI, 64, RB_MAX_W, true>(a, W, s);
+  }
+  if (a.ln_x != nullptr) {
+    coati_set_error("gemm_rb256: epilogue %d has no fused-LayerNorm variant", (int)EPI);
+    return COATI_EARG;
+  }
   if (split && W == RB_MAX_W) return launch_rb_shape<EPI, 32, RB_SPLIT_W>(a, RB_SPLIT_W, s);
   return launch_rb_shape<EPI, 64, RB_MAX_W>(a, W, s);
 }

@@ -60,11 +60,22 @@ struct GemmArgs {
   int rope_C;
   int rope_hs;
   const int* rope_pos;   // decode: when set, EVERY row sits at token position *rope_pos (device memory; graph replay)
+  // LayerNorm fused into the A load (row-block kernel, K = 256; gemm_rb256_ln_fusable): the operand is LN(ln_x) and is
+  // computed while the A slab is loaded; A / lda then name the bf16 buffer that RECEIVES the normalised rows (the weight
+  // gradient reads it later), ln_mean / ln_rstd the per-row statistics for the backward
+  const float* ln_x;        // [M, K] f32, null = plain bf16 A
+  long long ln_ldx;
+  const float* ln_gamma;    // [K]
+  const float* ln_beta;     // [K]
+  float* ln_mean;           // [M]
+  float* ln_rstd;           // [M]
 };
 
 int launch_gemm_nt(const GemmArgs& a, int a_f32, int epi, hipStream_t s);
 // row-block kernel for K = 256 (gemm_rb.hip); launch_gemm_nt dispatches to it when supported
 bool gemm_rb256_supported(const GemmArgs& a, int a_f32, int epi);
+// true when launch_gemm_nt(a, 0, epi) accepts the ln_* fields (LayerNorm fused into the operand load)
+bool gemm_rb256_ln_fusable(const GemmArgs& a, int epi);
 // column width of the EPI_CE_PARTIAL entries launch_gemm_nt writes for these arguments (64 or 128)
 int gemm_ce_tile_width(const GemmArgs& a);
 int launch_gemm_rb256(const GemmArgs& a, int epi, hipStream_t s);
