@@ -206,7 +206,7 @@ def test_tall_closed_shape_vs_oracle():
 
 
 def test_wide_batch_kernels_vs_oracle():
-    """57 600 token rows (480 x 120) at d = 256, one layer each: the size gates of the big-batch kernels are all open here
+    """57 720 token rows (481 x 120) at d = 256, one layer each: the size gates of the big-batch kernels are all open here
     -- row-block GEMMs with LayerNorm fused into the operand load, the N = 256 ring GEMM, the LDS-DMA weight gradient, the
     fused attention backward at four 32-row blocks -- and the oracle still finishes in seconds."""
     from oracle import coati_oracle as O
@@ -218,7 +218,7 @@ def test_wide_batch_kernels_vs_oracle():
     P = O.init_params(ocfg, seed=13)
     eng = Engine(ModelConfig(**kw), DEV)
     eng.load_state_dict(P)
-    batch, up = make_batch(480, 120, 16, 600, seed=9, n_special=12, p_bad=0.02, min_len=100)
+    batch, up = make_batch(481, 120, 16, 600, seed=9, n_special=12, p_bad=0.02, min_len=100)   # 57 720 rows: ragged last 32-row slab
     db = {k: v.to(DEV) for k, v in batch.items()}
     eng.train_step(db, up.to(DEV), lr=1e-3, optimizer=False)
     L = eng.losses()
