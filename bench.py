@@ -14,10 +14,19 @@ roofline: the dominant launch site is the transformer weight-gradient kernel (`x
 arithmetic intensity N*K/(N+K) = 128..205 flop/B is below the MI355X ridge (2.5 PFLOP/s / 8 TB/s = 312 flop/B), so the
 bound is HBM: achieved = algorithmic bytes per launch (both bf16 activation operands once + the f32 gradient
 read-modify-write) / average launch time.  `traffic` is the measured HBM bytes per launch of that
-kernel (rocprofv3 PMC passes of this same command, profiles/r01_pmc_summary.json), null if that file is absent."""
+kernel from the newest committed profiles/rNN_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over THIS
+command, `bench.py --steps 2 --warmup 1 --no-cpu-baseline`, collected by tools/profile_round.sh; `traffic_source` names the
+file and the round), null if there is none.  `step_roofline` prices the whole step: SURVEY 8(d)'s algorithmic FLOPs
+and HBM bytes per molecule evaluated on this batch / measured step time, against 2.5 PFLOP/s and 8 TB/s.
+
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment re-executes this script under
+`python -m torch.distributed.run --nproc-per-node N` (one rank per GPU, RCCL); the line then also carries `comm`: the
+collectives timed alone and the exposed (not hidden underneath the backward) part of the gradient all-reduces."""
 import argparse
+import glob
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -66,9 +75,76 @@ def cpu_baseline(batch_cpu, use_point, n_mol, threads=None, min_seconds=10.0):
         n += 1
         step(n + 1)
     dt = time.time() - t0
-    return {"value": round(n * n_mol / dt, 3), "unit": "molecules/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n} full fp32 steps (fwd+InfoNCE+AR+bwd+clip+AdamW) of the oracle on {n_mol} molecules of the "
-                      f"same workload (T={sub['tokens'].shape[1]}, A={sub['atoms'].shape[1]}, V={GRANDE['n_tok']}), {dt:.1f} s"}
+    out = {"value": round(n * n_mol / dt, 3), "unit": "molecules/s", "cores": torch.get_num_threads(), "kind": "port",
+           "sample": f"{n} full fp32 steps (fwd+InfoNCE+AR+bwd+clip+AdamW) of the oracle on {n_mol} molecules of the "
+                     f"same workload (T={sub['tokens'].shape[1]}, A={sub['atoms'].shape[1]}, V={GRANDE['n_tok']}), {dt:.1f} s"}
+    if threads is None and torch.get_num_threads() > 8:
+        # second reading at 8 threads (BASELINE.md section 2 measured the reference itself on 8 cores: ~6 molecules/s)
+        all_threads = torch.get_num_threads()
+        torch.set_num_threads(8)
+        step(n + 2)
+        t0 = time.time()
+        m = 0
+        while time.time() - t0 < 0.5 * min_seconds or m < 1:
+            m += 1
+            step(n + 2 + m)
+        out["value_8_threads"] = round(m * n_mol / (time.time() - t0), 3)
+        torch.set_num_threads(all_threads)
+    # the full BASELINE.md section 3 protocol (config-1 shape B=64 T=128, 3 warm-up + median of 10, all cores and 8 cores)
+    # takes minutes: tools/cpu_baseline_full.py runs it once per round, result in profiles/rNN_cpu_baseline_full.json
+    full = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_cpu_baseline_full.json")))
+    if full:
+        try:
+            with open(full[-1]) as f:
+                out["full_protocol"] = dict(json.load(f), source=os.path.relpath(full[-1], ROOT))
+        except (OSError, ValueError):
+            pass
+    return out
+
+
+def algorithmic_work(cfg, B, T1, T2, A, n_edges=None):
+    """FLOPs (multiply-add = 2) and HBM bytes of one training step for B molecules; padded token positions
+    are counted (the reference computes them), edges = the actual number of directed pairs inside the cutoff when known,
+    else A(A-1) per molecule."""
+    d, L, V, h, Lg = cfg["n_hidden_xformer"], cfg["n_layer_xformer"], cfg["n_tok"], cfg["n_hidden_e3nn"], cfg["n_layer_e3gnn"]
+    E = float(n_edges) if n_edges is not None else float(B) * A * (A - 1)
+    tl = lambda T: T * L * (24.0 * d * d + 4.0 * T * d)
+    fwd = B * (tl(T1) + tl(T2) + T2 * 2.0 * d * V)
+    fwd += Lg * (E * (2.0 * (2 * h + 1) * h + 2.0 * h * h) + B * A * (2.0 * 2 * h * h + 2.0 * h * h)) + B * A * (2.0 * 28 * h + 4.0 * h * h)
+    fwd += B * 5 * 2.0 * d * d + 2.0 * B * B * d * 2
+    bytes_ = B * ((T1 + T2) * L * 12.0 * d * 2 * 2 + T2 * d * 2.0)
+    return 3.0 * fwd, bytes_
+
+
+def time_comm(eng, D, batch_size, steps=10):
+    """Each collective of the data-parallel step timed alone (device events, this rank), in ms."""
+    import torch.distributed as dist
+    dev = eng.device
+    E = eng.cfg.n_embd_common
+    W = dist.get_world_size()
+    h = torch.randn(batch_size, E, device=dev)
+    big = torch.randn(W * batch_size, E, device=dev)
+    bk = D.grad_buckets(eng)
+    scratch = torch.zeros_like(eng.grads)
+    out = {}
+
+    def timed(name, fn):
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize(); dist.barrier()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(steps):
+            fn()
+        e1.record(); torch.cuda.synchronize()
+        out[name] = round(e0.elapsed_time(e1) / steps, 4)
+
+    timed("all_gather_embeddings_ms", lambda: D.all_gather_cat(h))
+    timed("reduce_scatter_embedding_grads_ms", lambda: D.reduce_scatter_sum(big))
+    for name, (a, b) in bk.items():
+        timed(f"all_reduce_{name}_ms", lambda a=a, b=b: dist.all_reduce(scratch[a:b], op=dist.ReduceOp.AVG))
+        out[f"all_reduce_{name}_MB"] = round((b - a) * 4 / 1e6, 2)
+    return out
 
 
 def main():
@@ -89,9 +165,32 @@ def main():
                     help="contrastive head: infonce = grande_closed (the headline metric); barlow = barlow_closed (configs[3])")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N`: become N ranks (one process per GPU over RCCL), same arguments
+        port = os.environ.get("MASTER_PORT", str(29500 + os.getpid() % 1000))
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        sys.exit(subprocess.call(cmd, env=env))
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and not (world == 1 and os.environ.get("COATI_FORCE_DIST") == "1"):
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s); n_gpus would be wrong")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("COATI_BENCH_LAUNCH_CHECK") == "1":
+        # CPU-side test hook (tests/test_host_cpu.py): rendezvous over gloo, report what the launcher produced, stop
+        import torch.distributed as dist
+        if world > 1:
+            dist.init_process_group("gloo")
+            seen = dist.get_world_size()
+            dist.barrier()
+            dist.destroy_process_group()
+        else:
+            seen = 1
+        if rank == 0:
+            print(json.dumps({"launch_check": True, "gpus_arg": args.gpus, "world_seen": seen}), flush=True)
+        return
     # COATI_FORCE_DIST=1 runs the collective path even at world size 1 (single-GPU smoke test of the RCCL calls)
     dist_on = world > 1 or (os.environ.get("COATI_FORCE_DIST") == "1" and "RANK" in os.environ)
     if dist_on:
@@ -99,6 +198,9 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        assert dist.get_world_size() == world, (dist.get_world_size(), world)
+        if torch.cuda.device_count() < world:
+            raise SystemExit(f"bench.py: {world} ranks but only {torch.cuda.device_count()} visible GPU(s)")
     dev = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(dev)
 
@@ -124,9 +226,9 @@ def main():
     batch = {k: v.to(dev) for k, v in batch_cpu.items()}
     up = up_cpu.to(dev)
 
-    def step():
+    def step(reduce_grads=True):
         if dist_on:
-            D.distributed_train_step(eng, batch, up, lr=5e-4, head=args.head)
+            D.distributed_train_step(eng, batch, up, lr=5e-4, head=args.head, reduce_grads=reduce_grads)
         else:
             eng.train_step(batch, up, lr=5e-4, head=args.head)
 
@@ -152,6 +254,21 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t)
     losses = D.global_losses(eng) if dist_on else eng.losses()
+    comm = None
+    if dist_on:
+        # exposed cost of the gradient all-reduces: the same steps with those four collectives skipped (outside the timed
+        # region; the replicas then drift apart, which no longer matters), then every collective alone
+        k2 = max(3, min(args.steps, 10))
+        sync()
+        t1 = time.perf_counter()
+        for _ in range(k2):
+            step(reduce_grads=False)
+        sync()
+        t_nr = torch.tensor([(time.perf_counter() - t1) / k2], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t_nr, op=torch.distributed.ReduceOp.MAX)
+        comm = time_comm(eng, D, args.batch)
+        comm["step_without_grad_allreduce_ms"] = round(1e3 * float(t_nr), 3)
+        comm["exposed_grad_allreduce_ms"] = round(1e3 * (dt / args.steps - float(t_nr)), 3)
 
     if args.all_sites and rank == 0:
         rows = []
@@ -177,21 +294,24 @@ def main():
         # bound by arithmetic intensity against the ridge point (dense bf16 MFMA peak / HBM peak)
         ridge = PEAK_BF16_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9)
         hbm_bound = site_bytes > 0 and (site_flops / site_bytes) < ridge
-        traffic = None
+        traffic, traffic_source = None, None
         try:
-            if args.config != "grande_closed":
-                raise OSError("PMC summary was collected for the grande_closed shapes only")
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")) as f:
-                traffic = json.load(f).get(args.roofline_site, {}).get("hbm_bytes_per_launch")
-        except (OSError, ValueError):
+            if args.config != "grande_closed" or args.batch != 1024 or args.seq != 80:
+                raise OSError("PMC summaries are collected for the grande_closed B=1024 T=80 shapes only")
+            cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
+            with open(cands[-1]) as f:
+                ent = json.load(f).get(args.roofline_site, {})
+            traffic = ent.get("hbm_bytes_per_launch")
+            traffic_source = f"{os.path.relpath(cands[-1], ROOT)} ({ent.get('command', 'isolated launches, tools/prof_wgrad.py')}); static file, not this run"
+        except (OSError, ValueError, IndexError):
             pass
         if hbm_bound:
             roof = {"bound": "hbm", "kernel": args.roofline_site, "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                    "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": traffic, "avg_launch_ms": round(avg_ms, 5), "launches": site_n,
+                    "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": traffic, "traffic_source": traffic_source, "avg_launch_ms": round(avg_ms, 5), "launches": site_n,
                     "bytes_per_launch": site_bytes, "flops_per_launch": site_flops, "tflops": round(tflops, 1)}
         else:
             roof = {"bound": "mfma", "kernel": args.roofline_site, "achieved": round(tflops, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(tflops / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "avg_launch_ms": round(avg_ms, 5), "launches": site_n,
+                    "frac": round(tflops / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_source, "avg_launch_ms": round(avg_ms, 5), "launches": site_n,
                     "bytes_per_launch": site_bytes, "flops_per_launch": site_flops}
         out = {
             "metric": "molecules/sec (contrastive+AR train step), " + (args.config if args.config != "grande_closed" else ("grande_closed" if args.head == "infonce" else "barlow_closed")),
@@ -214,6 +334,16 @@ def main():
             "loss": {k: round(v, 4) for k, v in losses.items() if k in ("ar_loss", "clip_loss", "loss")},
             "roofline": roof,
         }
+        T1, T2 = batch["raw_tokens"].shape[1], batch["tokens"].shape[1]
+        fl, by = algorithmic_work(MODEL, args.batch, T1, T2, args.atoms)
+        t_step = dt / args.steps
+        out["step_roofline"] = {"alg_tflop_per_step": round(fl / 1e12, 3), "step_tflops": round(fl / t_step / 1e12, 1),
+                                "mfma_frac": round(fl / t_step / 1e12 / PEAK_BF16_TFLOPS, 4),
+                                "alg_GB_per_step": round(by / 1e9, 2), "alg_GBps": round(by / t_step / 1e9, 1),
+                                "hbm_frac": round(by / t_step / 1e9 / PEAK_HBM_GBS, 4),
+                                "note": "SURVEY 8(d) formulas per rank (padded positions and all A(A-1) pairs counted), per-rank step time"}
+        if comm is not None:
+            out["comm"] = comm
         if world == 1 and not args.no_cpu_baseline and args.config == "grande_closed":
             out["cpu_baseline"] = cpu_baseline(batch_cpu, up_cpu, args.cpu_mols)
         print(json.dumps(out), flush=True)

@@ -1,7 +1,10 @@
 """Import-path alias so that code written against the reference (`from coati.training.train_coati import
 train_autoencoder, do_args`, `from coati.data.dataset import COATI_dataset`, `from coati.models.io.coati import
 load_e3gnn_smiles_clip_e2e`, ...; examples/training/train_grande.py:5,9) resolves to the MI355X implementation in
-`coati_amd`.  Only the modules on the accelerated path exist; anything else raises ImportError."""
+`coati_amd`.  Only the modules on the accelerated path exist; anything else raises ImportError.
+
+`coati.x.y` IS the module object `coati_amd.x.y` (same entry in sys.modules under both names); the real module keeps
+its own __spec__ / __path__ / __name__, so importlib.reload and pickling by qualified name keep working."""
 import importlib
 import importlib.abc
 import importlib.util
@@ -10,24 +13,33 @@ import sys
 _PREFIX = "coati."
 
 
-class _AliasFinder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
+class _AliasLoader(importlib.abc.Loader):
+    def __init__(self, real):
+        self.real = real
+
+    def create_module(self, spec):
+        mod = importlib.import_module(self.real)
+        self.keep = {k: getattr(mod, k) for k in ("__spec__", "__loader__", "__package__", "__path__", "__file__") if hasattr(mod, k)}
+        return mod
+
+    def exec_module(self, module):
+        # the import machinery has just stamped the alias spec on the real module: put the module's own attributes back
+        for k, v in self.keep.items():
+            setattr(module, k, v)
+
+
+class _AliasFinder(importlib.abc.MetaPathFinder):
     def find_spec(self, fullname, path=None, target=None):
         if not fullname.startswith(_PREFIX):
             return None
         real = "coati_amd." + fullname[len(_PREFIX):]
         try:
-            if importlib.util.find_spec(real) is None:
-                return None
+            real_spec = importlib.util.find_spec(real)
         except (ImportError, ValueError):
             return None
-        return importlib.util.spec_from_loader(fullname, self, is_package=True)
-
-    def create_module(self, spec):
-        mod = importlib.import_module("coati_amd." + spec.name[len(_PREFIX):])
-        return mod
-
-    def exec_module(self, module):
-        pass
+        if real_spec is None:
+            return None
+        return importlib.util.spec_from_loader(fullname, _AliasLoader(real), is_package=real_spec.submodule_search_locations is not None)
 
 
 sys.meta_path.insert(0, _AliasFinder())

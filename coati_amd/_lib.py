@@ -68,6 +68,7 @@ _SIGS = {
     "coati_engine_refresh_shadows": [P, P],
     "coati_engine_forward": [P, P, L, I, I, I, I, P, P, P, P, P, P, P, P, P, P, I, P],
     "coati_engine_logits": [P, P, L, P],
+    "coati_engine_encode": [P, P, L, I, I, I, P, P, P, P, P, P, P],
     "coati_engine_infonce": [P, P, P, P, P, P, I, I, I, F, P, P, P, P],
     "coati_engine_backward": [P, P, P, I, P],
     "coati_engine_optimizer_step": [P, F, F, F, F, F, F, I, P, P],
@@ -77,6 +78,7 @@ _SIGS = {
 }
 
 _lib = None
+ABI_VERSION = 1
 
 
 def lib():
@@ -85,8 +87,13 @@ def lib():
     if _lib is not None:
         return _lib
     path = _build.LIB
-    if not os.path.exists(path) or (os.environ.get("COATI_AMD_REBUILD") == "1"):
-        _build.build()
+    # build() is a no-op unless a source under csrc/ or include/ is newer than the library (build.needs_build); when no
+    # compiler is around (a box that only received the prebuilt .so) a stale-looking timestamp must not be fatal
+    try:
+        _build.build(force=os.environ.get("COATI_AMD_REBUILD") == "1", verbose=False)
+    except Exception:
+        if not os.path.exists(path):
+            raise
     if not os.path.exists(path):
         raise RuntimeError(f"coati_amd: {path} is missing and could not be built; there is no CPU fallback")
     # torch first: its wheel carries its own ROCm runtime; loading this library before torch would bind it to the system
@@ -95,6 +102,12 @@ def lib():
     l = ctypes.CDLL(path)
     l.coati_last_error.restype = c_char_p
     l.coati_abi_version.restype = c_int
+    if l.coati_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"coati_amd: {path} has ABI version {l.coati_abi_version()}, this package expects {ABI_VERSION}; "
+                           "rebuild with `python -m coati_amd.build --force`")
+    missing = [n for n in exported_symbols() if not hasattr(l, n)]
+    if missing:
+        raise RuntimeError(f"coati_amd: {path} lacks symbols {missing[:6]}; rebuild with `python -m coati_amd.build --force`")
     for name, sig in _SIGS.items():
         fn = getattr(l, name)
         fn.argtypes = sig

@@ -5,15 +5,21 @@ parity is UNPINNED and the only check is the oracle's own restatement (oracle.ba
 world size > 1: all-reduce of the per-dimension batch statistics (2 x 2E floats), of the E x E
 cross-correlation matrix, and of the 2 x 2E backward statistics -- no embedding all-gather is needed."""
 import torch
-import torch.distributed as dist
 
 from . import _lib
 from .ops import ptr, stream, sgemm
 
 
+def _default_all_reduce(t):
+    from .distributed import all_reduce_sum
+    return all_reduce_sum(t)
+
+
 def barlow_head(h_s: torch.Tensor, h_e: torch.Tensor, bad: torch.Tensor, lam: float = 5e-3, gscale: float = 1.0,
-                distributed: bool = False):
-    """Returns (loss[1] on device, dL/dh_s, dL/dh_e); gradients are multiplied by gscale."""
+                distributed: bool = False, all_reduce=None):
+    """Returns (loss[1] on device, dL/dh_s, dL/dh_e); gradients are multiplied by gscale.
+    all_reduce: in-place sum-over-ranks callable (default: coati_amd.distributed.all_reduce_sum)."""
+    _all_reduce = all_reduce or _default_all_reduce
     B, E = h_s.shape
     dev = h_s.device
     f32 = dict(device=dev, dtype=torch.float32)
@@ -24,15 +30,15 @@ def barlow_head(h_s: torch.Tensor, h_e: torch.Tensor, bad: torch.Tensor, lam: fl
     _lib.call("coati_colsum2", ptr(h_s), None, ptr(bad), ptr(stats[0]), B, E, stream())
     _lib.call("coati_colsum2", ptr(h_e), None, ptr(bad), ptr(stats[1]), B, E, stream())
     if distributed:
-        dist.all_reduce(stats)
-        dist.all_reduce(cnt[0:1])
+        _all_reduce(stats)
+        _all_reduce(cnt[0:1])
     zs, ze = torch.empty(B, E, **f32), torch.empty(B, E, **f32)
     rs = torch.empty(2, E, **f32)
     _lib.call("coati_standardize", ptr(h_s), ptr(bad), ptr(stats[0]), ptr(cnt), ptr(zs), ptr(rs[0]), B, E, stream())
     _lib.call("coati_standardize", ptr(h_e), ptr(bad), ptr(stats[1]), ptr(cnt), ptr(ze), ptr(rs[1]), B, E, stream())
     C = sgemm(zs, ze, trans_a=True)                      # [E,E] raw cross-correlation of the local rows
     if distributed:
-        dist.all_reduce(C)
+        _all_reduce(C)
     loss = torch.zeros(1, **f32)
     _lib.call("coati_barlow_dc", ptr(C), ptr(cnt), float(lam), ptr(loss), E, stream())   # C -> G = dL/dC / n
     dzs = sgemm(ze, C, trans_b=True)                     # dL/dzs~ = Ze~ G^T
@@ -41,7 +47,7 @@ def barlow_head(h_s: torch.Tensor, h_e: torch.Tensor, bad: torch.Tensor, lam: fl
     _lib.call("coati_colsum2", ptr(dzs), ptr(zs), ptr(bad), ptr(m[0]), B, E, stream())
     _lib.call("coati_colsum2", ptr(dze), ptr(ze), ptr(bad), ptr(m[1]), B, E, stream())
     if distributed:
-        dist.all_reduce(m)
+        _all_reduce(m)
     dS, dC = torch.empty(B, E, **f32), torch.empty(B, E, **f32)
     _lib.call("coati_standardize_bwd", ptr(dzs), ptr(zs), ptr(bad), ptr(rs[0]), ptr(m[0]), ptr(cnt), float(gscale), ptr(dS), B, E, stream())
     _lib.call("coati_standardize_bwd", ptr(dze), ptr(ze), ptr(bad), ptr(rs[1]), ptr(m[1]), ptr(cnt), float(gscale), ptr(dC), B, E, stream())

@@ -859,6 +859,46 @@ int coati_engine_forward(coati_engine* e, void* workspace, int64_t workspace_byt
   return COATI_OK;
 }
 
+// Inference encoders alone (clip_e2e.py:448-452 encode_tokens, :454-463 encode_points): only the requested tower runs --
+// the encoder pass + [STOP] pick + smiles_to_clip when raw_tokens is given, the point encoder + point_to_clip when
+// atoms / coords are given.  No decoder pass, no lm_head, nothing saved for a backward (have_fwd stays false).
+int coati_engine_encode(coati_engine* e, void* workspace, int64_t workspace_bytes, int B, int T1, int A,
+                        const int64_t* raw_tokens, const int64_t* atoms, const float* coords, float* h_smiles,
+                        float* h_e3gnn, float* scal, void* stream) {
+  COATI_CHECK_ARG(e && e->P && e->S && workspace && scal, "engine_encode: engine not bound / null argument");
+  COATI_CHECK_ARG((raw_tokens && h_smiles) || (atoms && coords && h_e3gnn), "engine_encode: nothing to encode");
+  const coati_config& c = e->cfg;
+  const bool do_tok = raw_tokens && h_smiles, do_pts = atoms && coords && h_e3gnn;
+  if (!do_tok) T1 = 1;
+  if (!do_pts) A = 1;
+  COATI_CHECK_SHAPE(B > 0 && T1 > 0 && A > 0 && T1 <= c.n_seq, "engine_encode: unsupported shape B=%d T1=%d A=%d", B, T1, A);
+  hipStream_t s = (hipStream_t)stream;
+  const int C = c.n_hidden_xformer, H = c.n_hidden_e3nn, E = c.n_embd_common;
+  Arena ar{reinterpret_cast<char*>(workspace), 0, (size_t)workspace_bytes, false};
+  const size_t need = carve(e, ar, B, T1, 1, A, B);
+  COATI_CHECK_ARG((int64_t)need <= workspace_bytes, "engine_encode: workspace too small (%zu > %lld)", need, (long long)workspace_bytes);
+  e->B = B; e->T1 = T1; e->T2 = 1; e->A = A;
+  e->have_fwd = false;
+  HIPCHK(hipMemsetAsync(scal, 0, 16 * sizeof(float), s));
+  HIPCHK(hipMemsetAsync(e->err_flag, 0, 4 * sizeof(int), s));
+  if (do_pts) {
+    e->atoms = reinterpret_cast<const long long*>(atoms);
+    COATI_TRY(gnn_fwd(e, e->atoms, coords, s));
+    COATI_TRY(launch_layernorm_fwd(e->hpoint, H, e->P + e->p2c_lnw, e->P + e->p2c_lnb, nullptr, 0, e->hp_ln, H, e->hp_mean, e->hp_rstd, B, H, s));
+    COATI_TRY(launch_sgemm(e->hp_ln, H, 1, e->P + e->p2c_w, 1, H, h_e3gnn, E, B, E, H, e->P + e->p2c_b, 1.f, 0, s));
+  }
+  if (do_tok) {
+    e->p1.idx = reinterpret_cast<const long long*>(raw_tokens);
+    COATI_TRY(xformer_fwd(e, e->p1, nullptr, s));
+    COATI_TRY(launch_find_stop(e->p1.idx, c.stop_token, e->stop_pos, e->err_flag, B, T1, s));
+    COATI_TRY(launch_gather_rows(e->p1.xf32, e->stop_pos, e->hstop, B, T1, C, s));
+    COATI_TRY(launch_layernorm_fwd(e->hstop, C, e->P + e->s2c_lnw, e->P + e->s2c_lnb, nullptr, 0, e->hs_ln, C, e->hs_mean, e->hs_rstd, B, C, s));
+    COATI_TRY(launch_sgemm(e->hs_ln, C, 1, e->P + e->s2c_w, 1, C, h_smiles, E, B, E, C, e->P + e->s2c_b, 1.f, 0, s));
+    HIPCHK(hipMemcpyAsync(scal + 6, e->err_flag, sizeof(int), hipMemcpyDeviceToDevice, s));
+  }
+  return COATI_OK;
+}
+
 int coati_engine_logits(coati_engine* e, float* logits, int64_t ldl, void* stream) {
   COATI_CHECK_ARG(e && e->have_fwd && logits, "engine_logits: no forward to read");
   const coati_config& c = e->cfg;

@@ -10,25 +10,71 @@ Exchange steps of the path (reference train_coati.py:256-258, autograd_funs.py:5
      transfers run on RCCL's stream underneath the remaining backward kernels (the encoder stage is cut in two: the
      upper layers' bucket travels underneath the lower half of that pass).
 The reference calls model.module.forward_dist and therefore never arms DDP's reducer: it does
-not average parameter gradients.  This implements the intended semantics."""
+not average parameter gradients.  This implements the intended semantics.
+
+Backends: "nccl" is the product path.  Under "gloo" (the CPU tests, and the two-processes-on-one-GPU test of the real
+step in tests/test_gpu_distributed.py) device tensors are staged through the host, because gloo has no
+all_gather_into_tensor / reduce_scatter_tensor / AVG for device memory."""
 import torch
 import torch.distributed as dist
+
+
+def _gloo():
+    return dist.get_backend() == "gloo"
+
+
+class _Done:
+    """stand-in for an async work handle whose collective already completed"""
+
+    def wait(self):
+        return True
 
 
 def all_gather_cat(t: torch.Tensor) -> torch.Tensor:
     """rank-major concatenation along dim 0 (autograd_funs.py:10-12)."""
     W = dist.get_world_size()
+    t = t.contiguous()
+    if _gloo():
+        parts = [torch.empty(t.shape, dtype=t.dtype) for _ in range(W)]
+        dist.all_gather(parts, t.cpu())
+        return torch.cat(parts, 0).to(t.device)
     out = torch.empty((W * t.shape[0],) + tuple(t.shape[1:]), device=t.device, dtype=t.dtype)
-    dist.all_gather_into_tensor(out, t.contiguous())
+    dist.all_gather_into_tensor(out, t)
     return out
 
 
 def reduce_scatter_sum(t_all: torch.Tensor) -> torch.Tensor:
     """sum over ranks of the rank's own row block (autograd_funs.py:18-21, fp32)."""
-    W = dist.get_world_size()
-    out = torch.empty((t_all.shape[0] // W,) + tuple(t_all.shape[1:]), device=t_all.device, dtype=t_all.dtype)
+    W, r = dist.get_world_size(), dist.get_rank()
+    n = t_all.shape[0] // W
+    if _gloo():
+        h = t_all.detach().cpu().contiguous()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM)
+        return h[r * n:(r + 1) * n].to(t_all.device).contiguous()
+    out = torch.empty((n,) + tuple(t_all.shape[1:]), device=t_all.device, dtype=t_all.dtype)
     dist.reduce_scatter_tensor(out, t_all.contiguous(), op=dist.ReduceOp.SUM)
     return out
+
+
+def all_reduce_sum(t: torch.Tensor) -> torch.Tensor:
+    """in-place sum over ranks (Barlow statistics, loss scalars)."""
+    if _gloo() and t.is_cuda:
+        h = t.detach().cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM)
+        t.copy_(h)
+        return t
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t
+
+
+def all_reduce_avg_async(t: torch.Tensor):
+    """in-place mean over ranks of a slice of the flat gradient buffer; returns a handle with .wait()."""
+    if _gloo():
+        h = t.detach().cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM)
+        t.copy_(h / dist.get_world_size())
+        return _Done()
+    return dist.all_reduce(t, op=dist.ReduceOp.AVG, async_op=True)
 
 
 def grad_buckets(eng):
@@ -43,9 +89,12 @@ def grad_buckets(eng):
             "heads": (hd0, eng.n_params)}
 
 
-def distributed_train_step(eng, batch, use_point, lr, do_clip=True, optimizer=True, head="infonce"):
+def distributed_train_step(eng, batch, use_point, lr, do_clip=True, optimizer=True, head="infonce", reduce_grads=True,
+                           **opt_kw):
     """do_minibatch at world_size > 1.  Returns (h_e3gnn, h_smiles, bad_rows) of the local rows.
-    head="barlow": Barlow-Twins head instead of InfoNCE (statistics / E x E matrix all-reduced, no embedding gather)."""
+    head="barlow": Barlow-Twins head instead of InfoNCE (statistics / E x E matrix all-reduced, no embedding gather).
+    reduce_grads=False skips the four gradient all-reduces (bench.py's measurement of their exposed cost).
+    opt_kw: weight_decay / max_norm / betas / eps for Engine.optimizer_step (train_coati.py:145-151, 276)."""
     W, rank = dist.get_world_size(), dist.get_rank()
     h_e, h_s, bad = eng.forward(batch["raw_tokens"], batch["tokens"], batch["atoms"], batch["coords"], use_point,
                                 y_next=batch["y_next"], train=True)
@@ -64,8 +113,9 @@ def distributed_train_step(eng, batch, use_point, lr, do_clip=True, optimizer=Tr
     works = []
 
     def launch(name):
-        a, b = bk[name]
-        works.append(dist.all_reduce(eng.grads[a:b], op=dist.ReduceOp.AVG, async_op=True))
+        if reduce_grads:
+            a, b = bk[name]
+            works.append(all_reduce_avg_async(eng.grads[a:b]))
 
     eng.backward(dS, dC, stage=1)
     launch("lm_head"); launch("heads")
@@ -80,16 +130,39 @@ def distributed_train_step(eng, batch, use_point, lr, do_clip=True, optimizer=Tr
     for w in works:
         w.wait()
     if optimizer:
-        eng.optimizer_step(lr)
+        eng.optimizer_step(lr, **opt_kw)
+    return h_e, h_s, bad
+
+
+def distributed_eval_step(eng, batch, use_point, do_clip=True):
+    """Forward + both losses only (the reference evaluates under torch.no_grad(), train_coati.py:237-271 with
+    partition != 'train'): no backward, no gradient all-reduce; the embedding all-gather stays so that the InfoNCE
+    value is the global-batch one."""
+    rank = dist.get_rank()
+    h_e, h_s, bad = eng.forward(batch["raw_tokens"], batch["tokens"], batch["atoms"], batch["coords"], use_point,
+                                y_next=batch["y_next"], train=False)
+    if do_clip:
+        s_all, c_all, bad_all = all_gather_cat(h_s), all_gather_cat(h_e), all_gather_cat(bad)
+        eng.infonce(h_s, h_e, s_all, c_all, bad_all, row0=rank * h_e.shape[0], gscale=0.0)
     return h_e, h_s, bad
 
 
 def global_losses(eng):
     """all-reduced loss scalars (every rank must call this)."""
     s = eng.scal.clone()
-    dist.all_reduce(s[:4], op=dist.ReduceOp.SUM)
+    all_reduce_sum(s[:4])
     s = s.cpu()
     ar = float(s[0] / s[1]) if s[1] > 0 else 0.0
     nv = float(s[4])
     clip = float(0.5 * (s[2] + s[3]) / nv) if nv > 0 else 0.0
     return {"ar_loss": ar, "clip_loss": clip, "loss": ar + clip * eng.token_entropy_unit()}
+
+
+def all_agree(flag: bool, device) -> bool:
+    """True when `flag` is true on every rank (one tiny all-reduce): collective decisions such as skipping a batch must
+    be taken by all ranks together or the next collective deadlocks."""
+    t = torch.tensor([1.0 if flag else 0.0], device=device)
+    if _gloo():
+        t = t.cpu()
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(t.item() > 0.5)

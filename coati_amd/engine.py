@@ -141,12 +141,34 @@ class Engine:
         h_s = torch.empty(B, E, device=self.device, dtype=torch.float32)
         bad = torch.empty(B, device=self.device, dtype=torch.uint8)
         self._keep = (raw_tokens, tokens, atoms, coords, use_point, y_next)  # keep inputs alive until backward
-        _lib.check(self.l.coati_engine_forward(self.h, ptr(self.workspace), need, B, T1, T2, A, ptr(raw_tokens), ptr(tokens),
+        _lib.check(self.l.coati_engine_forward(self.h, ptr(self.workspace), self.workspace.numel(), B, T1, T2, A, ptr(raw_tokens), ptr(tokens),
                                                ptr(y_next), ptr(atoms), ptr(coords), ptr(use_point), ptr(h_e), ptr(h_s),
                                                ptr(bad), ptr(self.scal), 1 if (train and self.grads is not None) else 0,
                                                stream()), "coati_engine_forward")
         self._shape = (B, T1, T2, A)
         return h_e, h_s, bad
+
+    def encode(self, raw_tokens=None, atoms=None, coords=None):
+        """encode_tokens / encode_points: only the requested tower runs.  Returns (h_smiles or None, h_e3gnn or None)."""
+        assert raw_tokens is not None or atoms is not None
+        B = (raw_tokens if raw_tokens is not None else atoms).shape[0]
+        T1 = raw_tokens.shape[1] if raw_tokens is not None else 1
+        A = atoms.shape[1] if atoms is not None else 1
+        E = self.cfg.n_embd_common
+        need = int(self.l.coati_engine_workspace_bytes(self.h, B, T1, 1, A, B))
+        if self.workspace is None or self.workspace.numel() < need:
+            self.workspace = None
+            self.workspace = torch.empty(need, device=self.device, dtype=torch.uint8)
+        h_s = torch.empty(B, E, device=self.device, dtype=torch.float32) if raw_tokens is not None else None
+        h_e = torch.empty(B, E, device=self.device, dtype=torch.float32) if atoms is not None else None
+        if coords is not None:
+            coords = coords.to(self.device, torch.float32).contiguous()
+        self._keep = (raw_tokens, atoms, coords)
+        _lib.check(self.l.coati_engine_encode(self.h, ptr(self.workspace), self.workspace.numel(), B, T1, A, ptr(raw_tokens),
+                                              ptr(atoms), ptr(coords), ptr(h_s), ptr(h_e), ptr(self.scal), stream()),
+                   "coati_engine_encode")
+        self._shape = None
+        return h_s, h_e
 
     def logits(self):
         B, _, T2, _ = self._shape
@@ -177,9 +199,10 @@ class Engine:
     def token_entropy_unit(self):
         return math.log(float(self.cfg.n_tok)) / math.log(2.0)
 
-    def train_step(self, batch, use_point, lr, do_clip=True, clip_weight=None, optimizer=True, head="infonce"):
+    def train_step(self, batch, use_point, lr, do_clip=True, clip_weight=None, optimizer=True, head="infonce", **opt_kw):
         """One single-GPU do_minibatch (train_coati.py:216-277).  Losses stay on the device in self.scal.
-        head: "infonce" (clip_e2e.py:27-47) or "barlow" (BASELINE configs[3]; parity unpinned, see barlow.py)."""
+        head: "infonce" (clip_e2e.py:27-47) or "barlow" (BASELINE configs[3]; parity unpinned, see barlow.py).
+        opt_kw: weight_decay / max_norm / betas / eps forwarded to optimizer_step (train_coati.py:145-151, 276)."""
         h_e, h_s, bad = self.forward(batch["raw_tokens"], batch["tokens"], batch["atoms"], batch["coords"], use_point,
                                      y_next=batch["y_next"], train=True)
         dS = dC = None
@@ -192,7 +215,15 @@ class Engine:
             dS, dC = self.infonce(h_s, h_e, h_s, h_e, bad, row0=0, gscale=0.5 * w)
         self.backward(dS, dC, 0)
         if optimizer:
-            self.optimizer_step(lr)
+            self.optimizer_step(lr, **opt_kw)
+        return h_e, h_s, bad
+
+    def eval_step(self, batch, use_point, do_clip=True):
+        """Forward + both losses, no backward (the reference's test partition runs under torch.no_grad())."""
+        h_e, h_s, bad = self.forward(batch["raw_tokens"], batch["tokens"], batch["atoms"], batch["coords"], use_point,
+                                     y_next=batch["y_next"], train=False)
+        if do_clip:
+            self.infonce(h_s, h_e, h_s, h_e, bad, row0=0, gscale=0.0)
         return h_e, h_s, bad
 
     def losses(self):

@@ -150,20 +150,16 @@ class e3gnn_smiles_clip_e2e(nn.Module):
         return h_e, h_s, logits, self.clip_loss(h_s, h_e, bad)
 
     def encode_tokens(self, token_indices, tokenizer):
-        """clip_e2e.py:448-452 (runs the full fixed launch sequence with placeholder point clouds)."""
-        idx = self._tok(token_indices)
-        B = idx.shape[0]
-        atoms = torch.ones(B, 2, dtype=torch.long, device=self.device)
-        coords = torch.zeros(B, 2, 3, device=self.device)
-        _, h_s, _, _ = self.forward_dist(idx, idx, atoms, coords, tokenizer, use_point=torch.zeros(B, dtype=torch.bool), return_logits=False)
+        """clip_e2e.py:448-452: smiles_to_clip(xformer.encode(tokens)) -- the encoder pass alone."""
+        self._sync_tokens(tokenizer)
+        h_s, _ = self.engine.encode(raw_tokens=self._tok(token_indices))
+        if int(self.engine.scal[6:7].view(torch.int32).item()) & 1:
+            raise RuntimeError("Some smiles in the batch do not have stop tokens. Did some tokenizations fail?")
         return h_s
 
     def encode_points(self, atoms, coords):
-        """clip_e2e.py:454-463 (placeholder token rows [SMILES][STOP])."""
-        B = atoms.shape[0]
-        c = self.engine.cfg
-        idx = torch.tensor([[2, c.stop_token]], dtype=torch.long, device=self.device).repeat(B, 1)
-        h_e, _, _, _ = self.forward_dist(idx, idx, atoms, coords, None, use_point=torch.ones(B, dtype=torch.bool), return_logits=False)
+        """clip_e2e.py:454-463: point_to_clip(point_encoder(atoms, coords)) -- the point encoder alone."""
+        _, h_e = self.engine.encode(atoms=self._tok(atoms), coords=coords)
         return h_e
 
     def special_tokens_from_clip(self, h_clip):

@@ -168,32 +168,57 @@ def train_autoencoder(gpu, args, dataset=None, tokenizer=None):
     def lr_at(epoch):   # CosineAnnealingLR(T_max=n_epochs), stepped once per epoch (train_coati.py:152, 381)
         return 0.5 * args.lr * (1.0 + math.cos(math.pi * epoch / max(args.n_epochs, 1)))
 
+    opt_kw = dict(weight_decay=float(args.weight_decay), max_norm=float(args.clip_grad))   # train_coati.py:145-151, 276
+
     def do_epoch(epoch, partition="train"):
         nonlocal n_toks, ngrad_updates
-        t0, ng, losses = time.time(), 0, []
+        t0, ng = time.time(), 0
+        # epoch statistics stay on the device: [sum of batch losses, batches, tokens] (the reference reads .item() per batch,
+        # train_coati.py:282, 309-335; here one read-back per epoch + the logging steps)
+        acc = torch.zeros(3, device=device, dtype=torch.float64)
+        teu = eng.token_entropy_unit()
         pipe = dataset.get_data_pipe(batch_size=args.batch_size, partition=partition, distributed_rankmod_total=world,
                                      distributed_rankmod_rank=rank, required_fields=["smiles"])
-        for i, batch in enumerate(pipe):
+        it = iter(pipe)
+        i = -1
+        while True:
+            batch = next(it, None)
+            if world > 1 and not D.all_agree(batch is not None, device):
+                break            # uneven batch counts: every rank stops with the shortest one (no dangling collective)
+            if batch is None:
+                break
+            i += 1
             dev = {k: v.to(device) for k, v in batch.items() if isinstance(v, torch.Tensor)}
             B = dev["atoms"].shape[0]
-            if not (dev["tokens"].shape[0] == B and dev["y_next"].shape[0] == B):
+            ok = dev["tokens"].shape[0] == B and dev["y_next"].shape[0] == B
+            if world > 1:
+                ok = D.all_agree(ok, device)     # a skip on one rank only would block the other ranks' collectives
+            if not ok:
                 print("a row was lost, skipping batch")          # train_coati.py:229-234
                 continue
             use_point = torch.rand((B,), device=device) > args.p_clip_emb_smi
             train = partition == "train"
-            if world > 1:
-                D.distributed_train_step(eng, dev, use_point, lr_at(epoch), do_clip=args.do_clip, optimizer=train)
+            if train:
+                if world > 1:
+                    D.distributed_train_step(eng, dev, use_point, lr_at(epoch), do_clip=args.do_clip, **opt_kw)
+                else:
+                    eng.train_step(dev, use_point, lr_at(epoch), do_clip=args.do_clip, **opt_kw)
+            elif world > 1:
+                D.distributed_eval_step(eng, dev, use_point, do_clip=args.do_clip)
             else:
-                eng.train_step(dev, use_point, lr_at(epoch), do_clip=args.do_clip, optimizer=train)
-            ngrad_updates += B
+                eng.eval_step(dev, use_point, do_clip=args.do_clip)
+            ngrad_updates += B          # both partitions, as train_coati.py:279-282
             ng += B
+            sc = eng.scal.double()
+            ar_d = sc[0] / torch.clamp(sc[1], min=1.0)
+            cl_d = 0.5 * (sc[2] + sc[3]) / torch.clamp(sc[4], min=1.0)
+            acc += torch.stack([ar_d + cl_d * teu, torch.ones_like(ar_d), (dev["tokens"] > 0).sum().double()])
             log_now = (i % int(args.log_batch_loss)) == 0
             if log_now or i % args.log_interval == 0:
                 L = D.global_losses(eng) if world > 1 else eng.losses()
-                n_toks += int((dev["tokens"] > 0).sum().item())
-                losses.append(L["loss"])
+                toks_now = n_toks + int(acc[2].item())
                 if rank == 0 and log_now:
-                    tags = {"n_toks": n_toks}
+                    tags = {"n_toks": toks_now}
                     offline_losses["batch_losses"].append(logger.log_metric(partition + "_batch_loss", L["loss"], epoch, i, tags))
                     offline_losses["ar_losses"].append(logger.log_metric(partition + "_ar_loss", L["ar_loss"], epoch, i, tags))
                     offline_losses["clip_losses"].append(logger.log_metric(partition + "_clip_loss", L["clip_loss"], epoch, i, tags))
@@ -203,12 +228,14 @@ def train_autoencoder(gpu, args, dataset=None, tokenizer=None):
             if ngrad_updates * world > float(args.ngrad_to_save) and rank == 0:
                 ngrad_updates = 0
                 doc = serialize_model(vars(args), dataset.summary, {k: v.cpu() for k, v in model.state_dict().items()}, model_kwargs,
-                                      optimizer_state(), n_toks_processed=n_toks, n_grads_processed=ngrad_updates,
+                                      optimizer_state(), n_toks_processed=n_toks + int(acc[2].item()), n_grads_processed=ngrad_updates,
                                       offline_loss=offline_losses)
                 logger.log_pytorch(doc, tags={"train_epoch": str(epoch), "dataset_epoch": str(epoch)})
+        a = acc.cpu()
+        n_toks += int(a[2])
         if rank == 0:
             print(f"epoch completed in {ng} grads and {time.time()-t0} seconds")
-        return sum(losses) / len(losses) if losses else None
+        return float(a[0] / a[1]) if a[1] > 0 else None    # mean of the per-batch losses over EVERY batch (train_coati.py:383-396)
 
     res = {"best_test": 1e10, "best_epoch": 0, "best_model": None}
     for epoch in range(args.n_epochs):

@@ -228,6 +228,14 @@ int coati_engine_forward(coati_engine* e, void* workspace, int64_t workspace_byt
                          const int64_t* raw_tokens, const int64_t* tokens, const int64_t* y_next,
                          const int64_t* atoms, const float* coords, const uint8_t* use_point, float* h_e3gnn,
                          float* h_smiles, uint8_t* bad_rows, float* scal, int train, void* stream);
+/* Inference encoders alone: e3gnn_smiles_clip_e2e.encode_tokens (clip_e2e.py:448-452) when raw_tokens + h_smiles are
+ * given, .encode_points (clip_e2e.py:454-463) when atoms + coords + h_e3gnn are given (either pair may be null).  Only
+ * the requested tower runs; workspace as for coati_engine_forward with T2 = 1.  scal[6] bit 0: a row without exactly
+ * one [STOP] (smiles_xformer.py:63-66). */
+int coati_engine_encode(coati_engine* e, void* workspace, int64_t workspace_bytes, int B, int T1, int A,
+                        const int64_t* raw_tokens, const int64_t* atoms, const float* coords, float* h_smiles,
+                        float* h_e3gnn, float* scal, void* stream);
+
 /* logits [B*T2, ldl] f32 of the last forward (API parity with forward_dist's third return value) */
 int coati_engine_logits(coati_engine* e, float* logits, int64_t ldl, void* stream);
 

@@ -185,3 +185,98 @@ def test_trie_tokenizer_matches_reference_golden(golden_dir):
         for w in c["words"]:
             t.add(w)
         assert t.split(c["text"]) == c["split"], (c["words"], c["text"])
+
+
+def test_bench_gpus_flag_launches_that_many_ranks():
+    """`python bench.py --gpus N` (the driver's command form) must become N ranks: the script re-executes itself under
+    torch.distributed.run.  COATI_BENCH_LAUNCH_CHECK=1 stops each rank after the rendezvous (gloo here, no GPU)."""
+    import subprocess
+    import sys
+    env = dict(os.environ, COATI_BENCH_LAUNCH_CHECK="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    assert json.loads(line) == {"launch_check": True, "gpus_arg": 2, "world_seen": 2}
+    # a launcher that produced another world size than --gpus says is an error, not a silently wrong n_gpus
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], env=dict(env, WORLD_SIZE="1", RANK="0"),
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "--gpus 4" in (r.stderr + r.stdout)
+
+
+class _FakeEngine:
+    """records the step calls; no device"""
+
+    def __init__(self):
+        from coati_amd.engine import Engine
+        self.calls = []
+        self.layout = {"xformer.emb.tok_emb.weight": (0, (4, 4)), "xformer.transformer.h.0.ln_1.weight": (64, (4,)),
+                       "xformer.transformer.h.1.ln_1.weight": (128, (4,)), "xformer.lm_head.weight": (192, (4, 4)),
+                       "point_encoder.embedding.weight": (256, (4, 4)), "point_to_clip.0.weight": (320, (4,))}
+        self.n_params = 384
+        self.grads = torch.arange(384, dtype=torch.float32)
+        self.scal = torch.zeros(16)
+        self._train_step = Engine.train_step.__get__(self)
+        self._eval_step = Engine.eval_step.__get__(self)
+
+    def token_entropy_unit(self):
+        return 2.0
+
+    def forward(self, *a, **k):
+        self.calls.append(("forward", k.get("train")))
+        return torch.ones(3, 4), torch.ones(3, 4), torch.zeros(3, dtype=torch.uint8)
+
+    def infonce(self, s, c, sa, ca, bad, row0=0, gscale=1.0):
+        self.calls.append(("infonce", row0, gscale, tuple(sa.shape)))
+        return torch.ones_like(sa), torch.ones_like(ca)
+
+    def backward(self, dS, dC, stage=0):
+        self.calls.append(("backward", stage))
+
+    def optimizer_step(self, lr, **kw):
+        self.calls.append(("optimizer_step", lr, kw))
+
+
+def test_optimizer_arguments_reach_the_optimizer():
+    """--weight_decay / --clip_grad (train_coati.py:145-151, 276) must arrive at Engine.optimizer_step on both the
+    single-GPU and the data-parallel step; the evaluation step runs forward + InfoNCE only."""
+    import torch.distributed as dist
+    from coati_amd import distributed as D
+    batch = {k: torch.zeros(3, 5, dtype=torch.long) for k in ("raw_tokens", "tokens", "atoms", "y_next")}
+    batch["coords"] = torch.zeros(3, 5, 3)
+    up = torch.ones(3, dtype=torch.bool)
+    e = _FakeEngine()
+    e._train_step(batch, up, 1e-3, weight_decay=0.03, max_norm=2.0)
+    assert e.calls[-1] == ("optimizer_step", 1e-3, {"weight_decay": 0.03, "max_norm": 2.0})
+    e.calls.clear()
+    e._eval_step(batch, up)
+    assert [c[0] for c in e.calls] == ["forward", "infonce"] and e.calls[0] == ("forward", False)
+    store = dist.HashStore()
+    dist.init_process_group("gloo", rank=0, world_size=1, store=store)
+    try:
+        e.calls.clear()
+        D.distributed_train_step(e, batch, up, 2e-3, weight_decay=0.07, max_norm=3.0)
+        names = [c[0] for c in e.calls]
+        assert names == ["forward", "infonce", "backward", "backward", "backward", "backward", "optimizer_step"]
+        assert [c[1] for c in e.calls if c[0] == "backward"] == [1, 4, 5, 3]
+        assert e.calls[-1] == ("optimizer_step", 2e-3, {"weight_decay": 0.07, "max_norm": 3.0})
+        # the five buckets tile the flat gradient buffer exactly once
+        bk = sorted(D.grad_buckets(e).values())
+        assert bk[0][0] == 0 and bk[-1][1] == e.n_params and all(a[1] == b[0] for a, b in zip(bk, bk[1:]))
+        e.calls.clear()
+        D.distributed_eval_step(e, batch, up)
+        assert [c[0] for c in e.calls] == ["forward", "infonce"]
+        assert D.all_agree(True, "cpu") and not D.all_agree(False, "cpu")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_trainer_passes_args_to_the_step():
+    """the trainer hands args.weight_decay / args.clip_grad to every training step and evaluates forward-only"""
+    import inspect
+    from coati_amd.training import train_coati as T
+    src = inspect.getsource(T.train_autoencoder)
+    assert "weight_decay=float(args.weight_decay)" in src and "max_norm=float(args.clip_grad)" in src
+    assert "eval_step" in src and "distributed_eval_step" in src and "**opt_kw" in src
