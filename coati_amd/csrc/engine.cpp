@@ -86,7 +86,7 @@ struct Arena {
 struct coati_engine {
   coati_config cfg;
   std::vector<Entry> entries;
-  int64_t n_params = 0, n_shadow = 0;
+  int64_t n_params = 0, n_shadow = 0, n_trainable = 0;
   int Vpad = 0;
   // parameter offsets
   int64_t tok_emb = 0, lnfw = 0, lnfb = 0, lmhead = 0, lmheadT = 0;
@@ -101,6 +101,7 @@ struct coati_engine {
   const int *lut_ix = nullptr, *lut_iy = nullptr;
   // per-step state (pointers into the caller's workspace)
   bool have_fwd = false;
+  bool have_ws = false;    // the workspace is carved (forward or encode): the InfoNCE / optimizer scratch pointers are valid
   int B = 0, T1 = 0, T2 = 0, A = 0;
   XPass p1, p2;
   const long long *y_next = nullptr, *atoms = nullptr;
@@ -229,11 +230,6 @@ void build_layout(coati_engine* e) {
     g.n0b = add_entry(e, p + "node_mlp.0.bias", H, 0);
     g.n3w = add_entry(e, p + "node_mlp.3.weight", H, H);
     g.n3b = add_entry(e, p + "node_mlp.3.bias", H, 0);
-    // coord_mlp is evaluated and discarded by the reference (e3gnn_clip.py:132): parameters kept for
-    // state_dict parity, never read, gradient stays zero.
-    g.c0w = add_entry(e, p + "coord_mlp.0.weight", H, H);
-    g.c0b = add_entry(e, p + "coord_mlp.0.bias", H, 0);
-    g.c2w = add_entry(e, p + "coord_mlp.2.weight", 1, H);
   }
   // --- heads (clip_e2e.py:419-435) ---
   e->p2c_lnw = add_entry(e, "point_to_clip.0.weight", H, 0);
@@ -246,6 +242,17 @@ void build_layout(coati_engine* e) {
   e->s2c_b = add_entry(e, "smiles_to_clip.1.bias", E, 0);
   e->tokw = add_entry(e, "point_clip_to_special_tokens.1.weight", E, E);
   e->tokb = add_entry(e, "point_clip_to_special_tokens.1.bias", E, 0);
+  // coord_mlp is evaluated and discarded by the reference (e3gnn_clip.py:132): its parameters never receive a gradient
+  // (p.grad is None), so torch's clip_grad_norm_ / AdamW skip them entirely -- no weight decay either.  They are kept for
+  // state_dict parity at the END of the flat buffers, behind n_trainable: the optimizer kernels stop in front of them.
+  e->n_trainable = e->n_params;
+  for (int l = 0; l < c.n_layer_e3gnn; ++l) {
+    const std::string p = "point_encoder.gcl_" + std::to_string(l) + ".";
+    GLayerP& g = e->gl[l];
+    g.c0w = add_entry(e, p + "coord_mlp.0.weight", H, H);
+    g.c0b = add_entry(e, p + "coord_mlp.0.bias", H, 0);
+    g.c2w = add_entry(e, p + "coord_mlp.2.weight", 1, H);
+  }
 
   // --- shadow extras ---
   e->n_shadow = e->n_params;
@@ -856,6 +863,7 @@ int coati_engine_forward(coati_engine* e, void* workspace, int64_t workspace_byt
   if (h_smiles) HIPCHK(hipMemcpyAsync(h_smiles, e->h_smiles, (size_t)B * E * sizeof(float), hipMemcpyDeviceToDevice, s));
   HIPCHK(hipMemcpyAsync(scal + 6, e->err_flag, sizeof(int), hipMemcpyDeviceToDevice, s));
   e->have_fwd = true;
+  e->have_ws = true;
   return COATI_OK;
 }
 
@@ -877,8 +885,10 @@ int coati_engine_encode(coati_engine* e, void* workspace, int64_t workspace_byte
   Arena ar{reinterpret_cast<char*>(workspace), 0, (size_t)workspace_bytes, false};
   const size_t need = carve(e, ar, B, T1, 1, A, B);
   COATI_CHECK_ARG((int64_t)need <= workspace_bytes, "engine_encode: workspace too small (%zu > %lld)", need, (long long)workspace_bytes);
+  if (e->nce) e->nce_cap = ((size_t)workspace_bytes - (size_t)(reinterpret_cast<char*>(e->nce) - reinterpret_cast<char*>(workspace))) / sizeof(float);
   e->B = B; e->T1 = T1; e->T2 = 1; e->A = A;
   e->have_fwd = false;
+  e->have_ws = true;
   HIPCHK(hipMemsetAsync(scal, 0, 16 * sizeof(float), s));
   HIPCHK(hipMemsetAsync(e->err_flag, 0, 4 * sizeof(int), s));
   if (do_pts) {
@@ -914,7 +924,7 @@ int coati_engine_infonce(coati_engine* e, const float* S_loc, const float* C_loc
   COATI_CHECK_SHAPE(B > 0 && Bg >= B && row0 >= 0 && row0 + B <= Bg, "engine_infonce: bad row range");
   hipStream_t s = (hipStream_t)stream;
   const int E = e->cfg.n_embd_common;
-  COATI_CHECK_ARG(e->have_fwd, "engine_infonce: needs the workspace of a forward call");
+  COATI_CHECK_ARG(e->have_ws, "engine_infonce: needs the workspace of a forward / encode call");
   // logits scratch [B, Bg] f32 x 2: the dedicated region sized at workspace time (world_size * B columns), or -- for the
   // stand-alone clip_loss API with another batch size -- the idle backward scratch of the decoder pass
   const size_t need = (size_t)2 * B * Bg;
@@ -1021,8 +1031,8 @@ int coati_engine_optimizer_step(coati_engine* e, float lr, float beta1, float be
   hipStream_t s = (hipStream_t)stream;
   {
     ProfScope ps(e, SITE_OPTIM, 0, s);
-    COATI_TRY(launch_grad_sqnorm(e->G, e->n_params, e->opt_partial, 1024, scal + 5, max_norm, scal + 8, s));
-    COATI_TRY(launch_adamw(e->P, e->G, e->Mo, e->Vo, e->S, e->n_params, lr, beta1, beta2, eps, weight_decay, step, scal + 8, 1.f, s));
+    COATI_TRY(launch_grad_sqnorm(e->G, e->n_trainable, e->opt_partial, 1024, scal + 5, max_norm, scal + 8, s));
+    COATI_TRY(launch_adamw(e->P, e->G, e->Mo, e->Vo, e->S, e->n_trainable, lr, beta1, beta2, eps, weight_decay, step, scal + 8, 1.f, s));
   }
   return refresh_shadows_impl(e, stream, true);
 }

@@ -1,6 +1,6 @@
 """Host-side mirror of the reference's model interface for the hot path (coati/models/encoding/clip_e2e.py):
 `e3gnn_smiles_clip_e2e` (same constructor kwargs, attributes, state_dict keys, forward_dist / encode_* signatures),
-`clip_loss`, and the tensorisation tail of `clip_ar_xform`.  All tensor maths runs in libcoati_hip.so through
+`clip_loss`, and `clip_ar_xform` (augmentation + tokenisation head over the C++ trie tokenizer, tensorisation tail).  All tensor maths runs in libcoati_hip.so through
 coati_amd.engine.Engine; this file only adapts the calling convention."""
 import math
 from typing import Any, Dict
@@ -29,6 +29,37 @@ def _attach(root: nn.Module, dotted: str, tensor: torch.Tensor, grad: torch.Tens
         if grad is not None:
             prm.grad = grad
         mod.register_parameter(parts[-1], prm)
+
+
+def reference_parameter_order(names):
+    """The order in which the reference registers its parameters (clip_e2e.py:381-435: point_encoder, xformer, then the
+    three heads; inside them e3gnn_clip.py:75-104 and smiles_xformer.py:71-100), i.e. the order of `model.parameters()`
+    and therefore of the per-parameter entries of a torch optimizer state_dict written by the reference.  The flat
+    device buffers use their own order (transformer first); this is the state_dict / checkpoint contract."""
+    def key(n):
+        p = n.split(".")
+        top = {"point_encoder": 0, "xformer": 1, "point_to_clip": 2, "smiles_to_clip": 3, "point_clip_to_special_tokens": 4}[p[0]]
+        wb = {"weight": 0, "bias": 1}[p[-1]]
+        if p[0] == "point_encoder":
+            if p[1] == "embedding":
+                return (top, 0, 0, 0, 0, wb)
+            if p[1] == "node_dec":
+                return (top, 1, 0, 0, int(p[2]), wb)
+            layer = int(p[1].split("_")[1])
+            return (top, 2, layer, {"edge_mlp": 0, "node_mlp": 1, "coord_mlp": 2}[p[2]], int(p[3]), wb)
+        if p[0] == "xformer":
+            if p[1] == "emb":
+                return (top, 0, 0, 0, 0, wb)
+            if p[1] == "lm_head":
+                return (top, 3, 0, 0, 0, wb)
+            if p[2] == "ln_f":
+                return (top, 2, 0, 0, 0, wb)
+            layer = int(p[3])
+            sub = {"ln_1": (0, 0), "attn": (1, {"c_attn": 0, "c_proj": 1}.get(p[5], 0)), "ln_2": (2, 0),
+                   "mlpf": (3, int(p[5]) if p[4] == "mlpf" else 0)}[p[4]]
+            return (top, 1, layer, sub[0], sub[1], wb)
+        return (top, int(p[1]), 0, 0, 0, wb)
+    return sorted(names, key=key)
 
 
 class clip_loss(nn.Module):
@@ -80,8 +111,9 @@ class e3gnn_smiles_clip_e2e(nn.Module):
         eng = Engine(cfg, self.device, train=True)
         object.__setattr__(self, "engine", eng)
         grads = eng.named_views("grads")
-        for name, view in eng.named_views("params").items():
-            _attach(self, name, view, grads[name])
+        views = eng.named_views("params")
+        for name in reference_parameter_order(views):
+            _attach(self, name, views[name], grads[name])
         for l in range(n_layer_xformer):   # causal-mask buffers of the reference state_dict (basic_transformer.py:117-123)
             _attach(self, f"xformer.transformer.h.{l}.attn.bias",
                     torch.tril(torch.ones(n_seq, n_seq, device=self.device)).view(1, 1, n_seq, n_seq), buffer=True)
@@ -207,12 +239,121 @@ class e3gnn_smiles_clip_e2e(nn.Module):
             raise NotImplementedError("tokenizer special ids differ from the engine's (stop/unk); rebuild the model with them")
 
 
-def tensorize_batch(batch: Dict[str, Any], tokenizer, dtype=torch.float, device="cpu", coord_noise=False):
+def _formula_text(atoms_row) -> str:
+    """"[FORMULA][ELM6][NUM6]..." from the element counts of one molecule (clip_e2e.py:126-141); empty when an element
+    occurs 150 times or more."""
+    import numpy as np
+    z = np.asarray(atoms_row).astype(int)
+    counts = np.bincount(z[z > 0])
+    if not (counts < 150).all():
+        return ""
+    return "[FORMULA]" + "".join(f"[ELM{el}][NUM{n}]" for el, n in enumerate(counts) if n > 0)
+
+
+def _two_cut_points(rng, lo, hi):
+    """two distinct sorted positions in [lo, hi], redrawn as a pair until they differ (clip_e2e.py:158-165, 198-202)"""
+    a = b = 1
+    while a == b:
+        a, b = sorted([rng.randint(lo, hi), rng.randint(lo, hi)])
+    return a, b
+
+
+def clip_ar_xform(batch: Dict[str, Any], tokenizer, p_dataset: float = 0.2, p_formula: float = 0.2, p_fim: float = 0.0,
+                  p_graph: float = 0.0, p_clip: float = 0.9, p_clip_cut: float = 0.3, p_randsmiles: float = 0.0,
+                  dtype: torch.dtype = torch.float, device: torch.device = torch.device("cpu"), coord_noise: bool = False,
+                  canon_smiles=None, permute_smiles=None, adj_mat_to_tokens=None, rng=None):
+    """coati.models.encoding.clip_e2e.clip_ar_xform (clip_e2e.py:50-330) with the reference's signature: per-row
+    representation choice ([SET] / [FORMULA] / graph prefixes in shuffled order), tokenisation (C++ trie tokenizer),
+    the [CLIP][UNK] prefix with probability p_clip -- with probability p_clip_cut in its fill-in-the-middle form
+    [CLIP][UNK] head [SUFFIX] tail [MIDDLE] middle [STOP] --, else plain fill-in-the-middle ([PREFIX] ...) with
+    probability p_fim, the raw [SMILES]...[STOP] row for the encoder pass (optionally of a permuted SMILES), oversize
+    fallback to the un-augmented row, failure rows (all-[PAD] `tokens`, [STOP][PAD]... `raw_tokens`), then the
+    tensorisation tail (tensorize_batch below).
+
+    The draws come from `rng` (default: the `random` module) in the reference's order, so a seeded run reproduces the
+    reference's batch.  rdkit is not a dependency: `canon_smiles` (Chem.CanonSmiles in the reference), `permute_smiles`
+    and `adj_mat_to_tokens` are injected callables; canonicalisation defaults to the identity, the other two are needed
+    only when p_randsmiles > 0 / a graph representation is drawn."""
+    import random as _random
+    import numpy as np
+    rng = rng or _random
+    for need in ("smiles", "source_collection", "atoms", "coords"):
+        assert need in batch
+    canon = canon_smiles or (lambda s: s)
+    n_seq = tokenizer.n_seq
+    enc = lambda text: tokenizer.tokenize_text(text, pad=False, range_check=False)   # noqa: E731
+    tok_rows, raw_rows = [], []
+
+    def fail_row():
+        r = np.zeros(n_seq, dtype=np.int64)
+        r[0] = tokenizer.stop_token
+        raw_rows.append(r)
+        tok_rows.append(np.zeros(n_seq, dtype=np.int64))
+
+    def padded(ids):
+        r = np.zeros(n_seq, dtype=np.int64)
+        r[: len(ids)] = ids
+        return r
+
+    for k, smi_in in enumerate(batch["smiles"]):
+        smi = canon(smi_in)
+        try:
+            # -- which representations, in which order (three draws, then one shuffle) --
+            reps = ["smiles"]
+            if rng.random() < p_dataset and "[" + batch["source_collection"][k] + "]" in tokenizer.special_tokens:
+                reps.append("set")
+            if rng.random() < p_formula:
+                reps.append("formula")
+            if rng.random() < p_graph and "adj_mat" in batch and "adj_mat_atoms" in batch:
+                reps.append("graph")
+            rng.shuffle(reps)
+            parts = {"set": lambda: "[SET][" + batch["source_collection"][k] + "]", "smiles": lambda: "[SMILES]" + smi,
+                     "formula": lambda: _formula_text(batch["atoms"][k]),
+                     "graph": lambda: adj_mat_to_tokens(batch["adj_mat"][k], batch["adj_mat_atoms"][k])}
+            ids = enc("".join(parts[r]() for r in reps) + "[STOP]")
+            # -- [CLIP][UNK] prefix / fill-in-the-middle --
+            if rng.random() < p_clip and len(ids) > 3:
+                if rng.random() < p_clip_cut:
+                    stop = ids.pop()
+                    m, sfx = _two_cut_points(rng, 2, len(ids))      # never inside the first two tokens
+                    ids = enc("[CLIP][UNK]") + ids[:m] + enc("[SUFFIX]") + ids[sfx:] + enc("[MIDDLE]") + ids[m:sfx] + [stop]
+                else:
+                    ids = enc("[CLIP][UNK]") + ids
+            elif rng.random() < p_fim and len(ids) > 4:
+                stop = ids.pop()
+                m, sfx = _two_cut_points(rng, 1, len(ids))
+                ids = enc("[PREFIX]") + ids[:m] + enc("[SUFFIX]") + ids[sfx:] + enc("[MIDDLE]") + ids[m:sfx] + [stop]
+            # -- the encoder pass's row --
+            plain = None
+            if rng.random() < p_randsmiles:
+                if permute_smiles is None:
+                    raise RuntimeError("p_randsmiles > 0 needs a permute_smiles callable (rdkit is not a dependency)")
+                raw_ids = enc("[SMILES]" + permute_smiles(smi) + "[STOP]")
+                plain = enc("[SMILES]" + smi + "[STOP]")
+            else:
+                raw_ids = enc("[SMILES]" + smi + "[STOP]")
+                plain = raw_ids
+            if len(ids) <= n_seq and len(raw_ids) <= n_seq:
+                tok_rows.append(padded(ids)); raw_rows.append(padded(raw_ids))
+            elif len(raw_ids) <= n_seq and len(plain) <= n_seq:
+                tok_rows.append(padded(plain)); raw_rows.append(padded(raw_ids))      # oversize: fall back to the plain row
+            else:
+                fail_row()
+                print("Too much seq data.", "[SMILES]" + smi + "[STOP]", len(raw_ids))
+        except Exception as ex:
+            print("Tokenize failure:", smi, " Except:", ex)
+            fail_row()
+    out = batch
+    out["tokens"] = torch.from_numpy(np.stack(tok_rows, 0)).to(device)
+    out["raw_tokens"] = torch.from_numpy(np.stack(raw_rows, 0)).to(device)
+    return tensorize_batch(out, tokenizer, dtype=dtype, device=device, coord_noise=coord_noise, inplace=True)
+
+
+def tensorize_batch(batch: Dict[str, Any], tokenizer, dtype=torch.float, device="cpu", coord_noise=False, inplace=False):
     """The tensorisation tail of clip_ar_xform (clip_e2e.py:288-330): given stacked `tokens` / `raw_tokens`
     ([B, n_seq] long) plus atoms/coords arrays, move to `device`, truncate columns to the longest row, build y_next
-    with the five masked special ids.  The SMILES augmentation + tokenisation head of clip_ar_xform needs rdkit and the
-    reference vocabularies and is out of scope."""
-    out = dict(batch)
+    with the five masked special ids.  (`batch_pipe.device_tail` is the same tail as two HIP kernels.)"""
+    out = batch if inplace else dict(batch)
     for col in ("tokens", "atoms", "raw_tokens"):
         if not isinstance(out[col], torch.Tensor):
             out[col] = torch.tensor(out[col], requires_grad=False)

@@ -18,9 +18,12 @@ class CPU_Unpickler(pickle.Unpickler):
 
 def load_e3gnn_smiles_clip_e2e(doc_url: str, device: str = "cuda:0", freeze: bool = True, strict: bool = False,
                                old_architecture=False, override_args=None, model_type="default", print_debug=False,
-                               tokenizer_factory=None):
-    """Returns (model, tokenizer).  `tokenizer_factory(vocab_name, n_seq)` builds the tokenizer (the reference's Trie
-    tokenizer + vocabularies are not part of this package); without it the second return value is None."""
+                               tokenizer_factory=None, vocab=None):
+    """Returns (model, tokenizer) like the reference (io/coati.py:25-100).  The tokenizer is
+    TrieTokenizer(n_seq=model_kwargs["n_seq"], **get_vocab(train_args["tokenizer_vocab"])) (io/coati.py:89); the
+    vocabulary files are user data and not shipped here: `vocab` (a {"special_tokens", "smiles_tokens"} dict or the
+    path of such a JSON file) or a directory in $COATI_VOCAB_PATH holding <vocab_name>.json supplies it;
+    `tokenizer_factory(vocab_name, n_seq)` overrides the construction.  With none of them the second value is None."""
     if model_type != "default" or old_architecture:
         raise NotImplementedError("only the default e3gnn_smiles_clip_e2e architecture is implemented")
     with open(doc_url, "rb") as f_in:
@@ -33,8 +36,16 @@ def load_e3gnn_smiles_clip_e2e(doc_url: str, device: str = "cuda:0", freeze: boo
     model = e3gnn_smiles_clip_e2e(**model_kwargs)
     model.load_state_dict(state, strict=strict)
     tokenizer = None
+    vocab_name = model_doc["train_args"]["tokenizer_vocab"]
     if tokenizer_factory is not None:
-        tokenizer = tokenizer_factory(model_doc["train_args"]["tokenizer_vocab"], model_kwargs["n_seq"])
+        tokenizer = tokenizer_factory(vocab_name, model_kwargs["n_seq"])
+    else:
+        from ..encoding.tokenizers import TrieTokenizer, get_vocab, load_vocab
+        try:
+            v = load_vocab(vocab) if isinstance(vocab, str) else (vocab if vocab is not None else get_vocab(vocab_name))
+            tokenizer = TrieTokenizer(n_seq=model_kwargs["n_seq"], **v)
+        except ValueError as ex:
+            print(f"load_e3gnn_smiles_clip_e2e: no tokenizer returned ({ex})")
     if freeze:
         for p in model.parameters():
             p.requires_grad = False

@@ -30,6 +30,57 @@ def serialize_model(train_args, dataset_summary, model_state_dict, model_kwargs,
     return d
 
 
+def _param_names(state_dict_keys):
+    """names of the parameters in model.parameters() order = the state_dict key order minus the buffers"""
+    keys = [(k[7:] if k.startswith("module.") else k) for k in state_dict_keys]
+    return [k for k in keys if not k.endswith(".attn.bias")]
+
+
+def optimizer_state_dict(eng, lr, weight_decay, betas=(0.9, 0.99), eps=1e-8):
+    """The flat AdamW moments as a torch.optim.AdamW.state_dict() (what the reference pickles, train_coati.py:296,433):
+    per-parameter {step, exp_avg, exp_avg_sq} indexed in model.parameters() order + one param_group.  Parameters that
+    never receive a gradient (coord_mlp) have no state entry, as in torch."""
+    from ..models.encoding.clip_e2e import reference_parameter_order
+    names = reference_parameter_order(list(eng.layout))
+    state = {}
+    for i, n in enumerate(names):
+        if "coord_mlp" in n or eng.step_count == 0:
+            continue
+        state[i] = {"step": torch.tensor(float(eng.step_count)), "exp_avg": eng.view(n, "adam_m").detach().cpu().clone(),
+                    "exp_avg_sq": eng.view(n, "adam_v").detach().cpu().clone()}
+    group = {"lr": lr, "betas": tuple(betas), "eps": eps, "weight_decay": weight_decay, "amsgrad": False, "maximize": False,
+             "foreach": None, "capturable": False, "differentiable": False, "fused": None, "decoupled_weight_decay": True,
+             "params": list(range(len(names)))}
+    return {"state": state, "param_groups": [group]}
+
+
+def load_optimizer_state(eng, opt_state, state_dict_keys):
+    """--resume_optimizer: map a torch.optim.AdamW.state_dict() written by the reference (or by optimizer_state_dict
+    above) into the flat m / v buffers; parameter index i <-> i-th parameter name of the checkpoint's state_dict.
+    (The first-round private {"flat": ...} form is still read.)"""
+    if "flat" in opt_state:
+        eng.adam_m.copy_(opt_state["flat"]["m"].to(eng.device)); eng.adam_v.copy_(opt_state["flat"]["v"].to(eng.device))
+        eng.step_count = int(opt_state["flat"]["step"])
+        return
+    names = _param_names(state_dict_keys)
+    order = [i for g in opt_state["param_groups"] for i in g["params"]]
+    if len(order) != len(names):
+        raise ValueError(f"optimizer state covers {len(order)} parameters, the checkpoint's state_dict has {len(names)}")
+    eng.adam_m.zero_(); eng.adam_v.zero_()
+    steps = set()
+    for pos, idx in enumerate(order):
+        st = opt_state["state"].get(idx)
+        if st is None:
+            continue
+        n = names[pos]
+        eng.view(n, "adam_m").copy_(st["exp_avg"].to(eng.device, torch.float32))
+        eng.view(n, "adam_v").copy_(st["exp_avg_sq"].to(eng.device, torch.float32))
+        steps.add(int(float(st["step"])))
+    if len(steps) > 1:
+        raise ValueError(f"per-parameter step counts differ ({sorted(steps)}): the flat AdamW kernel keeps one step count")
+    eng.step_count = steps.pop() if steps else 0
+
+
 def do_args(argv=None):
     """train_coati.py:442-580, flag for flag."""
     p = argparse.ArgumentParser(description="token_transformer")
@@ -153,17 +204,18 @@ def train_autoencoder(gpu, args, dataset=None, tokenizer=None):
         if args.load_transformer_only:
             sd = {k: v for k, v in sd.items() if k.split(".")[0] in ("xformer", "smiles_to_clip")}
         model.load_state_dict(sd, strict=False)
-        if args.resume_optimizer and isinstance(doc.get("optimizer"), dict) and "flat" in doc["optimizer"]:
-            eng.adam_m.copy_(doc["optimizer"]["flat"]["m"].to(device))
-            eng.adam_v.copy_(doc["optimizer"]["flat"]["v"].to(device))
-            eng.step_count = doc["optimizer"]["flat"]["step"]
+        if args.resume_optimizer:
+            try:
+                load_optimizer_state(eng, doc["optimizer"], list(doc["model"].keys()))
+            except Exception as Ex:          # train_coati.py:193-198: a checkpoint without usable optimizer state still resumes
+                print("failed to resume optimizer", Ex)
         print("Loaded from checkpoint. ")
     if world > 1:   # DDP's constructor broadcast: every replica starts from rank 0's weights
         dist.broadcast(eng.params, src=0)
         eng.refresh_shadows()
 
     def optimizer_state():
-        return {"flat": {"m": eng.adam_m.cpu(), "v": eng.adam_v.cpu(), "step": eng.step_count}}
+        return optimizer_state_dict(eng, lr=lr_at(0), weight_decay=float(args.weight_decay))
 
     def lr_at(epoch):   # CosineAnnealingLR(T_max=n_epochs), stepped once per epoch (train_coati.py:152, 381)
         return 0.5 * args.lr * (1.0 + math.cos(math.pi * epoch / max(args.n_epochs, 1)))

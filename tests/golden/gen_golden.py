@@ -236,6 +236,21 @@ def main():
             out.update(step_gradnorm=gn)
         opt.step()
         losses.append(float(loss))
+        if step == 0:
+            # n1: a checkpoint document written by the reference's own serialize_model (train_coati.py:37-57) right after
+            # its first optimizer step: state_dict incl. the attn.bias buffers + torch.optim.AdamW.state_dict()
+            import copy
+            import contextlib
+            import io
+            from coati.training.train_coati import serialize_model as ref_serialize
+            with contextlib.redirect_stdout(io.StringIO()):
+                doc = ref_serialize(train_args={"tokenizer_vocab": "golden_synth", "lr": 5e-4, "weight_decay": 0.1, "n_seq": 24},
+                                    dataset_summary={"dataset_type": "golden"}, model_state_dict=copy.deepcopy(model.state_dict()),
+                                    model_kwargs=dict(SMALL), optimizer_state_dict=copy.deepcopy(opt.state_dict()),
+                                    n_toks_processed=123, n_grads_processed=5,
+                                    offline_loss={"batch_losses": [], "ar_losses": [], "clip_losses": []})
+            with open(os.path.join(OUT, "ref_checkpoint_after1.pkl"), "wb") as f:
+                f.write(doc)
         if step in (0, 2):
             sdn = {k: v.clone() for k, v in model.state_dict().items() if not k.endswith(".attn.bias")}
             np.savez_compressed(os.path.join(OUT, f"small_model_after{step + 1}.npz"), **npify(sdn))
@@ -356,10 +371,78 @@ def main():
     with open(os.path.join(OUT, "tokenizer.json"), "w") as f:
         json.dump(dict(special=spec, smiles=smi_vocab, n_seq=32, cases=tcases, batch_tokens=bs.tolist(), batch_bad=bad,
                        decoded=dec, trie_cases=scases), f)
+    _clip_ar_xform_cases()
+    _loss_curve()
     # ---- G14 AllGatherFunction forward/backward under a 2-rank gloo group (autograd_funs.py:5-25) ----
     import torch.multiprocessing as mp
     mp.spawn(_allgather_worker, args=(2,), nprocs=2)
     print("golden vectors written to", OUT)
+
+
+def _clip_ar_xform_cases():
+    """a17: clip_ar_xform (clip_e2e.py:50-330) end to end on a synthetic vocabulary (CanonSmiles stubbed to the identity,
+    p_randsmiles = 0): dataset / formula prefixes, the [CLIP][UNK] prefix with and without the cut form, plain
+    fill-in-the-middle, a row that fails to tokenise, an oversize row, and the oversize fallback to the plain row."""
+    import contextlib
+    import io
+    spec = ["[PAD]", "[STOP]", "[SMILES]", "[GRAPH]", "[FORMULA]", "[SUFFIX]", "[MIDDLE]", "[UNK]", "[CLIP]", "[SET]",
+            "[PREFIX]", "[geom_drugs]", "[ELM1]", "[ELM6]", "[ELM7]", "[ELM8]"] + [f"[NUM{i}]" for i in range(1, 13)]
+    smi_vocab = ["C", "c", "N", "n", "O", "o", "(", ")", "=", "#", "1", "2", "Cl", "Br", "c1ccccc1", "C(=O)", "CC", "[nH]",
+                 "[C@@H]", "[C@H]", "N(C)", "c1", "cc", "[NH3+]", "S", "F", "OC", "C(=O)O"]
+    smiles = ["c1ccccc1", "CC(=O)O", "CCN(CC)CC", "CxC", "c1ccc2ccccc2c1O", "C" * 50, "C[C@@H](N)C(=O)O", "BrCCCl", "N", "CCOC(=O)c1ccccc1"]
+    atoms = np.array([[6, 6, 8, 1, 1, 0], [6, 6, 8, 8, 0, 0], [6, 7, 6, 6, 1, 1], [6, 6, 0, 0, 0, 0], [6, 6, 8, 6, 6, 6],
+                      [6, 6, 6, 6, 6, 6], [6, 7, 8, 8, 1, 0], [6, 6, 6, 1, 1, 1], [7, 1, 1, 1, 0, 0], [6, 8, 8, 6, 6, 1]])
+    coll = ["geom_drugs", "x", "geom_drugs", "x", "geom_drugs", "geom_drugs", "x", "geom_drugs", "x", "geom_drugs"]
+    cases = []
+    for name, seed, n_seq, kw in (
+            ("clip_mixed", 5, 40, dict(p_dataset=0.5, p_formula=0.5, p_fim=0.0, p_graph=0.3, p_clip=0.9, p_clip_cut=0.3)),
+            ("fim_only", 6, 40, dict(p_dataset=0.2, p_formula=0.0, p_fim=0.7, p_graph=0.0, p_clip=0.0, p_clip_cut=0.3)),
+            ("clip_cut_always_short_rows", 7, 14, dict(p_dataset=0.9, p_formula=0.9, p_fim=0.0, p_graph=0.0, p_clip=1.0, p_clip_cut=1.0)),
+            ("plain", 8, 40, dict(p_dataset=0.0, p_formula=0.0, p_fim=0.0, p_graph=0.0, p_clip=0.0, p_clip_cut=0.0))):
+        tk = TrieTokenizer(n_seq=n_seq, smiles_tokens=smi_vocab, special_tokens=spec)
+        random.seed(seed)
+        bt = {"smiles": np.array(smiles, dtype=object), "source_collection": np.array(coll, dtype=object),
+              "atoms": atoms.copy(), "coords": np.zeros((len(smiles), atoms.shape[1], 3))}
+        with contextlib.redirect_stdout(io.StringIO()):
+            res = ref_clip.clip_ar_xform(bt, tk, p_randsmiles=0.0, **kw)
+        cases.append(dict(name=name, seed=seed, n_seq=n_seq, kwargs=kw, tokens=res["tokens"].tolist(),
+                          raw_tokens=res["raw_tokens"].tolist(), y_next=res["y_next"].tolist()))
+    with open(os.path.join(OUT, "clip_ar_xform.json"), "w") as f:
+        json.dump(dict(special=spec, smiles_tokens=smi_vocab, smiles=smiles, atoms=atoms.tolist(), source_collection=coll,
+                       cases=cases), f)
+
+
+def _loss_curve(n_steps=40):
+    """north_star "loss-curve equivalent to reference": 40 optimiser steps of the reference (forward_dist + AR CE +
+    InfoNCE * log2 V + backward + clip_grad_norm_(10) + AdamW(lr 2e-3, wd 0.1, betas (0.9, 0.99))) cycling over four
+    different batches, from the weights of small_model.npz; per-step loss / ar / clip / grad-norm."""
+    torch.manual_seed(1)
+    model = ref_clip.e3gnn_smiles_clip_e2e(**SMALL)
+    z = np.load(os.path.join(OUT, "small_model.npz"))
+    model.load_state_dict({k: torch.from_numpy(z[k]) for k in z.files}, strict=False)
+    tokz = Tok(48, 24)
+    cl = ref_clip.clip_loss()
+    teu = float(np.log(float(48)) / np.log(2.0))
+    batches = []
+    for i in range(4):
+        raw, tok, atoms, coords = synth_batch(6, 16, 8, 48, seed=300 + i, bad_row=(i == 2), far_atom=False)
+        batches.append(dict(raw_tokens=raw, tokens=tok, atoms=atoms, coords=coords, y_next=y_next(tok)))
+    opt = torch.optim.AdamW(model.parameters(), lr=2e-3, weight_decay=0.1, betas=(0.9, 0.99), eps=1e-8)
+    rec = dict(loss=[], ar=[], clip=[], gradnorm=[])
+    for step in range(n_steps):
+        b = batches[step % 4]
+        opt.zero_grad()
+        he, hs, lg, bad = model.forward_dist(b["raw_tokens"], b["tokens"], b["atoms"], b["coords"], tokz, p_clip_emb_smi=0.0)
+        ar = torch.nn.functional.cross_entropy(lg.view(-1, lg.size(-1)), b["y_next"].view(-1), ignore_index=-1)
+        c = cl(hs, he, bad).mean()
+        loss = ar + c * teu
+        loss.backward()
+        gn = torch.nn.utils.clip_grad_norm_(model.parameters(), 10.0)
+        opt.step()
+        rec["loss"].append(float(loss)); rec["ar"].append(float(ar)); rec["clip"].append(float(c)); rec["gradnorm"].append(float(gn))
+    out = {f"b{i}_{k}": v for i, b in enumerate(batches) for k, v in b.items()}
+    out.update({k: np.array(v, dtype=np.float64) for k, v in rec.items()})
+    np.savez_compressed(os.path.join(OUT, "loss_curve.npz"), **npify(out))
 
 
 def _allgather_worker(rank, world):

@@ -117,3 +117,48 @@ def test_device_batch_tail_matches_reference_golden(golden_dir):
                             "coords": torch.zeros(B, 4, 3)}, Tk, device="cpu")
     t, r, y = device_tail(tok.to(DEV), raw.to(DEV), Tk)
     assert torch.equal(t.cpu(), host["tokens"]) and torch.equal(r.cpu(), host["raw_tokens"]) and torch.equal(y.cpu(), host["y_next"])
+
+
+def test_reference_written_checkpoint_loads_and_resumes(golden_dir):
+    """n1 against a document the REFERENCE wrote (ref_checkpoint_after1.pkl: its serialize_model + torch AdamW state,
+    right after its first optimizer step): (i) the loader returns (model, TrieTokenizer) with exactly those weights and
+    the model reproduces the reference's next loss; (ii) --resume_optimizer semantics: the per-parameter AdamW state
+    mapped into the flat m / v lets the next two steps follow the reference's steps 2 and 3."""
+    import json
+    from coati.models.io.coati import load_e3gnn_smiles_clip_e2e, CPU_Unpickler
+    from coati.models.encoding.tokenizers.trie_tokenizer import TrieTokenizer
+    from coati.training.train_coati import load_optimizer_state
+    path = os.path.join(golden_dir, "ref_checkpoint_after1.pkl")
+    with open(os.path.join(golden_dir, "clip_ar_xform.json")) as f:
+        g = json.load(f)
+    model, tok = load_e3gnn_smiles_clip_e2e(path, device="cuda:0", freeze=False,
+                                            vocab={"special_tokens": g["special"], "smiles_tokens": g["smiles_tokens"]})
+    assert isinstance(tok, TrieTokenizer) and tok.n_seq == 24 and tok.stop_token == 1 and tok.vocab["[UNK]"] == 7
+    A1 = np.load(os.path.join(golden_dir, "small_model_after1.npz"))
+    sd = model.state_dict()
+    for k in A1.files:
+        assert torch.equal(sd[k].cpu(), torch.from_numpy(A1[k])), k
+    v = np.load(os.path.join(golden_dir, "small_vectors.npz"))
+    batch = {k: torch.from_numpy(v["b_" + k]).to(DEV) for k in ("raw_tokens", "tokens", "atoms", "coords", "y_next")}
+    up = torch.ones(batch["atoms"].shape[0], dtype=torch.bool, device=DEV)
+    eng = model.engine
+    with open(path, "rb") as f:
+        doc = CPU_Unpickler(f, encoding="UTF-8").load()
+    load_optimizer_state(eng, doc["optimizer"], list(doc["model"].keys()))
+    assert eng.step_count == 1
+    losses = []
+    for _ in range(2):
+        eng.train_step(batch, up, lr=5e-4, weight_decay=0.1, max_norm=10.0)
+        losses.append(eng.losses()["loss"])
+    log(f"resumed from the reference's checkpoint: losses {losses} reference {v['step_losses'][1:3].tolist()}")
+    check("resumed loss curve (reference steps 2, 3)", torch.tensor(losses), torch.from_numpy(v["step_losses"][1:3]).float(), 2e-3)
+    A3 = np.load(os.path.join(golden_dir, "small_model_after3.npz"))
+    sd = model.state_dict()
+    for k in A1.files:
+        a1, a3 = torch.from_numpy(A1[k]), torch.from_numpy(A3[k])
+        if "coord_mlp" in k:
+            assert torch.equal(sd[k].cpu(), a3) and torch.equal(a1, a3), k     # never touched, on either side
+            continue
+        d_hip, d_ref = (sd[k].cpu() - a1).flatten().double(), (a3 - a1).flatten().double()
+        cos = float((d_hip @ d_ref) / (d_hip.norm() * d_ref.norm() + 1e-30))
+        assert cos > 0.9, (k, cos)

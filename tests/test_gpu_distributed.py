@@ -143,7 +143,8 @@ def test_two_process_barlow_distributed_equals_global_batch(tmp_path):
     eng = _global_run("barlow")
     bl = float(eng.barlow_loss)
     log(f"two-process Barlow: global-batch loss {bl:.6f}; ranks report {float(r[0]['barlow']):.6f} / {float(r[1]['barlow']):.6f}")
-    assert abs(float(r[0]["barlow"]) - bl) <= 2e-5 * max(1.0, abs(bl)) and float(r[0]["barlow"]) == float(r[1]["barlow"])
+    # (the loss scalar is an atomically accumulated fp32 sum: the two ranks agree to rounding, not bit for bit)
+    assert abs(float(r[0]["barlow"]) - bl) <= 2e-5 * max(1.0, abs(bl)) and abs(float(r[0]["barlow"]) - float(r[1]["barlow"])) <= 1e-6 * abs(bl)
     _compare_grads(eng, r[0]["grads"], 5e-2, "two-process Barlow step")
 
 
