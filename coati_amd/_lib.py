@@ -57,6 +57,7 @@ _SIGS = {
     "coati_infonce_rows": [P, L, I, I, I, P, P, P, F, P],
     "coati_count_valid": [P, I, P, P, P],
     "coati_colsum2": [P, P, P, P, I, I, P],
+    "coati_center_rows": [P, P, P, P, P, I, I, P],
     "coati_standardize": [P, P, P, P, P, P, I, I, P],
     "coati_barlow_dc": [P, P, F, P, I, P],
     "coati_standardize_bwd": [P, P, P, P, P, P, F, P, I, I, P],

@@ -2,7 +2,8 @@
 
 The reference repository holds no Barlow code (only checkpoint names), so this follows the Barlow-Twins formulation;
 parity is UNPINNED and the only check is the oracle's own restatement (oracle.barlow_loss).  Exchange pattern at
-world size > 1: all-reduce of the per-dimension batch statistics (2 x 2E floats), of the E x E
+world size > 1: all-reduce of the per-dimension batch statistics (2 x 2E floats, twice: mean, then
+centred second moment), of the E x E
 cross-correlation matrix, and of the 2 x 2E backward statistics -- no embedding all-gather is needed."""
 import torch
 
@@ -26,16 +27,26 @@ def barlow_head(h_s: torch.Tensor, h_e: torch.Tensor, bad: torch.Tensor, lam: fl
     bad = bad.to(torch.uint8).contiguous()
     cnt = torch.zeros(2, **f32)
     _lib.call("coati_count_valid", ptr(bad), B, ptr(cnt[0:1]), ptr(cnt[1:2]), stream())
+    # two-pass batch statistics: global mean first, then the variance of the CENTRED rows (E[z^2] - E[z]^2 loses the
+    # variance to cancellation when |mean| >> sigma; the result then depended on how many ranks the sums were split over)
     stats = torch.empty(2, 2 * E, **f32)
     _lib.call("coati_colsum2", ptr(h_s), None, ptr(bad), ptr(stats[0]), B, E, stream())
     _lib.call("coati_colsum2", ptr(h_e), None, ptr(bad), ptr(stats[1]), B, E, stream())
     if distributed:
         _all_reduce(stats)
         _all_reduce(cnt[0:1])
+    cs, ce = torch.empty(B, E, **f32), torch.empty(B, E, **f32)
+    _lib.call("coati_center_rows", ptr(h_s), ptr(bad), ptr(stats[0]), ptr(cnt), ptr(cs), B, E, stream())
+    _lib.call("coati_center_rows", ptr(h_e), ptr(bad), ptr(stats[1]), ptr(cnt), ptr(ce), B, E, stream())
+    stats2 = torch.empty(2, 2 * E, **f32)
+    _lib.call("coati_colsum2", ptr(cs), None, ptr(bad), ptr(stats2[0]), B, E, stream())
+    _lib.call("coati_colsum2", ptr(ce), None, ptr(bad), ptr(stats2[1]), B, E, stream())
+    if distributed:
+        _all_reduce(stats2)
     zs, ze = torch.empty(B, E, **f32), torch.empty(B, E, **f32)
     rs = torch.empty(2, E, **f32)
-    _lib.call("coati_standardize", ptr(h_s), ptr(bad), ptr(stats[0]), ptr(cnt), ptr(zs), ptr(rs[0]), B, E, stream())
-    _lib.call("coati_standardize", ptr(h_e), ptr(bad), ptr(stats[1]), ptr(cnt), ptr(ze), ptr(rs[1]), B, E, stream())
+    _lib.call("coati_standardize", ptr(cs), ptr(bad), ptr(stats2[0]), ptr(cnt), ptr(zs), ptr(rs[0]), B, E, stream())
+    _lib.call("coati_standardize", ptr(ce), ptr(bad), ptr(stats2[1]), ptr(cnt), ptr(ze), ptr(rs[1]), B, E, stream())
     C = sgemm(zs, ze, trans_a=True)                      # [E,E] raw cross-correlation of the local rows
     if distributed:
         _all_reduce(C)

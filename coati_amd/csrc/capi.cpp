@@ -162,6 +162,9 @@ int coati_count_valid(const uint8_t* bad, int n, float* count, float* inv, void*
 int coati_colsum2(const float* a, const float* b2, const uint8_t* bad, float* out, int B, int E, void* stream) {
   return launch_colsum2(a, b2, bad, out, B, E, S_(stream));
 }
+int coati_center_rows(const float* z, const uint8_t* bad, const float* sum, const float* count, float* zc, int B, int E, void* stream) {
+  return launch_center_rows(z, bad, sum, count, zc, B, E, S_(stream));
+}
 int coati_standardize(const float* z, const uint8_t* bad, const float* stats, const float* count, float* zt, float* rsigma,
                       int B, int E, void* stream) {
   return launch_standardize(z, bad, stats, count, zt, rsigma, B, E, S_(stream));

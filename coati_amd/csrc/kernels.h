@@ -212,6 +212,7 @@ int launch_infonce_rows(float* logits, long long ld, int R, int N, int label0, c
 int launch_count_valid(const unsigned char* bad, int n, float* out_count, float* out_inv, hipStream_t s);
 // Barlow-Twins head pieces (loss.hip)
 int launch_colsum2(const float* a, const float* b2, const unsigned char* bad, float* out, int B, int E, hipStream_t s);
+int launch_center_rows(const float* z, const unsigned char* bad, const float* sum, const float* count, float* zc, int B, int E, hipStream_t s);
 int launch_standardize(const float* z, const unsigned char* bad, const float* stats, const float* count, float* zt, float* rsigma,
                        int B, int E, hipStream_t s);
 int launch_barlow_dc(float* C, const float* count, float lam, float* loss, int E, hipStream_t s);

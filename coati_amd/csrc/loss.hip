@@ -161,6 +161,24 @@ int launch_colsum2(const float* a, const float* b2, const unsigned char* bad, fl
   return COATI_OK;
 }
 
+// zc = keep * (z - sum[c] / n): the first of two passes over the batch statistics.  The variance is then taken from the
+// CENTRED rows (sumsq of zc), not as E[z^2] - E[z]^2: with |mean| >> sigma the one-pass form loses the variance to
+// cancellation, and the summation order of the partial sums (1 rank vs N ranks) then shows up at 1e-4 in the gradients.
+__global__ void center_rows_kernel(const float* __restrict__ z, const unsigned char* __restrict__ bad, const float* __restrict__ sum,
+                                   const float* __restrict__ count, float* __restrict__ zc, int B, int E) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)B * E) return;
+  const int c = (int)(i % E), r = (int)(i / E);
+  zc[i] = bad[r] ? 0.f : z[i] - sum[c] / fmaxf(count[0], 1.f);
+}
+int launch_center_rows(const float* z, const unsigned char* bad, const float* sum, const float* count, float* zc, int B, int E,
+                       hipStream_t s) {
+  COATI_CHECK_ARG(z && bad && sum && count && zc, "center_rows: null operand");
+  hipLaunchKernelGGL(center_rows_kernel, dim3(cdiv((long long)B * E, 256)), dim3(256), 0, s, z, bad, sum, count, zc, B, E);
+  COATI_LAUNCH_CHECK("center_rows");
+  return COATI_OK;
+}
+
 // stats = [sum | sumsq] over the global valid rows, count[0] = n.  zt = keep (z - mu) * rsigma ; rsigma[c] written.
 __global__ void standardize_kernel(const float* __restrict__ z, const unsigned char* __restrict__ bad, const float* __restrict__ stats,
                                    const float* __restrict__ count, float* __restrict__ zt, float* __restrict__ rsigma, int B, int E) {

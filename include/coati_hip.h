@@ -171,6 +171,9 @@ int coati_infonce_rows(float* logits, int64_t ld, int R, int N, int label0, cons
  *   coati_standardize_bwd: batch-norm style backward of the standardisation, times `scale` */
 int coati_count_valid(const uint8_t* bad, int n, float* count, float* inv, void* stream);
 int coati_colsum2(const float* a, const float* b2, const uint8_t* bad, float* out, int B, int E, void* stream);
+/* zc = keep (z - sum/n): first pass of the two-pass batch statistics (variance from the centred rows) */
+int coati_center_rows(const float* z, const uint8_t* bad, const float* sum, const float* count, float* zc, int B, int E,
+                      void* stream);
 int coati_standardize(const float* z, const uint8_t* bad, const float* stats, const float* count, float* zt, float* rsigma,
                       int B, int E, void* stream);
 int coati_barlow_dc(float* C, const float* count, float lam, float* loss, int E, void* stream);

@@ -6,7 +6,12 @@ sees the reference.  rdkit / boto3 are absent, so import-time-only stubs are ins
 into sys.modules (SURVEY.md section 8c recipe).  Output: small .npz/.json fixtures (data
 only: inputs, weights and the reference's outputs).
 
-    python tests/golden/gen_golden.py
+    python tests/golden/gen_golden.py             # (re)write the fixtures
+    python tests/golden/gen_golden.py --verify    # regenerate into a temp dir and compare CONTENTS with the committed ones
+
+Every .npz / .json is byte-reproducible.  ref_checkpoint_after1.pkl is not: torch's pickle format names each storage by
+its memory address, so the file's bytes change from run to run while the unpickled document is identical (--verify
+compares the loaded tensors).
 """
 import json
 import os
@@ -18,7 +23,8 @@ import numpy as np
 import torch
 
 REF = "/root/reference"
-OUT = os.path.dirname(os.path.abspath(__file__))
+HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.environ.get("GOLDEN_OUT", HERE)
 
 
 def _stub_modules():
@@ -414,8 +420,9 @@ def _clip_ar_xform_cases():
 
 def _loss_curve(n_steps=40):
     """north_star "loss-curve equivalent to reference": 40 optimiser steps of the reference (forward_dist + AR CE +
-    InfoNCE * log2 V + backward + clip_grad_norm_(10) + AdamW(lr 2e-3, wd 0.1, betas (0.9, 0.99))) cycling over four
-    different batches, from the weights of small_model.npz; per-step loss / ar / clip / grad-norm."""
+    InfoNCE * log2 V + backward + clip_grad_norm_(10) + AdamW(lr 5e-4, wd 0.1, betas (0.9, 0.99)): train_grande.py's
+    optimiser settings) cycling over eight different batches of 12 molecules, from the weights of small_model.npz;
+    per-step loss / ar / clip / grad-norm."""
     torch.manual_seed(1)
     model = ref_clip.e3gnn_smiles_clip_e2e(**SMALL)
     z = np.load(os.path.join(OUT, "small_model.npz"))
@@ -424,13 +431,13 @@ def _loss_curve(n_steps=40):
     cl = ref_clip.clip_loss()
     teu = float(np.log(float(48)) / np.log(2.0))
     batches = []
-    for i in range(4):
-        raw, tok, atoms, coords = synth_batch(6, 16, 8, 48, seed=300 + i, bad_row=(i == 2), far_atom=False)
+    for i in range(8):
+        raw, tok, atoms, coords = synth_batch(12, 16, 8, 48, seed=300 + i, bad_row=(i == 2), far_atom=False)
         batches.append(dict(raw_tokens=raw, tokens=tok, atoms=atoms, coords=coords, y_next=y_next(tok)))
-    opt = torch.optim.AdamW(model.parameters(), lr=2e-3, weight_decay=0.1, betas=(0.9, 0.99), eps=1e-8)
+    opt = torch.optim.AdamW(model.parameters(), lr=5e-4, weight_decay=0.1, betas=(0.9, 0.99), eps=1e-8)
     rec = dict(loss=[], ar=[], clip=[], gradnorm=[])
     for step in range(n_steps):
-        b = batches[step % 4]
+        b = batches[step % 8]
         opt.zero_grad()
         he, hs, lg, bad = model.forward_dist(b["raw_tokens"], b["tokens"], b["atoms"], b["coords"], tokz, p_clip_emb_smi=0.0)
         ar = torch.nn.functional.cross_entropy(lg.view(-1, lg.size(-1)), b["y_next"].view(-1), ignore_index=-1)
@@ -461,5 +468,43 @@ def _allgather_worker(rank, world):
     dist.destroy_process_group()
 
 
+def _same(a, b):
+    if isinstance(a, torch.Tensor):
+        return isinstance(b, torch.Tensor) and a.dtype == b.dtype and torch.equal(a, b)
+    if isinstance(a, dict):
+        return isinstance(b, dict) and list(a.keys()) == list(b.keys()) and all(_same(a[k], b[k]) for k in a)
+    if isinstance(a, (list, tuple)):
+        return type(a) == type(b) and len(a) == len(b) and all(_same(x, y) for x, y in zip(a, b))
+    return a == b
+
+
+def verify():
+    """regenerate into a scratch directory (GOLDEN_OUT) in a child process and compare contents with the committed fixtures"""
+    import pickle
+    import subprocess
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        subprocess.run([sys.executable, os.path.abspath(__file__)], env=dict(os.environ, GOLDEN_OUT=tmp), check=True,
+                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        bad = []
+        for f in sorted(os.listdir(tmp)):
+            a, b = os.path.join(tmp, f), os.path.join(HERE, f)
+            if f.endswith(".npz"):
+                x, y = np.load(a), np.load(b)
+                ok = x.files == y.files and all(np.array_equal(x[k], y[k]) and x[k].dtype == y[k].dtype for k in x.files)
+            elif f.endswith(".pkl"):
+                ok = _same(pickle.load(open(a, "rb")), pickle.load(open(b, "rb")))
+            else:
+                ok = open(a, "rb").read() == open(b, "rb").read()
+            print(("same     " if ok else "DIFFERENT") + " " + f)
+            if not ok:
+                bad.append(f)
+        missing = [f for f in os.listdir(HERE) if f.endswith((".npz", ".json", ".pkl")) and f not in os.listdir(tmp)]
+        print("fixtures without a generator:", missing)
+        return not bad and not missing
+
+
 if __name__ == "__main__":
+    if "--verify" in sys.argv:
+        sys.exit(0 if verify() else 1)
     main()
