@@ -37,11 +37,11 @@ def test_model_mirror_against_golden(golden_dir):
     assert model.embed_dim == 64 and hasattr(model, "point_encoder") and hasattr(model, "smiles_to_clip")
     b = {k: torch.from_numpy(v["b_" + k]) for k in ("raw_tokens", "tokens", "atoms", "coords")}
     he, hs, logits, bad = model.forward_dist(b["raw_tokens"], b["tokens"], b["atoms"], b["coords"], Tok(), p_clip_emb_smi=0.0)
-    check("api h_e3gnn", he.cpu(), torch.from_numpy(v["fd_p0_h_e3gnn"]), 3e-2)
-    check("api logits", logits.cpu(), torch.from_numpy(v["fd_p0_logits"]), 3e-2)
+    check("api h_e3gnn", he.cpu(), torch.from_numpy(v["fd_p0_h_e3gnn"]), 6.5e-3)
+    check("api logits", logits.cpu(), torch.from_numpy(v["fd_p0_logits"]), 6.5e-3)
     assert bad.dtype == torch.bool and torch.equal(bad.cpu(), torch.from_numpy(v["fd_p0_bad"]))
-    check("api encode_tokens", model.encode_tokens(b["raw_tokens"], Tok()).cpu(), torch.from_numpy(v["fd_p0_h_smiles"]), 3e-2)
-    check("api encode_points", model.encode_points(b["atoms"], b["coords"]).cpu(), torch.from_numpy(v["fd_p0_h_e3gnn"]), 3e-2)
+    check("api encode_tokens", model.encode_tokens(b["raw_tokens"], Tok()).cpu(), torch.from_numpy(v["fd_p0_h_smiles"]), 6.5e-3)
+    check("api encode_points", model.encode_points(b["atoms"], b["coords"]).cpu(), torch.from_numpy(v["fd_p0_h_e3gnn"]), 6.5e-3)
     a, c, badr = torch.from_numpy(v["cl_a"]), torch.from_numpy(v["cl_b"]), torch.from_numpy(v["cl_bad"])
     check("api clip_loss", model.clip_loss(a.cuda(), c.cuda(), badr.cuda()).cpu(), torch.from_numpy(v["cl_l1"]), 1e-5)
     raw_bad = b["raw_tokens"].clone()
@@ -151,7 +151,7 @@ def test_reference_written_checkpoint_loads_and_resumes(golden_dir):
         eng.train_step(batch, up, lr=5e-4, weight_decay=0.1, max_norm=10.0)
         losses.append(eng.losses()["loss"])
     log(f"resumed from the reference's checkpoint: losses {losses} reference {v['step_losses'][1:3].tolist()}")
-    check("resumed loss curve (reference steps 2, 3)", torch.tensor(losses), torch.from_numpy(v["step_losses"][1:3]).float(), 2e-3)
+    check("resumed loss curve (reference steps 2, 3)", torch.tensor(losses), torch.from_numpy(v["step_losses"][1:3]).float(), 8e-4)
     A3 = np.load(os.path.join(golden_dir, "small_model_after3.npz"))
     sd = model.state_dict()
     for k in A1.files:

@@ -28,7 +28,7 @@ def small_engine(golden_dir):
 
 def test_decode_logits_match_reference_teacher_forced(small_engine):
     """Feed the reference's generated tokens one position at a time through the KV-cached path: the logits of every
-    position must match the reference's full-sequence forward (bf16 operands vs fp32: 3e-2 of the logit scale)."""
+    position must match the reference's full-sequence forward (bf16 operands vs fp32: 7e-3 of the logit scale; 3.5e-3 measured)."""
     eng, g = small_engine
     toks = torch.from_numpy(g["gen_tokens"]).to(DEV)
     payload = torch.from_numpy(g["gen_payload"]).to(DEV)
@@ -42,7 +42,7 @@ def test_decode_logits_match_reference_teacher_forced(small_engine):
         err = float((lg.cpu() - ref[:, t]).abs().max()) / scale
         worst = max(worst, err)
     log(f"decode vs reference logits: worst relative error {worst:.3e}")
-    assert worst < 3e-2
+    assert worst < 7e-3        # measured 3.5e-3
 
 
 def test_greedy_generation_matches_reference(small_engine):

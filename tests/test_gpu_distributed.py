@@ -94,10 +94,12 @@ def _global_run(head):
     return eng
 
 
-def _compare_grads(eng, avg, tol_bad, tag):
+def _compare_grads(eng, avg, tol_bad, tag, skip=()):
     from tests.gpu_util import log
     devs, bad = [], []
     for name, (off, shape) in eng.layout.items():
+        if name.endswith(skip) and skip:
+            continue
         n = int(np.prod(shape))
         a, b_ = eng.grads[off:off + n].cpu(), torch.from_numpy(avg[off:off + n])
         scale = float(a.abs().max())
@@ -111,7 +113,7 @@ def _compare_grads(eng, avg, tol_bad, tag):
     devs.sort()
     log(f"{tag}: parameter-gradient deviation from the 2B single-process run: median {devs[len(devs) // 2]:.3e}, worst {devs[-1]:.3e}")
     assert not bad, sorted(bad, reverse=True)[:6]
-    assert devs[len(devs) // 2] < 1e-3
+    assert devs[len(devs) // 2] < 1e-5
 
 
 def test_two_process_distributed_step_equals_global_batch(tmp_path):
@@ -130,7 +132,7 @@ def test_two_process_distributed_step_equals_global_batch(tmp_path):
     # Rows are processed identically in both runs; what differs is the fp32 summation order of the InfoNCE sums (1e-7),
     # which can flip single bf16 roundings of activation gradients (a flipped element moves a heavily cancelling bias
     # column sum by a few percent of its small scale)
-    _compare_grads(eng, r[0]["grads"], 5e-2, "two-process InfoNCE step")
+    _compare_grads(eng, r[0]["grads"], 5e-3, "two-process InfoNCE step")
 
 
 def test_two_process_barlow_distributed_equals_global_batch(tmp_path):
@@ -145,7 +147,9 @@ def test_two_process_barlow_distributed_equals_global_batch(tmp_path):
     log(f"two-process Barlow: global-batch loss {bl:.6f}; ranks report {float(r[0]['barlow']):.6f} / {float(r[1]['barlow']):.6f}")
     # (the loss scalar is an atomically accumulated fp32 sum: the two ranks agree to rounding, not bit for bit)
     assert abs(float(r[0]["barlow"]) - bl) <= 2e-5 * max(1.0, abs(bl)) and abs(float(r[0]["barlow"]) - float(r[1]["barlow"])) <= 1e-6 * abs(bl)
-    _compare_grads(eng, r[0]["grads"], 5e-2, "two-process Barlow step")
+    # the biases in front of the batch standardisation have an exactly-zero true gradient (a constant shift of every
+    # embedding is removed by the centring): what both runs hold there is rounding noise, 1e-7 of the weight gradients
+    _compare_grads(eng, r[0]["grads"], 5e-3, "two-process Barlow step", skip=("_to_clip.0.bias", "_to_clip.1.bias"))
 
 
 def test_barlow_distributed_against_oracle_on_concatenated_batch():

@@ -11,14 +11,17 @@ pytestmark = pytest.mark.gpu
 from tests.gpu_util import check, log  # noqa: E402
 
 DEV = "cuda:0"
-# fp tolerance of the bf16-operand HIP path against the fp32 reference path (relative to tensor scale)
-TOL_FWD = 3e-2
-TOL_GRAD = 6e-2
+# Stated tolerances = at most 2x the worst error measured on the MI355X (round 2, gpurun_out/test_report.txt).
+# fp tolerance of the bf16-operand HIP path against the fp32 reference path (relative to tensor scale):
+TOL_FWD = 6.5e-3       # measured 3.03e-3 (logits), 2.65e-3 (h_e3gnn), 1.39e-3 (h_smiles)
+TOL_GRAD = 3.8e-2      # measured 1.88e-2 (worst parameter gradient of the golden step)
+TOL_LOSS = 1e-3        # measured 4.8e-4 (clip), 1.5e-4 (ar)
 # against the oracle with bf16 storage simulated at the same points
-TOL_FWD_SIM = 1e-2
-TOL_GRAD_SIM = 4e-2
+TOL_FWD_SIM = 6.5e-3   # measured 3.16e-3
+TOL_GRAD_SIM = 4e-2    # measured 2.67e-2 (golden), 2.55e-2 (tall), 1.66e-2 (medium)
+TOL_LOSS_SIM = 1.2e-3  # measured 5.4e-4 (tall clip); the edge-shape cases keep 5e-3 (2.8e-3 measured on a 1-valid-row batch)
 TOL_GRADNORM = 1.3e-2
-TOL_CURVE = 2e-2
+TOL_CURVE = 2.5e-3     # 40-step curve: measured 8.8e-4 (loss), 1.2e-3 (clip), 8.2e-3 (grad norm: 5x this)
 
 
 @pytest.fixture(scope="module")
@@ -80,9 +83,9 @@ def test_step_losses_and_grads(setup, golden_dir):
     eng.train_step(batch, up, lr=5e-4, optimizer=False)
     L = eng.losses()
     log(f"losses {L}")
-    check("step ar loss", torch.tensor([L["ar_loss"]]), vec["step_ar"].reshape(1), 1e-2)
-    check("step clip loss", torch.tensor([L["clip_loss"]]), vec["step_clip"].reshape(1), 1e-2)
-    check("step loss", torch.tensor([L["loss"]]), vec["step_loss"].reshape(1), 1e-2)
+    check("step ar loss", torch.tensor([L["ar_loss"]]), vec["step_ar"].reshape(1), TOL_LOSS)
+    check("step clip loss", torch.tensor([L["clip_loss"]]), vec["step_clip"].reshape(1), TOL_LOSS)
+    check("step loss", torch.tensor([L["loss"]]), vec["step_loss"].reshape(1), TOL_LOSS)
     G = np.load(os.path.join(golden_dir, "small_step_grads.npz"))
     # oracle with bf16 storage simulation for the tight comparison
     Pg = {k: v.clone().requires_grad_(True) for k, v in P.items()}
@@ -124,8 +127,8 @@ def test_three_step_loss_curve(setup, golden_dir):
         L = eng.losses()
         losses.append(L["loss"]); norms.append(L["grad_norm"])
     log(f"loss curve {losses} ref {vec['step_losses'].tolist()} gradnorm {norms} ref0 {float(vec['step_gradnorm'])}")
-    check("loss curve", torch.tensor(losses), vec["step_losses"].float(), 1e-2)
-    check("grad norm step0", torch.tensor([norms[0]]), vec["step_gradnorm"].reshape(1), 3e-2)
+    check("loss curve", torch.tensor(losses), vec["step_losses"].float(), 3.5e-3)
+    check("grad norm step0", torch.tensor([norms[0]]), vec["step_gradnorm"].reshape(1), TOL_GRADNORM)
     A3 = np.load(os.path.join(golden_dir, "small_model_after3.npz"))
     sd = eng.state_dict()
     # 3 AdamW steps at lr 5e-4 move each weight by <= ~1.5e-3.  Adam's first steps are sign-like (m/sqrt(v) ~ +-1), so an
@@ -168,7 +171,7 @@ def test_forty_step_loss_curve_vs_reference(golden_dir):
     assert c["loss"][-8:].mean() < 0.85 * c["loss"][:8].mean()              # the curve really descends
     assert dev_["loss"].max() <= TOL_CURVE and dev_["ar"].max() <= TOL_CURVE
     assert np.abs(np.array(rec["clip"]) - c["clip"]).max() <= TOL_CURVE * max(1.0, float(np.abs(c["clip"]).max()))
-    assert dev_["gradnorm"].max() <= 5 * TOL_CURVE
+    assert dev_["gradnorm"].max() <= 7 * TOL_CURVE
 
 
 def test_medium_random_model_grads():
@@ -192,8 +195,8 @@ def test_medium_random_model_grads():
         loss, ar, cl, _ = O.step_loss(Pg, ocfg, batch, up)
     loss.backward()
     log(f"medium losses hip {L} oracle ar {float(ar):.6f} clip {float(cl):.6f}")
-    check("medium ar", torch.tensor([L["ar_loss"]]), ar.detach().reshape(1), 5e-3)
-    check("medium clip", torch.tensor([L["clip_loss"]]), cl.detach().reshape(1), 5e-3)
+    check("medium ar", torch.tensor([L["ar_loss"]]), ar.detach().reshape(1), TOL_LOSS_SIM)
+    check("medium clip", torch.tensor([L["clip_loss"]]), cl.detach().reshape(1), TOL_LOSS_SIM)
     grads = eng.named_views("grads")
     bad = []
     for k in sorted(eng.layout):
@@ -228,8 +231,8 @@ def test_tall_closed_shape_vs_oracle():
         loss, ar, cl, _ = O.step_loss(Pg, ocfg, batch, up)
     loss.backward()
     log(f"tall losses hip {L} oracle ar {float(ar):.6f} clip {float(cl):.6f}")
-    check("tall ar", torch.tensor([L["ar_loss"]]), ar.detach().reshape(1), 5e-3)
-    check("tall clip", torch.tensor([L["clip_loss"]]), cl.detach().reshape(1), 5e-3)
+    check("tall ar", torch.tensor([L["ar_loss"]]), ar.detach().reshape(1), TOL_LOSS_SIM)
+    check("tall clip", torch.tensor([L["clip_loss"]]), cl.detach().reshape(1), TOL_LOSS_SIM)
     grads = eng.named_views("grads")
     bad = []
     for k in sorted(eng.layout):
@@ -264,8 +267,8 @@ def test_wide_batch_kernels_vs_oracle():
         loss, ar, cl, _ = O.step_loss(Pg, ocfg, batch, up)
     loss.backward()
     log(f"wide losses hip {L} oracle ar {float(ar):.6f} clip {float(cl):.6f}")
-    check("wide ar", torch.tensor([L["ar_loss"]]), ar.detach().reshape(1), 5e-3)
-    check("wide clip", torch.tensor([L["clip_loss"]]), cl.detach().reshape(1), 5e-3)
+    check("wide ar", torch.tensor([L["ar_loss"]]), ar.detach().reshape(1), TOL_LOSS_SIM)
+    check("wide clip", torch.tensor([L["clip_loss"]]), cl.detach().reshape(1), TOL_LOSS_SIM)
     grads = eng.named_views("grads")
     bad = []
     for k in sorted(eng.layout):
@@ -334,8 +337,8 @@ def test_head_size_32_model_grads_and_decode():
     with O.sim_bf16():
         loss, ar, cl, _ = O.step_loss(Pg, ocfg, batch, up)
     loss.backward()
-    check("hs32 ar", torch.tensor([L["ar_loss"]]), ar.detach().reshape(1), 5e-3)
-    check("hs32 clip", torch.tensor([L["clip_loss"]]), cl.detach().reshape(1), 5e-3)
+    check("hs32 ar", torch.tensor([L["ar_loss"]]), ar.detach().reshape(1), TOL_LOSS_SIM)
+    check("hs32 clip", torch.tensor([L["clip_loss"]]), cl.detach().reshape(1), TOL_LOSS_SIM)
     grads = eng.named_views("grads")
     bad = []
     for k in sorted(eng.layout):
@@ -361,7 +364,7 @@ def test_head_size_32_model_grads_and_decode():
         ref = full[rows, t]
         worst = max(worst, float((lg[rows] - ref).abs().max()) / max(float(ref.abs().max()), 1e-6))
     log(f"hs32 decode vs full forward: worst relative error {worst:.3e}")
-    assert worst < 2e-2
+    assert worst < 5e-3        # measured 2.3e-3
 
 
 def test_two_rank_emulation_equals_global_batch():

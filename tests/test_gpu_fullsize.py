@@ -121,4 +121,4 @@ def test_ragged_full_width_step_vs_oracle():
             worst.append((float((g[k].cpu() - ref).abs().max()) / sc, k))
     worst.sort(reverse=True)
     log(f"ragged full-width step: worst gradient deviations {worst[:3]}")
-    assert worst[0][0] < 3e-2, worst[:5]
+    assert worst[0][0] < 1.7e-2, worst[:5]     # measured 8.3e-3

@@ -10,8 +10,9 @@ pytestmark = pytest.mark.gpu
 from tests.gpu_util import check, rbf, log  # noqa: E402
 
 DEV = "cuda:0"
-TB = 6e-3    # bf16-output tolerance relative to the tensor scale
-TF = 2e-5    # fp32-output tolerance
+# stated tolerances = at most 2x the worst error measured on the MI355X (gpurun_out/test_report.txt, round 2)
+TB = 6e-3    # bf16-output tolerance relative to the tensor scale (one bf16 rounding = 3.9e-3; measured <= 3.5e-3)
+TF = 2e-7    # fp32-output tolerance unit (measured <= 8e-7 on the K <= 1024 products: TF * 10)
 
 
 @pytest.fixture(scope="module")
@@ -86,9 +87,9 @@ def test_wgrad(ops, M, N, K, f32):
     dW = dW0.clone()
     db = db0.clone()
     ops.wgrad(A if f32 else A.bfloat16(), X.bfloat16(), dW[:, :K], db)
-    check(f"wgrad dW {M}x{N}x{K} f32={f32}", dW[:, :K], dW0[:, :K] + A.t() @ X, 3e-5 * math.sqrt(M))
+    check(f"wgrad dW {M}x{N}x{K} f32={f32}", dW[:, :K], dW0[:, :K] + A.t() @ X, 3e-8 * math.sqrt(M))   # fp32 accumulation over M rows; measured <= 4.2e-6 at M = 74 451
     check(f"wgrad untouched col {M}", dW[:, K], dW0[:, K], 0.0)
-    check(f"wgrad db {M}x{N}", db, db0 + A.sum(0), 3e-5 * math.sqrt(M))
+    check(f"wgrad db {M}x{N}", db, db0 + A.sum(0), 3e-8 * math.sqrt(M))   # fp32 accumulation over M rows; measured <= 4.2e-6 at M = 74 451
 
 
 @pytest.mark.parametrize("M,N,K", [(70, 33, 19), (1024, 1024, 256), (1, 256, 1024)])
@@ -98,13 +99,13 @@ def test_sgemm(ops, M, N, K):
     Bm = torch.randn(K, N, generator=g).to(DEV)
     bias = torch.randn(N, generator=g).to(DEV)
     ref = (A.double() @ Bm.double()).float()
-    check(f"sgemm nn {M}x{N}x{K}", ops.sgemm(A, Bm, bias=bias), ref + bias, 2e-6 * math.sqrt(K))
-    check(f"sgemm tn {M}x{N}x{K}", ops.sgemm(A.t().contiguous(), Bm, trans_a=True), ref, 2e-6 * math.sqrt(K))
-    check(f"sgemm nt {M}x{N}x{K}", ops.sgemm(A, Bm.t().contiguous(), trans_b=True, alpha=0.5), 0.5 * ref, 2e-6 * math.sqrt(K))
+    check(f"sgemm nn {M}x{N}x{K}", ops.sgemm(A, Bm, bias=bias), ref + bias, 1e-7 * math.sqrt(K))
+    check(f"sgemm tn {M}x{N}x{K}", ops.sgemm(A.t().contiguous(), Bm, trans_a=True), ref, 1e-7 * math.sqrt(K))
+    check(f"sgemm nt {M}x{N}x{K}", ops.sgemm(A, Bm.t().contiguous(), trans_b=True, alpha=0.5), 0.5 * ref, 1e-7 * math.sqrt(K))
     c0 = torch.randn(M, N, generator=g).to(DEV)
     c = c0.clone()
     ops.sgemm(A, Bm, out=c, accumulate=True)
-    check(f"sgemm acc {M}x{N}x{K}", c, c0 + ref, 2e-6 * math.sqrt(K))
+    check(f"sgemm acc {M}x{N}x{K}", c, c0 + ref, 1e-7 * math.sqrt(K))
 
 
 @pytest.mark.parametrize("M,C,affine", [(1000, 256, True), (77, 64, True), (513, 256, False), (9, 1024, True)])
@@ -118,20 +119,20 @@ def test_layernorm(ops, M, C, affine):
     br = beta.clone().requires_grad_(True) if affine else None
     ref = torch.nn.functional.layer_norm(xr, (C,), gr, br, 1e-5)
     y16, y32, mean, rstd = ops.layernorm_fwd(x, gamma, beta, want16=True, want32=True)
-    check(f"ln fwd32 {M}x{C}", y32, ref, 1e-5)
+    check(f"ln fwd32 {M}x{C}", y32, ref, 4e-7)
     check(f"ln fwd16 {M}x{C}", y16.float(), ref, TB)
     dy = rbf(torch.randn(M, C, generator=g)).to(DEV)
     dres = torch.randn(M, C, generator=g).to(DEV)
     ref.backward(dy)
     for dyt, tag in ((dy.bfloat16(), "bf16"), (dy, "f32")):
         dx, dg, db = ops.layernorm_bwd(dyt, x, mean, rstd, gamma, dres=dres)
-        check(f"ln bwd dx {M}x{C} {tag}", dx, xr.grad + dres, 2e-5)
+        check(f"ln bwd dx {M}x{C} {tag}", dx, xr.grad + dres, 3e-7)
         if affine:
-            check(f"ln bwd dgamma {M}x{C} {tag}", dg, gr.grad, 1e-4)
-            check(f"ln bwd dbeta {M}x{C} {tag}", db, br.grad, 1e-4)
+            check(f"ln bwd dgamma {M}x{C} {tag}", dg, gr.grad, 6e-7)
+            check(f"ln bwd dbeta {M}x{C} {tag}", db, br.grad, 6e-7)
     if not affine:
         dx, _, _ = ops.layernorm_bwd(dy, y32, None, rstd, None, x_is_xhat=True)
-        check(f"ln bwd xhat {M}x{C}", dx, xr.grad, 2e-5)
+        check(f"ln bwd xhat {M}x{C}", dx, xr.grad, 4e-7)
 
 
 @pytest.mark.parametrize("B,T,nh,hs", [(3, 12, 4, 16), (5, 80, 16, 16), (2, 250, 4, 16), (4, 33, 2, 16),
@@ -162,13 +163,13 @@ def test_attention(ops, B, T, nh, hs):
     att = att.masked_fill(~torch.tril(torch.ones(T, T, dtype=torch.bool)), float("-inf"))
     lse_ref = torch.logsumexp(att, -1)
     yr = (torch.softmax(att, -1) @ v).transpose(1, 2).reshape(B * T, C)
-    check(f"attn fwd y B{B} T{T} hs{hs}", y.float().cpu(), yr, 1.2e-2)
-    check(f"attn fwd lse B{B} T{T}", lse.cpu(), lse_ref, 5e-3)
+    check(f"attn fwd y B{B} T{T} hs{hs}", y.float().cpu(), yr, 6e-3)
+    check(f"attn fwd lse B{B} T{T}", lse.cpu(), lse_ref, 4e-7)
     yr.backward(dy.cpu())
     dqkv = ops.attn_bwd(qkv_dev, y, dy.bfloat16(), lse, B, T, nh, cos, sin, hs)
-    check(f"attn bwd dq B{B} T{T} hs{hs}", dqkv[:, :C].float().cpu(), qr.grad[:, :C], 2e-2)
-    check(f"attn bwd dk B{B} T{T}", dqkv[:, C:2 * C].float().cpu(), qr.grad[:, C:2 * C], 2e-2)
-    check(f"attn bwd dv B{B} T{T}", dqkv[:, 2 * C:].float().cpu(), qr.grad[:, 2 * C:], 2e-2)
+    check(f"attn bwd dq B{B} T{T} hs{hs}", dqkv[:, :C].float().cpu(), qr.grad[:, :C], 9e-3)
+    check(f"attn bwd dk B{B} T{T}", dqkv[:, C:2 * C].float().cpu(), qr.grad[:, C:2 * C], 1.1e-2)
+    check(f"attn bwd dv B{B} T{T}", dqkv[:, 2 * C:].float().cpu(), qr.grad[:, 2 * C:], 7e-3)
 
 
 def test_embed(ops):
@@ -195,7 +196,7 @@ def test_embed(ops):
                 ri[b] += dx[b * T + t]
             else:
                 rt[idx[b, t]] += dx[b * T + t]
-    check("embed bwd table", dt.cpu(), rt, 1e-6)
+    check("embed bwd table", dt.cpu(), rt, 2e-7)
     check("embed bwd inject", di.cpu(), ri, 1e-6)
 
 
@@ -211,12 +212,12 @@ def test_lmhead_ce(ops, M, V, K):
     loss = torch.nn.functional.cross_entropy(lr, tgt, ignore_index=-1)
     loss.backward()
     lse, scal = ops.ce_fwd(a.bfloat16(), W.bfloat16(), tgt.to(DEV))
-    check(f"ce lse V{V}", lse.cpu(), torch.logsumexp(logits, -1), 1e-5)
+    check(f"ce lse V{V}", lse.cpu(), torch.logsumexp(logits, -1), 7e-7)
     s = scal.cpu()
     assert int(s[1]) == int((tgt >= 0).sum())
-    check(f"ce loss V{V}", (s[0] / s[1]).reshape(1), loss.detach().reshape(1), 1e-5)
+    check(f"ce loss V{V}", (s[0] / s[1]).reshape(1), loss.detach().reshape(1), 6e-7)
     d = ops.ce_bwd(a.bfloat16(), W.bfloat16(), tgt.to(DEV), lse, scal)
-    check(f"ce dlogits V{V}", d[:, :V].float().cpu(), lr.grad, 1e-2)
+    check(f"ce dlogits V{V}", d[:, :V].float().cpu(), lr.grad, 5e-3)
     assert float(d[:, V:].float().abs().max()) == 0.0 if d.shape[1] > V else True
 
 
@@ -254,9 +255,9 @@ def test_barlow_head_vs_oracle():
     ref = O.barlow_loss(ar, br, bad)
     ref.sum().backward()
     loss, dS, dC = barlow_head(a.to(DEV), b.to(DEV), bad.to(DEV), lam=5e-3, gscale=1.0)
-    check("barlow loss", loss.cpu(), ref.detach(), 2e-5)
-    check("barlow d/da", dS.cpu(), ar.grad, 1e-4)
-    check("barlow d/db", dC.cpu(), br.grad, 1e-4)
+    check("barlow loss", loss.cpu(), ref.detach(), 2e-6)
+    check("barlow d/da", dS.cpu(), ar.grad, 1.1e-5)
+    check("barlow d/db", dC.cpu(), br.grad, 1.1e-5)
     assert float(dS[3].abs().max()) == 0.0
 
 
