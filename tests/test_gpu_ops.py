@@ -87,9 +87,9 @@ def test_wgrad(ops, M, N, K, f32):
     dW = dW0.clone()
     db = db0.clone()
     ops.wgrad(A if f32 else A.bfloat16(), X.bfloat16(), dW[:, :K], db)
-    check(f"wgrad dW {M}x{N}x{K} f32={f32}", dW[:, :K], dW0[:, :K] + A.t() @ X, 3e-8 * math.sqrt(M))   # fp32 accumulation over M rows; measured <= 4.2e-6 at M = 74 451
+    check(f"wgrad dW {M}x{N}x{K} f32={f32}", dW[:, :K], dW0[:, :K] + A.t() @ X, 8.5e-6)   # fp32 accumulation over M rows; measured <= 4.2e-6 (M = 74 451)
     check(f"wgrad untouched col {M}", dW[:, K], dW0[:, K], 0.0)
-    check(f"wgrad db {M}x{N}", db, db0 + A.sum(0), 3e-8 * math.sqrt(M))   # fp32 accumulation over M rows; measured <= 4.2e-6 at M = 74 451
+    check(f"wgrad db {M}x{N}", db, db0 + A.sum(0), 8.5e-6)   # fp32 accumulation over M rows; measured <= 4.2e-6 (M = 74 451)
 
 
 @pytest.mark.parametrize("M,N,K", [(70, 33, 19), (1024, 1024, 256), (1, 256, 1024)])
