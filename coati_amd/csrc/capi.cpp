@@ -20,6 +20,28 @@ int coati_gemm_nt(const void* A, int a_f32, int64_t lda, const uint16_t* B, int6
   return launch_gemm_nt(a, a_f32, epi, S_(stream));
 }
 
+int coati_mlp_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, const uint16_t* W1, int64_t ldw1,
+                  const float* b1, const uint16_t* W2, int64_t ldw2, const float* b2, int M, int C, int Hd, uint16_t* a,
+                  int64_t lda, float* mean, float* rstd, uint16_t* g, uint16_t* dg, int64_t ldh, float* out, int64_t ldo,
+                  void* stream) {
+  MlpArgs m;
+  memset(&m, 0, sizeof(m));
+  m.M = M; m.C = C; m.Hd = Hd; m.x = x; m.ldx = ldx; m.gamma = gamma; m.beta = beta; m.mean = mean; m.rstd = rstd;
+  m.a = a; m.lda = lda; m.W1 = W1; m.ldw1 = ldw1; m.b1 = b1; m.W2 = W2; m.ldw2 = ldw2; m.b2 = b2; m.h = g; m.d = dg;
+  m.ldh = ldh; m.out = out; m.ldo = ldo;
+  return launch_mlp_fwd(m, S_(stream));
+}
+
+int coati_mlp_dgrad(const uint16_t* dY, int64_t lddy, const uint16_t* W2T, int64_t ldw2t, const uint16_t* W1T,
+                    int64_t ldw1t, const uint16_t* dgelu, int M, int C, int Hd, uint16_t* dh, int64_t ldh,
+                    uint16_t* dA, int64_t ldda, void* stream) {
+  MlpArgs m;
+  memset(&m, 0, sizeof(m));
+  m.M = M; m.C = C; m.Hd = Hd; m.a = const_cast<uint16_t*>(dY); m.lda = lddy; m.W1 = W2T; m.ldw1 = ldw2t; m.W2 = W1T;
+  m.ldw2 = ldw1t; m.aux = dgelu; m.h = dh; m.ldh = ldh; m.out = dA; m.ldo = ldda;
+  return launch_mlp_bwd(m, S_(stream));
+}
+
 int coati_gemm_ce_partial(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw, int M, int V, int K,
                           void* partial, void* stream) {
   GemmArgs a;

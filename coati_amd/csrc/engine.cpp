@@ -11,6 +11,7 @@
 //                               carved deterministically per (B, T1, T2, A).
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -129,6 +130,15 @@ struct coati_engine {
   float* attnD;
   float *g_DH, *g_DO;
   bf16_t *g_do2, *g_dtd, *g_du, *g_dmi, *g_ds2, *g_dpre1, *g_dP;
+  // deferred transformer weight gradients (grouped launch, gemm.hip wgrad_dma_table_kernel): the bf16 activation gradients
+  // of every layer of a pass stay alive until the end of the pass, then ONE launch computes all 4 L weight gradients
+  std::vector<bf16_t*> w_dh4, w_dxa, w_dxb, w_dqkv;   // [L]: d(hidden), d x[l+1], d xmid[l], d qkv[l]
+  bool wg_group = false;                              // buffers carved (shape and COATI_WGRAD_GROUP allow it)
+  WgradTile* d_wtab = nullptr;                        // device tables: WTAB_SLOTS x (L x tiles per layer) entries
+  int wtab_cap = 0;                                   // entries per slot
+  struct WTabKey { const void* pass = nullptr; int lo = -1, hi = -1, M = 0, n = 0; long long sig = 0; };
+  WTabKey wtab_key[4];
+  const void* wtab_ws = nullptr;                      // workspace the cached tables were built for
   float* nce = nullptr;
   size_t nce_cap = 0;
   float* opt_partial;
@@ -429,6 +439,25 @@ size_t carve(coati_engine* e, Arena& ar, int B, int T1, int T2, int A, int Bg) {
   e->g_do2 = ar.take<bf16_t>(BA * H); e->g_dtd = ar.take<bf16_t>(BA * H); e->g_du = ar.take<bf16_t>(BA * H);
   e->g_dmi = ar.take<bf16_t>(BA * H); e->g_ds2 = ar.take<bf16_t>(Me * H); e->g_dpre1 = ar.take<bf16_t>(Me * H);
   e->g_dP = ar.take<bf16_t>(BA * 2 * H);
+  // deferred weight gradients: 9C bf16 per token and layer (6 GB at B*T = 81,920, L = 16: 288 GB of HBM make this free)
+  {
+    static const bool off = getenv("COATI_WGRAD_GROUP") != nullptr && atoi(getenv("COATI_WGRAD_GROUP")) == 0;   // A/B switch
+    const int L = c.n_layer_xformer;
+    e->wg_group = !off && C % 128 == 0 && Mmax >= 4096;
+    e->w_dh4.assign(L, nullptr); e->w_dxa.assign(L, nullptr); e->w_dxb.assign(L, nullptr); e->w_dqkv.assign(L, nullptr);
+    if (e->wg_group) {
+      for (int l = 0; l < L; ++l) {
+        e->w_dh4[l] = ar.take<bf16_t>(Mmax * 4 * C); e->w_dxa[l] = ar.take<bf16_t>(Mmax * C);
+        e->w_dxb[l] = ar.take<bf16_t>(Mmax * C); e->w_dqkv[l] = ar.take<bf16_t>(Mmax * 3 * C);
+      }
+      const int tpl = cdiv(3 * C, 128) * cdiv(C, 128) + cdiv(C, 128) * cdiv(C, 128) + 2 * cdiv(4 * C, 128) * cdiv(C, 128);
+      e->wtab_cap = L * tpl;
+      WgradTile* t = ar.take<WgradTile>((size_t)4 * e->wtab_cap);
+      if (t != e->d_wtab || ar.base != e->wtab_ws) for (auto& k : e->wtab_key) k = coati_engine::WTabKey();
+      e->d_wtab = t;
+      e->wtab_ws = ar.base;
+    }
+  }
   e->opt_partial = ar.take<float>(1024);
   e->ln_partial = ar.take<float>((size_t)COATI_LN_PARTIAL_ROWS * 2 * (C > H ? C : H));
   e->ln_part_x = ar.take<float>((size_t)(2 * c.n_layer_xformer + 1) * COATI_LN_PARTIAL_ROWS * 2 * C);
@@ -503,6 +532,50 @@ int xformer_fwd(coati_engine* e, XPass& p, const float* injection, hipStream_t s
   return launch_layernorm_fwd(p.x[L], C, e->P + e->lnfw, e->P + e->lnfb, p.af, C, p.xf32, C, p.meanf, p.rstdf, M, C, s);
 }
 
+// One launch for the 4 (l_hi - l_lo) weight gradients of a layer range (bias gradients included): the tile table is built
+// once per (pass, range, shape) and cached in the workspace.
+int xformer_wgrad_group(coati_engine* e, XPass& p, int l_lo, int l_hi, hipStream_t s) {
+  const int C = e->cfg.n_hidden_xformer, M = p.M;
+  const long long sig = (((long long)e->B * 1000003 + e->T1) * 1000003 + e->T2) * 1000003 + e->A;
+  int slot = -1;
+  for (int i = 0; i < 4; ++i)
+    if (e->wtab_key[i].pass == &p && e->wtab_key[i].lo == l_lo && e->wtab_key[i].hi == l_hi && e->wtab_key[i].M == M && e->wtab_key[i].sig == sig) slot = i;
+  double flops = 0.0, bytes = 0.0;
+  for (int l = l_lo; l < l_hi; ++l) {
+    flops += 2.0 * M * (3.0 + 1.0 + 4.0 + 4.0) * C * C;
+    bytes += (double)M * (3 + 1 + 1 + 1 + 4 + 1 + 1 + 4) * C * 2 + 12.0 * C * C * 8;   // every operand once + the f32 gradient read-modify-write
+  }
+  if (slot < 0) {
+    std::vector<WgradTile> tab;
+    auto add = [&](const bf16_t* A, int lda, const bf16_t* B, int ldb, int N, int K, int64_t w_off, int64_t b_off) -> int {
+      WgradArgs a;
+      a.A = A; a.lda = lda; a.B = B; a.ldb = ldb; a.M = M; a.N = N; a.K = K; a.dW = e->G + w_off; a.ldw = K; a.dbias = e->G + b_off; a.n_out = 0;
+      return wgrad_table_append(tab, a);
+    };
+    for (int l = l_hi - 1; l >= l_lo; --l) {
+      const XLayerP& w = e->xl[l];
+      COATI_TRY(add(e->w_dqkv[l], 3 * C, p.a1[l], C, 3 * C, C, w.attnw, w.attnb));
+      COATI_TRY(add(e->w_dxb[l], C, p.y[l], C, C, C, w.projw, w.projb));
+      COATI_TRY(add(e->w_dh4[l], 4 * C, p.a2[l], C, 4 * C, C, w.fc1w, w.fc1b));
+      COATI_TRY(add(e->w_dxa[l], C, p.g[l], 4 * C, C, 4 * C, w.fc2w, w.fc2b));
+    }
+    COATI_CHECK_ARG((int)tab.size() <= e->wtab_cap, "wgrad group: table overflow (%zu > %d)", tab.size(), e->wtab_cap);
+    static int rr = 0;
+    slot = rr++ & 3;
+    // pageable source: the runtime stages the copy before hipMemcpyAsync returns, so `tab` may go out of scope
+    if (hipMemcpyAsync(e->d_wtab + (size_t)slot * e->wtab_cap, tab.data(), tab.size() * sizeof(WgradTile), hipMemcpyHostToDevice, s) != hipSuccess ||
+        hipStreamSynchronize(s) != hipSuccess) {
+      coati_set_error("wgrad group: table upload failed");
+      return COATI_EHIP;
+    }
+    coati_engine::WTabKey k;
+    k.pass = &p; k.lo = l_lo; k.hi = l_hi; k.M = M; k.n = (int)tab.size(); k.sig = sig;
+    e->wtab_key[slot] = k;
+  }
+  ProfScope ps(e, SITE_XF_WGRAD, flops, s, bytes);
+  return launch_wgrad_table(e->d_wtab + (size_t)slot * e->wtab_cap, e->wtab_key[slot].n, s);
+}
+
 // dyf: gradient w.r.t. ln_f output, bf16 (decoder pass) or f32 (encoder pass)
 // layers [l_lo, l_hi) only, descending; the ln_f backward belongs to l_hi == L, the embedding backward to l_lo == 0
 int xformer_bwd(coati_engine* e, XPass& p, const void* dyf, int dyf_f32, float* dinjection, hipStream_t s, int l_hi = -1, int l_lo = 0) {
@@ -517,43 +590,54 @@ int xformer_bwd(coati_engine* e, XPass& p, const void* dyf, int dyf_f32, float* 
   fin.n = 0;
   int nblk = 0;
   auto ln_bwd = [&](const void* dy, int dy_f32, const float* x, const float* mean, const float* rstd, const float* gamma,
-                    const float* dres, size_t goff, size_t boff) -> int {
-    if (!defer) return launch_layernorm_bwd(dy, dy_f32, C, x, C, 0, mean, rstd, gamma, dres, DX, e->DX16, e->G + goff, e->G + boff, e->ln_partial, M, C, s);
+                    const float* dres, size_t goff, size_t boff, bf16_t* dx16) -> int {
+    if (!defer) return launch_layernorm_bwd(dy, dy_f32, C, x, C, 0, mean, rstd, gamma, dres, DX, dx16, e->G + goff, e->G + boff, e->ln_partial, M, C, s);
     fin.dg_off[fin.n] = (long long)goff;
     fin.db_off[fin.n] = (long long)boff;
-    return launch_layernorm_bwd_deferred(dy, dy_f32, C, x, C, 0, mean, rstd, gamma, dres, DX, e->DX16, e->ln_part_x + (fin.n++) * slot_stride, &nblk, M, C, s);
+    return launch_layernorm_bwd_deferred(dy, dy_f32, C, x, C, 0, mean, rstd, gamma, dres, DX, dx16, e->ln_part_x + (fin.n++) * slot_stride, &nblk, M, C, s);
   };
+  // Weight gradients: immediately, one launch per Linear (small shapes), or deferred to ONE grouped launch at the end of
+  // this call (grouped = every activation gradient of the layer range stays alive in its own buffer).
+  const bool grp = e->wg_group && M >= 4096;
   if (l_hi == L) {
     ProfScope ps(e, SITE_LN_BWD, 0, s, (double)M * C * ((dyf_f32 ? 4 : 2) + 4 + 4 + 2));
-    COATI_TRY(ln_bwd(dyf, dyf_f32, p.x[L], p.meanf, p.rstdf, e->P + e->lnfw, nullptr, e->lnfw, e->lnfb));
+    COATI_TRY(ln_bwd(dyf, dyf_f32, p.x[L], p.meanf, p.rstdf, e->P + e->lnfw, nullptr, e->lnfw, e->lnfb, grp ? e->w_dxa[L - 1] : e->DX16));
   }
   for (int l = l_hi - 1; l >= l_lo; --l) {
     const XLayerP& w = e->xl[l];
+    bf16_t* const dxa = grp ? e->w_dxa[l] : e->DX16;      // d x[l+1]
+    bf16_t* const dxb = grp ? e->w_dxb[l] : e->DX16;      // d xmid[l]
+    bf16_t* const dh4 = grp ? e->w_dh4[l] : e->dh4;
+    bf16_t* const dqkv = grp ? e->w_dqkv[l] : e->dqkv;
+    bf16_t* const dx_out = grp ? (l > 0 ? e->w_dxa[l - 1] : e->DX16) : e->DX16;   // d x[l] for the layer below
     // x[l+1] = xmid + g W2^T + b2
-    COATI_TRY(gemm(e, SITE_FC2_DGRAD, e->DX16, 0, C, e->S + w.fc2T, C, M, 4 * C, C, e->dh4, 4 * C, nullptr, EPI_MUL_AUX, p.hpre[l], nullptr, 4 * C, s));
+    COATI_TRY(gemm(e, SITE_FC2_DGRAD, dxa, 0, C, e->S + w.fc2T, C, M, 4 * C, C, dh4, 4 * C, nullptr, EPI_MUL_AUX, p.hpre[l], nullptr, 4 * C, s));
     // hpre = a2 W1^T + b1
-    COATI_TRY(gemm(e, SITE_FC1_DGRAD, e->dh4, 0, 4 * C, e->S + w.fc1T, 4 * C, M, C, 4 * C, e->da, C, nullptr, EPI_BF16, nullptr, nullptr, 0, s));
-    COATI_TRY(wgrad(e, SITE_XF_WGRAD, e->dh4, 0, 4 * C, p.a2[l], C, M, 4 * C, C, e->G + w.fc1w, C, e->G + w.fc1b, 0, s));
-    // (the fc2 weight gradient runs after the two consumers of dh4, so that dh4 is re-read while it is still warm)
-    COATI_TRY(wgrad(e, SITE_XF_WGRAD, e->DX16, 0, C, p.g[l], 4 * C, M, C, 4 * C, e->G + w.fc2w, 4 * C, e->G + w.fc2b, 0, s));
+    COATI_TRY(gemm(e, SITE_FC1_DGRAD, dh4, 0, 4 * C, e->S + w.fc1T, 4 * C, M, C, 4 * C, e->da, C, nullptr, EPI_BF16, nullptr, nullptr, 0, s));
+    if (!grp) {
+      COATI_TRY(wgrad(e, SITE_XF_WGRAD, dh4, 0, 4 * C, p.a2[l], C, M, 4 * C, C, e->G + w.fc1w, C, e->G + w.fc1b, 0, s));
+      // (the fc2 weight gradient runs after the two consumers of dh4, so that dh4 is re-read while it is still warm)
+      COATI_TRY(wgrad(e, SITE_XF_WGRAD, dxa, 0, C, p.g[l], 4 * C, M, C, 4 * C, e->G + w.fc2w, 4 * C, e->G + w.fc2b, 0, s));
+    }
     {
       ProfScope ps(e, SITE_LN_BWD, 0, s, (double)M * C * (2 + 4 + 4 + 4 + 2));   // dy16, x, dres in; dx, dx16 out
-      COATI_TRY(ln_bwd(e->da, 0, p.xmid[l], p.mean2[l], p.rstd2[l], e->P + w.ln2w, DX, w.ln2w, w.ln2b));
+      COATI_TRY(ln_bwd(e->da, 0, p.xmid[l], p.mean2[l], p.rstd2[l], e->P + w.ln2w, DX, w.ln2w, w.ln2b, dxb));
     }
     // xmid = x[l] + y Wp^T + bp
-    COATI_TRY(gemm(e, SITE_PROJ_DGRAD, e->DX16, 0, C, e->S + w.projT, C, M, C, C, e->dyb, C, nullptr, EPI_BF16, nullptr, nullptr, 0, s));
-    COATI_TRY(wgrad(e, SITE_XF_WGRAD, e->DX16, 0, C, p.y[l], C, M, C, C, e->G + w.projw, C, e->G + w.projb, 0, s));
+    COATI_TRY(gemm(e, SITE_PROJ_DGRAD, dxb, 0, C, e->S + w.projT, C, M, C, C, e->dyb, C, nullptr, EPI_BF16, nullptr, nullptr, 0, s));
+    if (!grp) COATI_TRY(wgrad(e, SITE_XF_WGRAD, dxb, 0, C, p.y[l], C, M, C, C, e->G + w.projw, C, e->G + w.projb, 0, s));
     {
       ProfScope ps(e, SITE_ATTN_BWD, 10.0 * p.B * (double)p.T * p.T * C, s, (double)M * 8 * C * 2 + (double)M * c.n_head * 8);   // qkv, y, dy in; dqkv out
-      COATI_TRY(launch_attn_bwd(p.qkv[l], p.y[l], e->dyb, p.lse[l], e->attnD, e->dqkv, e->cos_t, e->sin_t, p.B, p.T, c.n_head, C / c.n_head, s));
+      COATI_TRY(launch_attn_bwd(p.qkv[l], p.y[l], e->dyb, p.lse[l], e->attnD, dqkv, e->cos_t, e->sin_t, p.B, p.T, c.n_head, C / c.n_head, s));
     }
-    COATI_TRY(gemm(e, SITE_QKV_DGRAD, e->dqkv, 0, 3 * C, e->S + w.attnT, 3 * C, M, C, 3 * C, e->da, C, nullptr, EPI_BF16, nullptr, nullptr, 0, s));
-    COATI_TRY(wgrad(e, SITE_XF_WGRAD, e->dqkv, 0, 3 * C, p.a1[l], C, M, 3 * C, C, e->G + w.attnw, C, e->G + w.attnb, 0, s));
+    COATI_TRY(gemm(e, SITE_QKV_DGRAD, dqkv, 0, 3 * C, e->S + w.attnT, 3 * C, M, C, 3 * C, e->da, C, nullptr, EPI_BF16, nullptr, nullptr, 0, s));
+    if (!grp) COATI_TRY(wgrad(e, SITE_XF_WGRAD, dqkv, 0, 3 * C, p.a1[l], C, M, 3 * C, C, e->G + w.attnw, C, e->G + w.attnb, 0, s));
     {
       ProfScope ps(e, SITE_LN_BWD, 0, s, (double)M * C * (2 + 4 + 4 + 4 + 2));   // dy16, x, dres in; dx, dx16 out
-      COATI_TRY(ln_bwd(e->da, 0, p.x[l], p.mean1[l], p.rstd1[l], e->P + w.ln1w, DX, w.ln1w, w.ln1b));
+      COATI_TRY(ln_bwd(e->da, 0, p.x[l], p.mean1[l], p.rstd1[l], e->P + w.ln1w, DX, w.ln1w, w.ln1b, dx_out));
     }
   }
+  if (grp && l_hi > l_lo) COATI_TRY(xformer_wgrad_group(e, p, l_lo, l_hi, s));
   if (defer && fin.n > 0) {
     ProfScope ps(e, SITE_LN_BWD, 0, s, 0.0);
     COATI_TRY(launch_ln_finish_batched(e->ln_part_x, slot_stride, nblk, e->G, fin, C, s));

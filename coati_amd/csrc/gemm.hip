@@ -533,20 +533,15 @@ __device__ __forceinline__ void wd_dma16s(const void* base, unsigned off, unsign
 }
 template <int S> struct WdSlot { static constexpr int value = S; };
 
-template <bool BIAS, int NS>
-__global__ __launch_bounds__(512, 1) void wgrad_dma_kernel(WgradArgs p, int tiles_k, int chunks_per_split, int n_splits) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+// EXCL: this workgroup is the only one that writes its output tile (it streams ALL of M): the tile is committed with
+// plain read-add-stores instead of fp32 atomics (the grouped launch below); the bias partials stay atomic (tiles_k
+// workgroups share a bias slice).
+template <bool BIAS, int NS, bool EXCL>
+__device__ __forceinline__ void wgrad_dma_body(const WgradArgs& p, int tiles_k, int tile, int c_begin, int c_end, unsigned char* smem) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int grp = wave >> 2, wm = (wave >> 1) & 1, wn = wave & 1;
-  const int tiles = gridDim.x / n_splits;
-  const int wg = xcd_swizzle(blockIdx.x, gridDim.x);
-  const int split = wg / tiles, tile = wg - split * tiles;
   const int tile_n = tile / tiles_k, tile_k = tile - tile_n * tiles_k;
   const int n0 = tile_n * BM, k0 = tile_k * BN;
-  const int nchunks = (p.M + WD_CH - 1) / WD_CH;
-  const int c_begin = split * chunks_per_split;
-  int c_end = c_begin + chunks_per_split;
-  if (c_end > nchunks) c_end = nchunks;
   if (c_begin >= c_end) return;
   const int m_begin = c_begin * WD_CH;
   const int m_end = c_end * WD_CH < p.M ? c_end * WD_CH : p.M;
@@ -776,9 +771,71 @@ __global__ __launch_bounds__(512, 1) void wgrad_dma_kernel(WgradArgs p, int tile
       for (int r = 0; r < 16; ++r) {
         const int n = n0 + wm * 64 + i * 32 + frag_row(r, lane);
         const int k = k0 + wn * 64 + j * 32 + (lane & 31);
-        if (n < nout && k < p.K) atomicAdd(p.dW + (long long)n * p.ldw + k, v[j][r]);
+        if (n < nout && k < p.K) {
+          if constexpr (EXCL) p.dW[(long long)n * p.ldw + k] += v[j][r];
+          else atomicAdd(p.dW + (long long)n * p.ldw + k, v[j][r]);
+        }
       }
   }
+}
+
+template <bool BIAS, int NS>
+__global__ __launch_bounds__(512, 1) void wgrad_dma_kernel(WgradArgs p, int tiles_k, int chunks_per_split, int n_splits) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tiles = gridDim.x / n_splits;
+  const int wg = xcd_swizzle(blockIdx.x, gridDim.x);
+  const int split = wg / tiles, tile = wg - split * tiles;
+  const int nchunks = (p.M + WD_CH - 1) / WD_CH;
+  const int c_begin = split * chunks_per_split;
+  int c_end = c_begin + chunks_per_split;
+  if (c_end > nchunks) c_end = nchunks;
+  wgrad_dma_body<BIAS, NS, false>(p, tiles_k, tile, c_begin, c_end, smem);
+}
+
+// Grouped launch: one workgroup per OUTPUT TILE of a whole list of weight-gradient problems (all four Linear layers of
+// every transformer layer of a pass: 16 x 48 = 768 tiles = three rounds of 256 CUs).  Each workgroup streams all of M for
+// its tile, so nothing is split over M: no fp32 atomics on the tiles, no per-problem launch tail.  The table (one entry
+// per workgroup, device memory) is ordered problem by problem; xcd_swizzle hands each XCD a contiguous run of entries, so
+// the tiles that share an operand panel run at the same time on the same L2.
+template <bool BIAS, int NS>
+__global__ __launch_bounds__(512, 1) void wgrad_dma_table_kernel(const WgradTile* __restrict__ table) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const WgradTile& d = table[xcd_swizzle(blockIdx.x, gridDim.x)];
+  const WgradArgs p = d.p;
+  wgrad_dma_body<BIAS, NS, true>(p, d.tiles_k, d.tile, 0, (p.M + WD_CH - 1) / WD_CH, smem);
+}
+
+int wgrad_table_append(std::vector<WgradTile>& tab, const WgradArgs& a) {
+  COATI_CHECK_ARG(a.A && a.B && a.dW && a.dbias, "wgrad_table: null operand (the grouped kernel is the bias variant)");
+  COATI_CHECK_SHAPE(a.M > 0 && a.N % 8 == 0 && a.K % 8 == 0 && a.lda % 8 == 0 && a.ldb % 8 == 0, "wgrad_table: shape / alignment");
+  const int tiles_n = cdiv(a.N, BM), tiles_k = cdiv(a.K, BN);
+  for (int t = 0; t < tiles_n * tiles_k; ++t) tab.push_back(WgradTile{a, tiles_k, t});
+  return COATI_OK;
+}
+
+template <int NS>
+static int launch_wgrad_table_t(const WgradTile* dev_table, int n_tiles, hipStream_t s) {
+  static bool attr_set = false;
+  auto kern = wgrad_dma_table_kernel<true, NS>;
+  constexpr int lds = NS * WD_STAGE_BYTES;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) {
+      coati_set_error("wgrad(table): hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+      return COATI_EHIP;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(n_tiles), dim3(512), lds, s, dev_table);
+  COATI_LAUNCH_CHECK("wgrad_table");
+  return COATI_OK;
+}
+
+int launch_wgrad_table(const WgradTile* dev_table, int n_tiles, hipStream_t s) {
+  COATI_CHECK_ARG(dev_table && n_tiles > 0, "wgrad_table: empty table");
+  // ring depth (stages of 32 KiB; NS - 1 in flight): COATI_WGRAD_TABLE_NS = 3 | 4 (A/B switch)
+  static const int ns = getenv("COATI_WGRAD_TABLE_NS") ? atoi(getenv("COATI_WGRAD_TABLE_NS")) : 4;
+  return ns == 3 ? launch_wgrad_table_t<3>(dev_table, n_tiles, s) : launch_wgrad_table_t<4>(dev_table, n_tiles, s);
 }
 
 template <bool BIAS, int NS>

@@ -83,6 +83,29 @@ int launch_gemm_rb256(const GemmArgs& a, int epi, hipStream_t s);
 bool gemm_ring256_supported(const GemmArgs& a, int a_f32, int epi);
 int launch_gemm_ring256(const GemmArgs& a, int epi, hipStream_t s);
 
+// Chained MLP products at C = 256 (gemm_mlp.hip): forward LayerNorm -> W1 -> NewGELU (+ derivative) -> W2 -> residual, and
+// the backward input-gradient chain dY -> W2^T -> x NewGELU' -> W1^T.  The [M, Hd] intermediate feeds the second product
+// from registers; it is still written once (the weight gradients read it).
+struct MlpArgs {
+  int M, C, Hd;
+  // forward: x f32 [M, C] (LayerNorm input and residual); gamma / beta [C]; mean / rstd [M] out
+  const float* x; long long ldx;
+  const float* gamma; const float* beta; float* mean; float* rstd;
+  // forward: a = LayerNorm(x) bf16 [M, C], WRITTEN.  backward: a = dY bf16 [M, C], read
+  bf16_t* a; long long lda;
+  const bf16_t* W1; long long ldw1;   // [Hd, C]  forward: fc1 weight;   backward: fc2 weight transposed
+  const float* b1;                    // [Hd] forward only
+  const bf16_t* W2; long long ldw2;   // [C, Hd]  forward: fc2 weight;   backward: fc1 weight transposed
+  const float* b2;                    // [C] forward only
+  bf16_t* h; long long ldh;           // [M, Hd] out: forward NewGELU(pre); backward dh = (dY W2) * aux
+  bf16_t* d;                          // [M, Hd] out, forward: NewGELU'(pre) (row stride ldh)
+  const bf16_t* aux;                  // [M, Hd] in, backward: the saved NewGELU'(pre) (row stride ldh)
+  void* out; long long ldo;           // forward f32 [M, C] = x + h W2^T + b2;  backward bf16 [M, C] = dh W1
+};
+bool mlp_chain_supported(const MlpArgs& a);
+int launch_mlp_fwd(const MlpArgs& a, hipStream_t s);
+int launch_mlp_bwd(const MlpArgs& a, hipStream_t s);
+
 // dW[N,K] (f32, atomic +=) = A[M,N]^T * B[M,K];  dbias[N] (atomic +=) = colsum(A) if non-null
 struct WgradArgs {
   const void* A;   // [M,N] bf16 or f32
@@ -96,6 +119,18 @@ struct WgradArgs {
   int n_out;   // rows of dW that exist (0 -> N); columns of A beyond it must be zero
 };
 int launch_wgrad(const WgradArgs& a, int a_f32, hipStream_t s);
+// Grouped, atomics-free form (gemm.hip, wgrad_dma_table_kernel): one workgroup per 128 x 128 output tile of a list of
+// problems (bf16 A, bias), each streaming all of M.  The table lives in device memory (one entry per workgroup).
+struct WgradTile {
+  WgradArgs p;
+  int tiles_k;   // 128-column tiles along K of this problem
+  int tile;      // tile index inside the problem (tile_n * tiles_k + tile_k)
+};
+int launch_wgrad_table(const WgradTile* dev_table, int n_tiles, hipStream_t s);
+#ifdef __cplusplus
+#include <vector>
+int wgrad_table_append(std::vector<WgradTile>& tab, const WgradArgs& a);   // host: appends the problem's tiles
+#endif
 
 // C[M,N] (f32) = sum_k A(m,k) B(k,n) [+ bias[n]] [+ C];  A(m,k) = A[m*ars + k*acs], B(k,n) = B[k*brs + n*bcs]
 // exact-f32 MFMA (v_mfma_f32_32x32x2_f32).  alpha scales the product.

@@ -175,3 +175,32 @@ def ce_bwd(a, W, target, lse, scal):
     _lib.call("coati_gemm_ce_bwd", ptr(a), a.stride(0), ptr(W), W.stride(0), M, V, K, ptr(d), Vpad, Vpad, ptr(lse),
               ptr(target), ptr(scal), stream())
     return d
+
+
+def mlp_fwd(x, gamma, beta, W1, b1, W2, b2):
+    """chained LayerNorm -> W1 -> NewGELU -> W2 -> residual (C = 256).  Returns (out f32, a bf16, mean, rstd, g bf16, dg bf16)."""
+    _need_cuda(x, W1, W2)
+    M, C = x.shape
+    Hd = W1.shape[0]
+    dev = x.device
+    a = torch.empty(M, C, device=dev, dtype=torch.bfloat16)
+    g = torch.empty(M, Hd, device=dev, dtype=torch.bfloat16)
+    dg = torch.empty(M, Hd, device=dev, dtype=torch.bfloat16)
+    mean = torch.empty(M, device=dev, dtype=torch.float32)
+    rstd = torch.empty(M, device=dev, dtype=torch.float32)
+    out = torch.empty(M, C, device=dev, dtype=torch.float32)
+    _lib.call("coati_mlp_fwd", ptr(x), x.stride(0), ptr(gamma), ptr(beta), ptr(W1), W1.stride(0), ptr(b1), ptr(W2), W2.stride(0),
+              ptr(b2), M, C, Hd, ptr(a), C, ptr(mean), ptr(rstd), ptr(g), ptr(dg), Hd, ptr(out), C, stream())
+    return out, a, mean, rstd, g, dg
+
+
+def mlp_dgrad(dY, W2T, W1T, dgelu):
+    """chained dh = (dY W2) * dgelu ; dA = dh W1 (C = 256).  W2T [Hd, C], W1T [C, Hd].  Returns (dA bf16, dh bf16)."""
+    _need_cuda(dY, W2T, W1T, dgelu)
+    M, C = dY.shape
+    Hd = W2T.shape[0]
+    dh = torch.empty(M, Hd, device=dY.device, dtype=torch.bfloat16)
+    dA = torch.empty(M, C, device=dY.device, dtype=torch.bfloat16)
+    _lib.call("coati_mlp_dgrad", ptr(dY), dY.stride(0), ptr(W2T), W2T.stride(0), ptr(W1T), W1T.stride(0), ptr(dgelu), M, C, Hd,
+              ptr(dh), Hd, ptr(dA), C, stream())
+    return dA, dh

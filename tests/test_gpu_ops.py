@@ -273,3 +273,41 @@ def test_barlow_train_step_runs():
     eng.train_step(dev, up.to(DEV), lr=1e-3, head="barlow")
     L = eng.losses()
     assert torch.isfinite(eng.grads).all() and L["grad_norm"] > 0 and float(eng.barlow_loss) > 0
+
+
+@pytest.mark.parametrize("M,Hd", [(37, 64), (160, 1024), (1000, 1024), (40003, 1024), (323, 2048)])
+def test_mlp_chain(ops, M, Hd):
+    """gemm_mlp.hip: the chained forward LayerNorm -> W1 -> NewGELU (+ derivative) -> W2 -> residual and the chained
+    input-gradient products, against fp32 torch on the same bf16-rounded operands (ragged last 16-row slab and last
+    160-row workgroup, 2 .. 64 hidden chunks).  ASYMMETRIC random weights: a swapped row / column in either transposed
+    product would show."""
+    C = 256
+    g = torch.Generator().manual_seed(M + Hd)
+    x = (torch.randn(M, C, generator=g) * 1.3 + 0.2).to(DEV)
+    gamma = (1.0 + 0.1 * torch.randn(C, generator=g)).to(DEV); beta = (0.1 * torch.randn(C, generator=g)).to(DEV)
+    W1 = (torch.randn(Hd, C, generator=g) * 0.06).to(DEV).bfloat16(); b1 = (0.2 * torch.randn(Hd, generator=g)).to(DEV)
+    W2 = (torch.randn(C, Hd, generator=g) * 0.04).to(DEV).bfloat16(); b2 = (0.2 * torch.randn(C, generator=g)).to(DEV)
+    out, a, mean, rstd, gh, dg = ops.mlp_fwd(x, gamma, beta, W1, b1, W2, b2)
+    torch.cuda.synchronize()
+    xr = x.cpu()
+    a_ref = torch.nn.functional.layer_norm(xr, (C,), gamma.cpu(), beta.cpu(), 1e-5)
+    check(f"mlp chain a M{M} Hd{Hd}", a.float().cpu(), a_ref, TB)
+    check(f"mlp chain mean M{M}", mean.cpu(), xr.mean(1), 4e-6)
+    check(f"mlp chain rstd M{M}", rstd.cpu(), 1.0 / torch.sqrt(xr.var(1, unbiased=False) + 1e-5), 4e-6)
+    ab = a.float().cpu()                               # the kernel's own rounded operand
+    pre = (ab @ W1.float().cpu().t() + b1.cpu()).requires_grad_(True)
+    gref = gelu(pre)
+    gref.sum().backward()
+    check(f"mlp chain g M{M} Hd{Hd}", gh.float().cpu(), gref.detach(), TB)
+    check(f"mlp chain dgelu M{M} Hd{Hd}", dg.float().cpu(), pre.grad, TB)
+    out_ref = xr + gh.float().cpu() @ W2.float().cpu().t() + b2.cpu()
+    check(f"mlp chain out M{M} Hd{Hd}", out.cpu(), out_ref, 2e-6)
+    # backward chain
+    dY = (torch.randn(M, C, generator=g) * 0.5).to(DEV).bfloat16()
+    W2T = W2.t().contiguous(); W1T = W1.t().contiguous()
+    dA, dh = ops.mlp_dgrad(dY, W2T, W1T, dg)
+    torch.cuda.synchronize()
+    dh_ref = (dY.float().cpu() @ W2.float().cpu()) * dg.float().cpu()
+    check(f"mlp chain dh M{M} Hd{Hd}", dh.float().cpu(), dh_ref, TB)
+    dA_ref = dh.float().cpu() @ W1.float().cpu()
+    check(f"mlp chain dA M{M} Hd{Hd}", dA.float().cpu(), dA_ref, TB)
