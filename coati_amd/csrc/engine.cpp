@@ -64,7 +64,8 @@ struct XPass {  // saved activations of one transformer pass
   std::vector<float*> x;      // L+1 residual-stream snapshots [M,C]
   std::vector<float*> xmid;   // L
   std::vector<float*> mean1, rstd1, mean2, rstd2, lse;
-  std::vector<bf16_t*> a1, qkv, y, a2, hpre, g;
+  std::vector<bf16_t*> a1, qkv, y, a2, g;
+  std::vector<unsigned char*> hpre;   // NewGELU'(pre-activation) as 8-bit fixed point (common.h packq8)
   float *meanf, *rstdf, *xf32;
   bf16_t* af;
 };
@@ -344,7 +345,8 @@ int gemm(coati_engine* e, int site, const void* A, int a_f32, int64_t lda, const
   const bool out32 = (epi == EPI_F32 || epi == EPI_RES_F32 || epi == EPI_ACC_F32);
   double bytes = (double)M * K * (a_f32 ? 4 : 2) + (double)N * K * 2 + (double)M * N * (out32 ? 4 : 2);
   if (epi == EPI_RES_F32 || epi == EPI_ACC_F32) bytes += (double)M * N * 4;
-  if (epi == EPI_GELU || epi == EPI_SILU || epi == EPI_DGELU || epi == EPI_DSILU || epi == EPI_GELU_GRAD || epi == EPI_MUL_AUX) bytes += (double)M * N * 2;
+  if (epi == EPI_GELU || epi == EPI_SILU || epi == EPI_DGELU || epi == EPI_DSILU) bytes += (double)M * N * 2;
+  if (epi == EPI_GELU_GRAD || epi == EPI_MUL_AUX) bytes += (double)M * N;   // the saved NewGELU' is one byte per element
   ProfScope ps(e, site, 2.0 * M * N * K, s, bytes);
   return launch_gemm_nt(a, a_f32, epi, s);
 }
@@ -378,7 +380,7 @@ void carve_pass(coati_engine* e, Arena& ar, XPass& p, int B, int T) {
     p.qkv[l] = ar.take<bf16_t>(M * 3 * C);
     p.y[l] = ar.take<bf16_t>(M * C);
     p.a2[l] = ar.take<bf16_t>(M * C);
-    p.hpre[l] = ar.take<bf16_t>(M * 4 * C);
+    p.hpre[l] = ar.take<unsigned char>(M * 4 * C);
     p.g[l] = ar.take<bf16_t>(M * 4 * C);
   }
   p.meanf = ar.take<float>(M); p.rstdf = ar.take<float>(M);
@@ -523,7 +525,7 @@ int xformer_fwd(coati_engine* e, XPass& p, const float* injection, hipStream_t s
         ProfScope ps(e, SITE_LN_FWD, 0, s, (double)M * C * 6 + (double)M * 8);
         COATI_TRY(launch_layernorm_fwd(p.xmid[l], C, e->P + w.ln2w, e->P + w.ln2b, p.a2[l], C, nullptr, 0, p.mean2[l], p.rstd2[l], M, C, s));
       }
-      ProfScope ps(e, SITE_FC1_FWD, 2.0 * M * 4 * C * C, s, (double)M * C * (fuse ? 6 : 2) + 4.0 * C * C * 2 + (double)M * 4 * C * 4);
+      ProfScope ps(e, SITE_FC1_FWD, 2.0 * M * 4 * C * C, s, (double)M * C * (fuse ? 6 : 2) + 4.0 * C * C * 2 + (double)M * 4 * C * 3);
       COATI_TRY(launch_gemm_nt(a, 0, EPI_GELU_GRAD, s));
     }
     COATI_TRY(gemm(e, SITE_FC2_FWD, p.g[l], 0, 4 * C, e->S + w.fc2w, 4 * C, M, C, 4 * C, p.x[l + 1], C, e->P + w.fc2b, EPI_RES_F32, p.xmid[l], nullptr, C, s));

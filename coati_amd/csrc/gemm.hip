@@ -220,8 +220,12 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_nt_kernel(GemmArgs p) {
         pre[i].f0 = *reinterpret_cast<const float4*>(src);
         pre[i].f1 = *reinterpret_cast<const float4*>(src + 4);
       }
-      if constexpr (PRE_B16)
+      if constexpr (EPI == EPI_MUL_AUX) {   // 8 one-byte codes
+        const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned char*>(p.aux_in) + (long long)row * p.ld_aux + col0);
+        pre[i].h = make_uint4(u.x, u.y, 0, 0);
+      } else if constexpr (PRE_B16) {
         pre[i].h = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(p.aux_in) + (long long)row * p.ld_aux + col0);
+      }
     }
   }
 #pragma unroll

@@ -21,6 +21,7 @@ __device__ __forceinline__ void epilogue8(const GemmArgs& p, int row, int col0, 
   // staged: optional operand the caller pre-staged (in LDS) so that the epilogue issues no global load for it:
   //   EPI_QKV_ROPE       -> float[16] = [8 cos | 8 sin] of this row's token position (instead of the global tables)
   //   EPI_DGELU / DSILU  -> uint4 = the 8 saved pre-activations aux_in[row, col0..col0+7]
+  //   EPI_MUL_AUX        -> uint2 = the 8 saved 8-bit NewGELU' codes aux_in[row, col0..col0+7]
   //   EPI_EDGE_DPRE      -> float[8 + ...]: staged[e] = w1c of column col0+e, staged[64 + e] = b1 of column col0+e
   //   EPI_RES_F32        -> float4[2] = aux_in[row, col0..col0+7];   EPI_ACC_F32 -> float4[2] = C[row, col0..col0+7]
   const float* rope_row = (EPI == EPI_QKV_ROPE) ? reinterpret_cast<const float*>(staged) : nullptr;
@@ -119,7 +120,7 @@ __device__ __forceinline__ void epilogue8(const GemmArgs& p, int row, int col0, 
       o[e] = rot ? r : v[e];
     }
   } else if (EPI == EPI_GELU_GRAD) {
-    bf16_t* X = reinterpret_cast<bf16_t*>(p.aux_out);
+    unsigned char* X = reinterpret_cast<unsigned char*>(p.aux_out);   // NewGELU' as 8-bit fixed point (common.h, packq8)
     float d[8];
 #pragma unroll
     for (int e = 0; e < 8; e += 2) {
@@ -129,9 +130,9 @@ __device__ __forceinline__ void epilogue8(const GemmArgs& p, int row, int col0, 
       d[e] = dd.x; d[e + 1] = dd.y;
     }
     if (full) {
-      *reinterpret_cast<uint4*>(X + aoff) = pack8(d);
+      *reinterpret_cast<uint2*>(X + aoff) = packq8(d);
     } else {
-      for (int e = 0; e < 8 && col0 + e < N; ++e) X[aoff + e] = f2bf(d[e]);
+      for (int e = 0; e < 8 && col0 + e < N; ++e) X[aoff + e] = q8_one(d[e]);
     }
   } else if (EPI == EPI_GELU || EPI == EPI_SILU) {
     bf16_t* X = reinterpret_cast<bf16_t*>(p.aux_out);
@@ -142,7 +143,21 @@ __device__ __forceinline__ void epilogue8(const GemmArgs& p, int row, int col0, 
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] = (EPI == EPI_GELU) ? gelu_f(v[e]) : silu_f(v[e]);
-  } else if (EPI == EPI_DGELU || EPI == EPI_DSILU || EPI == EPI_MUL_AUX) {
+  } else if (EPI == EPI_MUL_AUX) {
+    const unsigned char* X = reinterpret_cast<const unsigned char*>(p.aux_in);   // 8-bit fixed point written by EPI_GELU_GRAD
+    float x[8];
+    if (pre && pre->have) {
+      unpackq8(make_uint2(pre->h.x, pre->h.y), x);
+    } else if (staged) {
+      unpackq8(*reinterpret_cast<const uint2*>(staged), x);
+    } else if (full) {
+      unpackq8(*reinterpret_cast<const uint2*>(X + aoff), x);
+    } else {
+      for (int e = 0; e < 8; ++e) x[e] = (col0 + e < N) ? dq8_one(X[aoff + e]) : 0.f;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = v[e] * x[e];
+  } else if (EPI == EPI_DGELU || EPI == EPI_DSILU) {
     const bf16_t* X = reinterpret_cast<const bf16_t*>(p.aux_in);
     float x[8];
     if (pre && pre->have) {
@@ -155,7 +170,7 @@ __device__ __forceinline__ void epilogue8(const GemmArgs& p, int row, int col0, 
       for (int e = 0; e < 8; ++e) x[e] = (col0 + e < N) ? bf2f(X[aoff + e]) : 0.f;
     }
 #pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = v[e] * ((EPI == EPI_MUL_AUX) ? x[e] : (EPI == EPI_DGELU) ? dgelu_f(x[e]) : dsilu_f(x[e]));
+    for (int e = 0; e < 8; ++e) o[e] = v[e] * ((EPI == EPI_DGELU) ? dgelu_f(x[e]) : dsilu_f(x[e]));
   } else if (EPI == EPI_CE_BWD) {
     const long long tgt = p.target[row];
     const float cnt = p.scal[1];

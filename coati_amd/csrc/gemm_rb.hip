@@ -153,6 +153,19 @@ __global__ __launch_bounds__(64 * MAXW, 640 / (64 * MAXW)) void gemm_rb256_kerne
   // row (task >> 3), columns (task & 7) * 8 .. +7): the epilogue reads its 16 B back with one ds_read_b128.  The block
   // is consumed after the MFMA phase of the same tile, behind the same vmcnt(0) as the next weight tile.
   auto load_aux = [&](int n0) {
+    if constexpr (EPI == EPI_MUL_AUX) {
+      // one-byte codes: a 16-B DMA piece = 16 columns; piece p = lane + 64 i <-> row p / PPR, columns (p % PPR) * 16 .. +15;
+      // the epilogue task (row, 8-column group cg) reads its 8 B at piece (row * PPR + cg / 2), half cg & 1
+      constexpr int PPR = RB_BN / 16;
+#pragma unroll
+      for (int i = 0; i < 32 * PPR / 64; ++i) {
+        const int pc = lane + 64 * i, row = m0 + pc / PPR, col = n0 + (pc % PPR) * 16;
+        const int rc = row < p.M ? row : p.M - 1, cc = col + 16 <= p.N ? col : 0;
+        const unsigned char* src = reinterpret_cast<const unsigned char*>(p.aux_in) + (long long)rc * p.ld_aux + cc;
+        __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(Xs + i * 1024), 16, 0, 0);
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < 2 * TPH; ++i) {
       const int t = lane + 64 * i, row = m0 + t / CGS, col = n0 + (t % CGS) * 8;
@@ -242,6 +255,7 @@ __global__ __launch_bounds__(64 * MAXW, 640 / (64 * MAXW)) void gemm_rb256_kerne
         const void* staged = nullptr;
         if constexpr (EPI == EPI_QKV_ROPE) staged = Rs + row * 16;
         if constexpr (AUX) staged = Xs + (size_t)(lane + 64 * (TPH * hf + i)) * 16;
+        if constexpr (EPI == EPI_MUL_AUX) staged = Xs + (size_t)(row * (RB_BN / 16) + (cg >> 1)) * 16 + (cg & 1) * 8;
         if constexpr (EDGE) staged = Rs + cg * 8;
         epilogue8<EPI, 1, RB_BN / 8>(q, m0 + row, j * RB_BN + cg * 8, v, (m0 + row) < p.M, j, ntiles, staged);
       };

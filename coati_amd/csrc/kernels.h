@@ -19,8 +19,8 @@ enum CoatiEpi {
   EPI_CE_BWD = 9,      // C(bf16) = (exp(acc - lse[row]) - [col==target[row]]) / count   (0 if target<0)
   EPI_EDGE_DPRE = 10,  // GNN: C(bf16) = acc * SiLU'(Pa[bj] + Pb[bk] + d2*w1c + b1)
   EPI_QKV_ROPE = 11,   // C(bf16) = RoPE(acc + bias) on the q and k column blocks (cols < 2*rope_C), plain on v
-  EPI_GELU_GRAD = 12,  // aux_out(bf16) = NewGELU'(acc + bias) ; C(bf16) = NewGELU(acc + bias): the backward is EPI_MUL_AUX
-  EPI_MUL_AUX = 13,    // C(bf16) = acc * aux_in(bf16)
+  EPI_GELU_GRAD = 12,  // aux_out(u8 fixed point, common.h packq8) = NewGELU'(acc + bias) ; C(bf16) = NewGELU(acc + bias): the backward is EPI_MUL_AUX
+  EPI_MUL_AUX = 13,    // C(bf16) = acc * dequant(aux_in(u8 fixed point))
   EPI_COUNT = 14
 };
 

@@ -39,13 +39,24 @@ def gemm_nt(A, W, bias=None, epi=EPI_BF16, aux_in=None, out=None, n_store=0):
     aux_out = None
     ld_aux = 0
     if epi in (EPI_GELU, EPI_SILU, EPI_GELU_GRAD):
-        aux_out = torch.empty(M, N, device=A.device, dtype=BF16)
+        # EPI_GELU_GRAD saves NewGELU' as 8-bit fixed point (dequantise with dq8 below); EPI_MUL_AUX reads that format
+        aux_out = torch.empty(M, N, device=A.device, dtype=torch.uint8 if epi == EPI_GELU_GRAD else BF16)
         ld_aux = aux_out.stride(0)
     if aux_in is not None:
         ld_aux = aux_in.stride(0)
     _lib.call("coati_gemm_nt", ptr(A), a_f32, A.stride(0), ptr(W), W.stride(0), M, N, K, ptr(out), out.stride(0),
               n_store, ptr(bias), ptr(aux_in), ptr(aux_out), ld_aux, epi, stream())
     return (out, aux_out) if aux_out is not None else out
+
+
+def dq8(q):
+    """value of the 8-bit fixed-point codes the forward MLP saves for NewGELU' (csrc/common.h: q / 200 - 0.13)"""
+    return q.float() / 200.0 - 0.13
+
+
+def q8(d):
+    """codes of values in [-0.13, 1.145] (round to nearest, saturating)"""
+    return torch.clamp(torch.round(d.float() * 200.0 + 26.0), 0, 255).to(torch.uint8)
 
 
 def wgrad(A, Bm, dW, dbias=None, n_out=0):

@@ -7,7 +7,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-from tests.gpu_util import check, rbf, log  # noqa: E402
+from tests.gpu_util import check, log, rbf, log  # noqa: E402
 
 DEV = "cuda:0"
 # stated tolerances = at most 2x the worst error measured on the MI355X (gpurun_out/test_report.txt, round 2)
@@ -61,13 +61,20 @@ def test_gemm_epilogues(ops, M, N, K):
         (dg,) = torch.autograd.grad(gelu(xg).sum(), xg)
         c = ops.gemm_nt(Ab, Wb, None, ops.EPI_DGELU, aux_in=x.bfloat16())
         check(f"gemm dgelu {M}x{N}x{K}", c.float(), (A @ W.t()) * dg, TB)
-        c = ops.gemm_nt(Ab, Wb, None, ops.EPI_MUL_AUX, aux_in=x.bfloat16())
-        check(f"gemm mul_aux {M}x{N}x{K}", c.float(), (A @ W.t()) * x, TB)
+        # EPI_MUL_AUX multiplies by the saved NewGELU' in its 8-bit fixed-point format (codes over the whole range incl. 0, 255)
+        xq = ops.q8(torch.rand(M, N, generator=g) * 1.275 - 0.13).to(DEV)
+        xq[0, 0], xq[0, 1] = 0, 255
+        c = ops.gemm_nt(Ab, Wb, None, ops.EPI_MUL_AUX, aux_in=xq)
+        check(f"gemm mul_aux {M}x{N}x{K}", c.float(), (A @ W.t()) * ops.dq8(xq), TB)
         rg = ref.clone().requires_grad_(True)
         (dref,) = torch.autograd.grad(gelu(rg).sum(), rg)
         c, dact = ops.gemm_nt(Ab, Wb, bias, ops.EPI_GELU_GRAD)
         check(f"gemm gelu_grad h {M}x{N}x{K}", c.float(), gelu(ref), TB)
-        check(f"gemm gelu_grad d {M}x{N}x{K}", dact.float(), dref, TB)
+        # NewGELU' saved as 8-bit fixed point: half a step (0.0025) of absolute error; 0 and 1 are exact codes
+        assert dact.dtype == torch.uint8
+        qerr = float((ops.dq8(dact) - dref).abs().max())
+        log(f"gemm gelu_grad d {M}x{N}x{K}: max |dequantised - exact| = {qerr:.5f} (half step 0.0025)")
+        assert qerr <= 0.0025 + 2e-5, qerr
         (ds,) = torch.autograd.grad(torch.nn.functional.silu(xg).sum(), xg)
         c = ops.gemm_nt(A, Wb, None, ops.EPI_DSILU, aux_in=x.bfloat16())
         check(f"gemm dsilu(A f32) {M}x{N}x{K}", c.float(), (A @ W.t()) * ds, TB)
