@@ -15,7 +15,9 @@ struct EpiPre {
 
 // CE_LANES: lanes that share one output row of the tile (EPI_CE_PARTIAL reduces across them): 16 for the 128-column
 // tiles of the tiled kernel, 8 for the 64-column tiles of the row-block kernel
-template <int EPI, int ROPE_PARTNER = 1, int CE_LANES = 16>
+// ROPE_HS: 0 = head size read from p.rope_hs at run time; 16 = compiled for head size 16 (row-block kernel: no second DPP
+// permutation, no selects)
+template <int EPI, int ROPE_PARTNER = 1, int CE_LANES = 16, int ROPE_HS = 0>
 __device__ __forceinline__ void epilogue8(const GemmArgs& p, int row, int col0, float (&v)[8], bool rowok,
                                           int tile_n, int tiles_n, const void* staged = nullptr, const EpiPre* pre = nullptr) {
   // staged: optional operand the caller pre-staged (in LDS) so that the epilogue issues no global load for it:
@@ -103,21 +105,35 @@ __device__ __forceinline__ void epilogue8(const GemmArgs& p, int row, int col0, 
     // This lane holds 8 consecutive dims of one head; the RoPE partner (d +- hs/2) sits in lane ^ 1 (head size 16) or
     // lane ^ 2 (head size 32): a DPP quad permutation (one VALU op), not a ds_bpermute through the LDS pipe.
     // RotaryEmbedding.rotary_embed (basic_transformer.py:83-100): y_i = x_i c_i - x_{i+h} s_i ; y_{i+h} = x_{i+h} c_i + x_i s_i
-    const bool hs32 = p.rope_hs == 32;
+    const bool hs32 = (ROPE_HS == 16) ? false : p.rope_hs == 32;
     const bool hi_half = (col0 & (hs32 ? 16 : 8)) != 0;
-    const int t = p.rope_pos ? *p.rope_pos : row % p.rope_T;
     const bool rot = col0 < 2 * p.rope_C;
-    const int tab = hs32 ? t * 32 + (col0 & 8) : t * 16;   // tables are [n_seq, hs] with entries i and i + hs/2 equal
+    if (ROPE_HS == 16 && !rot) {
+      // v block: nothing to rotate (wave-uniform for the row-block kernel: its 64-column tiles never straddle 2C)
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int vi = __builtin_bit_cast(int, v[e]);
-      const float o1 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, vi, 0xB1, 0xF, 0xF, true));   // lane ^ 1
-      const float o2 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, vi, 0x4E, 0xF, 0xF, true));   // lane ^ 2
-      const float other = (ROPE_PARTNER != 1) ? __shfl_xor(v[e], hs32 ? 2 * ROPE_PARTNER : ROPE_PARTNER, 64) : (hs32 ? o2 : o1);
-      const float c = rope_row ? rope_row[e] : p.rope_cos[tab + e];
-      const float s_ = rope_row ? rope_row[8 + e] : p.rope_sin[tab + e];
-      const float r = hi_half ? (v[e] * c + other * s_) : (v[e] * c - other * s_);
-      o[e] = rot ? r : v[e];
+      for (int e = 0; e < 8; ++e) o[e] = v[e];
+    } else {
+      const int t = (rope_row && ROPE_HS == 16) ? 0 : (p.rope_pos ? *p.rope_pos : row % p.rope_T);
+      const int tab = hs32 ? t * 32 + (col0 & 8) : t * 16;   // tables are [n_seq, hs] with entries i and i + hs/2 equal
+      const float sgn = hi_half ? 1.0f : -1.0f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int vi = __builtin_bit_cast(int, v[e]);
+        float other;
+        if (ROPE_PARTNER != 1) {
+          other = __shfl_xor(v[e], hs32 ? 2 * ROPE_PARTNER : ROPE_PARTNER, 64);
+        } else if (ROPE_HS == 16) {
+          other = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, vi, 0xB1, 0xF, 0xF, true));   // lane ^ 1
+        } else {
+          const float o1 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, vi, 0xB1, 0xF, 0xF, true));   // lane ^ 1
+          const float o2 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, vi, 0x4E, 0xF, 0xF, true));   // lane ^ 2
+          other = hs32 ? o2 : o1;
+        }
+        const float c = rope_row ? rope_row[e] : p.rope_cos[tab + e];
+        const float s_ = rope_row ? rope_row[8 + e] : p.rope_sin[tab + e];
+        const float r = fmaf(sgn * other, s_, v[e] * c);
+        o[e] = (ROPE_HS == 16 || rot) ? r : v[e];
+      }
     }
   } else if (EPI == EPI_GELU_GRAD) {
     unsigned char* X = reinterpret_cast<unsigned char*>(p.aux_out);   // NewGELU' as 8-bit fixed point (common.h, packq8)

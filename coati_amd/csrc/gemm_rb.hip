@@ -257,7 +257,7 @@ __global__ __launch_bounds__(64 * MAXW, 640 / (64 * MAXW)) void gemm_rb256_kerne
         if constexpr (AUX) staged = Xs + (size_t)(lane + 64 * (TPH * hf + i)) * 16;
         if constexpr (EPI == EPI_MUL_AUX) staged = Xs + (size_t)(row * (RB_BN / 16) + (cg >> 1)) * 16 + (cg & 1) * 8;
         if constexpr (EDGE) staged = Rs + cg * 8;
-        epilogue8<EPI, 1, RB_BN / 8>(q, m0 + row, j * RB_BN + cg * 8, v, (m0 + row) < p.M, j, ntiles, staged);
+        epilogue8<EPI, 1, RB_BN / 8, 16>(q, m0 + row, j * RB_BN + cg * 8, v, (m0 + row) < p.M, j, ntiles, staged);
       };
       // light epilogues run both tasks interleaved; the heavy ones (activation maths, extra operands) one after the
       // other, or their temporaries spill (the kernel lives at the 168-VGPR limit of 3 waves per SIMD)

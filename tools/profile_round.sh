@@ -1,8 +1,8 @@
 #!/bin/bash
-# Round artefacts, run on the GPU box from the repo root (gpurun):  bash tools/profile_round.sh r01
+# Round artefacts, run on the GPU box from the repo root (gpurun):  bash tools/profile_round.sh r02
 # Writes everything under gpurun_out/<tag>_*; copy what should be judged into profiles/.
 set -u
-TAG=${1:-r01}
+TAG=${1:-r02}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out
 mkdir -p $OUT
@@ -11,10 +11,14 @@ python $R/bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
 python $R/bench.py --steps 10 --warmup 3 --all-sites --no-cpu-baseline > $OUT/${TAG}_bench_nocpu.json 2> $OUT/${TAG}_bench_sites.txt
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof -o bench -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/${TAG}_bench_under_rocprof.json 2> /dev/null
 cp $(find $OUT/${TAG}_prof -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_bench_kernel_stats.csv
-# PMC passes (counters only with --kernel-trace; one counter group per pass)
+# HBM traffic of the dominant kernel from PMC passes over THE BENCH COMMAND itself (counters only with --kernel-trace; one
+# counter per pass): the grouped weight-gradient launch (wgrad_dma_table_kernel: 2 launches per step)
+export PMC_COMMAND="rocprofv3 --pmc <FETCH_SIZE|WRITE_SIZE> --kernel-trace -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline (round $TAG)"
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_$c -- python $R/tools/prof_wgrad.py > /dev/null 2>&1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_$c -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
 done
-python $R/tools/pmc_to_json.py xf_wgrad wgrad_dma_kernel $(find $OUT/${TAG}_pmc_FETCH_SIZE $OUT/${TAG}_pmc_WRITE_SIZE -name "*counter_collection.csv") > $OUT/${TAG}_pmc_summary.json
+python $R/tools/pmc_to_json.py xf_wgrad wgrad_dma_table_kernel $(find $OUT/${TAG}_pmc_FETCH_SIZE $OUT/${TAG}_pmc_WRITE_SIZE -name "*counter_collection.csv") > $OUT/${TAG}_pmc_summary.json
 python $R/tools/gemm_bench.py > $OUT/${TAG}_gemm_microbench.txt 2>&1
-tail -3 $OUT/${TAG}_bench.json; cat $OUT/${TAG}_pmc_summary.json; head -12 $OUT/${TAG}_bench_kernel_stats.csv
+python $R/tools/mlp_bench.py > $OUT/${TAG}_mlp_chain_bench.txt 2>&1
+python $R/tools/cpu_baseline_full.py > $OUT/${TAG}_cpu_baseline_full.json 2> /dev/null
+tail -3 $OUT/${TAG}_bench.json; cat $OUT/${TAG}_pmc_summary.json; head -12 $OUT/${TAG}_bench_kernel_stats.csv; cat $OUT/${TAG}_cpu_baseline_full.json
