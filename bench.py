@@ -163,6 +163,7 @@ def main():
                     help="grande_closed = the headline workload; coati2_shape = d=512 / head size 32 / 12 layers (bf16, extra)")
     ap.add_argument("--head", choices=["infonce", "barlow"], default="infonce",
                     help="contrastive head: infonce = grande_closed (the headline metric); barlow = barlow_closed (configs[3])")
+    ap.add_argument("--gnn-layers", type=int, default=-1, help="experiment only: override the number of E(3)-GNN layers (the line is then NOT the headline metric)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -208,7 +209,9 @@ def main():
     from coati_amd.synthetic import make_batch
     from coati_amd import distributed as D
 
-    MODEL = GRANDE if args.config == "grande_closed" else COATI2_SHAPE
+    MODEL = dict(GRANDE if args.config == "grande_closed" else COATI2_SHAPE)
+    if args.gnn_layers >= 0:
+        MODEL["n_layer_e3gnn"] = args.gnn_layers
     eng = Engine(ModelConfig(**MODEL), dev)
     # random-init weights of the grande architecture (no network for checkpoints): N(0, 0.02)-style init
     g = torch.Generator(device="cpu").manual_seed(0)
@@ -314,7 +317,8 @@ def main():
                     "frac": round(tflops / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_source, "avg_launch_ms": round(avg_ms, 5), "launches": site_n,
                     "bytes_per_launch": site_bytes, "flops_per_launch": site_flops}
         out = {
-            "metric": "molecules/sec (contrastive+AR train step), " + (args.config if args.config != "grande_closed" else ("grande_closed" if args.head == "infonce" else "barlow_closed")),
+            "metric": "molecules/sec (contrastive+AR train step), " + (args.config if args.config != "grande_closed" else ("grande_closed" if args.head == "infonce" else "barlow_closed"))
+                      + (f" [EXPERIMENT: {args.gnn_layers} GNN layers]" if args.gnn_layers >= 0 else ""),
             "value": round(mols / dt, 2),
             "unit": "molecules/s",
             "n_gpus": world,

@@ -123,6 +123,9 @@ struct coati_engine {
   std::vector<bf16_t*> g_hcat, g_P, g_e1, g_s2, g_upre, g_t;
   bf16_t *g_hfin16, *g_dpre, *g_td;
   float *g_mask, *g_d2, *g_w, *g_o, *g_o2;
+  // compacted edge list (gnn.hip launch_gnn_compact): built once per step on the device, length g_ne[0] never visits the host
+  int *g_seg, *g_ne, *g_ebj, *g_ebk, *g_erev, *g_pos;
+  float *g_ed2, *g_ew;
   // backward scratch
   float *DX;
   bf16_t *DX16, *g_DO16;
@@ -424,6 +427,8 @@ size_t carve(coati_engine* e, Arena& ar, int B, int T1, int T2, int A, int Bg) {
   }
   e->g_hfin16 = ar.take<bf16_t>(BA * H); e->g_dpre = ar.take<bf16_t>(BA * H); e->g_td = ar.take<bf16_t>(BA * H);
   e->g_mask = ar.take<float>(BA); e->g_d2 = ar.take<float>(Me); e->g_w = ar.take<float>(Me);
+  e->g_seg = ar.take<int>(BA + 1); e->g_ne = ar.take<int>(4); e->g_ebj = ar.take<int>(Me); e->g_ebk = ar.take<int>(Me);
+  e->g_erev = ar.take<int>(Me); e->g_pos = ar.take<int>(Me); e->g_ed2 = ar.take<float>(Me); e->g_ew = ar.take<float>(Me);
   e->g_o = ar.take<float>(BA * H); e->g_o2 = ar.take<float>(BA * H);
   // backward scratch
   e->DX = ar.take<float>(Mmax * C);
@@ -658,18 +663,27 @@ int gnn_fwd(coati_engine* e, const long long* atoms, const float* coords, hipStr
     bf16_t* h16 = Lg > 0 ? e->g_hcat[0] : e->g_hfin16;
     COATI_TRY(launch_gnn_embed(atoms, e->lut_ix, e->lut_iy, e->P + e->gembw, e->P + e->gembb, e->g_h32[0], h16, Lg > 0 ? 2 * H : H, e->g_rstd[0], e->g_mask, BA, H, s));
     COATI_TRY(launch_gnn_geom(coords, e->g_mask, c.msg_cutoff, e->g_d2, e->g_w, B, A, s));
+    // neighbour list of the step (the coordinates do not change across the layers; the reference rebuilds it 5 times)
+    COATI_TRY(launch_gnn_compact(e->g_w, e->g_d2, e->g_seg, e->g_ne, e->g_ebj, e->g_ebk, e->g_erev, e->g_ed2, e->g_ew, e->g_pos, B, A, s));
   }
   for (int l = 0; l < Lg; ++l) {
     const GLayerP& w = e->gl[l];
     COATI_TRY(gemm(e, SITE_GNN_NODE_GEMM, e->g_hcat[l], 0, 2 * H, e->S + w.w1ab, H, BA, 2 * H, H, e->g_P[l], 2 * H, nullptr, EPI_BF16, nullptr, nullptr, 0, s));
     {
       ProfScope ps(e, SITE_GNN_ELEMWISE, 0, s);
-      COATI_TRY(launch_gnn_edge_pre(e->g_P[l], 2 * H, e->g_d2, e->g_w, e->P + w.e0w + 2 * H, 2 * H + 1, e->P + w.e0b, e->g_e1[l], B, A, H, s));
+      COATI_TRY(launch_gnn_edge_pre_c(e->g_P[l], 2 * H, e->g_seg, e->g_ebk, e->g_ed2, e->P + w.e0w + 2 * H, 2 * H + 1, e->P + w.e0b, e->g_e1[l], BA, H, s));
     }
-    COATI_TRY(gemm(e, SITE_GNN_EDGE_GEMM, e->g_e1[l], 0, H, e->S + w.e3w, H, Me, H, H, e->g_s2[l], H, e->P + w.e3b, EPI_BF16, nullptr, nullptr, 0, s));
+    {   // rows = the edges that exist (device-side count); Me only sizes the grid
+      GemmArgs a;
+      memset(&a, 0, sizeof(a));
+      a.m_dev = e->g_ne;
+      a.A = e->g_e1[l]; a.lda = H; a.B = e->S + w.e3w; a.ldb = H; a.M = Me; a.N = H; a.K = H; a.C = e->g_s2[l]; a.ldc = H; a.bias = e->P + w.e3b;
+      ProfScope ps(e, SITE_GNN_EDGE_GEMM, 0, s);
+      COATI_TRY(launch_gemm_nt(a, 0, EPI_BF16, s));
+    }
     {
       ProfScope ps(e, SITE_GNN_ELEMWISE, 0, s);
-      COATI_TRY(launch_gnn_edge_reduce(e->g_s2[l], e->g_w, e->g_hcat[l] + H, 2 * H, B, A, H, s));
+      COATI_TRY(launch_gnn_edge_reduce_c(e->g_s2[l], e->g_seg, e->g_ew, e->g_hcat[l] + H, 2 * H, BA, H, s));
     }
     COATI_TRY(gemm(e, SITE_GNN_NODE_GEMM, e->g_hcat[l], 0, 2 * H, e->S + w.n0w, 2 * H, BA, H, 2 * H, e->g_t[l], H, e->P + w.n0b, EPI_SILU, nullptr, e->g_upre[l], H, s));
     COATI_TRY(gemm(e, SITE_GNN_NODE_GEMM, e->g_t[l], 0, H, e->S + w.n3w, H, BA, H, H, e->g_o, H, e->P + w.n3b, EPI_RES_F32, e->g_h32[l], nullptr, H, s));
@@ -712,21 +726,28 @@ int gnn_bwd(coati_engine* e, const float* dhpoint, hipStream_t s) {
     COATI_TRY(wgrad(e, SITE_GNN_WGRAD, e->g_du, 0, H, e->g_hcat[l], 2 * H, BA, H, 2 * H, e->G + w.n0w, 2 * H, e->G + w.n0b, 0, s));
     {
       ProfScope ps(e, SITE_GNN_ELEMWISE, 0, s);
-      COATI_TRY(launch_gnn_edge_reduce_bwd(e->g_dmi, H, e->g_s2[l], e->g_w, e->g_ds2, B, A, H, s));
+      COATI_TRY(launch_gnn_edge_reduce_bwd_c(e->g_dmi, H, e->g_s2[l], e->g_seg, e->g_ew, e->g_ds2, BA, H, s));
     }
     {
       GemmArgs a;
       memset(&a, 0, sizeof(a));
       a.A = e->g_ds2; a.lda = H; a.B = e->S + w.e3T; a.ldb = H; a.M = Me; a.N = H; a.K = H; a.C = e->g_dpre1; a.ldc = H;
-      a.P = e->g_P[l]; a.ldp = 2 * H; a.d2 = e->g_d2; a.w1c = e->P + w.e0w + 2 * H; a.w1c_stride = 2 * H + 1;
+      a.P = e->g_P[l]; a.ldp = 2 * H; a.d2 = e->g_ed2; a.w1c = e->P + w.e0w + 2 * H; a.w1c_stride = 2 * H + 1;
       a.b1 = e->P + w.e0b; a.natom = A; a.H = H;
-      ProfScope ps(e, SITE_GNN_EDGE_GEMM, 2.0 * Me * H * H, s, (double)Me * H * 4 + (double)H * H * 2);
+      a.m_dev = e->g_ne; a.e_bj = e->g_ebj; a.e_bk = e->g_ebk;
+      ProfScope ps(e, SITE_GNN_EDGE_GEMM, 0, s);
       COATI_TRY(launch_gemm_nt(a, 0, EPI_EDGE_DPRE, s));
     }
-    COATI_TRY(wgrad(e, SITE_GNN_WGRAD, e->g_ds2, 0, H, e->g_e1[l], H, Me, H, H, e->G + w.e3w, H, e->G + w.e3b, 0, s));
+    {
+      WgradArgs a;
+      a.A = e->g_ds2; a.lda = H; a.B = e->g_e1[l]; a.ldb = H; a.M = Me; a.N = H; a.K = H; a.dW = e->G + w.e3w; a.ldw = H; a.dbias = e->G + w.e3b;
+      a.n_out = 0; a.m_dev = e->g_ne;
+      ProfScope ps(e, SITE_GNN_WGRAD, 0, s);
+      COATI_TRY(launch_wgrad(a, 0, s));
+    }
     {
       ProfScope ps(e, SITE_GNN_ELEMWISE, 0, s);
-      COATI_TRY(launch_gnn_edge_pre_bwd(e->g_dpre1, e->g_d2, e->g_dP, 2 * H, e->G + w.e0w + 2 * H, 2 * H + 1, e->G + w.e0b, B, A, H, s));
+      COATI_TRY(launch_gnn_edge_pre_bwd_c(e->g_dpre1, e->g_seg, e->g_erev, e->g_ed2, e->g_dP, 2 * H, e->G + w.e0w + 2 * H, 2 * H + 1, e->G + w.e0b, BA, H, s));
     }
     COATI_TRY(gemm(e, SITE_GNN_NODE_GEMM, e->g_dP, 0, 2 * H, e->S + w.w1abT, 2 * H, BA, H, 2 * H, DO, H, nullptr, EPI_ACC_F32, nullptr, nullptr, 0, s));
     COATI_TRY(wgrad(e, SITE_GNN_WGRAD, e->g_dP, 0, 2 * H, e->g_hcat[l], 2 * H, BA, H, H, e->G + w.e0w, 2 * H + 1, nullptr, 0, s));

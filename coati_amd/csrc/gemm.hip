@@ -109,6 +109,7 @@ __device__ __forceinline__ void mma_ktile(const bf16_t* As, const bf16_t* Bs, in
 // form doubles the resident waves per CU (LDS still allows 2 workgroups) and halves the per-thread epilogue work.
 template <typename AT, typename STAGE_A, int EPI, int WAVES>
 __global__ __launch_bounds__(64 * WAVES, 2) void gemm_nt_kernel(GemmArgs p) {
+  if (p.m_dev) p.M = *p.m_dev;   // data-dependent row count (<= the M the grid was sized for)
   constexpr int NT = 64 * WAVES, MI = 8 / WAVES;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   bf16_t* const lds = reinterpret_cast<bf16_t*>(smem);
@@ -118,6 +119,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_nt_kernel(GemmArgs p) {
   const int wg = xcd_swizzle(blockIdx.x, gridDim.x);
   const int tile_m = wg / tiles_n, tile_n = wg - tile_m * tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
+  if (m0 >= p.M) return;   // (only with m_dev: the grid covers every row otherwise)
   const AT* A = reinterpret_cast<const AT*>(p.A);
 
   // the bias is folded into the accumulator initialisation (lane = output column): no bias loads in the epilogue
@@ -418,6 +420,10 @@ __global__ __launch_bounds__(64 * WAVES, 2) void wgrad_kernel(WgradArgs p, int t
   const int split = wg / tiles, tile = wg - split * tiles;
   const int tile_n = tile / tiles_k, tile_k = tile - tile_n * tiles_k;
   const int n0 = tile_n * BM, k0 = tile_k * BN;
+  if (p.m_dev) {   // data-dependent row count: the splits share the rows that exist
+    p.M = *p.m_dev;
+    chunks_per_split = ((p.M + 63) / 64 + n_splits - 1) / n_splits;
+  }
   const int nchunks = (p.M + 63) / 64;
   const int c_begin = split * chunks_per_split;
   int c_end = c_begin + chunks_per_split;
@@ -786,6 +792,10 @@ __device__ __forceinline__ void wgrad_dma_body(const WgradArgs& p, int tiles_k, 
 template <bool BIAS, int NS>
 __global__ __launch_bounds__(512, 1) void wgrad_dma_kernel(WgradArgs p, int tiles_k, int chunks_per_split, int n_splits) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  if (p.m_dev) {   // data-dependent row count: the splits share the rows that exist
+    p.M = *p.m_dev;
+    chunks_per_split = ((p.M + WD_CH - 1) / WD_CH + n_splits - 1) / n_splits;
+  }
   const int tiles = gridDim.x / n_splits;
   const int wg = xcd_swizzle(blockIdx.x, gridDim.x);
   const int split = wg / tiles, tile = wg - split * tiles;

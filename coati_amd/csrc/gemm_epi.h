@@ -200,10 +200,18 @@ __device__ __forceinline__ void epilogue8(const GemmArgs& p, int row, int col0, 
     }
   } else if (EPI == EPI_EDGE_DPRE) {
     const int A = p.natom, H = p.H;
-    const int bj = row / A, b = row / (A * A), k = row - bj * A;
+    int bj, bk;
+    if (p.e_bj) {   // compacted edge list
+      const int rr = rowok ? row : 0;
+      bj = p.e_bj[rr];
+      bk = p.e_bk[rr];
+    } else {        // dense grid
+      bj = row / A;
+      bk = (row / (A * A)) * A + (row - bj * A);
+    }
     const bf16_t* Pa = p.P + (long long)bj * p.ldp + col0;
-    const bf16_t* Pb = p.P + (long long)(b * A + k) * p.ldp + H + col0;
-    const float d2 = p.d2[row];
+    const bf16_t* Pb = p.P + (long long)bk * p.ldp + H + col0;
+    const float d2 = p.d2[rowok ? row : 0];
     float pa[8], pb[8];
     if (full) {
       unpack8(*reinterpret_cast<const uint4*>(Pa), pa);

@@ -39,6 +39,10 @@ __device__ __forceinline__ void rb_call_restrict(F&& f, int j, const bf16_t* __r
 
 template <int EPI, int RB_BN, int MAXW, bool LN = false>
 __global__ __launch_bounds__(64 * MAXW, 640 / (64 * MAXW)) void gemm_rb256_kernel(GemmArgs p, int W) {
+  if (p.m_dev) {   // data-dependent row count (<= the M the grid was sized for): workgroups past the end leave before any barrier
+    p.M = *p.m_dev;
+    if ((int)blockIdx.x * W * 32 >= p.M) return;
+  }
   constexpr int NACC = RB_BN / 32;                 // 32-column accumulator blocks per wave per tile
   constexpr int RB_TILE_HALFS = RB_BN * RB_K;      // [BN cols][256 k] bf16, unpadded, chunk-swizzled
   constexpr int RB_EPITCH = RB_BN + 4;             // floats per row of the per-wave transpose region

@@ -257,6 +257,7 @@ __global__ __launch_bounds__(64 * RG_WAVES, 1) void gemm_ring256_kernel(GemmArgs
 }
 
 bool gemm_ring256_supported(const GemmArgs& a, int a_f32, int epi) {
+  if (a.m_dev) return false;   // data-dependent row counts: the row-block / tiled kernels read them on the device
   static const bool off = getenv("COATI_NO_RING") != nullptr;   // A/B switch
   if (off || a_f32) return false;
   if (epi != EPI_BF16 && epi != EPI_RES_F32) return false;

@@ -349,6 +349,266 @@ int launch_gnn_edge_pre_bwd(const bf16_t* dpre, const float* d2, bf16_t* dP, lon
   return COATI_OK;
 }
 
+// =====================================================================================================================
+// Compacted edge list: the engine's path.  make_neighborlist (e_gcl_sparse.py:27-77) keeps only the pairs inside the
+// cutoff; the dense [B, A, A] grid above computes every slot (with n ~ U{8..16} atoms per 16-slot molecule and 85 % of the
+// pairs inside 5 A, 56 % of its rows are padding or out of range).  The list is built on the device from the dense weights
+// (w > 0 <=> edge), receiver-major, so that every per-receiver sum is a contiguous segment and nothing is atomic; its
+// length never visits the host (the edge-level GEMMs read it through GemmArgs::m_dev).
+// =====================================================================================================================
+__global__ void gnn_compact_count_kernel(const float* __restrict__ w, int* __restrict__ cnt, int BA, int A) {
+  const int bj = blockIdx.x * blockDim.x + threadIdx.x;
+  if (bj >= BA) return;
+  int n = 0;
+  for (int k = 0; k < A; ++k) n += w[(long long)bj * A + k] > 0.f;
+  cnt[bj] = n;
+}
+// exclusive scan of cnt[0..n) -> seg[0..n], seg[n] = total (one workgroup; n is a few ten thousand)
+__global__ __launch_bounds__(1024) void gnn_scan_kernel(const int* __restrict__ cnt, int* __restrict__ seg, int* __restrict__ total, int n) {
+  __shared__ int part[1024];
+  const int t = threadIdx.x, per = (n + 1023) / 1024;
+  const int lo = t * per, hi = lo + per < n ? lo + per : n;
+  int s = 0;
+  for (int i = lo; i < hi; ++i) s += cnt[i];
+  part[t] = s;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {
+    const int v = t >= off ? part[t - off] : 0;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  int run = part[t] - s;
+  for (int i = lo; i < hi; ++i) { seg[i] = run; run += cnt[i]; }
+  if (t == 1023) { seg[n] = part[1023]; total[0] = part[1023]; }
+}
+__global__ void gnn_compact_fill_kernel(const float* __restrict__ w, const float* __restrict__ d2, const int* __restrict__ seg,
+                                        int* __restrict__ e_bj, int* __restrict__ e_bk, float* __restrict__ e_d2,
+                                        float* __restrict__ e_w, int* __restrict__ pos, int BA, int A) {
+  const int bj = blockIdx.x * blockDim.x + threadIdx.x;
+  if (bj >= BA) return;
+  const int b = bj / A;
+  int e = seg[bj];
+  for (int k = 0; k < A; ++k) {
+    const long long slot = (long long)bj * A + k;
+    const float ww = w[slot];
+    if (ww > 0.f) {
+      e_bj[e] = bj; e_bk[e] = b * A + k; e_d2[e] = d2[slot]; e_w[e] = ww;
+      pos[slot] = e++;
+    }
+  }
+}
+__global__ void gnn_compact_rev_kernel(const int* __restrict__ n_edges, const int* __restrict__ e_bj, const int* __restrict__ e_bk,
+                                       const int* __restrict__ pos, int* __restrict__ e_rev, int A) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_edges[0]) return;
+  const int bj = e_bj[e], bk = e_bk[e];
+  e_rev[e] = pos[(long long)bk * A + (bj % A)];   // slot of (receiver k, sender j): the same molecule, the same distance
+}
+int launch_gnn_compact(const float* w_dense, const float* d2_dense, int* seg, int* n_edges, int* e_bj, int* e_bk, int* e_rev,
+                       float* e_d2, float* e_w, int* pos, int B, int A, hipStream_t s) {
+  COATI_CHECK_ARG(w_dense && d2_dense && seg && n_edges && e_bj && e_bk && e_rev && e_d2 && e_w && pos, "gnn_compact: null operand");
+  const int BA = B * A;
+  // the per-receiver counts are parked in e_rev (B*A*A ints, rewritten by the last pass)
+  hipLaunchKernelGGL(gnn_compact_count_kernel, dim3(cdiv(BA, 256)), dim3(256), 0, s, w_dense, e_rev, BA, A);
+  hipLaunchKernelGGL(gnn_scan_kernel, dim3(1), dim3(1024), 0, s, e_rev, seg, n_edges, BA);
+  hipLaunchKernelGGL(gnn_compact_fill_kernel, dim3(cdiv(BA, 256)), dim3(256), 0, s, w_dense, d2_dense, seg, e_bj, e_bk, e_d2, e_w, pos, BA, A);
+  hipLaunchKernelGGL(gnn_compact_rev_kernel, dim3(cdiv((long long)BA * A, 256)), dim3(256), 0, s, n_edges, e_bj, e_bk, pos, e_rev, A);
+  COATI_LAUNCH_CHECK("gnn_compact");
+  return COATI_OK;
+}
+
+// edge layer 1 on the list: one wave per receiver, looping over its segment
+__global__ __launch_bounds__(256) void gnn_edge_pre_c_kernel(const bf16_t* __restrict__ P, long long ldp, const int* __restrict__ seg,
+                                                             const int* __restrict__ e_bk, const float* __restrict__ e_d2,
+                                                             const float* __restrict__ w1c, long long w1c_stride,
+                                                             const float* __restrict__ b1, bf16_t* __restrict__ e1, int BA, int H) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int bj = blockIdx.x * 4 + wave;
+  if (bj >= BA) return;
+  const int e0 = seg[bj], n = seg[bj + 1] - e0;
+  // the segment's sender rows and distances: one coalesced load per wave, broadcast with readlane (n <= 63)
+  const int my_bk = lane < n ? e_bk[e0 + lane] : 0;
+  const float my_d2 = lane < n ? e_d2[e0 + lane] : 0.f;
+  for (int c = lane * 4; c < H; c += 256) {
+    const uint2 ua = *reinterpret_cast<const uint2*>(P + (long long)bj * ldp + c);
+    const float pa[4] = {bflo(ua.x), bfhi(ua.x), bflo(ua.y), bfhi(ua.y)};
+    float wc[4], bb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { wc[i] = w1c[(long long)(c + i) * w1c_stride]; bb[i] = b1[c + i]; }
+    for (int i0 = 0; i0 < n; i0 += 4) {
+      uint2 ub[4];
+      float dd[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + u < n ? i0 + u : n - 1;
+        const int bk = __builtin_amdgcn_readlane(my_bk, i);
+        dd[u] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_d2), i));
+        ub[u] = *reinterpret_cast<const uint2*>(P + (long long)bk * ldp + H + c);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (i0 + u >= n) break;
+        const float pb[4] = {bflo(ub[u].x), bfhi(ub[u].x), bflo(ub[u].y), bfhi(ub[u].y)};
+        float o[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = silu_f(pa[i] + pb[i] + dd[u] * wc[i] + bb[i]);
+        *reinterpret_cast<uint2*>(e1 + (long long)(e0 + i0 + u) * H + c) = make_uint2(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]));
+      }
+    }
+  }
+}
+int launch_gnn_edge_pre_c(const bf16_t* P, long long ldp, const int* seg, const int* e_bk, const float* e_d2, const float* w1c,
+                          long long w1c_stride, const float* b1, bf16_t* e1, int BA, int H, hipStream_t s) {
+  COATI_CHECK_ARG(P && seg && e_bk && e_d2 && w1c && b1 && e1, "gnn_edge_pre_c: null operand");
+  COATI_CHECK_SHAPE(H % 4 == 0 && ldp % 4 == 0, "gnn_edge_pre_c: alignment");
+  hipLaunchKernelGGL(gnn_edge_pre_c_kernel, dim3(cdiv(BA, 4)), dim3(256), 0, s, P, ldp, seg, e_bk, e_d2, w1c, w1c_stride, b1, e1, BA, H);
+  COATI_LAUNCH_CHECK("gnn_edge_pre_c");
+  return COATI_OK;
+}
+
+// mi[bj,:] = sum over the receiver's segment of SiLU(s2[e,:]) * w[e]
+__global__ __launch_bounds__(256) void gnn_edge_reduce_c_kernel(const bf16_t* __restrict__ s2, const int* __restrict__ seg,
+                                                                const float* __restrict__ e_w, bf16_t* __restrict__ mi,
+                                                                long long ldmi, int BA, int H) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int bj = blockIdx.x * 4 + wave;
+  if (bj >= BA) return;
+  const int e0 = seg[bj], n = seg[bj + 1] - e0;
+  const float my_w = lane < n ? e_w[e0 + lane] : 0.f;
+  for (int c = lane * 4; c < H; c += 256) {
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int i0 = 0; i0 < n; i0 += 4) {
+      uint2 u[4];
+      float ww[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int i = i0 + q < n ? i0 + q : n - 1;
+        ww[q] = i0 + q < n ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_w), i)) : 0.f;
+        u[q] = *reinterpret_cast<const uint2*>(s2 + (long long)(e0 + i) * H + c);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        acc[0] += silu_f(bflo(u[q].x)) * ww[q]; acc[1] += silu_f(bfhi(u[q].x)) * ww[q];
+        acc[2] += silu_f(bflo(u[q].y)) * ww[q]; acc[3] += silu_f(bfhi(u[q].y)) * ww[q];
+      }
+    }
+    *reinterpret_cast<uint2*>(mi + (long long)bj * ldmi + c) = make_uint2(pack2bf(acc[0], acc[1]), pack2bf(acc[2], acc[3]));
+  }
+}
+int launch_gnn_edge_reduce_c(const bf16_t* s2, const int* seg, const float* e_w, bf16_t* mi, long long ldmi, int BA, int H, hipStream_t s) {
+  COATI_CHECK_ARG(s2 && seg && e_w && mi, "gnn_edge_reduce_c: null operand");
+  COATI_CHECK_SHAPE(H % 4 == 0 && ldmi % 4 == 0, "gnn_edge_reduce_c: alignment");
+  hipLaunchKernelGGL(gnn_edge_reduce_c_kernel, dim3(cdiv(BA, 4)), dim3(256), 0, s, s2, seg, e_w, mi, ldmi, BA, H);
+  COATI_LAUNCH_CHECK("gnn_edge_reduce_c");
+  return COATI_OK;
+}
+
+// ds2[e,:] = dmi[receiver(e),:] * w[e] * SiLU'(s2[e,:])
+__global__ __launch_bounds__(256) void gnn_edge_reduce_bwd_c_kernel(const bf16_t* __restrict__ dmi, long long lddmi,
+                                                                    const bf16_t* __restrict__ s2, const int* __restrict__ seg,
+                                                                    const float* __restrict__ e_w, bf16_t* __restrict__ ds2, int BA, int H) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int bj = blockIdx.x * 4 + wave;
+  if (bj >= BA) return;
+  const int e0 = seg[bj], n = seg[bj + 1] - e0;
+  const float my_w = lane < n ? e_w[e0 + lane] : 0.f;
+  for (int c = lane * 4; c < H; c += 256) {
+    const uint2 ug = *reinterpret_cast<const uint2*>(dmi + (long long)bj * lddmi + c);
+    const float g[4] = {bflo(ug.x), bfhi(ug.x), bflo(ug.y), bfhi(ug.y)};
+    for (int i0 = 0; i0 < n; i0 += 4) {
+      uint2 u[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) u[q] = *reinterpret_cast<const uint2*>(s2 + (long long)(e0 + (i0 + q < n ? i0 + q : n - 1)) * H + c);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (i0 + q >= n) break;
+        const float ww = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_w), i0 + q));
+        *reinterpret_cast<uint2*>(ds2 + (long long)(e0 + i0 + q) * H + c) =
+            make_uint2(pack2bf(g[0] * ww * dsilu_f(bflo(u[q].x)), g[1] * ww * dsilu_f(bfhi(u[q].x))),
+                       pack2bf(g[2] * ww * dsilu_f(bflo(u[q].y)), g[3] * ww * dsilu_f(bfhi(u[q].y))));
+      }
+    }
+  }
+}
+int launch_gnn_edge_reduce_bwd_c(const bf16_t* dmi, long long lddmi, const bf16_t* s2, const int* seg, const float* e_w,
+                                 bf16_t* ds2, int BA, int H, hipStream_t s) {
+  COATI_CHECK_ARG(dmi && s2 && seg && e_w && ds2, "gnn_edge_reduce_bwd_c: null operand");
+  COATI_CHECK_SHAPE(H % 4 == 0 && lddmi % 4 == 0, "gnn_edge_reduce_bwd_c: alignment");
+  hipLaunchKernelGGL(gnn_edge_reduce_bwd_c_kernel, dim3(cdiv(BA, 4)), dim3(256), 0, s, dmi, lddmi, s2, seg, e_w, ds2, BA, H);
+  COATI_LAUNCH_CHECK("gnn_edge_reduce_bwd_c");
+  return COATI_OK;
+}
+
+// backward of the gather-add on the list: dPa[bj] = sum over the receiver's segment of dpre[e]; dPb[bj] = the same sum over
+// the REVERSE edges (sender bj: rows e_rev[e]), dw1c += sum dpre[e] d2[e], db1 += sum dpre[e].  Persistent workgroups: the
+// two column sums stay in registers across receivers, one atomic per channel and workgroup.
+__global__ __launch_bounds__(256) void gnn_edge_pre_bwd_c_kernel(const bf16_t* __restrict__ dpre, const int* __restrict__ seg,
+                                                                 const int* __restrict__ e_rev, const float* __restrict__ e_d2,
+                                                                 bf16_t* __restrict__ dP, long long lddp, float* __restrict__ dw1c,
+                                                                 long long dw1c_stride, float* __restrict__ db1, int BA, int H) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int c = lane * 4; c < H; c += 256) {
+    float sw[4] = {0.f, 0.f, 0.f, 0.f}, sb[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int bj = blockIdx.x * 4 + wave; bj < BA; bj += gridDim.x * 4) {
+      const int e0 = seg[bj], n = seg[bj + 1] - e0;
+      const int my_rev = lane < n ? e_rev[e0 + lane] : 0;
+      const float my_d2 = lane < n ? e_d2[e0 + lane] : 0.f;
+      float a[4] = {0.f, 0.f, 0.f, 0.f}, bsum[4] = {0.f, 0.f, 0.f, 0.f};
+      for (int i0 = 0; i0 < n; i0 += 4) {
+        uint2 u[4], r[4];
+        float dd[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const bool ok = i0 + q < n;
+          const int i = ok ? i0 + q : n - 1;
+          const int rv = __builtin_amdgcn_readlane(my_rev, i);
+          dd[q] = ok ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_d2), i)) : 0.f;
+          u[q] = *reinterpret_cast<const uint2*>(dpre + (long long)(e0 + i) * H + c);
+          r[q] = *reinterpret_cast<const uint2*>(dpre + (long long)rv * H + c);
+          if (!ok) { u[q] = make_uint2(0, 0); r[q] = make_uint2(0, 0); }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float x[4] = {bflo(u[q].x), bfhi(u[q].x), bflo(u[q].y), bfhi(u[q].y)};
+#pragma unroll
+          for (int i = 0; i < 4; ++i) { a[i] += x[i]; sw[i] = fmaf(x[i], dd[q], sw[i]); }
+          bsum[0] += bflo(r[q].x); bsum[1] += bfhi(r[q].x); bsum[2] += bflo(r[q].y); bsum[3] += bfhi(r[q].y);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) sb[i] += a[i];
+      *reinterpret_cast<uint2*>(dP + (long long)bj * lddp + c) = make_uint2(pack2bf(a[0], a[1]), pack2bf(a[2], a[3]));
+      *reinterpret_cast<uint2*>(dP + (long long)bj * lddp + H + c) = make_uint2(pack2bf(bsum[0], bsum[1]), pack2bf(bsum[2], bsum[3]));
+    }
+    // column sums: the 4 waves of the workgroup add up through LDS, then ONE atomic per channel and workgroup (thousands of
+    // same-address atomics serialise in the L2: 2048 workgroups x 4 waves made this kernel 1 ms)
+    __shared__ float red[2][4][256];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { red[0][wave][lane * 4 + i] = sw[i]; red[1][wave][lane * 4 + i] = sb[i]; }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int k = lane * 4 + i;
+        atomicAdd(dw1c + (long long)(c + i) * dw1c_stride, red[0][0][k] + red[0][1][k] + red[0][2][k] + red[0][3][k]);
+        atomicAdd(db1 + c + i, red[1][0][k] + red[1][1][k] + red[1][2][k] + red[1][3][k]);
+      }
+    }
+    __syncthreads();
+  }
+}
+int launch_gnn_edge_pre_bwd_c(const bf16_t* dpre, const int* seg, const int* e_rev, const float* e_d2, bf16_t* dP, long long lddp,
+                              float* dw1c, long long dw1c_stride, float* db1, int BA, int H, hipStream_t s) {
+  COATI_CHECK_ARG(dpre && seg && e_rev && e_d2 && dP && dw1c && db1, "gnn_edge_pre_bwd_c: null operand");
+  COATI_CHECK_SHAPE(H % 4 == 0 && lddp % 4 == 0, "gnn_edge_pre_bwd_c: alignment");
+  int blocks = cdiv(BA, 4);
+  if (blocks > 512) blocks = 512;   // 2 resident workgroups per CU, each loops over its receivers: 512 atomics per channel
+  hipLaunchKernelGGL(gnn_edge_pre_bwd_c_kernel, dim3(blocks), dim3(256), 0, s, dpre, seg, e_rev, e_d2, dP, lddp, dw1c, dw1c_stride, db1, BA, H);
+  COATI_LAUNCH_CHECK("gnn_edge_pre_bwd_c");
+  return COATI_OK;
+}
+
 // ---- masked mean readout (e3gnn_clip.py:134-137) and its backward ----------------------------------------------------
 __global__ __launch_bounds__(256) void gnn_readout_kernel(const float* __restrict__ o, const float* __restrict__ mask,
                                                           float* __restrict__ hp, int A, int H) {

@@ -25,6 +25,8 @@ enum CoatiEpi {
 };
 
 struct GemmArgs {
+  const int* m_dev;     // optional: the number of rows that exist, read on the DEVICE (<= M; M then only sizes the grid):
+                        // row counts that are data dependent (the E(3)-GNN's compacted edge list) need no host sync
   const void* A;        // [M,K] row-major, bf16 or f32 (a_f32)
   long long lda;
   const bf16_t* B;      // [N,K] row-major bf16 (NT: C = A * B^T)
@@ -53,6 +55,8 @@ struct GemmArgs {
   const float* b1;
   int natom;
   int H;
+  const int* e_bj;          // compacted edge list: row -> receiver node row / sender node row (null: dense grid, row = (b*A + j)*A + k)
+  const int* e_bk;
   // rotary epilogue: row m is token t = m % rope_T; tables [n_seq, rope_hs] f32; head size rope_hs = 16 or 32 (0 -> 16)
   const float* rope_cos;
   const float* rope_sin;
@@ -117,6 +121,7 @@ struct WgradArgs {
   long long ldw;
   float* dbias;
   int n_out;   // rows of dW that exist (0 -> N); columns of A beyond it must be zero
+  const int* m_dev = nullptr;   // optional: rows that exist, read on the device (<= M)
 };
 int launch_wgrad(const WgradArgs& a, int a_f32, hipStream_t s);
 // Grouped, atomics-free form (gemm.hip, wgrad_dma_table_kernel): one workgroup per 128 x 128 output tile of a list of
@@ -226,6 +231,18 @@ int launch_gnn_edge_reduce_bwd(const bf16_t* dmi, long long lddmi, const bf16_t*
                                int B, int A, int H, hipStream_t s);
 int launch_gnn_edge_pre_bwd(const bf16_t* dpre, const float* d2, bf16_t* dP, long long lddp, float* dw1c,
                             long long dw1c_stride, float* db1, int B, int A, int H, hipStream_t s);
+// Compacted edge list (the reference's neighbour list, e_gcl_sparse.py:27-77, built on the device, no host sync):
+// edges in receiver-major order; seg[bj] .. seg[bj+1] = the edges received by node row bj; e_rev[e] = the edge (k -> j) of
+// edge e = (j -> k) (the edge set is symmetric); n_edges[0] = E.  pos is a B*A*A int scratch.
+int launch_gnn_compact(const float* w_dense, const float* d2_dense, int* seg, int* n_edges, int* e_bj, int* e_bk, int* e_rev,
+                       float* e_d2, float* e_w, int* pos, int B, int A, hipStream_t s);
+int launch_gnn_edge_pre_c(const bf16_t* P, long long ldp, const int* seg, const int* e_bk, const float* e_d2, const float* w1c,
+                          long long w1c_stride, const float* b1, bf16_t* e1, int BA, int H, hipStream_t s);
+int launch_gnn_edge_reduce_c(const bf16_t* s2, const int* seg, const float* e_w, bf16_t* mi, long long ldmi, int BA, int H, hipStream_t s);
+int launch_gnn_edge_reduce_bwd_c(const bf16_t* dmi, long long lddmi, const bf16_t* s2, const int* seg, const float* e_w,
+                                 bf16_t* ds2, int BA, int H, hipStream_t s);
+int launch_gnn_edge_pre_bwd_c(const bf16_t* dpre, const int* seg, const int* e_rev, const float* e_d2, bf16_t* dP, long long lddp,
+                              float* dw1c, long long dw1c_stride, float* db1, int BA, int H, hipStream_t s);
 int launch_gnn_readout(const float* o, const float* mask, float* hp, int B, int A, int H, hipStream_t s);
 int launch_gnn_readout_bwd(const float* dhp, const float* mask, bf16_t* dout, int B, int A, int H, hipStream_t s);
 
