@@ -165,6 +165,10 @@ int coati_gnn_embed(const int64_t* atoms, const int32_t* lut_ix, const int32_t* 
 int coati_gnn_geom(const float* coords, const float* mask, float cutoff, float* d2, float* w, int B, int A, void* stream) {
   return launch_gnn_geom(coords, mask, cutoff, d2, w, B, A, S_(stream));
 }
+int coati_gnn_compact(const float* w_dense, const float* d2_dense, int32_t* seg, int32_t* n_edges, int32_t* e_bj, int32_t* e_bk,
+                      int32_t* e_rev, float* e_d2, float* e_w, int32_t* pos, int B, int A, void* stream) {
+  return launch_gnn_compact(w_dense, d2_dense, seg, n_edges, e_bj, e_bk, e_rev, e_d2, e_w, pos, B, A, S_(stream));
+}
 int coati_gnn_edge_pre(const uint16_t* P, int64_t ldp, const float* d2, const float* w1c, int64_t w1c_stride,
                        const float* b1, uint16_t* e1, int B, int A, int H, void* stream) {
   return launch_gnn_edge_pre(P, ldp, d2, nullptr, w1c, w1c_stride, b1, e1, B, A, H, S_(stream));

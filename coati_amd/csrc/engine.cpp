@@ -139,6 +139,8 @@ struct coati_engine {
   std::vector<bf16_t*> w_dh4, w_dxa, w_dxb, w_dqkv;   // [L]: d(hidden), d x[l+1], d xmid[l], d qkv[l]
   bool wg_group = false;                              // buffers carved (shape and COATI_WGRAD_GROUP allow it)
   WgradTile* d_wtab = nullptr;                        // device tables: WTAB_SLOTS x (L x tiles per layer) entries
+  int* d_wpace = nullptr;                             // pacing epoch counters of the grouped launch: [4 L problems][epochs]
+  int wpace_per = 0;                                  // ints per problem
   int wtab_cap = 0;                                   // entries per slot
   struct WTabKey { const void* pass = nullptr; int lo = -1, hi = -1, M = 0, n = 0; long long sig = 0; };
   WTabKey wtab_key[4];
@@ -459,6 +461,8 @@ size_t carve(coati_engine* e, Arena& ar, int B, int T1, int T2, int A, int Bg) {
       }
       const int tpl = cdiv(3 * C, 128) * cdiv(C, 128) + cdiv(C, 128) * cdiv(C, 128) + 2 * cdiv(4 * C, 128) * cdiv(C, 128);
       e->wtab_cap = L * tpl;
+      e->wpace_per = wgrad_table_pace_ints((int)Mmax);
+      e->d_wpace = ar.take<int>((size_t)4 * L * e->wpace_per);
       WgradTile* t = ar.take<WgradTile>((size_t)4 * e->wtab_cap);
       if (t != e->d_wtab || ar.base != e->wtab_ws) for (auto& k : e->wtab_key) k = coati_engine::WTabKey();
       e->d_wtab = t;
@@ -554,10 +558,11 @@ int xformer_wgrad_group(coati_engine* e, XPass& p, int l_lo, int l_hi, hipStream
   }
   if (slot < 0) {
     std::vector<WgradTile> tab;
+    int prob = 0;
     auto add = [&](const bf16_t* A, int lda, const bf16_t* B, int ldb, int N, int K, int64_t w_off, int64_t b_off) -> int {
       WgradArgs a;
       a.A = A; a.lda = lda; a.B = B; a.ldb = ldb; a.M = M; a.N = N; a.K = K; a.dW = e->G + w_off; a.ldw = K; a.dbias = e->G + b_off; a.n_out = 0;
-      return wgrad_table_append(tab, a);
+      return wgrad_table_append(tab, a, e->d_wpace + (size_t)(prob++) * e->wpace_per);
     };
     for (int l = l_hi - 1; l >= l_lo; --l) {
       const XLayerP& w = e->xl[l];
@@ -578,6 +583,11 @@ int xformer_wgrad_group(coati_engine* e, XPass& p, int l_lo, int l_hi, hipStream
     coati_engine::WTabKey k;
     k.pass = &p; k.lo = l_lo; k.hi = l_hi; k.M = M; k.n = (int)tab.size(); k.sig = sig;
     e->wtab_key[slot] = k;
+  }
+  // the pacing counters of this launch's problems start at zero
+  if (hipMemsetAsync(e->d_wpace, 0, (size_t)4 * (l_hi - l_lo) * e->wpace_per * sizeof(int), s) != hipSuccess) {
+    coati_set_error("wgrad group: counter reset failed");
+    return COATI_EHIP;
   }
   ProfScope ps(e, SITE_XF_WGRAD, flops, s, bytes);
   return launch_wgrad_table(e->d_wtab + (size_t)slot * e->wtab_cap, e->wtab_key[slot].n, s);

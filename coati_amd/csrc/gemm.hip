@@ -547,7 +547,8 @@ template <int S> struct WdSlot { static constexpr int value = S; };
 // plain read-add-stores instead of fp32 atomics (the grouped launch below); the bias partials stay atomic (tiles_k
 // workgroups share a bias slice).
 template <bool BIAS, int NS, bool EXCL>
-__device__ __forceinline__ void wgrad_dma_body(const WgradArgs& p, int tiles_k, int tile, int c_begin, int c_end, unsigned char* smem) {
+__device__ __forceinline__ void wgrad_dma_body(const WgradArgs& p, int tiles_k, int tile, int c_begin, int c_end, unsigned char* smem,
+                                               int* pace = nullptr, int group_size = 0) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int grp = wave >> 2, wm = (wave >> 1) & 1, wn = wave & 1;
   const int tile_n = tile / tiles_k, tile_k = tile - tile_n * tiles_k;
@@ -725,20 +726,46 @@ __device__ __forceinline__ void wgrad_dma_body(const WgradArgs& p, int tiles_k, 
     __builtin_amdgcn_sched_barrier(0);
     if (turn) bias_add();
   };
+  // Pacing (grouped launch): the workgroups of one problem share operand panels through their XCD's L2, but only while they
+  // stream the same rows at about the same time.  Over 1280 stages they drift apart (L2 misses of the launch grew from
+  // 1.10x the operand bytes at 160 stages to 1.71x at 1280: rocprofv3 FETCH_SIZE, profiles/r02_wgrad_traffic.txt), so every
+  // COATI_WG_EPOCH_STAGES stages a workgroup reports the epoch it enters and does not run more than one epoch ahead of the
+  // slowest sibling.  One lane does it: a returnless vector atomic to arrive, scalar loads (lgkmcnt, not vmcnt: the ring's DMA
+  // accounting is untouched) to wait; the other waves are held by the next stage barrier.  Deadlock-free: siblings are
+  // dispatched back to back, and a workgroup waits only for siblings.
+  auto pace_point = [&](int c) __attribute__((always_inline)) {
+    if constexpr (EXCL) {
+      if (pace != nullptr && (c % COATI_WG_EPOCH_STAGES) == 0 && tid == 0) {
+        const int ep = c / COATI_WG_EPOCH_STAGES;
+        __hip_atomic_fetch_add(pace + ep, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (ep > 1) {   // (the first report is made on entering epoch 1)
+          const int* prev = pace + ep - 1;
+          int seen;
+          // bounded: pacing is a performance aid -- if a sibling never shows up the workgroup goes on alone
+          for (int spin = 0; spin < (1 << 16); ++spin) {
+            // the scalar data cache is not coherent with the L2 where the atomics land: invalidate it before every poll
+            asm volatile("s_dcache_inv\n\ts_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(seen) : "s"(prev) : "memory");
+            if (seen >= group_size) break;
+            __builtin_amdgcn_s_sleep(8);
+          }
+        }
+      }
+    }
+  };
   static_assert(NS == 3 || NS == 4, "the main loop is unrolled for ring depths 3 and 4");
   for (int c = c_begin;;) {
     if constexpr (NS == 3) {
-      step(WdSlot<0>(), fa, fb); if (++c >= c_end) break;
-      step(WdSlot<1>(), fb, fa); if (++c >= c_end) break;
-      step(WdSlot<2>(), fa, fb); if (++c >= c_end) break;
-      step(WdSlot<0>(), fb, fa); if (++c >= c_end) break;
-      step(WdSlot<1>(), fa, fb); if (++c >= c_end) break;
-      step(WdSlot<2>(), fb, fa); if (++c >= c_end) break;
+      step(WdSlot<0>(), fa, fb); if (++c >= c_end) break; pace_point(c);
+      step(WdSlot<1>(), fb, fa); if (++c >= c_end) break; pace_point(c);
+      step(WdSlot<2>(), fa, fb); if (++c >= c_end) break; pace_point(c);
+      step(WdSlot<0>(), fb, fa); if (++c >= c_end) break; pace_point(c);
+      step(WdSlot<1>(), fa, fb); if (++c >= c_end) break; pace_point(c);
+      step(WdSlot<2>(), fb, fa); if (++c >= c_end) break; pace_point(c);
     } else {
-      step(WdSlot<0>(), fa, fb); if (++c >= c_end) break;
-      step(WdSlot<1>(), fb, fa); if (++c >= c_end) break;
-      step(WdSlot<2>(), fa, fb); if (++c >= c_end) break;
-      step(WdSlot<3>(), fb, fa); if (++c >= c_end) break;
+      step(WdSlot<0>(), fa, fb); if (++c >= c_end) break; pace_point(c);
+      step(WdSlot<1>(), fb, fa); if (++c >= c_end) break; pace_point(c);
+      step(WdSlot<2>(), fa, fb); if (++c >= c_end) break; pace_point(c);
+      step(WdSlot<3>(), fb, fa); if (++c >= c_end) break; pace_point(c);
     }
   }
   __builtin_amdgcn_s_waitcnt(0x0f70);   // the over-issued (zero-page) DMAs have landed: the ring is free
@@ -816,14 +843,23 @@ __global__ __launch_bounds__(512, 1) void wgrad_dma_table_kernel(const WgradTile
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const WgradTile& d = table[xcd_swizzle(blockIdx.x, gridDim.x)];
   const WgradArgs p = d.p;
-  wgrad_dma_body<BIAS, NS, true>(p, d.tiles_k, d.tile, 0, (p.M + WD_CH - 1) / WD_CH, smem);
+  wgrad_dma_body<BIAS, NS, true>(p, d.tiles_k, d.tile, 0, (p.M + WD_CH - 1) / WD_CH, smem, d.pace, d.group_size);
 }
 
-int wgrad_table_append(std::vector<WgradTile>& tab, const WgradArgs& a) {
+int wgrad_table_pace_ints(int M) { return cdiv(cdiv(M, WD_CH), COATI_WG_EPOCH_STAGES) + 1; }
+
+int wgrad_table_append(std::vector<WgradTile>& tab, const WgradArgs& a, int* pace) {
   COATI_CHECK_ARG(a.A && a.B && a.dW && a.dbias, "wgrad_table: null operand (the grouped kernel is the bias variant)");
   COATI_CHECK_SHAPE(a.M > 0 && a.N % 8 == 0 && a.K % 8 == 0 && a.lda % 8 == 0 && a.ldb % 8 == 0, "wgrad_table: shape / alignment");
   const int tiles_n = cdiv(a.N, BM), tiles_k = cdiv(a.K, BN);
-  for (int t = 0; t < tiles_n * tiles_k; ++t) tab.push_back(WgradTile{a, tiles_k, t});
+  // pacing needs every tile of the problem resident at the same time: at most one XCD's worth (32 CUs)
+  const int n = tiles_n * tiles_k;
+  // COATI_WGRAD_PACE=1 turns the pacing on.  Measured (profiles/r02_wgrad_traffic.txt): L2 misses per launch 18.3 GB -> 10.7 GB
+  // (= the operand bytes, every panel fetched once) but 2.80 -> 3.33 ms: the launch is bound by the L2 -> LDS fill rate of
+  // the CUs (~45 GB/s each, 12 TB/s in aggregate), not by what leaves the L2, and lock-stepping the siblings adds stalls.
+  static const bool want_pace = getenv("COATI_WGRAD_PACE") != nullptr && atoi(getenv("COATI_WGRAD_PACE")) == 1;
+  const bool paced = pace != nullptr && n > 1 && n <= 32 && want_pace;
+  for (int t = 0; t < n; ++t) tab.push_back(WgradTile{a, tiles_k, t, paced ? pace : nullptr, paced ? n : 0});
   return COATI_OK;
 }
 

@@ -408,6 +408,7 @@ __global__ void gnn_compact_rev_kernel(const int* __restrict__ n_edges, const in
 int launch_gnn_compact(const float* w_dense, const float* d2_dense, int* seg, int* n_edges, int* e_bj, int* e_bk, int* e_rev,
                        float* e_d2, float* e_w, int* pos, int B, int A, hipStream_t s) {
   COATI_CHECK_ARG(w_dense && d2_dense && seg && n_edges && e_bj && e_bk && e_rev && e_d2 && e_w && pos, "gnn_compact: null operand");
+  COATI_CHECK_SHAPE(B > 0 && A > 0 && A <= 64, "gnn_compact: at most 64 atoms per molecule (a receiver's segment is broadcast from one wave)");
   const int BA = B * A;
   // the per-receiver counts are parked in e_rev (B*A*A ints, rewritten by the last pass)
   hipLaunchKernelGGL(gnn_compact_count_kernel, dim3(cdiv(BA, 256)), dim3(256), 0, s, w_dense, e_rev, BA, A);

@@ -130,11 +130,18 @@ struct WgradTile {
   WgradArgs p;
   int tiles_k;   // 128-column tiles along K of this problem
   int tile;      // tile index inside the problem (tile_n * tiles_k + tile_k)
+  // pacing of the workgroups that share this problem's operand panels (see wgrad_dma_table_kernel): epoch counters
+  // [COATI_WG_EPOCHS_MAX] of this problem in device memory (zeroed before the launch), and the number of its tiles
+  // (0 = no pacing)
+  int* pace;
+  int group_size;
 };
+#define COATI_WG_EPOCH_STAGES 4                 // 64-row stages per pacing epoch
+int wgrad_table_pace_ints(int M);               // epoch counters one problem needs for M rows
 int launch_wgrad_table(const WgradTile* dev_table, int n_tiles, hipStream_t s);
 #ifdef __cplusplus
 #include <vector>
-int wgrad_table_append(std::vector<WgradTile>& tab, const WgradArgs& a);   // host: appends the problem's tiles
+int wgrad_table_append(std::vector<WgradTile>& tab, const WgradArgs& a, int* pace);   // host: appends the problem's tiles (pace: its epoch counters or null)
 #endif
 
 // C[M,N] (f32) = sum_k A(m,k) B(k,n) [+ bias[n]] [+ C];  A(m,k) = A[m*ars + k*acs], B(k,n) = B[k*brs + n*bcs]

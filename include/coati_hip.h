@@ -166,6 +166,13 @@ int coati_gnn_embed(const int64_t* atoms, const int32_t* lut_ix, const int32_t* 
                     int H, void* stream);
 int coati_gnn_geom(const float* coords, const float* mask, float cutoff, float* d2, float* w, int B, int A,
                    void* stream);
+/* make_neighborlist (e_gcl_sparse.py:27-77) on the device: the dense weights of coati_gnn_geom (w > 0 <=> edge) -> the
+ * compacted, receiver-major edge list the engine's GNN runs on.  seg [B*A + 1]: edges received by node row r are
+ * seg[r] .. seg[r+1]; n_edges[0] = E; e_bj / e_bk [E]: receiver / sender node rows (= Is*A+Js / Is*A+Ks of the reference,
+ * same order); e_rev [E]: index of the reverse edge; e_d2 / e_w [E]: squared distance / cutoff weight; pos: B*A*A int scratch.
+ * All edge arrays must hold B*A*A entries.  No host sync: consumers read n_edges on the device. */
+int coati_gnn_compact(const float* w_dense, const float* d2_dense, int32_t* seg, int32_t* n_edges, int32_t* e_bj, int32_t* e_bk,
+                      int32_t* e_rev, float* e_d2, float* e_w, int32_t* pos, int B, int A, void* stream);
 int coati_gnn_edge_pre(const uint16_t* P, int64_t ldp, const float* d2, const float* w1c, int64_t w1c_stride,
                        const float* b1, uint16_t* e1, int B, int A, int H, void* stream);
 int coati_gnn_edge_reduce(const uint16_t* s2, const float* w, uint16_t* mi, int64_t ldmi, int B, int A, int H,
