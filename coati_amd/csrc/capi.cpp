@@ -20,10 +20,15 @@ int coati_gemm_nt(const void* A, int a_f32, int64_t lda, const uint16_t* B, int6
   return launch_gemm_nt(a, a_f32, epi, S_(stream));
 }
 
-int coati_mlp_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, const uint16_t* W1, int64_t ldw1,
+int coati_mlp_permute_w1(const uint16_t* W1, int64_t ldw, uint16_t* W1p, int64_t ldp, int Hd, int C, void* stream) {
+  return launch_mlp_permute_w1(W1, ldw, W1p, ldp, Hd, C, S_(stream));
+}
+
+int coati_mlp_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, const uint16_t* W1p, int64_t ldw1,
                   const float* b1, const uint16_t* W2, int64_t ldw2, const float* b2, int M, int C, int Hd, uint16_t* a,
-                  int64_t lda, float* mean, float* rstd, uint16_t* g, uint16_t* dg, int64_t ldh, float* out, int64_t ldo,
+                  int64_t lda, float* mean, float* rstd, uint16_t* g, uint8_t* dg, int64_t ldh, float* out, int64_t ldo,
                   void* stream) {
+  const uint16_t* W1 = W1p;
   MlpArgs m;
   memset(&m, 0, sizeof(m));
   m.M = M; m.C = C; m.Hd = Hd; m.x = x; m.ldx = ldx; m.gamma = gamma; m.beta = beta; m.mean = mean; m.rstd = rstd;
@@ -33,7 +38,7 @@ int coati_mlp_fwd(const float* x, int64_t ldx, const float* gamma, const float* 
 }
 
 int coati_mlp_dgrad(const uint16_t* dY, int64_t lddy, const uint16_t* W2T, int64_t ldw2t, const uint16_t* W1T,
-                    int64_t ldw1t, const uint16_t* dgelu, int M, int C, int Hd, uint16_t* dh, int64_t ldh,
+                    int64_t ldw1t, const uint8_t* dgelu, int M, int C, int Hd, uint16_t* dh, int64_t ldh,
                     uint16_t* dA, int64_t ldda, void* stream) {
   MlpArgs m;
   memset(&m, 0, sizeof(m));

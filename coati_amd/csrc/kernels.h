@@ -102,12 +102,13 @@ struct MlpArgs {
   const bf16_t* W2; long long ldw2;   // [C, Hd]  forward: fc2 weight;   backward: fc1 weight transposed
   const float* b2;                    // [C] forward only
   bf16_t* h; long long ldh;           // [M, Hd] out: forward NewGELU(pre); backward dh = (dY W2) * aux
-  bf16_t* d;                          // [M, Hd] out, forward: NewGELU'(pre) (row stride ldh)
-  const bf16_t* aux;                  // [M, Hd] in, backward: the saved NewGELU'(pre) (row stride ldh)
+  void* d;                            // [M, Hd] out, forward: NewGELU'(pre) as 8-bit fixed point (common.h packq8; row stride ldh bytes)
+  const void* aux;                    // [M, Hd] in, backward: the saved 8-bit NewGELU' codes (row stride ldh bytes)
   void* out; long long ldo;           // forward f32 [M, C] = x + h W2^T + b2;  backward bf16 [M, C] = dh W1
 };
 bool mlp_chain_supported(const MlpArgs& a);
-int launch_mlp_fwd(const MlpArgs& a, hipStream_t s);
+int launch_mlp_fwd(const MlpArgs& a, hipStream_t s);   // W1 = the column-permuted fc1 copy (launch_mlp_permute_w1); d = 8-bit codes
+int launch_mlp_permute_w1(const bf16_t* W, long long ldw, bf16_t* Wp, long long ldp, int Hd, int C, hipStream_t s);
 int launch_mlp_bwd(const MlpArgs& a, hipStream_t s);
 
 // dW[N,K] (f32, atomic +=) = A[M,N]^T * B[M,K];  dbias[N] (atomic +=) = colsum(A) if non-null

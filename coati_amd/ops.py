@@ -188,26 +188,37 @@ def ce_bwd(a, W, target, lse, scal):
     return d
 
 
-def mlp_fwd(x, gamma, beta, W1, b1, W2, b2):
-    """chained LayerNorm -> W1 -> NewGELU -> W2 -> residual (C = 256).  Returns (out f32, a bf16, mean, rstd, g bf16, dg bf16)."""
+def mlp_permute_w1(W1):
+    """column-permuted copy of the fc1 weight the chained forward kernel reads (csrc/gemm_mlp.hip)"""
+    _need_cuda(W1)
+    Wp = torch.empty_like(W1)
+    _lib.call("coati_mlp_permute_w1", ptr(W1), W1.stride(0), ptr(Wp), Wp.stride(0), W1.shape[0], W1.shape[1], stream())
+    return Wp
+
+
+def mlp_fwd(x, gamma, beta, W1, b1, W2, b2, W1p=None):
+    """chained LayerNorm -> W1 -> NewGELU -> W2 -> residual (C = 256).  Returns (out f32, a bf16, mean, rstd, g bf16, dg u8 codes)."""
     _need_cuda(x, W1, W2)
     M, C = x.shape
     Hd = W1.shape[0]
     dev = x.device
+    if W1p is None:
+        W1p = mlp_permute_w1(W1)
     a = torch.empty(M, C, device=dev, dtype=torch.bfloat16)
     g = torch.empty(M, Hd, device=dev, dtype=torch.bfloat16)
-    dg = torch.empty(M, Hd, device=dev, dtype=torch.bfloat16)
+    dg = torch.empty(M, Hd, device=dev, dtype=torch.uint8)
     mean = torch.empty(M, device=dev, dtype=torch.float32)
     rstd = torch.empty(M, device=dev, dtype=torch.float32)
     out = torch.empty(M, C, device=dev, dtype=torch.float32)
-    _lib.call("coati_mlp_fwd", ptr(x), x.stride(0), ptr(gamma), ptr(beta), ptr(W1), W1.stride(0), ptr(b1), ptr(W2), W2.stride(0),
+    _lib.call("coati_mlp_fwd", ptr(x), x.stride(0), ptr(gamma), ptr(beta), ptr(W1p), W1p.stride(0), ptr(b1), ptr(W2), W2.stride(0),
               ptr(b2), M, C, Hd, ptr(a), C, ptr(mean), ptr(rstd), ptr(g), ptr(dg), Hd, ptr(out), C, stream())
     return out, a, mean, rstd, g, dg
 
 
 def mlp_dgrad(dY, W2T, W1T, dgelu):
-    """chained dh = (dY W2) * dgelu ; dA = dh W1 (C = 256).  W2T [Hd, C], W1T [C, Hd].  Returns (dA bf16, dh bf16)."""
+    """chained dh = (dY W2) * dequant(dgelu) ; dA = dh W1 (C = 256).  W2T [Hd, C], W1T [C, Hd], dgelu u8 codes.  Returns (dA bf16, dh bf16)."""
     _need_cuda(dY, W2T, W1T, dgelu)
+    assert dgelu.dtype == torch.uint8
     M, C = dY.shape
     Hd = W2T.shape[0]
     dh = torch.empty(M, Hd, device=dY.device, dtype=torch.bfloat16)

@@ -61,18 +61,22 @@ int coati_gemm_nt(const void* A, int a_f32, int64_t lda, const uint16_t* B, int6
                   void* C, int64_t ldc, int n_store, const float* bias, const void* aux_in, void* aux_out,
                   int64_t ld_aux, int epi, void* stream);
 
-/* Transformer MLP as ONE chained kernel at C = 256 (RotaryBlock.mlpf, basic_transformer.py:157-174, with ln_2 in front):
- *   a = LayerNorm(x; gamma, beta) (bf16, written with mean / rstd);  g = NewGELU(a W1^T + b1), dg = NewGELU'(...)  (bf16
- *   [M, Hd], written);  out = x + g W2^T + b2 (f32).  W1 [Hd, C], W2 [C, Hd] bf16 row-major.  The [M, Hd] intermediate
- *   feeds the second product from registers.  Returns -2 for shapes the chained kernel does not take (C != 256). */
-int coati_mlp_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, const uint16_t* W1, int64_t ldw1,
+/* Transformer MLP as ONE chained, wave-specialised kernel at C = 256 (RotaryBlock.mlpf, basic_transformer.py:157-174, with
+ * ln_2 in front):
+ *   a = LayerNorm(x; gamma, beta) (bf16, written with mean / rstd);  g = NewGELU(a W1^T + b1) (bf16 [M, Hd], written);
+ *   dg = NewGELU'(a W1^T + b1) as 8-bit fixed point (code q <-> q/200 - 0.13; [M, Hd] bytes, written);
+ *   out = x + g W2^T + b2 (f32).  W2 [C, Hd] bf16 row-major; W1p = the fc1 weight [Hd, C] with its columns permuted inside
+ *   every group of 32 (coati_mlp_permute_w1: position 8q + i <- channel 16 (i >> 2) + 4 q + (i & 3)).  The [M, Hd]
+ *   intermediate feeds the second product from registers and x is read once.  -2 for shapes it does not take (C != 256). */
+int coati_mlp_permute_w1(const uint16_t* W1, int64_t ldw, uint16_t* W1p, int64_t ldp, int Hd, int C, void* stream);
+int coati_mlp_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, const uint16_t* W1p, int64_t ldw1,
                   const float* b1, const uint16_t* W2, int64_t ldw2, const float* b2, int M, int C, int Hd, uint16_t* a,
-                  int64_t lda, float* mean, float* rstd, uint16_t* g, uint16_t* dg, int64_t ldh, float* out, int64_t ldo,
+                  int64_t lda, float* mean, float* rstd, uint16_t* g, uint8_t* dg, int64_t ldh, float* out, int64_t ldo,
                   void* stream);
-/* the matching input-gradient chain: dh = (dY W2) * dgelu (bf16 [M, Hd], written);  dA = dh W1 (bf16 [M, C]).
+/* the matching input-gradient chain: dh = (dY W2) * dequant(dgelu) (bf16 [M, Hd], written);  dA = dh W1 (bf16 [M, C]).
  *   W2T = W2 transposed [Hd, C], W1T = W1 transposed [C, Hd] (the engine's transposed bf16 shadows). */
 int coati_mlp_dgrad(const uint16_t* dY, int64_t lddy, const uint16_t* W2T, int64_t ldw2t, const uint16_t* W1T,
-                    int64_t ldw1t, const uint16_t* dgelu, int M, int C, int Hd, uint16_t* dh, int64_t ldh,
+                    int64_t ldw1t, const uint8_t* dgelu, int M, int C, int Hd, uint16_t* dh, int64_t ldh,
                     uint16_t* dA, int64_t ldda, void* stream);
 
 /* lm_head + cross-entropy without materialising logits (smiles_xformer.py:453 + train_coati.py:260-265):

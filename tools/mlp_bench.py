@@ -16,7 +16,8 @@ W1 = (torch.randn(Hd, C, device=dev) * 0.05).bfloat16(); b1 = torch.randn(Hd, de
 W2 = (torch.randn(C, Hd, device=dev) * 0.05).bfloat16(); b2 = torch.randn(C, device=dev) * 0.1
 W2T = W2.t().contiguous(); W1T = W1.t().contiguous()
 a = torch.empty(M, C, device=dev, dtype=torch.bfloat16)
-g = torch.empty(M, Hd, device=dev, dtype=torch.bfloat16); dg = torch.empty_like(g); dh = torch.empty_like(g)
+g = torch.empty(M, Hd, device=dev, dtype=torch.bfloat16); dg = torch.empty(M, Hd, device=dev, dtype=torch.uint8); dh = torch.empty_like(g)
+W1p = ops.mlp_permute_w1(W1)
 mean = torch.empty(M, device=dev); rstd = torch.empty(M, device=dev)
 out = torch.empty(M, C, device=dev); dA = torch.empty(M, C, device=dev, dtype=torch.bfloat16)
 dY = torch.randn(M, C, device=dev).bfloat16()
@@ -24,7 +25,7 @@ fl = 2.0 * 2 * M * C * Hd
 
 
 def chain_fwd():
-    _lib.call("coati_mlp_fwd", ptr(x), C, ptr(gamma), ptr(beta), ptr(W1), C, ptr(b1), ptr(W2), Hd, ptr(b2), M, C, Hd, ptr(a), C,
+    _lib.call("coati_mlp_fwd", ptr(x), C, ptr(gamma), ptr(beta), ptr(W1p), C, ptr(b1), ptr(W2), Hd, ptr(b2), M, C, Hd, ptr(a), C,
               ptr(mean), ptr(rstd), ptr(g), ptr(dg), Hd, ptr(out), C, stream())
 
 
@@ -41,11 +42,11 @@ def split_fwd():     # (LayerNorm unfused here; the engine's row-block FC1 fuses
 
 
 def split_bwd():
-    d4 = ops.gemm_nt(dY, W2T, None, ops.EPI_MUL_AUX, aux_in=dg)
+    d4 = ops.gemm_nt(dY, W2T, None, ops.EPI_MUL_AUX, aux_in=dg)     # dg: 8-bit codes (written by chain_fwd / split_fwd)
     ops.gemm_nt(d4, W1T, None, ops.EPI_BF16, out=dA)
 
 
-row("mlp chain fwd (x, a, g, dg, out: 6656 B/row)", timeit(chain_fwd), fl, M * 6656.0)
-row("mlp chain dgrad (dY, dg, dh, dA: 5120 B/row)", timeit(chain_bwd), fl, M * 5120.0)
-row("two launches fwd (FC1+GELU', FC2+res)", timeit(split_fwd), fl, M * 9728.0 - M * 1024.0)
-row("two launches dgrad (FC2 dgrad x GELU', FC1 dgrad)", timeit(split_bwd), fl, M * 7168.0)
+row("mlp chain fwd (x, a, g, dg u8, out: 4608 B/row)", timeit(chain_fwd), fl, M * 4608.0)
+row("mlp chain dgrad (dY, dg u8, dh, dA: 4096 B/row)", timeit(chain_bwd), fl, M * 4096.0)
+row("two launches fwd (FC1+GELU', FC2+res)", timeit(split_fwd), fl, M * 7680.0)
+row("two launches dgrad (FC2 dgrad x GELU', FC1 dgrad)", timeit(split_bwd), fl, M * 6144.0)
