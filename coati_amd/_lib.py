@@ -27,6 +27,7 @@ _SIGS = {
     "coati_ce_finish": [P, I, P, L, P, L, P, P, P, I, I, I, P],
     "coati_gemm_ce_bwd": [P, L, P, L, I, I, I, P, L, I, P, P, P, P],
     "coati_wgrad": [P, I, L, P, L, I, I, I, P, L, P, I, P],
+    "coati_wgrad_grouped": [I, P, P, P, P, I, P, P, P, P, P, I, P],
     "coati_sgemm": [P, L, L, P, L, L, P, L, I, I, I, P, F, I, P],
     "coati_layernorm_fwd": [P, L, P, P, P, L, P, L, P, P, I, I, P],
     "coati_layernorm_bwd": [P, I, L, P, L, I, P, P, P, P, P, P, P, P, P, I, I, P],

@@ -2,6 +2,7 @@
 #include <string.h>
 
 #include "../../include/coati_hip.h"
+#include <vector>
 #include "kernels.h"
 
 #define S_(x) ((hipStream_t)(x))
@@ -75,6 +76,36 @@ int coati_wgrad(const void* A, int a_f32, int64_t lda, const uint16_t* B, int64_
   WgradArgs a;
   a.A = A; a.lda = lda; a.B = B; a.ldb = ldb; a.M = M; a.N = N; a.K = K; a.dW = dW; a.ldw = ldw; a.dbias = dbias; a.n_out = n_out;
   return launch_wgrad(a, a_f32, S_(stream));
+}
+
+int coati_wgrad_grouped(int n_problems, const uint16_t* const* A, const int64_t* lda, const uint16_t* const* B, const int64_t* ldb, int M,
+                        const int* N, const int* K, float* const* dW, const int64_t* ldw, float* const* dbias, int tile_size, void* stream) {
+  COATI_CHECK_ARG(n_problems > 0 && A && lda && B && ldb && N && K && dW && ldw && dbias, "wgrad_grouped: null argument");
+  std::vector<WgradTile> tab;
+  for (int i = 0; i < n_problems; ++i) {
+    WgradArgs a;
+    a.A = A[i]; a.lda = lda[i]; a.B = B[i]; a.ldb = ldb[i]; a.M = M; a.N = N[i]; a.K = K[i]; a.dW = dW[i]; a.ldw = ldw[i]; a.dbias = dbias[i]; a.n_out = 0;
+    COATI_TRY(wgrad_table_append(tab, a, nullptr, tile_size));
+  }
+  // stand-alone entry point (tests, micro-benchmarks): the table is uploaded per call; the engine keeps its tables resident
+  WgradTile* d = nullptr;
+  hipStream_t s = S_(stream);
+  if (hipMalloc(&d, tab.size() * sizeof(WgradTile)) != hipSuccess) {
+    coati_set_error("wgrad_grouped: table allocation failed");
+    return COATI_EHIP;
+  }
+  int rc = COATI_OK;
+  if (hipMemcpyAsync(d, tab.data(), tab.size() * sizeof(WgradTile), hipMemcpyHostToDevice, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
+    coati_set_error("wgrad_grouped: table upload failed");
+    rc = COATI_EHIP;
+  }
+  if (rc == COATI_OK) rc = launch_wgrad_table(d, (int)tab.size(), s, tile_size);
+  if (hipStreamSynchronize(s) != hipSuccess && rc == COATI_OK) {
+    coati_set_error("wgrad_grouped: kernel failed");
+    rc = COATI_EHIP;
+  }
+  hipFree(d);
+  return rc;
 }
 
 int coati_sgemm(const float* A, int64_t ars, int64_t acs, const float* B, int64_t brs, int64_t bcs, float* C,

@@ -137,6 +137,7 @@ struct coati_engine {
   // deferred transformer weight gradients (grouped launch, gemm.hip wgrad_dma_table_kernel): the bf16 activation gradients
   // of every layer of a pass stay alive until the end of the pass, then ONE launch computes all 4 L weight gradients
   std::vector<bf16_t*> w_dh4, w_dxa, w_dxb, w_dqkv;   // [L]: d(hidden), d x[l+1], d xmid[l], d qkv[l]
+  int wg_tile = 128;                                  // output tile of the grouped launch: 256 when C % 256 == 0 (COATI_WGRAD_TILE=128 overrides)
   bool wg_group = false;                              // buffers carved (shape and COATI_WGRAD_GROUP allow it)
   WgradTile* d_wtab = nullptr;                        // device tables: WTAB_SLOTS x (L x tiles per layer) entries
   int* d_wpace = nullptr;                             // pacing epoch counters of the grouped launch: [4 L problems][epochs]
@@ -453,6 +454,8 @@ size_t carve(coati_engine* e, Arena& ar, int B, int T1, int T2, int A, int Bg) {
     static const bool off = getenv("COATI_WGRAD_GROUP") != nullptr && atoi(getenv("COATI_WGRAD_GROUP")) == 0;   // A/B switch
     const int L = c.n_layer_xformer;
     e->wg_group = !off && C % 128 == 0 && Mmax >= 4096;
+    static const int want_tile = getenv("COATI_WGRAD_TILE") ? atoi(getenv("COATI_WGRAD_TILE")) : 256;                // A/B switch
+    e->wg_tile = (want_tile == 256 && C % 256 == 0 && 40LL * 4 * C < (1LL << 30)) ? 256 : 128;
     e->w_dh4.assign(L, nullptr); e->w_dxa.assign(L, nullptr); e->w_dxb.assign(L, nullptr); e->w_dqkv.assign(L, nullptr);
     if (e->wg_group) {
       for (int l = 0; l < L; ++l) {
@@ -562,7 +565,7 @@ int xformer_wgrad_group(coati_engine* e, XPass& p, int l_lo, int l_hi, hipStream
     auto add = [&](const bf16_t* A, int lda, const bf16_t* B, int ldb, int N, int K, int64_t w_off, int64_t b_off) -> int {
       WgradArgs a;
       a.A = A; a.lda = lda; a.B = B; a.ldb = ldb; a.M = M; a.N = N; a.K = K; a.dW = e->G + w_off; a.ldw = K; a.dbias = e->G + b_off; a.n_out = 0;
-      return wgrad_table_append(tab, a, e->d_wpace + (size_t)(prob++) * e->wpace_per);
+      return wgrad_table_append(tab, a, e->d_wpace + (size_t)(prob++) * e->wpace_per, e->wg_tile);
     };
     for (int l = l_hi - 1; l >= l_lo; --l) {
       const XLayerP& w = e->xl[l];
@@ -590,7 +593,7 @@ int xformer_wgrad_group(coati_engine* e, XPass& p, int l_lo, int l_hi, hipStream
     return COATI_EHIP;
   }
   ProfScope ps(e, SITE_XF_WGRAD, flops, s, bytes);
-  return launch_wgrad_table(e->d_wtab + (size_t)slot * e->wtab_cap, e->wtab_key[slot].n, s);
+  return launch_wgrad_table(e->d_wtab + (size_t)slot * e->wtab_cap, e->wtab_key[slot].n, s, e->wg_tile);
 }
 
 // dyf: gradient w.r.t. ln_f output, bf16 (decoder pass) or f32 (encoder pass)

@@ -846,11 +846,225 @@ __global__ __launch_bounds__(512, 1) void wgrad_dma_table_kernel(const WgradTile
   wgrad_dma_body<BIAS, NS, true>(p, d.tiles_k, d.tile, 0, (p.M + WD_CH - 1) / WD_CH, smem, d.pace, d.group_size);
 }
 
+// =================================================================================================
+// Grouped weight gradients, 256 x 256 output tiles (round 2).  The 128 x 128 table kernel above is bound by the L2 -> LDS
+// fill rate of a CU (profiles/r02_wgrad_traffic.txt: 0.73 us per 32-KiB stage against 0.49 us for the DMAs alone) and by
+// what its sibling tiles re-read: a 128-wide tile fetches every operand panel of its problem 2..8 times.  A 256 x 256 tile
+// does twice the flops per byte brought into LDS (131 flop/B instead of 64) and has at most four siblings per panel.
+//   * one 512-thread workgroup = 2 x 4 waves, each wave a 128 (n) x 64 (k) block: acc[4][2] = 128 accumulator VGPRs;
+//   * a stage is 32 m-rows: [A0 | A1 | B0 | B1], four [32 m][128 col] blocks in the layout of the kernel above (256-B rows,
+//     64-B chunks XOR-swizzled by row & 3 on the GLOBAL side of the DMA, ds_read_b64_tr_b16 fragments) = 32 KiB; wave w
+//     issues the four 1-KiB pieces "rows 4 w .. 4 w + 3" of the four blocks; ring of NS stages, NS - 1 in flight;
+//   * the fragments are double-buffered per k-step of 16 rows (6 fragments = 24 VGPRs a set), not per stage:
+//       step c:  read (c, ks 1) | 8 MFMAs of (c, ks 0) | vmcnt + barrier | DMA of stage c + NS | read (c + 1, ks 0) | 8 MFMAs of (c, ks 1)
+//     16 MFMAs (512 matrix-core cycles) per wave per barrier, twice the ratio of the 128-wide kernel;
+//   * the tile is exclusive (one workgroup streams all of M): plain read-add-store commit, no atomics, no exchange;
+//   * N and K must be multiples of 256 (the transformer's are); only the last stage of M needs the zero page.
+// 16 layers x 12 tiles = 192 workgroups: one round on 192 of the 256 CUs, 24 per XCD = two whole layers per L2.
+// =================================================================================================
+#define W2_CH 32
+#define W2_BLK_BYTES (32 * WT_ROW_BYTES)
+#define W2_STAGE_BYTES (4 * W2_BLK_BYTES)
+struct W2Frags { bf16x8 a[4], b[2]; };
+
+template <int NS>
+__global__ __launch_bounds__(512, 1) void wgrad256_table_kernel(const WgradTile* __restrict__ table) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const WgradTile& d = table[xcd_swizzle(blockIdx.x, gridDim.x)];
+  const WgradArgs p = d.p;
+  const int tiles_k = d.tiles_k, tile = d.tile;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int tile_n = tile / tiles_k, tile_k = tile - tile_n * tiles_k;
+  const int n0 = tile_n * 256, k0 = tile_k * 256;
+  const int c_end = (p.M + W2_CH - 1) / W2_CH;
+  const bf16_t* A = reinterpret_cast<const bf16_t*>(p.A);
+
+  // DMA sources of this lane: piece "rows 4 wave .. + 3" of block b = 0..3 (A0, A1, B0, B1); LDS slot (row & 3 = lane >> 4,
+  // 16-B chunk q = lane & 15) <- global chunk qg of that row
+  const int rsub = lane >> 4, q = lane & 15;
+  const int qg = (((q >> 2) ^ rsub) << 2) | (q & 3);
+  const bf16_t* const zero = reinterpret_cast<const bf16_t*>(wd_zero_page) + q * 8;
+  const unsigned offa = (unsigned)(((4 * wave + rsub) * (int)p.lda + qg * 8) * 2);
+  const unsigned offb = (unsigned)(((4 * wave + rsub) * (int)p.ldb + qg * 8) * 2);
+  int cnext = 0;
+  typedef __attribute__((address_space(3))) unsigned char lds_u8;
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_u8*)smem);
+  const unsigned ldsw = lds0 + wave * 1024;
+  const bf16_t* ab = A + n0;       // row 0 of the next stage (scalar)
+  const bf16_t* bb = p.B + k0;
+  const long long ab_step = (long long)W2_CH * p.lda, bb_step = (long long)W2_CH * p.ldb;
+  auto issue = [&](int slot) __attribute__((always_inline)) {
+    const unsigned S = ldsw + slot * W2_STAGE_BYTES;
+    if ((cnext + 1) * W2_CH <= p.M) {
+      wd_dma16s(ab, offa, S);
+      wd_dma16s(ab, offa + 256u, S + W2_BLK_BYTES);
+      wd_dma16s(bb, offb, S + 2 * W2_BLK_BYTES);
+      wd_dma16s(bb, offb + 256u, S + 3 * W2_BLK_BYTES);
+    } else {
+      const int m = cnext * W2_CH + 4 * wave + rsub;
+      const bool ok = m < p.M;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        wd_dma16(ok ? A + n0 + 128 * h + qg * 8 + (long long)m * p.lda : zero, S + h * W2_BLK_BYTES);
+        wd_dma16(ok ? p.B + k0 + 128 * h + qg * 8 + (long long)m * p.ldb : zero, S + (2 + h) * W2_BLK_BYTES);
+      }
+    }
+    ++cnext;
+    ab += ab_step;
+    bb += bb_step;
+  };
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[i][0][r] = 0.f; acc[i][1][r] = 0.f; }
+
+  // fragment addresses: A block wm, 64-B chunk i (n columns 32 i ..); B block wn >> 1, chunk 2 (wn & 1) + j.  A second set
+  // 64 KiB up (opaque to the compiler) keeps the immediates of ring slots 2, 3 inside the 16-bit offset field.
+  typedef __attribute__((address_space(3))) v4s16 lds_v4;
+  unsigned la[4], lb[2], lah[4], lbh[2];
+  {
+    const int g = lane >> 4, kg = g >> 1, r0 = 8 * kg + ((lane & 15) >> 2), cb = (16 * (g & 1) + 4 * (lane & 3)) * 2;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) la[i] = lds0 + wm * W2_BLK_BYTES + wt_offset(r0, i * 64 + cb);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) lb[j] = lds0 + (2 + (wn >> 1)) * W2_BLK_BYTES + wt_offset(r0, (2 * (wn & 1) + j) * 64 + cb);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { lah[i] = la[i] + 0x10000u; asm volatile("" : "+v"(lah[i])); }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { lbh[j] = lb[j] + 0x10000u; asm volatile("" : "+v"(lbh[j])); }
+  }
+  auto frag_at = [&](unsigned addr) __attribute__((always_inline)) {
+    const v4s16 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(size_t)addr);
+    const v4s16 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(size_t)(addr + 4 * WT_ROW_BYTES));
+    typedef short v8s16 __attribute__((ext_vector_type(8)));
+    const v8s16 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, r);
+  };
+  auto fetch = [&](int slot, int ks, W2Frags& f) __attribute__((always_inline)) {
+    const bool high = slot * W2_STAGE_BYTES >= 0x10000;
+    const unsigned so = slot * W2_STAGE_BYTES - (high ? 0x10000u : 0u) + ks * 16 * WT_ROW_BYTES;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) f.a[i] = frag_at((high ? lah[i] : la[i]) + so);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) f.b[j] = frag_at((high ? lbh[j] : lb[j]) + so);
+  };
+  auto mma = [&](const W2Frags& f) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i], f.b[j], acc[i][j], 0, 0, 0);
+  };
+  // bias (column sums of A): thread -> columns 2 cp, 2 cp + 1 of the 256, rows 8 rq .. + 7 of the stage; the tiles_k
+  // workgroups that stream the same A rows take turns (stage % tiles_k == tile_k)
+  typedef __bf16 v2bf __attribute__((ext_vector_type(2)));
+  unsigned sel_lo_u, sel_hi_u;
+  asm volatile("v_mov_b32 %0, 0x3f80\n\tv_mov_b32 %1, 0x3f800000" : "=v"(sel_lo_u), "=v"(sel_hi_u));
+  const v2bf sel_lo = __builtin_bit_cast(v2bf, sel_lo_u), sel_hi = __builtin_bit_cast(v2bf, sel_hi_u);
+  float cs0 = 0.f, cs1 = 0.f;
+  const int cp = tid & 127, rq = tid >> 7;
+  int bias_ctr = tile_k;
+  unsigned bu[8];
+  auto bias_read = [&](int slot) __attribute__((always_inline)) {
+    const unsigned char* At = smem + slot * W2_STAGE_BYTES + (cp >> 6) * W2_BLK_BYTES;
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) bu[rr] = *reinterpret_cast<const unsigned*>(At + wt_offset(rq * 8 + rr, (cp & 63) * 4));
+  };
+  auto bias_add = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {
+      const v2bf u = __builtin_bit_cast(v2bf, bu[rr]);
+      cs0 = __builtin_amdgcn_fdot2_f32_bf16(u, sel_lo, cs0, false);
+      cs1 = __builtin_amdgcn_fdot2_f32_bf16(u, sel_hi, cs1, false);
+    }
+  };
+  constexpr int VM_KEEP = 4 * (NS - 2);
+  constexpr int VM_WAIT = 0x0f70 | (VM_KEEP & 15) | ((VM_KEEP >> 4) << 14);
+
+#pragma unroll
+  for (int s0 = 0; s0 < NS - 1; ++s0) issue(s0);
+  __builtin_amdgcn_s_waitcnt(VM_WAIT);
+  __builtin_amdgcn_s_barrier();
+  issue(NS - 1);
+  W2Frags f0, f1;
+  fetch(0, 0, f0);
+  auto step = [&](auto slot_c) __attribute__((always_inline)) {
+    constexpr int SL = decltype(slot_c)::value, SN = (SL + 1) % NS;
+    const bool turn = bias_ctr == 0;
+    bias_ctr = (bias_ctr == 0 ? tiles_k : bias_ctr) - 1;
+    if (turn) bias_read(SL);
+    fetch(SL, 1, f1);
+    mma(f0);
+#pragma unroll
+    for (int g = 0; g < 6; ++g) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // DS read
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (turn) bias_add();
+    __builtin_amdgcn_s_waitcnt(VM_WAIT & 0xf0ff);   // stage c + 1 has landed; + lgkmcnt(0): this wave's reads of stage c are complete
+    __builtin_amdgcn_s_barrier();
+    issue(SL);
+    fetch(SN, 0, f0);
+    mma(f1);
+#pragma unroll
+    for (int g = 0; g < 6; ++g) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  static_assert(NS == 4, "the main loop is unrolled for a ring of 4");
+  for (int c = 0;;) {
+    step(WdSlot<0>()); if (++c >= c_end) break;
+    step(WdSlot<1>()); if (++c >= c_end) break;
+    step(WdSlot<2>()); if (++c >= c_end) break;
+    step(WdSlot<3>()); if (++c >= c_end) break;
+  }
+  __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0) + lgkmcnt(0): the over-issued (zero-page) DMAs have landed, the ring is free
+  __builtin_amdgcn_s_barrier();
+
+  // bias partials: [4 row quarters][256 columns] through the (idle) ring; all workgroups of a tile row add into one slice
+  float* const bsum = reinterpret_cast<float*>(smem);
+  bsum[rq * 256 + 2 * cp] = cs0;
+  bsum[rq * 256 + 2 * cp + 1] = cs1;
+  __syncthreads();
+  if (tid < 256) {
+    const float t = bsum[tid] + bsum[256 + tid] + bsum[512 + tid] + bsum[768 + tid];
+    if (tiles_k == 1) p.dbias[n0 + tid] += t;
+    else atomicAdd(p.dbias + n0 + tid, t);
+  }
+  // exclusive tile: plain read-add-store
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = n0 + wm * 128 + i * 32 + frag_row(r, lane);
+        const int k = k0 + wn * 64 + j * 32 + (lane & 31);
+        p.dW[(long long)n * p.ldw + k] += acc[i][j][r];
+      }
+}
+
 int wgrad_table_pace_ints(int M) { return cdiv(cdiv(M, WD_CH), COATI_WG_EPOCH_STAGES) + 1; }
 
-int wgrad_table_append(std::vector<WgradTile>& tab, const WgradArgs& a, int* pace) {
+bool wgrad_table_tile256_ok(const WgradArgs& a) {
+  return a.N % 256 == 0 && a.K % 256 == 0 && a.n_out == 0 && a.m_dev == nullptr && 40LL * a.lda < (1LL << 30) && 40LL * a.ldb < (1LL << 30);
+}
+
+int wgrad_table_append(std::vector<WgradTile>& tab, const WgradArgs& a, int* pace, int tile_size) {
   COATI_CHECK_ARG(a.A && a.B && a.dW && a.dbias, "wgrad_table: null operand (the grouped kernel is the bias variant)");
   COATI_CHECK_SHAPE(a.M > 0 && a.N % 8 == 0 && a.K % 8 == 0 && a.lda % 8 == 0 && a.ldb % 8 == 0, "wgrad_table: shape / alignment");
+  COATI_CHECK_ARG(tile_size == 128 || tile_size == 256, "wgrad_table: tile size %d", tile_size);
+  if (tile_size == 256) {
+    COATI_CHECK_SHAPE(wgrad_table_tile256_ok(a), "wgrad_table: 256-wide tiles need N and K to be multiples of 256 (N=%d K=%d)", a.N, a.K);
+    const int tk = a.K / 256, nt = (a.N / 256) * tk;
+    for (int t = 0; t < nt; ++t) tab.push_back(WgradTile{a, tk, t, nullptr, 0});
+    return COATI_OK;
+  }
   const int tiles_n = cdiv(a.N, BM), tiles_k = cdiv(a.K, BN);
   // pacing needs every tile of the problem resident at the same time: at most one XCD's worth (32 CUs)
   const int n = tiles_n * tiles_k;
@@ -881,8 +1095,24 @@ static int launch_wgrad_table_t(const WgradTile* dev_table, int n_tiles, hipStre
   return COATI_OK;
 }
 
-int launch_wgrad_table(const WgradTile* dev_table, int n_tiles, hipStream_t s) {
+int launch_wgrad_table(const WgradTile* dev_table, int n_tiles, hipStream_t s, int tile_size) {
   COATI_CHECK_ARG(dev_table && n_tiles > 0, "wgrad_table: empty table");
+  if (tile_size == 256) {
+    static bool attr_set = false;
+    auto kern = wgrad256_table_kernel<4>;
+    constexpr int lds = 4 * W2_STAGE_BYTES;
+    if (!attr_set) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      if (e != hipSuccess) {
+        coati_set_error("wgrad(table 256): hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+        return COATI_EHIP;
+      }
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(n_tiles), dim3(512), lds, s, dev_table);
+    COATI_LAUNCH_CHECK("wgrad_table256");
+    return COATI_OK;
+  }
   // ring depth (stages of 32 KiB; NS - 1 in flight): COATI_WGRAD_TABLE_NS = 3 | 4 (A/B switch)
   static const int ns = getenv("COATI_WGRAD_TABLE_NS") ? atoi(getenv("COATI_WGRAD_TABLE_NS")) : 4;
   return ns == 3 ? launch_wgrad_table_t<3>(dev_table, n_tiles, s) : launch_wgrad_table_t<4>(dev_table, n_tiles, s);

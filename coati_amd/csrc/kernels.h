@@ -139,10 +139,11 @@ struct WgradTile {
 };
 #define COATI_WG_EPOCH_STAGES 4                 // 64-row stages per pacing epoch
 int wgrad_table_pace_ints(int M);               // epoch counters one problem needs for M rows
-int launch_wgrad_table(const WgradTile* dev_table, int n_tiles, hipStream_t s);
+int launch_wgrad_table(const WgradTile* dev_table, int n_tiles, hipStream_t s, int tile_size = 128);   // every entry of a table has the same tile size
+bool wgrad_table_tile256_ok(const WgradArgs& a);   // 256 x 256 tiles (wgrad256_table_kernel): N, K multiples of 256
 #ifdef __cplusplus
 #include <vector>
-int wgrad_table_append(std::vector<WgradTile>& tab, const WgradArgs& a, int* pace);   // host: appends the problem's tiles (pace: its epoch counters or null)
+int wgrad_table_append(std::vector<WgradTile>& tab, const WgradArgs& a, int* pace, int tile_size = 128);   // host: appends the problem's tiles (pace: its epoch counters or null)
 #endif
 
 // C[M,N] (f32) = sum_k A(m,k) B(k,n) [+ bias[n]] [+ C];  A(m,k) = A[m*ars + k*acs], B(k,n) = B[k*brs + n*bcs]

@@ -69,6 +69,24 @@ def wgrad(A, Bm, dW, dbias=None, n_out=0):
     return dW
 
 
+def wgrad_grouped(problems, tile_size=256):
+    """problems: list of (A[M,N] bf16, Bm[M,K] bf16, dW[N,K] f32, dbias[N] f32), all with the same M; one launch, no atomics
+    on dW: dW += A^T @ Bm, dbias += colsum(A)."""
+    import ctypes
+    n = len(problems)
+    for A, Bm, dW, db in problems:
+        _need_cuda(A, Bm, dW, db)
+        assert A.dtype == torch.bfloat16 and Bm.dtype == torch.bfloat16 and dW.dtype == torch.float32 and db.dtype == torch.float32
+    M = problems[0][0].shape[0]
+    PP, LL, II = ctypes.c_void_p * n, ctypes.c_int64 * n, ctypes.c_int * n
+    _lib.call("coati_wgrad_grouped", n,
+              PP(*[ptr(q[0]) for q in problems]), LL(*[q[0].stride(0) for q in problems]),
+              PP(*[ptr(q[1]) for q in problems]), LL(*[q[1].stride(0) for q in problems]), M,
+              II(*[q[0].shape[1] for q in problems]), II(*[q[1].shape[1] for q in problems]),
+              PP(*[ptr(q[2]) for q in problems]), LL(*[q[2].stride(0) for q in problems]),
+              PP(*[ptr(q[3]) for q in problems]), tile_size, stream())
+
+
 def sgemm(A, Bm, trans_a=False, trans_b=False, bias=None, alpha=1.0, out=None, accumulate=False):
     """out = alpha * op(A) @ op(Bm) (+bias) in exact fp32 (MFMA f32)."""
     _need_cuda(A, Bm)

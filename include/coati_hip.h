@@ -96,6 +96,14 @@ int coati_gemm_ce_bwd(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t
 int coati_wgrad(const void* A, int a_f32, int64_t lda, const uint16_t* B, int64_t ldb, int M, int N, int K,
                 float* dW, int64_t ldw, float* dbias, int n_out, void* stream);
 
+/* The same for a LIST of problems that share M, in ONE launch and without fp32 atomics on dW: one workgroup per output tile
+ * (tile_size 128 or 256; 256 needs every N and K to be a multiple of 256) streams all M rows of its tile.  bf16 A, dbias
+ * required.  This is how the engine computes the 4 x n_layer Linear gradients of a transformer pass (the reference's
+ * loss.backward() through RotaryBlock, basic_transformer.py:126-174).  Synchronises the stream (stand-alone entry point). */
+int coati_wgrad_grouped(int n_problems, const uint16_t* const* A, const int64_t* lda, const uint16_t* const* B, const int64_t* ldb,
+                        int M, const int* N, const int* K, float* const* dW, const int64_t* ldw, float* const* dbias,
+                        int tile_size, void* stream);
+
 /* exact-f32 GEMM with generic strides: C[M,N] = alpha * sum_k A[m*ars + k*acs] * B[k*brs + n*bcs] (+ bias[n])
  * (+ C when accumulate).  Used for the [B,256] projection heads and the InfoNCE logits (clip_e2e.py:36-37). */
 int coati_sgemm(const float* A, int64_t ars, int64_t acs, const float* B, int64_t brs, int64_t bcs, float* C,

@@ -99,6 +99,29 @@ def test_wgrad(ops, M, N, K, f32):
     check(f"wgrad db {M}x{N}", db, db0 + A.sum(0), 8.5e-6)   # fp32 accumulation over M rows; measured <= 4.2e-6 (M = 74 451)
 
 
+# the grouped, atomics-free launch (one workgroup per output tile, all of M): the four Linear shapes of a transformer layer,
+# ragged M (the last 32-row stage partly from the zero page), pre-filled outputs with an odd leading dimension
+@pytest.mark.parametrize("tile", [128, 256])
+@pytest.mark.parametrize("M,C", [(4099, 256), (20000, 256), (37, 256), (3001, 512)])
+def test_wgrad_grouped(ops, M, C, tile):
+    g = torch.Generator().manual_seed(M + tile)
+    shapes = [(3 * C, C), (C, C), (4 * C, C), (C, 4 * C)]
+    probs, refs = [], []
+    for N, K in shapes:
+        A = rbf(torch.randn(M, N, generator=g)).to(DEV)
+        X = rbf(torch.randn(M, K, generator=g)).to(DEV)
+        dW0 = torch.randn(N, K + 1, generator=g).to(DEV)
+        db0 = torch.randn(N, generator=g).to(DEV)
+        dW, db = dW0.clone(), db0.clone()
+        probs.append((A.bfloat16(), X.bfloat16(), dW[:, :K], db))
+        refs.append((dW, dW0, db, db0, A, X, K))
+    ops.wgrad_grouped(probs, tile_size=tile)
+    for (N, K), (dW, dW0, db, db0, A, X, _) in zip(shapes, refs):
+        check(f"wgrad_grouped[{tile}] dW {M}x{N}x{K}", dW[:, :K], dW0[:, :K] + A.t() @ X, 8.5e-6)   # same bound as test_wgrad
+        check(f"wgrad_grouped[{tile}] untouched col {M}x{N}x{K}", dW[:, K], dW0[:, K], 0.0)
+        check(f"wgrad_grouped[{tile}] db {M}x{N}", db, db0 + A.sum(0), 8.5e-6)
+
+
 @pytest.mark.parametrize("M,N,K", [(70, 33, 19), (1024, 1024, 256), (1, 256, 1024)])
 def test_sgemm(ops, M, N, K):
     g = torch.Generator().manual_seed(7)
