@@ -45,6 +45,37 @@ __device__ __forceinline__ void stage4(const bf16_t* src, long long stride, int 
   }
 }
 
+// The same with every load of the operand issued before the first LDS write (compile-time trip count: NT tasks per
+// thread): out-of-range rows / heads read a clamped address and are masked afterwards, so there is no branch between the
+// loads and one global round trip covers the whole operand (the looped form above costs one round trip per task when the
+// trip count is a runtime value).
+template <int HS, int TP>
+struct Stage4Regs { uint4 v[(TP * (HS / 2) + 255) / 256]; };
+template <int HS, int TP>
+__device__ __forceinline__ void stage4_load(Stage4Regs<HS, TP>& r, const bf16_t* src, long long stride, int T, int heads_here, int tid) {
+  constexpr int CPR = HS / 2, CPH = HS / 8, NT = (TP * CPR + 255) / 256;
+#pragma unroll
+  for (int i = 0; i < NT; ++i) {
+    const int task = tid + 256 * i, t = task / CPR, c = task - t * CPR;
+    const int tc = t < T ? t : T - 1, cc = (c / CPH) < heads_here ? c : 0;
+    r.v[i] = *reinterpret_cast<const uint4*>(src + (long long)tc * stride + cc * 8);
+  }
+}
+template <int HS, int TP>
+__device__ __forceinline__ void stage4_store(const Stage4Regs<HS, TP>& r, int T, unsigned char* smem, size_t per_wave_bytes, int image,
+                                             int heads_here, int tid) {
+  constexpr int CPR = HS / 2, CPH = HS / 8, NT = (TP * CPR + 255) / 256;
+#pragma unroll
+  for (int i = 0; i < NT; ++i) {
+    const int task = tid + 256 * i, t = task / CPR, c = task - t * CPR, w = c / CPH;
+    if (TP * CPR % 256 != 0 && task >= TP * CPR) break;
+    const unsigned keep = (t < T && w < heads_here) ? 0xffffffffu : 0u;   // mask, not select: the load stays unpredicated
+    const uint4 v = make_uint4(r.v[i].x & keep, r.v[i].y & keep, r.v[i].z & keep, r.v[i].w & keep);
+    bf16_t* img = reinterpret_cast<bf16_t*>(smem + (size_t)w * per_wave_bytes) + (size_t)image * TP * HS;
+    *reinterpret_cast<uint4*>(img + t * HS + (c - w * CPH) * 8) = v;
+  }
+}
+
 // A/B fragment of a row-major [*,HS] image for reduction step ks (16 dims each):
 // lane (r = lane&31, half = lane>>5) -> row blk*32+r, dims ks*16 + half*8..+7
 template <int HS>
@@ -126,6 +157,36 @@ __device__ __forceinline__ void tile_put_grad(unsigned char* tile, int wave, int
   }
   tile_put<HS>(tile, wave, lane, v);
 }
+// the same with the rotation rows already in registers (fetched early, so their global round trip hides behind the sweep)
+template <int HS>
+struct RopeRow { float4 cs[HS / 16], sn[HS / 16]; };
+template <int HS>
+__device__ __forceinline__ RopeRow<HS> rope_row_load(const float* cos_t, const float* sin_t, int t, int lane) {
+  RopeRow<HS> r;
+#pragma unroll
+  for (int gq = 0; gq < HS / 16; ++gq) {
+    r.cs[gq] = *reinterpret_cast<const float4*>(cos_t + t * HS + 8 * gq + 4 * (lane >> 5));
+    r.sn[gq] = *reinterpret_cast<const float4*>(sin_t + t * HS + 8 * gq + 4 * (lane >> 5));
+  }
+  return r;
+}
+template <int HS>
+__device__ __forceinline__ void tile_put_grad_rot(unsigned char* tile, int wave, int lane, const f32x16& g, const RopeRow<HS>& rr) {
+  float v[HS / 2];
+#pragma unroll
+  for (int j = 0; j < HS / 2; ++j) v[j] = g[j];
+#pragma unroll
+  for (int gq = 0; gq < HS / 16; ++gq) {
+    const float csv[4] = {rr.cs[gq].x, rr.cs[gq].y, rr.cs[gq].z, rr.cs[gq].w}, snv[4] = {rr.sn[gq].x, rr.sn[gq].y, rr.sn[gq].z, rr.sn[gq].w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float ga = v[4 * gq + j], gc = v[4 * (gq + HS / 16) + j];
+      v[4 * gq + j] = ga * csv[j] + gc * snv[j];
+      v[4 * (gq + HS / 16) + j] = gc * csv[j] - ga * snv[j];
+    }
+  }
+  tile_put<HS>(tile, wave, lane, v);
+}
 // cooperative store of one tile: task -> (row, 16-B chunk); dst points at (row 0, first head of the quad)
 template <int HS>
 __device__ __forceinline__ void tile_store(const unsigned char* tile, bf16_t* dst, long long stride, int row0, int T,
@@ -167,13 +228,27 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
   bf16_t* Vs = Ks + Tp * HS;
   const long long stride = 3LL * C;
   const bf16_t* base = qkv + (long long)b * T * stride + hq * 4 * HS;
-  stage4<HS>(base + C, stride, T, Tp, smem, pw, 0, heads_here, threadIdx.x);
-  stage4<HS>(base + 2 * C, stride, T, Tp, smem, pw, 1, heads_here, threadIdx.x);
-  __syncthreads();
   const bool active = hh < n_head;   // inactive waves of a partial quad only take part in the barriers
+  const bf16_t* qsrc = qkv + (long long)b * T * stride + (active ? hh : 0) * HS;
+  bf16x8 qnext[NK];   // the Q fragment of the next query block: fetched one block ahead, so only the first one is waited for
+  if constexpr (NB > 0) {
+    // every load of the prologue is issued before the first LDS write: one memory round trip for K, V and the first Q fragment
+    Stage4Regs<HS, NB ? 32 * NB : 32> rk, rv;
+    stage4_load<HS, NB ? 32 * NB : 32>(rk, base + C, stride, T, heads_here, threadIdx.x);
+    stage4_load<HS, NB ? 32 * NB : 32>(rv, base + 2 * C, stride, T, heads_here, threadIdx.x);
+#pragma unroll
+    for (int ks = 0; ks < NK; ++ks) qnext[ks] = gfrag(qsrc, stride, 0, ks, T, lane);
+    stage4_store<HS, NB ? 32 * NB : 32>(rk, T, smem, pw, 0, heads_here, threadIdx.x);
+    stage4_store<HS, NB ? 32 * NB : 32>(rv, T, smem, pw, 1, heads_here, threadIdx.x);
+  } else {
+    stage4<HS>(base + C, stride, T, Tp, smem, pw, 0, heads_here, threadIdx.x);
+    stage4<HS>(base + 2 * C, stride, T, Tp, smem, pw, 1, heads_here, threadIdx.x);
+#pragma unroll
+    for (int ks = 0; ks < NK; ++ks) qnext[ks] = gfrag(qsrc, stride, 0, ks, T, lane);
+  }
+  __syncthreads();
   unsigned char* const otile = smem + 4 * pw;
   bf16_t* const ydst = y + (long long)b * T * C + hq * 4 * HS;
-  const bf16_t* qsrc = qkv + (long long)b * T * stride + (active ? hh : 0) * HS;
 
   const int nblk = Tp >> 5, half = lane >> 5;
 #pragma unroll
@@ -182,7 +257,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
     if (active) {
       bf16x8 qf[NK];
 #pragma unroll
-      for (int ks = 0; ks < NK; ++ks) qf[ks] = gfrag(qsrc, stride, qb, ks, T, lane);
+      for (int ks = 0; ks < NK; ++ks) {
+        qf[ks] = qnext[ks];
+        if (qb + 1 < nblk) qnext[ks] = gfrag(qsrc, stride, qb + 1, ks, T, lane);
+      }
       float m_run = -INFINITY, l_run = 0.f;
       f32x16 o = zero16();
       for (int kb = 0; kb <= qb; ++kb) {
@@ -474,46 +552,59 @@ __global__ __launch_bounds__(256, (HS == 16 && NB <= 3) ? 3 : 2) void attn_bwd_f
   float* Ds = Ls + Tp;
   const long long stride = 3LL * C;
   const bf16_t* qbase = qkv + (long long)b * T * stride + hq * 4 * HS;
-  stage4<HS>(qbase, stride, T, Tp, smem, pw, 0, heads_here, threadIdx.x);
-  stage4<HS>(qbase + C, stride, T, Tp, smem, pw, 1, heads_here, threadIdx.x);
-  {  // dO image + D[t] = sum_d dO[t,d] O[t,d]: the thread that stages a 16-B chunk of dO also fetches the same chunk of O
-     // (same coalesced pattern, in flight together with the other staging loads); the HS/8 chunk lanes of a head then
-     // add up through DPP/shuffles
-    constexpr int CPR = HS / 2, CPH = HS / 8;
-    const bf16_t* gsrc = dy + (long long)b * T * C + hq * 4 * HS;
-    const bf16_t* osrc = y + (long long)b * T * C + hq * 4 * HS;
-#pragma unroll
-    for (int task = threadIdx.x; task < Tp * CPR; task += 256) {
-      const int t = task / CPR, c = task - t * CPR, w = c / CPH;
-      uint4 g = make_uint4(0, 0, 0, 0), o = make_uint4(0, 0, 0, 0);
-      if (t < T && w < heads_here) {
-        g = *reinterpret_cast<const uint4*>(gsrc + (long long)t * C + c * 8);
-        o = *reinterpret_cast<const uint4*>(osrc + (long long)t * C + c * 8);
-      }
-      unsigned char* hw = smem + (size_t)w * pw;
-      *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(hw) + (size_t)2 * Tp * HS + t * HS + (c - w * CPH) * 8) = g;
-      float g8[8], o8[8];
-      unpack8(g, g8);
-      unpack8(o, o8);
-      float d = 0.f;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) d += g8[i] * o8[i];
-      d += __shfl_xor(d, 1, 64);
-      if constexpr (CPH == 4) d += __shfl_xor(d, 2, 64);
-      if ((c & (CPH - 1)) == 0) reinterpret_cast<float*>(hw + (size_t)3 * Tp * HS * 2)[Tp + t] = d;
-    }
-  }
-  __syncthreads();
   const bool active = hh < n_head;
   const int hc = active ? hh : 0;
+  const bf16_t* vsrc = qkv + (long long)b * T * stride + 2 * C + hc * HS;
+  // Every global load of the prologue is issued before the first LDS write: the four staged operands (Q, K, dO, O), this
+  // head's log-sum-exp rows and the V fragment of key block 0 cost ONE memory round trip instead of one per staging task
+  // (SQ counters of the looped version: 75 % of the wave cycles parked in s_waitcnt).
+  Stage4Regs<HS, Tp> rq, rk, rg, ro;
+  stage4_load<HS, Tp>(rq, qbase, stride, T, heads_here, threadIdx.x);
+  stage4_load<HS, Tp>(rk, qbase + C, stride, T, heads_here, threadIdx.x);
+  stage4_load<HS, Tp>(rg, dy + (long long)b * T * C + hq * 4 * HS, C, T, heads_here, threadIdx.x);
+  stage4_load<HS, Tp>(ro, y + (long long)b * T * C + hq * 4 * HS, C, T, heads_here, threadIdx.x);
+  float lrow[(Tp + 63) / 64];
+#pragma unroll
+  for (int i = 0; i < (Tp + 63) / 64; ++i) {
+    const int t = lane + 64 * i;
+    lrow[i] = lse[((long long)b * n_head + hc) * T + (t < T ? t : T - 1)];
+  }
+  bf16x8 vnext[NK];
+#pragma unroll
+  for (int ks = 0; ks < NK; ++ks) vnext[ks] = gfrag(vsrc, stride, 0, ks, T, lane);
+  stage4_store<HS, Tp>(rq, T, smem, pw, 0, heads_here, threadIdx.x);
+  stage4_store<HS, Tp>(rk, T, smem, pw, 1, heads_here, threadIdx.x);
+  stage4_store<HS, Tp>(rg, T, smem, pw, 2, heads_here, threadIdx.x);
+  {  // D[t] = sum_d dO[t,d] O[t,d]: the thread that staged a 16-B chunk of dO holds the same chunk of O; the HS/8 chunk lanes
+     // of a head add up through shuffles (masked rows / heads contribute nothing: their dO chunk is zeroed below)
+    constexpr int CPR = HS / 2, CPH = HS / 8, NT = (Tp * CPR + 255) / 256;
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      const int task = threadIdx.x + 256 * i, t = task / CPR, c = task - t * CPR, w = c / CPH;
+      const bool ok = t < T && w < heads_here;
+      float g8[8], o8[8];
+      unpack8(rg.v[i], g8);
+      unpack8(ro.v[i], o8);
+      float d = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) d += g8[e] * o8[e];
+      d = ok ? d : 0.f;
+      d += __shfl_xor(d, 1, 64);
+      if constexpr (CPH == 4) d += __shfl_xor(d, 2, 64);
+      if ((Tp * CPR % 256 == 0 || task < Tp * CPR) && (c & (CPH - 1)) == 0)
+        reinterpret_cast<float*>(smem + (size_t)w * pw + (size_t)3 * Tp * HS * 2)[Tp + t] = d;
+    }
+  }
+  // log-sum-exp of this head's rows, pre-multiplied by log2(e) (rows >= T: +inf -> p = 0)
+#pragma unroll
+  for (int i = 0; i < (Tp + 63) / 64; ++i) {
+    const int t = lane + 64 * i;
+    if (t < Tp) Ls[t] = (t < T) ? lrow[i] * LOG2E : INFINITY;
+  }
+  __syncthreads();
   unsigned char* const otile = smem + 4 * pw;   // two tiles (dK | dV, then dQ); during a sweep they hold the dS tiles
   static_assert(4 * 32 * DST_PITCH * 2 <= 2 * ot_bytes<HS>(), "dS tiles must fit the output tiles");
   bf16_t* const dsT = reinterpret_cast<bf16_t*>(otile) + wave * 32 * DST_PITCH;
-  const bf16_t* vsrc = qkv + (long long)b * T * stride + 2 * C + hc * HS;
-  // log-sum-exp of this head's rows, pre-multiplied by log2(e) (rows >= T: +inf -> p = 0)
-  for (int t = lane; t < Tp; t += 64) Ls[t] = (t < T) ? lse[((long long)b * n_head + hc) * T + t] * LOG2E : INFINITY;
-  __builtin_amdgcn_s_waitcnt(0xc07f);
-  __builtin_amdgcn_wave_barrier();
 
   const int half = lane >> 5;
   const bool tail16 = T - (NB - 1) * 32 <= 16;
@@ -525,13 +616,15 @@ __global__ __launch_bounds__(256, (HS == 16 && NB <= 3) ? 3 : 2) void attn_bwd_f
   for (int kb = 0; kb < NB; ++kb) {
     const int key = kb * 32 + (lane & 31);
     if (active) {
+      // issued now, used after the sweep over the query blocks: the rotation rows of this key block and the V fragment of the next
+      const RopeRow<HS> rot = rope_row_load<HS>(cos_t, sin_t, key < T ? key : 0, lane);
       bf16x8 kf[NK], vf[NK];
 #pragma unroll
       for (int ks = 0; ks < NK; ++ks) {
         kf[ks] = rfrag<HS>(Ks, kb, ks, lane);
-        vf[ks] = gfrag(vsrc, stride, kb, ks, T, lane);
+        vf[ks] = vnext[ks];
+        if (kb + 1 < NB) vnext[ks] = gfrag(vsrc, stride, kb + 1, ks, T, lane);
       }
-      const bf16x8 kt0 = tfrag<HS>(Ks, kb * 32, lane), kt1 = tfrag<HS>(Ks, kb * 32 + 16, lane);
       f32x16 dk = zero16(), dv = zero16();
 #pragma unroll
       for (int qb = kb; qb < NB; ++qb) {
@@ -569,14 +662,15 @@ __global__ __launch_bounds__(256, (HS == 16 && NB <= 3) ? 3 : 2) void attn_bwd_f
         if (!short_q) dk = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tfrag<HS>(Qs, qb * 32 + 16, lane), pfrag(ds + 8), dk, 0, 0, 0);
         __builtin_amdgcn_s_waitcnt(0xc07f);   // the tile writes above are visible to the whole wave
         __builtin_amdgcn_wave_barrier();
-        dq[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kt0, dst_frag(dsT, 0, lane), dq[qb], 0, 0, 0);
-        dq[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kt1, dst_frag(dsT, 16, lane), dq[qb], 0, 0, 0);
+        // (K^T fragments re-read per pair: 8 registers fewer across the sweep than keeping them)
+        dq[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tfrag<HS>(Ks, kb * 32, lane), dst_frag(dsT, 0, lane), dq[qb], 0, 0, 0);
+        dq[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tfrag<HS>(Ks, kb * 32 + 16, lane), dst_frag(dsT, 16, lane), dq[qb], 0, 0, 0);
         __builtin_amdgcn_wave_barrier();      // the next pair's tile writes stay behind these reads
       }
 #pragma unroll
       for (int r = 0; r < LIVE; ++r) dk[r] *= SCALE;
       __syncthreads();   // every wave is done with its dS tile
-      tile_put_grad<HS>(otile, wave, lane, dk, true, cos_t, sin_t, key < T ? key : 0);
+      tile_put_grad_rot<HS>(otile, wave, lane, dk, rot);
       tile_put_grad<HS>(otile + ot_bytes<HS>(), wave, lane, dv, false, cos_t, sin_t, 0);
     } else {
       __syncthreads();
@@ -586,13 +680,18 @@ __global__ __launch_bounds__(256, (HS == 16 && NB <= 3) ? 3 : 2) void attn_bwd_f
     tile_store<HS>(otile + ot_bytes<HS>(), dbase + 2 * C, stride, kb * 32, T, heads_here, threadIdx.x);
     __syncthreads();
   }
+  RopeRow<HS> qrot[NB];   // the rotation rows of all query blocks: one round trip
 #pragma unroll
   for (int qb = 0; qb < NB; ++qb) {
     const int q = qb * 32 + (lane & 31);
+    qrot[qb] = rope_row_load<HS>(cos_t, sin_t, q < T ? q : 0, lane);
+  }
+#pragma unroll
+  for (int qb = 0; qb < NB; ++qb) {
     if (active) {
 #pragma unroll
       for (int r = 0; r < LIVE; ++r) dq[qb][r] *= SCALE;
-      tile_put_grad<HS>(otile, wave, lane, dq[qb], true, cos_t, sin_t, q < T ? q : 0);
+      tile_put_grad_rot<HS>(otile, wave, lane, dq[qb], qrot[qb]);
     }
     __syncthreads();
     tile_store<HS>(otile, dbase, stride, qb * 32, T, heads_here, threadIdx.x);

@@ -268,6 +268,8 @@ int launch_gemm_nt(const GemmArgs& a, int a_f32, int epi, hipStream_t s) {
   const bool out_f32 = (epi == EPI_F32 || epi == EPI_RES_F32 || epi == EPI_ACC_F32);
   if (epi != EPI_CE_PARTIAL)
     COATI_CHECK_SHAPE(a.ldc % (out_f32 ? 4 : 8) == 0, "gemm_nt: ldc=%lld alignment", a.ldc);
+  COATI_CHECK_SHAPE(((long long)a.M + 128) * a.ldc < (1LL << 32) && ((long long)a.M + 128) * a.ld_aux < (1LL << 32),
+                    "gemm_nt: output / aux rows do not fit 32-bit element offsets (M=%d ldc=%lld ld_aux=%lld)", a.M, a.ldc, a.ld_aux);
   if (epi == EPI_RES_F32) COATI_CHECK_ARG(a.aux_in && a.ld_aux % 4 == 0, "gemm_nt: residual missing/misaligned");
   if (epi == EPI_GELU || epi == EPI_SILU || epi == EPI_GELU_GRAD) COATI_CHECK_ARG(a.aux_out && a.ld_aux % 8 == 0, "gemm_nt: aux_out missing");
   if (epi == EPI_DGELU || epi == EPI_DSILU || epi == EPI_MUL_AUX) COATI_CHECK_ARG(a.aux_in && a.ld_aux % 8 == 0, "gemm_nt: aux_in missing");

@@ -57,8 +57,10 @@ __device__ __forceinline__ void epilogue8(const GemmArgs& p, int row, int col0, 
   if (!rowok && EPI != EPI_QKV_ROPE) return;
   const int nst = p.n_store > N ? p.n_store : N;
   if (col0 >= nst) return;
-  const long long off = (long long)row * p.ldc + col0;
-  const long long aoff = (long long)row * p.ld_aux + col0;
+  // element offsets fit 32 bits (launch_gemm_nt refuses M * ld >= 2^32): one 32-bit multiply per operand instead of a 64-bit
+  // one (three quarter-rate instructions) -- the epilogues are issue-bound (tools/probes/rb_trace.py)
+  const long long off = (long long)((unsigned)row * (unsigned)p.ldc + (unsigned)col0);
+  const long long aoff = (long long)((unsigned)row * (unsigned)p.ld_aux + (unsigned)col0);
   const bool full = (col0 + 8 <= N);
 
   if (EPI == EPI_F32 || EPI == EPI_RES_F32 || EPI == EPI_ACC_F32) {

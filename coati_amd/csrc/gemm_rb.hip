@@ -32,6 +32,22 @@
 #define RB_PD 3                           // LDS read pipeline depth of the MFMA loop
 #endif
 
+// Probe build (-DCOATI_RB_TRACE, tools/probes/rb_trace.py): shader-clock totals per phase for the waves of the first 16
+// workgroups of the LAST launch: [wg][wave][prologue, mfma, wait for the next tile / the staged operands, epilogue, barrier].
+#ifdef COATI_RB_TRACE
+__device__ unsigned long long rb_trace_buf[16 * RB_MAX_W * 8];
+extern "C" int coati_rb_trace_read(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(rb_trace_buf), sizeof(rb_trace_buf)) == hipSuccess ? 0 : -3;
+}
+#define RB_T0() unsigned long long rb_t_last = __builtin_amdgcn_s_memtime(), rb_t_acc[5] = {0, 0, 0, 0, 0}
+#define RB_T(i) do { const unsigned long long rb_t_now = __builtin_amdgcn_s_memtime(); rb_t_acc[i] += rb_t_now - rb_t_last; rb_t_last = rb_t_now; } while (0)
+#define RB_TDUMP() do { if (blockIdx.x < 16 && lane == 0) { for (int i = 0; i < 5; ++i) rb_trace_buf[(blockIdx.x * RB_MAX_W + wave) * 8 + i] = rb_t_acc[i]; } } while (0)
+#else
+#define RB_T0() do { } while (0)
+#define RB_T(i) do { } while (0)
+#define RB_TDUMP() do { } while (0)
+#endif
+
 template <typename F>
 __device__ __forceinline__ void rb_call_restrict(F&& f, int j, const bf16_t* __restrict__ cur, bf16_t* __restrict__ nxt) {
   f(j, cur, nxt);
@@ -59,6 +75,7 @@ __global__ __launch_bounds__(64 * MAXW, 640 / (64 * MAXW)) void gemm_rb256_kerne
   constexpr bool EDGE = (EPI == EPI_EDGE_DPRE);   // per-column constants of the tile staged in Rs: [64 w1c | 64 b1]
   const int m0 = (blockIdx.x * W + wave) * 32;
   const int fr = lane & 31, fk = (lane >> 5) * 8;
+  RB_T0();
 
   // resident A slab: A-operand fragments, lane (i = lane&31 -> row, kg = lane>>5) holds k = ks*16 + kg*8 .. +7
   bf16x8 af[16];
@@ -189,6 +206,7 @@ __global__ __launch_bounds__(64 * MAXW, 640 / (64 * MAXW)) void gemm_rb256_kerne
   for (int a = 0; a < NACC; ++a) { bz[a] = has_bias ? bias_at(32 * a + fr) : 0.f; bn[a] = 0.f; }
   __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0)
   __syncthreads();
+  RB_T(0);
 
   const int sw = fr & 31, hk = lane >> 5;
   auto tile = [&](int j, const bf16_t* cur, bf16_t* nxt) {
@@ -230,9 +248,11 @@ __global__ __launch_bounds__(64 * MAXW, 640 / (64 * MAXW)) void gemm_rb256_kerne
         __builtin_amdgcn_sched_barrier(0);   // keep the reads ahead of the MFMAs (the scheduler sinks them otherwise)
       }
     }
+    RB_T(1);
     // The next tile had the whole MFMA phase to land.  Waiting HERE -- before this tile's stores are issued -- lets the
     // stores stay in flight across the barrier and through the next MFMA phase (vmcnt completes in order).
     __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0)
+    RB_T(2);
     if constexpr (EDGE) {   // read back after the lgkmcnt(0) + wave barrier below
       if (lane < RB_BN) { Rs[lane] = ew; Rs[64 + lane] = eb; }
     }
@@ -276,7 +296,9 @@ __global__ __launch_bounds__(64 * MAXW, 640 / (64 * MAXW)) void gemm_rb256_kerne
       }
       __builtin_amdgcn_wave_barrier();      // the next writes to Es stay behind these reads
     }
+    RB_T(3);
     __syncthreads();
+    RB_T(4);
 #pragma unroll
     for (int a = 0; a < NACC; ++a) bz[a] = bn[a];
   };
@@ -284,6 +306,7 @@ __global__ __launch_bounds__(64 * MAXW, 640 / (64 * MAXW)) void gemm_rb256_kerne
   // global_load_lds before an LDS read it cannot prove disjoint from the DMA's target
   for (int j = 0; j < ntiles; ++j)
     rb_call_restrict(tile, j, Bs + (j & 1) * RB_TILE_HALFS, Bs + ((j + 1) & 1) * RB_TILE_HALFS);
+  RB_TDUMP();
 }
 
 static int rb_waves(int M) {
