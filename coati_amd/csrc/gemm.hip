@@ -926,7 +926,7 @@ __global__ __launch_bounds__(512, 1) void wgrad256_table_kernel(const WgradTile*
   // fragment addresses: A block wm, 64-B chunk i (n columns 32 i ..); B block wn >> 1, chunk 2 (wn & 1) + j.  A second set
   // 64 KiB up (opaque to the compiler) keeps the immediates of ring slots 2, 3 inside the 16-bit offset field.
   typedef __attribute__((address_space(3))) v4s16 lds_v4;
-  unsigned la[4], lb[2], lah[4], lbh[2];
+  unsigned la[4], lb[2], lah[4], lbh[2], lax[4], lbx[2];   // (lax / lbx: a third set 128 KiB up, ring slot 4 of the 5-deep ring)
   {
     const int g = lane >> 4, kg = g >> 1, r0 = 8 * kg + ((lane & 15) >> 2), cb = (16 * (g & 1) + 4 * (lane & 3)) * 2;
 #pragma unroll
@@ -937,6 +937,12 @@ __global__ __launch_bounds__(512, 1) void wgrad256_table_kernel(const WgradTile*
     for (int i = 0; i < 4; ++i) { lah[i] = la[i] + 0x10000u; asm volatile("" : "+v"(lah[i])); }
 #pragma unroll
     for (int j = 0; j < 2; ++j) { lbh[j] = lb[j] + 0x10000u; asm volatile("" : "+v"(lbh[j])); }
+    if constexpr (NS > 4) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { lax[i] = la[i] + 0x20000u; asm volatile("" : "+v"(lax[i])); }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) { lbx[j] = lb[j] + 0x20000u; asm volatile("" : "+v"(lbx[j])); }
+    }
   }
   auto frag_at = [&](unsigned addr) __attribute__((always_inline)) {
     const v4s16 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(size_t)addr);
@@ -946,12 +952,12 @@ __global__ __launch_bounds__(512, 1) void wgrad256_table_kernel(const WgradTile*
     return __builtin_bit_cast(bf16x8, r);
   };
   auto fetch = [&](int slot, int ks, W2Frags& f) __attribute__((always_inline)) {
-    const bool high = slot * W2_STAGE_BYTES >= 0x10000;
-    const unsigned so = slot * W2_STAGE_BYTES - (high ? 0x10000u : 0u) + ks * 16 * WT_ROW_BYTES;
+    const int bank = slot * W2_STAGE_BYTES / 0x10000;   // which 64-KiB window the slot lies in
+    const unsigned so = slot * W2_STAGE_BYTES - bank * 0x10000u + ks * 16 * WT_ROW_BYTES;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) f.a[i] = frag_at((high ? lah[i] : la[i]) + so);
+    for (int i = 0; i < 4; ++i) f.a[i] = frag_at((bank == 2 ? lax[i] : bank == 1 ? lah[i] : la[i]) + so);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) f.b[j] = frag_at((high ? lbh[j] : lb[j]) + so);
+    for (int j = 0; j < 2; ++j) f.b[j] = frag_at((bank == 2 ? lbx[j] : bank == 1 ? lbh[j] : lb[j]) + so);
   };
   auto mma = [&](const W2Frags& f) __attribute__((always_inline)) {
 #pragma unroll
@@ -1018,12 +1024,13 @@ __global__ __launch_bounds__(512, 1) void wgrad256_table_kernel(const WgradTile*
     }
     __builtin_amdgcn_sched_barrier(0);
   };
-  static_assert(NS == 4, "the main loop is unrolled for a ring of 4");
+  static_assert(NS == 4 || NS == 5, "the main loop is unrolled for rings of 4 and 5");
   for (int c = 0;;) {
     step(WdSlot<0>()); if (++c >= c_end) break;
     step(WdSlot<1>()); if (++c >= c_end) break;
     step(WdSlot<2>()); if (++c >= c_end) break;
     step(WdSlot<3>()); if (++c >= c_end) break;
+    if constexpr (NS == 5) { step(WdSlot<4>()); if (++c >= c_end) break; }
   }
   __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0) + lgkmcnt(0): the over-issued (zero-page) DMAs have landed, the ring is free
   __builtin_amdgcn_s_barrier();
@@ -1097,23 +1104,30 @@ static int launch_wgrad_table_t(const WgradTile* dev_table, int n_tiles, hipStre
   return COATI_OK;
 }
 
+template <int NS>
+static int launch_wgrad256_t(const WgradTile* dev_table, int n_tiles, hipStream_t s) {
+  static bool attr_set = false;
+  auto kern = wgrad256_table_kernel<NS>;
+  constexpr int lds = NS * W2_STAGE_BYTES;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) {
+      coati_set_error("wgrad(table 256): hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+      return COATI_EHIP;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(n_tiles), dim3(512), lds, s, dev_table);
+  COATI_LAUNCH_CHECK("wgrad_table256");
+  return COATI_OK;
+}
+
 int launch_wgrad_table(const WgradTile* dev_table, int n_tiles, hipStream_t s, int tile_size) {
   COATI_CHECK_ARG(dev_table && n_tiles > 0, "wgrad_table: empty table");
   if (tile_size == 256) {
-    static bool attr_set = false;
-    auto kern = wgrad256_table_kernel<4>;
-    constexpr int lds = 4 * W2_STAGE_BYTES;
-    if (!attr_set) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-      if (e != hipSuccess) {
-        coati_set_error("wgrad(table 256): hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-        return COATI_EHIP;
-      }
-      attr_set = true;
-    }
-    hipLaunchKernelGGL(kern, dim3(n_tiles), dim3(512), lds, s, dev_table);
-    COATI_LAUNCH_CHECK("wgrad_table256");
-    return COATI_OK;
+    // ring depth: 4 stages of 32 KiB (96 KiB in flight per CU) or 5 (128 KiB in flight, all 160 KiB of LDS): COATI_WGRAD256_NS
+    static const int ns256 = getenv("COATI_WGRAD256_NS") ? atoi(getenv("COATI_WGRAD256_NS")) : 4;
+    return ns256 == 5 ? launch_wgrad256_t<5>(dev_table, n_tiles, s) : launch_wgrad256_t<4>(dev_table, n_tiles, s);
   }
   // ring depth (stages of 32 KiB; NS - 1 in flight): COATI_WGRAD_TABLE_NS = 3 | 4 (A/B switch)
   static const int ns = getenv("COATI_WGRAD_TABLE_NS") ? atoi(getenv("COATI_WGRAD_TABLE_NS")) : 4;

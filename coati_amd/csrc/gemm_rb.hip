@@ -27,6 +27,7 @@
 #define RB_ROPE_FLOATS (32 * 16)          // 2 KiB per wave: [32 rows][8 cos | 8 sin]
 #define RB_AUX_BYTES 4096                 // per wave: the 32 x 64 bf16 block of saved pre-activations of the current tile
 #define RB_MAX_W 10
+#define RB_HALF_W 12                      // "8 + 4" shape: 8 waves of 32 rows + 4 waves of 16 rows = the same 320 rows per workgroup
 #define RB_SPLIT_W 5
 #ifndef RB_PD
 #define RB_PD 3                           // LDS read pipeline depth of the MFMA loop
@@ -35,13 +36,13 @@
 // Probe build (-DCOATI_RB_TRACE, tools/probes/rb_trace.py): shader-clock totals per phase for the waves of the first 16
 // workgroups of the LAST launch: [wg][wave][prologue, mfma, wait for the next tile / the staged operands, epilogue, barrier].
 #ifdef COATI_RB_TRACE
-__device__ unsigned long long rb_trace_buf[16 * RB_MAX_W * 8];
+__device__ unsigned long long rb_trace_buf[16 * RB_HALF_W * 8];
 extern "C" int coati_rb_trace_read(unsigned long long* out) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(rb_trace_buf), sizeof(rb_trace_buf)) == hipSuccess ? 0 : -3;
 }
 #define RB_T0() unsigned long long rb_t_last = __builtin_amdgcn_s_memtime(), rb_t_acc[5] = {0, 0, 0, 0, 0}
 #define RB_T(i) do { const unsigned long long rb_t_now = __builtin_amdgcn_s_memtime(); rb_t_acc[i] += rb_t_now - rb_t_last; rb_t_last = rb_t_now; } while (0)
-#define RB_TDUMP() do { if (blockIdx.x < 16 && lane == 0) { for (int i = 0; i < 5; ++i) rb_trace_buf[(blockIdx.x * RB_MAX_W + wave) * 8 + i] = rb_t_acc[i]; } } while (0)
+#define RB_TDUMP() do { if (blockIdx.x < 16 && lane == 0) { for (int i = 0; i < 5; ++i) rb_trace_buf[(blockIdx.x * RB_HALF_W + wave) * 8 + i] = rb_t_acc[i]; } } while (0)
 #else
 #define RB_T0() do { } while (0)
 #define RB_T(i) do { } while (0)
@@ -54,10 +55,15 @@ __device__ __forceinline__ void rb_call_restrict(F&& f, int j, const bf16_t* __r
 }
 
 template <int EPI, int RB_BN, int MAXW, bool LN = false>
-__global__ __launch_bounds__(64 * MAXW, 640 / (64 * MAXW)) void gemm_rb256_kernel(GemmArgs p, int W) {
+__global__ __launch_bounds__(64 * MAXW, (640 / (64 * MAXW)) > 0 ? (640 / (64 * MAXW)) : 1) void gemm_rb256_kernel(GemmArgs p, int W, int half_from) {
+  // W waves; waves >= half_from own 16 rows instead of 32 (half_from >= W: none).  The kernel is issue-bound per SIMD (MFMA +
+  // epilogue VALU of the waves that share it: tools/probes/rb_trace.py), and 10 full waves sit 3 / 3 / 2 / 2 on the four
+  // SIMDs -- a fifth of the wave time went into the tile barrier.  8 full + 4 half waves put 2 + 1/2 slabs on every SIMD:
+  // a half wave multiplies a whole 32-row MFMA block (rows 16..31 duplicate rows 0..15) but writes out only 16 rows.
+  const int rows_wg = (half_from < W ? half_from : W) * 32 + (half_from < W ? (W - half_from) * 16 : 0);
   if (p.m_dev) {   // data-dependent row count (<= the M the grid was sized for): workgroups past the end leave before any barrier
     p.M = *p.m_dev;
-    if ((int)blockIdx.x * W * 32 >= p.M) return;
+    if ((int)blockIdx.x * rows_wg >= p.M) return;
   }
   constexpr int NACC = RB_BN / 32;                 // 32-column accumulator blocks per wave per tile
   constexpr int RB_TILE_HALFS = RB_BN * RB_K;      // [BN cols][256 k] bf16, unpadded, chunk-swizzled
@@ -70,17 +76,21 @@ __global__ __launch_bounds__(64 * MAXW, 640 / (64 * MAXW)) void gemm_rb256_kerne
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   float* const Es = reinterpret_cast<float*>(smem + 2 * RB_TILE_HALFS * 2) + wave * RB_EFLOATS;
   float* const Rs = reinterpret_cast<float*>(smem + 2 * RB_TILE_HALFS * 2) + W * RB_EFLOATS + wave * RB_ROPE_FLOATS;
-  unsigned char* const Xs = smem + 2 * RB_TILE_HALFS * 2 + (size_t)W * RB_EFLOATS * 4 + wave * RB_AUX_BYTES;   // DGELU / DSILU
+  constexpr int AUXB = (EPI == EPI_MUL_AUX) ? RB_AUX_BYTES / 2 : RB_AUX_BYTES;   // (one-byte codes: half the block)
+  unsigned char* const Xs = smem + 2 * RB_TILE_HALFS * 2 + (size_t)W * RB_EFLOATS * 4 + wave * AUXB;   // DGELU / DSILU / MUL_AUX
   constexpr bool AUX = (EPI == EPI_DGELU || EPI == EPI_DSILU || EPI == EPI_MUL_AUX);
   constexpr bool EDGE = (EPI == EPI_EDGE_DPRE);   // per-column constants of the tile staged in Rs: [64 w1c | 64 b1]
-  const int m0 = (blockIdx.x * W + wave) * 32;
+  const bool halfw = wave >= half_from;
+  const int m0 = blockIdx.x * rows_wg + (halfw ? half_from * 32 + (wave - half_from) * 16 : wave * 32);
+  const int nrow = halfw ? 16 : 32;               // rows this wave owns
   const int fr = lane & 31, fk = (lane >> 5) * 8;
+  const int fra = fr & (nrow - 1);                // row this lane LOADS (a half wave's rows 16..31 repeat rows 0..15)
   RB_T0();
 
   // resident A slab: A-operand fragments, lane (i = lane&31 -> row, kg = lane>>5) holds k = ks*16 + kg*8 .. +7
   bf16x8 af[16];
   if constexpr (!LN) {
-    const int rc = (m0 + fr) < p.M ? (m0 + fr) : p.M - 1;
+    const int rc = (m0 + fra) < p.M ? (m0 + fra) : p.M - 1;
     const bf16_t* ap = reinterpret_cast<const bf16_t*>(p.A) + (long long)rc * p.lda + fk;
 #pragma unroll
     for (int ks = 0; ks < 16; ++ks) af[ks] = *reinterpret_cast<const bf16x8*>(ap + ks * 16);
@@ -88,7 +98,7 @@ __global__ __launch_bounds__(64 * MAXW, 640 / (64 * MAXW)) void gemm_rb256_kerne
     // LayerNorm fused into the slab load (reference basic_transformer.py:165-173: x + attn(ln_1(x)), ... mlp(ln_2(x))):
     // the lane pair (fr, kg = 0 / 1) holds one f32 row of 256 = 2 x 16 chunks of 8; two-pass statistics in registers
     // (same formulas as ln_fwd_kernel), normalised row -> bf16 fragments + the saved copy the weight gradient reads
-    const int row = m0 + fr, rc = row < p.M ? row : p.M - 1;
+    const int row = m0 + fra, rc = row < p.M ? row : p.M - 1;
     const float* xp = p.ln_x + (long long)rc * p.ln_ldx + fk;
     float xf[16][8];
 #pragma unroll
@@ -121,7 +131,7 @@ __global__ __launch_bounds__(64 * MAXW, 640 / (64 * MAXW)) void gemm_rb256_kerne
       }
     q2 += __shfl_xor(q2, 32, 64);
     const float rstd = 1.0f / sqrtf(q2 / (float)RB_K + 1e-5f);
-    if (lane < 32 && row < p.M) {
+    if (lane < 32 && fr < nrow && row < p.M) {
       p.ln_mean[row] = mean;
       p.ln_rstd[row] = rstd;
     }
@@ -137,7 +147,7 @@ __global__ __launch_bounds__(64 * MAXW, 640 / (64 * MAXW)) void gemm_rb256_kerne
       for (int i = 0; i < 8; ++i) o[i] = (xf[ks][i] - mean) * rstd * g[i] + bt[i];
       const uint4 u = pack8(o);
       af[ks] = __builtin_bit_cast(bf16x8, u);
-      if (row < p.M) *reinterpret_cast<uint4*>(op + ks * 16) = u;
+      if (row < p.M && fr < nrow) *reinterpret_cast<uint4*>(op + ks * 16) = u;
     }
   }
   if (EPI == EPI_QKV_ROPE) {
@@ -260,6 +270,7 @@ __global__ __launch_bounds__(64 * MAXW, 640 / (64 * MAXW)) void gemm_rb256_kerne
     // (lane = column, registers = rows) -> rows of 64 contiguous columns
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf) {
+      if (hf == 1 && halfw) break;   // (wave-uniform) a half wave has no rows 16..31
 #pragma unroll
       for (int rr = 0; rr < 8; ++rr) {
         const int r = hf * 8 + rr;
@@ -344,13 +355,18 @@ bool gemm_rb256_supported(const GemmArgs& a, int a_f32, int epi) {
   return true;
 }
 
+template <int EPI, int BN>
+constexpr size_t rb_per_wave_bytes() {
+  return (size_t)16 * (BN + 4) * 4 + ((EPI == EPI_QKV_ROPE || EPI == EPI_EDGE_DPRE) ? RB_ROPE_FLOATS * 4
+                                      : (EPI == EPI_DGELU || EPI == EPI_DSILU) ? RB_AUX_BYTES : (EPI == EPI_MUL_AUX) ? RB_AUX_BYTES / 2 : 0);
+}
+
 template <int EPI, int BN, int MAXW, bool LN = false>
 static int launch_rb_shape(const GemmArgs& a, int W, hipStream_t s) {
   static bool attr_set = false;
   auto kern = gemm_rb256_kernel<EPI, BN, MAXW, LN>;
   const size_t tile_bytes = (size_t)2 * BN * RB_K * 2;              // double-buffered weight tile
-  const size_t per_wave = (size_t)16 * (BN + 4) * 4 + ((EPI == EPI_QKV_ROPE || EPI == EPI_EDGE_DPRE) ? RB_ROPE_FLOATS * 4
-                                                       : (EPI == EPI_DGELU || EPI == EPI_DSILU || EPI == EPI_MUL_AUX) ? RB_AUX_BYTES : 0);
+  constexpr size_t per_wave = rb_per_wave_bytes<EPI, BN>();
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)(tile_bytes + MAXW * per_wave));
@@ -361,7 +377,11 @@ static int launch_rb_shape(const GemmArgs& a, int W, hipStream_t s) {
     attr_set = true;
   }
   const int blocks = cdiv(cdiv(a.M, 32), W);
-  hipLaunchKernelGGL(kern, dim3(blocks), dim3(64 * W), tile_bytes + W * per_wave, s, a, W);
+  if constexpr (MAXW == RB_HALF_W) {   // 8 + 4: the same 320 rows per workgroup as 10 full waves
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(64 * RB_HALF_W), tile_bytes + RB_HALF_W * per_wave, s, a, RB_HALF_W, 8);
+  } else {
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(64 * W), tile_bytes + W * per_wave, s, a, W, W);
+  }
   COATI_LAUNCH_CHECK("gemm_rb256");
   return COATI_OK;
 }
@@ -371,14 +391,26 @@ static int launch_rb_t(const GemmArgs& a, hipStream_t s) {
   // COATI_RB_SPLIT=1: two 5-wave workgroups per CU on 32-column tiles instead of one 10-wave workgroup on 64-column tiles
   static const bool split = getenv("COATI_RB_SPLIT") != nullptr && atoi(getenv("COATI_RB_SPLIT")) != 0;
   const int W = rb_waves(a.M);
+  // 8 full + 4 half waves instead of 10 full ones: measured per epilogue (bench --all-sites, M = 81,920): FC1 + GELU/GELU' 3.65 ->
+  // 3.51 ms/step, lm_head 0.78 -> 0.75 / 0.73 -> 0.72, but FC2 input gradient 2.41 -> 2.63 and QKV 2.37 -> 2.43 -- it pays only
+  // where the epilogue outweighs the extra MFMA block of a half wave.  COATI_RB_HALF=0 | 1 forces it off / on everywhere (A/B);
+  // epilogues whose per-wave LDS does not fit 12 times keep 10 waves.
+  static const int half_env = getenv("COATI_RB_HALF") ? atoi(getenv("COATI_RB_HALF")) : -1;
+  const bool half_on = half_env >= 0 ? half_env != 0 : (EPI == EPI_GELU_GRAD || EPI == EPI_CE_PARTIAL || EPI == EPI_CE_BWD);
+  constexpr bool half_fits = 2 * 64 * RB_K * 2 + RB_HALF_W * rb_per_wave_bytes<EPI, 64>() <= 160 * 1024;
+  const bool half = half_on && half_fits && W == RB_MAX_W && a.m_dev == nullptr;
   if constexpr (EPI == EPI_QKV_ROPE || EPI == EPI_GELU_GRAD) {
-    if (a.ln_x != nullptr) return launch_rb_shape<EPI, 64, RB_MAX_W, true>(a, W, s);
+    if (a.ln_x != nullptr) {
+      if constexpr (half_fits) { if (half) return launch_rb_shape<EPI, 64, RB_HALF_W, true>(a, W, s); }
+      return launch_rb_shape<EPI, 64, RB_MAX_W, true>(a, W, s);
+    }
   }
   if (a.ln_x != nullptr) {
     coati_set_error("gemm_rb256: epilogue %d has no fused-LayerNorm variant", (int)EPI);
     return COATI_EARG;
   }
   if (split && W == RB_MAX_W) return launch_rb_shape<EPI, 32, RB_SPLIT_W>(a, RB_SPLIT_W, s);
+  if constexpr (half_fits) { if (half) return launch_rb_shape<EPI, 64, RB_HALF_W>(a, W, s); }
   return launch_rb_shape<EPI, 64, RB_MAX_W>(a, W, s);
 }
 

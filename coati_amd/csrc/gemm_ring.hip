@@ -47,6 +47,22 @@ __device__ __forceinline__ void rg_wait_vm(int n) {
   else __builtin_amdgcn_s_waitcnt(0x0f70);
 }
 
+// Probe build (-DCOATI_RB_TRACE, tools/probes/rb_trace.py): shader-clock totals per phase for the waves of the first 16
+// workgroups of the last launch: [wg][wave][before the loop, wait (vmcnt + barrier), MFMA + DMA issue, write-out].
+#ifdef COATI_RB_TRACE
+__device__ unsigned long long rg_trace_buf[16 * RG_WAVES * 8];
+extern "C" int coati_rg_trace_read(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(rg_trace_buf), sizeof(rg_trace_buf)) == hipSuccess ? 0 : -3;
+}
+#define RG_T0() unsigned long long rg_t_last = __builtin_amdgcn_s_memtime(), rg_t_acc[4] = {0, 0, 0, 0}
+#define RG_T(i) do { const unsigned long long rg_t_now = __builtin_amdgcn_s_memtime(); rg_t_acc[i] += rg_t_now - rg_t_last; rg_t_last = rg_t_now; } while (0)
+#define RG_TDUMP() do { if (blockIdx.x < 16 && lane == 0) { for (int i = 0; i < 4; ++i) rg_trace_buf[(blockIdx.x * RG_WAVES + wave) * 8 + i] = rg_t_acc[i]; } } while (0)
+#else
+#define RG_T0() do { } while (0)
+#define RG_T(i) do { } while (0)
+#define RG_TDUMP() do { } while (0)
+#endif
+
 template <int EPI>
 __global__ __launch_bounds__(64 * RG_WAVES, 1) void gemm_ring256_kernel(GemmArgs p, int nblocks) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -152,9 +168,11 @@ __global__ __launch_bounds__(64 * RG_WAVES, 1) void gemm_ring256_kernel(GemmArgs
 
   const int total = mine * nk;
   const int vm_keep = my_dmas * (RG_NS - 2);
+  RG_T0();
   issue();
   issue();
   acc_init();
+  RG_T(0);
   int sc = 0, kc = 0, bc = 0;   // MFMA pointer: ring slot, k chunk, block index
   int st_cnt = 0, st_age = 2;   // stores issued by the last write-out, stages since then
   for (int s = 0; s < total; ++s) {
@@ -169,6 +187,7 @@ __global__ __launch_bounds__(64 * RG_WAVES, 1) void gemm_ring256_kernel(GemmArgs
     }
     ++st_age;
     __builtin_amdgcn_s_barrier();
+    RG_T(1);
     const unsigned char* S = smem + sc * RG_STAGE_BYTES;
     // two fragment sets: the 5 reads of k step ks + 1 are issued in the shadow of the 4 MFMAs of step ks
     {
@@ -200,6 +219,7 @@ __global__ __launch_bounds__(64 * RG_WAVES, 1) void gemm_ring256_kernel(GemmArgs
       issue_advance();
     }
     sc = sc + 1 == RG_NS ? 0 : sc + 1;
+    RG_T(2);
     if (++kc == nk) {
       // the block is complete: write it out straight from the accumulator layout (the next block's first stages are in
       // flight meanwhile)
@@ -252,8 +272,10 @@ __global__ __launch_bounds__(64 * RG_WAVES, 1) void gemm_ring256_kernel(GemmArgs
       kc = 0;
       ++bc;
       acc_init();
+      RG_T(3);
     }
   }
+  RG_TDUMP();
 }
 
 bool gemm_ring256_supported(const GemmArgs& a, int a_f32, int epi) {

@@ -33,3 +33,27 @@ us = timeit(f); dump("FC1 + GELU/GELU' (bf16 A)", us)
 W3 = (torch.randn(768, 256, generator=g) * 0.05).to(dev).bfloat16()
 f = lambda: ops.gemm_nt(A, W3, None, ops.EPI_BF16)
 us = timeit(f); dump("plain bf16 N=768", us)
+
+
+def dump_ring(tag, us):
+    buf = (ctypes.c_uint64 * (16 * 10 * 8))()
+    assert lib.coati_rg_trace_read(buf) == 0
+    a = np.array(buf, dtype=np.float64).reshape(16, 10, 8)[:, :, :4]
+    tot = a.sum(-1).mean()
+    names = ["before loop", "wait (vmcnt + barrier)", "MFMA + DMA issue", "write-out"]
+    print(f"{tag}: {us:.1f} us/launch; cycles per wave {tot:.0f} = " + "  ".join(f"{n} {a[:, :, i].mean():.0f} ({100 * a[:, :, i].mean() / tot:.0f}%)" for i, n in enumerate(names)))
+    print("   per wave (wg 0): " + " | ".join(" ".join(f"{a[0, w, i]:.0f}" for i in range(4)) for w in (0, 1, 4, 8, 9)))
+G = torch.randn(M, 1024, generator=g).to(dev).bfloat16()
+W2 = (torch.randn(256, 1024, generator=g) * 0.05).to(dev).bfloat16()
+b2 = torch.randn(256, generator=g).to(dev)
+X = torch.randn(M, 256, generator=g).to(dev)
+out = torch.empty(M, 256, device=dev)
+f = lambda: ops.gemm_nt(G, W2, b2, ops.EPI_RES_F32, aux_in=X, out=out)
+us = timeit(f); dump_ring("ring: FC2 + residual (K = 1024, f32 out)", us)
+out16 = torch.empty(M, 256, device=dev, dtype=torch.bfloat16)
+f = lambda: ops.gemm_nt(G, W2, None, ops.EPI_BF16, out=out16)
+us = timeit(f); dump_ring("ring: FC1 input gradient (K = 1024, bf16 out)", us)
+Y = torch.randn(M, 256, generator=g).to(dev).bfloat16()
+Wp = (torch.randn(256, 256, generator=g) * 0.05).to(dev).bfloat16()
+f = lambda: ops.gemm_nt(Y, Wp, b2, ops.EPI_RES_F32, aux_in=X, out=out)
+us = timeit(f); dump_ring("ring: proj + residual (K = 256, f32 out)", us)
