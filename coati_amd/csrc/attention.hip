@@ -28,6 +28,21 @@ template <int HS> __device__ __forceinline__ constexpr float att_scale_log2e() {
 typedef short v4s16a __attribute__((ext_vector_type(4)));
 typedef short v8s16a __attribute__((ext_vector_type(8)));
 
+// LDS bank swizzle of the row-major [T][HS] images (round 2; SQ_LDS_BANK_CONFLICT was 41 % / 50 % of SQ_LDS_IDX_ACTIVE in the
+// backward / forward kernel).  A row is 32 B (HS = 16) or 64 B (HS = 32), so 8 (4) consecutive rows span the 64 banks and
+// rows 8 (4) apart start on the same bank: the 16 lanes of one ds_read_b128 cycle (16 different rows, same 16-B chunk) hit
+// every bank group twice (four times).  The 16-B chunk c of row t is therefore stored at chunk position
+// c ^ ((t / rows_per_span) & (chunks_per_row - 1)): rows that used to collide now sit in different chunks.  Applied by the
+// staging writes and by both fragment reads (the transpose read takes per-lane addresses).
+template <int HS>
+__device__ __forceinline__ int img_chunk(int t, int c) {
+  constexpr int CPH = HS / 8, SPAN = 256 / (HS * 2);   // chunks per row; rows per 256-B bank span
+  return c ^ ((t / SPAN) & (CPH - 1));
+}
+// The per-head image sets of a workgroup are ATT_PW_PAD bytes further apart than their size: with a multiple of 256 B
+// between them, the 8 lanes of one ds_write_b128 cycle of the staging (same row, 4 heads x 2 chunks) hit the same banks 4 times.
+#define ATT_PW_PAD 64
+
 // Cooperative staging of one operand for the 4 heads of a workgroup: rows t < T, 4 * HS contiguous bf16 per row (128 /
 // 256 B); HS/2 consecutive threads fetch one row -> fully coalesced 16-B loads.  Chunk c of a row lands in head
 // c / (HS/8)'s row-major image at dims (c % (HS/8)) * 8.  Rows [T, Tp) are zero-filled.  q and k arrive already rotated
@@ -41,7 +56,7 @@ __device__ __forceinline__ void stage4(const bf16_t* src, long long stride, int 
     uint4 v = make_uint4(0, 0, 0, 0);
     if (t < T && w < heads_here) v = *reinterpret_cast<const uint4*>(src + (long long)t * stride + c * 8);
     bf16_t* img = reinterpret_cast<bf16_t*>(smem + (size_t)w * per_wave_bytes) + (size_t)image * Tp * HS;
-    *reinterpret_cast<uint4*>(img + t * HS + (c - w * CPH) * 8) = v;
+    *reinterpret_cast<uint4*>(img + t * HS + img_chunk<HS>(t, c - w * CPH) * 8) = v;
   }
 }
 
@@ -72,7 +87,7 @@ __device__ __forceinline__ void stage4_store(const Stage4Regs<HS, TP>& r, int T,
     const unsigned keep = (t < T && w < heads_here) ? 0xffffffffu : 0u;   // mask, not select: the load stays unpredicated
     const uint4 v = make_uint4(r.v[i].x & keep, r.v[i].y & keep, r.v[i].z & keep, r.v[i].w & keep);
     bf16_t* img = reinterpret_cast<bf16_t*>(smem + (size_t)w * per_wave_bytes) + (size_t)image * TP * HS;
-    *reinterpret_cast<uint4*>(img + t * HS + (c - w * CPH) * 8) = v;
+    *reinterpret_cast<uint4*>(img + t * HS + img_chunk<HS>(t, c - w * CPH) * 8) = v;
   }
 }
 
@@ -80,7 +95,9 @@ __device__ __forceinline__ void stage4_store(const Stage4Regs<HS, TP>& r, int T,
 // lane (r = lane&31, half = lane>>5) -> row blk*32+r, dims ks*16 + half*8..+7
 template <int HS>
 __device__ __forceinline__ bf16x8 rfrag(const bf16_t* rm, int blk, int ks, int lane) {
-  return *reinterpret_cast<const bf16x8*>(rm + (blk * 32 + (lane & 31)) * HS + ks * 16 + (lane >> 5) * 8);
+  // (blk * 32 rows do not change the swizzle: the offset inside the block is a function of the lane alone)
+  const int tl = lane & 31;
+  return *reinterpret_cast<const bf16x8*>(rm + blk * 32 * HS + (tl * HS + img_chunk<HS>(tl, ks * 2 + (lane >> 5)) * 8));
 }
 // The same fragment straight from global memory (rows >= T read as zero): for the operand that is needed for ONE
 // 32-row block only, so it never occupies LDS.
@@ -97,9 +114,16 @@ __device__ __forceinline__ bf16x8 gfrag(const bf16_t* src, long long stride, int
 template <int HS>
 __device__ __forceinline__ bf16x8 tfrag(const bf16_t* rm, int base, int lane) {
   typedef __attribute__((address_space(3))) v4s16a lds_v4;
-  const bf16_t* p = rm + (base + 4 * (lane >> 5) + ((lane & 15) >> 2)) * HS + 4 * (lane & 3) + (HS == 32 ? 16 * ((lane >> 4) & 1) : 0);
+  // this lane's 8-B piece: dims 4 (lane & 3) .. + 3 (+ 16 for the second 16-lane group at HS = 32) = chunk c, half (lane & 1);
+  // rows t and t + 8 of the two reads may swizzle differently (HS = 16: they do)
+  // (base is a multiple of 16 rows: it does not change the swizzle, so both offsets are functions of the lane alone and every
+  // call shares the same two address registers)
+  const int tl = 4 * (lane >> 5) + ((lane & 15) >> 2);
+  const int c = ((lane & 3) >> 1) + (HS == 32 ? 2 * ((lane >> 4) & 1) : 0), h8 = 4 * (lane & 1);
+  const bf16_t* p = rm + base * HS + (tl * HS + img_chunk<HS>(tl, c) * 8 + h8);
+  const bf16_t* p2 = rm + base * HS + ((tl + 8) * HS + img_chunk<HS>(tl + 8, c) * 8 + h8);
   const v4s16a lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)p);
-  const v4s16a hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(p + 8 * HS));
+  const v4s16a hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)p2);
   // lanes with d >= 16 feed don't-care rows of the A operand: MFMA output rows are independent and rows 16..31 of the
   // result (accumulator registers 8..15) are never read, so no masking is needed.
   const v8s16a r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
@@ -223,7 +247,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
   const int hh = hq * 4 + wave;
   const int heads_here = (n_head - hq * 4) < 4 ? (n_head - hq * 4) : 4;
   const int C = n_head * HS, Tp = NB ? 32 * NB : ((T + 31) & ~31);
-  const size_t pw = (size_t)2 * Tp * HS * 2;
+  const size_t pw = (size_t)2 * Tp * HS * 2 + ATT_PW_PAD;
   bf16_t* Ks = reinterpret_cast<bf16_t*>(smem + (size_t)wave * pw);
   bf16_t* Vs = Ks + Tp * HS;
   const long long stride = 3LL * C;
@@ -316,7 +340,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
 template <int HS, int NB>
 static int launch_attn_fwd_t(const bf16_t* qkv, bf16_t* y, float* lse, int B, int T, int n_head, hipStream_t s) {
   const int Tp = (T + 31) & ~31;
-  const size_t lds = (size_t)4 * 2 * Tp * HS * 2 + ot_bytes<HS>();
+  const size_t lds = (size_t)4 * (2 * Tp * HS * 2 + ATT_PW_PAD) + ot_bytes<HS>();
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<HS, NB>),
@@ -364,7 +388,7 @@ __global__ __launch_bounds__(256, HS == 16 ? 4 : 2) void attn_bwd_dq_kernel(cons
   const int hh = hq * 4 + wave;
   const int heads_here = (n_head - hq * 4) < 4 ? (n_head - hq * 4) : 4;
   const int C = n_head * HS, Tp = (T + 31) & ~31;
-  const size_t pw = (size_t)2 * Tp * HS * 2;
+  const size_t pw = (size_t)2 * Tp * HS * 2 + ATT_PW_PAD;
   bf16_t* Ks = reinterpret_cast<bf16_t*>(smem + (size_t)wave * pw);
   bf16_t* Vs = Ks + Tp * HS;
   const long long stride = 3LL * C;
@@ -444,7 +468,7 @@ __global__ __launch_bounds__(256, HS == 16 ? 3 : 2) void attn_bwd_dkv_kernel(con
   const int hh = hq * 4 + wave;
   const int heads_here = (n_head - hq * 4) < 4 ? (n_head - hq * 4) : 4;
   const int C = n_head * HS, Tp = (T + 31) & ~31;
-  const size_t pw = (size_t)2 * Tp * HS * 2 + (size_t)2 * Tp * 4;
+  const size_t pw = (size_t)2 * Tp * HS * 2 + (size_t)2 * Tp * 4 + ATT_PW_PAD;
   unsigned char* my = smem + (size_t)wave * pw;
   bf16_t* Qs = reinterpret_cast<bf16_t*>(my);
   bf16_t* Gs = Qs + Tp * HS;
@@ -543,7 +567,7 @@ __global__ __launch_bounds__(256, (HS == 16 && NB <= 3) ? 3 : 2) void attn_bwd_f
   const int hh = hq * 4 + wave;
   const int heads_here = (n_head - hq * 4) < 4 ? (n_head - hq * 4) : 4;
   const int C = n_head * HS;
-  constexpr size_t pw = (size_t)3 * Tp * HS * 2 + (size_t)2 * Tp * 4;
+  constexpr size_t pw = (size_t)3 * Tp * HS * 2 + (size_t)2 * Tp * 4 + ATT_PW_PAD;
   unsigned char* my = smem + (size_t)wave * pw;
   bf16_t* Qs = reinterpret_cast<bf16_t*>(my);
   bf16_t* Ks = Qs + Tp * HS;
@@ -703,7 +727,7 @@ template <int HS, int NB>
 static int launch_attn_bwd_fused_t(const bf16_t* qkv, const bf16_t* y, const bf16_t* dy, const float* lse, bf16_t* dqkv,
                                    const float* cos_t, const float* sin_t, int B, int T, int n_head, hipStream_t s) {
   constexpr int Tp = 32 * NB;
-  const size_t lds = (size_t)4 * ((size_t)3 * Tp * HS * 2 + (size_t)2 * Tp * 4) + 2 * ot_bytes<HS>();
+  const size_t lds = (size_t)4 * ((size_t)3 * Tp * HS * 2 + (size_t)2 * Tp * 4 + ATT_PW_PAD) + 2 * ot_bytes<HS>();
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_fused_kernel<HS, NB>),
@@ -725,8 +749,8 @@ template <int HS>
 static int launch_attn_bwd_t(const bf16_t* qkv, const bf16_t* y, const bf16_t* dy, const float* lse, float* dscratch,
                              bf16_t* dqkv, const float* cos_t, const float* sin_t, int B, int T, int n_head, hipStream_t s) {
   const int Tp = (T + 31) & ~31;
-  const size_t lds_dq = (size_t)4 * 2 * Tp * HS * 2 + ot_bytes<HS>();
-  const size_t lds_dkv = (size_t)4 * (2 * Tp * HS * 2 + 2 * Tp * 4) + 2 * ot_bytes<HS>();
+  const size_t lds_dq = (size_t)4 * (2 * Tp * HS * 2 + ATT_PW_PAD) + ot_bytes<HS>();
+  const size_t lds_dkv = (size_t)4 * (2 * Tp * HS * 2 + 2 * Tp * 4 + ATT_PW_PAD) + 2 * ot_bytes<HS>();
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel<HS>),
