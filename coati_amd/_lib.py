@@ -22,6 +22,7 @@ _SIGS = {
     "coati_gemm_nt": [P, I, L, P, L, I, I, I, P, L, I, P, P, P, L, I, P],
     "coati_mlp_permute_w1": [P, L, P, L, I, I, P],
     "coati_mlp_fwd": [P, L, P, P, P, L, P, P, L, P, I, I, I, P, L, P, P, P, P, L, P, L, P],
+    "coati_mlp_fwd_paired": [P, L, P, P, P, L, P, P, L, P, I, I, I, P, L, P, P, P, P, L, P, L, P],
     "coati_mlp_dgrad": [P, L, P, L, P, L, P, I, I, I, P, L, P, L, P],
     "coati_gemm_ce_partial": [P, L, P, L, I, I, I, P, P],
     "coati_ce_finish": [P, I, P, L, P, L, P, P, P, I, I, I, P],

@@ -38,6 +38,18 @@ int coati_mlp_fwd(const float* x, int64_t ldx, const float* gamma, const float* 
   return launch_mlp_fwd(m, S_(stream));
 }
 
+int coati_mlp_fwd_paired(const float* x, int64_t ldx, const float* gamma, const float* beta, const uint16_t* W1, int64_t ldw1,
+                         const float* b1, const uint16_t* W2, int64_t ldw2, const float* b2, int M, int C, int Hd, uint16_t* a,
+                         int64_t lda, float* mean, float* rstd, uint16_t* g, uint8_t* dg, int64_t ldh, float* out, int64_t ldo,
+                         void* stream) {
+  MlpArgs m;
+  memset(&m, 0, sizeof(m));
+  m.M = M; m.C = C; m.Hd = Hd; m.x = x; m.ldx = ldx; m.gamma = gamma; m.beta = beta; m.mean = mean; m.rstd = rstd;
+  m.a = a; m.lda = lda; m.W1 = W1; m.ldw1 = ldw1; m.b1 = b1; m.W2 = W2; m.ldw2 = ldw2; m.b2 = b2; m.h = g; m.d = dg;
+  m.ldh = ldh; m.out = out; m.ldo = ldo;
+  return launch_mlp_pair_fwd(m, S_(stream));
+}
+
 int coati_mlp_dgrad(const uint16_t* dY, int64_t lddy, const uint16_t* W2T, int64_t ldw2t, const uint16_t* W1T,
                     int64_t ldw1t, const uint8_t* dgelu, int M, int C, int Hd, uint16_t* dh, int64_t ldh,
                     uint16_t* dA, int64_t ldda, void* stream) {

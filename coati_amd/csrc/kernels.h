@@ -110,6 +110,9 @@ bool mlp_chain_supported(const MlpArgs& a);
 int launch_mlp_fwd(const MlpArgs& a, hipStream_t s);   // W1 = the column-permuted fc1 copy (launch_mlp_permute_w1); d = 8-bit codes
 int launch_mlp_permute_w1(const bf16_t* W, long long ldw, bf16_t* Wp, long long ldp, int Hd, int C, hipStream_t s);
 int launch_mlp_bwd(const MlpArgs& a, hipStream_t s);
+// Paired-wave forward (gemm_mlp2.hip): same operands, W1 = the plain fc1 weight [Hd, C]
+bool mlp_pair_supported(const MlpArgs& a);
+int launch_mlp_pair_fwd(const MlpArgs& a, hipStream_t s);
 
 // dW[N,K] (f32, atomic +=) = A[M,N]^T * B[M,K];  dbias[N] (atomic +=) = colsum(A) if non-null
 struct WgradArgs {

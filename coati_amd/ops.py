@@ -214,13 +214,16 @@ def mlp_permute_w1(W1):
     return Wp
 
 
-def mlp_fwd(x, gamma, beta, W1, b1, W2, b2, W1p=None):
-    """chained LayerNorm -> W1 -> NewGELU -> W2 -> residual (C = 256).  Returns (out f32, a bf16, mean, rstd, g bf16, dg u8 codes)."""
+def mlp_fwd(x, gamma, beta, W1, b1, W2, b2, W1p=None, paired=False):
+    """chained LayerNorm -> W1 -> NewGELU -> W2 -> residual (C = 256).  Returns (out f32, a bf16, mean, rstd, g bf16, dg u8 codes).
+    paired=True: the paired-wave kernel (gemm_mlp2.hip, plain W1)."""
     _need_cuda(x, W1, W2)
     M, C = x.shape
     Hd = W1.shape[0]
     dev = x.device
-    if W1p is None:
+    if paired:
+        W1p = W1
+    elif W1p is None:
         W1p = mlp_permute_w1(W1)
     a = torch.empty(M, C, device=dev, dtype=torch.bfloat16)
     g = torch.empty(M, Hd, device=dev, dtype=torch.bfloat16)
@@ -228,7 +231,7 @@ def mlp_fwd(x, gamma, beta, W1, b1, W2, b2, W1p=None):
     mean = torch.empty(M, device=dev, dtype=torch.float32)
     rstd = torch.empty(M, device=dev, dtype=torch.float32)
     out = torch.empty(M, C, device=dev, dtype=torch.float32)
-    _lib.call("coati_mlp_fwd", ptr(x), x.stride(0), ptr(gamma), ptr(beta), ptr(W1p), W1p.stride(0), ptr(b1), ptr(W2), W2.stride(0),
+    _lib.call("coati_mlp_fwd_paired" if paired else "coati_mlp_fwd", ptr(x), x.stride(0), ptr(gamma), ptr(beta), ptr(W1p), W1p.stride(0), ptr(b1), ptr(W2), W2.stride(0),
               ptr(b2), M, C, Hd, ptr(a), C, ptr(mean), ptr(rstd), ptr(g), ptr(dg), Hd, ptr(out), C, stream())
     return out, a, mean, rstd, g, dg
 

@@ -73,6 +73,13 @@ int coati_mlp_fwd(const float* x, int64_t ldx, const float* gamma, const float* 
                   const float* b1, const uint16_t* W2, int64_t ldw2, const float* b2, int M, int C, int Hd, uint16_t* a,
                   int64_t lda, float* mean, float* rstd, uint16_t* g, uint8_t* dg, int64_t ldh, float* out, int64_t ldo,
                   void* stream);
+/* The same forward as ONE kernel of paired waves (gemm_mlp2.hip): a producer wave runs FC1 + NewGELU on 32-unit tiles and hands
+ * each g tile through LDS to its consumer wave, which accumulates FC2 into a 32 x 256 block initialised with x + b2.  W1 is
+ * the plain fc1 weight [Hd, C] (no column permutation); every other operand as coati_mlp_fwd. */
+int coati_mlp_fwd_paired(const float* x, int64_t ldx, const float* gamma, const float* beta, const uint16_t* W1, int64_t ldw1,
+                         const float* b1, const uint16_t* W2, int64_t ldw2, const float* b2, int M, int C, int Hd, uint16_t* a,
+                         int64_t lda, float* mean, float* rstd, uint16_t* g, uint8_t* dg, int64_t ldh, float* out, int64_t ldo,
+                         void* stream);
 /* the matching input-gradient chain: dh = (dY W2) * dequant(dgelu) (bf16 [M, Hd], written);  dA = dh W1 (bf16 [M, C]).
  *   W2T = W2 transposed [Hd, C], W1T = W1 transposed [C, Hd] (the engine's transposed bf16 shadows). */
 int coati_mlp_dgrad(const uint16_t* dY, int64_t lddy, const uint16_t* W2T, int64_t ldw2t, const uint16_t* W1T,

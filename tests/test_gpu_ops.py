@@ -333,6 +333,18 @@ def test_mlp_chain(ops, M, Hd):
     assert float((ops.dq8(dg).cpu() - pre.grad).abs().max()) <= 0.0025 + 2e-5
     out_ref = xr + gh.float().cpu() @ W2.float().cpu().t() + b2.cpu()
     check(f"mlp chain out M{M} Hd{Hd}", out.cpu(), out_ref, 2e-6)
+    # the paired-wave forward (gemm_mlp2.hip): same operands, plain W1; held to the same references
+    out2, a2, mean2, rstd2, gh2, dg2 = ops.mlp_fwd(x, gamma, beta, W1, b1, W2, b2, paired=True)
+    torch.cuda.synchronize()
+    check(f"mlp paired a M{M} Hd{Hd}", a2.float().cpu(), a_ref, TB)
+    check(f"mlp paired mean M{M}", mean2.cpu(), xr.mean(1), 4e-6)
+    check(f"mlp paired rstd M{M}", rstd2.cpu(), 1.0 / torch.sqrt(xr.var(1, unbiased=False) + 1e-5), 4e-6)
+    pre2 = (a2.float().cpu() @ W1.float().cpu().t() + b1.cpu()).requires_grad_(True)
+    gref2 = gelu(pre2)
+    gref2.sum().backward()
+    check(f"mlp paired g M{M} Hd{Hd}", gh2.float().cpu(), gref2.detach(), TB)
+    assert float((ops.dq8(dg2).cpu() - pre2.grad).abs().max()) <= 0.0025 + 2e-5
+    check(f"mlp paired out M{M} Hd{Hd}", out2.cpu(), xr + gh2.float().cpu() @ W2.float().cpu().t() + b2.cpu(), 2e-6)
     # backward chain
     dY = (torch.randn(M, C, generator=g) * 0.5).to(DEV).bfloat16()
     W2T = W2.t().contiguous(); W1T = W1.t().contiguous()

@@ -29,6 +29,11 @@ def chain_fwd():
               ptr(mean), ptr(rstd), ptr(g), ptr(dg), Hd, ptr(out), C, stream())
 
 
+def pair_fwd():
+    _lib.call("coati_mlp_fwd_paired", ptr(x), C, ptr(gamma), ptr(beta), ptr(W1), C, ptr(b1), ptr(W2), Hd, ptr(b2), M, C, Hd, ptr(a), C,
+              ptr(mean), ptr(rstd), ptr(g), ptr(dg), Hd, ptr(out), C, stream())
+
+
 def chain_bwd():
     _lib.call("coati_mlp_dgrad", ptr(dY), C, ptr(W2T), C, ptr(W1T), Hd, ptr(dg), M, C, Hd, ptr(dh), Hd, ptr(dA), C, stream())
 
@@ -47,6 +52,7 @@ def split_bwd():
 
 
 row("mlp chain fwd (x, a, g, dg u8, out: 4608 B/row)", timeit(chain_fwd), fl, M * 4608.0)
+row("mlp paired-wave fwd (same 4608 B/row)", timeit(pair_fwd), fl, M * 4608.0)
 row("mlp chain dgrad (dY, dg u8, dh, dA: 4096 B/row)", timeit(chain_bwd), fl, M * 4096.0)
 row("two launches fwd (FC1+GELU', FC2+res)", timeit(split_fwd), fl, M * 7680.0)
 row("two launches dgrad (FC2 dgrad x GELU', FC1 dgrad)", timeit(split_bwd), fl, M * 6144.0)
