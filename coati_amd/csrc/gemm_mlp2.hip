@@ -22,6 +22,9 @@
 #include <cstdlib>
 #include "gemm_epi.h"
 
+#ifndef M2_QPRIO
+#define M2_QPRIO 2
+#endif
 #define M2_C 256
 #define M2_BN 32                               // hidden units per tile
 #define M2_ROWS 160                            // rows per workgroup
@@ -215,6 +218,7 @@ __global__ __launch_bounds__(640, 1) void mlp_pair_fwd_kernel(MlpArgs p) {
     M2_TDUMP();
   } else {
     // =============================== Q: FC2 + residual ===============================
+    if (p.M >= 0) __builtin_amdgcn_s_setprio(M2_QPRIO);   // consumers are short MFMA bursts: let them go first (A/B: -DM2_QPRIO=0)
     // accumulator = x + b2: lane = output column inside a 32-column block, registers = rows (frag_row)
     f32x16 acc2[8];
     // The residual x (128 values per lane) is NOT loaded up front -- 128 dword loads per consumer wave next to the producers'
