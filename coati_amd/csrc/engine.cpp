@@ -522,6 +522,18 @@ int xformer_fwd(coati_engine* e, XPass& p, const float* injection, hipStream_t s
       COATI_TRY(launch_attn_fwd(p.qkv[l], p.y[l], p.lse[l], p.B, p.T, c.n_head, C / c.n_head, s));
     }
     COATI_TRY(gemm(e, SITE_PROJ_FWD, p.y[l], 0, C, e->S + w.projw, C, M, C, C, p.xmid[l], C, e->P + w.projb, EPI_RES_F32, p.x[l], nullptr, C, s));
+    // COATI_MLP_PAIRED=1 (experiment): the MLP forward as ONE paired-wave kernel (gemm_mlp2.hip) instead of FC1 + FC2
+    static const bool mlp_paired = getenv("COATI_MLP_PAIRED") != nullptr && atoi(getenv("COATI_MLP_PAIRED")) == 1;
+    if (mlp_paired && C == 256 && M >= 4096) {
+      MlpArgs m;
+      memset(&m, 0, sizeof(m));
+      m.M = M; m.C = C; m.Hd = 4 * C; m.x = p.xmid[l]; m.ldx = C; m.gamma = e->P + w.ln2w; m.beta = e->P + w.ln2b; m.mean = p.mean2[l]; m.rstd = p.rstd2[l];
+      m.a = p.a2[l]; m.lda = C; m.W1 = e->S + w.fc1w; m.ldw1 = C; m.b1 = e->P + w.fc1b; m.W2 = e->S + w.fc2w; m.ldw2 = 4 * C; m.b2 = e->P + w.fc2b;
+      m.h = p.g[l]; m.d = p.hpre[l]; m.ldh = 4 * C; m.out = p.x[l + 1]; m.ldo = C;
+      ProfScope ps(e, SITE_FC1_FWD, 4.0 * M * 4 * C * C, s, (double)M * 4608);
+      COATI_TRY(launch_mlp_pair_fwd(m, s));
+      continue;
+    }
     {
       // hpre holds NewGELU'(pre-activation), not the pre-activation: the backward multiplies instead of re-evaluating the
       // sigmoid (the activation epilogues are VALU-bound: 2 quarter-rate transcendentals per element).  ln_2 is fused into

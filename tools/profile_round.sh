@@ -19,6 +19,8 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 python $R/tools/pmc_to_json.py xf_wgrad _table_kernel $(find $OUT/${TAG}_pmc_FETCH_SIZE $OUT/${TAG}_pmc_WRITE_SIZE -name "*counter_collection.csv") > $OUT/${TAG}_pmc_summary.json
 python $R/tools/gemm_bench.py > $OUT/${TAG}_gemm_microbench.txt 2>&1
-python $R/tools/mlp_bench.py > $OUT/${TAG}_mlp_chain_bench.txt 2>&1
+python $R/tools/mlp_bench.py > $OUT/${TAG}_mlp_bench_raw.txt 2>&1       # (profiles/<tag>_mlp_chain_bench.txt is the annotated record of these runs)
+python $R/tools/probes/membw.py > $OUT/${TAG}_membw.txt 2>&1
+bash $R/tools/pmc_sq.sh > /dev/null 2>&1 && cp $OUT/pmcsq_table.txt $OUT/${TAG}_sq_counters.txt
 python $R/tools/cpu_baseline_full.py > $OUT/${TAG}_cpu_baseline_full.json 2> /dev/null
 tail -3 $OUT/${TAG}_bench.json; cat $OUT/${TAG}_pmc_summary.json; head -12 $OUT/${TAG}_bench_kernel_stats.csv; cat $OUT/${TAG}_cpu_baseline_full.json
