@@ -7,14 +7,17 @@ Exchange steps of the path (reference train_coati.py:256-258, autograd_funs.py:5
      computes the full Bg x Bg on every rank) and produces partial gradients for all Bg embeddings;
   3. reduce-scatter(sum) of those partials (what AllGatherFunction.backward does);
   4. bucketed gradient all-reduce (mean) over the flat fp32 gradient buffer, launched stage by stage so the
-     transfers run on RCCL's stream underneath the remaining backward kernels (the encoder stage is cut in two: the
-     upper layers' bucket travels underneath the lower half of that pass).
+     transfers run on RCCL's stream underneath the remaining backward kernels: the lm_head / head buckets underneath the
+     encoder stage; the transformer buckets after it (both passes add into the same weights, and the pass's weight
+     gradients are ONE grouped launch -- cutting the stage in two, the round-1 schedule, doubles that launch:
+     COATI_DP_SPLIT=1), the point-encoder bucket last.
 The reference calls model.module.forward_dist and therefore never arms DDP's reducer: it does
 not average parameter gradients.  This implements the intended semantics.
 
 Backends: "nccl" is the product path.  Under "gloo" (the CPU tests, and the two-processes-on-one-GPU test of the real
 step in tests/test_gpu_distributed.py) device tensors are staged through the host, because gloo has no
 all_gather_into_tensor / reduce_scatter_tensor / AVG for device memory."""
+import os
 import torch
 import torch.distributed as dist
 
@@ -89,6 +92,10 @@ def grad_buckets(eng):
             "heads": (hd0, eng.n_params)}
 
 
+# COATI_DP_SPLIT=1: the encoder stage of the data-parallel backward in two halves (round-1 schedule, A/B switch)
+_SPLIT_ENCODER_STAGE = os.environ.get("COATI_DP_SPLIT", "0") == "1"
+
+
 def distributed_train_step(eng, batch, use_point, lr, do_clip=True, optimizer=True, head="infonce", reduce_grads=True,
                            **opt_kw):
     """do_minibatch at world_size > 1.  Returns (h_e3gnn, h_smiles, bad_rows) of the local rows.
@@ -119,12 +126,20 @@ def distributed_train_step(eng, batch, use_point, lr, do_clip=True, optimizer=Tr
 
     eng.backward(dS, dC, stage=1)
     launch("lm_head"); launch("heads")
-    # the encoder stage in two halves: the upper layers' gradients (both passes are through them) travel underneath the
-    # lower half of the backward
-    eng.backward(None, None, stage=4)
-    launch("xformer_hi")
-    eng.backward(None, None, stage=5)
-    launch("xformer_lo")
+    if _SPLIT_ENCODER_STAGE:
+        # the encoder stage in two halves: the upper layers' gradients (both passes are through them) travel underneath the
+        # lower half of the backward
+        eng.backward(None, None, stage=4)
+        launch("xformer_hi")
+        eng.backward(None, None, stage=5)
+        launch("xformer_lo")
+    else:
+        # ONE encoder stage: the transformer's weight gradients of a pass are one grouped launch of 16 layers x 12 output
+        # tiles, each tile streaming all rows -- a launch over half of the layers takes as long as the whole one (2.0 ms),
+        # so the split costs 2 ms of compute per step to hide an all-reduce of 50 MB (round 2, world size 1 over RCCL:
+        # 36.2 ms split).  The lm_head / head buckets still travel underneath this stage.
+        eng.backward(None, None, stage=2)
+        launch("xformer_hi"); launch("xformer_lo")
     eng.backward(None, None, stage=3)
     launch("gnn")
     for w in works:
