@@ -259,9 +259,18 @@ def test_optimizer_arguments_reach_the_optimizer():
         e.calls.clear()
         D.distributed_train_step(e, batch, up, 2e-3, weight_decay=0.07, max_norm=3.0)
         names = [c[0] for c in e.calls]
-        assert names == ["forward", "infonce", "backward", "backward", "backward", "backward", "optimizer_step"]
-        assert [c[1] for c in e.calls if c[0] == "backward"] == [1, 4, 5, 3]
+        # decoder stage | ONE encoder stage (the pass's weight gradients are one grouped launch) | point-encoder stage
+        assert names == ["forward", "infonce", "backward", "backward", "backward", "optimizer_step"]
+        assert [c[1] for c in e.calls if c[0] == "backward"] == [1, 2, 3]
         assert e.calls[-1] == ("optimizer_step", 2e-3, {"weight_decay": 0.07, "max_norm": 3.0})
+        # the round-1 schedule (encoder stage in two halves) stays available behind COATI_DP_SPLIT=1
+        D._SPLIT_ENCODER_STAGE = True
+        try:
+            e.calls.clear()
+            D.distributed_train_step(e, batch, up, 2e-3)
+            assert [c[1] for c in e.calls if c[0] == "backward"] == [1, 4, 5, 3]
+        finally:
+            D._SPLIT_ENCODER_STAGE = False
         # the five buckets tile the flat gradient buffer exactly once
         bk = sorted(D.grad_buckets(e).values())
         assert bk[0][0] == 0 and bk[-1][1] == e.n_params and all(a[1] == b[0] for a, b in zip(bk, bk[1:]))
