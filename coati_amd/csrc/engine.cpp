@@ -160,7 +160,7 @@ struct coati_engine {
   // side stream: the point encoder (independent of the transformer passes) runs concurrently with them
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-  bool overlap = true;
+  bool overlap = getenv("COATI_NO_OVERLAP") == nullptr;   // (A/B switch: the point encoder on the main stream)
   bool gnn_bwd_done = false;   // staged backward: stage 2 already ran the point-encoder backward on the side stream
   bool gnn_side_pending = false;   // stage 4 forked it; stage 5 joins
   // profiling
@@ -799,6 +799,8 @@ int head_linear_bwd(coati_engine* e, const float* dY, const float* X, int64_t w_
 
 int ensure_side(coati_engine* e) {
   if (e->side) return COATI_OK;
+  // (a high-priority side stream was tried in round 2: no change -- 34.8 ms either way; with COATI_NO_OVERLAP=1 the step
+  // takes 34.85 ms: the transformer's kernels hold every CU's LDS, so the point encoder's kernels run in their tails)
   if (hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming) != hipSuccess) {
