@@ -23,7 +23,7 @@
 #include "gemm_epi.h"
 
 #ifndef M2_QPRIO
-#define M2_QPRIO 2
+#define M2_QPRIO 3
 #endif
 #define M2_C 256
 #define M2_BN 32                               // hidden units per tile
@@ -155,6 +155,7 @@ __global__ __launch_bounds__(640, 1) void mlp_pair_fwd_kernel(MlpArgs p) {
         const int c = (j + 1) * M2_BN + fr;
         bn = p.b1[c < p.Hd ? c : p.Hd - 1];
       }
+      __builtin_amdgcn_s_setprio(M2_QPRIO);   // MFMA phase first, epilogue at the default priority (as in gemm_rb.hip)
       f32x16 acc;
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = bz;
@@ -171,6 +172,7 @@ __global__ __launch_bounds__(640, 1) void mlp_pair_fwd_kernel(MlpArgs p) {
         }
       }
       M2_T(1);
+      __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): the next W1 tile has landed (it had the MFMA phase); this tile's stores go out behind it
       M2_T(2);
       unsigned char* const gt = smem + M2_OFF_G + ((j & 1) * 5 + pr) * M2_GT_BYTES;

@@ -20,6 +20,9 @@
 #include <cstdlib>
 #include "kernels.h"
 
+#ifndef RG_PRIO
+#define RG_PRIO 0   // (probe: MFMA section at raised priority -- within the noise on every ring site, unlike the row-block kernel)
+#endif
 #define RG_BR 160                           // rows per block
 #define RG_BK 64                            // k per stage
 #define RG_WAVES 10
@@ -188,6 +191,9 @@ __global__ __launch_bounds__(64 * RG_WAVES, 1) void gemm_ring256_kernel(GemmArgs
     ++st_age;
     __builtin_amdgcn_s_barrier();
     RG_T(1);
+#if RG_PRIO
+    __builtin_amdgcn_s_setprio(3);   // MFMA + DMA-issue section at raised wave priority, write-out at the default one (see gemm_rb.hip)
+#endif
     const unsigned char* S = smem + sc * RG_STAGE_BYTES;
     // two fragment sets: the 5 reads of k step ks + 1 are issued in the shadow of the 4 MFMAs of step ks
     {
@@ -220,6 +226,9 @@ __global__ __launch_bounds__(64 * RG_WAVES, 1) void gemm_ring256_kernel(GemmArgs
     }
     sc = sc + 1 == RG_NS ? 0 : sc + 1;
     RG_T(2);
+#if RG_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
     if (++kc == nk) {
       // the block is complete: write it out straight from the accumulator layout (the next block's first stages are in
       // flight meanwhile)
