@@ -86,6 +86,9 @@ int launch_gemm_rb256(const GemmArgs& a, int epi, hipStream_t s);
 // ring kernel for N = 256, long K (gemm_ring.hip)
 bool gemm_ring256_supported(const GemmArgs& a, int a_f32, int epi);
 int launch_gemm_ring256(const GemmArgs& a, int epi, hipStream_t s);
+// the same products on 320-row blocks (gemm_ring2.hip): the weight is streamed through LDS once per CU instead of twice
+bool gemm_ring320_supported(const GemmArgs& a, int a_f32, int epi);
+int launch_gemm_ring320(const GemmArgs& a, int epi, hipStream_t s);
 
 // Chained MLP products at C = 256 (gemm_mlp.hip): forward LayerNorm -> W1 -> NewGELU (+ derivative) -> W2 -> residual, and
 // the backward input-gradient chain dY -> W2^T -> x NewGELU' -> W1^T.  The [M, Hd] intermediate feeds the second product
