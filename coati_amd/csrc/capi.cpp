@@ -93,6 +93,8 @@ int coati_wgrad(const void* A, int a_f32, int64_t lda, const uint16_t* B, int64_
 int coati_wgrad_grouped(int n_problems, const uint16_t* const* A, const int64_t* lda, const uint16_t* const* B, const int64_t* ldb, int M,
                         const int* N, const int* K, float* const* dW, const int64_t* ldw, float* const* dbias, int tile_size, void* stream) {
   COATI_CHECK_ARG(n_problems > 0 && A && lda && B && ldb && N && K && dW && ldw && dbias, "wgrad_grouped: null argument");
+  const bool want_split = tile_size == -256;   // -256: 256-wide tiles in the split form (192 tiles on 256 workgroups, ordered commits)
+  if (want_split) tile_size = 256;
   std::vector<WgradTile> tab;
   for (int i = 0; i < n_problems; ++i) {
     WgradArgs a;
@@ -101,7 +103,21 @@ int coati_wgrad_grouped(int n_problems, const uint16_t* const* A, const int64_t*
   }
   // stand-alone entry point (tests, micro-benchmarks): the table is uploaded per call; the engine keeps its tables resident
   WgradTile* d = nullptr;
+  int* tickets = nullptr;
   hipStream_t s = S_(stream);
+  // tile_size 256 with 192 tiles (16 transformer layers): the split form (all 256 CUs, ordered commits), as in the engine
+  const int n_tiles = (int)tab.size();
+  const bool split = want_split && n_tiles == 192;
+  if (split) {
+    if (hipMalloc(&tickets, n_tiles * sizeof(int)) != hipSuccess || hipMemsetAsync(tickets, 0, n_tiles * sizeof(int), s) != hipSuccess) {
+      coati_set_error("wgrad_grouped: ticket allocation failed");
+      return COATI_EHIP;
+    }
+    std::vector<WgradTile> segs;
+    int rcs = wgrad_table_split256(tab, 256, tickets, segs);
+    if (rcs != COATI_OK) { hipFree(tickets); return rcs; }
+    tab.swap(segs);
+  }
   if (hipMalloc(&d, tab.size() * sizeof(WgradTile)) != hipSuccess) {
     coati_set_error("wgrad_grouped: table allocation failed");
     return COATI_EHIP;
@@ -111,12 +127,13 @@ int coati_wgrad_grouped(int n_problems, const uint16_t* const* A, const int64_t*
     coati_set_error("wgrad_grouped: table upload failed");
     rc = COATI_EHIP;
   }
-  if (rc == COATI_OK) rc = launch_wgrad_table(d, (int)tab.size(), s, tile_size);
+  if (rc == COATI_OK) rc = split ? launch_wgrad_table_split256(d, 256, s) : launch_wgrad_table(d, (int)tab.size(), s, tile_size);
   if (hipStreamSynchronize(s) != hipSuccess && rc == COATI_OK) {
     coati_set_error("wgrad_grouped: kernel failed");
     rc = COATI_EHIP;
   }
   hipFree(d);
+  if (tickets) hipFree(tickets);
   return rc;
 }
 

@@ -143,7 +143,7 @@ struct coati_engine {
   int* d_wpace = nullptr;                             // pacing epoch counters of the grouped launch: [4 L problems][epochs]
   int wpace_per = 0;                                  // ints per problem
   int wtab_cap = 0;                                   // entries per slot
-  struct WTabKey { const void* pass = nullptr; int lo = -1, hi = -1, M = 0, n = 0; long long sig = 0; };
+  struct WTabKey { const void* pass = nullptr; int lo = -1, hi = -1, M = 0, n = 0; long long sig = 0; bool split = false; };
   WTabKey wtab_key[4];
   const void* wtab_ws = nullptr;                      // workspace the cached tables were built for
   float* nce = nullptr;
@@ -586,6 +586,19 @@ int xformer_wgrad_group(coati_engine* e, XPass& p, int l_lo, int l_hi, hipStream
       COATI_TRY(add(e->w_dh4[l], 4 * C, p.a2[l], C, 4 * C, C, w.fc1w, w.fc1b));
       COATI_TRY(add(e->w_dxa[l], C, p.g[l], 4 * C, C, 4 * C, w.fc2w, w.fc2b));
     }
+    // 256-wide tiles of a whole pass (192) leave a quarter of the CUs idle: the split form (COATI_WGRAD_SPLIT=1) puts three
+    // quarters of M on a tile's main workgroup and the last quarter on a helper, ordered commits.  EXPERIMENT, off: 2.14 ms per
+    // launch against 2.04 -- with all 256 CUs streaming the launch is no faster, i.e. it is bound by what the memory system
+    // delivers for this pattern (11.3 GB in 2.0 ms = 5.6 TB/s), not by the number of CUs.
+    static const bool want_split = getenv("COATI_WGRAD_SPLIT") != nullptr && atoi(getenv("COATI_WGRAD_SPLIT")) == 1;
+    bool split = false;
+    if (want_split && e->wg_tile == 256 && tab.size() == 192 && 3 * 256 <= e->wtab_cap &&
+        (int)tab.size() <= 4 * (l_hi - l_lo) * e->wpace_per) {
+      std::vector<WgradTile> segs;
+      COATI_TRY(wgrad_table_split256(tab, 256, e->d_wpace, segs));
+      tab.swap(segs);
+      split = true;
+    }
     COATI_CHECK_ARG((int)tab.size() <= e->wtab_cap, "wgrad group: table overflow (%zu > %d)", tab.size(), e->wtab_cap);
     static int rr = 0;
     slot = rr++ & 3;
@@ -596,7 +609,7 @@ int xformer_wgrad_group(coati_engine* e, XPass& p, int l_lo, int l_hi, hipStream
       return COATI_EHIP;
     }
     coati_engine::WTabKey k;
-    k.pass = &p; k.lo = l_lo; k.hi = l_hi; k.M = M; k.n = (int)tab.size(); k.sig = sig;
+    k.pass = &p; k.lo = l_lo; k.hi = l_hi; k.M = M; k.n = (int)tab.size(); k.sig = sig; k.split = split;
     e->wtab_key[slot] = k;
   }
   // the pacing counters of this launch's problems start at zero
@@ -605,6 +618,7 @@ int xformer_wgrad_group(coati_engine* e, XPass& p, int l_lo, int l_hi, hipStream
     return COATI_EHIP;
   }
   ProfScope ps(e, SITE_XF_WGRAD, flops, s, bytes);
+  if (e->wtab_key[slot].split) return launch_wgrad_table_split256(e->d_wtab + (size_t)slot * e->wtab_cap, 256, s);
   return launch_wgrad_table(e->d_wtab + (size_t)slot * e->wtab_cap, e->wtab_key[slot].n, s, e->wg_tile);
 }
 

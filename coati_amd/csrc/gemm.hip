@@ -12,6 +12,7 @@
 // ds_read_b128 fragment reads are conflict-free without an XOR swizzle.  The accumulator tile is
 // transposed through LDS so the epilogue works on 8 consecutive columns per lane (16-B stores).
 #include <stdlib.h>
+#include <algorithm>
 #include <cstdlib>
 #include "kernels.h"
 
@@ -868,19 +869,32 @@ __global__ __launch_bounds__(512, 1) void wgrad_dma_table_kernel(const WgradTile
 #define W2_CH 32
 #define W2_BLK_BYTES (32 * WT_ROW_BYTES)
 #define W2_STAGE_BYTES (4 * W2_BLK_BYTES)
+#define W2_SEGS 3                                // table entries per workgroup in the split form
 struct W2Frags { bf16x8 a[4], b[2]; };
 
-template <int NS>
+// SPLIT: 192 tiles leave a quarter of the CUs idle, and a CU cannot take in more than ~21 B/clk (one 32-KiB stage per
+// ~1.5 k cycles), so the launch is bound by how many CUs stream.  The split form runs W2_SEGS table entries (segments: a
+// tile and a range of its M stages) per workgroup; a tile then has two contributors, which commit in a fixed order -- the
+// host's schedule (who finishes first) decides it: contributor `order` waits until the tile's ticket counter reads `order`,
+// adds its part with plain read-add-stores, then releases the counter -- so the sum is still deterministic and
+// atomics-free on the tile.  The schedule keeps the sibling tiles of a problem on the same rows at the same time (they
+// share operand panels through their XCD's L2): see wgrad_table_split256.
+template <int NS, bool SPLIT>
 __global__ __launch_bounds__(512, 1) void wgrad256_table_kernel(const WgradTile* __restrict__ table) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const WgradTile& d = table[xcd_swizzle(blockIdx.x, gridDim.x)];
+  const int wgi = xcd_swizzle(blockIdx.x, gridDim.x);
+#pragma unroll 1
+  for (int seg = 0; seg < (SPLIT ? W2_SEGS : 1); ++seg) {
+  const WgradTile& d = table[SPLIT ? W2_SEGS * wgi + seg : wgi];
+  if (SPLIT && d.c_begin >= d.c_end) continue;
   const WgradArgs p = d.p;
   const int tiles_k = d.tiles_k, tile = d.tile;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
   const int tile_n = tile / tiles_k, tile_k = tile - tile_n * tiles_k;
   const int n0 = tile_n * 256, k0 = tile_k * 256;
-  const int c_end = (p.M + W2_CH - 1) / W2_CH;
+  const int c_begin = SPLIT ? d.c_begin : 0;
+  const int c_end = SPLIT ? d.c_end : (p.M + W2_CH - 1) / W2_CH;
   const bf16_t* A = reinterpret_cast<const bf16_t*>(p.A);
 
   // DMA sources of this lane: piece "rows 4 wave .. + 3" of block b = 0..3 (A0, A1, B0, B1); LDS slot (row & 3 = lane >> 4,
@@ -890,12 +904,12 @@ __global__ __launch_bounds__(512, 1) void wgrad256_table_kernel(const WgradTile*
   const bf16_t* const zero = reinterpret_cast<const bf16_t*>(wd_zero_page) + q * 8;
   const unsigned offa = (unsigned)(((4 * wave + rsub) * (int)p.lda + qg * 8) * 2);
   const unsigned offb = (unsigned)(((4 * wave + rsub) * (int)p.ldb + qg * 8) * 2);
-  int cnext = 0;
+  int cnext = c_begin;
   typedef __attribute__((address_space(3))) unsigned char lds_u8;
   const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_u8*)smem);
   const unsigned ldsw = lds0 + wave * 1024;
-  const bf16_t* ab = A + n0;       // row 0 of the next stage (scalar)
-  const bf16_t* bb = p.B + k0;
+  const bf16_t* ab = A + n0 + (long long)c_begin * W2_CH * p.lda;       // row 0 of the next stage (scalar)
+  const bf16_t* bb = p.B + k0 + (long long)c_begin * W2_CH * p.ldb;
   const long long ab_step = (long long)W2_CH * p.lda, bb_step = (long long)W2_CH * p.ldb;
   auto issue = [&](int slot) __attribute__((always_inline)) {
     const unsigned S = ldsw + slot * W2_STAGE_BYTES;
@@ -974,7 +988,7 @@ __global__ __launch_bounds__(512, 1) void wgrad256_table_kernel(const WgradTile*
   const v2bf sel_lo = __builtin_bit_cast(v2bf, sel_lo_u), sel_hi = __builtin_bit_cast(v2bf, sel_hi_u);
   float cs0 = 0.f, cs1 = 0.f;
   const int cp = tid & 127, rq = tid >> 7;
-  int bias_ctr = tile_k;
+  int bias_ctr = (tile_k - c_begin % tiles_k + tiles_k) % tiles_k;   // stages until this workgroup's turn
   unsigned bu[8];
   auto bias_read = [&](int slot) __attribute__((always_inline)) {
     const unsigned char* At = smem + slot * W2_STAGE_BYTES + (cp >> 6) * W2_BLK_BYTES;
@@ -1026,7 +1040,7 @@ __global__ __launch_bounds__(512, 1) void wgrad256_table_kernel(const WgradTile*
     __builtin_amdgcn_sched_barrier(0);
   };
   static_assert(NS == 4 || NS == 5, "the main loop is unrolled for rings of 4 and 5");
-  for (int c = 0;;) {
+  for (int c = c_begin;;) {
     step(WdSlot<0>()); if (++c >= c_end) break;
     step(WdSlot<1>()); if (++c >= c_end) break;
     step(WdSlot<2>()); if (++c >= c_end) break;
@@ -1043,10 +1057,22 @@ __global__ __launch_bounds__(512, 1) void wgrad256_table_kernel(const WgradTile*
   __syncthreads();
   if (tid < 256) {
     const float t = bsum[tid] + bsum[256 + tid] + bsum[512 + tid] + bsum[768 + tid];
-    if (tiles_k == 1) p.dbias[n0 + tid] += t;
+    if (!SPLIT && tiles_k == 1) p.dbias[n0 + tid] += t;
     else atomicAdd(p.dbias + n0 + tid, t);
   }
-  // exclusive tile: plain read-add-store
+  const bool ordered = SPLIT && d.order >= 0;
+  if (ordered && d.order > 0) {
+    // wait for the contributors scheduled before this one (bounded: the schedule guarantees they do not wait for us)
+    if (tid == 0) {
+      for (int spin = 0; spin < (1 << 24); ++spin) {
+        if (__hip_atomic_load(d.pace, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= d.order) break;
+        __builtin_amdgcn_s_sleep(16);
+      }
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  }
+  // this workgroup is the only one that touches the tile now: plain read-add-store
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -1057,6 +1083,13 @@ __global__ __launch_bounds__(512, 1) void wgrad256_table_kernel(const WgradTile*
         const int k = k0 + wn * 64 + j * 32 + (lane & 31);
         p.dW[(long long)n * p.ldw + k] += acc[i][j][r];
       }
+  if (ordered) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __syncthreads();
+    if (tid == 0) __hip_atomic_fetch_add(d.pace, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (SPLIT) __syncthreads();   // the next segment's DMAs overwrite the ring (and the bias partials in it)
+  }
 }
 
 int wgrad_table_pace_ints(int M) { return cdiv(cdiv(M, WD_CH), COATI_WG_EPOCH_STAGES) + 1; }
@@ -1105,10 +1138,10 @@ static int launch_wgrad_table_t(const WgradTile* dev_table, int n_tiles, hipStre
   return COATI_OK;
 }
 
-template <int NS>
+template <int NS, bool SPLIT>
 static int launch_wgrad256_t(const WgradTile* dev_table, int n_tiles, hipStream_t s) {
   static bool attr_set = false;
-  auto kern = wgrad256_table_kernel<NS>;
+  auto kern = wgrad256_table_kernel<NS, SPLIT>;
   constexpr int lds = NS * W2_STAGE_BYTES;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -1123,12 +1156,58 @@ static int launch_wgrad256_t(const WgradTile* dev_table, int n_tiles, hipStream_
   return COATI_OK;
 }
 
+// Split form of a 256-wide table (see wgrad256_table_kernel<NS, true>): `tiles` = the table wgrad_table_append built,
+// 192 entries = 8 XCDs x 24 (two transformer layers per XCD); G = 256 workgroups; tickets = one zeroed int per tile.
+// Output: W2_SEGS x G entries (an empty segment has c_begin == c_end).  Per XCD (32 consecutive workgroups after
+// xcd_swizzle): 24 MAIN workgroups stream the first three quarters of M of "their" tile; 8 HELPER workgroups stream the last
+// quarter of three tiles each, eight consecutive tiles (whole problems) per time slot -- so at any time the tiles of a
+// problem are on the same rows, mains with mains and helpers with helpers, and every workgroup streams 3/4 of M.
+// (A first version cut the 768 quarter tiles into 256 runs of three: correct, but the siblings of a problem were then on
+// different rows at the same time, their shared panel was fetched once per tile, and the launch took 2.68 instead of 1.96 ms.)
+// Commit order of a tile: its helper first (it finishes after 1, 2 or 3 of the three slots), its main second.
+int wgrad_table_split256(const std::vector<WgradTile>& tiles, int G, int* tickets, std::vector<WgradTile>& out) {
+  const int nt = (int)tiles.size();
+  COATI_CHECK_ARG(nt == 192 && G == 256 && tickets, "wgrad_table_split256: the schedule is built for 192 tiles on 256 workgroups");
+  out.assign((size_t)W2_SEGS * G, WgradTile{});
+  for (int x = 0; x < 8; ++x) {
+    for (int i = 0; i < 24; ++i) {           // mains
+      const int t = 24 * x + i, w = 32 * x + i;
+      const int c_all = cdiv(tiles[t].p.M, W2_CH), Q = cdiv(c_all, 4);
+      WgradTile e = tiles[t];
+      e.c_begin = 0;
+      e.c_end = 3 * Q < c_all ? 3 * Q : c_all;
+      e.pace = tickets + t;
+      e.order = 3 * Q < c_all ? 1 : -1;        // (nothing left for a helper: exclusive)
+      out[(size_t)W2_SEGS * w] = e;
+    }
+    for (int h = 0; h < 8; ++h) {            // helpers
+      const int w = 32 * x + 24 + h;
+      for (int sl = 0; sl < 3; ++sl) {
+        const int t = 24 * x + 8 * sl + h;
+        const int c_all = cdiv(tiles[t].p.M, W2_CH), Q = cdiv(c_all, 4);
+        WgradTile e = tiles[t];
+        e.c_begin = 3 * Q < c_all ? 3 * Q : c_all;
+        e.c_end = c_all;
+        e.pace = tickets + t;
+        e.order = 0;
+        out[(size_t)W2_SEGS * w + sl] = e;
+      }
+    }
+  }
+  return COATI_OK;
+}
+
+int launch_wgrad_table_split256(const WgradTile* dev_table, int G, hipStream_t s) {
+  COATI_CHECK_ARG(dev_table && G > 0, "wgrad_table_split256: empty table");
+  return launch_wgrad256_t<4, true>(dev_table, G, s);
+}
+
 int launch_wgrad_table(const WgradTile* dev_table, int n_tiles, hipStream_t s, int tile_size) {
   COATI_CHECK_ARG(dev_table && n_tiles > 0, "wgrad_table: empty table");
   if (tile_size == 256) {
     // ring depth: 4 stages of 32 KiB (96 KiB in flight per CU) or 5 (128 KiB in flight, all 160 KiB of LDS): COATI_WGRAD256_NS
     static const int ns256 = getenv("COATI_WGRAD256_NS") ? atoi(getenv("COATI_WGRAD256_NS")) : 4;
-    return ns256 == 5 ? launch_wgrad256_t<5>(dev_table, n_tiles, s) : launch_wgrad256_t<4>(dev_table, n_tiles, s);
+    return ns256 == 5 ? launch_wgrad256_t<5, false>(dev_table, n_tiles, s) : launch_wgrad256_t<4, false>(dev_table, n_tiles, s);
   }
   // ring depth (stages of 32 KiB; NS - 1 in flight): COATI_WGRAD_TABLE_NS = 3 | 4 (A/B switch)
   static const int ns = getenv("COATI_WGRAD_TABLE_NS") ? atoi(getenv("COATI_WGRAD_TABLE_NS")) : 4;

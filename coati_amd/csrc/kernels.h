@@ -142,14 +142,20 @@ struct WgradTile {
   // (0 = no pacing)
   int* pace;
   int group_size;
+  // split form of the 256-wide launch (wgrad_table_split256): this entry is one SEGMENT -- stages [c_begin, c_end) of the
+  // tile's M range -- and `order` is its place in the tile's commit order (-1: the only contributor); `pace` then points at
+  // the tile's ticket counter
+  int c_begin = 0, c_end = 0, order = -1;
 };
 #define COATI_WG_EPOCH_STAGES 4                 // 64-row stages per pacing epoch
 int wgrad_table_pace_ints(int M);               // epoch counters one problem needs for M rows
 int launch_wgrad_table(const WgradTile* dev_table, int n_tiles, hipStream_t s, int tile_size = 128);   // every entry of a table has the same tile size
-bool wgrad_table_tile256_ok(const WgradArgs& a);   // 256 x 256 tiles (wgrad256_table_kernel): N, K multiples of 256
+bool wgrad_table_tile256_ok(const WgradArgs& a);
+int launch_wgrad_table_split256(const WgradTile* dev_table, int G, hipStream_t s);   // dev_table: 2 G segment entries   // 256 x 256 tiles (wgrad256_table_kernel): N, K multiples of 256
 #ifdef __cplusplus
 #include <vector>
-int wgrad_table_append(std::vector<WgradTile>& tab, const WgradArgs& a, int* pace, int tile_size = 128);   // host: appends the problem's tiles (pace: its epoch counters or null)
+int wgrad_table_append(std::vector<WgradTile>& tab, const WgradArgs& a, int* pace, int tile_size = 128);
+int wgrad_table_split256(const std::vector<WgradTile>& tiles, int G, int* tickets, std::vector<WgradTile>& out);   // host: 2 G segments, commit orders   // host: appends the problem's tiles (pace: its epoch counters or null)
 #endif
 
 // C[M,N] (f32) = sum_k A(m,k) B(k,n) [+ bias[n]] [+ C];  A(m,k) = A[m*ars + k*acs], B(k,n) = B[k*brs + n*bcs]

@@ -69,7 +69,7 @@ def wgrad(A, Bm, dW, dbias=None, n_out=0):
     return dW
 
 
-def wgrad_grouped(problems, tile_size=256):
+def wgrad_grouped(problems, tile_size=256, split=False):
     """problems: list of (A[M,N] bf16, Bm[M,K] bf16, dW[N,K] f32, dbias[N] f32), all with the same M; one launch, no atomics
     on dW: dW += A^T @ Bm, dbias += colsum(A)."""
     import ctypes
@@ -84,7 +84,7 @@ def wgrad_grouped(problems, tile_size=256):
               PP(*[ptr(q[1]) for q in problems]), LL(*[q[1].stride(0) for q in problems]), M,
               II(*[q[0].shape[1] for q in problems]), II(*[q[1].shape[1] for q in problems]),
               PP(*[ptr(q[2]) for q in problems]), LL(*[q[2].stride(0) for q in problems]),
-              PP(*[ptr(q[3]) for q in problems]), tile_size, stream())
+              PP(*[ptr(q[3]) for q in problems]), -256 if (split and tile_size == 256) else tile_size, stream())
 
 
 def sgemm(A, Bm, trans_a=False, trans_b=False, bias=None, alpha=1.0, out=None, accumulate=False):

@@ -104,7 +104,9 @@ int coati_wgrad(const void* A, int a_f32, int64_t lda, const uint16_t* B, int64_
                 float* dW, int64_t ldw, float* dbias, int n_out, void* stream);
 
 /* The same for a LIST of problems that share M, in ONE launch and without fp32 atomics on dW: one workgroup per output tile
- * (tile_size 128 or 256; 256 needs every N and K to be a multiple of 256) streams all M rows of its tile.  bf16 A, dbias
+ * (tile_size 128 or 256; 256 needs every N and K to be a multiple of 256; -256 = the 256-wide tiles in the split form: with
+ * exactly 192 tiles, three quarters of M on a tile's main workgroup and the last quarter on a helper, committed in a fixed
+ * order through ticket counters -- an experiment, no faster) streams all M rows of its tile.  bf16 A, dbias
  * required.  This is how the engine computes the 4 x n_layer Linear gradients of a transformer pass (the reference's
  * loss.backward() through RotaryBlock, basic_transformer.py:126-174).  Synchronises the stream (stand-alone entry point). */
 int coati_wgrad_grouped(int n_problems, const uint16_t* const* A, const int64_t* lda, const uint16_t* const* B, const int64_t* ldb,

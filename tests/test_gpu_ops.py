@@ -122,6 +122,39 @@ def test_wgrad_grouped(ops, M, C, tile):
         check(f"wgrad_grouped[{tile}] db {M}x{N}", db, db0 + A.sum(0), 8.5e-6)
 
 
+@pytest.mark.parametrize("M,layers", [(2000, 16), (8191, 16), (333, 16), (40, 16)])
+def test_wgrad_grouped_split(ops, M, layers):
+    """the split form of the 256-wide grouped launch (192 tiles = 16 layers: three quarters of M on a tile's main workgroup,
+    the last quarter on a helper, ordered commits through ticket counters); gradients pre-filled; the result must not
+    depend on which contributor came first (M = 40: fewer stages than quarters)"""
+    C = 256
+    g = torch.Generator().manual_seed(M + layers)
+    shapes = [(3 * C, C), (C, C), (4 * C, C), (C, 4 * C)]
+    probs, refs = [], []
+    for l in range(layers):
+        for N, K in shapes:
+            A = rbf(torch.randn(M, N, generator=g)).to(DEV)
+            X = rbf(torch.randn(M, K, generator=g)).to(DEV)
+            dW0 = torch.randn(N, K, generator=g).to(DEV)
+            db0 = torch.randn(N, generator=g).to(DEV)
+            dW, db = dW0.clone(), db0.clone()
+            probs.append((A.bfloat16(), X.bfloat16(), dW, db))
+            refs.append((dW, dW0, db, db0, A, X))
+    ops.wgrad_grouped(probs, tile_size=256, split=True)
+    torch.cuda.synchronize()
+    first = [p[2].clone() for p in probs]
+    for i, (dW, dW0, db, db0, A, X) in enumerate(refs):
+        check(f"wgrad split dW problem {i} M{M}", dW, dW0 + A.t() @ X, 8.5e-6)
+        check(f"wgrad split db problem {i} M{M}", db, db0 + A.sum(0), 8.5e-6)
+    # run to run: bit-identical tiles (the commit order is fixed by the schedule, not by arrival)
+    for (A, X, dW, db), (_, dW0, _, db0, _, _) in zip(probs, refs):
+        dW.copy_(dW0); db.copy_(db0)
+    ops.wgrad_grouped(probs, tile_size=256, split=True)
+    torch.cuda.synchronize()
+    for i, p in enumerate(probs):
+        assert torch.equal(p[2], first[i]), f"problem {i}: the split launch is not deterministic"
+
+
 @pytest.mark.parametrize("M,N,K", [(70, 33, 19), (1024, 1024, 256), (1, 256, 1024)])
 def test_sgemm(ops, M, N, K):
     g = torch.Generator().manual_seed(7)
