@@ -8,23 +8,25 @@
 // streams again.  With 320 rows per block (M = 81,920: 256 blocks = exactly one per CU) the weight is streamed once per CU
 // instead of twice: fill bytes per (row x k) drop from 5.1 to 3.5.
 //   * 10 waves, wave w owns rows 32 w .. + 31 and ALL 256 columns: 8 accumulator blocks = 128 VGPRs;
-//   * a stage is 32 k: [320 activation rows | 256 weight rows] x 64 B = 36 KiB, 4-slot ring = 144 KiB, three stages in
-//     flight (108 KiB, as many bytes as the 160-row kernel keeps in flight); rows are unpadded, the 16-B chunk c of row r
-//     sits at chunk position c ^ ((r >> 2) & 3) (applied on the global side of the DMA): the 16 lanes of one ds_read_b128
-//     cycle (16 different rows, same k chunk) hit 16 different bank groups;
-//   * per stage and wave: 2 activation fragments, 16 weight fragments streamed three deep, 16 MFMAs (32 x 256 x 32);
+//   * a stage is 64 k: [320 activation rows | 256 weight rows] x 128 B = 72 KiB, DOUBLE-buffered (144 KiB): one stage in
+//     flight while the other is multiplied -- enough when a stage's fill (~3.6 k cycles at the ~20 B/clk a CU takes in) is
+//     longer than its 32 MFMAs per wave (~3.1 k cycles on a 3-wave SIMD); rows are unpadded, the 16-B chunk c of row r sits at
+//     chunk position c ^ ((r >> 1) & 7) (applied on the global side of the DMA);
+//   * per stage and wave: 4 activation fragments, 32 weight fragments streamed three deep, 32 MFMAs (32 x 256 x 64);
 //   * results leave straight from the accumulator layout (lane = column: one 128-B line per half-wave and instruction),
 //     the residual in four passes of 32 values per lane.
+// (A first version used 32-k stages in a 4-slot ring: 64-B rows, DMA pieces of 16 half lines instead of 8 whole ones --
+// slower than the 160-row kernel on every site.)
 // The DMA is issued from inline assembly (see gemm.hip): the vmcnt bookkeeping of the ring is hand-placed.
 #include <cstdlib>
 #include "kernels.h"
 
 #define R2_BR 320
-#define R2_BK 32
+#define R2_BK 64
 #define R2_WAVES 10
-#define R2_NS 4
-#define R2_A_BYTES (R2_BR * R2_BK * 2)      // 20 KiB
-#define R2_W_BYTES (256 * R2_BK * 2)        // 16 KiB
+#define R2_NS 2
+#define R2_A_BYTES (R2_BR * R2_BK * 2)      // 40 KiB
+#define R2_W_BYTES (256 * R2_BK * 2)        // 32 KiB
 #define R2_STAGE_BYTES (R2_A_BYTES + R2_W_BYTES)
 #define R2_LDS_BYTES (R2_NS * R2_STAGE_BYTES)   // 147,456 B
 
@@ -44,52 +46,51 @@ __global__ __launch_bounds__(64 * R2_WAVES, 1) void gemm_ring320_kernel(GemmArgs
   const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_u8*)smem);
   const int row_blk = blk * R2_BR;
 
-  // ---- DMA side.  Piece q (1 KiB = 16 rows x 64 B) of an operand: lane -> row 16 q + (lane >> 2), LDS chunk slot lane & 3,
-  // global chunk (lane & 3) ^ ((row >> 2) & 3) = (lane & 3) ^ ((lane >> 4) & 3).  A wave takes activation pieces
-  // {wave, wave + 10} and weight pieces {wave (, wave + 10 for waves 0..5)}.
-  const int lrow = lane >> 2;
-  const int cg = (lane & 3) ^ ((lane >> 4) & 3);
-  const int nwp = wave < 6 ? 2 : 1;
-  const int my_dmas = 2 + nwp;
-  // every block walks k from its own starting chunk (only for the bf16-output products: see gemm_ring.hip)
-  const bool ROT = (EPI != EPI_RES_F32) && nk >= 16;
-  int kk = ROT ? (blk * 2) % nk : 0;     // k chunk of the next stage to fetch
+  // ---- DMA side.  Piece q (1 KiB = 8 rows x 128 B, whole lines) of an operand: lane -> row 8 q + (lane >> 3), LDS chunk slot
+  // lane & 7, global chunk (lane & 7) ^ ((row >> 1) & 7).  Activation pieces 0..39: wave w takes w, w + 10, w + 20, w + 30;
+  // weight pieces 0..31: wave w takes w, w + 10, w + 20 (, w + 30 for waves 0 and 1).  Pieces of one wave have the same
+  // row parity pattern, so one chunk permutation per lane: (8 q) >> 1 = 4 q, (4 q) & 7 = 4 (q & 1): q of one parity class
+  // only if all pieces of a wave share q & 1 -- w, w + 10, w + 20, w + 30 do.
+  const int lrow = lane >> 3;
+  const int cg = (lane & 7) ^ ((((wave & 1) << 2) + (lane >> 4)) & 7);
+  const int nwp = wave < 2 ? 4 : 3;
+  // (64-k stages, double-buffered: the 32-k form of this kernel had to use 64-B rows to fit four stages, i.e. DMA pieces of
+  // 16 half lines -- the cost of a DMA instruction follows the lines it touches -- and lost what the halved weight stream gains)
+  const bool ROT = (EPI != EPI_RES_F32) && nk >= 8;
+  int kk = ROT ? blk % nk : 0;           // k chunk of the next stage to fetch
   int slot = 0;
-  const bf16_t* arow[2];
+  const bf16_t* arow[4];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    int r = row_blk + 16 * (wave + R2_WAVES * i) + lrow;
+  for (int i = 0; i < 4; ++i) {
+    int r = row_blk + 8 * (wave + R2_WAVES * i) + lrow;
     r = r < p.M ? r : p.M - 1;             // rows past M re-read row M - 1 (their outputs are never stored)
     arow[i] = A + (long long)r * p.lda + cg * 8;
   }
-  const bf16_t* wrow[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) wrow[i] = p.B + (long long)(16 * (wave + R2_WAVES * i) + lrow) * p.ldb + cg * 8;
-  // the DMAs of a stage are issued in two halves (activation pieces | weight pieces), the second one in the middle of the
-  // stage being multiplied: a steadier request stream than a burst behind every barrier
+  const bf16_t* const wrow0 = p.B + (long long)(8 * wave + lrow) * p.ldb + cg * 8;
+  const long long w_p = 8LL * R2_WAVES * p.ldb;
   auto issue_a = [&]() __attribute__((always_inline)) {
     const unsigned S = lds0 + slot * R2_STAGE_BYTES + wave * 1024;
     const int ko = kk * R2_BK;
-    r2_dma16(arow[0] + ko, S);
-    r2_dma16(arow[1] + ko, S + R2_WAVES * 1024);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r2_dma16(arow[i] + ko, S + i * R2_WAVES * 1024);
   };
   auto issue_w = [&]() __attribute__((always_inline)) {
-    const unsigned S = lds0 + slot * R2_STAGE_BYTES + wave * 1024;
-    const int ko = kk * R2_BK;
-    r2_dma16(wrow[0] + ko, S + R2_A_BYTES);
-    if (nwp == 2) r2_dma16(wrow[1] + ko, S + R2_A_BYTES + R2_WAVES * 1024);
+    const unsigned S = lds0 + slot * R2_STAGE_BYTES + R2_A_BYTES + wave * 1024;
+    const bf16_t* wb = wrow0 + kk * R2_BK;
+    r2_dma16(wb, S);
+    r2_dma16(wb + w_p, S + R2_WAVES * 1024);
+    r2_dma16(wb + 2 * w_p, S + 2 * R2_WAVES * 1024);
+    if (nwp == 4) r2_dma16(wb + 3 * w_p, S + 3 * R2_WAVES * 1024);
     kk = kk + 1 == nk ? 0 : kk + 1;
-    slot = slot + 1 == R2_NS ? 0 : slot + 1;
-  };
-  auto issue = [&]() __attribute__((always_inline)) {
-    issue_a();
-    issue_w();
+    slot ^= 1;
   };
 
-  // ---- MFMA side: lane (fr = lane & 31, kg = lane >> 5) reads chunk (2 ks + kg) ^ ((fr >> 2) & 3) of row fr (+ 32 j)
-  const int fr = lane & 31, kg = lane >> 5, sw = (fr >> 2) & 3;
-  const unsigned xo0 = (unsigned)(fr * 64 + (((0 + kg) ^ sw) << 4)), xo1 = (unsigned)(fr * 64 + (((2 + kg) ^ sw) << 4));
-  const unsigned a_row = (unsigned)(wave * 32 * 64);
+  // ---- MFMA side: lane (fr = lane & 31, kg = lane >> 5) reads chunk (2 ks + kg) ^ ((fr >> 1) & 7) of its rows
+  const int fr = lane & 31, kg = lane >> 5, swz = (fr >> 1) & 7;
+  unsigned xo[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) xo[ks] = (unsigned)(fr * 128 + (((2 * ks + kg) ^ swz) << 4));
+  const unsigned a_row = (unsigned)(wave * 32 * 128);
 
   f32x16 acc[8];
 #pragma unroll
@@ -99,43 +100,37 @@ __global__ __launch_bounds__(64 * R2_WAVES, 1) void gemm_ring320_kernel(GemmArgs
     for (int r = 0; r < 16; ++r) acc[j][r] = b;
   }
 
-  // prologue: NS - 1 stages in flight
-#pragma unroll
-  for (int i = 0; i < R2_NS - 1; ++i) issue();
-  int sc = 0;
+  issue_a();
+  issue_w();
   for (int s = 0; s < nk; ++s) {
-    // stage s has landed (this wave's pieces; the barrier covers the others): NS - 2 younger stages may stay in flight
-    if (s + R2_NS - 1 <= nk) {
-      if (my_dmas == 4) __builtin_amdgcn_s_waitcnt(0x0f78);   // vmcnt(8)
-      else __builtin_amdgcn_s_waitcnt(0x0f76);                // vmcnt(6)
-    } else {
-      __builtin_amdgcn_s_waitcnt(0x0f70);                     // the stream ends: wait for everything
-    }
+    __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): stage s has landed (this wave's pieces; the barrier covers the others)
     __builtin_amdgcn_s_barrier();
-    // every wave is done with stage s - 1: its slot takes stage s + NS - 1
-    const bool more = s + R2_NS - 1 < nk;
+    // every wave is done with stage s - 1: its buffer takes stage s + 1, the activation pieces now, the weight pieces after
+    // the first k-step (a steadier request stream than one burst)
+    const bool more = s + 1 < nk;
     if (more) issue_a();
-    const unsigned char* S = smem + sc * R2_STAGE_BYTES;
+    const unsigned char* S = smem + (s & 1) * R2_STAGE_BYTES;
     const unsigned char* Sa = S + a_row;
     const unsigned char* Sw = S + R2_A_BYTES;
-    const bf16x8 fa0 = *reinterpret_cast<const bf16x8*>(Sa + xo0), fa1 = *reinterpret_cast<const bf16x8*>(Sa + xo1);
-    // 16 weight fragments (k-step ks, column block j), streamed three deep ahead of their MFMAs
+    // 32 weight fragments (k-step ks, column block j), streamed three deep ahead of their MFMAs
+    bf16x8 fa[2];
+    fa[0] = *reinterpret_cast<const bf16x8*>(Sa + xo[0]);
     bf16x8 fw[3];
-    fw[0] = *reinterpret_cast<const bf16x8*>(Sw + xo0);
-    fw[1] = *reinterpret_cast<const bf16x8*>(Sw + 2048 + xo0);
+    fw[0] = *reinterpret_cast<const bf16x8*>(Sw + xo[0]);
+    fw[1] = *reinterpret_cast<const bf16x8*>(Sw + 4096 + xo[0]);
 #pragma unroll
-    for (int t = 0; t < 16; ++t) {
+    for (int t = 0; t < 32; ++t) {
       const int ks = t >> 3, j = t & 7;
-      if (t + 2 < 16) {
+      if (t + 2 < 32) {
         const int t2 = t + 2, ks2 = t2 >> 3, j2 = t2 & 7;
-        fw[t2 % 3] = *reinterpret_cast<const bf16x8*>(Sw + j2 * 2048 + (ks2 ? xo1 : xo0));
+        fw[t2 % 3] = *reinterpret_cast<const bf16x8*>(Sw + j2 * 4096 + xo[ks2]);
       }
-      acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ks ? fa1 : fa0, fw[t % 3], acc[j], 0, 0, 0);
+      if (j == 4 && ks < 3) fa[(ks + 1) & 1] = *reinterpret_cast<const bf16x8*>(Sa + xo[ks + 1]);
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks & 1], fw[t % 3], acc[j], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
       if (t == 7 && more) issue_w();
     }
-    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): this wave's reads of stage s are complete before the next barrier frees the slot
-    sc = sc + 1 == R2_NS ? 0 : sc + 1;
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): this wave's reads of stage s are complete before the next barrier frees the buffer
   }
 
   // ---- write-out, straight from the accumulator layout: register r of block j = row frag_row(r), column 32 j + fr
@@ -176,10 +171,11 @@ __global__ __launch_bounds__(64 * R2_WAVES, 1) void gemm_ring320_kernel(GemmArgs
 
 bool gemm_ring320_supported(const GemmArgs& a, int a_f32, int epi) {
   if (a.m_dev) return false;
-  // EXPERIMENT, off by default: measured per step at M = 81,920 against the 160-row kernel (bench --all-sites, same box):
-  // FC2 + residual 3.02 -> 3.14..3.40 ms, FC1 dgrad 1.73 -> 1.73..1.82, QKV dgrad 1.53 -> 1.58..1.72, proj 1.57 -> 1.68..1.75:
-  // halving the weight stream did not pay for the exposed prologue / write-out of a single block per workgroup and twice
-  // the barriers per k.  COATI_RING320=1 selects it.
+  // EXPERIMENT, off by default: measured per step at M = 81,920 against the 160-row kernel (bench --all-sites, same box), this
+  // (second) version: FC2 + residual 3.06 -> 3.16 ms, FC1 dgrad 1.75 -> 1.83, QKV dgrad 1.53 -> 1.71, proj 1.59 -> 1.67; the
+  // first version (32-k stages, 4-slot ring, 64-B rows) 3.14..3.40 / 1.73..1.82 / 1.58..1.72 / 1.68..1.75.  Halving the weight
+  // stream does not pay for one stage in flight instead of two, the exposed prologue / write-out of a single block per
+  // workgroup and a kernel at the 168-register limit.  COATI_RING320=1 selects it.
   static const bool on = getenv("COATI_RING320") != nullptr && atoi(getenv("COATI_RING320")) == 1;
   if (!on || a_f32) return false;
   if (epi != EPI_BF16 && epi != EPI_RES_F32) return false;
