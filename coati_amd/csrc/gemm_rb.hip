@@ -60,12 +60,12 @@ extern "C" int coati_rb_trace_read(unsigned long long* out) {
 #endif
 
 template <typename F>
-__device__ __forceinline__ void rb_call_restrict(F&& f, int j, const bf16_t* __restrict__ cur, bf16_t* __restrict__ nxt) {
-  f(j, cur, nxt);
+__device__ __forceinline__ void rb_call_restrict(F&& f, int jt, int jn, const bf16_t* __restrict__ cur, bf16_t* __restrict__ nxt) {
+  f(jt, jn, cur, nxt);
 }
 
 template <int EPI, int RB_BN, int MAXW, bool LN = false>
-__global__ __launch_bounds__(64 * MAXW, (640 / (64 * MAXW)) > 0 ? (640 / (64 * MAXW)) : 1) void gemm_rb256_kernel(GemmArgs p, int W, int half_from) {
+__global__ __launch_bounds__(64 * MAXW, (640 / (64 * MAXW)) > 0 ? (640 / (64 * MAXW)) : 1) void gemm_rb256_kernel(GemmArgs p, int W, int half_from, int rot) {
   // W waves; waves >= half_from own 16 rows instead of 32 (half_from >= W: none).  The kernel is issue-bound per SIMD (MFMA +
   // epilogue VALU of the waves that share it: tools/probes/rb_trace.py), and 10 full waves sit 3 / 3 / 2 / 2 on the four
   // SIMDs -- a fifth of the wave time went into the tile barrier.  8 full + 4 half waves put 2 + 1/2 slabs on every SIMD:
@@ -220,16 +220,20 @@ __global__ __launch_bounds__(64 * MAXW, (640 / (64 * MAXW)) > 0 ? (640 / (64 * M
   GemmArgs q = p;
   q.bias = nullptr;   // folded into the accumulator initialisation below
 
-  load_tile(0, Bs);
+  // rot: every workgroup walks the weight tiles from its own starting tile instead of all 256 reading the same 32-KiB tile
+  // out of the L2 and writing the same 128-B column of their power-of-two pitched output rows at the same time.  Every tile is
+  // a complete sum over k and the CE epilogues index their partials by tile, so the order does not enter any result.
+  const int j0 = rot ? (int)(blockIdx.x % (unsigned)ntiles) : 0;
+  load_tile(j0 * RB_BN, Bs);
   float bz[NACC], bn[NACC];
 #pragma unroll
-  for (int a = 0; a < NACC; ++a) { bz[a] = has_bias ? bias_at(32 * a + fr) : 0.f; bn[a] = 0.f; }
+  for (int a = 0; a < NACC; ++a) { bz[a] = has_bias ? bias_at(j0 * RB_BN + 32 * a + fr) : 0.f; bn[a] = 0.f; }
   __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0)
   __syncthreads();
   RB_T(0);
 
   const int sw = fr & 31, hk = lane >> 5;
-  auto tile = [&](int j, const bf16_t* cur, bf16_t* nxt) {
+  auto tile = [&](int jt, int jn, const bf16_t* cur, bf16_t* nxt) {   // jt: this tile, jn: the one to prefetch
     // prefetch for tile j + 1 (past the last tile: a clamped, unused re-read of the last rows).  Every wave finished
     // reading that buffer before the barrier that ended the previous iteration.
 #if RB_PRIO == 1
@@ -237,15 +241,15 @@ __global__ __launch_bounds__(64 * MAXW, (640 / (64 * MAXW)) > 0 ? (640 / (64 * M
 #elif RB_PRIO == 2
     __builtin_amdgcn_s_setprio(RB_PRIO_HI);
 #endif
-    load_tile((j + 1) * RB_BN, nxt);
-    if constexpr (AUX) load_aux(j * RB_BN);
+    load_tile(jn * RB_BN, nxt);
+    if constexpr (AUX) load_aux(jt * RB_BN);
     if (has_bias) {
 #pragma unroll
-      for (int a = 0; a < NACC; ++a) bn[a] = bias_at((j + 1) * RB_BN + 32 * a + fr);
+      for (int a = 0; a < NACC; ++a) bn[a] = bias_at(jn * RB_BN + 32 * a + fr);
     }
     float ew = 0.f, eb = 0.f;
     if constexpr (EDGE) {   // lane = column of this tile (clamped); written to LDS after the MFMA phase
-      const int c = j * RB_BN + (lane % RB_BN), cc = c < p.N ? c : p.N - 1;
+      const int c = jt * RB_BN + (lane % RB_BN), cc = c < p.N ? c : p.N - 1;
       ew = p.w1c[(long long)cc * p.w1c_stride];
       eb = p.b1[cc];
     }
@@ -312,7 +316,7 @@ __global__ __launch_bounds__(64 * MAXW, (640 / (64 * MAXW)) > 0 ? (640 / (64 * M
         if constexpr (AUX) staged = Xs + (size_t)(lane + 64 * (TPH * hf + i)) * 16;
         if constexpr (EPI == EPI_MUL_AUX) staged = Xs + (size_t)(row * (RB_BN / 16) + (cg >> 1)) * 16 + (cg & 1) * 8;
         if constexpr (EDGE) staged = Rs + cg * 8;
-        epilogue8<EPI, 1, RB_BN / 8, 16>(q, m0 + row, j * RB_BN + cg * 8, v, (m0 + row) < p.M, j, ntiles, staged);
+        epilogue8<EPI, 1, RB_BN / 8, 16>(q, m0 + row, jt * RB_BN + cg * 8, v, (m0 + row) < p.M, jt, ntiles, staged);
       };
       // light epilogues run both tasks interleaved; the heavy ones (activation maths, extra operands) one after the
       // other, or their temporaries spill (the kernel lives at the 168-VGPR limit of 3 waves per SIMD)
@@ -335,8 +339,11 @@ __global__ __launch_bounds__(64 * MAXW, (640 / (64 * MAXW)) > 0 ? (640 / (64 * M
   };
   // cur / nxt reach the tile body as __restrict__ parameters (rb_call_restrict): the compiler waits for every pending
   // global_load_lds before an LDS read it cannot prove disjoint from the DMA's target
-  for (int j = 0; j < ntiles; ++j)
-    rb_call_restrict(tile, j, Bs + (j & 1) * RB_TILE_HALFS, Bs + ((j + 1) & 1) * RB_TILE_HALFS);
+  for (int j = 0, jt = j0; j < ntiles; ++j) {
+    const int jn = jt + 1 == ntiles ? 0 : jt + 1;   // (behind the last tile: an unused re-read of the first one)
+    rb_call_restrict(tile, jt, jn, Bs + (j & 1) * RB_TILE_HALFS, Bs + ((j + 1) & 1) * RB_TILE_HALFS);
+    jt = jn;
+  }
   RB_TDUMP();
 }
 
@@ -397,10 +404,13 @@ static int launch_rb_shape(const GemmArgs& a, int W, hipStream_t s) {
     attr_set = true;
   }
   const int blocks = cdiv(cdiv(a.M, 32), W);
+  // rotated tile order: measured per epilogue (COATI_RB_ROT=0 | 1 forces it off / on everywhere, default: where it paid)
+  static const int rot_env = getenv("COATI_RB_ROT") ? atoi(getenv("COATI_RB_ROT")) : -1;
+  const int rot = rot_env >= 0 ? (rot_env != 0) : (EPI == EPI_MUL_AUX);
   if constexpr (MAXW == RB_HALF_W) {   // 8 + 4: the same 320 rows per workgroup as 10 full waves
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(64 * RB_HALF_W), tile_bytes + RB_HALF_W * per_wave, s, a, RB_HALF_W, 8);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(64 * RB_HALF_W), tile_bytes + RB_HALF_W * per_wave, s, a, RB_HALF_W, 8, rot);
   } else {
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(64 * W), tile_bytes + W * per_wave, s, a, W, W);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(64 * W), tile_bytes + W * per_wave, s, a, W, W, rot);
   }
   COATI_LAUNCH_CHECK("gemm_rb256");
   return COATI_OK;
