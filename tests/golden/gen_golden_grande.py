@@ -1,0 +1,208 @@
+"""
+Golden vectors at the HEADLINE architecture (grande_closed: d = 256, 16 transformer layers, 16 heads, E(3)-GNN 256 x 5,
+V = 10 322 = the may_closedparen vocabulary size, n_seq 250: examples/training/train_grande.py:21-35), produced by
+IMPORTING THE REFERENCE in the build container (same stubs as gen_golden.py).  SURVEY section 8(c) G5 / G13 "L = 16, V = 10 322".
+
+The 20.4 M weights (81 MB) are not stored: they are the deterministic draw of oracle.coati_oracle.init_params(cfg, seed = 16)
+(a torch CPU generator, identical on the GPU box: same image), loaded into the reference model with load_state_dict; the
+fixture keeps a per-parameter checksum of them so that a drifting generator is detected instead of blamed on a kernel.
+
+What is stored (all produced by the reference's own modules; fp32):
+  * inputs: 4 batches of 16 molecules (tokens up to 64 wide, 16-atom clouds), the use-point masks of every step;
+  * forward_dist (clip_e2e.py:772-814) on batch 0 with a mixed injection mask: h_e3gnn, h_smiles, bad_rows, log-sum-exp and
+    arg-max of every logits row, the logits at the target token, and full logits rows of 3 molecules;
+  * the training step (train_coati.py:216-277) on batch 0: ar / clip / total loss, clip_grad_norm_ value, the L2 norm and a
+    fixed random projection of EVERY parameter gradient, full gradients of representative parameters (layers 0 / 8 / 15
+    c_attn, c_proj, mlpf, ln; ln_f; gcl_0 / gcl_4; heads), row subsets of tok_emb / lm_head gradients; after the first AdamW
+    step: the same norms / projections of the weight change and a strided sample of the new weights;
+  * a 20-step curve (AdamW lr 5e-4, wd 0.1, betas (0.9, 0.99), clip 10) cycling over the 4 batches: loss / ar / clip / grad-norm.
+
+    python tests/golden/gen_golden_grande.py            # (re)write tests/golden/grande_golden.npz  (about 3 minutes of CPU)
+    python tests/golden/gen_golden_grande.py --verify   # regenerate into a scratch directory and compare contents
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+OUT = os.environ.get("GOLDEN_OUT", HERE)
+sys.path.insert(0, HERE)
+sys.path.insert(1, ROOT)
+
+GRANDE = dict(n_layer_e3gnn=5, n_layer_xformer=16, n_hidden_xformer=256, n_hidden_e3nn=256, n_embd_common=256, n_head=16,
+              n_seq=250, n_tok=10322)
+SEED = 16
+N_STEPS = 20
+FULL_GRADS = [
+    "xformer.transformer.h.0.attn.c_attn.weight", "xformer.transformer.h.0.attn.c_attn.bias",
+    "xformer.transformer.h.0.ln_1.weight", "xformer.transformer.h.0.ln_1.bias",
+    "xformer.transformer.h.0.mlpf.0.weight", "xformer.transformer.h.0.mlpf.2.bias",
+    "xformer.transformer.h.8.attn.c_attn.weight", "xformer.transformer.h.8.attn.c_proj.weight",
+    "xformer.transformer.h.8.ln_2.weight", "xformer.transformer.h.8.mlpf.2.weight",
+    "xformer.transformer.h.15.attn.c_attn.weight", "xformer.transformer.h.15.mlpf.0.weight",
+    "xformer.transformer.h.15.mlpf.0.bias", "xformer.transformer.h.15.ln_2.bias",
+    "xformer.transformer.ln_f.weight", "xformer.transformer.ln_f.bias",
+    "point_encoder.embedding.weight", "point_encoder.gcl_0.edge_mlp.0.weight", "point_encoder.gcl_0.node_mlp.0.weight",
+    "point_encoder.gcl_4.edge_mlp.3.weight", "point_encoder.gcl_4.node_mlp.3.weight", "point_encoder.node_dec.3.weight",
+    "point_to_clip.1.weight", "smiles_to_clip.1.weight", "smiles_to_clip.0.weight", "point_clip_to_special_tokens.1.weight",
+]
+ROW_GRADS = ["xformer.emb.tok_emb.weight", "xformer.lm_head.weight"]   # 10 322 x 256: rows 0..63 + every 41st row
+
+
+def row_subset(V):
+    return np.unique(np.concatenate([np.arange(64), np.arange(0, V, 41)]))
+
+
+def projection(name, numel):
+    """fixed +-1 vector per parameter (a torch CPU generator seeded from the name)"""
+    s = 0
+    for ch in name:
+        s = (s * 131 + ord(ch)) % 2147483647
+    return (torch.randint(0, 2, (numel,), generator=torch.Generator().manual_seed(s)) * 2 - 1).float()
+
+
+def make_inputs():
+    from coati_amd.synthetic import make_batch
+    batches, masks = [], []
+    for i in range(4):
+        b, _ = make_batch(16, 48 + 5 * i + (1 if i == 3 else 0), 16, GRANDE["n_tok"], seed=9000 + i, n_special=1596,
+                          p_bad=0.0, min_len=12)
+        if i in (0, 2):            # one bad row (tokenisation failure: all-PAD tokens, [STOP] PAD... raw_tokens), clip_e2e.py:299-311
+            b["tokens"][5] = 0
+            b["raw_tokens"][5] = 0
+            b["raw_tokens"][5, 0] = 1
+            from coati_amd.synthetic import y_next_from_tokens
+            b["y_next"] = y_next_from_tokens(b["tokens"])
+        batches.append(b)
+    g = torch.Generator().manual_seed(4242)
+    for s in range(N_STEPS + 1):
+        masks.append(torch.rand(16, generator=g))
+    return batches, masks
+
+
+def main():
+    import gen_golden as G               # stubs rdkit / boto3, puts the reference on sys.path
+    from oracle import coati_oracle as O
+    ref_clip = G.ref_clip
+    torch.manual_seed(0)
+    torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
+    ocfg = O.OracleConfig(**GRANDE)
+    P = O.init_params(ocfg, seed=SEED)
+    model = ref_clip.e3gnn_smiles_clip_e2e(biases=True, torch_emb=False, residual=False, norm_clips=True, norm_embed=False,
+                                           token_mlp=True, **GRANDE)
+    missing, unexpected = model.load_state_dict(P, strict=False)
+    assert not unexpected and all(k.endswith(".attn.bias") for k in missing), (missing, unexpected)
+    names = [n for n, _ in model.named_parameters()]
+    assert set(names) == set(P)
+    tokz = G.Tok(GRANDE["n_tok"], 250)
+    batches, masks = make_inputs()
+    out = {"seed": np.array(SEED), "n_steps": np.array(N_STEPS)}
+    for i, b in enumerate(batches):
+        out.update({f"b{i}_{k}": v for k, v in b.items()})
+    out["rand"] = torch.stack(masks)                      # use_point = rand > 0.5 (clip_e2e.py:800-808)
+    out["wsum"] = np.array([float(P[n].double().sum()) for n in names])
+    out["wabs"] = np.array([float(P[n].double().abs().sum()) for n in names])
+    out["names"] = np.array(names)
+
+    real_rand = torch.rand
+    cur = {"m": None}
+
+    def fake_rand(*a, **k):
+        return cur["m"].clone()
+
+    cl = ref_clip.clip_loss()
+    teu = float(np.log(float(GRANDE["n_tok"])) / np.log(2.0))          # train_coati.py:87
+    b = batches[0]
+
+    # ---- forward_dist on batch 0, mixed injection --------------------------------------------------------------------
+    with torch.no_grad():
+        cur["m"] = masks[N_STEPS]
+        torch.rand = fake_rand
+        he, hs, lg, bad = model.forward_dist(b["raw_tokens"], b["tokens"], b["atoms"], b["coords"], tokz, p_clip_emb_smi=0.5)
+        torch.rand = real_rand
+    yn = b["y_next"]
+    tgt = torch.gather(lg, 2, yn.clamp(min=0).unsqueeze(-1)).squeeze(-1)
+    out.update(fd_h_e3gnn=he, fd_h_smiles=hs, fd_bad=bad, fd_lse=torch.logsumexp(lg, -1), fd_argmax=lg.argmax(-1),
+               fd_logit_at_target=tgt, fd_logits_rows=lg[[0, 5, 11]].contiguous(), fd_rows=np.array([0, 5, 11]))
+
+    # ---- 20 steps; the first one is dumped in detail ------------------------------------------------------------------
+    opt = torch.optim.AdamW(model.parameters(), lr=5e-4, weight_decay=0.1, betas=(0.9, 0.99), eps=1e-8)
+    rec = dict(loss=[], ar=[], clip=[], gradnorm=[])
+    rows = row_subset(GRANDE["n_tok"])
+    out["row_subset"] = rows
+    for step in range(N_STEPS):
+        b = batches[step % 4]
+        opt.zero_grad()
+        cur["m"] = masks[step]
+        torch.rand = fake_rand
+        he, hs, lg, bad = model.forward_dist(b["raw_tokens"], b["tokens"], b["atoms"], b["coords"], tokz, p_clip_emb_smi=0.5)
+        torch.rand = real_rand
+        ar = torch.nn.functional.cross_entropy(lg.view(-1, lg.size(-1)), b["y_next"].view(-1), ignore_index=-1)   # train_coati.py:260-265
+        c = cl(hs, he, bad).mean()
+        loss = ar + c * teu                                                                                     # train_coati.py:270
+        loss.backward()
+        if step == 0:
+            gn_all, gp_all = [], []
+            for n, p in model.named_parameters():
+                g = p.grad if p.grad is not None else torch.zeros_like(p)
+                gn_all.append(float(g.double().norm()))
+                gp_all.append(float((g.double().flatten() * projection(n, g.numel()).double()).sum()))
+                if n in FULL_GRADS:
+                    out["grad." + n] = g.clone()
+                if n in ROW_GRADS:
+                    out["gradrows." + n] = g[rows].clone()
+            out.update(grad_norms=np.array(gn_all), grad_projs=np.array(gp_all), step_ar=ar.detach(), step_clip=c.detach(),
+                       step_loss=loss.detach())
+            w0 = {n: p.detach().clone() for n, p in model.named_parameters()}
+        gn = torch.nn.utils.clip_grad_norm_(model.parameters(), 10.0)                                           # train_coati.py:276
+        opt.step()
+        if step == 0:
+            out["step_gradnorm"] = gn
+            dn, dp = [], []
+            for n, p in model.named_parameters():
+                d = (p.detach() - w0[n]).double()
+                dn.append(float(d.norm()))
+                dp.append(float((d.flatten() * projection(n, d.numel()).double()).sum()))
+                if n in FULL_GRADS:
+                    out["after1." + n] = p.detach().flatten()[::7].clone()
+            out.update(delta_norms=np.array(dn), delta_projs=np.array(dp))
+            del w0
+        for k, v in (("loss", loss), ("ar", ar), ("clip", c), ("gradnorm", gn)):
+            rec[k].append(float(v))
+        print(f"step {step}: loss {float(loss):.5f} ar {float(ar):.5f} clip {float(c):.5f} gn {float(gn):.4f}", flush=True)
+    out.update({"curve_" + k: np.array(v, dtype=np.float64) for k, v in rec.items()})
+    out["teu"] = np.array(teu)
+    np.savez_compressed(os.path.join(OUT, "grande_golden.npz"), **G.npify(out))
+    print("written", os.path.join(OUT, "grande_golden.npz"))
+
+
+def verify():
+    import subprocess
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        subprocess.run([sys.executable, os.path.abspath(__file__)], env=dict(os.environ, GOLDEN_OUT=tmp), check=True,
+                       stdout=subprocess.DEVNULL)
+        x, y = np.load(os.path.join(tmp, "grande_golden.npz")), np.load(os.path.join(HERE, "grande_golden.npz"))
+        ok = x.files == y.files
+        for k in x.files:
+            if x[k].dtype.kind == "f":
+                # the reference's CPU kernels are run-to-run deterministic for a fixed thread count; across thread counts
+                # sums re-associate: compare at 1e-5 of scale
+                sc = max(float(np.abs(y[k]).max()), 1e-30)
+                same = x[k].shape == y[k].shape and float(np.abs(x[k] - y[k]).max()) <= 1e-5 * sc
+            else:
+                same = np.array_equal(x[k], y[k])
+            if not same:
+                print("DIFFERENT", k)
+                ok = False
+        print("grande_golden.npz", "same" if ok else "DIFFERENT")
+        return ok
+
+
+if __name__ == "__main__":
+    if "--verify" in sys.argv:
+        sys.exit(0 if verify() else 1)
+    main()

@@ -21,7 +21,15 @@ TOL_FWD_SIM = 6.5e-3   # measured 3.16e-3
 TOL_GRAD_SIM = 4e-2    # measured 2.67e-2 (golden), 2.55e-2 (tall), 1.66e-2 (medium)
 TOL_LOSS_SIM = 1.2e-3  # measured 5.4e-4 (tall clip); the edge-shape cases keep 5e-3 (2.8e-3 measured on a 1-valid-row batch)
 TOL_GRADNORM = 1.3e-2
-TOL_CURVE = 2.5e-3     # 40-step curve: measured 8.8e-4 (loss), 1.2e-3 (clip), 8.2e-3 (grad norm: 5x this)
+TOL_CURVE = 2.5e-3     # 40-step curve: measured 2.2e-3 (loss), 1.2e-3 (clip)
+# Gradient NORM of the 40-step toy curve: this model's gradient norm (5 .. 45, lr 5e-4 on 64-wide layers) is sensitive to operand
+# rounding -- the ORACLE with bf16 storage simulated (CPU, shares no kernel with the engine) deviates from the reference's
+# curve by up to 2.3e-2 (step 28; 1.8e-2 at step 32, 2.0e-2 at step 12; median 3.6e-3), and the fp32 oracle started from weights
+# perturbed by 1e-3 by up to 8.6e-3 (tools/curve_bf16_sim.py, profiles/r03_curve_bf16_sim.txt).  The engine measured 1.75e-2 at
+# step 32 (round 2): inside that envelope.  Bound = 2x the simulation's worst step, plus a median bound that a systematic
+# gradient error would break.
+TOL_CURVE_GN_MAX = 4.6e-2
+TOL_CURVE_GN_MEDIAN = 1.0e-2
 
 
 @pytest.fixture(scope="module")
@@ -171,7 +179,8 @@ def test_forty_step_loss_curve_vs_reference(golden_dir):
     assert c["loss"][-8:].mean() < 0.85 * c["loss"][:8].mean()              # the curve really descends
     assert dev_["loss"].max() <= TOL_CURVE and dev_["ar"].max() <= TOL_CURVE
     assert np.abs(np.array(rec["clip"]) - c["clip"]).max() <= TOL_CURVE * max(1.0, float(np.abs(c["clip"]).max()))
-    assert dev_["gradnorm"].max() <= 7 * TOL_CURVE
+    log(f"40-step curve: grad-norm deviation median {np.median(dev_['gradnorm']):.3e}")
+    assert dev_["gradnorm"].max() <= TOL_CURVE_GN_MAX and np.median(dev_["gradnorm"]) <= TOL_CURVE_GN_MEDIAN
 
 
 def test_medium_random_model_grads():
