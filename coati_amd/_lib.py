@@ -85,7 +85,7 @@ _SIGS = {
 }
 
 _lib = None
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 def lib():

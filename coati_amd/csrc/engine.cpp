@@ -146,6 +146,8 @@ struct coati_engine {
   struct WTabKey { const void* pass = nullptr; int lo = -1, hi = -1, M = 0, n = 0; long long sig = 0; bool split = false; };
   WTabKey wtab_key[4];
   const void* wtab_ws = nullptr;                      // workspace the cached tables were built for
+  long long carve_sig = -1;                           // (B, T1, T2, A) of the last carve: the cached tables die with any other shape
+  int wtab_rr = 0;                                    // round-robin slot of the next table upload
   float* nce = nullptr;
   size_t nce_cap = 0;
   float* opt_partial;
@@ -471,6 +473,12 @@ size_t carve(coati_engine* e, Arena& ar, int B, int T1, int T2, int A, int Bg) {
       e->d_wtab = t;
       e->wtab_ws = ar.base;
     }
+    // The cached tile tables live INSIDE the workspace: any carve for another shape (an encode call, a smaller last batch, a
+    // shape that does not take the grouped launch) lays other buffers over them, so the cache is only valid while the very
+    // same (B, T1, T2, A) is carved again
+    const long long csig = (((long long)B * 1000003 + T1) * 1000003 + T2) * 1000003 + A;
+    if (!e->wg_group || csig != e->carve_sig) for (auto& k : e->wtab_key) k = coati_engine::WTabKey();
+    e->carve_sig = csig;
   }
   e->opt_partial = ar.take<float>(1024);
   e->ln_partial = ar.take<float>((size_t)COATI_LN_PARTIAL_ROWS * 2 * (C > H ? C : H));
@@ -600,8 +608,7 @@ int xformer_wgrad_group(coati_engine* e, XPass& p, int l_lo, int l_hi, hipStream
       split = true;
     }
     COATI_CHECK_ARG((int)tab.size() <= e->wtab_cap, "wgrad group: table overflow (%zu > %d)", tab.size(), e->wtab_cap);
-    static int rr = 0;
-    slot = rr++ & 3;
+    slot = e->wtab_rr++ & 3;
     // pageable source: the runtime stages the copy before hipMemcpyAsync returns, so `tab` may go out of scope
     if (hipMemcpyAsync(e->d_wtab + (size_t)slot * e->wtab_cap, tab.data(), tab.size() * sizeof(WgradTile), hipMemcpyHostToDevice, s) != hipSuccess ||
         hipStreamSynchronize(s) != hipSuccess) {

@@ -408,7 +408,7 @@ __global__ void gnn_compact_rev_kernel(const int* __restrict__ n_edges, const in
 int launch_gnn_compact(const float* w_dense, const float* d2_dense, int* seg, int* n_edges, int* e_bj, int* e_bk, int* e_rev,
                        float* e_d2, float* e_w, int* pos, int B, int A, hipStream_t s) {
   COATI_CHECK_ARG(w_dense && d2_dense && seg && n_edges && e_bj && e_bk && e_rev && e_d2 && e_w && pos, "gnn_compact: null operand");
-  COATI_CHECK_SHAPE(B > 0 && A > 0 && A <= 64, "gnn_compact: at most 64 atoms per molecule (a receiver's segment is broadcast from one wave)");
+  COATI_CHECK_SHAPE(B > 0 && A > 0 && (long long)B * A * A < (1LL << 31), "gnn_compact: B*A*A must fit 31 bits");   // any A: the *_c kernels walk a receiver's segment in 64-edge chunks
   const int BA = B * A;
   // the per-receiver counts are parked in e_rev (B*A*A ints, rewritten by the last pass)
   hipLaunchKernelGGL(gnn_compact_count_kernel, dim3(cdiv(BA, 256)), dim3(256), 0, s, w_dense, e_rev, BA, A);
@@ -428,33 +428,37 @@ __global__ __launch_bounds__(256) void gnn_edge_pre_c_kernel(const bf16_t* __res
   const int bj = blockIdx.x * 4 + wave;
   if (bj >= BA) return;
   const int e0 = seg[bj], n = seg[bj + 1] - e0;
-  // the segment's sender rows and distances: one coalesced load per wave, broadcast with readlane (n <= 63)
-  const int my_bk = lane < n ? e_bk[e0 + lane] : 0;
-  const float my_d2 = lane < n ? e_d2[e0 + lane] : 0.f;
   for (int c = lane * 4; c < H; c += 256) {
     const uint2 ua = *reinterpret_cast<const uint2*>(P + (long long)bj * ldp + c);
     const float pa[4] = {bflo(ua.x), bfhi(ua.x), bflo(ua.y), bfhi(ua.y)};
     float wc[4], bb[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) { wc[i] = w1c[(long long)(c + i) * w1c_stride]; bb[i] = b1[c + i]; }
-    for (int i0 = 0; i0 < n; i0 += 4) {
-      uint2 ub[4];
-      float dd[4];
+    // the segment's sender rows and distances: one coalesced load per wave and 64-edge chunk, broadcast with readlane
+    // (one chunk whenever the molecule has at most 64 atoms)
+    for (int base = 0; base < n; base += 64) {
+      const int nn = n - base < 64 ? n - base : 64;
+      const int my_bk = lane < nn ? e_bk[e0 + base + lane] : 0;
+      const float my_d2 = lane < nn ? e_d2[e0 + base + lane] : 0.f;
+      for (int i0 = 0; i0 < nn; i0 += 4) {
+        uint2 ub[4];
+        float dd[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int i = i0 + u < n ? i0 + u : n - 1;
-        const int bk = __builtin_amdgcn_readlane(my_bk, i);
-        dd[u] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_d2), i));
-        ub[u] = *reinterpret_cast<const uint2*>(P + (long long)bk * ldp + H + c);
-      }
+        for (int u = 0; u < 4; ++u) {
+          const int i = i0 + u < nn ? i0 + u : nn - 1;
+          const int bk = __builtin_amdgcn_readlane(my_bk, i);
+          dd[u] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_d2), i));
+          ub[u] = *reinterpret_cast<const uint2*>(P + (long long)bk * ldp + H + c);
+        }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        if (i0 + u >= n) break;
-        const float pb[4] = {bflo(ub[u].x), bfhi(ub[u].x), bflo(ub[u].y), bfhi(ub[u].y)};
-        float o[4];
+        for (int u = 0; u < 4; ++u) {
+          if (i0 + u >= nn) break;
+          const float pb[4] = {bflo(ub[u].x), bfhi(ub[u].x), bflo(ub[u].y), bfhi(ub[u].y)};
+          float o[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) o[i] = silu_f(pa[i] + pb[i] + dd[u] * wc[i] + bb[i]);
-        *reinterpret_cast<uint2*>(e1 + (long long)(e0 + i0 + u) * H + c) = make_uint2(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]));
+          for (int i = 0; i < 4; ++i) o[i] = silu_f(pa[i] + pb[i] + dd[u] * wc[i] + bb[i]);
+          *reinterpret_cast<uint2*>(e1 + (long long)(e0 + base + i0 + u) * H + c) = make_uint2(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]));
+        }
       }
     }
   }
@@ -476,22 +480,25 @@ __global__ __launch_bounds__(256) void gnn_edge_reduce_c_kernel(const bf16_t* __
   const int bj = blockIdx.x * 4 + wave;
   if (bj >= BA) return;
   const int e0 = seg[bj], n = seg[bj + 1] - e0;
-  const float my_w = lane < n ? e_w[e0 + lane] : 0.f;
   for (int c = lane * 4; c < H; c += 256) {
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int i0 = 0; i0 < n; i0 += 4) {
-      uint2 u[4];
-      float ww[4];
+    for (int base = 0; base < n; base += 64) {
+      const int nn = n - base < 64 ? n - base : 64;
+      const float my_w = lane < nn ? e_w[e0 + base + lane] : 0.f;
+      for (int i0 = 0; i0 < nn; i0 += 4) {
+        uint2 u[4];
+        float ww[4];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int i = i0 + q < n ? i0 + q : n - 1;
-        ww[q] = i0 + q < n ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_w), i)) : 0.f;
-        u[q] = *reinterpret_cast<const uint2*>(s2 + (long long)(e0 + i) * H + c);
-      }
+        for (int q = 0; q < 4; ++q) {
+          const int i = i0 + q < nn ? i0 + q : nn - 1;
+          ww[q] = i0 + q < nn ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_w), i)) : 0.f;
+          u[q] = *reinterpret_cast<const uint2*>(s2 + (long long)(e0 + base + i) * H + c);
+        }
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        acc[0] += silu_f(bflo(u[q].x)) * ww[q]; acc[1] += silu_f(bfhi(u[q].x)) * ww[q];
-        acc[2] += silu_f(bflo(u[q].y)) * ww[q]; acc[3] += silu_f(bfhi(u[q].y)) * ww[q];
+        for (int q = 0; q < 4; ++q) {
+          acc[0] += silu_f(bflo(u[q].x)) * ww[q]; acc[1] += silu_f(bfhi(u[q].x)) * ww[q];
+          acc[2] += silu_f(bflo(u[q].y)) * ww[q]; acc[3] += silu_f(bfhi(u[q].y)) * ww[q];
+        }
       }
     }
     *reinterpret_cast<uint2*>(mi + (long long)bj * ldmi + c) = make_uint2(pack2bf(acc[0], acc[1]), pack2bf(acc[2], acc[3]));
@@ -513,21 +520,24 @@ __global__ __launch_bounds__(256) void gnn_edge_reduce_bwd_c_kernel(const bf16_t
   const int bj = blockIdx.x * 4 + wave;
   if (bj >= BA) return;
   const int e0 = seg[bj], n = seg[bj + 1] - e0;
-  const float my_w = lane < n ? e_w[e0 + lane] : 0.f;
   for (int c = lane * 4; c < H; c += 256) {
     const uint2 ug = *reinterpret_cast<const uint2*>(dmi + (long long)bj * lddmi + c);
     const float g[4] = {bflo(ug.x), bfhi(ug.x), bflo(ug.y), bfhi(ug.y)};
-    for (int i0 = 0; i0 < n; i0 += 4) {
-      uint2 u[4];
+    for (int base = 0; base < n; base += 64) {
+      const int nn = n - base < 64 ? n - base : 64;
+      const float my_w = lane < nn ? e_w[e0 + base + lane] : 0.f;
+      for (int i0 = 0; i0 < nn; i0 += 4) {
+        uint2 u[4];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) u[q] = *reinterpret_cast<const uint2*>(s2 + (long long)(e0 + (i0 + q < n ? i0 + q : n - 1)) * H + c);
+        for (int q = 0; q < 4; ++q) u[q] = *reinterpret_cast<const uint2*>(s2 + (long long)(e0 + base + (i0 + q < nn ? i0 + q : nn - 1)) * H + c);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        if (i0 + q >= n) break;
-        const float ww = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_w), i0 + q));
-        *reinterpret_cast<uint2*>(ds2 + (long long)(e0 + i0 + q) * H + c) =
-            make_uint2(pack2bf(g[0] * ww * dsilu_f(bflo(u[q].x)), g[1] * ww * dsilu_f(bfhi(u[q].x))),
-                       pack2bf(g[2] * ww * dsilu_f(bflo(u[q].y)), g[3] * ww * dsilu_f(bfhi(u[q].y))));
+        for (int q = 0; q < 4; ++q) {
+          if (i0 + q >= nn) break;
+          const float ww = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_w), i0 + q));
+          *reinterpret_cast<uint2*>(ds2 + (long long)(e0 + base + i0 + q) * H + c) =
+              make_uint2(pack2bf(g[0] * ww * dsilu_f(bflo(u[q].x)), g[1] * ww * dsilu_f(bfhi(u[q].x))),
+                         pack2bf(g[2] * ww * dsilu_f(bflo(u[q].y)), g[3] * ww * dsilu_f(bfhi(u[q].y))));
+        }
       }
     }
   }
@@ -553,28 +563,31 @@ __global__ __launch_bounds__(256) void gnn_edge_pre_bwd_c_kernel(const bf16_t* _
     float sw[4] = {0.f, 0.f, 0.f, 0.f}, sb[4] = {0.f, 0.f, 0.f, 0.f};
     for (int bj = blockIdx.x * 4 + wave; bj < BA; bj += gridDim.x * 4) {
       const int e0 = seg[bj], n = seg[bj + 1] - e0;
-      const int my_rev = lane < n ? e_rev[e0 + lane] : 0;
-      const float my_d2 = lane < n ? e_d2[e0 + lane] : 0.f;
       float a[4] = {0.f, 0.f, 0.f, 0.f}, bsum[4] = {0.f, 0.f, 0.f, 0.f};
-      for (int i0 = 0; i0 < n; i0 += 4) {
-        uint2 u[4], r[4];
-        float dd[4];
+      for (int base = 0; base < n; base += 64) {
+        const int nn = n - base < 64 ? n - base : 64;
+        const int my_rev = lane < nn ? e_rev[e0 + base + lane] : 0;
+        const float my_d2 = lane < nn ? e_d2[e0 + base + lane] : 0.f;
+        for (int i0 = 0; i0 < nn; i0 += 4) {
+          uint2 u[4], r[4];
+          float dd[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const bool ok = i0 + q < n;
-          const int i = ok ? i0 + q : n - 1;
-          const int rv = __builtin_amdgcn_readlane(my_rev, i);
-          dd[q] = ok ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_d2), i)) : 0.f;
-          u[q] = *reinterpret_cast<const uint2*>(dpre + (long long)(e0 + i) * H + c);
-          r[q] = *reinterpret_cast<const uint2*>(dpre + (long long)rv * H + c);
-          if (!ok) { u[q] = make_uint2(0, 0); r[q] = make_uint2(0, 0); }
-        }
+          for (int q = 0; q < 4; ++q) {
+            const bool ok = i0 + q < nn;
+            const int i = ok ? i0 + q : nn - 1;
+            const int rv = __builtin_amdgcn_readlane(my_rev, i);
+            dd[q] = ok ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_d2), i)) : 0.f;
+            u[q] = *reinterpret_cast<const uint2*>(dpre + (long long)(e0 + base + i) * H + c);
+            r[q] = *reinterpret_cast<const uint2*>(dpre + (long long)rv * H + c);
+            if (!ok) { u[q] = make_uint2(0, 0); r[q] = make_uint2(0, 0); }
+          }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const float x[4] = {bflo(u[q].x), bfhi(u[q].x), bflo(u[q].y), bfhi(u[q].y)};
+          for (int q = 0; q < 4; ++q) {
+            const float x[4] = {bflo(u[q].x), bfhi(u[q].x), bflo(u[q].y), bfhi(u[q].y)};
 #pragma unroll
-          for (int i = 0; i < 4; ++i) { a[i] += x[i]; sw[i] = fmaf(x[i], dd[q], sw[i]); }
-          bsum[0] += bflo(r[q].x); bsum[1] += bfhi(r[q].x); bsum[2] += bflo(r[q].y); bsum[3] += bfhi(r[q].y);
+            for (int i = 0; i < 4; ++i) { a[i] += x[i]; sw[i] = fmaf(x[i], dd[q], sw[i]); }
+            bsum[0] += bflo(r[q].x); bsum[1] += bfhi(r[q].x); bsum[2] += bflo(r[q].y); bsum[3] += bfhi(r[q].y);
+          }
         }
       }
 #pragma unroll

@@ -173,11 +173,30 @@ def global_losses(eng):
     return {"ar_loss": ar, "clip_loss": clip, "loss": ar + clip * eng.token_entropy_unit()}
 
 
-def all_agree(flag: bool, device) -> bool:
-    """True when `flag` is true on every rank (one tiny all-reduce): collective decisions such as skipping a batch must
-    be taken by all ranks together or the next collective deadlocks."""
-    t = torch.tensor([1.0 if flag else 0.0], device=device)
+_CONTROL = None
+
+
+def control_group():
+    """Host-side (gloo) process group for control decisions.  Under "nccl" a flag exchanged on the default group is a device
+    collective queued BEHIND the previous step's kernels, and reading it back stalls the host on the whole device queue
+    every batch; a CPU tensor on a gloo group costs one socket round trip and leaves the device running ahead."""
+    global _CONTROL
     if _gloo():
-        t = t.cpu()
-    dist.all_reduce(t, op=dist.ReduceOp.MIN)
-    return bool(t.item() > 0.5)
+        return None                      # the default group is already host-side
+    if _CONTROL is None:
+        _CONTROL = dist.new_group(backend="gloo")
+    return _CONTROL
+
+
+def all_agree_flags(flags):
+    """Element-wise AND over the ranks of a short list of booleans, ONE host-side all-reduce (MIN): collective decisions
+    such as "every rank still has a batch" / "no rank lost a row" must be taken by all ranks together or the next
+    collective deadlocks.  Returns a list of bools."""
+    t = torch.tensor([1.0 if f else 0.0 for f in flags])
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=control_group())
+    return [bool(x > 0.5) for x in t.tolist()]
+
+
+def all_agree(flag: bool, device=None) -> bool:
+    """True when `flag` is true on every rank."""
+    return all_agree_flags([flag])[0]

@@ -57,11 +57,11 @@ def optimizer_state_dict(eng, lr, weight_decay, betas=(0.9, 0.99), eps=1e-8):
 def load_optimizer_state(eng, opt_state, state_dict_keys):
     """--resume_optimizer: map a torch.optim.AdamW.state_dict() written by the reference (or by optimizer_state_dict
     above) into the flat m / v buffers; parameter index i <-> i-th parameter name of the checkpoint's state_dict.
-    (The first-round private {"flat": ...} form is still read.)"""
+    Only this NAMED per-parameter form is read: the first-round private {"flat": m, v} dump is rejected -- the flat layout
+    has changed since (coord_mlp moved behind n_trainable), so its offsets would land on the wrong parameters."""
     if "flat" in opt_state:
-        eng.adam_m.copy_(opt_state["flat"]["m"].to(eng.device)); eng.adam_v.copy_(opt_state["flat"]["v"].to(eng.device))
-        eng.step_count = int(opt_state["flat"]["step"])
-        return
+        raise ValueError("optimizer state in the round-1 flat form: its offsets belong to an older parameter layout; "
+                         "resume from the weights only or re-save with optimizer_state_dict()")
     names = _param_names(state_dict_keys)
     order = [i for g in opt_state["param_groups"] for i in g["params"]]
     if len(order) != len(names):
@@ -225,9 +225,13 @@ def train_autoencoder(gpu, args, dataset=None, tokenizer=None):
     def do_epoch(epoch, partition="train"):
         nonlocal n_toks, ngrad_updates
         t0, ng = time.time(), 0
-        # epoch statistics stay on the device: [sum of batch losses, batches, tokens] (the reference reads .item() per batch,
-        # train_coati.py:282, 309-335; here one read-back per epoch + the logging steps)
-        acc = torch.zeros(3, device=device, dtype=torch.float64)
+        # epoch statistics stay on the device (the reference reads .item() per batch, train_coati.py:282, 309-335; here one
+        # read-back per epoch + the logging steps): the token count, and every batch's raw loss sums [ar sum, ar count,
+        # clip sum 1, clip sum 2, valid rows] -- at world > 1 the first four are RANK-LOCAL (the rank's tokens, its local
+        # rows of the InfoNCE matrices) while the valid-row count is global, so the per-batch loss is formed only after the
+        # sums of all ranks are added, once per epoch (same arithmetic as D.global_losses)
+        acc = torch.zeros(1, device=device, dtype=torch.float64)
+        hist = []
         teu = eng.token_entropy_unit()
         pipe = dataset.get_data_pipe(batch_size=args.batch_size, partition=partition, distributed_rankmod_total=world,
                                      distributed_rankmod_rank=rank, required_fields=["smiles"])
@@ -235,16 +239,18 @@ def train_autoencoder(gpu, args, dataset=None, tokenizer=None):
         i = -1
         while True:
             batch = next(it, None)
-            if world > 1 and not D.all_agree(batch is not None, device):
-                break            # uneven batch counts: every rank stops with the shortest one (no dangling collective)
-            if batch is None:
+            have = batch is not None
+            ok = have and batch["tokens"].shape[0] == batch["atoms"].shape[0] and batch["y_next"].shape[0] == batch["atoms"].shape[0]
+            if world > 1:
+                # ONE host-side exchange per batch for both decisions: uneven batch counts (every rank stops with the
+                # shortest one, no dangling collective) and a skip that must be taken by all ranks or by none
+                have, ok = D.all_agree_flags([have, ok])
+            if not have:
                 break
             i += 1
-            dev = {k: v.to(device) for k, v in batch.items() if isinstance(v, torch.Tensor)}
-            B = dev["atoms"].shape[0]
-            ok = dev["tokens"].shape[0] == B and dev["y_next"].shape[0] == B
-            if world > 1:
-                ok = D.all_agree(ok, device)     # a skip on one rank only would block the other ranks' collectives
+            if ok:
+                dev = {k: v.to(device) for k, v in batch.items() if isinstance(v, torch.Tensor)}
+                B = dev["atoms"].shape[0]
             if not ok:
                 print("a row was lost, skipping batch")          # train_coati.py:229-234
                 continue
@@ -261,14 +267,12 @@ def train_autoencoder(gpu, args, dataset=None, tokenizer=None):
                 eng.eval_step(dev, use_point, do_clip=args.do_clip)
             ngrad_updates += B          # both partitions, as train_coati.py:279-282
             ng += B
-            sc = eng.scal.double()
-            ar_d = sc[0] / torch.clamp(sc[1], min=1.0)
-            cl_d = 0.5 * (sc[2] + sc[3]) / torch.clamp(sc[4], min=1.0)
-            acc += torch.stack([ar_d + cl_d * teu, torch.ones_like(ar_d), (dev["tokens"] > 0).sum().double()])
+            hist.append(eng.scal[:5].double())
+            acc += (dev["tokens"] > 0).sum().double()
             log_now = (i % int(args.log_batch_loss)) == 0
             if log_now or i % args.log_interval == 0:
                 L = D.global_losses(eng) if world > 1 else eng.losses()
-                toks_now = n_toks + int(acc[2].item())
+                toks_now = n_toks + int(acc[0].item())
                 if rank == 0 and log_now:
                     tags = {"n_toks": toks_now}
                     offline_losses["batch_losses"].append(logger.log_metric(partition + "_batch_loss", L["loss"], epoch, i, tags))
@@ -280,14 +284,20 @@ def train_autoencoder(gpu, args, dataset=None, tokenizer=None):
             if ngrad_updates * world > float(args.ngrad_to_save) and rank == 0:
                 ngrad_updates = 0
                 doc = serialize_model(vars(args), dataset.summary, {k: v.cpu() for k, v in model.state_dict().items()}, model_kwargs,
-                                      optimizer_state(), n_toks_processed=n_toks + int(acc[2].item()), n_grads_processed=ngrad_updates,
+                                      optimizer_state(), n_toks_processed=n_toks + int(acc[0].item()), n_grads_processed=ngrad_updates,
                                       offline_loss=offline_losses)
                 logger.log_pytorch(doc, tags={"train_epoch": str(epoch), "dataset_epoch": str(epoch)})
-        a = acc.cpu()
-        n_toks += int(a[2])
+        n_toks += int(acc.cpu()[0])
         if rank == 0:
             print(f"epoch completed in {ng} grads and {time.time()-t0} seconds")
-        return float(a[0] / a[1]) if a[1] > 0 else None    # mean of the per-batch losses over EVERY batch (train_coati.py:383-396)
+        if not hist:
+            return None
+        H = torch.stack(hist)                       # [batches, 5]
+        if world > 1:                               # every rank ran the same number of batches (all_agree_flags above)
+            H = torch.cat([D.all_reduce_sum(H[:, :4].contiguous()), H[:, 4:]], dim=1)
+        H = H.cpu()
+        per_batch = H[:, 0] / H[:, 1].clamp(min=1.0) + 0.5 * (H[:, 2] + H[:, 3]) / H[:, 4].clamp(min=1.0) * teu
+        return float(per_batch.mean())              # mean of the per-batch losses over EVERY batch (train_coati.py:383-396), identical on every rank
 
     res = {"best_test": 1e10, "best_epoch": 0, "best_model": None}
     for epoch in range(args.n_epochs):

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define COATI_ABI_VERSION 1
+#define COATI_ABI_VERSION 2
 
 const char* coati_last_error(void);
 int coati_abi_version(void);
