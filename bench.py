@@ -53,7 +53,7 @@ def cpu_baseline(batch_cpu, use_point, n_mol, min_seconds=8.0):
     section 2 measured the reference itself on 8 cores) and at torch's default thread count (`value_all_threads`)."""
     from oracle import coati_oracle as O
     cfg = O.OracleConfig(**GRANDE)
-    sub = {k: v[:n_mol].clone() for k, v in batch_cpu.items()}
+    sub = {k: v[:n_mol].clone() for k, v in batch_cpu.items() if k != "rows"}
     up = use_point[:n_mol].clone()
 
     def run(threads, seconds):
@@ -161,6 +161,9 @@ def main():
                     help="grande_closed = the headline workload; coati2_shape = d=512 / head size 32 / 12 layers (bf16, extra)")
     ap.add_argument("--head", choices=["infonce", "barlow"], default="infonce",
                     help="contrastive head: infonce = grande_closed (the headline metric); barlow = barlow_closed (configs[3])")
+    ap.add_argument("--padded", action="store_true",
+                    help="run the transformer passes on the padded [B, T] layout as the reference does; default: packed rows "
+                         "(the rows' real prefixes only -- same losses and gradients, see DESIGN.md section 2a); the line reports both")
     ap.add_argument("--gnn-layers", type=int, default=-1, help="experiment only: override the number of E(3)-GNN layers (the line is then NOT the headline metric)")
     args = ap.parse_args()
 
@@ -223,15 +226,18 @@ def main():
             else:
                 v.zero_()
     eng.refresh_shadows()
-    batch_cpu, up_cpu = make_batch(args.batch, args.seq, args.atoms, MODEL["n_tok"], seed=1234 + rank)
-    batch = {k: v.to(dev) for k, v in batch_cpu.items()}
+    batch_cpu, up_cpu = make_batch(args.batch, args.seq, args.atoms, MODEL["n_tok"], seed=1234 + rank, with_rows=True)
+    batch_padded = {k: v.to(dev) for k, v in batch_cpu.items() if k != "rows"}
+    batch_packed = dict(batch_padded, rows=batch_cpu["rows"])      # the counts stay on the host (the data loader made them there)
+    batch = batch_padded if args.padded else batch_packed
     up = up_cpu.to(dev)
 
-    def step(reduce_grads=True):
+    def step(reduce_grads=True, b=None):
+        b = batch if b is None else b
         if dist_on:
-            D.distributed_train_step(eng, batch, up, lr=5e-4, head=args.head, reduce_grads=reduce_grads)
+            D.distributed_train_step(eng, b, up, lr=5e-4, head=args.head, reduce_grads=reduce_grads)
         else:
-            eng.train_step(batch, up, lr=5e-4, head=args.head)
+            eng.train_step(b, up, lr=5e-4, head=args.head)
 
     def sync():
         if dist_on:
@@ -242,6 +248,12 @@ def main():
         step()
     eng.prof_select(args.roofline_site)
     sync()
+    smi = None
+    if rank == 0:   # one rocm-smi sample taken WHILE the timed steps run (cross-check for a GPU-activity sampler that reads nothing)
+        try:
+            smi = subprocess.Popen(["rocm-smi", "--showuse"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+        except Exception:   # noqa: BLE001
+            smi = None
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -255,6 +267,24 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t)
     losses = D.global_losses(eng) if dist_on else eng.losses()
+    # the other row layout, outside the timed region: the same steps on the padded [B, T] matrices (what the reference
+    # computes) when the line is the packed one, and vice versa -- so that the line carries both numbers
+    other = batch_packed if args.padded else batch_padded
+    k_o = max(3, min(args.steps, 10))
+    for _ in range(2):
+        step(b=other)
+    sync()
+    t_o = time.perf_counter()
+    for _ in range(k_o):
+        step(b=other)
+    sync()
+    dt_other = (time.perf_counter() - t_o) / k_o
+    if dist_on:
+        t = torch.tensor([dt_other], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt_other = float(t)
+    for _ in range(2):
+        step()          # leave the engine in the timed layout (profiling below)
     comm = None
     if dist_on:
         # exposed cost of the gradient all-reduces: the same steps with those four collectives skipped (outside the timed
@@ -302,6 +332,8 @@ def main():
             cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
             with open(cands[-1]) as f:
                 ent = json.load(f).get(args.roofline_site, {})
+            if ent.get("layout", "padded") != ("padded" if args.padded else "packed"):
+                raise OSError("the newest PMC summary was collected on the other row layout")
             traffic = ent.get("hbm_bytes_per_launch")
             traffic_source = f"{os.path.relpath(cands[-1], ROOT)} ({ent.get('command', 'isolated launches, tools/prof_wgrad.py')}); static file, not this run"
         except (OSError, ValueError, IndexError):
@@ -332,7 +364,15 @@ def main():
                                     f"coati2_shape d=512 L=12 nh=16 (head size 32) + E3GNN h=512x5, V=4266 (parity unpinned)") + f", batch {args.batch}/GPU, "
                                    f"seq_len {args.seq}, {args.atoms}-atom point clouds, InfoNCE + AR loss, bf16 MFMA operands / "
                                    f"fp32 accumulate + fp32 master weights, random-init weights",
-                       "global_batch": args.batch * world, "seq_len": args.seq, "parallelism": f"dp{world}"},
+                       "global_batch": args.batch * world, "seq_len": args.seq, "parallelism": f"dp{world}",
+                       "row_layout": "padded [B, T] (as the reference computes)" if args.padded else
+                                     "packed rows: the transformer passes skip the positions behind each row's last token (zero contribution to "
+                                     "both losses and every gradient under causal attention); same losses / gradients as the padded layout "
+                                     "(tests/test_gpu_packed.py); --padded times the padded layout",
+                       "rows_rank0": {"packed": [int(x) for x in batch_cpu["rows"].tolist()],
+                                      "padded": [args.batch * batch_cpu["raw_tokens"].shape[1], args.batch * batch_cpu["tokens"].shape[1]]}},
+            ("packed_rows" if args.padded else "padded_layout"): {"ms_per_step": round(1e3 * dt_other, 3), "value": round(args.batch * world / dt_other, 2),
+                                                                 "steps": k_o, "note": "same workload on the other row layout, timed after the main region"},
             "loss": {k: round(v, 4) for k, v in losses.items() if k in ("ar_loss", "clip_loss", "loss")},
             "roofline": roof,
         }
@@ -346,6 +386,12 @@ def main():
                                 "note": "SURVEY 8(d) formulas per rank (padded positions and all A(A-1) pairs counted), per-rank step time"}
         if comm is not None:
             out["comm"] = comm
+        if smi is not None:
+            try:
+                so, _ = smi.communicate(timeout=30)
+                print("[bench] rocm-smi --showuse sampled during the timed steps: " + " | ".join(l.strip() for l in so.splitlines() if "GPU[" in l), file=sys.stderr)
+            except Exception as ex:   # noqa: BLE001
+                print(f"[bench] rocm-smi sample failed: {ex}", file=sys.stderr)
         if world == 1 and not args.no_cpu_baseline and args.config == "grande_closed":
             out["cpu_baseline"] = cpu_baseline(batch_cpu, up_cpu, args.cpu_mols)
         print(json.dumps(out), flush=True)

@@ -20,15 +20,11 @@ class CoatiConfig(ctypes.Structure):
 
 _SIGS = {
     "coati_gemm_nt": [P, I, L, P, L, I, I, I, P, L, I, P, P, P, L, I, P],
-    "coati_mlp_permute_w1": [P, L, P, L, I, I, P],
-    "coati_mlp_fwd": [P, L, P, P, P, L, P, P, L, P, I, I, I, P, L, P, P, P, P, L, P, L, P],
-    "coati_mlp_fwd_paired": [P, L, P, P, P, L, P, P, L, P, I, I, I, P, L, P, P, P, P, L, P, L, P],
-    "coati_mlp_dgrad": [P, L, P, L, P, L, P, I, I, I, P, L, P, L, P],
     "coati_gemm_ce_partial": [P, L, P, L, I, I, I, P, P],
     "coati_ce_finish": [P, I, P, L, P, L, P, P, P, I, I, I, P],
     "coati_gemm_ce_bwd": [P, L, P, L, I, I, I, P, L, I, P, P, P, P],
     "coati_wgrad": [P, I, L, P, L, I, I, I, P, L, P, I, P],
-    "coati_wgrad_grouped": [I, P, P, P, P, I, P, P, P, P, P, I, P],
+    "coati_wgrad_grouped": [I, P, P, P, P, I, P, P, P, P, P, I, P, L, P],
     "coati_sgemm": [P, L, L, P, L, L, P, L, I, I, I, P, F, I, P],
     "coati_layernorm_fwd": [P, L, P, P, P, L, P, L, P, P, I, I, P],
     "coati_layernorm_bwd": [P, I, L, P, L, I, P, P, P, P, P, P, P, P, P, I, I, P],
@@ -73,7 +69,10 @@ _SIGS = {
     "coati_engine_entry": [P, I, c_char_p, I, POINTER(c_int64), POINTER(c_int32), POINTER(c_int32)],
     "coati_engine_bind": [P, P, P, P, P, P, P, P, P, P],
     "coati_engine_refresh_shadows": [P, P],
-    "coati_engine_forward": [P, P, L, I, I, I, I, P, P, P, P, P, P, P, P, P, P, I, P],
+    "coati_engine_forward": [P, P, L, I, I, I, I, P, P, P, P, P, P, P, P, P, P, I, L, L, P],
+    "coati_seq_pack": [P, P, I, I, I, I, P, P, P, P, P, P],
+    "coati_attn_fwd_varlen": [P, P, P, P, I, I, I, I, P],
+    "coati_attn_bwd_varlen": [P, P, P, P, P, P, P, P, P, I, I, I, I, P],
     "coati_engine_logits": [P, P, L, P],
     "coati_engine_encode": [P, P, L, I, I, I, P, P, P, P, P, P, P],
     "coati_engine_infonce": [P, P, P, P, P, P, I, I, I, F, P, P, P, P],
@@ -126,6 +125,8 @@ def lib():
         getattr(l, name).restype = c_int64
     l.coati_engine_workspace_bytes.argtypes = [P, I, I, I, I, I]
     l.coati_engine_workspace_bytes.restype = c_int64
+    l.coati_wgrad_grouped_workspace_bytes.argtypes = [I, P, P, I]
+    l.coati_wgrad_grouped_workspace_bytes.restype = c_int64
     l.coati_engine_decode_workspace_bytes.argtypes = [P, I, I]
     l.coati_engine_decode_workspace_bytes.restype = c_int64
     l.coati_tokenizer_create.argtypes = [P, P, I, P, P, I, P]
@@ -151,6 +152,7 @@ def exported_symbols():
     return sorted(list(_SIGS) + ["coati_last_error", "coati_abi_version", "coati_engine_destroy",
                                  "coati_engine_param_elems", "coati_engine_shadow_elems",
                                  "coati_engine_workspace_bytes", "coati_engine_decode_workspace_bytes", "coati_engine_n_entries",
+                                 "coati_wgrad_grouped_workspace_bytes",
                                  "coati_tokenizer_create", "coati_tokenizer_destroy", "coati_tokenizer_encode",
                                  "coati_tokenizer_pieces", "coati_tokenizer_encode_batch",
                                  "coati_engine_site_count", "coati_engine_site_name"])

@@ -234,16 +234,32 @@ __device__ __forceinline__ f32x16 score_block(const bf16_t* Xs, int blk, const b
   return s;
 }
 
+// Sequence b of a kernel: rows [row0, row0 + T) of the token-major matrices.  Padded layout: row0 = b * Tl, T = Tl.  Packed rows
+// (seq_off != null, embed.hip launch_seq_pack): row0 = seq_off[b], T = seq_off[b + 1] - seq_off[b] <= Tl; lse / D keep the
+// padded pitch Tl.  The NB > 0 kernels are then launched once per block count: a workgroup whose sequence does not have
+// exactly NB 32-row blocks belongs to another launch and leaves at once (uniform over the workgroup).
+#define ATT_SEQ(NB_)                                                                   \
+  int T = Tl;                                                                          \
+  long long row0 = (long long)b * Tl;                                                  \
+  if (seq_off != nullptr) {                                                            \
+    const int o_ = seq_off[b];                                                         \
+    T = seq_off[b + 1] - o_;                                                           \
+    row0 = o_;                                                                         \
+    if (T <= 0 || ((NB_) > 0 && (T > 32 * (NB_) || T <= 32 * ((NB_) - 1)))) return;    \
+  }
+
 // NB > 0: the sequence fits NB 32-row blocks and every loop bound is a compile-time constant (the staging loads of a
 // workgroup are then issued back to back instead of one load -> store round trip per iteration); NB = 0: any T <= 256.
 template <int HS, int NB>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ y,
-                                                       float* __restrict__ lse, int T, int n_head, int quads) {
+                                                       float* __restrict__ lse, int Tl, int n_head, int quads,
+                                                       const int* __restrict__ seq_off) {
   constexpr int NK = HS / 16, LIVE = HS / 2;
   constexpr float SCALE = att_scale<HS>(), SCALE_LOG2E = att_scale_log2e<HS>();
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int b = blockIdx.x / quads, hq = blockIdx.x - b * quads;
+  ATT_SEQ(NB);
   const int hh = hq * 4 + wave;
   const int heads_here = (n_head - hq * 4) < 4 ? (n_head - hq * 4) : 4;
   const int C = n_head * HS, Tp = NB ? 32 * NB : ((T + 31) & ~31);
@@ -251,9 +267,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
   bf16_t* Ks = reinterpret_cast<bf16_t*>(smem + (size_t)wave * pw);
   bf16_t* Vs = Ks + Tp * HS;
   const long long stride = 3LL * C;
-  const bf16_t* base = qkv + (long long)b * T * stride + hq * 4 * HS;
+  const bf16_t* base = qkv + row0 * stride + hq * 4 * HS;
   const bool active = hh < n_head;   // inactive waves of a partial quad only take part in the barriers
-  const bf16_t* qsrc = qkv + (long long)b * T * stride + (active ? hh : 0) * HS;
+  const bf16_t* qsrc = qkv + row0 * stride + (active ? hh : 0) * HS;
   bf16x8 qnext[NK];   // the Q fragment of the next query block: fetched one block ahead, so only the first one is waited for
   if constexpr (NB > 0) {
     // every load of the prologue is issued before the first LDS write: one memory round trip for K, V and the first Q fragment
@@ -272,7 +288,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
   }
   __syncthreads();
   unsigned char* const otile = smem + 4 * pw;
-  bf16_t* const ydst = y + (long long)b * T * C + hq * 4 * HS;
+  bf16_t* const ydst = y + row0 * C + hq * 4 * HS;
 
   const int nblk = Tp >> 5, half = lane >> 5;
 #pragma unroll
@@ -329,7 +345,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
 #pragma unroll
       for (int r = 0; r < LIVE; ++r) v[r] = o[r] * inv;
       tile_put<HS>(otile, wave, lane, v);
-      if (q < T && half == 0) lse[((long long)b * n_head + hh) * T + q] = m_run * SCALE + __logf(l_run);
+      if (q < T && half == 0) lse[((long long)b * n_head + hh) * Tl + q] = m_run * SCALE + __logf(l_run);
     }
     __syncthreads();
     tile_store<HS>(otile, ydst, C, qb * 32, T, heads_here, threadIdx.x);
@@ -338,8 +354,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
 }
 
 template <int HS, int NB>
-static int launch_attn_fwd_t(const bf16_t* qkv, bf16_t* y, float* lse, int B, int T, int n_head, hipStream_t s) {
-  const int Tp = (T + 31) & ~31;
+static int launch_attn_fwd_t(const bf16_t* qkv, bf16_t* y, float* lse, int B, int T, int n_head, hipStream_t s, const int* seq_off) {
+  const int Tp = NB ? 32 * NB : ((T + 31) & ~31);
   const size_t lds = (size_t)4 * (2 * Tp * HS * 2 + ATT_PW_PAD) + ot_bytes<HS>();
   static bool attr_set = false;
   if (!attr_set) {
@@ -352,21 +368,31 @@ static int launch_attn_fwd_t(const bf16_t* qkv, bf16_t* y, float* lse, int B, in
     attr_set = true;
   }
   const int quads = cdiv(n_head, 4);
-  hipLaunchKernelGGL((attn_fwd_kernel<HS, NB>), dim3(B * quads), dim3(256), lds, s, qkv, y, lse, T, n_head, quads);
+  hipLaunchKernelGGL((attn_fwd_kernel<HS, NB>), dim3(B * quads), dim3(256), lds, s, qkv, y, lse, T, n_head, quads, seq_off);
   COATI_LAUNCH_CHECK("attn_fwd");
   return COATI_OK;
 }
 
-int launch_attn_fwd(const bf16_t* qkv, bf16_t* y, float* lse, int B, int T, int n_head, int head_size, hipStream_t s) {
+int launch_attn_fwd(const bf16_t* qkv, bf16_t* y, float* lse, int B, int T, int n_head, int head_size, hipStream_t s, const int* seq_off) {
   COATI_CHECK_ARG(qkv && y && lse, "attn_fwd: null operand");
   COATI_CHECK_SHAPE(B > 0 && T > 0 && T <= 256 && n_head > 0 && (head_size == 16 || head_size == 32),
                     "attn_fwd: unsupported shape B=%d T=%d nh=%d hs=%d", B, T, n_head, head_size);
   const int nb = (T + 31) / 32;
-#define FWD_CASE(H, N) if (head_size == H && nb == N) return launch_attn_fwd_t<H, N>(qkv, y, lse, B, T, n_head, s);
+  if (seq_off != nullptr && nb <= 4) {
+    // packed rows: one launch per block count 1 .. nb; a workgroup runs in the launch its sequence's length belongs to
+    for (int n = 1; n <= nb; ++n) {
+#define FWD_CASE(H, N) if (head_size == H && n == N) COATI_TRY((launch_attn_fwd_t<H, N>(qkv, y, lse, B, T, n_head, s, seq_off)));
+      FWD_CASE(16, 1) FWD_CASE(16, 2) FWD_CASE(16, 3) FWD_CASE(16, 4)
+      FWD_CASE(32, 1) FWD_CASE(32, 2) FWD_CASE(32, 3) FWD_CASE(32, 4)
+#undef FWD_CASE
+    }
+    return COATI_OK;
+  }
+#define FWD_CASE(H, N) if (head_size == H && nb == N) return launch_attn_fwd_t<H, N>(qkv, y, lse, B, T, n_head, s, seq_off);
   FWD_CASE(16, 1) FWD_CASE(16, 2) FWD_CASE(16, 3) FWD_CASE(16, 4)
   FWD_CASE(32, 1) FWD_CASE(32, 2) FWD_CASE(32, 3) FWD_CASE(32, 4)
 #undef FWD_CASE
-  return head_size == 16 ? launch_attn_fwd_t<16, 0>(qkv, y, lse, B, T, n_head, s) : launch_attn_fwd_t<32, 0>(qkv, y, lse, B, T, n_head, s);
+  return head_size == 16 ? launch_attn_fwd_t<16, 0>(qkv, y, lse, B, T, n_head, s, seq_off) : launch_attn_fwd_t<32, 0>(qkv, y, lse, B, T, n_head, s, seq_off);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -379,12 +405,13 @@ __global__ __launch_bounds__(256, HS == 16 ? 4 : 2) void attn_bwd_dq_kernel(cons
                                                           const bf16_t* __restrict__ dy, const float* __restrict__ lse,
                                                           float* __restrict__ Dout, bf16_t* __restrict__ dqkv,
                                                           const float* __restrict__ cos_t, const float* __restrict__ sin_t,
-                                                          int T, int n_head, int quads) {
+                                                          int Tl, int n_head, int quads, const int* __restrict__ seq_off) {
   constexpr int NK = HS / 16, LIVE = HS / 2;
   constexpr float SCALE = att_scale<HS>(), SCALE_LOG2E = att_scale_log2e<HS>();
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int b = blockIdx.x / quads, hq = blockIdx.x - b * quads;
+  ATT_SEQ(0);
   const int hh = hq * 4 + wave;
   const int heads_here = (n_head - hq * 4) < 4 ? (n_head - hq * 4) : 4;
   const int C = n_head * HS, Tp = (T + 31) & ~31;
@@ -392,20 +419,20 @@ __global__ __launch_bounds__(256, HS == 16 ? 4 : 2) void attn_bwd_dq_kernel(cons
   bf16_t* Ks = reinterpret_cast<bf16_t*>(smem + (size_t)wave * pw);
   bf16_t* Vs = Ks + Tp * HS;
   const long long stride = 3LL * C;
-  const bf16_t* qbase = qkv + (long long)b * T * stride + hq * 4 * HS;
+  const bf16_t* qbase = qkv + row0 * stride + hq * 4 * HS;
   stage4<HS>(qbase + C, stride, T, Tp, smem, pw, 0, heads_here, threadIdx.x);
   stage4<HS>(qbase + 2 * C, stride, T, Tp, smem, pw, 1, heads_here, threadIdx.x);
   __syncthreads();
   const bool active = hh < n_head;
   const int hc = active ? hh : 0;
   unsigned char* const otile = smem + 4 * pw;
-  const bf16_t* ybase = y + (long long)b * T * C + hc * HS;
-  const bf16_t* qsrc = qkv + (long long)b * T * stride + hc * HS;
-  const bf16_t* gsrc = dy + (long long)b * T * C + hc * HS;
-  const long long sbase = ((long long)b * n_head + hc) * T;
+  const bf16_t* ybase = y + row0 * C + hc * HS;
+  const bf16_t* qsrc = qkv + row0 * stride + hc * HS;
+  const bf16_t* gsrc = dy + row0 * C + hc * HS;
+  const long long sbase = ((long long)b * n_head + hc) * Tl;
 
   const int nblk = Tp >> 5, half = lane >> 5;
-  bf16_t* const dbase = dqkv + (long long)b * T * stride + hq * 4 * HS;
+  bf16_t* const dbase = dqkv + row0 * stride + hq * 4 * HS;
   for (int qb = 0; qb < nblk; ++qb) {
     const int q = qb * 32 + (lane & 31);
     if (active) {
@@ -459,12 +486,14 @@ template <int HS>
 __global__ __launch_bounds__(256, HS == 16 ? 3 : 2) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dy,
                                                            const float* __restrict__ lse, const float* __restrict__ Din,
                                                            bf16_t* __restrict__ dqkv, const float* __restrict__ cos_t,
-                                                           const float* __restrict__ sin_t, int T, int n_head, int quads) {
+                                                           const float* __restrict__ sin_t, int Tl, int n_head, int quads,
+                                                           const int* __restrict__ seq_off) {
   constexpr int NK = HS / 16, LIVE = HS / 2;
   constexpr float SCALE = att_scale<HS>(), SCALE_LOG2E = att_scale_log2e<HS>();
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int b = blockIdx.x / quads, hq = blockIdx.x - b * quads;
+  ATT_SEQ(0);
   const int hh = hq * 4 + wave;
   const int heads_here = (n_head - hq * 4) < 4 ? (n_head - hq * 4) : 4;
   const int C = n_head * HS, Tp = (T + 31) & ~31;
@@ -475,16 +504,16 @@ __global__ __launch_bounds__(256, HS == 16 ? 3 : 2) void attn_bwd_dkv_kernel(con
   float* Ls = reinterpret_cast<float*>(Gs + Tp * HS);
   float* Ds = Ls + Tp;
   const long long stride = 3LL * C;
-  const bf16_t* qbase = qkv + (long long)b * T * stride + hq * 4 * HS;
+  const bf16_t* qbase = qkv + row0 * stride + hq * 4 * HS;
   stage4<HS>(qbase, stride, T, Tp, smem, pw, 0, heads_here, threadIdx.x);
-  stage4<HS>(dy + (long long)b * T * C + hq * 4 * HS, (long long)C, T, Tp, smem, pw, 1, heads_here, threadIdx.x);
+  stage4<HS>(dy + row0 * C + hq * 4 * HS, (long long)C, T, Tp, smem, pw, 1, heads_here, threadIdx.x);
   __syncthreads();
   const bool active = hh < n_head;
   const int hc = active ? hh : 0;
   unsigned char* const otile = smem + 4 * pw;   // two tiles: dK, dV
-  const bf16_t* ksrc = qkv + (long long)b * T * stride + C + hc * HS;
+  const bf16_t* ksrc = qkv + row0 * stride + C + hc * HS;
   for (int t = lane; t < Tp; t += 64) {
-    const long long o = ((long long)b * n_head + hc) * T + t;
+    const long long o = ((long long)b * n_head + hc) * Tl + t;
     Ls[t] = (t < T) ? lse[o] : INFINITY;
     Ds[t] = (t < T) ? Din[o] : 0.f;
   }
@@ -492,7 +521,7 @@ __global__ __launch_bounds__(256, HS == 16 ? 3 : 2) void attn_bwd_dkv_kernel(con
   __builtin_amdgcn_wave_barrier();
 
   const int nblk = Tp >> 5, half = lane >> 5;
-  bf16_t* const dbase = dqkv + (long long)b * T * stride + hq * 4 * HS;
+  bf16_t* const dbase = dqkv + row0 * stride + hq * 4 * HS;
   for (int kb = 0; kb < nblk; ++kb) {
     const int key = kb * 32 + (lane & 31);
     if (active) {
@@ -558,12 +587,14 @@ template <int HS, int NB>
 __global__ __launch_bounds__(256, (HS == 16 && NB <= 3) ? 3 : 2) void attn_bwd_fused_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ y,
                                                              const bf16_t* __restrict__ dy, const float* __restrict__ lse,
                                                              bf16_t* __restrict__ dqkv, const float* __restrict__ cos_t,
-                                                             const float* __restrict__ sin_t, int T, int n_head, int quads) {
+                                                             const float* __restrict__ sin_t, int Tl, int n_head, int quads,
+                                                             const int* __restrict__ seq_off) {
   constexpr int NK = HS / 16, LIVE = HS / 2, Tp = 32 * NB;
   constexpr float SCALE = att_scale<HS>(), SCALE_LOG2E = att_scale_log2e<HS>();
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int b = blockIdx.x / quads, hq = blockIdx.x - b * quads;
+  ATT_SEQ(NB);
   const int hh = hq * 4 + wave;
   const int heads_here = (n_head - hq * 4) < 4 ? (n_head - hq * 4) : 4;
   const int C = n_head * HS;
@@ -575,23 +606,23 @@ __global__ __launch_bounds__(256, (HS == 16 && NB <= 3) ? 3 : 2) void attn_bwd_f
   float* Ls = reinterpret_cast<float*>(Gs + Tp * HS);
   float* Ds = Ls + Tp;
   const long long stride = 3LL * C;
-  const bf16_t* qbase = qkv + (long long)b * T * stride + hq * 4 * HS;
+  const bf16_t* qbase = qkv + row0 * stride + hq * 4 * HS;
   const bool active = hh < n_head;
   const int hc = active ? hh : 0;
-  const bf16_t* vsrc = qkv + (long long)b * T * stride + 2 * C + hc * HS;
+  const bf16_t* vsrc = qkv + row0 * stride + 2 * C + hc * HS;
   // Every global load of the prologue is issued before the first LDS write: the four staged operands (Q, K, dO, O), this
   // head's log-sum-exp rows and the V fragment of key block 0 cost ONE memory round trip instead of one per staging task
   // (SQ counters of the looped version: 75 % of the wave cycles parked in s_waitcnt).
   Stage4Regs<HS, Tp> rq, rk, rg, ro;
   stage4_load<HS, Tp>(rq, qbase, stride, T, heads_here, threadIdx.x);
   stage4_load<HS, Tp>(rk, qbase + C, stride, T, heads_here, threadIdx.x);
-  stage4_load<HS, Tp>(rg, dy + (long long)b * T * C + hq * 4 * HS, C, T, heads_here, threadIdx.x);
-  stage4_load<HS, Tp>(ro, y + (long long)b * T * C + hq * 4 * HS, C, T, heads_here, threadIdx.x);
+  stage4_load<HS, Tp>(rg, dy + row0 * C + hq * 4 * HS, C, T, heads_here, threadIdx.x);
+  stage4_load<HS, Tp>(ro, y + row0 * C + hq * 4 * HS, C, T, heads_here, threadIdx.x);
   float lrow[(Tp + 63) / 64];
 #pragma unroll
   for (int i = 0; i < (Tp + 63) / 64; ++i) {
     const int t = lane + 64 * i;
-    lrow[i] = lse[((long long)b * n_head + hc) * T + (t < T ? t : T - 1)];
+    lrow[i] = lse[((long long)b * n_head + hc) * Tl + (t < T ? t : T - 1)];
   }
   bf16x8 vnext[NK];
 #pragma unroll
@@ -632,7 +663,7 @@ __global__ __launch_bounds__(256, (HS == 16 && NB <= 3) ? 3 : 2) void attn_bwd_f
 
   const int half = lane >> 5;
   const bool tail16 = T - (NB - 1) * 32 <= 16;
-  bf16_t* const dbase = dqkv + (long long)b * T * stride + hq * 4 * HS;
+  bf16_t* const dbase = dqkv + row0 * stride + hq * 4 * HS;
   f32x16 dq[NB];
 #pragma unroll
   for (int i = 0; i < NB; ++i) dq[i] = zero16();
@@ -725,7 +756,7 @@ __global__ __launch_bounds__(256, (HS == 16 && NB <= 3) ? 3 : 2) void attn_bwd_f
 
 template <int HS, int NB>
 static int launch_attn_bwd_fused_t(const bf16_t* qkv, const bf16_t* y, const bf16_t* dy, const float* lse, bf16_t* dqkv,
-                                   const float* cos_t, const float* sin_t, int B, int T, int n_head, hipStream_t s) {
+                                   const float* cos_t, const float* sin_t, int B, int T, int n_head, hipStream_t s, const int* seq_off) {
   constexpr int Tp = 32 * NB;
   const size_t lds = (size_t)4 * ((size_t)3 * Tp * HS * 2 + (size_t)2 * Tp * 4 + ATT_PW_PAD) + 2 * ot_bytes<HS>();
   static bool attr_set = false;
@@ -740,14 +771,14 @@ static int launch_attn_bwd_fused_t(const bf16_t* qkv, const bf16_t* y, const bf1
   }
   const int quads = cdiv(n_head, 4);
   hipLaunchKernelGGL((attn_bwd_fused_kernel<HS, NB>), dim3(B * quads), dim3(256), lds, s, qkv, y, dy, lse, dqkv, cos_t, sin_t, T,
-                     n_head, quads);
+                     n_head, quads, seq_off);
   COATI_LAUNCH_CHECK("attn_bwd_fused");
   return COATI_OK;
 }
 
 template <int HS>
 static int launch_attn_bwd_t(const bf16_t* qkv, const bf16_t* y, const bf16_t* dy, const float* lse, float* dscratch,
-                             bf16_t* dqkv, const float* cos_t, const float* sin_t, int B, int T, int n_head, hipStream_t s) {
+                             bf16_t* dqkv, const float* cos_t, const float* sin_t, int B, int T, int n_head, hipStream_t s, const int* seq_off) {
   const int Tp = (T + 31) & ~31;
   const size_t lds_dq = (size_t)4 * (2 * Tp * HS * 2 + ATT_PW_PAD) + ot_bytes<HS>();
   const size_t lds_dkv = (size_t)4 * (2 * Tp * HS * 2 + 2 * Tp * 4 + ATT_PW_PAD) + 2 * ot_bytes<HS>();
@@ -765,16 +796,17 @@ static int launch_attn_bwd_t(const bf16_t* qkv, const bf16_t* y, const bf16_t* d
   }
   const int quads = cdiv(n_head, 4);
   hipLaunchKernelGGL(attn_bwd_dq_kernel<HS>, dim3(B * quads), dim3(256), lds_dq, s, qkv, y, dy, lse, dscratch, dqkv, cos_t,
-                     sin_t, T, n_head, quads);
+                     sin_t, T, n_head, quads, seq_off);
   COATI_LAUNCH_CHECK("attn_bwd_dq");
   hipLaunchKernelGGL(attn_bwd_dkv_kernel<HS>, dim3(B * quads), dim3(256), lds_dkv, s, qkv, dy, lse, dscratch, dqkv, cos_t,
-                     sin_t, T, n_head, quads);
+                     sin_t, T, n_head, quads, seq_off);
   COATI_LAUNCH_CHECK("attn_bwd_dkv");
   return COATI_OK;
 }
 
 int launch_attn_bwd(const bf16_t* qkv, const bf16_t* y, const bf16_t* dy, const float* lse, float* dscratch,
-                    bf16_t* dqkv, const float* cos_t, const float* sin_t, int B, int T, int n_head, int head_size, hipStream_t s) {
+                    bf16_t* dqkv, const float* cos_t, const float* sin_t, int B, int T, int n_head, int head_size, hipStream_t s,
+                    const int* seq_off) {
   COATI_CHECK_ARG(qkv && y && dy && lse && dscratch && dqkv && cos_t && sin_t, "attn_bwd: null operand");
   COATI_CHECK_SHAPE(B > 0 && T > 0 && T <= 256 && n_head > 0 && (head_size == 16 || head_size == 32),
                     "attn_bwd: unsupported shape B=%d T=%d nh=%d hs=%d", B, T, n_head, head_size);
@@ -783,11 +815,21 @@ int launch_attn_bwd(const bf16_t* qkv, const bf16_t* y, const bf16_t* dy, const 
   static const bool fused = getenv("COATI_ATTN_FUSED_BWD") == nullptr || atoi(getenv("COATI_ATTN_FUSED_BWD")) != 0;
   if (fused && T <= 128) {
     const int nb = (T + 31) / 32;
-#define FUSED_CASE(H, N) if (head_size == H && nb == N) return launch_attn_bwd_fused_t<H, N>(qkv, y, dy, lse, dqkv, cos_t, sin_t, B, T, n_head, s);
+    if (seq_off != nullptr) {
+      // packed rows: one launch per block count 1 .. nb (see ATT_SEQ)
+      for (int n = 1; n <= nb; ++n) {
+#define FUSED_CASE(H, N) if (head_size == H && n == N) COATI_TRY((launch_attn_bwd_fused_t<H, N>(qkv, y, dy, lse, dqkv, cos_t, sin_t, B, T, n_head, s, seq_off)));
+        FUSED_CASE(16, 1) FUSED_CASE(16, 2) FUSED_CASE(16, 3) FUSED_CASE(16, 4)
+        FUSED_CASE(32, 1) FUSED_CASE(32, 2) FUSED_CASE(32, 3) FUSED_CASE(32, 4)
+#undef FUSED_CASE
+      }
+      return COATI_OK;
+    }
+#define FUSED_CASE(H, N) if (head_size == H && nb == N) return launch_attn_bwd_fused_t<H, N>(qkv, y, dy, lse, dqkv, cos_t, sin_t, B, T, n_head, s, seq_off);
     FUSED_CASE(16, 1) FUSED_CASE(16, 2) FUSED_CASE(16, 3) FUSED_CASE(16, 4)
     FUSED_CASE(32, 1) FUSED_CASE(32, 2) FUSED_CASE(32, 3) FUSED_CASE(32, 4)
 #undef FUSED_CASE
   }
-  return head_size == 16 ? launch_attn_bwd_t<16>(qkv, y, dy, lse, dscratch, dqkv, cos_t, sin_t, B, T, n_head, s)
-                         : launch_attn_bwd_t<32>(qkv, y, dy, lse, dscratch, dqkv, cos_t, sin_t, B, T, n_head, s);
+  return head_size == 16 ? launch_attn_bwd_t<16>(qkv, y, dy, lse, dscratch, dqkv, cos_t, sin_t, B, T, n_head, s, seq_off)
+                         : launch_attn_bwd_t<32>(qkv, y, dy, lse, dscratch, dqkv, cos_t, sin_t, B, T, n_head, s, seq_off);
 }

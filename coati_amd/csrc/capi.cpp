@@ -21,45 +21,6 @@ int coati_gemm_nt(const void* A, int a_f32, int64_t lda, const uint16_t* B, int6
   return launch_gemm_nt(a, a_f32, epi, S_(stream));
 }
 
-int coati_mlp_permute_w1(const uint16_t* W1, int64_t ldw, uint16_t* W1p, int64_t ldp, int Hd, int C, void* stream) {
-  return launch_mlp_permute_w1(W1, ldw, W1p, ldp, Hd, C, S_(stream));
-}
-
-int coati_mlp_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, const uint16_t* W1p, int64_t ldw1,
-                  const float* b1, const uint16_t* W2, int64_t ldw2, const float* b2, int M, int C, int Hd, uint16_t* a,
-                  int64_t lda, float* mean, float* rstd, uint16_t* g, uint8_t* dg, int64_t ldh, float* out, int64_t ldo,
-                  void* stream) {
-  const uint16_t* W1 = W1p;
-  MlpArgs m;
-  memset(&m, 0, sizeof(m));
-  m.M = M; m.C = C; m.Hd = Hd; m.x = x; m.ldx = ldx; m.gamma = gamma; m.beta = beta; m.mean = mean; m.rstd = rstd;
-  m.a = a; m.lda = lda; m.W1 = W1; m.ldw1 = ldw1; m.b1 = b1; m.W2 = W2; m.ldw2 = ldw2; m.b2 = b2; m.h = g; m.d = dg;
-  m.ldh = ldh; m.out = out; m.ldo = ldo;
-  return launch_mlp_fwd(m, S_(stream));
-}
-
-int coati_mlp_fwd_paired(const float* x, int64_t ldx, const float* gamma, const float* beta, const uint16_t* W1, int64_t ldw1,
-                         const float* b1, const uint16_t* W2, int64_t ldw2, const float* b2, int M, int C, int Hd, uint16_t* a,
-                         int64_t lda, float* mean, float* rstd, uint16_t* g, uint8_t* dg, int64_t ldh, float* out, int64_t ldo,
-                         void* stream) {
-  MlpArgs m;
-  memset(&m, 0, sizeof(m));
-  m.M = M; m.C = C; m.Hd = Hd; m.x = x; m.ldx = ldx; m.gamma = gamma; m.beta = beta; m.mean = mean; m.rstd = rstd;
-  m.a = a; m.lda = lda; m.W1 = W1; m.ldw1 = ldw1; m.b1 = b1; m.W2 = W2; m.ldw2 = ldw2; m.b2 = b2; m.h = g; m.d = dg;
-  m.ldh = ldh; m.out = out; m.ldo = ldo;
-  return launch_mlp_pair_fwd(m, S_(stream));
-}
-
-int coati_mlp_dgrad(const uint16_t* dY, int64_t lddy, const uint16_t* W2T, int64_t ldw2t, const uint16_t* W1T,
-                    int64_t ldw1t, const uint8_t* dgelu, int M, int C, int Hd, uint16_t* dh, int64_t ldh,
-                    uint16_t* dA, int64_t ldda, void* stream) {
-  MlpArgs m;
-  memset(&m, 0, sizeof(m));
-  m.M = M; m.C = C; m.Hd = Hd; m.a = const_cast<uint16_t*>(dY); m.lda = lddy; m.W1 = W2T; m.ldw1 = ldw2t; m.W2 = W1T;
-  m.ldw2 = ldw1t; m.aux = dgelu; m.h = dh; m.ldh = ldh; m.out = dA; m.ldo = ldda;
-  return launch_mlp_bwd(m, S_(stream));
-}
-
 int coati_gemm_ce_partial(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw, int M, int V, int K,
                           void* partial, void* stream) {
   GemmArgs a;
@@ -90,51 +51,32 @@ int coati_wgrad(const void* A, int a_f32, int64_t lda, const uint16_t* B, int64_
   return launch_wgrad(a, a_f32, S_(stream));
 }
 
-int coati_wgrad_grouped(int n_problems, const uint16_t* const* A, const int64_t* lda, const uint16_t* const* B, const int64_t* ldb, int M,
-                        const int* N, const int* K, float* const* dW, const int64_t* ldw, float* const* dbias, int tile_size, void* stream) {
-  COATI_CHECK_ARG(n_problems > 0 && A && lda && B && ldb && N && K && dW && ldw && dbias, "wgrad_grouped: null argument");
-  const bool want_split = tile_size == -256;   // -256: 256-wide tiles in the split form (192 tiles on 256 workgroups, ordered commits)
-  if (want_split) tile_size = 256;
+int64_t coati_wgrad_grouped_workspace_bytes(int n_problems, const int* N, const int* K, int tile_size) {
+  if (n_problems <= 0 || !N || !K || (tile_size != 128 && tile_size != 256)) return 0;
+  int64_t tiles = 0;
+  for (int i = 0; i < n_problems; ++i) tiles += (int64_t)cdiv(N[i], tile_size) * cdiv(K[i], tile_size);
+  return tiles * (int64_t)sizeof(WgradTile);
+}
+
+int coati_wgrad_grouped(int n_problems, const uint16_t* const* A, const int64_t* lda, const uint16_t* const* B, const int64_t* ldb,
+                        int M, const int* N, const int* K, float* const* dW, const int64_t* ldw, float* const* dbias, int tile_size,
+                        void* workspace, int64_t workspace_bytes, void* stream) {
+  COATI_CHECK_ARG(n_problems > 0 && A && lda && B && ldb && N && K && dW && ldw && dbias && workspace, "wgrad_grouped: null argument");
   std::vector<WgradTile> tab;
   for (int i = 0; i < n_problems; ++i) {
     WgradArgs a;
     a.A = A[i]; a.lda = lda[i]; a.B = B[i]; a.ldb = ldb[i]; a.M = M; a.N = N[i]; a.K = K[i]; a.dW = dW[i]; a.ldw = ldw[i]; a.dbias = dbias[i]; a.n_out = 0;
-    COATI_TRY(wgrad_table_append(tab, a, nullptr, tile_size));
+    COATI_TRY(wgrad_table_append(tab, a, tile_size));
   }
-  // stand-alone entry point (tests, micro-benchmarks): the table is uploaded per call; the engine keeps its tables resident
-  WgradTile* d = nullptr;
-  int* tickets = nullptr;
+  COATI_CHECK_ARG((int64_t)(tab.size() * sizeof(WgradTile)) <= workspace_bytes, "wgrad_grouped: workspace too small (%zu tiles)", tab.size());
   hipStream_t s = S_(stream);
-  // tile_size 256 with 192 tiles (16 transformer layers): the split form (all 256 CUs, ordered commits), as in the engine
-  const int n_tiles = (int)tab.size();
-  const bool split = want_split && n_tiles == 192;
-  if (split) {
-    if (hipMalloc(&tickets, n_tiles * sizeof(int)) != hipSuccess || hipMemsetAsync(tickets, 0, n_tiles * sizeof(int), s) != hipSuccess) {
-      coati_set_error("wgrad_grouped: ticket allocation failed");
-      return COATI_EHIP;
-    }
-    std::vector<WgradTile> segs;
-    int rcs = wgrad_table_split256(tab, 256, tickets, segs);
-    if (rcs != COATI_OK) { hipFree(tickets); return rcs; }
-    tab.swap(segs);
-  }
-  if (hipMalloc(&d, tab.size() * sizeof(WgradTile)) != hipSuccess) {
-    coati_set_error("wgrad_grouped: table allocation failed");
+  // the tile table goes into the CALLER's device workspace (the library allocates nothing); pageable source: the runtime
+  // stages the copy before hipMemcpyAsync returns, so `tab` may go out of scope; the launch is ordered behind it on `s`
+  if (hipMemcpyAsync(workspace, tab.data(), tab.size() * sizeof(WgradTile), hipMemcpyHostToDevice, s) != hipSuccess) {
+    coati_set_error("wgrad_grouped: table upload failed");
     return COATI_EHIP;
   }
-  int rc = COATI_OK;
-  if (hipMemcpyAsync(d, tab.data(), tab.size() * sizeof(WgradTile), hipMemcpyHostToDevice, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
-    coati_set_error("wgrad_grouped: table upload failed");
-    rc = COATI_EHIP;
-  }
-  if (rc == COATI_OK) rc = split ? launch_wgrad_table_split256(d, 256, s) : launch_wgrad_table(d, (int)tab.size(), s, tile_size);
-  if (hipStreamSynchronize(s) != hipSuccess && rc == COATI_OK) {
-    coati_set_error("wgrad_grouped: kernel failed");
-    rc = COATI_EHIP;
-  }
-  hipFree(d);
-  if (tickets) hipFree(tickets);
-  return rc;
+  return launch_wgrad_table(reinterpret_cast<const WgradTile*>(workspace), (int)tab.size(), s, tile_size);
 }
 
 int coati_sgemm(const float* A, int64_t ars, int64_t acs, const float* B, int64_t brs, int64_t bcs, float* C,
@@ -157,6 +99,21 @@ int coati_attn_fwd(const uint16_t* qkv, uint16_t* y, float* lse, int B, int T, i
 }
 int coati_attn_fwd_hs(const uint16_t* qkv, uint16_t* y, float* lse, int B, int T, int n_head, int head_size, void* stream) {
   return launch_attn_fwd(qkv, y, lse, B, T, n_head, head_size, S_(stream));
+}
+int coati_seq_pack(const int64_t* tok, const int64_t* y, int pad_token, int B, int T, int rows_expect, int32_t* off,
+                   int32_t* row_src, int32_t* row_t, int64_t* ypk, int32_t* err, void* stream) {
+  return launch_seq_pack(LL(tok), LL(y), pad_token, B, T, rows_expect, off, row_src, row_t, reinterpret_cast<long long*>(ypk), err, S_(stream));
+}
+int coati_attn_fwd_varlen(const uint16_t* qkv, uint16_t* y, float* lse, const int32_t* seq_off, int B, int T, int n_head,
+                          int head_size, void* stream) {
+  COATI_CHECK_ARG(seq_off, "attn_fwd_varlen: null seq_off");
+  return launch_attn_fwd(qkv, y, lse, B, T, n_head, head_size, S_(stream), seq_off);
+}
+int coati_attn_bwd_varlen(const uint16_t* qkv, const uint16_t* y, const uint16_t* dy, const float* lse, float* dscratch,
+                          uint16_t* dqkv, const float* cos_t, const float* sin_t, const int32_t* seq_off, int B, int T,
+                          int n_head, int head_size, void* stream) {
+  COATI_CHECK_ARG(seq_off, "attn_bwd_varlen: null seq_off");
+  return launch_attn_bwd(qkv, y, dy, lse, dscratch, dqkv, cos_t, sin_t, B, T, n_head, head_size, S_(stream), seq_off);
 }
 int coati_gemm_qkv_rope(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw, const float* bias, int M, int C,
                         uint16_t* qkv, int64_t ldc, const float* cos_t, const float* sin_t, int T, void* stream) {

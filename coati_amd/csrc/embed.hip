@@ -9,14 +9,15 @@
 
 __global__ __launch_bounds__(256) void embed_fwd_kernel(const long long* __restrict__ idx, const float* __restrict__ table,
                                                         const float* __restrict__ injection, int unk, float* __restrict__ x,
-                                                        int M, int T, int C, int V) {
+                                                        int M, int T, int C, int V, const int* __restrict__ row_src) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int m = blockIdx.x * 4 + wave;
   if (m >= M) return;
-  long long tok = idx[m];
+  const int ms = row_src ? row_src[m] : m;   // packed rows: output row m is slot ms = b * T + t of the padded [B, T] token matrix
+  long long tok = idx[ms];
   const float* src;
   if (injection != nullptr && tok == unk) {
-    src = injection + (long long)(m / T) * C;
+    src = injection + (long long)(ms / T) * C;
   } else {
     if (tok < 0) tok = 0;
     if (tok >= V) tok = V - 1;
@@ -27,11 +28,11 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const long long* __restr
 }
 
 int launch_embed_fwd(const long long* idx, const float* table, const float* injection, int unk_token, float* x,
-                     int B, int T, int C, int V, hipStream_t s) {
+                     int B, int T, int C, int V, hipStream_t s, const int* row_src, int rows) {
   COATI_CHECK_ARG(idx && table && x, "embed_fwd: null operand");
   COATI_CHECK_SHAPE(B > 0 && T > 0 && C % 4 == 0 && V > 0, "embed_fwd: unsupported shape");
-  const int M = B * T;
-  hipLaunchKernelGGL(embed_fwd_kernel, dim3(cdiv(M, 4)), dim3(256), 0, s, idx, table, injection, unk_token, x, M, T, C, V);
+  const int M = row_src ? rows : B * T;
+  hipLaunchKernelGGL(embed_fwd_kernel, dim3(cdiv(M, 4)), dim3(256), 0, s, idx, table, injection, unk_token, x, M, T, C, V, row_src);
   COATI_LAUNCH_CHECK("embed_fwd");
   return COATI_OK;
 }
@@ -43,7 +44,7 @@ int launch_embed_fwd(const long long* idx, const float* table, const float* inje
 #define EMB_RUN 32
 __global__ __launch_bounds__(256) void embed_bwd_kernel(const long long* __restrict__ idx, const float* __restrict__ dx,
                                                         float* __restrict__ dtable, float* __restrict__ dinj, int unk,
-                                                        int B, int T, int C, int V) {
+                                                        int B, int T, int C, int V, const int* __restrict__ off) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int t = blockIdx.x;
   const int b0 = (blockIdx.y * 4 + wave) * EMB_RUN;
@@ -65,8 +66,13 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const long long* __restr
       }
     };
     for (int b = b0; b < b1; ++b) {
-      const long long m = (long long)b * T + t;
+      long long m = (long long)b * T + t;
       long long tok = idx[m];
+      if (off != nullptr) {   // packed rows: molecule b owns rows off[b] .. off[b + 1]; positions behind its last token do not exist
+        const int o = off[b];
+        if (t >= off[b + 1] - o) continue;
+        m = o + t;
+      }
       float* dst;
       if (dinj != nullptr && tok == unk) {
         dst = dinj + (long long)b * C;
@@ -96,10 +102,10 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const long long* __restr
 }
 
 int launch_embed_bwd(const long long* idx, const float* dx, float* dtable, float* dinjection, int unk_token,
-                     int B, int T, int C, int V, hipStream_t s) {
+                     int B, int T, int C, int V, hipStream_t s, const int* off) {
   COATI_CHECK_ARG(idx && dx && dtable, "embed_bwd: null operand");
   COATI_CHECK_SHAPE(B > 0 && T > 0 && C % 4 == 0 && V > 0, "embed_bwd: unsupported shape");
-  hipLaunchKernelGGL(embed_bwd_kernel, dim3(T, cdiv(B, 4 * EMB_RUN)), dim3(256), 0, s, idx, dx, dtable, dinjection, unk_token, B, T, C, V);
+  hipLaunchKernelGGL(embed_bwd_kernel, dim3(T, cdiv(B, 4 * EMB_RUN)), dim3(256), 0, s, idx, dx, dtable, dinjection, unk_token, B, T, C, V, off);
   COATI_LAUNCH_CHECK("embed_bwd");
   return COATI_OK;
 }
@@ -123,25 +129,25 @@ int launch_find_stop(const long long* idx, int stop_token, int* pos, int* err, i
 }
 
 __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ x, const int* __restrict__ pos,
-                                                          float* __restrict__ out, int B, int T, int C) {
+                                                          float* __restrict__ out, int B, int T, int C, const int* __restrict__ off) {
   const int lane = threadIdx.x & 63, b = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (b >= B) return;
-  const float* src = x + ((long long)b * T + pos[b]) * C;
+  const float* src = x + ((off ? (long long)off[b] : (long long)b * T) + pos[b]) * C;
   for (int c = lane * 4; c < C; c += 256) *reinterpret_cast<float4*>(out + (long long)b * C + c) = *reinterpret_cast<const float4*>(src + c);
 }
 
-int launch_gather_rows(const float* x, const int* pos, float* out, int B, int T, int C, hipStream_t s) {
+int launch_gather_rows(const float* x, const int* pos, float* out, int B, int T, int C, hipStream_t s, const int* off) {
   COATI_CHECK_ARG(x && pos && out, "gather_rows: null operand");
-  hipLaunchKernelGGL(gather_rows_kernel, dim3(cdiv(B, 4)), dim3(256), 0, s, x, pos, out, B, T, C);
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(cdiv(B, 4)), dim3(256), 0, s, x, pos, out, B, T, C, off);
   COATI_LAUNCH_CHECK("gather_rows");
   return COATI_OK;
 }
 
 __global__ __launch_bounds__(256) void scatter_rows_add_kernel(const float* __restrict__ dout, const int* __restrict__ pos,
-                                                               float* __restrict__ dx, int B, int T, int C) {
+                                                               float* __restrict__ dx, int B, int T, int C, const int* __restrict__ off) {
   const int lane = threadIdx.x & 63, b = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (b >= B) return;
-  float* dst = dx + ((long long)b * T + pos[b]) * C;
+  float* dst = dx + ((off ? (long long)off[b] : (long long)b * T) + pos[b]) * C;
   for (int c = lane * 4; c < C; c += 256) {
     float4 d = *reinterpret_cast<float4*>(dst + c);
     const float4 g = *reinterpret_cast<const float4*>(dout + (long long)b * C + c);
@@ -150,10 +156,86 @@ __global__ __launch_bounds__(256) void scatter_rows_add_kernel(const float* __re
   }
 }
 
-int launch_scatter_rows_add(const float* dout, const int* pos, float* dx, int B, int T, int C, hipStream_t s) {
+int launch_scatter_rows_add(const float* dout, const int* pos, float* dx, int B, int T, int C, hipStream_t s, const int* off) {
   COATI_CHECK_ARG(dout && pos && dx, "scatter_rows_add: null operand");
-  hipLaunchKernelGGL(scatter_rows_add_kernel, dim3(cdiv(B, 4)), dim3(256), 0, s, dout, pos, dx, B, T, C);
+  hipLaunchKernelGGL(scatter_rows_add_kernel, dim3(cdiv(B, 4)), dim3(256), 0, s, dout, pos, dx, B, T, C, off);
   COATI_LAUNCH_CHECK("scatter_rows_add");
+  return COATI_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Packed rows ("ragged" batches).  clip_ar_xform pads every row of a batch to the longest one (clip_e2e.py:288-330), and the
+// reference computes the padding: under causal attention a position behind a row's last token influences no earlier
+// position, its targets are -1 (ignored by the AR loss, train_coati.py:260-265) and the encoder reads the [STOP] position
+// only (smiles_xformer.py:50-68) -- so those positions contribute EXACTLY zero to both losses and to every gradient.  The
+// engine therefore runs the transformer passes on the concatenation of the rows' real prefixes:
+//   len[b]     = 1 + last position whose token is not [PAD] or whose target is not -1
+//   off[b]     = exclusive prefix sum, off[B] = number of packed rows (must equal the count the caller computed on the host)
+//   row_src[m] = b * T + t : slot of packed row m in the padded [B, T] matrices;  row_t[m] = t (rotary position)
+//   ypk[m]     = y_next[b, t]
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void seq_len_kernel(const long long* __restrict__ tok, const long long* __restrict__ y, int pad,
+                                                      int* __restrict__ len, int B, int T) {
+  const int lane = threadIdx.x & 63, b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;
+  int last = 0;
+  for (int t = lane; t < T; t += 64) {
+    const bool live = tok[(long long)b * T + t] != pad || (y != nullptr && y[(long long)b * T + t] >= 0);
+    if (live) last = t + 1;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { const int v = __shfl_xor(last, o, 64); last = v > last ? v : last; }
+  if (lane == 0) len[b] = last;
+}
+// exclusive scan of len[0..B) in place -> off[0..B], off[B] = total; err |= 2 when the total differs from the host's count
+__global__ __launch_bounds__(1024) void seq_scan_kernel(int* __restrict__ off, int B, int expect, int* __restrict__ err) {
+  __shared__ int part[1024];
+  const int t = threadIdx.x, per = (B + 1023) / 1024;
+  const int lo = t * per, hi = lo + per < B ? lo + per : B;
+  int sum = 0;
+  for (int i = lo; i < hi; ++i) sum += off[i];
+  part[t] = sum;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {
+    const int v = t >= o ? part[t - o] : 0;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  int run = part[t] - sum;
+  for (int i = lo; i < hi; ++i) { const int l = off[i]; off[i] = run; run += l; }
+  if (t == 1023) {
+    off[B] = part[1023];
+    if (part[1023] != expect) atomicOr(err, 2);
+  }
+}
+__global__ void seq_fill_kernel(const int* __restrict__ off, const long long* __restrict__ y, int* __restrict__ row_src,
+                                int* __restrict__ row_t, long long* __restrict__ ypk, int B, int T, int cap) {
+  const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= (long long)B * T) return;
+  const int b = (int)(g / T), t = (int)(g - (long long)b * T);
+  const int o = off[b];
+  if (t >= off[b + 1] - o) return;
+  const int m = o + t;
+  if (m >= cap) return;   // (only when the host's count was too small: flagged by the scan)
+  row_src[m] = (int)g;
+  row_t[m] = t;
+  if (ypk != nullptr) ypk[m] = y[g];
+}
+int launch_seq_pack(const long long* tok, const long long* y, int pad_token, int B, int T, int rows_expect, int* off,
+                    int* row_src, int* row_t, long long* ypk, int* err, hipStream_t s) {
+  COATI_CHECK_ARG(tok && off && row_src && row_t && err && (ypk == nullptr || y != nullptr), "seq_pack: null operand");
+  COATI_CHECK_SHAPE(B > 0 && T > 0 && rows_expect > 0 && rows_expect <= (long long)B * T, "seq_pack: bad row count %d for %d x %d", rows_expect, B, T);
+  // rows the fill does not reach (a count mismatch: flagged) still have to index inside the matrices
+  if (hipMemsetAsync(row_src, 0, (size_t)rows_expect * sizeof(int), s) != hipSuccess || hipMemsetAsync(row_t, 0, (size_t)rows_expect * sizeof(int), s) != hipSuccess ||
+      (ypk != nullptr && hipMemsetAsync(ypk, 0xff, (size_t)rows_expect * sizeof(long long), s) != hipSuccess)) {
+    coati_set_error("seq_pack: memset failed");
+    return COATI_EHIP;
+  }
+  hipLaunchKernelGGL(seq_len_kernel, dim3(cdiv(B, 4)), dim3(256), 0, s, tok, y, pad_token, off, B, T);
+  hipLaunchKernelGGL(seq_scan_kernel, dim3(1), dim3(1024), 0, s, off, B, rows_expect, err);
+  hipLaunchKernelGGL(seq_fill_kernel, dim3(cdiv((long long)B * T, 256)), dim3(256), 0, s, off, y, row_src, row_t, ypk, B, T, rows_expect);
+  COATI_LAUNCH_CHECK("seq_pack");
   return COATI_OK;
 }
 

@@ -59,8 +59,14 @@ struct GLayerP {
 };
 
 struct XPass {  // saved activations of one transformer pass
-  int B, T, M;
+  int B, T, M;               // M = rows the pass runs on: B * T (padded layout) or the number of packed rows
   const long long* idx;
+  // packed rows (embed.hip launch_seq_pack): the pass runs on the concatenation of every row's real prefix
+  bool packed = false;
+  int* off = nullptr;        // [B + 1] first packed row of each sequence
+  int* row_src = nullptr;    // [M] slot b * T + t of packed row m
+  int* row_t = nullptr;      // [M] token position of packed row m (rotary embedding)
+  long long* ypk = nullptr;  // [M] packed targets (decoder pass)
   std::vector<float*> x;      // L+1 residual-stream snapshots [M,C]
   std::vector<float*> xmid;   // L
   std::vector<float*> mean1, rstd1, mean2, rstd2, lse;
@@ -140,10 +146,8 @@ struct coati_engine {
   int wg_tile = 128;                                  // output tile of the grouped launch: 256 when C % 256 == 0 (COATI_WGRAD_TILE=128 overrides)
   bool wg_group = false;                              // buffers carved (shape and COATI_WGRAD_GROUP allow it)
   WgradTile* d_wtab = nullptr;                        // device tables: WTAB_SLOTS x (L x tiles per layer) entries
-  int* d_wpace = nullptr;                             // pacing epoch counters of the grouped launch: [4 L problems][epochs]
-  int wpace_per = 0;                                  // ints per problem
   int wtab_cap = 0;                                   // entries per slot
-  struct WTabKey { const void* pass = nullptr; int lo = -1, hi = -1, M = 0, n = 0; long long sig = 0; bool split = false; };
+  struct WTabKey { const void* pass = nullptr; int lo = -1, hi = -1, M = 0, n = 0; long long sig = 0; };
   WTabKey wtab_key[4];
   const void* wtab_ws = nullptr;                      // workspace the cached tables were built for
   long long carve_sig = -1;                           // (B, T1, T2, A) of the last carve: the cached tables die with any other shape
@@ -394,6 +398,8 @@ void carve_pass(coati_engine* e, Arena& ar, XPass& p, int B, int T) {
   p.meanf = ar.take<float>(M); p.rstdf = ar.take<float>(M);
   p.xf32 = ar.take<float>(M * C);
   p.af = ar.take<bf16_t>(M * C);
+  p.packed = false;
+  p.off = ar.take<int>((size_t)B + 1); p.row_src = ar.take<int>(M); p.row_t = ar.take<int>(M); p.ypk = ar.take<long long>(M);
 }
 
 size_t carve(coati_engine* e, Arena& ar, int B, int T1, int T2, int A, int Bg) {
@@ -466,8 +472,6 @@ size_t carve(coati_engine* e, Arena& ar, int B, int T1, int T2, int A, int Bg) {
       }
       const int tpl = cdiv(3 * C, 128) * cdiv(C, 128) + cdiv(C, 128) * cdiv(C, 128) + 2 * cdiv(4 * C, 128) * cdiv(C, 128);
       e->wtab_cap = L * tpl;
-      e->wpace_per = wgrad_table_pace_ints((int)Mmax);
-      e->d_wpace = ar.take<int>((size_t)4 * L * e->wpace_per);
       WgradTile* t = ar.take<WgradTile>((size_t)4 * e->wtab_cap);
       if (t != e->d_wtab || ar.base != e->wtab_ws) for (auto& k : e->wtab_key) k = coati_engine::WTabKey();
       e->d_wtab = t;
@@ -503,7 +507,7 @@ int xformer_fwd(coati_engine* e, XPass& p, const float* injection, hipStream_t s
   const int C = c.n_hidden_xformer, L = c.n_layer_xformer, M = p.M;
   {
     ProfScope ps(e, SITE_EMBED, 0, s);
-    COATI_TRY(launch_embed_fwd(p.idx, e->P + e->tok_emb, injection, c.unk_token, p.x[0], p.B, p.T, C, c.n_tok, s));
+    COATI_TRY(launch_embed_fwd(p.idx, e->P + e->tok_emb, injection, c.unk_token, p.x[0], p.B, p.T, C, c.n_tok, s, p.packed ? p.row_src : nullptr, M));
   }
   for (int l = 0; l < L; ++l) {
     const XLayerP& w = e->xl[l];
@@ -515,6 +519,7 @@ int xformer_fwd(coati_engine* e, XPass& p, const float* injection, hipStream_t s
       memset(&a, 0, sizeof(a));
       a.A = p.a1[l]; a.lda = C; a.B = e->S + w.attnw; a.ldb = C; a.M = M; a.N = 3 * C; a.K = C; a.C = p.qkv[l]; a.ldc = 3 * C;
       a.bias = e->P + w.attnb; a.rope_cos = e->cos_t; a.rope_sin = e->sin_t; a.rope_T = p.T; a.rope_C = C; a.rope_hs = C / c.n_head;
+      a.rope_row_t = p.packed ? p.row_t : nullptr;
       const bool fuse = gemm_rb256_ln_fusable(a, EPI_QKV_ROPE);
       if (fuse) {
         a.ln_x = p.x[l]; a.ln_ldx = C; a.ln_gamma = e->P + w.ln1w; a.ln_beta = e->P + w.ln1b; a.ln_mean = p.mean1[l]; a.ln_rstd = p.rstd1[l];
@@ -526,22 +531,10 @@ int xformer_fwd(coati_engine* e, XPass& p, const float* injection, hipStream_t s
       COATI_TRY(launch_gemm_nt(a, 0, EPI_QKV_ROPE, s));
     }
     {
-      ProfScope ps(e, SITE_ATTN_FWD, 4.0 * p.B * (double)p.T * p.T * C, s, (double)M * 4 * C * 2 + (double)M * c.n_head * 4);   // qkv in, y + lse out
-      COATI_TRY(launch_attn_fwd(p.qkv[l], p.y[l], p.lse[l], p.B, p.T, c.n_head, C / c.n_head, s));
+      ProfScope ps(e, SITE_ATTN_FWD, 4.0 * M * (double)p.T * C, s, (double)M * 4 * C * 2 + (double)M * c.n_head * 4);   // qkv in, y + lse out
+      COATI_TRY(launch_attn_fwd(p.qkv[l], p.y[l], p.lse[l], p.B, p.T, c.n_head, C / c.n_head, s, p.packed ? p.off : nullptr));
     }
     COATI_TRY(gemm(e, SITE_PROJ_FWD, p.y[l], 0, C, e->S + w.projw, C, M, C, C, p.xmid[l], C, e->P + w.projb, EPI_RES_F32, p.x[l], nullptr, C, s));
-    // COATI_MLP_PAIRED=1 (experiment): the MLP forward as ONE paired-wave kernel (gemm_mlp2.hip) instead of FC1 + FC2
-    static const bool mlp_paired = getenv("COATI_MLP_PAIRED") != nullptr && atoi(getenv("COATI_MLP_PAIRED")) == 1;
-    if (mlp_paired && C == 256 && M >= 4096) {
-      MlpArgs m;
-      memset(&m, 0, sizeof(m));
-      m.M = M; m.C = C; m.Hd = 4 * C; m.x = p.xmid[l]; m.ldx = C; m.gamma = e->P + w.ln2w; m.beta = e->P + w.ln2b; m.mean = p.mean2[l]; m.rstd = p.rstd2[l];
-      m.a = p.a2[l]; m.lda = C; m.W1 = e->S + w.fc1w; m.ldw1 = C; m.b1 = e->P + w.fc1b; m.W2 = e->S + w.fc2w; m.ldw2 = 4 * C; m.b2 = e->P + w.fc2b;
-      m.h = p.g[l]; m.d = p.hpre[l]; m.ldh = 4 * C; m.out = p.x[l + 1]; m.ldo = C;
-      ProfScope ps(e, SITE_FC1_FWD, 4.0 * M * 4 * C * C, s, (double)M * 4608);
-      COATI_TRY(launch_mlp_pair_fwd(m, s));
-      continue;
-    }
     {
       // hpre holds NewGELU'(pre-activation), not the pre-activation: the backward multiplies instead of re-evaluating the
       // sigmoid (the activation epilogues are VALU-bound: 2 quarter-rate transcendentals per element).  ln_2 is fused into
@@ -569,11 +562,13 @@ int xformer_fwd(coati_engine* e, XPass& p, const float* injection, hipStream_t s
 // One launch for the 4 (l_hi - l_lo) weight gradients of a layer range (bias gradients included): the tile table is built
 // once per (pass, range, shape) and cached in the workspace.
 int xformer_wgrad_group(coati_engine* e, XPass& p, int l_lo, int l_hi, hipStream_t s) {
-  const int C = e->cfg.n_hidden_xformer, M = p.M;
+  // the table is built for the padded row count of the pass (it only fixes operand addresses and tile indices); the rows a
+  // launch really streams (fewer with packed rows, different every batch) are a kernel argument
+  const int C = e->cfg.n_hidden_xformer, M = p.M, Mtab = p.B * p.T;
   const long long sig = (((long long)e->B * 1000003 + e->T1) * 1000003 + e->T2) * 1000003 + e->A;
   int slot = -1;
   for (int i = 0; i < 4; ++i)
-    if (e->wtab_key[i].pass == &p && e->wtab_key[i].lo == l_lo && e->wtab_key[i].hi == l_hi && e->wtab_key[i].M == M && e->wtab_key[i].sig == sig) slot = i;
+    if (e->wtab_key[i].pass == &p && e->wtab_key[i].lo == l_lo && e->wtab_key[i].hi == l_hi && e->wtab_key[i].M == Mtab && e->wtab_key[i].sig == sig) slot = i;
   double flops = 0.0, bytes = 0.0;
   for (int l = l_lo; l < l_hi; ++l) {
     flops += 2.0 * M * (3.0 + 1.0 + 4.0 + 4.0) * C * C;
@@ -581,11 +576,10 @@ int xformer_wgrad_group(coati_engine* e, XPass& p, int l_lo, int l_hi, hipStream
   }
   if (slot < 0) {
     std::vector<WgradTile> tab;
-    int prob = 0;
     auto add = [&](const bf16_t* A, int lda, const bf16_t* B, int ldb, int N, int K, int64_t w_off, int64_t b_off) -> int {
       WgradArgs a;
-      a.A = A; a.lda = lda; a.B = B; a.ldb = ldb; a.M = M; a.N = N; a.K = K; a.dW = e->G + w_off; a.ldw = K; a.dbias = e->G + b_off; a.n_out = 0;
-      return wgrad_table_append(tab, a, e->d_wpace + (size_t)(prob++) * e->wpace_per, e->wg_tile);
+      a.A = A; a.lda = lda; a.B = B; a.ldb = ldb; a.M = Mtab; a.N = N; a.K = K; a.dW = e->G + w_off; a.ldw = K; a.dbias = e->G + b_off; a.n_out = 0;
+      return wgrad_table_append(tab, a, e->wg_tile);
     };
     for (int l = l_hi - 1; l >= l_lo; --l) {
       const XLayerP& w = e->xl[l];
@@ -593,19 +587,6 @@ int xformer_wgrad_group(coati_engine* e, XPass& p, int l_lo, int l_hi, hipStream
       COATI_TRY(add(e->w_dxb[l], C, p.y[l], C, C, C, w.projw, w.projb));
       COATI_TRY(add(e->w_dh4[l], 4 * C, p.a2[l], C, 4 * C, C, w.fc1w, w.fc1b));
       COATI_TRY(add(e->w_dxa[l], C, p.g[l], 4 * C, C, 4 * C, w.fc2w, w.fc2b));
-    }
-    // 256-wide tiles of a whole pass (192) leave a quarter of the CUs idle: the split form (COATI_WGRAD_SPLIT=1) puts three
-    // quarters of M on a tile's main workgroup and the last quarter on a helper, ordered commits.  EXPERIMENT, off: 2.14 ms per
-    // launch against 2.04 -- with all 256 CUs streaming the launch is no faster, i.e. it is bound by what the memory system
-    // delivers for this pattern (11.3 GB in 2.0 ms = 5.6 TB/s), not by the number of CUs.
-    static const bool want_split = getenv("COATI_WGRAD_SPLIT") != nullptr && atoi(getenv("COATI_WGRAD_SPLIT")) == 1;
-    bool split = false;
-    if (want_split && e->wg_tile == 256 && tab.size() == 192 && 3 * 256 <= e->wtab_cap &&
-        (int)tab.size() <= 4 * (l_hi - l_lo) * e->wpace_per) {
-      std::vector<WgradTile> segs;
-      COATI_TRY(wgrad_table_split256(tab, 256, e->d_wpace, segs));
-      tab.swap(segs);
-      split = true;
     }
     COATI_CHECK_ARG((int)tab.size() <= e->wtab_cap, "wgrad group: table overflow (%zu > %d)", tab.size(), e->wtab_cap);
     slot = e->wtab_rr++ & 3;
@@ -616,17 +597,11 @@ int xformer_wgrad_group(coati_engine* e, XPass& p, int l_lo, int l_hi, hipStream
       return COATI_EHIP;
     }
     coati_engine::WTabKey k;
-    k.pass = &p; k.lo = l_lo; k.hi = l_hi; k.M = M; k.n = (int)tab.size(); k.sig = sig; k.split = split;
+    k.pass = &p; k.lo = l_lo; k.hi = l_hi; k.M = Mtab; k.n = (int)tab.size(); k.sig = sig;
     e->wtab_key[slot] = k;
   }
-  // the pacing counters of this launch's problems start at zero
-  if (hipMemsetAsync(e->d_wpace, 0, (size_t)4 * (l_hi - l_lo) * e->wpace_per * sizeof(int), s) != hipSuccess) {
-    coati_set_error("wgrad group: counter reset failed");
-    return COATI_EHIP;
-  }
   ProfScope ps(e, SITE_XF_WGRAD, flops, s, bytes);
-  if (e->wtab_key[slot].split) return launch_wgrad_table_split256(e->d_wtab + (size_t)slot * e->wtab_cap, 256, s);
-  return launch_wgrad_table(e->d_wtab + (size_t)slot * e->wtab_cap, e->wtab_key[slot].n, s, e->wg_tile);
+  return launch_wgrad_table(e->d_wtab + (size_t)slot * e->wtab_cap, e->wtab_key[slot].n, s, e->wg_tile, M);
 }
 
 // dyf: gradient w.r.t. ln_f output, bf16 (decoder pass) or f32 (encoder pass)
@@ -680,8 +655,8 @@ int xformer_bwd(coati_engine* e, XPass& p, const void* dyf, int dyf_f32, float* 
     COATI_TRY(gemm(e, SITE_PROJ_DGRAD, dxb, 0, C, e->S + w.projT, C, M, C, C, e->dyb, C, nullptr, EPI_BF16, nullptr, nullptr, 0, s));
     if (!grp) COATI_TRY(wgrad(e, SITE_XF_WGRAD, dxb, 0, C, p.y[l], C, M, C, C, e->G + w.projw, C, e->G + w.projb, 0, s));
     {
-      ProfScope ps(e, SITE_ATTN_BWD, 10.0 * p.B * (double)p.T * p.T * C, s, (double)M * 8 * C * 2 + (double)M * c.n_head * 8);   // qkv, y, dy in; dqkv out
-      COATI_TRY(launch_attn_bwd(p.qkv[l], p.y[l], e->dyb, p.lse[l], e->attnD, dqkv, e->cos_t, e->sin_t, p.B, p.T, c.n_head, C / c.n_head, s));
+      ProfScope ps(e, SITE_ATTN_BWD, 10.0 * M * (double)p.T * C, s, (double)M * 8 * C * 2 + (double)M * c.n_head * 8);   // qkv, y, dy in; dqkv out
+      COATI_TRY(launch_attn_bwd(p.qkv[l], p.y[l], e->dyb, p.lse[l], e->attnD, dqkv, e->cos_t, e->sin_t, p.B, p.T, c.n_head, C / c.n_head, s, p.packed ? p.off : nullptr));
     }
     COATI_TRY(gemm(e, SITE_QKV_DGRAD, dqkv, 0, 3 * C, e->S + w.attnT, 3 * C, M, C, 3 * C, e->da, C, nullptr, EPI_BF16, nullptr, nullptr, 0, s));
     if (!grp) COATI_TRY(wgrad(e, SITE_XF_WGRAD, dqkv, 0, 3 * C, p.a1[l], C, M, 3 * C, C, e->G + w.attnw, C, e->G + w.attnb, 0, s));
@@ -697,7 +672,7 @@ int xformer_bwd(coati_engine* e, XPass& p, const void* dyf, int dyf_f32, float* 
   }
   if (l_lo > 0) return COATI_OK;
   ProfScope ps(e, SITE_EMBED, 0, s);
-  return launch_embed_bwd(p.idx, DX, e->G + e->tok_emb, dinjection, c.unk_token, p.B, p.T, C, c.n_tok, s);
+  return launch_embed_bwd(p.idx, DX, e->G + e->tok_emb, dinjection, c.unk_token, p.B, p.T, C, c.n_tok, s, p.packed ? p.off : nullptr);
 }
 
 // ---- point encoder -------------------------------------------------------------------------------------
@@ -941,13 +916,15 @@ int coati_engine_refresh_shadows(coati_engine* e, void* stream) { return refresh
 int coati_engine_forward(coati_engine* e, void* workspace, int64_t workspace_bytes, int B, int T1, int T2, int A,
                          const int64_t* raw_tokens, const int64_t* tokens, const int64_t* y_next,
                          const int64_t* atoms, const float* coords, const uint8_t* use_point, float* h_e3gnn,
-                         float* h_smiles, uint8_t* bad_rows, float* scal, int train, void* stream) {
+                         float* h_smiles, uint8_t* bad_rows, float* scal, int train, int64_t rows1, int64_t rows2, void* stream) {
   COATI_CHECK_ARG(e && e->P && e->S, "engine_forward: engine not bound");
   COATI_CHECK_ARG(workspace && raw_tokens && tokens && atoms && coords && use_point && scal, "engine_forward: null argument");
   COATI_CHECK_ARG(!train || (e->G && y_next), "engine_forward: training needs grads and y_next");
   const coati_config& c = e->cfg;
   COATI_CHECK_SHAPE(B > 0 && T1 > 0 && T2 > 0 && A > 0 && T1 <= c.n_seq && T2 <= c.n_seq,
                     "engine_forward: unsupported shape B=%d T1=%d T2=%d A=%d (n_seq=%d)", B, T1, T2, A, c.n_seq);
+  COATI_CHECK_SHAPE(rows1 >= 0 && rows2 >= 0 && rows1 <= (int64_t)B * T1 && rows2 <= (int64_t)B * T2 && (rows1 > 0) == (rows2 > 0),
+                    "engine_forward: packed row counts %lld / %lld do not fit %d x %d / %d x %d", (long long)rows1, (long long)rows2, B, T1, B, T2);
   hipStream_t s = (hipStream_t)stream;
   const int C = c.n_hidden_xformer, H = c.n_hidden_e3nn, E = c.n_embd_common;
   Arena ar{reinterpret_cast<char*>(workspace), 0, (size_t)workspace_bytes, false};
@@ -967,6 +944,15 @@ int coati_engine_forward(coati_engine* e, void* workspace, int64_t workspace_byt
   HIPCHK(hipMemsetAsync(scal, 0, 16 * sizeof(float), s));
   HIPCHK(hipMemsetAsync(e->err_flag, 0, 4 * sizeof(int), s));
   if (train) HIPCHK(hipMemsetAsync(e->G, 0, (size_t)e->n_params * sizeof(float), s));
+  // ---- packed rows: both transformer passes run on the rows' real prefixes only (embed.hip, launch_seq_pack); the counts
+  // come from the caller (the batch assembler knows them on the host: no device -> host sync here), the device checks them
+  if (rows1 > 0) {
+    COATI_TRY(launch_seq_pack(e->p1.idx, nullptr, c.pad_token, B, T1, (int)rows1, e->p1.off, e->p1.row_src, e->p1.row_t, nullptr, e->err_flag, s));
+    COATI_TRY(launch_seq_pack(e->p2.idx, e->y_next, c.pad_token, B, T2, (int)rows2, e->p2.off, e->p2.row_src, e->p2.row_t, e->y_next ? e->p2.ypk : nullptr, e->err_flag, s));
+    e->p1.packed = e->p2.packed = true;
+    e->p1.M = (int)rows1;
+    e->p2.M = (int)rows2;
+  }
   {
     // ones[B] for bias column sums
     std::vector<float> dummy;  // (filled on device below)
@@ -988,7 +974,7 @@ int coati_engine_forward(coati_engine* e, void* workspace, int64_t workspace_byt
   COATI_TRY(launch_sgemm(e->hp_ln, H, 1, e->P + e->p2c_w, 1, H, e->h_e3gnn, E, B, E, H, e->P + e->p2c_b, 1.f, 0, s));
   // ---- smiles_to_clip ----
   COATI_TRY(launch_find_stop(e->p1.idx, c.stop_token, e->stop_pos, e->err_flag, B, T1, s));
-  COATI_TRY(launch_gather_rows(e->p1.xf32, e->stop_pos, e->hstop, B, T1, C, s));
+  COATI_TRY(launch_gather_rows(e->p1.xf32, e->stop_pos, e->hstop, B, T1, C, s, e->p1.packed ? e->p1.off : nullptr));
   COATI_TRY(launch_layernorm_fwd(e->hstop, C, e->P + e->s2c_lnw, e->P + e->s2c_lnb, nullptr, 0, e->hs_ln, C, e->hs_mean, e->hs_rstd, B, C, s));
   COATI_TRY(launch_sgemm(e->hs_ln, C, 1, e->P + e->s2c_w, 1, C, e->h_smiles, E, B, E, C, e->P + e->s2c_b, 1.f, 0, s));
   // ---- special token (clip_e2e.py:800-808) ----
@@ -1002,7 +988,7 @@ int coati_engine_forward(coati_engine* e, void* workspace, int64_t workspace_byt
   if (bad_rows) COATI_TRY(launch_bad_rows(e->p2.idx, bad_rows, B, T2, s));
   // ---- lm_head + AR cross-entropy, logits never materialised (smiles_xformer.py:453, train_coati.py:260-265) ----
   if (y_next) {
-    const int M2 = B * T2;
+    const int M2 = e->p2.M;
     GemmArgs a;
     memset(&a, 0, sizeof(a));
     a.A = e->p2.af; a.lda = C; a.B = e->S + e->lmhead; a.ldb = C; a.M = M2; a.N = c.n_tok; a.K = C; a.partial = e->ce_partial;
@@ -1012,7 +998,7 @@ int coati_engine_forward(coati_engine* e, void* workspace, int64_t workspace_byt
       ProfScope ps(e, SITE_LMHEAD_FWD, 2.0 * M2 * c.n_tok * C, s, (double)M2 * C * 2 + (double)c.n_tok * C * 2);   // logits never leave the chip
       COATI_TRY(launch_gemm_nt(a, 0, EPI_CE_PARTIAL, s));
     }
-    COATI_TRY(launch_ce_finish(e->ce_partial, tiles_v, e->p2.af, C, e->S + e->lmhead, C, e->y_next, e->ce_lse, scal, M2, C, c.n_tok, s));
+    COATI_TRY(launch_ce_finish(e->ce_partial, tiles_v, e->p2.af, C, e->S + e->lmhead, C, e->p2.packed ? e->p2.ypk : e->y_next, e->ce_lse, scal, M2, C, c.n_tok, s));
   }
   if (h_e3gnn) HIPCHK(hipMemcpyAsync(h_e3gnn, e->h_e3gnn, (size_t)B * E * sizeof(float), hipMemcpyDeviceToDevice, s));
   if (h_smiles) HIPCHK(hipMemcpyAsync(h_smiles, e->h_smiles, (size_t)B * E * sizeof(float), hipMemcpyDeviceToDevice, s));
@@ -1068,6 +1054,7 @@ int coati_engine_logits(coati_engine* e, float* logits, int64_t ldl, void* strea
   COATI_CHECK_ARG(e && e->have_fwd && logits, "engine_logits: no forward to read");
   const coati_config& c = e->cfg;
   hipStream_t s = (hipStream_t)stream;
+  COATI_CHECK_ARG(!e->p2.packed, "engine_logits: the last forward ran on packed rows (logits of padded positions do not exist): run it with rows1 = rows2 = 0");
   return gemm(e, SITE_LMHEAD_FWD, e->p2.af, 0, c.n_hidden_xformer, e->S + e->lmhead, c.n_hidden_xformer, e->B * e->T2, c.n_tok,
               c.n_hidden_xformer, logits, ldl, nullptr, EPI_F32, nullptr, nullptr, 0, s);
 }
@@ -1111,13 +1098,13 @@ int coati_engine_backward(coati_engine* e, const float* dh_smiles, const float* 
   const coati_config& c = e->cfg;
   const int C = c.n_hidden_xformer, H = c.n_hidden_e3nn, E = c.n_embd_common, B = e->B;
   if (stage == 0 || stage == 1) {
-    const int M2 = B * e->T2;
+    const int M2 = e->p2.M;
     // ---- lm_head backward: dlogits (bf16) -> d(af), dW_lm ----
     {
       GemmArgs a;
       memset(&a, 0, sizeof(a));
       a.A = e->p2.af; a.lda = C; a.B = e->S + e->lmhead; a.ldb = C; a.M = M2; a.N = c.n_tok; a.K = C;
-      a.C = e->dlogits; a.ldc = e->Vpad; a.n_store = e->Vpad; a.lse = e->ce_lse; a.target = e->y_next; a.scal = e->scal;
+      a.C = e->dlogits; a.ldc = e->Vpad; a.n_store = e->Vpad; a.lse = e->ce_lse; a.target = e->p2.packed ? e->p2.ypk : e->y_next; a.scal = e->scal;
       ProfScope ps(e, SITE_LMHEAD_DLOGITS, 2.0 * M2 * c.n_tok * C, s, (double)M2 * C * 2 + (double)c.n_tok * C * 2 + (double)M2 * e->Vpad * 2);
       COATI_TRY(launch_gemm_nt(a, 0, EPI_CE_BWD, s));
     }
@@ -1161,7 +1148,7 @@ int coati_engine_backward(coati_engine* e, const float* dh_smiles, const float* 
     // ---- encoder pass: gradient enters at the [STOP] rows of ln_f's output ----
     float* dxf = reinterpret_cast<float*>(e->dh4);  // [M1, C] f32 scratch (dh4 is idle here: 4C bf16 >= C f32)
     HIPCHK(hipMemsetAsync(dxf, 0, (size_t)e->p1.M * C * sizeof(float), s));
-    COATI_TRY(launch_scatter_rows_add(e->dhstop, e->stop_pos, dxf, B, e->T1, C, s));
+    COATI_TRY(launch_scatter_rows_add(e->dhstop, e->stop_pos, dxf, B, e->T1, C, s, e->p1.packed ? e->p1.off : nullptr));
     // xformer_bwd consumes dyf in its first kernel (ln_f backward) before dh4 is rewritten
     COATI_TRY(xformer_bwd(e, e->p1, dxf, 1, nullptr, s, Lx, stage == 4 ? Lmid : 0));
   }

@@ -282,7 +282,6 @@ int launch_gemm_nt(const GemmArgs& a, int a_f32, int epi, hipStream_t s) {
     static const bool no_rb = getenv("COATI_NO_RB") != nullptr;   // A/B switch for benchmarking
     // N = 256 with a bf16 / residual epilogue: the ring kernel, also at K = 256 (proj forward 57 -> 44 us against the
     // row-block kernel); every other K = 256 product: the row-block kernel
-    if (gemm_ring320_supported(a, a_f32, epi)) return launch_gemm_ring320(a, epi, s);
     if (gemm_ring256_supported(a, a_f32, epi)) return launch_gemm_ring256(a, epi, s);
     if (!no_rb && gemm_rb256_supported(a, a_f32, epi)) return launch_gemm_rb256(a, epi, s);
   }
@@ -551,8 +550,7 @@ template <int S> struct WdSlot { static constexpr int value = S; };
 // plain read-add-stores instead of fp32 atomics (the grouped launch below); the bias partials stay atomic (tiles_k
 // workgroups share a bias slice).
 template <bool BIAS, int NS, bool EXCL>
-__device__ __forceinline__ void wgrad_dma_body(const WgradArgs& p, int tiles_k, int tile, int c_begin, int c_end, unsigned char* smem,
-                                               int* pace = nullptr, int group_size = 0) {
+__device__ __forceinline__ void wgrad_dma_body(const WgradArgs& p, int tiles_k, int tile, int c_begin, int c_end, unsigned char* smem) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int grp = wave >> 2, wm = (wave >> 1) & 1, wn = wave & 1;
   const int tile_n = tile / tiles_k, tile_k = tile - tile_n * tiles_k;
@@ -730,46 +728,20 @@ __device__ __forceinline__ void wgrad_dma_body(const WgradArgs& p, int tiles_k, 
     __builtin_amdgcn_sched_barrier(0);
     if (turn) bias_add();
   };
-  // Pacing (grouped launch): the workgroups of one problem share operand panels through their XCD's L2, but only while they
-  // stream the same rows at about the same time.  Over 1280 stages they drift apart (L2 misses of the launch grew from
-  // 1.10x the operand bytes at 160 stages to 1.71x at 1280: rocprofv3 FETCH_SIZE, profiles/r02_wgrad_traffic.txt), so every
-  // COATI_WG_EPOCH_STAGES stages a workgroup reports the epoch it enters and does not run more than one epoch ahead of the
-  // slowest sibling.  One lane does it: a returnless vector atomic to arrive, scalar loads (lgkmcnt, not vmcnt: the ring's DMA
-  // accounting is untouched) to wait; the other waves are held by the next stage barrier.  Deadlock-free: siblings are
-  // dispatched back to back, and a workgroup waits only for siblings.
-  auto pace_point = [&](int c) __attribute__((always_inline)) {
-    if constexpr (EXCL) {
-      if (pace != nullptr && (c % COATI_WG_EPOCH_STAGES) == 0 && tid == 0) {
-        const int ep = c / COATI_WG_EPOCH_STAGES;
-        __hip_atomic_fetch_add(pace + ep, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (ep > 1) {   // (the first report is made on entering epoch 1)
-          const int* prev = pace + ep - 1;
-          int seen;
-          // bounded: pacing is a performance aid -- if a sibling never shows up the workgroup goes on alone
-          for (int spin = 0; spin < (1 << 16); ++spin) {
-            // the scalar data cache is not coherent with the L2 where the atomics land: invalidate it before every poll
-            asm volatile("s_dcache_inv\n\ts_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(seen) : "s"(prev) : "memory");
-            if (seen >= group_size) break;
-            __builtin_amdgcn_s_sleep(8);
-          }
-        }
-      }
-    }
-  };
   static_assert(NS == 3 || NS == 4, "the main loop is unrolled for ring depths 3 and 4");
   for (int c = c_begin;;) {
     if constexpr (NS == 3) {
-      step(WdSlot<0>(), fa, fb); if (++c >= c_end) break; pace_point(c);
-      step(WdSlot<1>(), fb, fa); if (++c >= c_end) break; pace_point(c);
-      step(WdSlot<2>(), fa, fb); if (++c >= c_end) break; pace_point(c);
-      step(WdSlot<0>(), fb, fa); if (++c >= c_end) break; pace_point(c);
-      step(WdSlot<1>(), fa, fb); if (++c >= c_end) break; pace_point(c);
-      step(WdSlot<2>(), fb, fa); if (++c >= c_end) break; pace_point(c);
+      step(WdSlot<0>(), fa, fb); if (++c >= c_end) break;
+      step(WdSlot<1>(), fb, fa); if (++c >= c_end) break;
+      step(WdSlot<2>(), fa, fb); if (++c >= c_end) break;
+      step(WdSlot<0>(), fb, fa); if (++c >= c_end) break;
+      step(WdSlot<1>(), fa, fb); if (++c >= c_end) break;
+      step(WdSlot<2>(), fb, fa); if (++c >= c_end) break;
     } else {
-      step(WdSlot<0>(), fa, fb); if (++c >= c_end) break; pace_point(c);
-      step(WdSlot<1>(), fb, fa); if (++c >= c_end) break; pace_point(c);
-      step(WdSlot<2>(), fa, fb); if (++c >= c_end) break; pace_point(c);
-      step(WdSlot<3>(), fb, fa); if (++c >= c_end) break; pace_point(c);
+      step(WdSlot<0>(), fa, fb); if (++c >= c_end) break;
+      step(WdSlot<1>(), fb, fa); if (++c >= c_end) break;
+      step(WdSlot<2>(), fa, fb); if (++c >= c_end) break;
+      step(WdSlot<3>(), fb, fa); if (++c >= c_end) break;
     }
   }
   __builtin_amdgcn_s_waitcnt(0x0f70);   // the over-issued (zero-page) DMAs have landed: the ring is free
@@ -843,11 +815,12 @@ __global__ __launch_bounds__(512, 1) void wgrad_dma_kernel(WgradArgs p, int tile
 // per workgroup, device memory) is ordered problem by problem; xcd_swizzle hands each XCD a contiguous run of entries, so
 // the tiles that share an operand panel run at the same time on the same L2.
 template <bool BIAS, int NS>
-__global__ __launch_bounds__(512, 1) void wgrad_dma_table_kernel(const WgradTile* __restrict__ table) {
+__global__ __launch_bounds__(512, 1) void wgrad_dma_table_kernel(const WgradTile* __restrict__ table, int M_rt) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const WgradTile& d = table[xcd_swizzle(blockIdx.x, gridDim.x)];
-  const WgradArgs p = d.p;
-  wgrad_dma_body<BIAS, NS, true>(p, d.tiles_k, d.tile, 0, (p.M + WD_CH - 1) / WD_CH, smem, d.pace, d.group_size);
+  WgradArgs p = d.p;
+  if (M_rt > 0) p.M = M_rt;   // the rows of THIS launch (the cached table holds the largest count: packed rows change every batch)
+  wgrad_dma_body<BIAS, NS, true>(p, d.tiles_k, d.tile, 0, (p.M + WD_CH - 1) / WD_CH, smem);
 }
 
 // =================================================================================================
@@ -869,32 +842,24 @@ __global__ __launch_bounds__(512, 1) void wgrad_dma_table_kernel(const WgradTile
 #define W2_CH 32
 #define W2_BLK_BYTES (32 * WT_ROW_BYTES)
 #define W2_STAGE_BYTES (4 * W2_BLK_BYTES)
-#define W2_SEGS 3                                // table entries per workgroup in the split form
 struct W2Frags { bf16x8 a[4], b[2]; };
 
-// SPLIT: 192 tiles leave a quarter of the CUs idle, and a CU cannot take in more than ~21 B/clk (one 32-KiB stage per
-// ~1.5 k cycles), so the launch is bound by how many CUs stream.  The split form runs W2_SEGS table entries (segments: a
-// tile and a range of its M stages) per workgroup; a tile then has two contributors, which commit in a fixed order -- the
-// host's schedule (who finishes first) decides it: contributor `order` waits until the tile's ticket counter reads `order`,
-// adds its part with plain read-add-stores, then releases the counter -- so the sum is still deterministic and
-// atomics-free on the tile.  The schedule keeps the sibling tiles of a problem on the same rows at the same time (they
-// share operand panels through their XCD's L2): see wgrad_table_split256.
-template <int NS, bool SPLIT>
-__global__ __launch_bounds__(512, 1) void wgrad256_table_kernel(const WgradTile* __restrict__ table) {
+// (A split form that also used the 64 idle CUs -- three quarters of M on a tile's main workgroup, the last quarter on a helper,
+// ordered commits through ticket counters -- was built in round 2 and measured no faster (2.14 vs 2.04 ms): the launch is bound
+// by what the memory system delivers, not by the number of CUs.  Removed in round 3; see DESIGN.md.)
+template <int NS>
+__global__ __launch_bounds__(512, 1) void wgrad256_table_kernel(const WgradTile* __restrict__ table, int M_rt) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int wgi = xcd_swizzle(blockIdx.x, gridDim.x);
-#pragma unroll 1
-  for (int seg = 0; seg < (SPLIT ? W2_SEGS : 1); ++seg) {
-  const WgradTile& d = table[SPLIT ? W2_SEGS * wgi + seg : wgi];
-  if (SPLIT && d.c_begin >= d.c_end) continue;
-  const WgradArgs p = d.p;
+  const WgradTile& d = table[xcd_swizzle(blockIdx.x, gridDim.x)];
+  WgradArgs p = d.p;
+  if (M_rt > 0) p.M = M_rt;   // the rows of THIS launch (see wgrad_dma_table_kernel)
   const int tiles_k = d.tiles_k, tile = d.tile;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
   const int tile_n = tile / tiles_k, tile_k = tile - tile_n * tiles_k;
   const int n0 = tile_n * 256, k0 = tile_k * 256;
-  const int c_begin = SPLIT ? d.c_begin : 0;
-  const int c_end = SPLIT ? d.c_end : (p.M + W2_CH - 1) / W2_CH;
+  const int c_begin = 0;
+  const int c_end = (p.M + W2_CH - 1) / W2_CH;
   const bf16_t* A = reinterpret_cast<const bf16_t*>(p.A);
 
   // DMA sources of this lane: piece "rows 4 wave .. + 3" of block b = 0..3 (A0, A1, B0, B1); LDS slot (row & 3 = lane >> 4,
@@ -1057,20 +1022,8 @@ __global__ __launch_bounds__(512, 1) void wgrad256_table_kernel(const WgradTile*
   __syncthreads();
   if (tid < 256) {
     const float t = bsum[tid] + bsum[256 + tid] + bsum[512 + tid] + bsum[768 + tid];
-    if (!SPLIT && tiles_k == 1) p.dbias[n0 + tid] += t;
+    if (tiles_k == 1) p.dbias[n0 + tid] += t;
     else atomicAdd(p.dbias + n0 + tid, t);
-  }
-  const bool ordered = SPLIT && d.order >= 0;
-  if (ordered && d.order > 0) {
-    // wait for the contributors scheduled before this one (bounded: the schedule guarantees they do not wait for us)
-    if (tid == 0) {
-      for (int spin = 0; spin < (1 << 24); ++spin) {
-        if (__hip_atomic_load(d.pace, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= d.order) break;
-        __builtin_amdgcn_s_sleep(16);
-      }
-    }
-    __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   }
   // this workgroup is the only one that touches the tile now: plain read-add-store
 #pragma unroll
@@ -1083,45 +1036,30 @@ __global__ __launch_bounds__(512, 1) void wgrad256_table_kernel(const WgradTile*
         const int k = k0 + wn * 64 + j * 32 + (lane & 31);
         p.dW[(long long)n * p.ldw + k] += acc[i][j][r];
       }
-  if (ordered) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    __syncthreads();
-    if (tid == 0) __hip_atomic_fetch_add(d.pace, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  if (SPLIT) __syncthreads();   // the next segment's DMAs overwrite the ring (and the bias partials in it)
-  }
 }
-
-int wgrad_table_pace_ints(int M) { return cdiv(cdiv(M, WD_CH), COATI_WG_EPOCH_STAGES) + 1; }
 
 bool wgrad_table_tile256_ok(const WgradArgs& a) {
   return a.N % 256 == 0 && a.K % 256 == 0 && a.n_out == 0 && a.m_dev == nullptr && 40LL * a.lda < (1LL << 30) && 40LL * a.ldb < (1LL << 30);
 }
 
-int wgrad_table_append(std::vector<WgradTile>& tab, const WgradArgs& a, int* pace, int tile_size) {
+int wgrad_table_append(std::vector<WgradTile>& tab, const WgradArgs& a, int tile_size) {
   COATI_CHECK_ARG(a.A && a.B && a.dW && a.dbias, "wgrad_table: null operand (the grouped kernel is the bias variant)");
   COATI_CHECK_SHAPE(a.M > 0 && a.N % 8 == 0 && a.K % 8 == 0 && a.lda % 8 == 0 && a.ldb % 8 == 0, "wgrad_table: shape / alignment");
   COATI_CHECK_ARG(tile_size == 128 || tile_size == 256, "wgrad_table: tile size %d", tile_size);
   if (tile_size == 256) {
     COATI_CHECK_SHAPE(wgrad_table_tile256_ok(a), "wgrad_table: 256-wide tiles need N and K to be multiples of 256 (N=%d K=%d)", a.N, a.K);
     const int tk = a.K / 256, nt = (a.N / 256) * tk;
-    for (int t = 0; t < nt; ++t) tab.push_back(WgradTile{a, tk, t, nullptr, 0});
+    for (int t = 0; t < nt; ++t) tab.push_back(WgradTile{a, tk, t});
     return COATI_OK;
   }
   const int tiles_n = cdiv(a.N, BM), tiles_k = cdiv(a.K, BN);
-  // pacing needs every tile of the problem resident at the same time: at most one XCD's worth (32 CUs)
   const int n = tiles_n * tiles_k;
-  // COATI_WGRAD_PACE=1 turns the pacing on.  Measured (profiles/r02_wgrad_traffic.txt): L2 misses per launch 18.3 GB -> 10.7 GB
-  // (= the operand bytes, every panel fetched once) but 2.80 -> 3.33 ms: the launch is bound by the L2 -> LDS fill rate of
-  // the CUs (~45 GB/s each, 12 TB/s in aggregate), not by what leaves the L2, and lock-stepping the siblings adds stalls.
-  static const bool want_pace = getenv("COATI_WGRAD_PACE") != nullptr && atoi(getenv("COATI_WGRAD_PACE")) == 1;
-  const bool paced = pace != nullptr && n > 1 && n <= 32 && want_pace;
-  for (int t = 0; t < n; ++t) tab.push_back(WgradTile{a, tiles_k, t, paced ? pace : nullptr, paced ? n : 0});
+  for (int t = 0; t < n; ++t) tab.push_back(WgradTile{a, tiles_k, t});
   return COATI_OK;
 }
 
 template <int NS>
-static int launch_wgrad_table_t(const WgradTile* dev_table, int n_tiles, hipStream_t s) {
+static int launch_wgrad_table_t(const WgradTile* dev_table, int n_tiles, hipStream_t s, int M_rt) {
   static bool attr_set = false;
   auto kern = wgrad_dma_table_kernel<true, NS>;
   constexpr int lds = NS * WD_STAGE_BYTES;
@@ -1133,15 +1071,15 @@ static int launch_wgrad_table_t(const WgradTile* dev_table, int n_tiles, hipStre
     }
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3(n_tiles), dim3(512), lds, s, dev_table);
+  hipLaunchKernelGGL(kern, dim3(n_tiles), dim3(512), lds, s, dev_table, M_rt);
   COATI_LAUNCH_CHECK("wgrad_table");
   return COATI_OK;
 }
 
-template <int NS, bool SPLIT>
-static int launch_wgrad256_t(const WgradTile* dev_table, int n_tiles, hipStream_t s) {
+template <int NS>
+static int launch_wgrad256_t(const WgradTile* dev_table, int n_tiles, hipStream_t s, int M_rt) {
   static bool attr_set = false;
-  auto kern = wgrad256_table_kernel<NS, SPLIT>;
+  auto kern = wgrad256_table_kernel<NS>;
   constexpr int lds = NS * W2_STAGE_BYTES;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -1151,67 +1089,18 @@ static int launch_wgrad256_t(const WgradTile* dev_table, int n_tiles, hipStream_
     }
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3(n_tiles), dim3(512), lds, s, dev_table);
+  hipLaunchKernelGGL(kern, dim3(n_tiles), dim3(512), lds, s, dev_table, M_rt);
   COATI_LAUNCH_CHECK("wgrad_table256");
   return COATI_OK;
 }
 
-// Split form of a 256-wide table (see wgrad256_table_kernel<NS, true>): `tiles` = the table wgrad_table_append built,
-// 192 entries = 8 XCDs x 24 (two transformer layers per XCD); G = 256 workgroups; tickets = one zeroed int per tile.
-// Output: W2_SEGS x G entries (an empty segment has c_begin == c_end).  Per XCD (32 consecutive workgroups after
-// xcd_swizzle): 24 MAIN workgroups stream the first three quarters of M of "their" tile; 8 HELPER workgroups stream the last
-// quarter of three tiles each, eight consecutive tiles (whole problems) per time slot -- so at any time the tiles of a
-// problem are on the same rows, mains with mains and helpers with helpers, and every workgroup streams 3/4 of M.
-// (A first version cut the 768 quarter tiles into 256 runs of three: correct, but the siblings of a problem were then on
-// different rows at the same time, their shared panel was fetched once per tile, and the launch took 2.68 instead of 1.96 ms.)
-// Commit order of a tile: its helper first (it finishes after 1, 2 or 3 of the three slots), its main second.
-int wgrad_table_split256(const std::vector<WgradTile>& tiles, int G, int* tickets, std::vector<WgradTile>& out) {
-  const int nt = (int)tiles.size();
-  COATI_CHECK_ARG(nt == 192 && G == 256 && tickets, "wgrad_table_split256: the schedule is built for 192 tiles on 256 workgroups");
-  out.assign((size_t)W2_SEGS * G, WgradTile{});
-  for (int x = 0; x < 8; ++x) {
-    for (int i = 0; i < 24; ++i) {           // mains
-      const int t = 24 * x + i, w = 32 * x + i;
-      const int c_all = cdiv(tiles[t].p.M, W2_CH), Q = cdiv(c_all, 4);
-      WgradTile e = tiles[t];
-      e.c_begin = 0;
-      e.c_end = 3 * Q < c_all ? 3 * Q : c_all;
-      e.pace = tickets + t;
-      e.order = 3 * Q < c_all ? 1 : -1;        // (nothing left for a helper: exclusive)
-      out[(size_t)W2_SEGS * w] = e;
-    }
-    for (int h = 0; h < 8; ++h) {            // helpers
-      const int w = 32 * x + 24 + h;
-      for (int sl = 0; sl < 3; ++sl) {
-        const int t = 24 * x + 8 * sl + h;
-        const int c_all = cdiv(tiles[t].p.M, W2_CH), Q = cdiv(c_all, 4);
-        WgradTile e = tiles[t];
-        e.c_begin = 3 * Q < c_all ? 3 * Q : c_all;
-        e.c_end = c_all;
-        e.pace = tickets + t;
-        e.order = 0;
-        out[(size_t)W2_SEGS * w + sl] = e;
-      }
-    }
-  }
-  return COATI_OK;
-}
-
-int launch_wgrad_table_split256(const WgradTile* dev_table, int G, hipStream_t s) {
-  COATI_CHECK_ARG(dev_table && G > 0, "wgrad_table_split256: empty table");
-  return launch_wgrad256_t<4, true>(dev_table, G, s);
-}
-
-int launch_wgrad_table(const WgradTile* dev_table, int n_tiles, hipStream_t s, int tile_size) {
+int launch_wgrad_table(const WgradTile* dev_table, int n_tiles, hipStream_t s, int tile_size, int M_rt) {
   COATI_CHECK_ARG(dev_table && n_tiles > 0, "wgrad_table: empty table");
   if (tile_size == 256) {
-    // ring depth: 4 stages of 32 KiB (96 KiB in flight per CU) or 5 (128 KiB in flight, all 160 KiB of LDS): COATI_WGRAD256_NS
-    static const int ns256 = getenv("COATI_WGRAD256_NS") ? atoi(getenv("COATI_WGRAD256_NS")) : 4;
-    return ns256 == 5 ? launch_wgrad256_t<5, false>(dev_table, n_tiles, s) : launch_wgrad256_t<4, false>(dev_table, n_tiles, s);
+    // ring of 4 stages of 32 KiB (96 KiB in flight per CU); a 5-deep ring (all 160 KiB of LDS) measured the same (round 2)
+    return launch_wgrad256_t<4>(dev_table, n_tiles, s, M_rt);
   }
-  // ring depth (stages of 32 KiB; NS - 1 in flight): COATI_WGRAD_TABLE_NS = 3 | 4 (A/B switch)
-  static const int ns = getenv("COATI_WGRAD_TABLE_NS") ? atoi(getenv("COATI_WGRAD_TABLE_NS")) : 4;
-  return ns == 3 ? launch_wgrad_table_t<3>(dev_table, n_tiles, s) : launch_wgrad_table_t<4>(dev_table, n_tiles, s);
+  return launch_wgrad_table_t<4>(dev_table, n_tiles, s, M_rt);   // ring of 4 stages of 32 KiB, 3 in flight
 }
 
 template <bool BIAS, int NS>

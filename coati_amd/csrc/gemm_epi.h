@@ -115,7 +115,7 @@ __device__ __forceinline__ void epilogue8(const GemmArgs& p, int row, int col0, 
 #pragma unroll
       for (int e = 0; e < 8; ++e) o[e] = v[e];
     } else {
-      const int t = (rope_row && ROPE_HS == 16) ? 0 : (p.rope_pos ? *p.rope_pos : row % p.rope_T);
+      const int t = (rope_row && ROPE_HS == 16) ? 0 : (p.rope_pos ? *p.rope_pos : (p.rope_row_t ? p.rope_row_t[row < p.M ? row : p.M - 1] : row % p.rope_T));
       const int tab = hs32 ? t * 32 + (col0 & 8) : t * 16;   // tables are [n_seq, hs] with entries i and i + hs/2 equal
       const float sgn = hi_half ? 1.0f : -1.0f;
 #pragma unroll

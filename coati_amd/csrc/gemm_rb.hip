@@ -162,7 +162,14 @@ __global__ __launch_bounds__(64 * MAXW, (640 / (64 * MAXW)) > 0 ? (640 / (64 * M
   }
   if (EPI == EPI_QKV_ROPE) {
     // lane -> (row = lane >> 1, cos | sin): 8 floats each
-    const int r = lane >> 1, t = (m0 + r) % p.rope_T;
+    const int r = lane >> 1;
+    int t;
+    if (p.rope_row_t != nullptr) {   // packed rows: the position comes from the row map (rows past M re-read the last one)
+      const int mr = m0 + r < p.M ? m0 + r : p.M - 1;
+      t = p.rope_row_t[mr];
+    } else {
+      t = (m0 + r) % p.rope_T;
+    }
     const float* src = ((lane & 1) ? p.rope_sin : p.rope_cos) + t * 16;
     const float4 x0 = *reinterpret_cast<const float4*>(src), x1 = *reinterpret_cast<const float4*>(src + 4);
     *reinterpret_cast<float4*>(Rs + r * 16 + (lane & 1) * 8) = x0;
@@ -376,7 +383,9 @@ bool gemm_rb256_supported(const GemmArgs& a, int a_f32, int epi) {
   if (epi == EPI_CE_PARTIAL && a.partial_tile != 64) return false;   // the caller's partial buffer is laid out for 128-column tiles
   if (epi == EPI_QKV_ROPE && a.rope_hs == 32) return false;   // the staged rotary rows are laid out for head size 16
   if (a.N % 16 != 0 && epi != EPI_CE_BWD && epi != EPI_CE_PARTIAL) return false;   // (those two write no N-wide rows)
-  if (rb_waves(a.M) < 8) return false;   // small problems run on the tiled kernel
+  // small problems run on the tiled kernel.  (Packed rows: a full-size batch carries ~50 000 rows instead of 81 920, i.e.
+  // 6-7 slabs per workgroup -- still one round of one workgroup per CU, with LayerNorm fused into the operand load.)
+  if (rb_waves(a.M) < 5) return false;
   if ((excl & 1) && a.N < 512) return false;
   if ((excl & 2) && (epi == EPI_RES_F32 || epi == EPI_ACC_F32 || epi == EPI_F32 || epi == EPI_DGELU || epi == EPI_DSILU || epi == EPI_MUL_AUX || epi == EPI_EDGE_DPRE)) return false;
   return true;

@@ -428,7 +428,12 @@ __global__ __launch_bounds__(256) void gnn_edge_pre_c_kernel(const bf16_t* __res
   const int bj = blockIdx.x * 4 + wave;
   if (bj >= BA) return;
   const int e0 = seg[bj], n = seg[bj + 1] - e0;
-  for (int c = lane * 4; c < H; c += 256) {
+  // every lane walks the loop (H < 256 leaves lanes without channels): the segment metadata is read with readlane from
+  // ALL 64 lanes, so the loads that fill it must not sit in divergent control flow; lanes without channels compute on
+  // channel 0 and store nothing
+  for (int c0 = 0; c0 < H; c0 += 256) {
+    const bool act = c0 + lane * 4 < H;
+    const int c = act ? c0 + lane * 4 : 0;
     const uint2 ua = *reinterpret_cast<const uint2*>(P + (long long)bj * ldp + c);
     const float pa[4] = {bflo(ua.x), bfhi(ua.x), bflo(ua.y), bfhi(ua.y)};
     float wc[4], bb[4];
@@ -457,7 +462,7 @@ __global__ __launch_bounds__(256) void gnn_edge_pre_c_kernel(const bf16_t* __res
           float o[4];
 #pragma unroll
           for (int i = 0; i < 4; ++i) o[i] = silu_f(pa[i] + pb[i] + dd[u] * wc[i] + bb[i]);
-          *reinterpret_cast<uint2*>(e1 + (long long)(e0 + base + i0 + u) * H + c) = make_uint2(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]));
+          if (act) *reinterpret_cast<uint2*>(e1 + (long long)(e0 + base + i0 + u) * H + c) = make_uint2(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]));
         }
       }
     }
@@ -480,7 +485,12 @@ __global__ __launch_bounds__(256) void gnn_edge_reduce_c_kernel(const bf16_t* __
   const int bj = blockIdx.x * 4 + wave;
   if (bj >= BA) return;
   const int e0 = seg[bj], n = seg[bj + 1] - e0;
-  for (int c = lane * 4; c < H; c += 256) {
+  // every lane walks the loop (H < 256 leaves lanes without channels): the segment metadata is read with readlane from
+  // ALL 64 lanes, so the loads that fill it must not sit in divergent control flow; lanes without channels compute on
+  // channel 0 and store nothing
+  for (int c0 = 0; c0 < H; c0 += 256) {
+    const bool act = c0 + lane * 4 < H;
+    const int c = act ? c0 + lane * 4 : 0;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
     for (int base = 0; base < n; base += 64) {
       const int nn = n - base < 64 ? n - base : 64;
@@ -501,7 +511,7 @@ __global__ __launch_bounds__(256) void gnn_edge_reduce_c_kernel(const bf16_t* __
         }
       }
     }
-    *reinterpret_cast<uint2*>(mi + (long long)bj * ldmi + c) = make_uint2(pack2bf(acc[0], acc[1]), pack2bf(acc[2], acc[3]));
+    if (act) *reinterpret_cast<uint2*>(mi + (long long)bj * ldmi + c) = make_uint2(pack2bf(acc[0], acc[1]), pack2bf(acc[2], acc[3]));
   }
 }
 int launch_gnn_edge_reduce_c(const bf16_t* s2, const int* seg, const float* e_w, bf16_t* mi, long long ldmi, int BA, int H, hipStream_t s) {
@@ -520,7 +530,12 @@ __global__ __launch_bounds__(256) void gnn_edge_reduce_bwd_c_kernel(const bf16_t
   const int bj = blockIdx.x * 4 + wave;
   if (bj >= BA) return;
   const int e0 = seg[bj], n = seg[bj + 1] - e0;
-  for (int c = lane * 4; c < H; c += 256) {
+  // every lane walks the loop (H < 256 leaves lanes without channels): the segment metadata is read with readlane from
+  // ALL 64 lanes, so the loads that fill it must not sit in divergent control flow; lanes without channels compute on
+  // channel 0 and store nothing
+  for (int c0 = 0; c0 < H; c0 += 256) {
+    const bool act = c0 + lane * 4 < H;
+    const int c = act ? c0 + lane * 4 : 0;
     const uint2 ug = *reinterpret_cast<const uint2*>(dmi + (long long)bj * lddmi + c);
     const float g[4] = {bflo(ug.x), bfhi(ug.x), bflo(ug.y), bfhi(ug.y)};
     for (int base = 0; base < n; base += 64) {
@@ -534,7 +549,7 @@ __global__ __launch_bounds__(256) void gnn_edge_reduce_bwd_c_kernel(const bf16_t
         for (int q = 0; q < 4; ++q) {
           if (i0 + q >= nn) break;
           const float ww = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_w), i0 + q));
-          *reinterpret_cast<uint2*>(ds2 + (long long)(e0 + base + i0 + q) * H + c) =
+          if (act) *reinterpret_cast<uint2*>(ds2 + (long long)(e0 + base + i0 + q) * H + c) =
               make_uint2(pack2bf(g[0] * ww * dsilu_f(bflo(u[q].x)), g[1] * ww * dsilu_f(bfhi(u[q].x))),
                          pack2bf(g[2] * ww * dsilu_f(bflo(u[q].y)), g[3] * ww * dsilu_f(bfhi(u[q].y))));
         }
@@ -559,7 +574,12 @@ __global__ __launch_bounds__(256) void gnn_edge_pre_bwd_c_kernel(const bf16_t* _
                                                                  bf16_t* __restrict__ dP, long long lddp, float* __restrict__ dw1c,
                                                                  long long dw1c_stride, float* __restrict__ db1, int BA, int H) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int c = lane * 4; c < H; c += 256) {
+  // every lane walks the loop (H < 256 leaves lanes without channels): the segment metadata is read with readlane from
+  // ALL 64 lanes, so the loads that fill it must not sit in divergent control flow; lanes without channels compute on
+  // channel 0 and store nothing
+  for (int c0 = 0; c0 < H; c0 += 256) {
+    const bool act = c0 + lane * 4 < H;
+    const int c = act ? c0 + lane * 4 : 0;
     float sw[4] = {0.f, 0.f, 0.f, 0.f}, sb[4] = {0.f, 0.f, 0.f, 0.f};
     for (int bj = blockIdx.x * 4 + wave; bj < BA; bj += gridDim.x * 4) {
       const int e0 = seg[bj], n = seg[bj + 1] - e0;
@@ -592,16 +612,18 @@ __global__ __launch_bounds__(256) void gnn_edge_pre_bwd_c_kernel(const bf16_t* _
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i) sb[i] += a[i];
-      *reinterpret_cast<uint2*>(dP + (long long)bj * lddp + c) = make_uint2(pack2bf(a[0], a[1]), pack2bf(a[2], a[3]));
-      *reinterpret_cast<uint2*>(dP + (long long)bj * lddp + H + c) = make_uint2(pack2bf(bsum[0], bsum[1]), pack2bf(bsum[2], bsum[3]));
+      if (act) {
+        *reinterpret_cast<uint2*>(dP + (long long)bj * lddp + c) = make_uint2(pack2bf(a[0], a[1]), pack2bf(a[2], a[3]));
+        *reinterpret_cast<uint2*>(dP + (long long)bj * lddp + H + c) = make_uint2(pack2bf(bsum[0], bsum[1]), pack2bf(bsum[2], bsum[3]));
+      }
     }
     // column sums: the 4 waves of the workgroup add up through LDS, then ONE atomic per channel and workgroup (thousands of
     // same-address atomics serialise in the L2: 2048 workgroups x 4 waves made this kernel 1 ms)
     __shared__ float red[2][4][256];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { red[0][wave][lane * 4 + i] = sw[i]; red[1][wave][lane * 4 + i] = sb[i]; }
+    for (int i = 0; i < 4; ++i) { red[0][wave][lane * 4 + i] = act ? sw[i] : 0.f; red[1][wave][lane * 4 + i] = act ? sb[i] : 0.f; }
     __syncthreads();
-    if (wave == 0) {
+    if (wave == 0 && act) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int k = lane * 4 + i;

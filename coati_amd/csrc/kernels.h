@@ -64,6 +64,7 @@ struct GemmArgs {
   int rope_C;
   int rope_hs;
   const int* rope_pos;   // decode: when set, EVERY row sits at token position *rope_pos (device memory; graph replay)
+  const int* rope_row_t; // packed rows: when set, row m sits at token position rope_row_t[m] (instead of m % rope_T)
   // LayerNorm fused into the A load (row-block kernel, K = 256; gemm_rb256_ln_fusable): the operand is LN(ln_x) and is
   // computed while the A slab is loaded; A / lda then name the bf16 buffer that RECEIVES the normalised rows (the weight
   // gradient reads it later), ln_mean / ln_rstd the per-row statistics for the backward
@@ -86,37 +87,6 @@ int launch_gemm_rb256(const GemmArgs& a, int epi, hipStream_t s);
 // ring kernel for N = 256, long K (gemm_ring.hip)
 bool gemm_ring256_supported(const GemmArgs& a, int a_f32, int epi);
 int launch_gemm_ring256(const GemmArgs& a, int epi, hipStream_t s);
-// the same products on 320-row blocks (gemm_ring2.hip): the weight is streamed through LDS once per CU instead of twice
-bool gemm_ring320_supported(const GemmArgs& a, int a_f32, int epi);
-int launch_gemm_ring320(const GemmArgs& a, int epi, hipStream_t s);
-
-// Chained MLP products at C = 256 (gemm_mlp.hip): forward LayerNorm -> W1 -> NewGELU (+ derivative) -> W2 -> residual, and
-// the backward input-gradient chain dY -> W2^T -> x NewGELU' -> W1^T.  The [M, Hd] intermediate feeds the second product
-// from registers; it is still written once (the weight gradients read it).
-struct MlpArgs {
-  int M, C, Hd;
-  // forward: x f32 [M, C] (LayerNorm input and residual); gamma / beta [C]; mean / rstd [M] out
-  const float* x; long long ldx;
-  const float* gamma; const float* beta; float* mean; float* rstd;
-  // forward: a = LayerNorm(x) bf16 [M, C], WRITTEN.  backward: a = dY bf16 [M, C], read
-  bf16_t* a; long long lda;
-  const bf16_t* W1; long long ldw1;   // [Hd, C]  forward: fc1 weight;   backward: fc2 weight transposed
-  const float* b1;                    // [Hd] forward only
-  const bf16_t* W2; long long ldw2;   // [C, Hd]  forward: fc2 weight;   backward: fc1 weight transposed
-  const float* b2;                    // [C] forward only
-  bf16_t* h; long long ldh;           // [M, Hd] out: forward NewGELU(pre); backward dh = (dY W2) * aux
-  void* d;                            // [M, Hd] out, forward: NewGELU'(pre) as 8-bit fixed point (common.h packq8; row stride ldh bytes)
-  const void* aux;                    // [M, Hd] in, backward: the saved 8-bit NewGELU' codes (row stride ldh bytes)
-  void* out; long long ldo;           // forward f32 [M, C] = x + h W2^T + b2;  backward bf16 [M, C] = dh W1
-};
-bool mlp_chain_supported(const MlpArgs& a);
-int launch_mlp_fwd(const MlpArgs& a, hipStream_t s);   // W1 = the column-permuted fc1 copy (launch_mlp_permute_w1); d = 8-bit codes
-int launch_mlp_permute_w1(const bf16_t* W, long long ldw, bf16_t* Wp, long long ldp, int Hd, int C, hipStream_t s);
-int launch_mlp_bwd(const MlpArgs& a, hipStream_t s);
-// Paired-wave forward (gemm_mlp2.hip): same operands, W1 = the plain fc1 weight [Hd, C]
-bool mlp_pair_supported(const MlpArgs& a);
-int launch_mlp_pair_fwd(const MlpArgs& a, hipStream_t s);
-
 // dW[N,K] (f32, atomic +=) = A[M,N]^T * B[M,K];  dbias[N] (atomic +=) = colsum(A) if non-null
 struct WgradArgs {
   const void* A;   // [M,N] bf16 or f32
@@ -137,25 +107,12 @@ struct WgradTile {
   WgradArgs p;
   int tiles_k;   // 128-column tiles along K of this problem
   int tile;      // tile index inside the problem (tile_n * tiles_k + tile_k)
-  // pacing of the workgroups that share this problem's operand panels (see wgrad_dma_table_kernel): epoch counters
-  // [COATI_WG_EPOCHS_MAX] of this problem in device memory (zeroed before the launch), and the number of its tiles
-  // (0 = no pacing)
-  int* pace;
-  int group_size;
-  // split form of the 256-wide launch (wgrad_table_split256): this entry is one SEGMENT -- stages [c_begin, c_end) of the
-  // tile's M range -- and `order` is its place in the tile's commit order (-1: the only contributor); `pace` then points at
-  // the tile's ticket counter
-  int c_begin = 0, c_end = 0, order = -1;
 };
-#define COATI_WG_EPOCH_STAGES 4                 // 64-row stages per pacing epoch
-int wgrad_table_pace_ints(int M);               // epoch counters one problem needs for M rows
-int launch_wgrad_table(const WgradTile* dev_table, int n_tiles, hipStream_t s, int tile_size = 128);   // every entry of a table has the same tile size
+int launch_wgrad_table(const WgradTile* dev_table, int n_tiles, hipStream_t s, int tile_size = 128, int M_rt = 0);   // M_rt > 0: rows of this launch (<= the M of the table entries)   // every entry of a table has the same tile size
 bool wgrad_table_tile256_ok(const WgradArgs& a);
-int launch_wgrad_table_split256(const WgradTile* dev_table, int G, hipStream_t s);   // dev_table: 2 G segment entries   // 256 x 256 tiles (wgrad256_table_kernel): N, K multiples of 256
 #ifdef __cplusplus
 #include <vector>
-int wgrad_table_append(std::vector<WgradTile>& tab, const WgradArgs& a, int* pace, int tile_size = 128);
-int wgrad_table_split256(const std::vector<WgradTile>& tiles, int G, int* tickets, std::vector<WgradTile>& out);   // host: 2 G segments, commit orders   // host: appends the problem's tiles (pace: its epoch counters or null)
+int wgrad_table_append(std::vector<WgradTile>& tab, const WgradArgs& a, int tile_size = 128);   // host: appends the tiles of one problem
 #endif
 
 // C[M,N] (f32) = sum_k A(m,k) B(k,n) [+ bias[n]] [+ C];  A(m,k) = A[m*ars + k*acs], B(k,n) = B[k*brs + n*bcs]
@@ -196,22 +153,32 @@ int launch_ln_finish_batched(const float* partial, long long slot_stride, int nb
 // ------------------------------------------------------------------------------------------------
 // attention, head size 16 (attention.hip)
 // ------------------------------------------------------------------------------------------------
-int launch_attn_fwd(const bf16_t* qkv, bf16_t* y, float* lse, int B, int T, int n_head, int head_size, hipStream_t s);
+// seq_off [B + 1] (optional): packed rows -- sequence b owns rows seq_off[b] .. seq_off[b + 1] of qkv / y / dy / dqkv and has
+// that many tokens (<= T); lse / dscratch keep the padded [B, nh, T] layout
+int launch_attn_fwd(const bf16_t* qkv, bf16_t* y, float* lse, int B, int T, int n_head, int head_size, hipStream_t s,
+                    const int* seq_off = nullptr);
 int launch_attn_bwd(const bf16_t* qkv, const bf16_t* y, const bf16_t* dy, const float* lse, float* dscratch, bf16_t* dqkv,
-                    const float* cos, const float* sin, int B, int T, int n_head, int head_size, hipStream_t s);
+                    const float* cos, const float* sin, int B, int T, int n_head, int head_size, hipStream_t s,
+                    const int* seq_off = nullptr);
 
 // ------------------------------------------------------------------------------------------------
 // embedding / token kernels (embed.hip)
 // ------------------------------------------------------------------------------------------------
+// row_src / off: packed rows (launch_seq_pack below); null = the padded [B, T] layout
 int launch_embed_fwd(const long long* idx, const float* table, const float* injection, int unk_token, float* x,
-                     int B, int T, int C, int V, hipStream_t s);
+                     int B, int T, int C, int V, hipStream_t s, const int* row_src = nullptr, int rows = 0);
 int launch_embed_bwd(const long long* idx, const float* dx, float* dtable, float* dinjection, int unk_token,
-                     int B, int T, int C, int V, hipStream_t s);
+                     int B, int T, int C, int V, hipStream_t s, const int* off = nullptr);
+// Packed rows: the transformer passes run on the concatenation of every row's real prefix (embed.hip).  off [B + 1],
+// row_src / row_t [rows_expect] ints, ypk [rows_expect] (optional: the packed targets); err |= 2 when the device-side total
+// differs from rows_expect (the count the caller computed on the host)
+int launch_seq_pack(const long long* tok, const long long* y, int pad_token, int B, int T, int rows_expect, int* off,
+                    int* row_src, int* row_t, long long* ypk, int* err, hipStream_t s);
 // pos[b] = position of the single stop token of row b; err[0] |= 1 if some row has != 1 stop tokens
 int launch_find_stop(const long long* idx, int stop_token, int* pos, int* err, int B, int T, hipStream_t s);
-int launch_gather_rows(const float* x, const int* pos, float* out, int B, int T, int C, hipStream_t s);
+int launch_gather_rows(const float* x, const int* pos, float* out, int B, int T, int C, hipStream_t s, const int* off = nullptr);
 // dx[b, pos[b], :] += dout[b, :]
-int launch_scatter_rows_add(const float* dout, const int* pos, float* dx, int B, int T, int C, hipStream_t s);
+int launch_scatter_rows_add(const float* dout, const int* pos, float* dx, int B, int T, int C, hipStream_t s, const int* off = nullptr);
 // bad[b] = sum_t tokens[b,t] < 1
 int launch_bad_rows(const long long* tokens, unsigned char* bad, int B, int T, hipStream_t s);
 // inference decode (decode.hip)

@@ -104,7 +104,7 @@ def distributed_train_step(eng, batch, use_point, lr, do_clip=True, optimizer=Tr
     opt_kw: weight_decay / max_norm / betas / eps for Engine.optimizer_step (train_coati.py:145-151, 276)."""
     W, rank = dist.get_world_size(), dist.get_rank()
     h_e, h_s, bad = eng.forward(batch["raw_tokens"], batch["tokens"], batch["atoms"], batch["coords"], use_point,
-                                y_next=batch["y_next"], train=True)
+                                y_next=batch["y_next"], train=True, rows=batch.get("rows"))
     B = h_e.shape[0]
     dS = dC = None
     if do_clip and head == "barlow":
@@ -155,7 +155,7 @@ def distributed_eval_step(eng, batch, use_point, do_clip=True):
     value is the global-batch one."""
     rank = dist.get_rank()
     h_e, h_s, bad = eng.forward(batch["raw_tokens"], batch["tokens"], batch["atoms"], batch["coords"], use_point,
-                                y_next=batch["y_next"], train=False)
+                                y_next=batch["y_next"], train=False, rows=batch.get("rows"))
     if do_clip:
         s_all, c_all, bad_all = all_gather_cat(h_s), all_gather_cat(h_e), all_gather_cat(bad)
         eng.infonce(h_s, h_e, s_all, c_all, bad_all, row0=rank * h_e.shape[0], gscale=0.0)

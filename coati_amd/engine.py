@@ -31,6 +31,10 @@ class ModelConfig:
     unk_token: int = 7
 
 
+# COATI_PACK_ROWS=0 ignores the batches' packed-row counts: every step then runs on the padded [B, T] layout (A/B switch)
+import os as _os
+PACK_ROWS = _os.environ.get("COATI_PACK_ROWS", "1") != "0"
+
 SCAL_AR_SUM, SCAL_AR_COUNT, SCAL_CLIP1, SCAL_CLIP2, SCAL_NVALID, SCAL_GRADNORM, SCAL_ERR = 0, 1, 2, 3, 4, 5, 6
 
 
@@ -124,8 +128,10 @@ class Engine:
             self.workspace = torch.empty(need, device=self.device, dtype=torch.uint8)
         return need
 
-    def forward(self, raw_tokens, tokens, atoms, coords, use_point, y_next=None, train=True):
-        """forward_dist (+ AR loss sums when y_next is given).  Returns (h_e3gnn, h_smiles, bad_rows)."""
+    def forward(self, raw_tokens, tokens, atoms, coords, use_point, y_next=None, train=True, rows=None):
+        """forward_dist (+ AR loss sums when y_next is given).  Returns (h_e3gnn, h_smiles, bad_rows).
+        rows = (rows1, rows2): run both transformer passes on PACKED rows -- the rows' real prefixes only, counts from
+        coati_amd.synthetic.packed_rows / the batch assembler (host ints); None = the padded layout (needed by logits())."""
         B, T1 = raw_tokens.shape
         T2 = tokens.shape[1]
         A = atoms.shape[1]
@@ -141,11 +147,18 @@ class Engine:
         h_s = torch.empty(B, E, device=self.device, dtype=torch.float32)
         bad = torch.empty(B, device=self.device, dtype=torch.uint8)
         self._keep = (raw_tokens, tokens, atoms, coords, use_point, y_next)  # keep inputs alive until backward
+        if rows is not None and PACK_ROWS:
+            r1, r2 = (int(x) for x in (rows.tolist() if isinstance(rows, torch.Tensor) else rows))   # keep the tensor on the host: a device tensor costs a sync
+        else:
+            r1 = r2 = 0
+        if r1 <= 0 or r2 <= 0:
+            r1 = r2 = 0          # nothing to pack (e.g. every row failed to tokenise): padded layout
         _lib.check(self.l.coati_engine_forward(self.h, ptr(self.workspace), self.workspace.numel(), B, T1, T2, A, ptr(raw_tokens), ptr(tokens),
                                                ptr(y_next), ptr(atoms), ptr(coords), ptr(use_point), ptr(h_e), ptr(h_s),
                                                ptr(bad), ptr(self.scal), 1 if (train and self.grads is not None) else 0,
-                                               stream()), "coati_engine_forward")
+                                               r1, r2, stream()), "coati_engine_forward")
         self._shape = (B, T1, T2, A)
+        self._packed = r1 > 0
         return h_e, h_s, bad
 
     def encode(self, raw_tokens=None, atoms=None, coords=None):
@@ -171,6 +184,8 @@ class Engine:
         return h_s, h_e
 
     def logits(self):
+        if getattr(self, "_packed", False):
+            raise RuntimeError("logits(): the last forward ran on packed rows; call forward(..., rows=None)")
         B, _, T2, _ = self._shape
         V = self.cfg.n_tok
         ld = (V + 7) // 8 * 8
@@ -204,7 +219,7 @@ class Engine:
         head: "infonce" (clip_e2e.py:27-47) or "barlow" (BASELINE configs[3]; parity unpinned, see barlow.py).
         opt_kw: weight_decay / max_norm / betas / eps forwarded to optimizer_step (train_coati.py:145-151, 276)."""
         h_e, h_s, bad = self.forward(batch["raw_tokens"], batch["tokens"], batch["atoms"], batch["coords"], use_point,
-                                     y_next=batch["y_next"], train=True)
+                                     y_next=batch["y_next"], train=True, rows=batch.get("rows"))
         dS = dC = None
         if do_clip and head == "barlow":
             from .barlow import barlow_head
@@ -221,7 +236,7 @@ class Engine:
     def eval_step(self, batch, use_point, do_clip=True):
         """Forward + both losses, no backward (the reference's test partition runs under torch.no_grad())."""
         h_e, h_s, bad = self.forward(batch["raw_tokens"], batch["tokens"], batch["atoms"], batch["coords"], use_point,
-                                     y_next=batch["y_next"], train=False)
+                                     y_next=batch["y_next"], train=False, rows=batch.get("rows"))
         if do_clip:
             self.infonce(h_s, h_e, h_s, h_e, bad, row0=0, gscale=0.0)
         return h_e, h_s, bad
@@ -232,6 +247,8 @@ class Engine:
         err = int(s[SCAL_ERR:SCAL_ERR + 1].view(torch.int32)[0])
         if err & 1:
             raise RuntimeError("Some smiles in the batch do not have stop tokens. Did some tokenizations fail?")
+        if err & 2:
+            raise RuntimeError("packed rows: the row counts passed to forward() differ from what the device found in the tokens")
         ar = float(s[SCAL_AR_SUM] / s[SCAL_AR_COUNT]) if s[SCAL_AR_COUNT] > 0 else 0.0
         nv = float(s[SCAL_NVALID])
         clip = float(0.5 * (s[SCAL_CLIP1] + s[SCAL_CLIP2]) / nv) if nv > 0 else 0.0

@@ -357,6 +357,13 @@ def tensorize_batch(batch: Dict[str, Any], tokenizer, dtype=torch.float, device=
     for col in ("tokens", "atoms", "raw_tokens"):
         if not isinstance(out[col], torch.Tensor):
             out[col] = torch.tensor(out[col], requires_grad=False)
+    if not out["tokens"].is_cuda and not out["raw_tokens"].is_cuda and tokenizer.pad_token == 0:
+        # packed-row counts (coati_hip.h, coati_engine_forward rows1 / rows2) while the tokens are still on the host: the
+        # engine then skips the padding the reference computes (a target y_next[t] != -1 implies a token at t + 1, so the
+        # token matrix alone gives the counts)
+        from ...synthetic import packed_rows
+        out["rows"] = torch.tensor(packed_rows(out["raw_tokens"], out["tokens"]), dtype=torch.int64)
+    for col in ("tokens", "atoms", "raw_tokens"):
         out[col] = out[col].to(device, torch.long)
     if not isinstance(out["coords"], torch.Tensor):
         out["coords"] = torch.tensor(out["coords"], requires_grad=False)

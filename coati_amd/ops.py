@@ -69,7 +69,7 @@ def wgrad(A, Bm, dW, dbias=None, n_out=0):
     return dW
 
 
-def wgrad_grouped(problems, tile_size=256, split=False):
+def wgrad_grouped(problems, tile_size=256):
     """problems: list of (A[M,N] bf16, Bm[M,K] bf16, dW[N,K] f32, dbias[N] f32), all with the same M; one launch, no atomics
     on dW: dW += A^T @ Bm, dbias += colsum(A)."""
     import ctypes
@@ -79,12 +79,16 @@ def wgrad_grouped(problems, tile_size=256, split=False):
         assert A.dtype == torch.bfloat16 and Bm.dtype == torch.bfloat16 and dW.dtype == torch.float32 and db.dtype == torch.float32
     M = problems[0][0].shape[0]
     PP, LL, II = ctypes.c_void_p * n, ctypes.c_int64 * n, ctypes.c_int * n
+    Ns, Ks = II(*[q[0].shape[1] for q in problems]), II(*[q[1].shape[1] for q in problems])
+    nbytes = int(_lib.lib().coati_wgrad_grouped_workspace_bytes(n, Ns, Ks, tile_size))
+    ws = torch.empty(max(nbytes, 1), device=problems[0][0].device, dtype=torch.uint8)   # the caller owns the tile table
     _lib.call("coati_wgrad_grouped", n,
               PP(*[ptr(q[0]) for q in problems]), LL(*[q[0].stride(0) for q in problems]),
               PP(*[ptr(q[1]) for q in problems]), LL(*[q[1].stride(0) for q in problems]), M,
-              II(*[q[0].shape[1] for q in problems]), II(*[q[1].shape[1] for q in problems]),
+              Ns, Ks,
               PP(*[ptr(q[2]) for q in problems]), LL(*[q[2].stride(0) for q in problems]),
-              PP(*[ptr(q[3]) for q in problems]), -256 if (split and tile_size == 256) else tile_size, stream())
+              PP(*[ptr(q[3]) for q in problems]), tile_size, ptr(ws), nbytes, stream())
+    return ws
 
 
 def sgemm(A, Bm, trans_a=False, trans_b=False, bias=None, alpha=1.0, out=None, accumulate=False):
@@ -164,6 +168,38 @@ def attn_bwd(qkv, y, dy, lse, B, T, n_head, cos, sin, hs=16):
     return dqkv
 
 
+def seq_pack(tok, y=None, pad=0, rows=None):
+    """row map of the packed layout of a padded [B, T] token matrix (coati_seq_pack): off [B + 1], row_src, row_t [rows], ypk, err"""
+    B, T = tok.shape
+    if rows is None:
+        from .synthetic import packed_rows
+        rows = packed_rows(tok, tok, y)[1] if y is not None else packed_rows(tok, tok)[0]
+    dev = tok.device
+    off = torch.empty(B + 1, device=dev, dtype=torch.int32)
+    row_src = torch.empty(rows, device=dev, dtype=torch.int32)
+    row_t = torch.empty(rows, device=dev, dtype=torch.int32)
+    ypk = torch.empty(rows, device=dev, dtype=torch.int64) if y is not None else None
+    err = torch.zeros(4, device=dev, dtype=torch.int32)
+    _lib.call("coati_seq_pack", ptr(tok), ptr(y), pad, B, T, rows, ptr(off), ptr(row_src), ptr(row_t), ptr(ypk), ptr(err), stream())
+    return off, row_src, row_t, ypk, err
+
+
+def attn_fwd_varlen(qkv, off, B, T, n_head, hs=16):
+    """causal attention on packed rows: sequence b = rows off[b] .. off[b + 1] of qkv (at most T tokens)"""
+    _need_cuda(qkv)
+    y = torch.zeros(qkv.shape[0], n_head * hs, device=qkv.device, dtype=BF16)
+    lse = torch.zeros(B, n_head, T, device=qkv.device, dtype=torch.float32)
+    _lib.call("coati_attn_fwd_varlen", ptr(qkv), ptr(y), ptr(lse), ptr(off), B, T, n_head, hs, stream())
+    return y, lse
+
+
+def attn_bwd_varlen(qkv, y, dy, lse, off, B, T, n_head, cos, sin, hs=16):
+    dqkv = torch.zeros_like(qkv)
+    dscratch = torch.empty(B, n_head, T, device=qkv.device, dtype=torch.float32)
+    _lib.call("coati_attn_bwd_varlen", ptr(qkv), ptr(y), ptr(dy), ptr(lse), ptr(dscratch), ptr(dqkv), ptr(cos), ptr(sin), ptr(off), B, T, n_head, hs, stream())
+    return dqkv
+
+
 def embed_fwd(idx, table, injection=None, unk=7):
     B, T = idx.shape
     V, C = table.shape
@@ -204,46 +240,3 @@ def ce_bwd(a, W, target, lse, scal):
     _lib.call("coati_gemm_ce_bwd", ptr(a), a.stride(0), ptr(W), W.stride(0), M, V, K, ptr(d), Vpad, Vpad, ptr(lse),
               ptr(target), ptr(scal), stream())
     return d
-
-
-def mlp_permute_w1(W1):
-    """column-permuted copy of the fc1 weight the chained forward kernel reads (csrc/gemm_mlp.hip)"""
-    _need_cuda(W1)
-    Wp = torch.empty_like(W1)
-    _lib.call("coati_mlp_permute_w1", ptr(W1), W1.stride(0), ptr(Wp), Wp.stride(0), W1.shape[0], W1.shape[1], stream())
-    return Wp
-
-
-def mlp_fwd(x, gamma, beta, W1, b1, W2, b2, W1p=None, paired=False):
-    """chained LayerNorm -> W1 -> NewGELU -> W2 -> residual (C = 256).  Returns (out f32, a bf16, mean, rstd, g bf16, dg u8 codes).
-    paired=True: the paired-wave kernel (gemm_mlp2.hip, plain W1)."""
-    _need_cuda(x, W1, W2)
-    M, C = x.shape
-    Hd = W1.shape[0]
-    dev = x.device
-    if paired:
-        W1p = W1
-    elif W1p is None:
-        W1p = mlp_permute_w1(W1)
-    a = torch.empty(M, C, device=dev, dtype=torch.bfloat16)
-    g = torch.empty(M, Hd, device=dev, dtype=torch.bfloat16)
-    dg = torch.empty(M, Hd, device=dev, dtype=torch.uint8)
-    mean = torch.empty(M, device=dev, dtype=torch.float32)
-    rstd = torch.empty(M, device=dev, dtype=torch.float32)
-    out = torch.empty(M, C, device=dev, dtype=torch.float32)
-    _lib.call("coati_mlp_fwd_paired" if paired else "coati_mlp_fwd", ptr(x), x.stride(0), ptr(gamma), ptr(beta), ptr(W1p), W1p.stride(0), ptr(b1), ptr(W2), W2.stride(0),
-              ptr(b2), M, C, Hd, ptr(a), C, ptr(mean), ptr(rstd), ptr(g), ptr(dg), Hd, ptr(out), C, stream())
-    return out, a, mean, rstd, g, dg
-
-
-def mlp_dgrad(dY, W2T, W1T, dgelu):
-    """chained dh = (dY W2) * dequant(dgelu) ; dA = dh W1 (C = 256).  W2T [Hd, C], W1T [C, Hd], dgelu u8 codes.  Returns (dA bf16, dh bf16)."""
-    _need_cuda(dY, W2T, W1T, dgelu)
-    assert dgelu.dtype == torch.uint8
-    M, C = dY.shape
-    Hd = W2T.shape[0]
-    dh = torch.empty(M, Hd, device=dY.device, dtype=torch.bfloat16)
-    dA = torch.empty(M, C, device=dY.device, dtype=torch.bfloat16)
-    _lib.call("coati_mlp_dgrad", ptr(dY), dY.stride(0), ptr(W2T), W2T.stride(0), ptr(W1T), W1T.stride(0), ptr(dgelu), M, C, Hd,
-              ptr(dh), Hd, ptr(dA), C, stream())
-    return dA, dh

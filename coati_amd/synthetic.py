@@ -16,7 +16,23 @@ def y_next_from_tokens(tokens):
     return y
 
 
-def make_batch(B, T, A, V, seed=1234, n_special=1596, p_clip=0.9, p_bad=0.01, min_len=16, device="cpu"):
+def packed_rows(raw_tokens, tokens, y_next=None):
+    """Host-side row counts of the packed layout (include/coati_hip.h, coati_engine_forward rows1 / rows2): per row
+    1 + the last position that holds a non-[PAD] token (or, for `tokens`, a target that is not -1), summed over the batch.
+    The batch assembler calls this while the tokens are still on the host; on device tensors it costs one synchronisation."""
+    def count(tok, y):
+        live = tok != PAD
+        if y is not None:
+            live = live | (y >= 0)
+        T = tok.shape[1]
+        last = (live.to(torch.int32) * torch.arange(1, T + 1, device=tok.device, dtype=torch.int32)).amax(dim=1)
+        return int(last.sum().item())
+    return count(raw_tokens, None), count(tokens, y_next)
+
+
+def make_batch(B, T, A, V, seed=1234, n_special=1596, p_clip=0.9, p_bad=0.01, min_len=16, device="cpu", with_rows=False):
+    """with_rows: add batch["rows"] = CPU int64 [rows1, rows2], the packed-row counts (packed_rows above) -- Engine.train_step
+    then runs the transformer passes on the rows' real prefixes only."""
     g = torch.Generator().manual_seed(seed)
     n_special = min(n_special, V - 2)
     Lmax = T - 4                      # [CLIP][UNK][SMILES] body [STOP]
@@ -53,5 +69,8 @@ def make_batch(B, T, A, V, seed=1234, n_special=1596, p_clip=0.9, p_bad=0.01, mi
     coords = (torch.randn(B, A, 3, generator=g) * 1.5).float()
     batch = dict(raw_tokens=raw, tokens=tok, y_next=y_next_from_tokens(tok), atoms=atoms, coords=coords)
     use_point = torch.rand(B, generator=g) > 0.5
+    rows = packed_rows(raw, tok, batch["y_next"])        # on the host, before the upload (what a data loader does)
     batch = {k: v.to(device) for k, v in batch.items()}
+    if with_rows:
+        batch["rows"] = torch.tensor(rows, dtype=torch.int64)     # stays on the host
     return batch, use_point.to(device)

@@ -249,7 +249,7 @@ def train_autoencoder(gpu, args, dataset=None, tokenizer=None):
                 break
             i += 1
             if ok:
-                dev = {k: v.to(device) for k, v in batch.items() if isinstance(v, torch.Tensor)}
+                dev = {k: (v if k == "rows" else v.to(device)) for k, v in batch.items() if isinstance(v, torch.Tensor)}   # "rows": host-side packed-row counts
                 B = dev["atoms"].shape[0]
             if not ok:
                 print("a row was lost, skipping batch")          # train_coati.py:229-234

@@ -61,31 +61,6 @@ int coati_gemm_nt(const void* A, int a_f32, int64_t lda, const uint16_t* B, int6
                   void* C, int64_t ldc, int n_store, const float* bias, const void* aux_in, void* aux_out,
                   int64_t ld_aux, int epi, void* stream);
 
-/* Transformer MLP as ONE chained, wave-specialised kernel at C = 256 (RotaryBlock.mlpf, basic_transformer.py:157-174, with
- * ln_2 in front):
- *   a = LayerNorm(x; gamma, beta) (bf16, written with mean / rstd);  g = NewGELU(a W1^T + b1) (bf16 [M, Hd], written);
- *   dg = NewGELU'(a W1^T + b1) as 8-bit fixed point (code q <-> q/200 - 0.13; [M, Hd] bytes, written);
- *   out = x + g W2^T + b2 (f32).  W2 [C, Hd] bf16 row-major; W1p = the fc1 weight [Hd, C] with its columns permuted inside
- *   every group of 32 (coati_mlp_permute_w1: position 8q + i <- channel 16 (i >> 2) + 4 q + (i & 3)).  The [M, Hd]
- *   intermediate feeds the second product from registers and x is read once.  -2 for shapes it does not take (C != 256). */
-int coati_mlp_permute_w1(const uint16_t* W1, int64_t ldw, uint16_t* W1p, int64_t ldp, int Hd, int C, void* stream);
-int coati_mlp_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, const uint16_t* W1p, int64_t ldw1,
-                  const float* b1, const uint16_t* W2, int64_t ldw2, const float* b2, int M, int C, int Hd, uint16_t* a,
-                  int64_t lda, float* mean, float* rstd, uint16_t* g, uint8_t* dg, int64_t ldh, float* out, int64_t ldo,
-                  void* stream);
-/* The same forward as ONE kernel of paired waves (gemm_mlp2.hip): a producer wave runs FC1 + NewGELU on 32-unit tiles and hands
- * each g tile through LDS to its consumer wave, which accumulates FC2 into a 32 x 256 block initialised with x + b2.  W1 is
- * the plain fc1 weight [Hd, C] (no column permutation); every other operand as coati_mlp_fwd. */
-int coati_mlp_fwd_paired(const float* x, int64_t ldx, const float* gamma, const float* beta, const uint16_t* W1, int64_t ldw1,
-                         const float* b1, const uint16_t* W2, int64_t ldw2, const float* b2, int M, int C, int Hd, uint16_t* a,
-                         int64_t lda, float* mean, float* rstd, uint16_t* g, uint8_t* dg, int64_t ldh, float* out, int64_t ldo,
-                         void* stream);
-/* the matching input-gradient chain: dh = (dY W2) * dequant(dgelu) (bf16 [M, Hd], written);  dA = dh W1 (bf16 [M, C]).
- *   W2T = W2 transposed [Hd, C], W1T = W1 transposed [C, Hd] (the engine's transposed bf16 shadows). */
-int coati_mlp_dgrad(const uint16_t* dY, int64_t lddy, const uint16_t* W2T, int64_t ldw2t, const uint16_t* W1T,
-                    int64_t ldw1t, const uint8_t* dgelu, int M, int C, int Hd, uint16_t* dh, int64_t ldh,
-                    uint16_t* dA, int64_t ldda, void* stream);
-
 /* lm_head + cross-entropy without materialising logits (smiles_xformer.py:453 + train_coati.py:260-265):
  * partial[M, ceil(V/128)] receives per-tile (max, sum exp) pairs; coati_ce_finish merges them into lse[M] and
  * adds sum(lse - logit[target]) to scal[0] and the number of targets != -1 to scal[1]. */
@@ -104,14 +79,15 @@ int coati_wgrad(const void* A, int a_f32, int64_t lda, const uint16_t* B, int64_
                 float* dW, int64_t ldw, float* dbias, int n_out, void* stream);
 
 /* The same for a LIST of problems that share M, in ONE launch and without fp32 atomics on dW: one workgroup per output tile
- * (tile_size 128 or 256; 256 needs every N and K to be a multiple of 256; -256 = the 256-wide tiles in the split form: with
- * exactly 192 tiles, three quarters of M on a tile's main workgroup and the last quarter on a helper, committed in a fixed
- * order through ticket counters -- an experiment, no faster) streams all M rows of its tile.  bf16 A, dbias
+ * (tile_size 128 or 256; 256 needs every N and K to be a multiple of 256) streams all M rows of its tile.  bf16 A, dbias
  * required.  This is how the engine computes the 4 x n_layer Linear gradients of a transformer pass (the reference's
- * loss.backward() through RotaryBlock, basic_transformer.py:126-174).  Synchronises the stream (stand-alone entry point). */
+ * loss.backward() through RotaryBlock, basic_transformer.py:126-174).  The tile table is written into `workspace` (device
+ * memory of the caller, coati_wgrad_grouped_workspace_bytes; it must stay untouched until the launch has run); nothing is
+ * allocated and the stream is not synchronised. */
+int64_t coati_wgrad_grouped_workspace_bytes(int n_problems, const int* N, const int* K, int tile_size);
 int coati_wgrad_grouped(int n_problems, const uint16_t* const* A, const int64_t* lda, const uint16_t* const* B, const int64_t* ldb,
                         int M, const int* N, const int* K, float* const* dW, const int64_t* ldw, float* const* dbias,
-                        int tile_size, void* stream);
+                        int tile_size, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* exact-f32 GEMM with generic strides: C[M,N] = alpha * sum_k A[m*ars + k*acs] * B[k*brs + n*bcs] (+ bias[n])
  * (+ C when accumulate).  Used for the [B,256] projection heads and the InfoNCE logits (clip_e2e.py:36-37). */
@@ -144,6 +120,18 @@ int coati_attn_bwd(const uint16_t* qkv, const uint16_t* y, const uint16_t* dy, c
 /* head-size-generic variants (head_size = 16 or 32; the un-suffixed entry points are head size 16): qkv / cache / rope
    tables as above with 16 replaced by head_size (rope tables [n_seq, head_size]) */
 int coati_attn_fwd_hs(const uint16_t* qkv, uint16_t* y, float* lse, int B, int T, int n_head, int head_size, void* stream);
+/* Packed rows (variable-length sequences without padding, see coati_engine_forward): coati_seq_pack derives the row map of
+ * a padded token matrix tok [B, T] (y optional [B, T] targets): off [B + 1], row_src / row_t [rows_expect] int32, ypk
+ * [rows_expect] int64 (optional), err |= 2 when the device-side row count differs from rows_expect.  The _varlen attention
+ * entry points take seq_off = off: sequence b owns rows off[b] .. off[b + 1] of qkv / y / dy / dqkv; lse and dscratch keep
+ * the padded [B, nh, T] layout. */
+int coati_seq_pack(const int64_t* tok, const int64_t* y, int pad_token, int B, int T, int rows_expect, int32_t* off,
+                   int32_t* row_src, int32_t* row_t, int64_t* ypk, int32_t* err, void* stream);
+int coati_attn_fwd_varlen(const uint16_t* qkv, uint16_t* y, float* lse, const int32_t* seq_off, int B, int T, int n_head,
+                          int head_size, void* stream);
+int coati_attn_bwd_varlen(const uint16_t* qkv, const uint16_t* y, const uint16_t* dy, const float* lse, float* dscratch,
+                          uint16_t* dqkv, const float* cos_t, const float* sin_t, const int32_t* seq_off, int B, int T,
+                          int n_head, int head_size, void* stream);
 int coati_attn_bwd_hs(const uint16_t* qkv, const uint16_t* y, const uint16_t* dy, const float* lse, float* dscratch,
                       uint16_t* dqkv, const float* cos_t, const float* sin_t, int B, int T, int n_head, int head_size,
                       void* stream);
@@ -268,11 +256,20 @@ int coati_engine_refresh_shadows(coati_engine* e, void* stream);
 /* forward_dist + AR loss.  raw_tokens [B,T1], tokens [B,T2], y_next [B,T2], atoms [B,A] int64; coords [B,A,3] f32;
  * use_point [B] uint8 (1 -> inject the point-cloud token; replaces `rand(B) > p_clip_emb_smi`, clip_e2e.py:802).
  * Outputs: h_e3gnn, h_smiles [B,E] f32; bad_rows [B] uint8; scal[0] = sum AR loss, scal[1] = #targets,
- * scal[6] = error flags (bit 0: a raw_tokens row without exactly one [STOP]).  Zeroes the gradient buffer. */
+ * scal[6] = error flags (bit 0: a raw_tokens row without exactly one [STOP]).  Zeroes the gradient buffer.
+ *
+ * rows1 / rows2 > 0: PACKED ROWS.  clip_ar_xform pads every row to the batch's longest (clip_e2e.py:288-330) and the reference
+ * computes the padding; under causal attention the positions behind a row's last token influence nothing that reaches a
+ * loss (their targets are -1, train_coati.py:260-265; the encoder reads the [STOP] position only, smiles_xformer.py:50-68),
+ * so both transformer passes then run on the concatenation of the rows' real prefixes: rows1 = sum over rows of
+ * (1 + last non-[PAD] position) of raw_tokens, rows2 the same for tokens (a position also counts when its y_next is not
+ * -1).  The caller computes the counts on the host (the batch assembler has the tokens there: no device -> host sync); the
+ * device recomputes them and sets scal[6] bit 1 on a mismatch.  Losses, gradients, h_e3gnn / h_smiles are those of the padded
+ * run; coati_engine_logits is not available after a packed forward.  rows1 = rows2 = 0: the padded layout. */
 int coati_engine_forward(coati_engine* e, void* workspace, int64_t workspace_bytes, int B, int T1, int T2, int A,
                          const int64_t* raw_tokens, const int64_t* tokens, const int64_t* y_next,
                          const int64_t* atoms, const float* coords, const uint8_t* use_point, float* h_e3gnn,
-                         float* h_smiles, uint8_t* bad_rows, float* scal, int train, void* stream);
+                         float* h_smiles, uint8_t* bad_rows, float* scal, int train, int64_t rows1, int64_t rows2, void* stream);
 /* Inference encoders alone: e3gnn_smiles_clip_e2e.encode_tokens (clip_e2e.py:448-452) when raw_tokens + h_smiles are
  * given, .encode_points (clip_e2e.py:454-463) when atoms + coords + h_e3gnn are given (either pair may be null).  Only
  * the requested tower runs; workspace as for coati_engine_forward with T2 = 1.  scal[6] bit 0: a row without exactly

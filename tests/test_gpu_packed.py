@@ -1,0 +1,145 @@
+"""Packed rows: the transformer passes on the concatenation of the rows' real prefixes instead of the padded [B, T] matrices
+(include/coati_hip.h, coati_engine_forward rows1 / rows2).  The reference computes the padding (clip_e2e.py:288-330 pads to
+the longest row); positions behind a row's last token cannot influence a loss or a gradient under causal attention, so the
+packed step must reproduce the padded one: the row map bit-exactly, attention per sequence, losses and every gradient of the
+engine -- and the reference's own golden step."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from tests.gpu_util import check, log, rbf  # noqa: E402
+
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from coati_amd import ops as o
+    return o
+
+
+def test_seq_pack_row_map_bit_exact(ops):
+    from coati_amd.synthetic import make_batch, packed_rows
+    batch, _ = make_batch(37, 29, 5, 90, seed=4, n_special=12, p_bad=0.15, min_len=3, with_rows=True)
+    tok, y = batch["tokens"], batch["y_next"]
+    r1, r2 = batch["rows"].tolist()
+    for name, t, yy, rows in (("raw", batch["raw_tokens"], None, r1), ("tok", tok, y, r2)):
+        live = t != 0
+        if yy is not None:
+            live = live | (yy >= 0)
+        T = t.shape[1]
+        lens = (live.int() * torch.arange(1, T + 1)).amax(1)
+        assert int(lens.sum()) == rows
+        off_ref = torch.cat([torch.zeros(1, dtype=torch.long), lens.cumsum(0)])
+        src_ref = torch.cat([torch.arange(int(l)) + b * T for b, l in enumerate(lens)])
+        off, row_src, row_t, ypk, err = ops.seq_pack(t.to(DEV), None if yy is None else yy.to(DEV), rows=rows)
+        assert torch.equal(off.cpu().long(), off_ref), name
+        assert torch.equal(row_src.cpu().long(), src_ref), name
+        assert torch.equal(row_t.cpu().long(), src_ref % T), name
+        if yy is not None:
+            assert torch.equal(ypk.cpu(), yy.reshape(-1)[src_ref])
+        assert int(err[0]) == 0
+        # a wrong host-side count is detected, not silently used
+        *_, err = ops.seq_pack(t.to(DEV), None if yy is None else yy.to(DEV), rows=rows - 1)
+        assert int(err[0]) & 2
+
+
+@pytest.mark.parametrize("B,T,nh,hs", [(9, 80, 16, 16), (7, 128, 8, 16), (5, 33, 4, 32), (6, 100, 16, 32), (4, 200, 4, 16)])
+def test_attention_varlen_equals_padded_rows(ops, B, T, nh, hs):
+    """every sequence of a packed batch gets what the padded kernels give its real rows (same kernels, same block walk:
+    bit-identical), one launch per block count"""
+    C = nh * hs
+    g = torch.Generator().manual_seed(B * T)
+    lens = torch.randint(1, T + 1, (B,), generator=g)
+    lens[0] = T
+    lens[1] = 1
+    if B > 2:
+        lens[2] = 32
+    qkv = rbf(torch.randn(B, T, 3 * C, generator=g))
+    dy = rbf(torch.randn(B, T, C, generator=g))
+    keep = torch.arange(T).unsqueeze(0) < lens.unsqueeze(1)
+    cos, sin = ops.rope_tables(256, hs, device=DEV)
+    # padded run on rows whose padding is zero (what the engine's padded path sees is irrelevant: causal)
+    qd = qkv.to(DEV).bfloat16().view(B * T, 3 * C)
+    dyp = (dy * keep.unsqueeze(-1)).to(DEV).bfloat16().view(B * T, C)
+    y_pad, lse_pad = ops.attn_fwd(qd, B, T, nh, hs)
+    dq_pad = ops.attn_bwd(qd, y_pad, dyp, lse_pad, B, T, nh, cos, sin, hs)
+    idx = keep.view(-1).nonzero().squeeze(1).to(DEV)
+    off = torch.cat([torch.zeros(1, dtype=torch.long), lens.cumsum(0)]).to(DEV, torch.int32)
+    qp, dyk = qd[idx].contiguous(), dyp[idx].contiguous()
+    y_pk, lse_pk = ops.attn_fwd_varlen(qp, off, B, T, nh, hs)
+    dq_pk = ops.attn_bwd_varlen(qp, y_pk, dyk, lse_pk, off, B, T, nh, cos, sin, hs)
+    check(f"varlen attn fwd B{B} T{T} hs{hs}", y_pk.float(), y_pad[idx].float(), 0.0)
+    lk = keep.unsqueeze(1).expand(B, nh, T).to(DEV)
+    check(f"varlen attn lse B{B} T{T}", lse_pk[lk], lse_pad[lk], 0.0)
+    # (the rotation back of dq / dk uses the token position: same position in both layouts)
+    check(f"varlen attn bwd B{B} T{T} hs{hs}", dq_pk.float(), dq_pad[idx].float(), 0.0 if T <= 128 else 2e-3)
+
+
+def _both_steps(kw, batch, up, seed):
+    from oracle import coati_oracle as O
+    from coati_amd.engine import Engine, ModelConfig
+    P = O.init_params(O.OracleConfig(**kw), seed=seed)
+    out = []
+    for packed in (False, True):
+        eng = Engine(ModelConfig(**kw), DEV)
+        eng.load_state_dict(P)
+        db = {k: (v if k == "rows" else v.to(DEV)) for k, v in batch.items() if packed or k != "rows"}
+        h_e, h_s, bad = eng.train_step(db, up.to(DEV), lr=1e-3, optimizer=False)
+        assert getattr(eng, "_packed") == packed
+        out.append((eng.losses(), {k: v.cpu().clone() for k, v in eng.named_views("grads").items()}, h_e.cpu(), h_s.cpu()))
+    return out
+
+
+@pytest.mark.parametrize("name,kw,shape", [
+    ("medium", dict(n_layer_e3gnn=2, n_layer_xformer=3, n_hidden_xformer=128, n_hidden_e3nn=128, n_embd_common=128, n_head=8, n_seq=64, n_tok=300), (24, 40, 12)),
+    ("wide", dict(n_layer_e3gnn=1, n_layer_xformer=2, n_hidden_xformer=256, n_hidden_e3nn=256, n_embd_common=256, n_head=16, n_seq=250, n_tok=1003), (700, 83, 16)),
+    ("hs32", dict(n_layer_e3gnn=1, n_layer_xformer=2, n_hidden_xformer=128, n_hidden_e3nn=64, n_embd_common=128, n_head=4, n_seq=140, n_tok=200), (20, 130, 9)),
+])
+def test_packed_step_equals_padded_step(name, kw, shape):
+    """the engine's packed step against its own padded step (same weights, same batch): forward embeddings identical, losses
+    to fp32 summation order, gradients to the accumulation order of the weight-gradient kernels"""
+    from coati_amd.synthetic import make_batch
+    B, T, A = shape
+    batch, up = make_batch(B, T, A, kw["n_tok"], seed=B + T, n_special=12, p_bad=0.05, min_len=5, with_rows=True)
+    (Lp, gp, hep, hsp), (Lk, gk, hek, hsk) = _both_steps(kw, batch, up, seed=5)
+    log(f"packed vs padded [{name}]: rows {batch['rows'].tolist()} of {B * (T - 2)} / {B * T}; losses padded {Lp} packed {Lk}")
+    check(f"packed [{name}] h_e3gnn", hek, hep, 0.0)
+    check(f"packed [{name}] h_smiles", hsk, hsp, 1e-6)
+    assert Lk["n_targets"] == Lp["n_targets"] and Lk["n_valid"] == Lp["n_valid"]
+    assert abs(Lk["ar_loss"] - Lp["ar_loss"]) <= 2e-6 * abs(Lp["ar_loss"]) and abs(Lk["clip_loss"] - Lp["clip_loss"]) <= 2e-6 * abs(Lp["clip_loss"])
+    worst = sorted(((float((gk[k] - gp[k]).abs().max()) / max(float(gp[k].abs().max()), 1e-30), k) for k in gp if float(gp[k].abs().max()) > 0), reverse=True)
+    log(f"packed vs padded [{name}]: worst gradient deviations {worst[:3]}")
+    assert worst[0][0] <= 2e-3, worst[:5]      # bf16 re-rounding where an f32 sum changed its last bit
+
+
+def test_packed_golden_step_vs_reference(golden_dir):
+    """the reference's own golden step (small model: forward_dist embeddings, losses, every parameter gradient), packed"""
+    from coati_amd.engine import Engine, ModelConfig
+    from coati_amd.synthetic import packed_rows
+    z = np.load(os.path.join(golden_dir, "small_model.npz"))
+    P = {k: torch.from_numpy(z[k]) for k in z.files}
+    v = np.load(os.path.join(golden_dir, "small_vectors.npz"))
+    vec = {k: torch.from_numpy(v[k]) for k in v.files}
+    G = np.load(os.path.join(golden_dir, "small_step_grads.npz"))
+    eng = Engine(ModelConfig(n_layer_e3gnn=2, n_layer_xformer=2, n_hidden_xformer=64, n_hidden_e3nn=64, n_embd_common=64, n_head=4, n_seq=24, n_tok=48), DEV)
+    eng.load_state_dict(P)
+    batch = {k: vec["b_" + k] for k in ("raw_tokens", "tokens", "atoms", "coords", "y_next")}
+    rows = torch.tensor(packed_rows(batch["raw_tokens"], batch["tokens"], batch["y_next"]))
+    db = {k: t.to(DEV) for k, t in batch.items()}
+    db["rows"] = rows
+    up = torch.ones(batch["atoms"].shape[0], dtype=torch.bool, device=DEV)
+    h_e, h_s, _ = eng.train_step(db, up, lr=5e-4, optimizer=False)
+    assert eng._packed
+    L = eng.losses()
+    check("packed golden h_e3gnn", h_e.cpu(), vec["fd_p0_h_e3gnn"], 6.5e-3)
+    check("packed golden h_smiles", h_s.cpu(), vec["fd_p0_h_smiles"], 6.5e-3)
+    check("packed golden ar", torch.tensor([L["ar_loss"]]), vec["step_ar"].reshape(1), 1e-3)
+    check("packed golden clip", torch.tensor([L["clip_loss"]]), vec["step_clip"].reshape(1), 1e-3)
+    grads = eng.named_views("grads")
+    for k in sorted(eng.layout):
+        check("packed golden grad " + k, grads[k].cpu(), torch.from_numpy(G["grad." + k]), 3.8e-2)

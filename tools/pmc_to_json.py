@@ -22,4 +22,5 @@ if write is not None:
     out["hbm_write_bytes_per_launch"] = write * 1024
 if fetch is not None and write is not None:
     out["hbm_bytes_per_launch"] = out["hbm_read_bytes_per_launch"] + out["hbm_write_bytes_per_launch"]
+out["layout"] = os.environ.get("PMC_LAYOUT", "packed")
 print(json.dumps({site: out}, indent=1))
