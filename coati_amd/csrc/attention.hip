@@ -236,8 +236,8 @@ __device__ __forceinline__ f32x16 score_block(const bf16_t* Xs, int blk, const b
 
 // Sequence b of a kernel: rows [row0, row0 + T) of the token-major matrices.  Padded layout: row0 = b * Tl, T = Tl.  Packed rows
 // (seq_off != null, embed.hip launch_seq_pack): row0 = seq_off[b], T = seq_off[b + 1] - seq_off[b] <= Tl; lse / D keep the
-// padded pitch Tl.  The NB > 0 kernels are then launched once per block count: a workgroup whose sequence does not have
-// exactly NB 32-row blocks belongs to another launch and leaves at once (uniform over the workgroup).
+// padded pitch Tl.  The kernels with compile-time block counts then run through the *_varlen_kernel dispatchers below: a
+// workgroup executes the body compiled for its own sequence's number of 32-row blocks.
 #define ATT_SEQ(NB_)                                                                   \
   int T = Tl;                                                                          \
   long long row0 = (long long)b * Tl;                                                  \
@@ -245,21 +245,18 @@ __device__ __forceinline__ f32x16 score_block(const bf16_t* Xs, int blk, const b
     const int o_ = seq_off[b];                                                         \
     T = seq_off[b + 1] - o_;                                                           \
     row0 = o_;                                                                         \
-    if (T <= 0 || ((NB_) > 0 && (T > 32 * (NB_) || T <= 32 * ((NB_) - 1)))) return;    \
+    if (T <= 0) return;                                                                \
   }
 
 // NB > 0: the sequence fits NB 32-row blocks and every loop bound is a compile-time constant (the staging loads of a
 // workgroup are then issued back to back instead of one load -> store round trip per iteration); NB = 0: any T <= 256.
 template <int HS, int NB>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ y,
-                                                       float* __restrict__ lse, int Tl, int n_head, int quads,
-                                                       const int* __restrict__ seq_off) {
+__device__ __forceinline__ void attn_fwd_body(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ y, float* __restrict__ lse,
+                                              int Tl, int n_head, int b, int hq, int T, long long row0) {
   constexpr int NK = HS / 16, LIVE = HS / 2;
   constexpr float SCALE = att_scale<HS>(), SCALE_LOG2E = att_scale_log2e<HS>();
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int b = blockIdx.x / quads, hq = blockIdx.x - b * quads;
-  ATT_SEQ(NB);
   const int hh = hq * 4 + wave;
   const int heads_here = (n_head - hq * 4) < 4 ? (n_head - hq * 4) : 4;
   const int C = n_head * HS, Tp = NB ? 32 * NB : ((T + 31) & ~31);
@@ -354,9 +351,46 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
 }
 
 template <int HS, int NB>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ y,
+                                                       float* __restrict__ lse, int Tl, int n_head, int quads,
+                                                       const int* __restrict__ seq_off) {
+  const int b = blockIdx.x / quads, hq = blockIdx.x - b * quads;
+  ATT_SEQ(0);
+  attn_fwd_body<HS, NB>(qkv, y, lse, Tl, n_head, b, hq, T, row0);
+}
+// packed rows, T <= 32 * NBMAX <= 128: ONE launch; every workgroup runs the body compiled for its own sequence's block count
+// (separate launches per block count, the first form, serialised three under-filled grids: no gain over the padded batch)
+template <int HS, int NBMAX>
+__global__ __launch_bounds__(256) void attn_fwd_varlen_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ y,
+                                                              float* __restrict__ lse, int Tl, int n_head, int quads,
+                                                              const int* __restrict__ seq_off) {
+  const int b = blockIdx.x / quads, hq = blockIdx.x - b * quads;
+  ATT_SEQ(0);
+  const int nb = (T + 31) >> 5;   // uniform over the workgroup
+  if (nb == 1) attn_fwd_body<HS, 1>(qkv, y, lse, Tl, n_head, b, hq, T, row0);
+  else if (NBMAX >= 2 && nb == 2) attn_fwd_body<HS, (NBMAX >= 2 ? 2 : 1)>(qkv, y, lse, Tl, n_head, b, hq, T, row0);
+  else if (NBMAX >= 3 && nb == 3) attn_fwd_body<HS, (NBMAX >= 3 ? 3 : 1)>(qkv, y, lse, Tl, n_head, b, hq, T, row0);
+  else if (NBMAX >= 4 && nb == 4) attn_fwd_body<HS, (NBMAX >= 4 ? 4 : 1)>(qkv, y, lse, Tl, n_head, b, hq, T, row0);
+}
+
+template <int HS, int NB>
 static int launch_attn_fwd_t(const bf16_t* qkv, bf16_t* y, float* lse, int B, int T, int n_head, hipStream_t s, const int* seq_off) {
   const int Tp = NB ? 32 * NB : ((T + 31) & ~31);
   const size_t lds = (size_t)4 * (2 * Tp * HS * 2 + ATT_PW_PAD) + ot_bytes<HS>();
+  if (seq_off != nullptr && NB > 0) {   // packed rows: one launch, per-workgroup block count
+    static bool attr_v = false;
+    if (!attr_v) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_varlen_kernel<HS, NB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+        coati_set_error("attn_fwd(varlen): hipFuncSetAttribute failed");
+        return COATI_EHIP;
+      }
+      attr_v = true;
+    }
+    const int quads = cdiv(n_head, 4);
+    hipLaunchKernelGGL((attn_fwd_varlen_kernel<HS, NB>), dim3(B * quads), dim3(256), lds, s, qkv, y, lse, T, n_head, quads, seq_off);
+    COATI_LAUNCH_CHECK("attn_fwd_varlen");
+    return COATI_OK;
+  }
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<HS, NB>),
@@ -378,16 +412,6 @@ int launch_attn_fwd(const bf16_t* qkv, bf16_t* y, float* lse, int B, int T, int 
   COATI_CHECK_SHAPE(B > 0 && T > 0 && T <= 256 && n_head > 0 && (head_size == 16 || head_size == 32),
                     "attn_fwd: unsupported shape B=%d T=%d nh=%d hs=%d", B, T, n_head, head_size);
   const int nb = (T + 31) / 32;
-  if (seq_off != nullptr && nb <= 4) {
-    // packed rows: one launch per block count 1 .. nb; a workgroup runs in the launch its sequence's length belongs to
-    for (int n = 1; n <= nb; ++n) {
-#define FWD_CASE(H, N) if (head_size == H && n == N) COATI_TRY((launch_attn_fwd_t<H, N>(qkv, y, lse, B, T, n_head, s, seq_off)));
-      FWD_CASE(16, 1) FWD_CASE(16, 2) FWD_CASE(16, 3) FWD_CASE(16, 4)
-      FWD_CASE(32, 1) FWD_CASE(32, 2) FWD_CASE(32, 3) FWD_CASE(32, 4)
-#undef FWD_CASE
-    }
-    return COATI_OK;
-  }
 #define FWD_CASE(H, N) if (head_size == H && nb == N) return launch_attn_fwd_t<H, N>(qkv, y, lse, B, T, n_head, s, seq_off);
   FWD_CASE(16, 1) FWD_CASE(16, 2) FWD_CASE(16, 3) FWD_CASE(16, 4)
   FWD_CASE(32, 1) FWD_CASE(32, 2) FWD_CASE(32, 3) FWD_CASE(32, 4)
@@ -584,17 +608,14 @@ __device__ __forceinline__ bf16x8 dst_frag(const bf16_t* tile, int base, int lan
 }
 
 template <int HS, int NB>
-__global__ __launch_bounds__(256, (HS == 16 && NB <= 3) ? 3 : 2) void attn_bwd_fused_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ y,
-                                                             const bf16_t* __restrict__ dy, const float* __restrict__ lse,
-                                                             bf16_t* __restrict__ dqkv, const float* __restrict__ cos_t,
-                                                             const float* __restrict__ sin_t, int Tl, int n_head, int quads,
-                                                             const int* __restrict__ seq_off) {
+__device__ __forceinline__ void attn_bwd_fused_body(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ y,
+                                                    const bf16_t* __restrict__ dy, const float* __restrict__ lse,
+                                                    bf16_t* __restrict__ dqkv, const float* __restrict__ cos_t,
+                                                    const float* __restrict__ sin_t, int Tl, int n_head, int b, int hq, int T, long long row0) {
   constexpr int NK = HS / 16, LIVE = HS / 2, Tp = 32 * NB;
   constexpr float SCALE = att_scale<HS>(), SCALE_LOG2E = att_scale_log2e<HS>();
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int b = blockIdx.x / quads, hq = blockIdx.x - b * quads;
-  ATT_SEQ(NB);
   const int hh = hq * 4 + wave;
   const int heads_here = (n_head - hq * 4) < 4 ? (n_head - hq * 4) : 4;
   const int C = n_head * HS;
@@ -755,10 +776,50 @@ __global__ __launch_bounds__(256, (HS == 16 && NB <= 3) ? 3 : 2) void attn_bwd_f
 }
 
 template <int HS, int NB>
+__global__ __launch_bounds__(256, (HS == 16 && NB <= 3) ? 3 : 2) void attn_bwd_fused_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ y,
+                                                             const bf16_t* __restrict__ dy, const float* __restrict__ lse,
+                                                             bf16_t* __restrict__ dqkv, const float* __restrict__ cos_t,
+                                                             const float* __restrict__ sin_t, int Tl, int n_head, int quads,
+                                                             const int* __restrict__ seq_off) {
+  const int b = blockIdx.x / quads, hq = blockIdx.x - b * quads;
+  ATT_SEQ(0);
+  attn_bwd_fused_body<HS, NB>(qkv, y, dy, lse, dqkv, cos_t, sin_t, Tl, n_head, b, hq, T, row0);
+}
+// packed rows: one launch, per-workgroup block count (see attn_fwd_varlen_kernel)
+template <int HS, int NBMAX>
+__global__ __launch_bounds__(256, (HS == 16 && NBMAX <= 3) ? 3 : 2) void attn_bwd_fused_varlen_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ y,
+                                                             const bf16_t* __restrict__ dy, const float* __restrict__ lse,
+                                                             bf16_t* __restrict__ dqkv, const float* __restrict__ cos_t,
+                                                             const float* __restrict__ sin_t, int Tl, int n_head, int quads,
+                                                             const int* __restrict__ seq_off) {
+  const int b = blockIdx.x / quads, hq = blockIdx.x - b * quads;
+  ATT_SEQ(0);
+  const int nb = (T + 31) >> 5;
+  if (nb == 1) attn_bwd_fused_body<HS, 1>(qkv, y, dy, lse, dqkv, cos_t, sin_t, Tl, n_head, b, hq, T, row0);
+  else if (NBMAX >= 2 && nb == 2) attn_bwd_fused_body<HS, (NBMAX >= 2 ? 2 : 1)>(qkv, y, dy, lse, dqkv, cos_t, sin_t, Tl, n_head, b, hq, T, row0);
+  else if (NBMAX >= 3 && nb == 3) attn_bwd_fused_body<HS, (NBMAX >= 3 ? 3 : 1)>(qkv, y, dy, lse, dqkv, cos_t, sin_t, Tl, n_head, b, hq, T, row0);
+  else if (NBMAX >= 4 && nb == 4) attn_bwd_fused_body<HS, (NBMAX >= 4 ? 4 : 1)>(qkv, y, dy, lse, dqkv, cos_t, sin_t, Tl, n_head, b, hq, T, row0);
+}
+
+template <int HS, int NB>
 static int launch_attn_bwd_fused_t(const bf16_t* qkv, const bf16_t* y, const bf16_t* dy, const float* lse, bf16_t* dqkv,
                                    const float* cos_t, const float* sin_t, int B, int T, int n_head, hipStream_t s, const int* seq_off) {
   constexpr int Tp = 32 * NB;
   const size_t lds = (size_t)4 * ((size_t)3 * Tp * HS * 2 + (size_t)2 * Tp * 4 + ATT_PW_PAD) + 2 * ot_bytes<HS>();
+  if (seq_off != nullptr) {   // packed rows: one launch, per-workgroup block count
+    static bool attr_v = false;
+    if (!attr_v) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_fused_varlen_kernel<HS, NB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+        coati_set_error("attn_bwd(fused, varlen): hipFuncSetAttribute failed");
+        return COATI_EHIP;
+      }
+      attr_v = true;
+    }
+    const int quads = cdiv(n_head, 4);
+    hipLaunchKernelGGL((attn_bwd_fused_varlen_kernel<HS, NB>), dim3(B * quads), dim3(256), lds, s, qkv, y, dy, lse, dqkv, cos_t, sin_t, T, n_head, quads, seq_off);
+    COATI_LAUNCH_CHECK("attn_bwd_fused_varlen");
+    return COATI_OK;
+  }
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_fused_kernel<HS, NB>),
@@ -815,16 +876,6 @@ int launch_attn_bwd(const bf16_t* qkv, const bf16_t* y, const bf16_t* dy, const 
   static const bool fused = getenv("COATI_ATTN_FUSED_BWD") == nullptr || atoi(getenv("COATI_ATTN_FUSED_BWD")) != 0;
   if (fused && T <= 128) {
     const int nb = (T + 31) / 32;
-    if (seq_off != nullptr) {
-      // packed rows: one launch per block count 1 .. nb (see ATT_SEQ)
-      for (int n = 1; n <= nb; ++n) {
-#define FUSED_CASE(H, N) if (head_size == H && n == N) COATI_TRY((launch_attn_bwd_fused_t<H, N>(qkv, y, dy, lse, dqkv, cos_t, sin_t, B, T, n_head, s, seq_off)));
-        FUSED_CASE(16, 1) FUSED_CASE(16, 2) FUSED_CASE(16, 3) FUSED_CASE(16, 4)
-        FUSED_CASE(32, 1) FUSED_CASE(32, 2) FUSED_CASE(32, 3) FUSED_CASE(32, 4)
-#undef FUSED_CASE
-      }
-      return COATI_OK;
-    }
 #define FUSED_CASE(H, N) if (head_size == H && nb == N) return launch_attn_bwd_fused_t<H, N>(qkv, y, dy, lse, dqkv, cos_t, sin_t, B, T, n_head, s, seq_off);
     FUSED_CASE(16, 1) FUSED_CASE(16, 2) FUSED_CASE(16, 3) FUSED_CASE(16, 4)
     FUSED_CASE(32, 1) FUSED_CASE(32, 2) FUSED_CASE(32, 3) FUSED_CASE(32, 4)

@@ -29,16 +29,14 @@
 #define RB_PRIO_HI 3
 #endif
 #define RB_K 256
-// Two shapes of the same kernel (template BN, MAXW):
-//   BN = 64, up to 10 waves, ONE workgroup per CU  -- fewest barriers (default);
-//   BN = 32, 5 waves, TWO workgroups per CU        -- the two workgroups' MFMA / epilogue phases interleave
-//                                                     (COATI_RB_SPLIT=1; A/B in DESIGN.md).
+// One workgroup per CU on 64-column weight tiles (template BN, MAXW = the most waves an instantiation runs with: 7 / 10 / 12).
+// (Two 5-wave workgroups per CU on 32-column tiles were measured in round 1 -- 51 -> 73 us -- and removed in round 3.)
 #define RB_EFLOATS_MAX (16 * 68)          // per-wave transpose region, floats (16 rows x (BN + 4))
 #define RB_ROPE_FLOATS (32 * 16)          // 2 KiB per wave: [32 rows][8 cos | 8 sin]
 #define RB_AUX_BYTES 4096                 // per wave: the 32 x 64 bf16 block of saved pre-activations of the current tile
 #define RB_MAX_W 10
 #define RB_HALF_W 12                      // "8 + 4" shape: 8 waves of 32 rows + 4 waves of 16 rows = the same 320 rows per workgroup
-#define RB_SPLIT_W 5
+#define RB_FEW_W 7                        // instantiation for 5 .. 7 waves per workgroup
 #ifndef RB_PD
 #define RB_PD 3                           // LDS read pipeline depth of the MFMA loop
 #endif
@@ -186,8 +184,12 @@ __global__ __launch_bounds__(64 * MAXW, (640 / (64 * MAXW)) > 0 ? (640 / (64 * M
   typedef __attribute__((address_space(3))) void lds_void;
   typedef __attribute__((address_space(1))) const void gbl_void;
   auto load_tile = [&](int n0, bf16_t* S) {
+    // RB_BN / 2 pieces over the W waves: 4 turns cover a 64-column tile from 8 waves on; the instantiation for 5 .. 7 waves
+    // (RB_FEW_W: 6-7 slabs per workgroup, what packed rows bring) takes up to 7.  Compile-time turn count: a longer loop
+    // with skipped turns in the 8 .. 12-wave kernels cost 10 % of the step (the uniform branches split the tile's schedule).
+    constexpr int TURNS = MAXW >= 8 ? 4 : 7;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < TURNS; ++i) {
       const int k = wave + W * i;            // wave-uniform: which 1-KiB piece (two rows) of the tile
       if (k < RB_BN / 2) {
         const int r = 2 * k + (lane >> 5), q = lane & 31;
@@ -427,8 +429,6 @@ static int launch_rb_shape(const GemmArgs& a, int W, hipStream_t s) {
 
 template <int EPI>
 static int launch_rb_t(const GemmArgs& a, hipStream_t s) {
-  // COATI_RB_SPLIT=1: two 5-wave workgroups per CU on 32-column tiles instead of one 10-wave workgroup on 64-column tiles
-  static const bool split = getenv("COATI_RB_SPLIT") != nullptr && atoi(getenv("COATI_RB_SPLIT")) != 0;
   const int W = rb_waves(a.M);
   // 8 full + 4 half waves instead of 10 full ones: measured per epilogue (bench --all-sites, M = 81,920): FC1 + GELU/GELU' 3.65 ->
   // 3.51 ms/step, lm_head 0.78 -> 0.75 / 0.73 -> 0.72, but FC2 input gradient 2.41 -> 2.63 and QKV 2.37 -> 2.43 -- it pays only
@@ -440,6 +440,7 @@ static int launch_rb_t(const GemmArgs& a, hipStream_t s) {
   const bool half = half_on && half_fits && W == RB_MAX_W && a.m_dev == nullptr;
   if constexpr (EPI == EPI_QKV_ROPE || EPI == EPI_GELU_GRAD) {
     if (a.ln_x != nullptr) {
+      if (W <= RB_FEW_W) return launch_rb_shape<EPI, 64, RB_FEW_W, true>(a, W, s);
       if constexpr (half_fits) { if (half) return launch_rb_shape<EPI, 64, RB_HALF_W, true>(a, W, s); }
       return launch_rb_shape<EPI, 64, RB_MAX_W, true>(a, W, s);
     }
@@ -448,7 +449,7 @@ static int launch_rb_t(const GemmArgs& a, hipStream_t s) {
     coati_set_error("gemm_rb256: epilogue %d has no fused-LayerNorm variant", (int)EPI);
     return COATI_EARG;
   }
-  if (split && W == RB_MAX_W) return launch_rb_shape<EPI, 32, RB_SPLIT_W>(a, RB_SPLIT_W, s);
+  if (W <= RB_FEW_W) return launch_rb_shape<EPI, 64, RB_FEW_W>(a, W, s);
   if constexpr (half_fits) { if (half) return launch_rb_shape<EPI, 64, RB_HALF_W>(a, W, s); }
   return launch_rb_shape<EPI, 64, RB_MAX_W>(a, W, s);
 }

@@ -23,14 +23,20 @@
 #ifndef RG_PRIO
 #define RG_PRIO 0   // (probe: MFMA section at raised priority -- within the noise on every ring site, unlike the row-block kernel)
 #endif
-#define RG_BR 160                           // rows per block
+// Row groups per block RGM = 5 (160 rows, 10 waves: M = 81 920 is exactly 2 blocks per CU) or 4 (128 rows, 8 waves): the launch
+// picks the block height whose last round wastes less -- packed rows bring ~50 000 rows per pass, i.e. 1.2 rounds of 160-row
+// blocks (every CU waits for the 53 that run a second block) but 1.5 rounds of 128-row blocks, 20 % fewer rows on the busiest CU.
 #define RG_BK 64                            // k per stage
-#define RG_WAVES 10
 #define RG_NS 3
-#define RG_A_BYTES (RG_BR * RG_BK * 2)      // 20 KiB
+#define RG_MAXW 10
 #define RG_W_BYTES (256 * RG_BK * 2)        // 32 KiB
-#define RG_STAGE_BYTES (RG_A_BYTES + RG_W_BYTES)
-#define RG_LDS_BYTES (RG_NS * RG_STAGE_BYTES)   // 159,744 B
+template <int RGM> struct RgShape {
+  static constexpr int BR = 32 * RGM;                        // rows per block
+  static constexpr int WAVES = 2 * RGM;
+  static constexpr int A_BYTES = BR * RG_BK * 2;             // 20 / 16 KiB
+  static constexpr int STAGE_BYTES = A_BYTES + RG_W_BYTES;
+  static constexpr int LDS_BYTES = RG_NS * STAGE_BYTES;      // 159,744 / 147,456 B
+};
 
 __device__ __forceinline__ void rg_dma16(const void* g, unsigned lds) {   // per-lane 64-bit address
   asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(lds) : "memory", "m0");
@@ -53,21 +59,23 @@ __device__ __forceinline__ void rg_wait_vm(int n) {
 // Probe build (-DCOATI_RB_TRACE, tools/probes/rb_trace.py): shader-clock totals per phase for the waves of the first 16
 // workgroups of the last launch: [wg][wave][before the loop, wait (vmcnt + barrier), MFMA + DMA issue, write-out].
 #ifdef COATI_RB_TRACE
-__device__ unsigned long long rg_trace_buf[16 * RG_WAVES * 8];
+__device__ unsigned long long rg_trace_buf[16 * RG_MAXW * 8];
 extern "C" int coati_rg_trace_read(unsigned long long* out) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(rg_trace_buf), sizeof(rg_trace_buf)) == hipSuccess ? 0 : -3;
 }
 #define RG_T0() unsigned long long rg_t_last = __builtin_amdgcn_s_memtime(), rg_t_acc[4] = {0, 0, 0, 0}
 #define RG_T(i) do { const unsigned long long rg_t_now = __builtin_amdgcn_s_memtime(); rg_t_acc[i] += rg_t_now - rg_t_last; rg_t_last = rg_t_now; } while (0)
-#define RG_TDUMP() do { if (blockIdx.x < 16 && lane == 0) { for (int i = 0; i < 4; ++i) rg_trace_buf[(blockIdx.x * RG_WAVES + wave) * 8 + i] = rg_t_acc[i]; } } while (0)
+#define RG_TDUMP() do { if (blockIdx.x < 16 && lane == 0) { for (int i = 0; i < 4; ++i) rg_trace_buf[(blockIdx.x * RG_MAXW + wave) * 8 + i] = rg_t_acc[i]; } } while (0)
 #else
 #define RG_T0() do { } while (0)
 #define RG_T(i) do { } while (0)
 #define RG_TDUMP() do { } while (0)
 #endif
 
-template <int EPI>
-__global__ __launch_bounds__(64 * RG_WAVES, 1) void gemm_ring256_kernel(GemmArgs p, int nblocks) {
+template <int EPI, int RGM>
+__global__ __launch_bounds__(64 * 2 * RGM, 1) void gemm_ring256_kernel(GemmArgs p, int nblocks) {
+  constexpr int RG_BR = RgShape<RGM>::BR, RG_WAVES = RgShape<RGM>::WAVES, RG_A_BYTES = RgShape<RGM>::A_BYTES,
+                RG_STAGE_BYTES = RgShape<RGM>::STAGE_BYTES;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   typedef __attribute__((address_space(3))) unsigned char lds_u8;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -86,7 +94,7 @@ __global__ __launch_bounds__(64 * RG_WAVES, 1) void gemm_ring256_kernel(GemmArgs
   const int cg = (lane & 7) ^ ((((wave & 1) << 2) + (lane >> 4)) & 7);
   const unsigned offa = (unsigned)((lrow * (int)p.lda + cg * 8) * 2);
   const unsigned offw = (unsigned)((lrow * (int)p.ldb + cg * 8) * 2);
-  const int nwp = wave < 2 ? 4 : 3;              // weight pieces of this wave
+  const int nwp = (32 - wave + RG_WAVES - 1) / RG_WAVES;   // weight pieces of this wave: 4 for waves 0, 1 of 10, else 3; 4 each of 8
   const int my_dmas = 2 + nwp;
   // DMA pointer: all scalar, carried from stage to stage (the instruction count of a stage is on the critical path: the
   // first version recomputed bases and the k rotation every stage and spent 7 scalar instructions per MFMA).
@@ -293,15 +301,16 @@ bool gemm_ring256_supported(const GemmArgs& a, int a_f32, int epi) {
   if (off || a_f32) return false;
   if (epi != EPI_BF16 && epi != EPI_RES_F32) return false;
   if (a.N != 256 || a.K % RG_BK != 0 || a.K < 256) return false;
-  if (a.M < 256 * RG_BR / 2) return false;                      // fewer than half the CUs busy: the tiled kernel spreads better
+  if (a.M < 256 * 160 / 2) return false;                        // fewer than half the CUs busy: the tiled kernel spreads better
   if (130LL * a.lda >= (1LL << 30) || 260LL * a.ldb >= (1LL << 30)) return false;
   return true;
 }
 
-template <int EPI>
+template <int EPI, int RGM>
 static int launch_ring_t(const GemmArgs& a, hipStream_t s) {
+  constexpr int RG_BR = RgShape<RGM>::BR, RG_WAVES = RgShape<RGM>::WAVES, RG_LDS_BYTES = RgShape<RGM>::LDS_BYTES;
   static bool attr_set = false;
-  auto kern = gemm_ring256_kernel<EPI>;
+  auto kern = gemm_ring256_kernel<EPI, RGM>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, RG_LDS_BYTES);
     if (e != hipSuccess) {
@@ -318,5 +327,11 @@ static int launch_ring_t(const GemmArgs& a, hipStream_t s) {
 }
 
 int launch_gemm_ring256(const GemmArgs& a, int epi, hipStream_t s) {
-  return epi == EPI_RES_F32 ? launch_ring_t<EPI_RES_F32>(a, s) : launch_ring_t<EPI_BF16>(a, s);
+  // block height: rows the busiest of the 256 persistent workgroups walks = rounds x block rows; ties go to the 160-row form
+  // (less weight re-streaming per row).  COATI_RING_ROWS = 128 | 160 forces one (A/B switch).
+  static const int force = getenv("COATI_RING_ROWS") ? atoi(getenv("COATI_RING_ROWS")) : 0;
+  const long long busiest160 = (long long)cdiv(cdiv(a.M, 160), 256) * 160, busiest128 = (long long)cdiv(cdiv(a.M, 128), 256) * 128;
+  const bool small = force ? force == 128 : busiest128 < busiest160;
+  if (small) return epi == EPI_RES_F32 ? launch_ring_t<EPI_RES_F32, 4>(a, s) : launch_ring_t<EPI_BF16, 4>(a, s);
+  return epi == EPI_RES_F32 ? launch_ring_t<EPI_RES_F32, 5>(a, s) : launch_ring_t<EPI_BF16, 5>(a, s);
 }

@@ -93,7 +93,41 @@ def grad_buckets(eng):
 
 
 # COATI_DP_SPLIT=1: the encoder stage of the data-parallel backward in two halves (round-1 schedule, A/B switch)
-_SPLIT_ENCODER_STAGE = os.environ.get("COATI_DP_SPLIT", "0") == "1"
+# Encoder stage of the staged backward in one piece or in two halves (see distributed_train_step).  COATI_DP_SPLIT=0 | 1 forces
+# a schedule; unset, the schedule is MEASURED: after 3 warm-up steps three steps of each form are timed (device-synchronised,
+# those six steps only) and the faster one -- MAX over ranks, so that every rank picks the same -- is kept.
+_SPLIT_ENV = os.environ.get("COATI_DP_SPLIT")
+_SPLIT_ENCODER_STAGE = _SPLIT_ENV == "1"
+_AUTO = {"step": 0, "t": [0.0, 0.0], "decided": _SPLIT_ENV is not None}
+
+
+def _schedule_begin():
+    """returns (use_split, timing_slot or None) for this step"""
+    if _AUTO["decided"] or not dist.is_initialized() or dist.get_backend() != "nccl":
+        return _SPLIT_ENCODER_STAGE, None
+    k = _AUTO["step"]
+    _AUTO["step"] += 1
+    if k < 3:
+        return False, None
+    if k < 9:
+        return (k - 3) >= 3, (0 if k - 3 < 3 else 1)
+    return _SPLIT_ENCODER_STAGE, None
+
+
+def _schedule_end(slot, seconds):
+    global _SPLIT_ENCODER_STAGE
+    if slot is None:
+        return
+    _AUTO["t"][slot] += seconds
+    if _AUTO["step"] == 9:
+        t = torch.tensor(_AUTO["t"], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=control_group())
+        _SPLIT_ENCODER_STAGE = bool(t[1] < t[0])
+        _AUTO["decided"] = True
+        if dist.get_rank() == 0:
+            print(f"[coati_amd.distributed] encoder stage of the data-parallel backward: one piece {1e3 * float(t[0]) / 3:.3f} ms/step, "
+                  f"two halves {1e3 * float(t[1]) / 3:.3f} ms/step -> {'two halves' if _SPLIT_ENCODER_STAGE else 'one piece'}", flush=True)
+
 
 
 def distributed_train_step(eng, batch, use_point, lr, do_clip=True, optimizer=True, head="infonce", reduce_grads=True,
@@ -103,6 +137,11 @@ def distributed_train_step(eng, batch, use_point, lr, do_clip=True, optimizer=Tr
     reduce_grads=False skips the four gradient all-reduces (bench.py's measurement of their exposed cost).
     opt_kw: weight_decay / max_norm / betas / eps for Engine.optimizer_step (train_coati.py:145-151, 276)."""
     W, rank = dist.get_world_size(), dist.get_rank()
+    split_stage, slot = _schedule_begin() if (reduce_grads and optimizer) else (_SPLIT_ENCODER_STAGE, None)
+    if slot is not None:
+        import time
+        torch.cuda.synchronize()
+        t_begin = time.perf_counter()
     h_e, h_s, bad = eng.forward(batch["raw_tokens"], batch["tokens"], batch["atoms"], batch["coords"], use_point,
                                 y_next=batch["y_next"], train=True, rows=batch.get("rows"))
     B = h_e.shape[0]
@@ -126,7 +165,7 @@ def distributed_train_step(eng, batch, use_point, lr, do_clip=True, optimizer=Tr
 
     eng.backward(dS, dC, stage=1)
     launch("lm_head"); launch("heads")
-    if _SPLIT_ENCODER_STAGE:
+    if split_stage:
         # the encoder stage in two halves: the upper layers' gradients (both passes are through them) travel underneath the
         # lower half of the backward
         eng.backward(None, None, stage=4)
@@ -146,6 +185,9 @@ def distributed_train_step(eng, batch, use_point, lr, do_clip=True, optimizer=Tr
         w.wait()
     if optimizer:
         eng.optimizer_step(lr, **opt_kw)
+    if slot is not None:
+        torch.cuda.synchronize()
+        _schedule_end(slot, time.perf_counter() - t_begin)
     return h_e, h_s, bad
 
 

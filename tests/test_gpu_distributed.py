@@ -41,18 +41,28 @@ def _rank_batch(r, mask_ar=True):
     return b, up
 
 
-def _worker(rank, world, port, head, out_dir):
+def _worker(rank, world, port, head, out_dir, backend="gloo"):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    DEV = "cuda:0"
+    if backend == "nccl":          # the product path: one GPU per rank, RCCL collectives on device memory
+        DEV = f"cuda:{rank}"
+        torch.cuda.set_device(rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(DEV))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from coati_amd.engine import Engine, ModelConfig
         from coati_amd import distributed as D
+        from coati_amd.synthetic import packed_rows
         eng = Engine(ModelConfig(**KW), DEV)
         _weights(eng)
         b, up = _rank_batch(rank)
         db = {k: v.to(DEV) for k, v in b.items()}
+        if backend == "nccl":      # and on packed rows, as the bench runs it
+            db["rows"] = torch.tensor(packed_rows(b["raw_tokens"], b["tokens"], b["y_next"]))
         D.distributed_train_step(eng, db, up.to(DEV), lr=1e-3, head=head, optimizer=False)
         torch.cuda.synchronize()
         grads = eng.grads.clone()
@@ -67,9 +77,9 @@ def _worker(rank, world, port, head, out_dir):
         dist.destroy_process_group()
 
 
-def _run_two_ranks(head, tmp_path, port):
+def _run_two_ranks(head, tmp_path, port, backend="gloo"):
     ctx = mp.get_context("spawn")
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, head, str(tmp_path))) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, head, str(tmp_path), backend)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:
@@ -133,6 +143,21 @@ def test_two_process_distributed_step_equals_global_batch(tmp_path):
     # which can flip single bf16 roundings of activation gradients (a flipped element moves a heavily cancelling bias
     # column sum by a few percent of its small scale)
     _compare_grads(eng, r[0]["grads"], 5e-3, "two-process InfoNCE step")
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two visible GPUs: RCCL refuses two ranks on one device")
+def test_two_gpu_rccl_step_equals_global_batch(tmp_path):
+    """The same equivalence over REAL RCCL ("nccl" backend, one GPU per rank): all_gather_into_tensor, reduce_scatter_tensor and
+    the asynchronous all_reduce(AVG) buckets on device memory -- the calls the gloo runs stage through the host -- with the
+    ranks' batches in the packed-row layout.  Runs on any box that shows two or more GPUs (the builder's box shows one)."""
+    from tests.gpu_util import log
+    r = _run_two_ranks("infonce", tmp_path, 29651, backend="nccl")
+    assert np.array_equal(r[0]["grads"], r[1]["grads"]) and np.array_equal(r[0]["params"], r[1]["params"])
+    eng = _global_run("infonce")
+    Lg = eng.losses()
+    log(f"two-GPU RCCL step: global-batch clip loss {Lg['clip_loss']:.6f}; ranks report {float(r[0]['clip']):.6f} / {float(r[1]['clip']):.6f}")
+    assert abs(float(r[0]["clip"]) - Lg["clip_loss"]) < 2e-4 * max(1.0, abs(Lg["clip_loss"]))
+    _compare_grads(eng, r[0]["grads"], 5e-3, "two-GPU RCCL step")
 
 
 def test_two_process_barlow_distributed_equals_global_batch(tmp_path):

@@ -42,6 +42,15 @@ def gr(golden_dir):
     return g, ocfg, P, names, batches, masks, eng, db
 
 
+def _layout(db, batches, layout):
+    """padded: the [B, T] matrices as the reference computes them; packed: + the host-side row counts, so that the engine
+    skips the positions behind each row's last token"""
+    if layout == "padded":
+        return db
+    from coati_amd.synthetic import packed_rows
+    return [dict(d, rows=torch.tensor(packed_rows(b["raw_tokens"], b["tokens"], b["y_next"]))) for d, b in zip(db, batches)]
+
+
 def test_forward_dist_grande_vs_reference(gr):
     g, ocfg, P, names, batches, masks, eng, db = gr
     b = db[0]
@@ -64,13 +73,16 @@ def test_forward_dist_grande_vs_reference(gr):
     assert agree > 0.97
 
 
-def test_step_grads_adamw_grande_vs_reference(gr):
+@pytest.mark.parametrize("layout", ["padded", "packed"])
+def test_step_grads_adamw_grande_vs_reference(gr, layout):
     g, ocfg, P, names, batches, masks, eng, db = gr
+    db = _layout(db, batches, layout)
     eng.load_state_dict(P)
     eng.adam_m.zero_(); eng.adam_v.zero_(); eng.step_count = 0
     eng.train_step(db[0], masks[0].to(DEV), lr=5e-4, weight_decay=0.1, max_norm=10.0, optimizer=False)
+    assert eng._packed == (layout == "packed")
     L = eng.losses()
-    log(f"grande step: hip {L}  reference ar {float(g['step_ar']):.6f} clip {float(g['step_clip']):.6f} loss {float(g['step_loss']):.6f}")
+    log(f"grande step [{layout}]: hip {L}  reference ar {float(g['step_ar']):.6f} clip {float(g['step_clip']):.6f} loss {float(g['step_loss']):.6f}")
     check("grande ar", torch.tensor([L["ar_loss"]]), torch.from_numpy(g["step_ar"]).reshape(1), TOL_LOSS)
     check("grande clip", torch.tensor([L["clip_loss"]]), torch.from_numpy(g["step_clip"]).reshape(1), TOL_LOSS)
     check("grande loss", torch.tensor([L["loss"]]), torch.from_numpy(g["step_loss"]).reshape(1), TOL_LOSS)
@@ -113,11 +125,13 @@ def test_step_grads_adamw_grande_vs_reference(gr):
             assert cos > 0.9, (n, cos)     # measured >= 0.9528 (h.0.attn.c_attn.bias), 0.994+ for every matrix
 
 
-def test_twenty_step_loss_curve_grande_vs_reference(gr):
+@pytest.mark.parametrize("layout", ["padded", "packed"])
+def test_twenty_step_loss_curve_grande_vs_reference(gr, layout):
     """north_star "loss-curve equivalent to reference" AT THE HEADLINE ARCHITECTURE: 20 optimiser steps (clip-norm 10, AdamW
     lr 5e-4, wd 0.1, betas (0.9, 0.99): train_grande.py's settings) cycling over 4 batches, mixed point / SMILES injection,
     against the curve the reference produced on its fp32 CPU path."""
     g, ocfg, P, names, batches, masks, eng, db = gr
+    db = _layout(db, batches, layout)
     eng.load_state_dict(P)
     eng.adam_m.zero_(); eng.adam_v.zero_(); eng.step_count = 0
     n = int(g["n_steps"])
@@ -129,7 +143,7 @@ def test_twenty_step_loss_curve_grande_vs_reference(gr):
     dev_ = {k: np.abs(np.array(v) - g["curve_" + k]) / np.maximum(np.abs(g["curve_" + k]), 1e-6) for k, v in rec.items()}
     log("grande 20-step curve: reference ar " + " ".join(f"{x:.3f}" for x in g["curve_ar"]))
     log("grande 20-step curve: hip       ar " + " ".join(f"{x:.3f}" for x in rec["ar"]))
-    log("grande 20-step curve: max relative deviation " + ", ".join(f"{k} {v.max():.3e} (step {int(v.argmax())}, median {np.median(v):.2e})" for k, v in dev_.items()))
+    log(f"grande 20-step curve [{layout}]: max relative deviation " + ", ".join(f"{k} {v.max():.3e} (step {int(v.argmax())}, median {np.median(v):.2e})" for k, v in dev_.items()))
     assert g["curve_ar"][-4:].mean() < 0.9 * g["curve_ar"][:4].mean()      # the curve really descends
     for k in ("loss", "ar", "clip"):
         assert dev_[k].max() <= TOL_CURVE, (k, dev_[k].max())

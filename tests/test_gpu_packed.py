@@ -95,26 +95,31 @@ def _both_steps(kw, batch, up, seed):
     return out
 
 
-@pytest.mark.parametrize("name,kw,shape", [
-    ("medium", dict(n_layer_e3gnn=2, n_layer_xformer=3, n_hidden_xformer=128, n_hidden_e3nn=128, n_embd_common=128, n_head=8, n_seq=64, n_tok=300), (24, 40, 12)),
-    ("wide", dict(n_layer_e3gnn=1, n_layer_xformer=2, n_hidden_xformer=256, n_hidden_e3nn=256, n_embd_common=256, n_head=16, n_seq=250, n_tok=1003), (700, 83, 16)),
-    ("hs32", dict(n_layer_e3gnn=1, n_layer_xformer=2, n_hidden_xformer=128, n_hidden_e3nn=64, n_embd_common=128, n_head=4, n_seq=140, n_tok=200), (20, 130, 9)),
+# same_kernels: both row counts take the same GEMM kernels, so every row is computed by the same code and only summation orders
+# differ.  "wide": 58 100 padded rows run the LayerNorm-fused row-block GEMMs with 8 waves, the ~37 000 packed rows with 5
+# (another instantiation, and the lm_head / CE tiles fall differently): bf16 roundings may land on the other side
+@pytest.mark.parametrize("name,kw,shape,same_kernels", [
+    ("medium", dict(n_layer_e3gnn=2, n_layer_xformer=3, n_hidden_xformer=128, n_hidden_e3nn=128, n_embd_common=128, n_head=8, n_seq=64, n_tok=300), (24, 40, 12), True),
+    ("wide", dict(n_layer_e3gnn=1, n_layer_xformer=2, n_hidden_xformer=256, n_hidden_e3nn=256, n_embd_common=256, n_head=16, n_seq=250, n_tok=1003), (700, 83, 16), False),
+    ("hs32", dict(n_layer_e3gnn=1, n_layer_xformer=2, n_hidden_xformer=128, n_hidden_e3nn=64, n_embd_common=128, n_head=4, n_seq=140, n_tok=200), (20, 130, 9), True),
 ])
-def test_packed_step_equals_padded_step(name, kw, shape):
+def test_packed_step_equals_padded_step(name, kw, shape, same_kernels):
     """the engine's packed step against its own padded step (same weights, same batch): forward embeddings identical, losses
-    to fp32 summation order, gradients to the accumulation order of the weight-gradient kernels"""
+    to fp32 summation order, gradients to the accumulation order of the weight-gradient kernels -- where the two row counts
+    select the same kernels; otherwise to bf16 rounding"""
     from coati_amd.synthetic import make_batch
     B, T, A = shape
     batch, up = make_batch(B, T, A, kw["n_tok"], seed=B + T, n_special=12, p_bad=0.05, min_len=5, with_rows=True)
     (Lp, gp, hep, hsp), (Lk, gk, hek, hsk) = _both_steps(kw, batch, up, seed=5)
     log(f"packed vs padded [{name}]: rows {batch['rows'].tolist()} of {B * (T - 2)} / {B * T}; losses padded {Lp} packed {Lk}")
     check(f"packed [{name}] h_e3gnn", hek, hep, 0.0)
-    check(f"packed [{name}] h_smiles", hsk, hsp, 1e-6)
+    check(f"packed [{name}] h_smiles", hsk, hsp, 1e-6 if same_kernels else 3e-3)       # measured 7.9e-4 on "wide"
     assert Lk["n_targets"] == Lp["n_targets"] and Lk["n_valid"] == Lp["n_valid"]
-    assert abs(Lk["ar_loss"] - Lp["ar_loss"]) <= 2e-6 * abs(Lp["ar_loss"]) and abs(Lk["clip_loss"] - Lp["clip_loss"]) <= 2e-6 * abs(Lp["clip_loss"])
+    tl = 2e-6 if same_kernels else 5e-4
+    assert abs(Lk["ar_loss"] - Lp["ar_loss"]) <= tl * abs(Lp["ar_loss"]) and abs(Lk["clip_loss"] - Lp["clip_loss"]) <= tl * abs(Lp["clip_loss"]), (Lk, Lp)
     worst = sorted(((float((gk[k] - gp[k]).abs().max()) / max(float(gp[k].abs().max()), 1e-30), k) for k in gp if float(gp[k].abs().max()) > 0), reverse=True)
     log(f"packed vs padded [{name}]: worst gradient deviations {worst[:3]}")
-    assert worst[0][0] <= 2e-3, worst[:5]      # bf16 re-rounding where an f32 sum changed its last bit
+    assert worst[0][0] <= (2e-3 if same_kernels else 2e-2), worst[:5]      # bf16 re-rounding where an f32 sum changed its last bit
 
 
 def test_packed_golden_step_vs_reference(golden_dir):
