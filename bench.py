@@ -164,6 +164,9 @@ def main():
     ap.add_argument("--padded", action="store_true",
                     help="run the transformer passes on the padded [B, T] layout as the reference does; default: packed rows "
                          "(the rows' real prefixes only -- same losses and gradients, see DESIGN.md section 2a); the line reports both")
+    ap.add_argument("--fp8", action="store_true",
+                    help="BASELINE.json configs[4]: the transformer's Linear forward / input-gradient products on MXFP8 (e4m3 + E8M0 block "
+                         "scales, v_mfma_scale_f32_32x32x64_f8f6f4); weight gradients, attention, lm_head and the GNN stay bf16 / f32")
     ap.add_argument("--gnn-layers", type=int, default=-1, help="experiment only: override the number of E(3)-GNN layers (the line is then NOT the headline metric)")
     args = ap.parse_args()
 
@@ -213,7 +216,7 @@ def main():
     MODEL = dict(GRANDE if args.config == "grande_closed" else COATI2_SHAPE)
     if args.gnn_layers >= 0:
         MODEL["n_layer_e3gnn"] = args.gnn_layers
-    eng = Engine(ModelConfig(**MODEL), dev)
+    eng = Engine(ModelConfig(fp8=args.fp8, **MODEL), dev)
     # random-init weights of the grande architecture (no network for checkpoints): N(0, 0.02)-style init
     g = torch.Generator(device="cpu").manual_seed(0)
     with torch.no_grad():
@@ -360,12 +363,13 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "bf16",
+            "dtype": "fp8" if args.fp8 else "bf16",
             "data": "synthetic",
             "config": {"workload": (f"grande_closed d=256 L=16 nh=16 + E3GNN h=256x5, V=10322" if args.config == "grande_closed" else
                                     f"coati2_shape d=512 L=12 nh=16 (head size 32) + E3GNN h=512x5, V=4266 (parity unpinned)") + f", batch {args.batch}/GPU, "
-                                   f"seq_len {args.seq}, {args.atoms}-atom point clouds, InfoNCE + AR loss, bf16 MFMA operands / "
-                                   f"fp32 accumulate + fp32 master weights, random-init weights",
+                                   f"seq_len {args.seq}, {args.atoms}-atom point clouds, InfoNCE + AR loss, "
+                                   + ("MXFP8 (e4m3, E8M0 scale per 32 k) operands for the transformer's Linear forward / input-gradient products, bf16 elsewhere / "
+                                      if args.fp8 else "bf16 MFMA operands / ") + "fp32 accumulate + fp32 master weights, random-init weights",
                        "global_batch": args.batch * world, "seq_len": args.seq, "parallelism": f"dp{world}",
                        "row_layout": "padded [B, T] (as the reference computes)" if args.padded else
                                      "packed rows: the transformer passes skip the positions behind each row's last token (zero contribution to "

@@ -14,12 +14,14 @@ class CoatiConfig(ctypes.Structure):
         ("n_layer_xformer", c_int32), ("n_layer_e3gnn", c_int32), ("n_hidden_xformer", c_int32),
         ("n_hidden_e3nn", c_int32), ("n_embd_common", c_int32), ("n_head", c_int32), ("n_seq", c_int32),
         ("n_tok", c_int32), ("msg_cutoff", c_float), ("pad_token", c_int32), ("stop_token", c_int32),
-        ("unk_token", c_int32),
+        ("unk_token", c_int32), ("use_fp8", c_int32),
     ]
 
 
 _SIGS = {
     "coati_gemm_nt": [P, I, L, P, L, I, I, I, P, L, I, P, P, P, L, I, P],
+    "coati_quant_mx8": [P, I, L, P, L, P, I, I, P],
+    "coati_gemm_mx8": [P, L, P, P, L, P, I, I, I, P, L, P, P, P, L, I, P],
     "coati_gemm_ce_partial": [P, L, P, L, I, I, I, P, P],
     "coati_ce_finish": [P, I, P, L, P, L, P, P, P, I, I, I, P],
     "coati_gemm_ce_bwd": [P, L, P, L, I, I, I, P, L, I, P, P, P, P],
@@ -69,6 +71,7 @@ _SIGS = {
     "coati_engine_entry": [P, I, c_char_p, I, POINTER(c_int64), POINTER(c_int32), POINTER(c_int32)],
     "coati_engine_bind": [P, P, P, P, P, P, P, P, P, P],
     "coati_engine_refresh_shadows": [P, P],
+    "coati_engine_bind_fp8": [P, P, L],
     "coati_engine_forward": [P, P, L, I, I, I, I, P, P, P, P, P, P, P, P, P, P, I, L, L, P],
     "coati_seq_pack": [P, P, I, I, I, I, P, P, P, P, P, P],
     "coati_attn_fwd_varlen": [P, P, P, P, I, I, I, I, P],
@@ -127,6 +130,8 @@ def lib():
     l.coati_engine_workspace_bytes.restype = c_int64
     l.coati_wgrad_grouped_workspace_bytes.argtypes = [I, P, P, I]
     l.coati_wgrad_grouped_workspace_bytes.restype = c_int64
+    l.coati_engine_fp8_bytes.argtypes = [P]
+    l.coati_engine_fp8_bytes.restype = c_int64
     l.coati_engine_decode_workspace_bytes.argtypes = [P, I, I]
     l.coati_engine_decode_workspace_bytes.restype = c_int64
     l.coati_tokenizer_create.argtypes = [P, P, I, P, P, I, P]
@@ -152,7 +157,7 @@ def exported_symbols():
     return sorted(list(_SIGS) + ["coati_last_error", "coati_abi_version", "coati_engine_destroy",
                                  "coati_engine_param_elems", "coati_engine_shadow_elems",
                                  "coati_engine_workspace_bytes", "coati_engine_decode_workspace_bytes", "coati_engine_n_entries",
-                                 "coati_wgrad_grouped_workspace_bytes",
+                                 "coati_wgrad_grouped_workspace_bytes", "coati_engine_fp8_bytes",
                                  "coati_tokenizer_create", "coati_tokenizer_destroy", "coati_tokenizer_encode",
                                  "coati_tokenizer_pieces", "coati_tokenizer_encode_batch",
                                  "coati_engine_site_count", "coati_engine_site_name"])

@@ -21,6 +21,19 @@ int coati_gemm_nt(const void* A, int a_f32, int64_t lda, const uint16_t* B, int6
   return launch_gemm_nt(a, a_f32, epi, S_(stream));
 }
 
+int coati_quant_mx8(const void* x, int x_f32, int64_t ldx, uint8_t* q, int64_t ldq, uint8_t* scales, int M, int K, void* stream) {
+  return launch_quant_mx8(x, x_f32, ldx, q, ldq, scales, M, K, S_(stream));
+}
+int coati_gemm_mx8(const uint8_t* A, int64_t lda, const uint8_t* a_scales, const uint8_t* W, int64_t ldw, const uint8_t* w_scales,
+                   int M, int N, int K, void* C, int64_t ldc, const float* bias, const void* aux_in, void* aux_out, int64_t ld_aux,
+                   int epi, void* stream) {
+  GemmArgs a;
+  memset(&a, 0, sizeof(a));
+  a.A = A; a.lda = lda; a.B = reinterpret_cast<const bf16_t*>(W); a.ldb = ldw; a.M = M; a.N = N; a.K = K; a.C = C; a.ldc = ldc;
+  a.bias = bias; a.aux_in = aux_in; a.aux_out = aux_out; a.ld_aux = ld_aux;
+  COATI_CHECK_ARG(epi != EPI_QKV_ROPE, "gemm_mx8: the rotary epilogue is an engine-internal call");
+  return launch_gemm_mx8(a, a_scales, w_scales, epi, S_(stream));
+}
 int coati_gemm_ce_partial(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw, int M, int V, int K,
                           void* partial, void* stream) {
   GemmArgs a;

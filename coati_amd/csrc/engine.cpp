@@ -52,6 +52,8 @@ const char* kSiteNames[SITE_COUNT] = {
 struct XLayerP {  // offsets into the flat parameter buffer
   int64_t ln1w, ln1b, attnw, attnb, projw, projb, ln2w, ln2b, fc1w, fc1b, fc2w, fc2b;
   int64_t attnT, projT, fc1T, fc2T;  // offsets into the shadow buffer
+  // fp8 mode: byte offsets into the MXFP8 weight buffer: data of [natural | transposed] x {attn, proj, fc1, fc2}, then their scales
+  int64_t q8[8], s8[8];
 };
 struct GLayerP {
   int64_t e0w, e0b, e3w, e3b, n0w, n0b, n3w, n3b, c0w, c0b, c2w;
@@ -105,6 +107,9 @@ struct coati_engine {
   // bound buffers
   float *P = nullptr, *G = nullptr, *Mo = nullptr, *Vo = nullptr;
   bf16_t* S = nullptr;
+  unsigned char* S8 = nullptr;     // fp8 mode: MXFP8 copies of the transformer weights (caller-owned, coati_engine_bind_fp8)
+  int64_t n_fp8 = 0;               // its size in bytes
+  unsigned char *q8 = nullptr, *q8s = nullptr;   // fp8 mode: the quantised A operand of the current product + its scales (workspace)
   const float *cos_t = nullptr, *sin_t = nullptr;
   const int *lut_ix = nullptr, *lut_iy = nullptr;
   // per-step state (pointers into the caller's workspace)
@@ -296,6 +301,17 @@ void build_layout(coati_engine* e) {
   e->gd0T = add_shadow(e, (int64_t)H * H);
   e->gd3T = add_shadow(e, (int64_t)H * H);
 
+  // fp8 mode: MXFP8 weight copies.  index 0..3 = natural [N, K] of attn / proj / fc1 / fc2 (forward products), 4..7 = the
+  // transposed copies [K_in, N_out] (input-gradient products: the contraction runs over the layer's outputs)
+  e->n_fp8 = 0;
+  if (c.use_fp8) {
+    for (auto& x : e->xl) {
+      const int64_t rows[8] = {3 * C, C, 4 * C, C, C, C, C, 4 * C}, cols[8] = {C, C, C, 4 * C, 3 * C, C, 4 * C, C};
+      for (int i = 0; i < 8; ++i) { x.q8[i] = e->n_fp8; e->n_fp8 += (rows[i] * cols[i] + 255) & ~(int64_t)255; }
+      for (int i = 0; i < 8; ++i) { x.s8[i] = e->n_fp8; e->n_fp8 += (rows[i] * cols[i] / 32 + 255) & ~(int64_t)255; }
+    }
+  }
+
   // job table of the one-launch shadow refresh
   auto job = [&](int64_t src, int ld_src, int64_t dst, int ld_dst, int rows, int cols, int transpose) {
     e->tile_start.push_back(e->n_job_tiles);
@@ -370,6 +386,20 @@ int wgrad(coati_engine* e, int site, const void* A, int a_f32, int64_t lda, cons
   // algorithmic bytes: both activation operands once + the f32 gradient read-modify-write
   ProfScope ps(e, site, 2.0 * M * N * K, s, (double)M * N * (a_f32 ? 4 : 2) + (double)M * K * 2 + (double)N * K * 8);
   return launch_wgrad(a, a_f32, s);
+}
+
+// fp8 mode: one Linear product on MXFP8 -- quantise the bf16 A operand (rows of K) into the scratch, then the block-scaled fp8
+// matrix-core GEMM against the layer's MXFP8 weight copy `wi` (XLayerP::q8 / s8 index) with the usual fused epilogue
+int gemm8(coati_engine* e, int site, const XLayerP& w, int wi, const bf16_t* A, int64_t lda, int M, int N, int K, GemmArgs a, int epi, hipStream_t s) {
+  COATI_CHECK_ARG(e->S8 && e->q8, "fp8 mode: coati_engine_bind_fp8 has not been called");
+  a.A = e->q8; a.lda = K; a.B = reinterpret_cast<const bf16_t*>(e->S8 + w.q8[wi]); a.ldb = K; a.M = M; a.N = N; a.K = K;
+  const bool out32 = (epi == EPI_F32 || epi == EPI_RES_F32);
+  double bytes = (double)M * K * 3 + (double)M * K * (1.0 + 1.0 / 32) + (double)N * K * (1.0 + 1.0 / 32) + (double)M * N * (out32 ? 4 : 2);   // quantiser pass + product
+  if (epi == EPI_RES_F32) bytes += (double)M * N * 4;
+  if (epi == EPI_GELU_GRAD || epi == EPI_MUL_AUX) bytes += (double)M * N;
+  ProfScope ps(e, site, 2.0 * M * N * K, s, bytes);
+  COATI_TRY(launch_quant_mx8(A, 0, lda, e->q8, K, e->q8s, M, K, s));
+  return launch_gemm_mx8(a, e->q8s, e->S8 + w.s8[wi], epi, s);
 }
 
 // ---- workspace carving -----------------------------------------------------------------------------------
@@ -484,6 +514,10 @@ size_t carve(coati_engine* e, Arena& ar, int B, int T1, int T2, int A, int Bg) {
     if (!e->wg_group || csig != e->carve_sig) for (auto& k : e->wtab_key) k = coati_engine::WTabKey();
     e->carve_sig = csig;
   }
+  if (c.use_fp8) {   // the quantised A operand of one product (at most 4 C wide) + its block scales
+    e->q8 = ar.take<unsigned char>(Mmax * 4 * C);
+    e->q8s = ar.take<unsigned char>(Mmax * 4 * C / 32);
+  }
   e->opt_partial = ar.take<float>(1024);
   e->ln_partial = ar.take<float>((size_t)COATI_LN_PARTIAL_ROWS * 2 * (C > H ? C : H));
   e->ln_part_x = ar.take<float>((size_t)(2 * c.n_layer_xformer + 1) * COATI_LN_PARTIAL_ROWS * 2 * C);
@@ -511,6 +545,36 @@ int xformer_fwd(coati_engine* e, XPass& p, const float* injection, hipStream_t s
   }
   for (int l = 0; l < L; ++l) {
     const XLayerP& w = e->xl[l];
+    if (c.use_fp8) {
+      // MXFP8 products (BASELINE.json configs[4]); LayerNorm, attention, residual stream and saved tensors as in the bf16 path
+      GemmArgs a;
+      {
+        ProfScope ps(e, SITE_LN_FWD, 0, s, (double)M * C * 6 + (double)M * 8);
+        COATI_TRY(launch_layernorm_fwd(p.x[l], C, e->P + w.ln1w, e->P + w.ln1b, p.a1[l], C, nullptr, 0, p.mean1[l], p.rstd1[l], M, C, s));
+      }
+      memset(&a, 0, sizeof(a));
+      a.C = p.qkv[l]; a.ldc = 3 * C; a.bias = e->P + w.attnb; a.rope_cos = e->cos_t; a.rope_sin = e->sin_t; a.rope_T = p.T; a.rope_C = C;
+      a.rope_hs = C / c.n_head; a.rope_row_t = p.packed ? p.row_t : nullptr;
+      COATI_TRY(gemm8(e, SITE_QKV_FWD, w, 0, p.a1[l], C, M, 3 * C, C, a, EPI_QKV_ROPE, s));
+      {
+        ProfScope ps(e, SITE_ATTN_FWD, 4.0 * M * (double)p.T * C, s, (double)M * 4 * C * 2 + (double)M * c.n_head * 4);
+        COATI_TRY(launch_attn_fwd(p.qkv[l], p.y[l], p.lse[l], p.B, p.T, c.n_head, C / c.n_head, s, p.packed ? p.off : nullptr));
+      }
+      memset(&a, 0, sizeof(a));
+      a.C = p.xmid[l]; a.ldc = C; a.bias = e->P + w.projb; a.aux_in = p.x[l]; a.ld_aux = C;
+      COATI_TRY(gemm8(e, SITE_PROJ_FWD, w, 1, p.y[l], C, M, C, C, a, EPI_RES_F32, s));
+      {
+        ProfScope ps(e, SITE_LN_FWD, 0, s, (double)M * C * 6 + (double)M * 8);
+        COATI_TRY(launch_layernorm_fwd(p.xmid[l], C, e->P + w.ln2w, e->P + w.ln2b, p.a2[l], C, nullptr, 0, p.mean2[l], p.rstd2[l], M, C, s));
+      }
+      memset(&a, 0, sizeof(a));
+      a.C = p.g[l]; a.ldc = 4 * C; a.bias = e->P + w.fc1b; a.aux_out = p.hpre[l]; a.ld_aux = 4 * C;
+      COATI_TRY(gemm8(e, SITE_FC1_FWD, w, 2, p.a2[l], C, M, 4 * C, C, a, EPI_GELU_GRAD, s));
+      memset(&a, 0, sizeof(a));
+      a.C = p.x[l + 1]; a.ldc = C; a.bias = e->P + w.fc2b; a.aux_in = p.xmid[l]; a.ld_aux = C;
+      COATI_TRY(gemm8(e, SITE_FC2_FWD, w, 3, p.g[l], 4 * C, M, C, 4 * C, a, EPI_RES_F32, s));
+      continue;
+    }
     {
       // QKV projection with RoPE applied to the q,k blocks in the epilogue (saved qkv holds the ROTATED q,k).  Where the
       // row-block kernel takes the product, ln_1 is evaluated inside its operand load (x f32 in; a1, mean, rstd out): no
@@ -639,9 +703,19 @@ int xformer_bwd(coati_engine* e, XPass& p, const void* dyf, int dyf_f32, float* 
     bf16_t* const dqkv = grp ? e->w_dqkv[l] : e->dqkv;
     bf16_t* const dx_out = grp ? (l > 0 ? e->w_dxa[l - 1] : e->DX16) : e->DX16;   // d x[l] for the layer below
     // x[l+1] = xmid + g W2^T + b2
+    if (c.use_fp8) {   // input gradients on MXFP8: the gradient rows are quantised like the activations (e4m3, block of 32 along k)
+      GemmArgs a;
+      memset(&a, 0, sizeof(a));
+      a.C = dh4; a.ldc = 4 * C; a.aux_in = p.hpre[l]; a.ld_aux = 4 * C;
+      COATI_TRY(gemm8(e, SITE_FC2_DGRAD, w, 7, dxa, C, M, 4 * C, C, a, EPI_MUL_AUX, s));
+      memset(&a, 0, sizeof(a));
+      a.C = e->da; a.ldc = C;
+      COATI_TRY(gemm8(e, SITE_FC1_DGRAD, w, 6, dh4, 4 * C, M, C, 4 * C, a, EPI_BF16, s));
+    } else {
     COATI_TRY(gemm(e, SITE_FC2_DGRAD, dxa, 0, C, e->S + w.fc2T, C, M, 4 * C, C, dh4, 4 * C, nullptr, EPI_MUL_AUX, p.hpre[l], nullptr, 4 * C, s));
     // hpre = a2 W1^T + b1
     COATI_TRY(gemm(e, SITE_FC1_DGRAD, dh4, 0, 4 * C, e->S + w.fc1T, 4 * C, M, C, 4 * C, e->da, C, nullptr, EPI_BF16, nullptr, nullptr, 0, s));
+    }
     if (!grp) {
       COATI_TRY(wgrad(e, SITE_XF_WGRAD, dh4, 0, 4 * C, p.a2[l], C, M, 4 * C, C, e->G + w.fc1w, C, e->G + w.fc1b, 0, s));
       // (the fc2 weight gradient runs after the two consumers of dh4, so that dh4 is re-read while it is still warm)
@@ -652,13 +726,27 @@ int xformer_bwd(coati_engine* e, XPass& p, const void* dyf, int dyf_f32, float* 
       COATI_TRY(ln_bwd(e->da, 0, p.xmid[l], p.mean2[l], p.rstd2[l], e->P + w.ln2w, DX, w.ln2w, w.ln2b, dxb));
     }
     // xmid = x[l] + y Wp^T + bp
+    if (c.use_fp8) {
+      GemmArgs a;
+      memset(&a, 0, sizeof(a));
+      a.C = e->dyb; a.ldc = C;
+      COATI_TRY(gemm8(e, SITE_PROJ_DGRAD, w, 5, dxb, C, M, C, C, a, EPI_BF16, s));
+    } else {
     COATI_TRY(gemm(e, SITE_PROJ_DGRAD, dxb, 0, C, e->S + w.projT, C, M, C, C, e->dyb, C, nullptr, EPI_BF16, nullptr, nullptr, 0, s));
+    }
     if (!grp) COATI_TRY(wgrad(e, SITE_XF_WGRAD, dxb, 0, C, p.y[l], C, M, C, C, e->G + w.projw, C, e->G + w.projb, 0, s));
     {
       ProfScope ps(e, SITE_ATTN_BWD, 10.0 * M * (double)p.T * C, s, (double)M * 8 * C * 2 + (double)M * c.n_head * 8);   // qkv, y, dy in; dqkv out
       COATI_TRY(launch_attn_bwd(p.qkv[l], p.y[l], e->dyb, p.lse[l], e->attnD, dqkv, e->cos_t, e->sin_t, p.B, p.T, c.n_head, C / c.n_head, s, p.packed ? p.off : nullptr));
     }
+    if (c.use_fp8) {
+      GemmArgs a;
+      memset(&a, 0, sizeof(a));
+      a.C = e->da; a.ldc = C;
+      COATI_TRY(gemm8(e, SITE_QKV_DGRAD, w, 4, dqkv, 3 * C, M, C, 3 * C, a, EPI_BF16, s));
+    } else {
     COATI_TRY(gemm(e, SITE_QKV_DGRAD, dqkv, 0, 3 * C, e->S + w.attnT, 3 * C, M, C, 3 * C, e->da, C, nullptr, EPI_BF16, nullptr, nullptr, 0, s));
+    }
     if (!grp) COATI_TRY(wgrad(e, SITE_XF_WGRAD, dqkv, 0, 3 * C, p.a1[l], C, M, 3 * C, C, e->G + w.attnw, C, e->G + w.attnb, 0, s));
     {
       ProfScope ps(e, SITE_LN_BWD, 0, s, (double)M * C * (2 + 4 + 4 + 4 + 2));   // dy16, x, dres in; dx, dx16 out
@@ -838,6 +926,7 @@ int coati_engine_create(const coati_config* cfg, coati_engine** out) {
   COATI_CHECK_SHAPE(E == C, "engine_create: n_embd_common (%d) must equal n_hidden_xformer (%d)", E, C);
   COATI_CHECK_SHAPE(cfg->n_seq > 0 && cfg->n_seq <= 256 && cfg->n_tok > 8, "engine_create: n_seq must be <= 256");
   COATI_CHECK_SHAPE(cfg->n_layer_xformer >= 1 && cfg->n_layer_e3gnn >= 0, "engine_create: bad layer counts");
+  COATI_CHECK_SHAPE(!cfg->use_fp8 || C % 128 == 0, "engine_create: fp8 mode needs n_hidden_xformer %% 128 == 0 (C=%d)", C);
   coati_engine* e = new coati_engine();
   e->cfg = *cfg;
   build_layout(e);
@@ -885,6 +974,28 @@ int coati_engine_bind(coati_engine* e, float* params, float* grads, float* adam_
   return COATI_OK;
 }
 
+int64_t coati_engine_fp8_bytes(const coati_engine* e) { return e ? e->n_fp8 : 0; }
+int coati_engine_bind_fp8(coati_engine* e, uint8_t* fp8_shadow, int64_t bytes) {
+  COATI_CHECK_ARG(e && e->cfg.use_fp8 && fp8_shadow && bytes >= e->n_fp8, "engine_bind_fp8: not an fp8 engine / buffer too small");
+  e->S8 = fp8_shadow;
+  return COATI_OK;
+}
+
+// fp8 mode: MXFP8 copies of the transformer weights from the (fresh) bf16 shadows: natural [N, K] for the forward products,
+// the transposed shadows for the input-gradient products (each quantised along ITS contraction dimension)
+static int refresh_fp8_weights(coati_engine* e, hipStream_t s) {
+  if (!e->cfg.use_fp8) return COATI_OK;
+  COATI_CHECK_ARG(e->S8, "fp8 mode: coati_engine_bind_fp8 has not been called");
+  const int C = e->cfg.n_hidden_xformer;
+  for (const XLayerP& w : e->xl) {
+    const int64_t src[8] = {w.attnw, w.projw, w.fc1w, w.fc2w, w.attnT, w.projT, w.fc1T, w.fc2T};
+    const int rows[8] = {3 * C, C, 4 * C, C, C, C, C, 4 * C}, cols[8] = {C, C, C, 4 * C, 3 * C, C, 4 * C, C};
+    for (int i = 0; i < 8; ++i)
+      COATI_TRY(launch_quant_mx8(e->S + src[i], 0, cols[i], e->S8 + w.q8[i], cols[i], e->S8 + w.s8[i], rows[i], cols[i], s));
+  }
+  return COATI_OK;
+}
+
 static int refresh_shadows_impl(coati_engine* e, void* stream, bool natural_done) {
   COATI_CHECK_ARG(e && e->P && e->S, "refresh_shadows: engine not bound");
   hipStream_t s = (hipStream_t)stream;
@@ -901,14 +1012,15 @@ static int refresh_shadows_impl(coati_engine* e, void* stream, bool natural_done
       }
       e->jobs_uploaded = true;
     }
-    return launch_shadow_jobs(e->d_jobs, e->d_tile_start, (int)e->jobs.size(), e->n_job_tiles, e->P, e->S, s);
+    COATI_TRY(launch_shadow_jobs(e->d_jobs, e->d_tile_start, (int)e->jobs.size(), e->n_job_tiles, e->P, e->S, s));
+    return refresh_fp8_weights(e, s);
   }
   // no workspace yet (first refresh after loading weights): one launch per matrix
   for (const ShadowJob& j : e->jobs) {
     if (j.transpose) COATI_TRY(launch_transpose_cast(e->P + j.src_off, j.ld_src, e->S + j.dst_off, j.ld_dst, j.rows, j.cols, s));
     else COATI_TRY(launch_pack_rows_cast(e->P + j.src_off, j.ld_src, e->S + j.dst_off, j.ld_dst, j.rows, j.cols, s));
   }
-  return COATI_OK;
+  return refresh_fp8_weights(e, s);
 }
 
 int coati_engine_refresh_shadows(coati_engine* e, void* stream) { return refresh_shadows_impl(e, stream, false); }

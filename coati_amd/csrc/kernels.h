@@ -87,6 +87,12 @@ int launch_gemm_rb256(const GemmArgs& a, int epi, hipStream_t s);
 // ring kernel for N = 256, long K (gemm_ring.hip)
 bool gemm_ring256_supported(const GemmArgs& a, int a_f32, int epi);
 int launch_gemm_ring256(const GemmArgs& a, int epi, hipStream_t s);
+// MXFP8 (gemm_mx8.hip): e4m3 operands + one E8M0 scale per 32 k, v_mfma_scale_f32_32x32x64_f8f6f4.  a.A / a.B are the e4m3
+// bytes (a.lda / a.ldb in bytes), sa / sb the scale bytes [rows, K / 32]; K % 128 == 0; epilogues BF16, F32, RES_F32, GELU_GRAD,
+// MUL_AUX, QKV_ROPE.  launch_quant_mx8 quantises rows of bf16 / f32 (blocks of 32 along k, shared exponent floor(log2 amax) - 8).
+int launch_gemm_mx8(const GemmArgs& a, const unsigned char* sa, const unsigned char* sb, int epi, hipStream_t s);
+int launch_quant_mx8(const void* x, int x_f32, long long ldx, unsigned char* q, long long ldq, unsigned char* scales, int M, int K, hipStream_t s);
+
 // dW[N,K] (f32, atomic +=) = A[M,N]^T * B[M,K];  dbias[N] (atomic +=) = colsum(A) if non-null
 struct WgradArgs {
   const void* A;   // [M,N] bf16 or f32

@@ -29,6 +29,7 @@ class ModelConfig:
     pad_token: int = 0
     stop_token: int = 1
     unk_token: int = 7
+    fp8: bool = False     # BASELINE.json configs[4]: the transformer's Linear forward / input-gradient products on MXFP8 (needs C % 128 == 0)
 
 
 # COATI_PACK_ROWS=0 ignores the batches' packed-row counts: every step then runs on the padded [B, T] layout (A/B switch)
@@ -47,7 +48,7 @@ class Engine:
         self.l = _lib.lib()
         c = _lib.CoatiConfig(cfg.n_layer_xformer, cfg.n_layer_e3gnn, cfg.n_hidden_xformer, cfg.n_hidden_e3nn,
                              cfg.n_embd_common, cfg.n_head, cfg.n_seq, cfg.n_tok, cfg.msg_cutoff, cfg.pad_token,
-                             cfg.stop_token, cfg.unk_token)
+                             cfg.stop_token, cfg.unk_token, 1 if cfg.fp8 else 0)
         h = ctypes.c_void_p()
         _lib.check(self.l.coati_engine_create(ctypes.byref(c), ctypes.byref(h)), "coati_engine_create")
         self.h = h
@@ -73,6 +74,11 @@ class Engine:
         _lib.check(self.l.coati_engine_bind(h, ptr(self.params), ptr(self.grads), ptr(self.adam_m), ptr(self.adam_v),
                                             ptr(self.shadow), ptr(self.cos), ptr(self.sin), ptr(self.lut_ix),
                                             ptr(self.lut_iy)), "coati_engine_bind")
+        self.shadow8 = None
+        if cfg.fp8:   # MXFP8 copies of the transformer weights (e4m3 + E8M0 scales), refreshed with the bf16 shadows
+            n8 = int(self.l.coati_engine_fp8_bytes(h))
+            self.shadow8 = torch.zeros(n8, device=dev, dtype=torch.uint8)
+            _lib.check(self.l.coati_engine_bind_fp8(h, ptr(self.shadow8), n8), "coati_engine_bind_fp8")
         self.workspace = None
         self.scal = torch.zeros(16, device=dev, dtype=torch.float32)
         self._shape = None

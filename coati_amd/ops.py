@@ -49,6 +49,35 @@ def gemm_nt(A, W, bias=None, epi=EPI_BF16, aux_in=None, out=None, n_store=0):
     return (out, aux_out) if aux_out is not None else out
 
 
+def quant_mx8(x):
+    """rows of bf16 / f32 x [M, K] -> (q [M, K] uint8 holding OCP e4m3, scales [M, K / 32] uint8 holding E8M0): MXFP8 blocks of 32 along k"""
+    _need_cuda(x)
+    M, K = x.shape
+    q = torch.empty(M, K, device=x.device, dtype=torch.uint8)
+    sc = torch.empty(M, K // 32, device=x.device, dtype=torch.uint8)
+    _lib.call("coati_quant_mx8", ptr(x), 1 if x.dtype == torch.float32 else 0, x.stride(0), ptr(q), q.stride(0), ptr(sc), M, K, stream())
+    return q, sc
+
+
+def gemm_mx8(Aq, As, Wq, Ws, bias=None, epi=EPI_BF16, aux_in=None, out=None):
+    """C = epilogue(dequant(Aq, As) @ dequant(Wq, Ws)^T + bias) on the block-scaled fp8 matrix core instruction (K % 128 == 0)"""
+    _need_cuda(Aq, Wq)
+    M, K = Aq.shape
+    N = Wq.shape[0]
+    out_f32 = epi in (EPI_F32, EPI_RES_F32, EPI_ACC_F32)
+    if out is None:
+        out = torch.empty(M, N, device=Aq.device, dtype=torch.float32 if out_f32 else BF16)
+    aux_out, ld_aux = None, 0
+    if epi == EPI_GELU_GRAD:
+        aux_out = torch.empty(M, N, device=Aq.device, dtype=torch.uint8)
+        ld_aux = aux_out.stride(0)
+    if aux_in is not None:
+        ld_aux = aux_in.stride(0)
+    _lib.call("coati_gemm_mx8", ptr(Aq), Aq.stride(0), ptr(As), ptr(Wq), Wq.stride(0), ptr(Ws), M, N, K, ptr(out), out.stride(0),
+              ptr(bias), ptr(aux_in), ptr(aux_out), ld_aux, epi, stream())
+    return (out, aux_out) if aux_out is not None else out
+
+
 def dq8(q):
     """value of the 8-bit fixed-point codes the forward MLP saves for NewGELU' (csrc/common.h: q / 200 - 0.13)"""
     return q.float() / 200.0 - 0.13

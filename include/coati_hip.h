@@ -61,6 +61,17 @@ int coati_gemm_nt(const void* A, int a_f32, int64_t lda, const uint16_t* B, int6
                   void* C, int64_t ldc, int n_store, const float* bias, const void* aux_in, void* aux_out,
                   int64_t ld_aux, int epi, void* stream);
 
+/* MXFP8 (OCP Microscaling: e4m3 elements, one E8M0 scale per 32 consecutive k) -- BASELINE.json configs[4] "fp8 MFMA GEMMs".
+ * coati_quant_mx8: rows of bf16 (x_f32 = 0) or f32 x [M, K] -> q [M, K] e4m3 bytes + scales [M, K / 32] (K % 32 == 0; shared
+ * exponent floor(log2 amax) - 8, saturating conversion).  coati_gemm_mx8: C[M, N] = epilogue(A W^T + bias) on
+ * v_mfma_scale_f32_32x32x64_f8f6f4 (the matrix core applies the block scales), fp32 accumulation, K % 128 == 0, lda / ldw in
+ * bytes, epilogues COATI_EPI_BF16 / F32 / RES_F32 / GELU_GRAD / MUL_AUX as coati_gemm_nt.  Replaces F.linear / its input
+ * gradient in the d = 512 transformer block (simple_coati2/transformer_only.py:43) when the engine runs with fp8 = 1. */
+int coati_quant_mx8(const void* x, int x_f32, int64_t ldx, uint8_t* q, int64_t ldq, uint8_t* scales, int M, int K, void* stream);
+int coati_gemm_mx8(const uint8_t* A, int64_t lda, const uint8_t* a_scales, const uint8_t* W, int64_t ldw, const uint8_t* w_scales,
+                   int M, int N, int K, void* C, int64_t ldc, const float* bias, const void* aux_in, void* aux_out, int64_t ld_aux,
+                   int epi, void* stream);
+
 /* lm_head + cross-entropy without materialising logits (smiles_xformer.py:453 + train_coati.py:260-265):
  * partial[M, ceil(V/128)] receives per-tile (max, sum exp) pairs; coati_ce_finish merges them into lse[M] and
  * adds sum(lse - logit[target]) to scal[0] and the number of targets != -1 to scal[1]. */
@@ -231,6 +242,8 @@ typedef struct coati_config {
   int32_t n_tok;            /* V */
   float msg_cutoff;         /* effective cutoff of e_gcl_sparse (always 5.0 in the reference) */
   int32_t pad_token, stop_token, unk_token;
+  int32_t use_fp8;          /* 1: the four Linear layers of every transformer block run their forward and input-gradient
+                               products on MXFP8 (coati_gemm_mx8); needs C % 128 == 0 and coati_engine_bind_fp8 */
 } coati_config;
 
 typedef struct coati_engine coati_engine;
@@ -250,6 +263,10 @@ int64_t coati_engine_workspace_bytes(const coati_engine* e, int B, int T1, int T
  * RoPE tables [n_seq,16] f32, periodic-table LUTs [120] int32 (one-hot indices, -1 = none). */
 int coati_engine_bind(coati_engine* e, float* params, float* grads, float* adam_m, float* adam_v, uint16_t* shadow,
                       const float* rope_cos, const float* rope_sin, const int32_t* lut_ix, const int32_t* lut_iy);
+/* fp8 mode (cfg.use_fp8): caller-owned buffer for the MXFP8 copies of the transformer weights (e4m3 + E8M0 scales, natural
+ * and transposed), coati_engine_fp8_bytes bytes; refreshed together with the bf16 shadows */
+int64_t coati_engine_fp8_bytes(const coati_engine* e);
+int coati_engine_bind_fp8(coati_engine* e, uint8_t* fp8_shadow, int64_t bytes);
 /* rebuild every bf16 shadow (natural + transposed/packed) from the f32 parameters */
 int coati_engine_refresh_shadows(coati_engine* e, void* stream);
 

@@ -364,6 +364,46 @@ def test_staged_backward_equals_whole_backward():
             assert float((a - b).abs().max()) <= 1e-5 * scale + 1e-12, (order, name, float((a - b).abs().max()), scale)
 
 
+@pytest.mark.parametrize("layout", ["padded", "packed"])
+def test_coati2_width_d512_step_vs_oracle(layout):
+    """BASELINE.json configs[4] at its real width: d = 512, 16 heads of size 32, vocabulary 4266 (coati2_12_12), E(3)-GNN at
+    h = 512 -- the only pinned maths of that config is the transformer block at this width (reference
+    coati/models/simple_coati2/transformer_only.py:43, same block as basic_transformer.py:157-174; the 3D encoder and the
+    training step have no reference code: parity unpinned).  One layer each and 128 molecules x 80 tokens (10 240 rows) so
+    that the oracle finishes in seconds while the K = 512 / N = 1536 / 2048 products, the grouped 256-wide weight gradient at
+    K = 512 and 2048, the head-size-32 attention and the lm_head at V = 4266 all run at their real widths."""
+    from oracle import coati_oracle as O
+    from coati_amd.engine import Engine, ModelConfig
+    from coati_amd.synthetic import make_batch
+    kw = dict(n_layer_e3gnn=1, n_layer_xformer=1, n_hidden_xformer=512, n_hidden_e3nn=512, n_embd_common=512, n_head=16,
+              n_seq=250, n_tok=4266)
+    ocfg = O.OracleConfig(**kw)
+    P = O.init_params(ocfg, seed=512)
+    eng = Engine(ModelConfig(**kw), DEV)
+    eng.load_state_dict(P)
+    batch, up = make_batch(128, 80, 16, 4266, seed=51, n_special=330, p_bad=0.03, min_len=16, with_rows=(layout == "packed"))
+    db = {k: (v if k == "rows" else v.to(DEV)) for k, v in batch.items()}
+    eng.train_step(db, up.to(DEV), lr=1e-3, optimizer=False)
+    assert eng._packed == (layout == "packed")
+    L = eng.losses()
+    Pg = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    with O.sim_bf16():
+        loss, ar, cl, _ = O.step_loss(Pg, ocfg, batch, up)
+    loss.backward()
+    check(f"d512 [{layout}] ar", torch.tensor([L["ar_loss"]]), ar.detach().reshape(1), TOL_LOSS_SIM)
+    check(f"d512 [{layout}] clip", torch.tensor([L["clip_loss"]]), cl.detach().reshape(1), TOL_LOSS_SIM)
+    grads = eng.named_views("grads")
+    worst = []
+    for k in sorted(eng.layout):
+        ref = Pg[k].grad if Pg[k].grad is not None else torch.zeros_like(P[k])
+        if float(ref.abs().max()) > 0:
+            worst.append((float((grads[k].cpu() - ref).abs().max()) / float(ref.abs().max()), k))
+    worst.sort(reverse=True)
+    log(f"d512 [{layout}] worst gradient deviations {worst[:4]}")
+    assert worst[0][0] <= TOL_GRAD_SIM, worst[:6]
+
+
 def test_head_size_32_model_grads_and_decode():
     """The COATI2-size transformer shape (n_embd / n_head = 32): a full training step against
     the oracle (pinned at head size 32 by tests/test_oracle_golden.py::test_block_head_size_32), and the KV-cached decode

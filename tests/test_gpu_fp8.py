@@ -1,0 +1,126 @@
+"""MXFP8 path (BASELINE.json configs[4] "fp8 MFMA GEMMs"): the quantiser against the OCP Microscaling definition evaluated
+with torch (bit-exact), the block-scaled fp8 matrix-core GEMM against fp32 torch on the DEQUANTISED operands (exact products,
+fp32 accumulation order only), and the engine in fp8 mode against its own bf16 path and the oracle.  The reference has no fp8
+code (README.md:28): this is parity against our own bf16 path, stated as such."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from tests.gpu_util import check, log, rbf  # noqa: E402
+
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from coati_amd import ops as o
+    return o
+
+
+def mx_quant_ref(x):
+    """OCP MX v1.0: block of 32 along the last dim; shared exponent floor(log2(max |x|)) - emax(e4m3 = 8); elements
+    round-to-nearest-even e4m3 with saturation (torch.float8_e4m3fn after a clamp to +-448)"""
+    M, K = x.shape
+    xb = x.float().view(M, K // 32, 32)
+    am = xb.abs().amax(-1)
+    e = torch.floor(torch.log2(torch.clamp(am, min=1e-45)))
+    e = torch.where(am > 0, e, torch.full_like(e, -127.0))
+    se = torch.clamp(e - 8, -127, 127)
+    scaled = (xb * torch.exp2(-se).unsqueeze(-1)).clamp(-448.0, 448.0)
+    q = scaled.to(torch.float8_e4m3fn)
+    return q.view(M, K), (se + 127).to(torch.uint8), (q.float() * torch.exp2(se).unsqueeze(-1)).view(M, K)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_quant_mx8_bit_exact(ops, dtype):
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(301, 512, generator=g) * torch.exp2(torch.randint(-12, 9, (301, 1), generator=g).float())
+    x[5, :64] = 0.0                      # an all-zero block
+    x[6, 70] = 3.0e4                     # a block dominated by one element
+    x[7, 0:32] = 447.0; x[7, 1] = 500.0  # saturation inside the top binade
+    x = x.to(dtype)
+    q, sc = ops.quant_mx8(x.to(DEV))
+    q_ref, sc_ref, _ = mx_quant_ref(x)
+    assert torch.equal(sc.cpu(), sc_ref), (sc.cpu()[:2], sc_ref[:2])
+    assert torch.equal(q.cpu(), q_ref.view(torch.uint8))
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 192, 128), (1000, 1536, 512), (4099, 512, 2048), (128, 2048, 512), (77, 130 // 2 * 2 + 62, 256)])
+def test_gemm_mx8_vs_dequantised_fp32(ops, M, N, K):
+    """the block scales are applied by the matrix core: rows / k blocks get wildly different magnitudes, so a misplaced scale
+    (wrong lane, wrong block, wrong byte) is orders of magnitude off"""
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g) * torch.exp2(torch.randint(-6, 6, (M, K // 32), generator=g).float()).repeat_interleave(32, 1)
+    W = torch.randn(N, K, generator=g) / math.sqrt(K) * torch.exp2(torch.randint(-5, 5, (N, K // 32), generator=g).float()).repeat_interleave(32, 1)
+    bias = torch.randn(N, generator=g)
+    Aq, As = ops.quant_mx8(A.to(DEV))
+    Wq, Ws = ops.quant_mx8(W.to(DEV))
+    _, _, Ad = mx_quant_ref(A)
+    _, _, Wd = mx_quant_ref(W)
+    ref = Ad.double() @ Wd.double().t() + bias.double()
+    c = ops.gemm_mx8(Aq, As, Wq, Ws, bias.to(DEV), ops.EPI_F32)
+    check(f"mx8 gemm f32 {M}x{N}x{K}", c.cpu().double(), ref, 5e-5)    # fp32 accumulation of products spanning 2^22 in magnitude
+    c = ops.gemm_mx8(Aq, As, Wq, Ws, bias.to(DEV), ops.EPI_BF16)
+    check(f"mx8 gemm bf16 {M}x{N}x{K}", c.float().cpu().double(), ref, 6e-3)
+    if N % 8 == 0:
+        res = torch.randn(M, N, generator=g)
+        c = ops.gemm_mx8(Aq, As, Wq, Ws, bias.to(DEV), ops.EPI_RES_F32, aux_in=res.to(DEV))
+        check(f"mx8 gemm res {M}x{N}x{K}", c.cpu().double(), ref + res.double(), 5e-5)
+    # what fp8 costs: against the unquantised product
+    full = A.double() @ W.double().t() + bias.double()
+    e = float((ref - full).abs().max()) / float(full.abs().max())
+    log(f"mx8 gemm {M}x{N}x{K}: quantisation error of the product {e:.3e} of its scale")
+    assert e < 8e-2
+
+
+@pytest.mark.parametrize("name,kw,shape", [
+    ("d128", dict(n_layer_e3gnn=1, n_layer_xformer=2, n_hidden_xformer=128, n_hidden_e3nn=128, n_embd_common=128, n_head=8, n_seq=64, n_tok=300), (48, 40, 10)),
+    ("d512", dict(n_layer_e3gnn=1, n_layer_xformer=1, n_hidden_xformer=512, n_hidden_e3nn=512, n_embd_common=512, n_head=16, n_seq=250, n_tok=4266), (128, 80, 16)),
+])
+def test_engine_fp8_step_vs_bf16_path_and_oracle(name, kw, shape):
+    """The engine with fp8 = True (the four Linear layers of every transformer block: forward and input-gradient products on
+    MXFP8, weight gradients / attention / lm_head / GNN unchanged) against the same engine in bf16 and against the fp32 oracle:
+    what e4m3 operands (3 mantissa bits, one scale per 32 k) cost on a whole step.  d512 = the width of BASELINE.json configs[4]."""
+    from oracle import coati_oracle as O
+    from coati_amd.engine import Engine, ModelConfig
+    from coati_amd.synthetic import make_batch
+    B, T, A = shape
+    ocfg = O.OracleConfig(**kw)
+    P = O.init_params(ocfg, seed=88)
+    batch, up = make_batch(B, T, A, kw["n_tok"], seed=B, n_special=12, p_bad=0.04, min_len=8, with_rows=True)
+    db = {k: (v if k == "rows" else v.to(DEV)) for k, v in batch.items()}
+    res = {}
+    for mode in ("bf16", "fp8"):
+        eng = Engine(ModelConfig(fp8=(mode == "fp8"), **kw), DEV)
+        eng.load_state_dict(P)
+        h_e, h_s, _ = eng.train_step(db, up.to(DEV), lr=1e-3, optimizer=False)
+        res[mode] = (eng.losses(), {k: v.cpu().clone() for k, v in eng.named_views("grads").items()}, h_s.cpu())
+    Pg = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    loss, ar, cl, _ = O.step_loss(Pg, ocfg, {k: v for k, v in batch.items() if k != "rows"}, up)
+    loss.backward()
+    L8, g8, hs8 = res["fp8"]
+    L16, g16, hs16 = res["bf16"]
+    log(f"fp8 [{name}] losses: fp8 {L8['ar_loss']:.5f} / {L8['clip_loss']:.5f}  bf16 {L16['ar_loss']:.5f} / {L16['clip_loss']:.5f}  oracle {float(ar):.5f} / {float(cl):.5f}")
+    check(f"fp8 [{name}] h_smiles vs bf16 path", hs8, hs16, 6e-2)
+    assert abs(L8["ar_loss"] - float(ar)) <= 1e-2 * abs(float(ar)) and abs(L8["clip_loss"] - float(cl)) <= 3e-2 * abs(float(cl)), (L8, float(ar), float(cl))
+    worst8, worst16 = [], []
+    for k in sorted(g8):
+        ref = Pg[k].grad if Pg[k].grad is not None else torch.zeros_like(P[k])
+        sc = float(ref.abs().max())
+        if sc > 0:
+            worst8.append((float((g8[k] - ref).abs().max()) / sc, k))
+            worst16.append((float((g16[k] - ref).abs().max()) / sc, k))
+    worst8.sort(reverse=True); worst16.sort(reverse=True)
+    log(f"fp8 [{name}] worst gradient deviations from the fp32 oracle: fp8 {worst8[:3]}  bf16 {worst16[:2]}")
+    assert worst8[0][0] <= 0.25, worst8[:5]
+    # cosine of every gradient tensor with the oracle's: the direction survives e4m3
+    for k in g8:
+        ref = Pg[k].grad
+        if ref is None or float(ref.abs().max()) == 0 or ref.numel() < 64:
+            continue
+        cos = float((g8[k].flatten().double() @ ref.flatten().double()) / (g8[k].double().norm() * ref.double().norm() + 1e-30))
+        assert cos > 0.97, (k, cos)
