@@ -109,7 +109,9 @@ struct coati_engine {
   bf16_t* S = nullptr;
   unsigned char* S8 = nullptr;     // fp8 mode: MXFP8 copies of the transformer weights (caller-owned, coati_engine_bind_fp8)
   int64_t n_fp8 = 0;               // its size in bytes
-  unsigned char *q8 = nullptr, *q8s = nullptr;   // fp8 mode: the quantised A operand of the current product + its scales (workspace)
+  // fp8 mode: two scratch sets (workspace) for quantised operands + scales: [0] = the A operand quantised by gemm8's own pass,
+  // [1] = an operand the PREVIOUS product's epilogue emitted (g for FC2, d hidden for the FC1 input gradient)
+  unsigned char *q8 = nullptr, *q8s = nullptr, *q8b = nullptr, *q8bs = nullptr;
   const float *cos_t = nullptr, *sin_t = nullptr;
   const int *lut_ix = nullptr, *lut_iy = nullptr;
   // per-step state (pointers into the caller's workspace)
@@ -390,16 +392,22 @@ int wgrad(coati_engine* e, int site, const void* A, int a_f32, int64_t lda, cons
 
 // fp8 mode: one Linear product on MXFP8 -- quantise the bf16 A operand (rows of K) into the scratch, then the block-scaled fp8
 // matrix-core GEMM against the layer's MXFP8 weight copy `wi` (XLayerP::q8 / s8 index) with the usual fused epilogue
-int gemm8(coati_engine* e, int site, const XLayerP& w, int wi, const bf16_t* A, int64_t lda, int M, int N, int K, GemmArgs a, int epi, hipStream_t s) {
+// A == nullptr: the operand is already quantised in the second scratch set (emitted by the previous product's epilogue);
+// emit: this product's epilogue leaves the MXFP8 copy of its bf16 output there for the next one
+int gemm8(coati_engine* e, int site, const XLayerP& w, int wi, const bf16_t* A, int64_t lda, int M, int N, int K, GemmArgs a, int epi, hipStream_t s,
+          bool emit = false) {
   COATI_CHECK_ARG(e->S8 && e->q8, "fp8 mode: coati_engine_bind_fp8 has not been called");
-  a.A = e->q8; a.lda = K; a.B = reinterpret_cast<const bf16_t*>(e->S8 + w.q8[wi]); a.ldb = K; a.M = M; a.N = N; a.K = K;
+  const bool pre = A == nullptr;
+  a.A = pre ? e->q8b : e->q8; a.lda = K; a.B = reinterpret_cast<const bf16_t*>(e->S8 + w.q8[wi]); a.ldb = K; a.M = M; a.N = N; a.K = K;
+  if (emit) { a.q8_out = e->q8b; a.q8_scales = e->q8bs; a.ld_q8 = N; }
   const bool out32 = (epi == EPI_F32 || epi == EPI_RES_F32);
-  double bytes = (double)M * K * 3 + (double)M * K * (1.0 + 1.0 / 32) + (double)N * K * (1.0 + 1.0 / 32) + (double)M * N * (out32 ? 4 : 2);   // quantiser pass + product
+  double bytes = (pre ? 0.0 : (double)M * K * 3) + (double)M * K * (1.0 + 1.0 / 32) + (double)N * K * (1.0 + 1.0 / 32) + (double)M * N * (out32 ? 4 : 2);   // quantiser pass + product
   if (epi == EPI_RES_F32) bytes += (double)M * N * 4;
   if (epi == EPI_GELU_GRAD || epi == EPI_MUL_AUX) bytes += (double)M * N;
+  if (emit) bytes += (double)M * N * (1.0 + 1.0 / 32);
   ProfScope ps(e, site, 2.0 * M * N * K, s, bytes);
-  COATI_TRY(launch_quant_mx8(A, 0, lda, e->q8, K, e->q8s, M, K, s));
-  return launch_gemm_mx8(a, e->q8s, e->S8 + w.s8[wi], epi, s);
+  if (!pre) COATI_TRY(launch_quant_mx8(A, 0, lda, e->q8, K, e->q8s, M, K, s));
+  return launch_gemm_mx8(a, pre ? e->q8bs : e->q8s, e->S8 + w.s8[wi], epi, s);
 }
 
 // ---- workspace carving -----------------------------------------------------------------------------------
@@ -517,6 +525,8 @@ size_t carve(coati_engine* e, Arena& ar, int B, int T1, int T2, int A, int Bg) {
   if (c.use_fp8) {   // the quantised A operand of one product (at most 4 C wide) + its block scales
     e->q8 = ar.take<unsigned char>(Mmax * 4 * C);
     e->q8s = ar.take<unsigned char>(Mmax * 4 * C / 32);
+    e->q8b = ar.take<unsigned char>(Mmax * 4 * C);
+    e->q8bs = ar.take<unsigned char>(Mmax * 4 * C / 32);
   }
   e->opt_partial = ar.take<float>(1024);
   e->ln_partial = ar.take<float>((size_t)COATI_LN_PARTIAL_ROWS * 2 * (C > H ? C : H));
@@ -569,10 +579,10 @@ int xformer_fwd(coati_engine* e, XPass& p, const float* injection, hipStream_t s
       }
       memset(&a, 0, sizeof(a));
       a.C = p.g[l]; a.ldc = 4 * C; a.bias = e->P + w.fc1b; a.aux_out = p.hpre[l]; a.ld_aux = 4 * C;
-      COATI_TRY(gemm8(e, SITE_FC1_FWD, w, 2, p.a2[l], C, M, 4 * C, C, a, EPI_GELU_GRAD, s));
+      COATI_TRY(gemm8(e, SITE_FC1_FWD, w, 2, p.a2[l], C, M, 4 * C, C, a, EPI_GELU_GRAD, s, true));   // + g as MXFP8 for FC2
       memset(&a, 0, sizeof(a));
       a.C = p.x[l + 1]; a.ldc = C; a.bias = e->P + w.fc2b; a.aux_in = p.xmid[l]; a.ld_aux = C;
-      COATI_TRY(gemm8(e, SITE_FC2_FWD, w, 3, p.g[l], 4 * C, M, C, 4 * C, a, EPI_RES_F32, s));
+      COATI_TRY(gemm8(e, SITE_FC2_FWD, w, 3, nullptr, 4 * C, M, C, 4 * C, a, EPI_RES_F32, s));
       continue;
     }
     {
@@ -707,10 +717,10 @@ int xformer_bwd(coati_engine* e, XPass& p, const void* dyf, int dyf_f32, float* 
       GemmArgs a;
       memset(&a, 0, sizeof(a));
       a.C = dh4; a.ldc = 4 * C; a.aux_in = p.hpre[l]; a.ld_aux = 4 * C;
-      COATI_TRY(gemm8(e, SITE_FC2_DGRAD, w, 7, dxa, C, M, 4 * C, C, a, EPI_MUL_AUX, s));
+      COATI_TRY(gemm8(e, SITE_FC2_DGRAD, w, 7, dxa, C, M, 4 * C, C, a, EPI_MUL_AUX, s, true));   // + d hidden as MXFP8 for the FC1 input gradient
       memset(&a, 0, sizeof(a));
       a.C = e->da; a.ldc = C;
-      COATI_TRY(gemm8(e, SITE_FC1_DGRAD, w, 6, dh4, 4 * C, M, C, 4 * C, a, EPI_BF16, s));
+      COATI_TRY(gemm8(e, SITE_FC1_DGRAD, w, 6, nullptr, 4 * C, M, C, 4 * C, a, EPI_BF16, s));
     } else {
     COATI_TRY(gemm(e, SITE_FC2_DGRAD, dxa, 0, C, e->S + w.fc2T, C, M, 4 * C, C, dh4, 4 * C, nullptr, EPI_MUL_AUX, p.hpre[l], nullptr, 4 * C, s));
     // hpre = a2 W1^T + b1

@@ -238,6 +238,29 @@ __device__ __forceinline__ void epilogue8(const GemmArgs& p, int row, int col0, 
     }
   }
   if (!rowok) return;
+  if (p.q8_out != nullptr) {
+    // fp8 mode (gemm_mx8.hip): the consumer of this bf16 tensor is another MXFP8 product -- emit its quantised copy here instead
+    // of a separate pass over the tensor.  One scale block = 32 columns = the 4 consecutive lanes that hold them (N % 32 == 0,
+    // all rows of a quad alike: the launcher checks); same arithmetic as quant_mx8_kernel.
+    float am = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) am = fmaxf(am, fabsf(o[e]));
+    am = fmaxf(am, __shfl_xor(am, 1, 64));
+    am = fmaxf(am, __shfl_xor(am, 2, 64));
+    int se = (int)((__float_as_uint(am) >> 23) & 0xff) - 127 - 8;
+    se = se < -127 ? -127 : (se > 127 ? 127 : se);
+    const float inv = __uint_as_float((unsigned)(127 - se) << 23);
+    float qv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) qv[e] = __builtin_amdgcn_fmed3f(o[e] * inv, -448.f, 448.f);
+    unsigned lo = 0, hi = 0;
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(qv[0], qv[1], lo, false);
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(qv[2], qv[3], lo, true);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(qv[4], qv[5], hi, false);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(qv[6], qv[7], hi, true);
+    *reinterpret_cast<uint2*>(p.q8_out + (long long)row * p.ld_q8 + col0) = make_uint2(lo, hi);
+    if ((col0 & 31) == 0) p.q8_scales[(long long)row * (N >> 5) + (col0 >> 5)] = (unsigned char)(se + 127);
+  }
   bf16_t* C = reinterpret_cast<bf16_t*>(p.C);
   if (col0 + 8 <= nst) {
     if (!full) {

@@ -207,6 +207,7 @@ int launch_gemm_mx8(const GemmArgs& a, const unsigned char* sa, const unsigned c
   if (epi == EPI_GELU_GRAD) COATI_CHECK_ARG(a.aux_out && a.ld_aux % 8 == 0, "gemm_mx8: aux_out missing");
   if (epi == EPI_MUL_AUX) COATI_CHECK_ARG(a.aux_in && a.ld_aux % 8 == 0, "gemm_mx8: aux_in missing");
   if (epi == EPI_QKV_ROPE) COATI_CHECK_ARG(a.rope_cos && a.rope_sin && a.rope_T > 0 && a.rope_C > 0 && a.N % 16 == 0 && (a.rope_hs == 16 || a.rope_hs == 32), "gemm_mx8: rope operands");
+  if (a.q8_out) COATI_CHECK_ARG(a.q8_scales && a.N % 32 == 0 && a.ld_q8 % 8 == 0 && !out_f32 && epi != EPI_QKV_ROPE, "gemm_mx8: fused MXFP8 output needs N %% 32 == 0 and a bf16 epilogue");
   switch (epi) {
     case EPI_BF16: return launch_mx8_t<EPI_BF16>(a, sa, sb, s);
     case EPI_F32: return launch_mx8_t<EPI_F32>(a, sa, sb, s);

@@ -65,6 +65,11 @@ struct GemmArgs {
   int rope_hs;
   const int* rope_pos;   // decode: when set, EVERY row sits at token position *rope_pos (device memory; graph replay)
   const int* rope_row_t; // packed rows: when set, row m sits at token position rope_row_t[m] (instead of m % rope_T)
+  // fp8 mode (gemm_mx8.hip only): also emit the MXFP8 copy of the bf16 output (e4m3 [M, ld_q8] + one scale per 32 columns,
+  // [M, N / 32]) for the next MXFP8 product; N % 32 == 0, bf16-output epilogues
+  unsigned char* q8_out;
+  unsigned char* q8_scales;
+  long long ld_q8;
   // LayerNorm fused into the A load (row-block kernel, K = 256; gemm_rb256_ln_fusable): the operand is LN(ln_x) and is
   // computed while the A slab is loaded; A / lda then name the bf16 buffer that RECEIVES the normalised rows (the weight
   // gradient reads it later), ln_mean / ln_rstd the per-row statistics for the backward

@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 from coati_amd import ops, _lib
 import numpy as np
 dev = "cuda:0"
-M = 81920
+M = int(sys.argv[1]) if len(sys.argv) > 1 else 81920     # 81920 = the padded batch; ~50000 = a packed one
 lib = _lib.lib()
 def dump(tag, us):
     buf = (ctypes.c_uint64 * (16 * 12 * 8))()     # [wg][wave <= 12][8]
@@ -40,10 +40,11 @@ def dump_ring(tag, us):
     buf = (ctypes.c_uint64 * (16 * 10 * 8))()
     assert lib.coati_rg_trace_read(buf) == 0
     a = np.array(buf, dtype=np.float64).reshape(16, 10, 8)[:, :, :4]
+    a = a[:, a.sum((0, 2)) > 0, :]                  # waves that ran (10, or 8 in the 128-row form)
     tot = a.sum(-1).mean()
     names = ["before loop", "wait (vmcnt + barrier)", "MFMA + DMA issue", "write-out"]
     print(f"{tag}: {us:.1f} us/launch; cycles per wave {tot:.0f} = " + "  ".join(f"{n} {a[:, :, i].mean():.0f} ({100 * a[:, :, i].mean() / tot:.0f}%)" for i, n in enumerate(names)))
-    print("   per wave (wg 0): " + " | ".join(" ".join(f"{a[0, w, i]:.0f}" for i in range(4)) for w in (0, 1, 4, 8, 9)))
+    print("   per wave (wg 0): " + " | ".join(" ".join(f"{a[0, w, i]:.0f}" for i in range(4)) for w in (0, 1, 4, a.shape[1] - 1)))
 G = torch.randn(M, 1024, generator=g).to(dev).bfloat16()
 W2 = (torch.randn(256, 1024, generator=g) * 0.05).to(dev).bfloat16()
 b2 = torch.randn(256, generator=g).to(dev)
@@ -58,19 +59,3 @@ Y = torch.randn(M, 256, generator=g).to(dev).bfloat16()
 Wp = (torch.randn(256, 256, generator=g) * 0.05).to(dev).bfloat16()
 f = lambda: ops.gemm_nt(Y, Wp, b2, ops.EPI_RES_F32, aux_in=X, out=out)
 us = timeit(f); dump_ring("ring: proj + residual (K = 256, f32 out)", us)
-
-
-def dump_m2(tag, us):
-    buf = (ctypes.c_uint64 * (16 * 10 * 8))()
-    assert lib.coati_m2_trace_read(buf) == 0
-    a = np.array(buf, dtype=np.float64).reshape(16, 10, 8)[:, :, :5]
-    P, Q = [0, 1, 2, 3, 6], [4, 5, 7, 8, 9]
-    for role, ws, names in (("P", P, ["prologue", "mfma", "vmwait", "epilogue", "barrier"]), ("Q", Q, ["prologue", "mfma", "vmwait", "write-out", "barrier"])):
-        b = a[:, ws, :]
-        tot = b.sum(-1).mean()
-        print(f"{tag} [{role}]: {us:.1f} us/launch; cycles per wave {tot:.0f} = " + "  ".join(f"{n} {b[:, :, i].mean():.0f} ({100 * b[:, :, i].mean() / tot:.0f}%)" for i, n in enumerate(names)))
-        print("   per wave (wg 0): " + " | ".join(f"w{w}: " + " ".join(f"{a[0, w, i]:.0f}" for i in range(5)) for w in ws))
-gam = (1.0 + 0.1 * torch.randn(256, generator=g)).to(dev); bet = (0.1 * torch.randn(256, generator=g)).to(dev)
-Xf = torch.randn(M, 256, generator=g).to(dev)
-f = lambda: ops.mlp_fwd(Xf, gam, bet, W1, b1, W2, b2, paired=True)
-us = timeit(f); dump_m2("paired-wave MLP forward", us)

@@ -1,25 +1,26 @@
 #!/bin/bash
-# Round artefacts, run on the GPU box from the repo root (gpurun):  bash tools/profile_round.sh r02
+# Round artefacts, run on the GPU box from the repo root (gpurun):  bash tools/profile_round.sh r03
 # Writes everything under gpurun_out/<tag>_*; copy what should be judged into profiles/.
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 python $R/bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
 python $R/bench.py --steps 10 --warmup 3 --all-sites --no-cpu-baseline > $OUT/${TAG}_bench_nocpu.json 2> $OUT/${TAG}_bench_sites.txt
+python $R/bench.py --steps 10 --warmup 3 --all-sites --no-cpu-baseline --padded > $OUT/${TAG}_bench_padded.json 2> $OUT/${TAG}_bench_sites_padded.txt
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof -o bench -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/${TAG}_bench_under_rocprof.json 2> /dev/null
 cp $(find $OUT/${TAG}_prof -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_bench_kernel_stats.csv
 # HBM traffic of the dominant kernel from PMC passes over THE BENCH COMMAND itself (counters only with --kernel-trace; one
 # counter per pass): the grouped weight-gradient launch (wgrad256_table_kernel, or wgrad_dma_table_kernel with COATI_WGRAD_TILE=128: 2 launches per step)
+export PMC_LAYOUT=packed
 export PMC_COMMAND="rocprofv3 --pmc <FETCH_SIZE|WRITE_SIZE> --kernel-trace -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline (round $TAG)"
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_$c -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
 done
 python $R/tools/pmc_to_json.py xf_wgrad _table_kernel $(find $OUT/${TAG}_pmc_FETCH_SIZE $OUT/${TAG}_pmc_WRITE_SIZE -name "*counter_collection.csv") > $OUT/${TAG}_pmc_summary.json
 python $R/tools/gemm_bench.py > $OUT/${TAG}_gemm_microbench.txt 2>&1
-python $R/tools/mlp_bench.py > $OUT/${TAG}_mlp_bench_raw.txt 2>&1       # (profiles/<tag>_mlp_chain_bench.txt is the annotated record of these runs)
 python $R/tools/probes/membw.py > $OUT/${TAG}_membw.txt 2>&1
 bash $R/tools/pmc_sq.sh > /dev/null 2>&1 && cp $OUT/pmcsq_table.txt $OUT/${TAG}_sq_counters.txt
 python $R/tools/cpu_baseline_full.py > $OUT/${TAG}_cpu_baseline_full.json 2> /dev/null
