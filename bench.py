@@ -164,6 +164,7 @@ def main():
     ap.add_argument("--padded", action="store_true",
                     help="run the transformer passes on the padded [B, T] layout as the reference does; default: packed rows "
                          "(the rows' real prefixes only -- same losses and gradients, see DESIGN.md section 2a); the line reports both")
+    ap.add_argument("--no-other-layout", action="store_true", help="skip the untimed steps on the other row layout (profiling runs: every kernel in the trace then belongs to the timed layout)")
     ap.add_argument("--fp8", action="store_true",
                     help="BASELINE.json configs[4]: the transformer's Linear forward / input-gradient products on MXFP8 (e4m3 + E8M0 block "
                          "scales, v_mfma_scale_f32_32x32x64_f8f6f4); weight gradients, attention, lm_head and the GNN stay bf16 / f32")
@@ -276,20 +277,22 @@ def main():
     # computes) when the line is the packed one, and vice versa -- so that the line carries both numbers
     other = batch_packed if args.padded else batch_padded
     k_o = max(3, min(args.steps, 10))
-    for _ in range(2):
-        step(b=other)
-    sync()
-    t_o = time.perf_counter()
-    for _ in range(k_o):
-        step(b=other)
-    sync()
-    dt_other = (time.perf_counter() - t_o) / k_o
-    if dist_on:
-        t = torch.tensor([dt_other], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt_other = float(t)
-    for _ in range(2):
-        step()          # leave the engine in the timed layout (profiling below)
+    dt_other = None
+    if not args.no_other_layout:
+        for _ in range(2):
+            step(b=other)
+        sync()
+        t_o = time.perf_counter()
+        for _ in range(k_o):
+            step(b=other)
+        sync()
+        dt_other = (time.perf_counter() - t_o) / k_o
+        if dist_on:
+            t = torch.tensor([dt_other], device=dev, dtype=torch.float64)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            dt_other = float(t)
+        for _ in range(2):
+            step()          # leave the engine in the timed layout (profiling below)
     comm = None
     if dist_on:
         # exposed cost of the gradient all-reduces: the same steps with those four collectives skipped (outside the timed
@@ -377,8 +380,9 @@ def main():
                                      "(tests/test_gpu_packed.py); --padded times the padded layout",
                        "rows_rank0": {"packed": [int(x) for x in batch_cpu["rows"].tolist()],
                                       "padded": [args.batch * batch_cpu["raw_tokens"].shape[1], args.batch * batch_cpu["tokens"].shape[1]]}},
-            ("packed_rows" if args.padded else "padded_layout"): {"ms_per_step": round(1e3 * dt_other, 3), "value": round(args.batch * world / dt_other, 2),
-                                                                 "steps": k_o, "note": "same workload on the other row layout, timed after the main region"},
+            ("packed_rows" if args.padded else "padded_layout"): (None if dt_other is None else {
+                "ms_per_step": round(1e3 * dt_other, 3), "value": round(args.batch * world / dt_other, 2),
+                "steps": k_o, "note": "same workload on the other row layout, timed after the main region"}),
             "loss": {k: round(v, 4) for k, v in losses.items() if k in ("ar_loss", "clip_loss", "loss")},
             "roofline": roof,
         }

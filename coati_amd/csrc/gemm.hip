@@ -285,14 +285,13 @@ int launch_gemm_nt(const GemmArgs& a, int a_f32, int epi, hipStream_t s) {
     if (gemm_ring256_supported(a, a_f32, epi)) return launch_gemm_ring256(a, epi, s);
     if (!no_rb && gemm_rb256_supported(a, a_f32, epi)) return launch_gemm_rb256(a, epi, s);
   }
-  static const bool w4 = getenv("COATI_GEMM_W4") != nullptr;   // A/B switch: 4-wave instead of 8-wave workgroups
 #define NT_CASE(E)                                                                  \
   case E:                                                                           \
-    return a_f32 ? launch_nt_t<float, StageF32, E, 4>(a, s) : (w4 ? launch_nt_t<bf16_t, StageB16, E, 4>(a, s) : launch_nt_t<bf16_t, StageB16, E, 8>(a, s));
+    return a_f32 ? launch_nt_t<float, StageF32, E, 4>(a, s) : launch_nt_t<bf16_t, StageB16, E, 8>(a, s);
 #define NT_CASE_B16(E)                                                              \
   case E:                                                                           \
     COATI_CHECK_ARG(!a_f32, "gemm_nt: epilogue %d has no f32-A variant", (int)E);   \
-    return w4 ? launch_nt_t<bf16_t, StageB16, E, 4>(a, s) : launch_nt_t<bf16_t, StageB16, E, 8>(a, s);
+    return launch_nt_t<bf16_t, StageB16, E, 8>(a, s);
   switch (epi) {
     NT_CASE(EPI_BF16)
     NT_CASE(EPI_F32)
@@ -1120,8 +1119,7 @@ static int launch_wgrad_dma_t(const WgradArgs& a, hipStream_t s) {
   const int tiles_n = cdiv(a.N, BM), tiles_k = cdiv(a.K, BN);
   const int tiles = tiles_n * tiles_k;
   const int nchunks = cdiv(a.M, WD_CH);
-  static const int slot_env = getenv("COATI_WGRAD_SLOTS") ? atoi(getenv("COATI_WGRAD_SLOTS")) : 0;
-  const int slots = slot_env > 0 ? slot_env : (tiles > 128 ? 512 : 256);   // one workgroup per CU (two rounds when the tiles alone almost fill one)
+  const int slots = tiles > 128 ? 512 : 256;   // one workgroup per CU (two rounds when the tiles alone almost fill one)
   int splits = slots / tiles;
   if (splits > cdiv(nchunks, 4)) splits = cdiv(nchunks, 4);
   if (splits < 1) splits = 1;

@@ -379,8 +379,6 @@ int gemm_ce_tile_width(const GemmArgs& a) {
 
 // true when (a, epi) can run on the row-block kernel
 bool gemm_rb256_supported(const GemmArgs& a, int a_f32, int epi) {
-  // COATI_RB_EXCLUDE (A/B switch for tuning): bit 1 = N < 512, bit 2 = epilogues with extra row-major operands
-  static const int excl = getenv("COATI_RB_EXCLUDE") ? atoi(getenv("COATI_RB_EXCLUDE")) : 0;
   if (a_f32 || a.K != RB_K) return false;
   if (epi == EPI_CE_PARTIAL && a.partial_tile != 64) return false;   // the caller's partial buffer is laid out for 128-column tiles
   if (epi == EPI_QKV_ROPE && a.rope_hs == 32) return false;   // the staged rotary rows are laid out for head size 16
@@ -388,8 +386,6 @@ bool gemm_rb256_supported(const GemmArgs& a, int a_f32, int epi) {
   // small problems run on the tiled kernel.  (Packed rows: a full-size batch carries ~50 000 rows instead of 81 920, i.e.
   // 6-7 slabs per workgroup -- still one round of one workgroup per CU, with LayerNorm fused into the operand load.)
   if (rb_waves(a.M) < 5) return false;
-  if ((excl & 1) && a.N < 512) return false;
-  if ((excl & 2) && (epi == EPI_RES_F32 || epi == EPI_ACC_F32 || epi == EPI_F32 || epi == EPI_DGELU || epi == EPI_DSILU || epi == EPI_MUL_AUX || epi == EPI_EDGE_DPRE)) return false;
   return true;
 }
 

@@ -10,14 +10,14 @@ cd /tmp && export TMPDIR=/tmp
 python $R/bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
 python $R/bench.py --steps 10 --warmup 3 --all-sites --no-cpu-baseline > $OUT/${TAG}_bench_nocpu.json 2> $OUT/${TAG}_bench_sites.txt
 python $R/bench.py --steps 10 --warmup 3 --all-sites --no-cpu-baseline --padded > $OUT/${TAG}_bench_padded.json 2> $OUT/${TAG}_bench_sites_padded.txt
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof -o bench -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/${TAG}_bench_under_rocprof.json 2> /dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof -o bench -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-other-layout > $OUT/${TAG}_bench_under_rocprof.json 2> /dev/null
 cp $(find $OUT/${TAG}_prof -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_bench_kernel_stats.csv
 # HBM traffic of the dominant kernel from PMC passes over THE BENCH COMMAND itself (counters only with --kernel-trace; one
 # counter per pass): the grouped weight-gradient launch (wgrad256_table_kernel, or wgrad_dma_table_kernel with COATI_WGRAD_TILE=128: 2 launches per step)
 export PMC_LAYOUT=packed
-export PMC_COMMAND="rocprofv3 --pmc <FETCH_SIZE|WRITE_SIZE> --kernel-trace -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline (round $TAG)"
+export PMC_COMMAND="rocprofv3 --pmc <FETCH_SIZE|WRITE_SIZE> --kernel-trace -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-other-layout (round $TAG)"
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_$c -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_$c -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-other-layout > /dev/null 2>&1
 done
 python $R/tools/pmc_to_json.py xf_wgrad _table_kernel $(find $OUT/${TAG}_pmc_FETCH_SIZE $OUT/${TAG}_pmc_WRITE_SIZE -name "*counter_collection.csv") > $OUT/${TAG}_pmc_summary.json
 python $R/tools/gemm_bench.py > $OUT/${TAG}_gemm_microbench.txt 2>&1
