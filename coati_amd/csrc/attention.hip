@@ -790,7 +790,7 @@ __global__ __launch_bounds__(256, (HS == 16 && NB <= 3) ? 3 : 2) void attn_bwd_f
 // staged operands + dQ of every block), so one launch for all lengths runs the short sequences at the long ones' occupancy:
 // measured 2.58 ms per step against 2.32 for separate launches (the forward, two operands, is the other way round).
 template <int HS, int NBMAX, int NBMIN>
-__global__ __launch_bounds__(256, (HS == 16 && NBMAX <= 3) ? 3 : 2) void attn_bwd_fused_varlen_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ y,
+__global__ __launch_bounds__(256, (HS == 16 && NBMAX <= 2) ? 4 : ((HS == 16 && NBMAX <= 3) ? 3 : 2)) void attn_bwd_fused_varlen_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ y,
                                                              const bf16_t* __restrict__ dy, const float* __restrict__ lse,
                                                              bf16_t* __restrict__ dqkv, const float* __restrict__ cos_t,
                                                              const float* __restrict__ sin_t, int Tl, int n_head, int quads,
