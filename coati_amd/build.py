@@ -10,7 +10,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libcoati_hip.so")
 OBJDIR = os.path.join(HERE, "build")
-HIP_UNITS = ["gemm.hip", "gemm_rb.hip", "gemm_ring.hip", "gemm_mx8.hip", "norm.hip", "attention.hip", "embed.hip", "gnn.hip", "loss.hip", "optim.hip", "batch.hip", "decode.hip"]
+HIP_UNITS = ["gemm.hip", "gemm_rb.hip", "gemm_rb16.hip", "gemm_ring.hip", "gemm_mx8.hip", "norm.hip", "attention.hip", "embed.hip", "gnn.hip", "loss.hip", "optim.hip", "batch.hip", "decode.hip"]
 CPP_UNITS = ["engine.cpp", "capi.cpp", "tokenizer.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"] + os.environ.get("COATI_AMD_CXXFLAGS", "").split()   # (probe builds: -DCOATI_RB_TRACE)
 

@@ -89,6 +89,9 @@ bool gemm_rb256_ln_fusable(const GemmArgs& a, int epi);
 // column width of the EPI_CE_PARTIAL entries launch_gemm_nt writes for these arguments (64 or 128)
 int gemm_ce_tile_width(const GemmArgs& a);
 int launch_gemm_rb256(const GemmArgs& a, int epi, hipStream_t s);
+// the same on 16-row slabs / 13-16 waves per workgroup (gemm_rb16.hip): packed batch sizes (36 865 .. 65 536 rows)
+bool gemm_rb16_supported(const GemmArgs& a, int a_f32, int epi);
+int launch_gemm_rb16(const GemmArgs& a, int epi, hipStream_t s);
 // ring kernel for N = 256, long K (gemm_ring.hip)
 bool gemm_ring256_supported(const GemmArgs& a, int a_f32, int epi);
 int launch_gemm_ring256(const GemmArgs& a, int epi, hipStream_t s);

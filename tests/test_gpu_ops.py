@@ -25,8 +25,9 @@ def gelu(x):
     return 0.5 * x * (1.0 + torch.tanh(math.sqrt(2.0 / math.pi) * (x + 0.044715 * x ** 3)))
 
 
+# (40000, 256, 256) and (50001, 320, 256) take the 16-row-slab row-block kernel (gemm_rb16.hip: 36 865 .. 65 536 rows, K = 256)
 # the last three rows take the N = 256 ring kernel (bf16 / residual epilogues): full blocks, a ragged last block, K = 512
-@pytest.mark.parametrize("M,N,K", [(300, 192, 256), (128, 768, 64), (1000, 130, 128), (64, 64, 1024), (2000, 192, 256), (1411, 1024, 256), (40000, 256, 256), (33000, 768, 256),
+@pytest.mark.parametrize("M,N,K", [(300, 192, 256), (128, 768, 64), (1000, 130, 128), (64, 64, 1024), (2000, 192, 256), (1411, 1024, 256), (40000, 256, 256), (33000, 768, 256), (50001, 320, 256),
                                    (40960, 256, 1024), (30011, 256, 768), (24000, 256, 512)])
 def test_gemm_epilogues(ops, M, N, K):
     g = torch.Generator(device="cpu").manual_seed(M + N + K)
@@ -230,7 +231,7 @@ def test_embed(ops):
     check("embed bwd inject", di.cpu(), ri, 1e-6)
 
 
-@pytest.mark.parametrize("M,V,K", [(200, 48, 64), (700, 10322, 256)])
+@pytest.mark.parametrize("M,V,K", [(200, 48, 64), (700, 10322, 256), (40003, 1000, 256)])   # the last: 16-row-slab kernel
 def test_lmhead_ce(ops, M, V, K):
     g = torch.Generator().manual_seed(V)
     a = rbf(torch.randn(M, K, generator=g)).to(DEV)
@@ -251,7 +252,8 @@ def test_lmhead_ce(ops, M, V, K):
     assert float(d[:, V:].float().abs().max()) == 0.0 if d.shape[1] > V else True
 
 
-@pytest.mark.parametrize("B,T,nh,hs", [(3, 12, 4, 16), (7, 80, 16, 16), (3, 20, 4, 32), (1024, 80, 16, 32), (5, 33, 8, 32)])
+@pytest.mark.parametrize("B,T,nh,hs", [(3, 12, 4, 16), (7, 80, 16, 16), (3, 20, 4, 32), (1024, 80, 16, 32), (5, 33, 8, 32),
+                                       (601, 80, 16, 16)])   # 48 080 rows: the 16-row-slab kernel
 def test_gemm_qkv_rope(ops, B, T, nh, hs):
     from oracle import coati_oracle as O
     C = nh * hs
