@@ -8,16 +8,18 @@
 // VGPRs, 13-16 waves per workgroup, 4 waves per SIMD.  A packed batch brings ~200 rows per CU = 13 slabs: one workgroup per CU,
 // one round.  Same structure otherwise: A-stationary slab in registers (LayerNorm evaluated inside the slab load for the QKV /
 // FC1 products, basic_transformer.py:165-173), 64-column weight tiles L2 -> LDS by global_load_lds, double-buffered, one
-// workgroup barrier per tile, per-wave LDS transpose -> epilogue8 on 8 consecutive columns (gemm_epi.h).
+// workgroup barrier per tile.  The product is issued TRANSPOSED (weight rows as the MFMA's row operand, the slab as its column
+// operand) with the tile's weight rows permuted among the MFMA blocks so that a lane ends with 8 / 16 CONSECUTIVE columns of one
+// output row: the epilogue (gemm_epi.h) runs straight out of the accumulators -- no LDS transpose, no per-wave LDS at all.
+// What bounds it now: every wave reads the whole 32-KiB tile out of LDS for 16 rows (twice the 32-row kernel's bytes per flop):
+// ~21 of the 40 us of the plain N = 1024 product are LDS-read cycles; the activation epilogues add their VALU time on top.
 #include <cstdlib>
 #include "gemm_epi.h"
 
 #define R16_K 256
 #define R16_BN 64
 #define R16_TILE_HALFS (R16_BN * R16_K)          // 32 KiB per buffer
-#define R16_EPITCH (R16_BN + 4)
-#define R16_EFLOATS (16 * R16_EPITCH)            // per-wave transpose region: 16 rows x 64 columns (+ pad)
-#define R16_ROPE_FLOATS (16 * 16)                // per wave: [16 rows][8 cos | 8 sin]; EPI_MUL_AUX: the 16 x 64 one-byte codes
+#define R16_BIAS_MAX 4096                        // bias vectors up to this many columns are staged in LDS (longer: not this kernel)
 #define R16_MAXW 16
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
@@ -28,16 +30,38 @@ __device__ __forceinline__ void r16_call_restrict(F&& f, int jt, int jn, const b
   f(jt, jn, cur, nxt);
 }
 
+// Output mapping (no LDS transpose).  The MFMA runs as D = Wblk (16 weight rows x 32 k) * slab^T: lane (m = lane & 15, kq = lane >> 4)
+// then holds row m of the slab's output and, for column block a, the four weight rows i = 4 kq + r.  WHICH weight row of the tile
+// sits at (a, i) is free -- it only decides the LDS address of the operand read:
+//   MAP 0:  n = 32 (a >> 1) + 8 kq + 4 (a & 1) + r : the lane owns columns 8 kq .. + 7 and 32 + 8 kq .. + 7; one 16-B store per lane
+//           covers a contiguous 64-B half line per row (4 lanes)
+//   MAP 1:  n = 16 kq + 4 a + r : the lane owns the 16 consecutive columns 16 kq .. + 15 = one head of 16: the rotary partner of every
+//           element is in the same lane (EPI_QKV_ROPE)
+// The tile's 16-B chunk c of weight row n sits at chunk position c ^ f(n) with f's low 4 bits = i: the 16 lanes of an operand read
+// that share k hit 16 different bank groups.
+template <int MAP>
+__device__ __forceinline__ int r16_wrow(int a, int i) {
+  return MAP == 0 ? 32 * (a >> 1) + 8 * (i >> 2) + 4 * (a & 1) + (i & 3) : 16 * (i >> 2) + 4 * a + (i & 3);
+}
+template <int MAP>
+__device__ __forceinline__ int r16_swz(int n) {
+  return MAP == 0 ? ((n & 3) | (((n >> 3) & 3) << 2) | (((n >> 2) & 1) << 4)) : ((n & 3) | (((n >> 4) & 3) << 2) | (((n >> 2) & 1) << 4));
+}
+
 template <int EPI, bool LN>
 __global__ __launch_bounds__(64 * R16_MAXW, 1) void gemm_rb16_kernel(GemmArgs p, int W, int rot) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int MAP = (EPI == EPI_QKV_ROPE || EPI == EPI_GELU_GRAD) ? 1 : 0;
   bf16_t* const Bs = reinterpret_cast<bf16_t*>(smem);
+  float* const BiasS = reinterpret_cast<float*>(smem + 2 * R16_TILE_HALFS * 2);   // bias[N] (+ one tile of slack), read as broadcasts
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  float* const Es = reinterpret_cast<float*>(smem + 2 * R16_TILE_HALFS * 2) + wave * R16_EFLOATS;
-  float* const Rs = reinterpret_cast<float*>(smem + 2 * R16_TILE_HALFS * 2) + W * R16_EFLOATS + wave * R16_ROPE_FLOATS;
   const int m0 = (blockIdx.x * W + wave) * 16;
   const int fr = lane & 15, kq = lane >> 4;       // this lane's row of the slab, its 8-k group inside a 32-k step
-  constexpr int CGS = R16_BN / 8;
+  const int ntiles = (p.N + R16_BN - 1) / R16_BN;
+  const bool has_bias = p.bias != nullptr;
+  if (has_bias) {
+    for (int c = tid; c < ntiles * R16_BN; c += blockDim.x) BiasS[c] = c < p.N ? p.bias[c] : 0.f;
+  }
 
   // ---- resident A slab: fragment ks holds k = 32 ks + 8 kq .. + 7 of row fr
   bf16x8 af[8];
@@ -95,19 +119,19 @@ __global__ __launch_bounds__(64 * R16_MAXW, 1) void gemm_rb16_kernel(GemmArgs p,
     }
     __syncthreads();   // everyone has read gamma / beta: the buffer may receive its weight tile
   }
+  // rotary table row of this lane's slab row: [8 cos | 8 sin], the same for every head = every tile: registers for the whole kernel
+  float rc_[8], rs_[8];
   if constexpr (EPI == EPI_QKV_ROPE) {
-    // rotary rows of this wave's 16 rows: lane -> (row = lane >> 2, quarter): 4 floats of [8 cos | 8 sin]
-    const int r = lane >> 2, qd = lane & 3;
-    const int mr = m0 + r < p.M ? m0 + r : p.M - 1;
-    const int t = p.rope_row_t != nullptr ? p.rope_row_t[mr] : (m0 + r) % p.rope_T;
-    const float* src = (qd < 2 ? p.rope_cos : p.rope_sin) + t * 16 + (qd & 1) * 4;
-    *reinterpret_cast<float4*>(Rs + r * 16 + qd * 4) = *reinterpret_cast<const float4*>(src);
+    const int t = p.rope_row_t != nullptr ? p.rope_row_t[rc] : rc % p.rope_T;
+    const float4 c0 = *reinterpret_cast<const float4*>(p.rope_cos + t * 16), c1 = *reinterpret_cast<const float4*>(p.rope_cos + t * 16 + 4);
+    const float4 s0 = *reinterpret_cast<const float4*>(p.rope_sin + t * 16), s1 = *reinterpret_cast<const float4*>(p.rope_sin + t * 16 + 4);
+    rc_[0] = c0.x; rc_[1] = c0.y; rc_[2] = c0.z; rc_[3] = c0.w; rc_[4] = c1.x; rc_[5] = c1.y; rc_[6] = c1.z; rc_[7] = c1.w;
+    rs_[0] = s0.x; rs_[1] = s0.y; rs_[2] = s0.z; rs_[3] = s0.w; rs_[4] = s1.x; rs_[5] = s1.y; rs_[6] = s1.z; rs_[7] = s1.w;
   }
 
-  const int ntiles = (p.N + R16_BN - 1) / R16_BN;
   typedef __attribute__((address_space(3))) void lds_void;
   typedef __attribute__((address_space(1))) const void gbl_void;
-  // weight tile: 32 pieces of 1 KiB (two 512-B rows), piece k by wave k % W; chunk c of row r at position c ^ (r & 31)
+  // weight tile: 32 pieces of 1 KiB (two 512-B rows), piece k by wave k % W; chunk c of row r at position c ^ f(r)
   auto load_tile = [&](int n0, bf16_t* S) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {      // W >= 8: 4 turns cover the 32 pieces
@@ -115,89 +139,129 @@ __global__ __launch_bounds__(64 * R16_MAXW, 1) void gemm_rb16_kernel(GemmArgs p,
       if (k < R16_BN / 2) {
         const int r = 2 * k + (lane >> 5), q = lane & 31;
         const int g = n0 + r, gc = g < p.N ? g : p.N - 1;
-        const bf16_t* src = p.B + (long long)gc * p.ldb + ((q ^ (r & 31)) * 8);
+        const bf16_t* src = p.B + (long long)gc * p.ldb + ((q ^ r16_swz<MAP>(r)) * 8);
         __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(S + k * 512), 16, 0, 0);
       }
     }
   };
-  // EPI_MUL_AUX: the 16 x 64 one-byte codes of this wave's output block = ONE 1-KiB DMA (lane -> row lane / 4, 16 columns),
-  // issued before the MFMA phase of the tile, behind the same vmcnt(0) as the next weight tile; the epilogue task (row, 8-column
-  // group) reads its 8 B back at row * 64 + 8 cg
-  unsigned char* const Xs = reinterpret_cast<unsigned char*>(Rs);
-  auto load_aux = [&](int n0) {
-    const int row = m0 + (lane >> 2), col = n0 + (lane & 3) * 16;
-    const int rc2 = row < p.M ? row : p.M - 1, cc = col + 16 <= p.N ? col : 0;
-    const unsigned char* src = reinterpret_cast<const unsigned char*>(p.aux_in) + (long long)rc2 * p.ld_aux + cc;
-    __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)Xs, 16, 0, 0);
-  };
-  auto bias_at = [&](int col) { return p.bias[col < p.N ? col : p.N - 1]; };
-  const bool has_bias = p.bias != nullptr;
   GemmArgs q = p;
   q.bias = nullptr;   // folded into the accumulator initialisation
 
   const int j0 = rot ? (int)(blockIdx.x % (unsigned)ntiles) : 0;
   load_tile(j0 * R16_BN, Bs);
-  float bz[4], bn[4];
-#pragma unroll
-  for (int a = 0; a < 4; ++a) { bz[a] = has_bias ? bias_at(j0 * R16_BN + 16 * a + fr) : 0.f; bn[a] = 0.f; }
   __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0)
-  __syncthreads();
+  __syncthreads();                      // (also: the bias vector is in LDS)
+
+  // this lane's operand rows and its output columns inside a tile
+  int wofs[4], wsw[4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    const int n = r16_wrow<MAP>(a, fr);
+    wofs[a] = n * R16_K;
+    wsw[a] = r16_swz<MAP>(n);
+  }
+  const int colA = MAP == 0 ? 8 * kq : 16 * kq, colB = MAP == 0 ? 32 + 8 * kq : 16 * kq + 8;   // acc[0..1] -> colA .. + 7, acc[2..3] -> colB .. + 7
+  const bool rowok = row_l < p.M;
 
   auto tile = [&](int jt, int jn, const bf16_t* cur, bf16_t* nxt) {
     load_tile(jn * R16_BN, nxt);
-    if constexpr (EPI == EPI_MUL_AUX) load_aux(jt * R16_BN);
-    if (has_bias) {
-#pragma unroll
-      for (int a = 0; a < 4; ++a) bn[a] = bias_at(jn * R16_BN + 16 * a + fr);
+    uint4 xq = make_uint4(0, 0, 0, 0);
+    if constexpr (EPI == EPI_MUL_AUX) {
+      // the 16 saved NewGELU' codes of this lane's columns (MAP 0: two 8-B pieces), in flight during the MFMA phase
+      const unsigned char* X = reinterpret_cast<const unsigned char*>(p.aux_in) + (long long)rc * p.ld_aux + jt * R16_BN;
+      const int nb = p.N - jt * R16_BN;   // (N % 16 == 0: an 8-column piece is inside or outside as a whole; outside ones are not stored)
+      const uint2 x0 = *reinterpret_cast<const uint2*>(X + (colA + 8 <= nb ? colA : 0)), x1 = *reinterpret_cast<const uint2*>(X + (colB + 8 <= nb ? colB : 0));
+      xq = make_uint4(x0.x, x0.y, x1.x, x1.y);
     }
     f32x4_t acc[4];
+    if (has_bias) {
+      acc[0] = *reinterpret_cast<const f32x4_t*>(BiasS + jt * R16_BN + colA);
+      acc[1] = *reinterpret_cast<const f32x4_t*>(BiasS + jt * R16_BN + colA + 4);
+      acc[2] = *reinterpret_cast<const f32x4_t*>(BiasS + jt * R16_BN + colB);
+      acc[3] = *reinterpret_cast<const f32x4_t*>(BiasS + jt * R16_BN + colB + 4);
+    } else {
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) acc[a][r] = bz[a];
+      for (int a = 0; a < 4; ++a) acc[a] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    }
     {
-      // B fragment of column block a (16 weight rows), k step ks: lane (n = fr, kq) reads chunk 4 ks + kq of row 16 a + fr
-      const bf16_t* wp = cur + fr * R16_K;
-      const int sw = fr;   // (16 a is a multiple of 16: row & 31 = fr + 16 (a & 1))
       bf16x8 wf[2][4];
 #pragma unroll
-      for (int a = 0; a < 4; ++a) wf[0][a] = *reinterpret_cast<const bf16x8*>(wp + a * 16 * R16_K + (((kq) ^ (sw + 16 * (a & 1))) * 8));
+      for (int a = 0; a < 4; ++a) wf[0][a] = *reinterpret_cast<const bf16x8*>(cur + wofs[a] + ((kq ^ wsw[a]) * 8));
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) {
         if (ks + 1 < 8) {
 #pragma unroll
-          for (int a = 0; a < 4; ++a)
-            wf[(ks + 1) & 1][a] = *reinterpret_cast<const bf16x8*>(wp + a * 16 * R16_K + (((4 * (ks + 1) + kq) ^ (sw + 16 * (a & 1))) * 8));
+          for (int a = 0; a < 4; ++a) wf[(ks + 1) & 1][a] = *reinterpret_cast<const bf16x8*>(cur + wofs[a] + (((4 * (ks + 1) + kq) ^ wsw[a]) * 8));
         }
 #pragma unroll
-        for (int a = 0; a < 4; ++a) acc[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks], wf[ks & 1][a], acc[a], 0, 0, 0);
+        for (int a = 0; a < 4; ++a) acc[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks & 1][a], af[ks], acc[a], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
     __builtin_amdgcn_s_waitcnt(0x0f70);   // the next tile has landed (this wave's pieces): wait BEFORE this tile's stores are issued
-    // wave-private transpose: accumulator (lane = column fr of block a, register r = row 4 kq + r) -> rows of 64 contiguous columns
+    float v0[8] = {acc[0][0], acc[0][1], acc[0][2], acc[0][3], acc[1][0], acc[1][1], acc[1][2], acc[1][3]};
+    float v1[8] = {acc[2][0], acc[2][1], acc[2][2], acc[2][3], acc[3][0], acc[3][1], acc[3][2], acc[3][3]};
+    const int c0 = jt * R16_BN + colA, c1 = jt * R16_BN + colB;
+    if constexpr (EPI == EPI_CE_PARTIAL) {
+      // (max, sum exp) over the tile's 64 columns of row fr: 16 in this lane, the rest in lanes fr + 16, + 32, + 48
+      float mx = -INFINITY;
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+      for (int e = 0; e < 8; ++e) {
+        if (c0 + e < p.N) mx = fmaxf(mx, v0[e]);
+        if (c1 + e < p.N) mx = fmaxf(mx, v1[e]);
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      float sm = 0.f;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) Es[(4 * kq + r) * R16_EPITCH + 16 * a + fr] = acc[a][r];
-    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0)
-    __builtin_amdgcn_wave_barrier();
+      for (int e = 0; e < 8; ++e) {
+        if (c0 + e < p.N) sm += __expf(v0[e] - mx);
+        if (c1 + e < p.N) sm += __expf(v1[e] - mx);
+      }
+      sm += __shfl_xor(sm, 16, 64);
+      sm += __shfl_xor(sm, 32, 64);
+      if (rowok && kq == 0) p.partial[(long long)row_l * ntiles + jt] = make_float2(mx, sm);
+    } else if constexpr (EPI == EPI_QKV_ROPE) {
+      // RotaryEmbedding.rotary_embed (basic_transformer.py:83-100) on one head of 16: v0 = dims 0..7, v1 = dims 8..15 of the same
+      // head: y_i = x_i c_i - x_{i+8} s_i ; y_{i+8} = x_{i+8} c_i + x_i s_i.  The v block (columns >= 2C) is stored as it is
+      // (wave-uniform: a 64-column tile never straddles 2C)
+      if (jt * R16_BN < 2 * p.rope_C) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int t = lane + 64 * i, rl = t / CGS, cg = t % CGS;
-      float v[8];
-      const float4 c0 = *reinterpret_cast<const float4*>(Es + rl * R16_EPITCH + cg * 8);
-      const float4 c1 = *reinterpret_cast<const float4*>(Es + rl * R16_EPITCH + cg * 8 + 4);
-      v[0] = c0.x; v[1] = c0.y; v[2] = c0.z; v[3] = c0.w; v[4] = c1.x; v[5] = c1.y; v[6] = c1.z; v[7] = c1.w;
-      const void* staged = nullptr;
-      if constexpr (EPI == EPI_QKV_ROPE) staged = Rs + rl * 16;
-      if constexpr (EPI == EPI_MUL_AUX) staged = Xs + rl * 64 + cg * 8;
-      epilogue8<EPI, 1, R16_BN / 8, 16>(q, m0 + rl, jt * R16_BN + cg * 8, v, (m0 + rl) < p.M, jt, ntiles, staged);
+        for (int e = 0; e < 8; ++e) {
+          const float lo = v0[e], hi = v1[e];
+          v0[e] = fmaf(-hi, rs_[e], lo * rc_[e]);
+          v1[e] = fmaf(lo, rs_[e], hi * rc_[e]);
+        }
+      }
+      epilogue8<EPI_BF16>(q, row_l, c0, v0, rowok, jt, ntiles);
+      epilogue8<EPI_BF16>(q, row_l, c1, v1, rowok, jt, ntiles);
+    } else if constexpr (EPI == EPI_GELU_GRAD) {
+      // 16 consecutive columns: NewGELU -> two 16-B stores (32 B of the row), NewGELU' (8-bit fixed point, common.h) -> ONE 16-B store
+      float d0[8], d1[8];
+#pragma unroll
+      for (int e = 0; e < 8; e += 2) {
+        coati_v2f hh, dd;
+        gelu_and_grad_f2(coati_v2f{v0[e], v0[e + 1]}, hh, dd);
+        v0[e] = hh.x; v0[e + 1] = hh.y; d0[e] = dd.x; d0[e + 1] = dd.y;
+        gelu_and_grad_f2(coati_v2f{v1[e], v1[e + 1]}, hh, dd);
+        v1[e] = hh.x; v1[e + 1] = hh.y; d1[e] = dd.x; d1[e + 1] = dd.y;
+      }
+      if (rowok && c0 + 16 <= p.N) {   // (N % 16 == 0)
+        const uint2 q0 = packq8(d0), q1 = packq8(d1);
+        *reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(p.aux_out) + (unsigned)row_l * (unsigned)p.ld_aux + (unsigned)c0) = make_uint4(q0.x, q0.y, q1.x, q1.y);
+        bf16_t* C = reinterpret_cast<bf16_t*>(p.C) + (unsigned)row_l * (unsigned)p.ldc + (unsigned)c0;
+        *reinterpret_cast<uint4*>(C) = pack8(v0);
+        *reinterpret_cast<uint4*>(C + 8) = pack8(v1);
+      }
+    } else if constexpr (EPI == EPI_MUL_AUX) {
+      const uint2 x0 = make_uint2(xq.x, xq.y), x1 = make_uint2(xq.z, xq.w);
+      epilogue8<EPI>(q, row_l, c0, v0, rowok, jt, ntiles, &x0);
+      epilogue8<EPI>(q, row_l, c1, v1, rowok, jt, ntiles, &x1);
+    } else {
+      epilogue8<EPI>(q, row_l, c0, v0, rowok, jt, ntiles);
+      epilogue8<EPI>(q, row_l, c1, v1, rowok, jt, ntiles);
     }
-    __builtin_amdgcn_wave_barrier();      // the next writes to Es stay behind these reads
     __syncthreads();
-#pragma unroll
-    for (int a = 0; a < 4; ++a) bz[a] = bn[a];
   };
   for (int j = 0, jt = j0; j < ntiles; ++j) {
     const int jn = jt + 1 == ntiles ? 0 : jt + 1;
@@ -219,6 +283,10 @@ bool gemm_rb16_supported(const GemmArgs& a, int a_f32, int epi) {
   if (epi == EPI_CE_PARTIAL && a.partial_tile != 64) return false;
   if (epi == EPI_QKV_ROPE && a.rope_hs == 32) return false;
   if (a.N % 16 != 0 && epi != EPI_CE_BWD && epi != EPI_CE_PARTIAL) return false;
+  if (a.bias != nullptr && cdiv(a.N, R16_BN) * R16_BN > R16_BIAS_MAX) return false;
+  if (a.q8_out != nullptr) return false;                              // (the fused MXFP8 emission assumes epilogue8's lane layout)
+  if (epi == EPI_GELU_GRAD && a.n_store > a.N) return false;
+  if (epi == EPI_QKV_ROPE && (a.rope_C % 32 != 0 || a.rope_pos != nullptr)) return false;   // 64-column tiles must not straddle 2C
   const int W = rb16_waves(a.M);
   return W >= 9 && W <= R16_MAXW;   // 36 865 .. 65 536 rows: below, the 32-row kernel or the tiled one; above, the 32-row kernel
 }
@@ -228,9 +296,8 @@ static int launch_rb16_t(const GemmArgs& a, hipStream_t s) {
   static bool attr_set = false;
   auto kern = gemm_rb16_kernel<EPI, LN>;
   constexpr size_t tile_bytes = (size_t)2 * R16_TILE_HALFS * 2;
-  constexpr size_t per_wave = (size_t)R16_EFLOATS * 4 + (EPI == EPI_QKV_ROPE || EPI == EPI_MUL_AUX ? R16_ROPE_FLOATS * 4 : 0);
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(tile_bytes + R16_MAXW * per_wave)) != hipSuccess) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(tile_bytes + R16_BIAS_MAX * 4)) != hipSuccess) {
       coati_set_error("gemm_rb16: hipFuncSetAttribute failed");
       return COATI_EHIP;
     }
@@ -239,7 +306,8 @@ static int launch_rb16_t(const GemmArgs& a, hipStream_t s) {
   const int W = rb16_waves(a.M);
   const int blocks = cdiv(cdiv(a.M, 16), W);
   const int rot = (EPI == EPI_MUL_AUX);
-  hipLaunchKernelGGL(kern, dim3(blocks), dim3(64 * W), tile_bytes + W * per_wave, s, a, W, rot);
+  const size_t bias_bytes = a.bias != nullptr ? (size_t)cdiv(a.N, R16_BN) * R16_BN * 4 : 0;
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(64 * W), tile_bytes + bias_bytes, s, a, W, rot);
   COATI_LAUNCH_CHECK("gemm_rb16");
   return COATI_OK;
 }
