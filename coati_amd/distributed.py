@@ -18,6 +18,7 @@ Backends: "nccl" is the product path.  Under "gloo" (the CPU tests, and the two-
 step in tests/test_gpu_distributed.py) device tensors are staged through the host, because gloo has no
 all_gather_into_tensor / reduce_scatter_tensor / AVG for device memory."""
 import os
+import sys
 import torch
 import torch.distributed as dist
 
@@ -126,7 +127,7 @@ def _schedule_end(slot, seconds):
         _AUTO["decided"] = True
         if dist.get_rank() == 0:
             print(f"[coati_amd.distributed] encoder stage of the data-parallel backward: one piece {1e3 * float(t[0]) / 3:.3f} ms/step, "
-                  f"two halves {1e3 * float(t[1]) / 3:.3f} ms/step -> {'two halves' if _SPLIT_ENCODER_STAGE else 'one piece'}", flush=True)
+                  f"two halves {1e3 * float(t[1]) / 3:.3f} ms/step -> {'two halves' if _SPLIT_ENCODER_STAGE else 'one piece'}", file=sys.stderr, flush=True)
 
 
 
