@@ -326,10 +326,205 @@ static int launch_ring_t(const GemmArgs& a, hipStream_t s) {
   return COATI_OK;
 }
 
+
+// ---- one round: every workgroup owns ONE span of R <= 224 rows (round 3) -------------------------------------------------
+// A packed batch brings ~50 000 rows: 391 blocks of 128 rows are 1.53 rounds over the 256 persistent workgroups -- every launch
+// takes the time of two rounds (tools/ring_rounds.py: K = 1024, bf16 out: 22.9 us for 32 768 rows, 37-40 us for anything between
+// 36 000 and 65 536).  Here the M rows are cut into 256 equal spans of R = ceil(M / 256) rows (rounded up to 8 = one DMA piece),
+// one per CU, 14 waves = 7 row groups x 2 column halves.  A 224-row stage of 64 k is 28 KiB of A + 32 KiB of weight: three of
+// them do not fit the LDS, so the two operands get rings of their own depth -- 3 slots for A (HBM latency: issued two stages
+// ahead), 2 slots for the weight (L2 latency: one stage ahead): 84 + 64 = 148 KiB.  Issue order inside a stage: W(s + 1) first,
+// then A(s + 2), so that the in-order vmcnt wait in front of the next barrier can leave exactly the A(s + 2) pieces in flight.
+// Pieces whose rows lie behind the span are not loaded at all (their products are never stored).
+#define R1_GROUPS 7
+#define R1_BR (32 * R1_GROUPS)
+#define R1_WAVES (2 * R1_GROUPS)
+#define R1_A_BYTES (R1_BR * RG_BK * 2)                                  // 28 KiB
+#define R1_LDS_BYTES (3 * R1_A_BYTES + 2 * RG_W_BYTES)                  // 151,552 B
+
+__device__ __forceinline__ void r1_wait_vm(int n) {   // s_waitcnt vmcnt(n), n = 0 .. 2 (the count is an immediate)
+  if (n >= 2) __builtin_amdgcn_s_waitcnt(0x0f72);
+  else if (n == 1) __builtin_amdgcn_s_waitcnt(0x0f71);
+  else __builtin_amdgcn_s_waitcnt(0x0f70);
+}
+
+template <int EPI>
+__global__ __launch_bounds__(64 * R1_WAVES, 1) void gemm_ring1_kernel(GemmArgs p, int R) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  typedef __attribute__((address_space(3))) unsigned char lds_u8;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int nk = p.K / RG_BK;
+  const int row0 = blockIdx.x * R;
+  if (row0 >= p.M) return;
+  const int row_end = row0 + R < p.M ? row0 + R : p.M, nvalid = row_end - row0;
+  const bf16_t* A = reinterpret_cast<const bf16_t*>(p.A);
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_u8*)smem);
+  const unsigned ldsW = lds0 + 3 * R1_A_BYTES;
+
+  // ---- DMA side (pieces of 8 rows x 128 B, chunk permutation as in gemm_ring256_kernel): A pieces {wave, wave + 14}, weight
+  // pieces {wave, wave + 14 (, wave + 28 for waves 0 .. 3)}
+  const int lrow = lane >> 3;
+  const int cg = (lane & 7) ^ ((((wave & 1) << 2) + (lane >> 4)) & 7);
+  const unsigned offa = (unsigned)((lrow * (int)p.lda + cg * 8) * 2);
+  const unsigned offw = (unsigned)((lrow * (int)p.ldb + cg * 8) * 2);
+  const int nwp = wave < 4 ? 3 : 2;
+  // an A piece is loaded whole (all 8 rows inside the span), clamped (the span ends inside it: the last workgroup only, R is a
+  // multiple of 8) or not at all
+  const int q0 = wave, q1 = wave + R1_WAVES;
+  const int a0 = 8 * q0 + 8 <= nvalid ? 2 : (8 * q0 < nvalid ? 1 : 0), a1 = 8 * q1 + 8 <= nvalid ? 2 : (8 * q1 < nvalid ? 1 : 0);
+  const int nA = (a0 != 0) + (a1 != 0);
+  const bool ROT = (EPI != EPI_RES_F32) && nk >= 8;   // (see gemm_ring256_kernel: the forward product keeps its k order)
+  const int kk0 = ROT ? (int)(blockIdx.x % (unsigned)nk) : 0;
+  const bf16_t* const pa = A + (long long)row0 * p.lda;
+  auto issue_a_piece = [&](int q, int mode, int kk, unsigned slot) __attribute__((always_inline)) {
+    if (mode == 2) {
+      rg_dma16s(pa + (long long)8 * q * p.lda + kk * RG_BK, offa, slot + q * 1024);
+    } else if (mode == 1) {
+      int r = row0 + 8 * q + lrow;
+      r = r < row_end ? r : row_end - 1;
+      rg_dma16(A + (long long)r * p.lda + kk * RG_BK + cg * 8, slot + q * 1024);
+    }
+  };
+  auto issue_w = [&](int kk, unsigned slot) __attribute__((always_inline)) {
+    const bf16_t* wb = p.B + (long long)8 * wave * p.ldb + kk * RG_BK;
+    const long long w_p = 8LL * R1_WAVES * p.ldb;
+    rg_dma16s(wb, offw, slot + wave * 1024);
+    rg_dma16s(wb + w_p, offw, slot + (wave + R1_WAVES) * 1024);
+    if (nwp == 3) rg_dma16s(wb + 2 * w_p, offw, slot + (wave + 2 * R1_WAVES) * 1024);
+  };
+  auto kwrap = [&](int k) { return k >= nk ? k - nk : k; };
+
+  // ---- MFMA side: lane (r = lane & 31, kg = lane >> 5) reads chunk (2 ks + kg) ^ ((r >> 1) & 7) of its rows
+  const int fr = lane & 31, kg = lane >> 5, swz = (fr >> 1) & 7;
+  unsigned xo[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) xo[ks] = (unsigned)(fr * 128 + (((2 * ks + kg) ^ swz) << 4));
+  const unsigned a_row = (unsigned)(wm * 32 * 128), w_row = (unsigned)(wn * 128 * 128);
+
+  f32x16 acc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float b = p.bias != nullptr ? p.bias[wn * 128 + j * 32 + fr] : 0.f;   // lane = output column
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = b;
+  }
+
+  // prologue: A(0), W(0), A(1)
+  issue_a_piece(q0, a0, kk0, lds0);
+  issue_a_piece(q1, a1, kk0, lds0);
+  issue_w(kk0, ldsW);
+  if (nk > 1) {
+    issue_a_piece(q0, a0, kwrap(kk0 + 1), lds0 + R1_A_BYTES);
+    issue_a_piece(q1, a1, kwrap(kk0 + 1), lds0 + R1_A_BYTES);
+  }
+  int sa = 0, sw = 0;                      // ring slots of the stage being multiplied
+  int kk1 = kwrap(kk0 + 1), kk2 = kwrap(kk1 + 1);   // k chunks of stages s + 1, s + 2
+  for (int s = 0; s < nk; ++s) {
+    // stage s has landed (this wave's pieces; the barrier covers the others) and every wave is done with stage s - 1, whose
+    // slots the DMAs of this stage overwrite; in flight behind the wait: the A pieces of stage s + 1
+    r1_wait_vm(s + 1 < nk ? nA : 0);
+    __builtin_amdgcn_s_barrier();
+    const unsigned char* SA = smem + sa * R1_A_BYTES;
+    const unsigned char* SW = smem + 3 * R1_A_BYTES + sw * RG_W_BYTES;
+    const int sa2 = sa == 0 ? 2 : sa - 1;                        // (sa + 2) % 3
+    {
+      bf16x8 fa[2], fw[2][4];
+      fa[0] = *reinterpret_cast<const bf16x8*>(SA + a_row + xo[0]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fw[0][j] = *reinterpret_cast<const bf16x8*>(SW + w_row + j * 4096 + xo[0]);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const int cur = ks & 1, nxt = cur ^ 1;
+        if (ks < 3) {
+          if (ks == 0) { if (s + 1 < nk) issue_w(kk1, ldsW + (sw ^ 1) * RG_W_BYTES); }
+          else if (s + 2 < nk) issue_a_piece(ks == 1 ? q0 : q1, ks == 1 ? a0 : a1, kk2, lds0 + sa2 * R1_A_BYTES);
+          fa[nxt] = *reinterpret_cast<const bf16x8*>(SA + a_row + xo[ks + 1]);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) fw[nxt][j] = *reinterpret_cast<const bf16x8*>(SW + w_row + j * 4096 + xo[ks + 1]);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur], fw[cur][j], acc[j], 0, 0, 0);
+        if (ks < 3) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#pragma unroll
+          for (int j = 1; j < 4; ++j) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          }
+        }
+      }
+    }
+    sa = sa == 2 ? 0 : sa + 1;
+    sw ^= 1;
+    kk1 = kk2;
+    kk2 = kwrap(kk2 + 1);
+  }
+
+  // ---- write-out straight from the accumulator layout (one register: 32 consecutive columns of one row per half-wave)
+  const int wrow0 = row0 + wm * 32;
+  const bool full = (wm + 1) * 32 <= nvalid;   // wave-uniform
+  if (EPI == EPI_RES_F32) {
+    const float* res = reinterpret_cast<const float*>(p.aux_in) + wn * 128 + fr;
+    float* out = reinterpret_cast<float*>(p.C) + wn * 128 + fr;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {   // 8 rows at a time: 32 residual values in flight per lane (128-VGPR budget: 4 waves per SIMD)
+      float x[8][4];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const int row = wrow0 + rg_frag_row(8 * h + r, lane), rc = (full || row < row_end) ? row : row_end - 1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) x[r][j] = res[(long long)rc * p.ld_aux + j * 32];
+      }
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const int row = wrow0 + rg_frag_row(8 * h + r, lane);
+        if (full || row < row_end) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) out[(long long)row * p.ldc + j * 32] = acc[j][8 * h + r] + x[r][j];
+        }
+      }
+    }
+  } else {
+    bf16_t* out = reinterpret_cast<bf16_t*>(p.C) + wn * 128 + fr;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = wrow0 + rg_frag_row(r, lane);
+      if (full || row < row_end) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) out[(long long)row * p.ldc + j * 32] = f2bf(acc[j][r]);
+      }
+    }
+  }
+}
+
+template <int EPI>
+static int launch_ring1_t(const GemmArgs& a, int R, hipStream_t s) {
+  static bool attr_set = false;
+  auto kern = gemm_ring1_kernel<EPI>;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, R1_LDS_BYTES);
+    if (e != hipSuccess) {
+      coati_set_error("gemm_ring1: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+      return COATI_EHIP;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(cdiv(a.M, R)), dim3(64 * R1_WAVES), R1_LDS_BYTES, s, a, R);
+  COATI_LAUNCH_CHECK("gemm_ring1");
+  return COATI_OK;
+}
+
 int launch_gemm_ring256(const GemmArgs& a, int epi, hipStream_t s) {
   // block height: rows the busiest of the 256 persistent workgroups walks = rounds x block rows; ties go to the 160-row form
   // (less weight re-streaming per row).  COATI_RING_ROWS = 128 | 160 forces one (A/B switch).
   static const int force = getenv("COATI_RING_ROWS") ? atoi(getenv("COATI_RING_ROWS")) : 0;
+  // more than one round of 160-row blocks, at most 224 rows per CU: the one-round kernel (COATI_RING_ROWS = 224 forces it for
+  // smaller M too; any other value switches it off)
+  const int R = cdiv(cdiv(a.M, 256), 8) * 8;
+  if (R <= R1_BR && (force ? force == 224 : a.M > 256 * 160))
+    return epi == EPI_RES_F32 ? launch_ring1_t<EPI_RES_F32>(a, R, s) : launch_ring1_t<EPI_BF16>(a, R, s);
   const long long busiest160 = (long long)cdiv(cdiv(a.M, 160), 256) * 160, busiest128 = (long long)cdiv(cdiv(a.M, 128), 256) * 128;
   const bool small = force ? force == 128 : busiest128 < busiest160;
   if (small) return epi == EPI_RES_F32 ? launch_ring_t<EPI_RES_F32, 4>(a, s) : launch_ring_t<EPI_BF16, 4>(a, s);

@@ -28,7 +28,8 @@ def gelu(x):
 # (40000, 256, 256) and (50001, 320, 256) take the 16-row-slab row-block kernel (gemm_rb16.hip: 36 865 .. 65 536 rows, K = 256)
 # the last three rows take the N = 256 ring kernel (bf16 / residual epilogues): full blocks, a ragged last block, K = 512
 @pytest.mark.parametrize("M,N,K", [(300, 192, 256), (128, 768, 64), (1000, 130, 128), (64, 64, 1024), (2000, 192, 256), (1411, 1024, 256), (40000, 256, 256), (33000, 768, 256), (50001, 320, 256),
-                                   (40960, 256, 1024), (30011, 256, 768), (24000, 256, 512)])
+                                   (40960, 256, 1024), (30011, 256, 768), (24000, 256, 512),
+                                   (50003, 256, 1024), (45000, 256, 256), (57344, 256, 512)])   # one-round ring kernel (spans of <= 224 rows, ragged last span)
 def test_gemm_epilogues(ops, M, N, K):
     g = torch.Generator(device="cpu").manual_seed(M + N + K)
     A = rbf(torch.randn(M, K, generator=g)).to(DEV)
@@ -246,7 +247,8 @@ def test_lmhead_ce(ops, M, V, K):
     check(f"ce lse V{V}", lse.cpu(), torch.logsumexp(logits, -1), 7e-7)
     s = scal.cpu()
     assert int(s[1]) == int((tgt >= 0).sum())
-    check(f"ce loss V{V}", (s[0] / s[1]).reshape(1), loss.detach().reshape(1), 6e-7)
+    # mean over the targets, fp32 atomics in arrival order: 32 000 terms measured <= 8.2e-7 over runs (700 terms: <= 3e-7)
+    check(f"ce loss V{V}", (s[0] / s[1]).reshape(1), loss.detach().reshape(1), 6e-7 if M < 10000 else 1.7e-6)
     d = ops.ce_bwd(a.bfloat16(), W.bfloat16(), tgt.to(DEV), lse, scal)
     check(f"ce dlogits V{V}", d[:, :V].float().cpu(), lr.grad, 5e-3)
     assert float(d[:, V:].float().abs().max()) == 0.0 if d.shape[1] > V else True
