@@ -309,21 +309,25 @@ def main():
         comm["step_without_grad_allreduce_ms"] = round(1e3 * float(t_nr), 3)
         comm["exposed_grad_allreduce_ms"] = round(1e3 * (dt / args.steps - float(t_nr)), 3)
 
-    if args.all_sites and rank == 0:
-        rows = []
+    # one step per launch site with HIP events around that site's launches (outside the timed region): the per-site table
+    # (stderr with --all-sites) and the `site_roofline` list of the JSON line -- every site of >= 2 % of the step with its
+    # algorithmic bytes per second against the HBM peak, so that the line shows the whole family, not only the nominated kernel
+    site_rows = []
+    if rank == 0 and not dist_on:
         for s in eng.site_names():
             eng.prof_select(s)
             step()
             torch.cuda.synchronize()
             ms, n, fl = eng.prof_collect()
-            rows.append((ms, s, n, fl, eng.prof_last_bytes()))
+            site_rows.append((ms, s, n, fl, eng.prof_last_bytes()))
         eng.prof_select(-1)
-        tot = sum(r[0] for r in rows)
-        for ms, s, n, fl, by in sorted(rows, reverse=True):
-            tf = (fl * n / (ms * 1e-3) / 1e12) if ms > 0 and fl > 0 else 0.0
-            tb = (by * n / (ms * 1e-3) / 1e12) if ms > 0 and by > 0 else 0.0
-            print(f"  site {s:16s} {ms:8.3f} ms/step  {100 * ms / max(tot, 1e-9):5.1f}%  launches {n:4d}  {tf:7.1f} TFLOP/s  {tb:5.2f} TB/s (algorithmic)", file=sys.stderr)
-        print(f"  sum of sites {tot:.3f} ms/step", file=sys.stderr)
+        tot = sum(r[0] for r in site_rows)
+        if args.all_sites:
+            for ms, s, n, fl, by in sorted(site_rows, reverse=True):
+                tf = (fl * n / (ms * 1e-3) / 1e12) if ms > 0 and fl > 0 else 0.0
+                tb = (by * n / (ms * 1e-3) / 1e12) if ms > 0 and by > 0 else 0.0
+                print(f"  site {s:16s} {ms:8.3f} ms/step  {100 * ms / max(tot, 1e-9):5.1f}%  launches {n:4d}  {tf:7.1f} TFLOP/s  {tb:5.2f} TB/s (algorithmic)", file=sys.stderr)
+            print(f"  sum of sites {tot:.3f} ms/step", file=sys.stderr)
 
     if rank == 0:
         mols = args.batch * world * args.steps
@@ -386,6 +390,17 @@ def main():
             "loss": {k: round(v, 4) for k, v in losses.items() if k in ("ar_loss", "clip_loss", "loss")},
             "roofline": roof,
         }
+        if site_rows:
+            tot_sites = sum(r[0] for r in site_rows)
+            out["site_roofline"] = {
+                "note": "one step per launch site, HIP events around that site's launches, after the timed region; achieved = "
+                        "the site's algorithmic bytes / its time; sites of >= 2 % of the step",
+                "sum_of_sites_ms": round(tot_sites, 3),
+                "sites": [{"site": s_, "ms_per_step": round(ms, 3), "launches": n,
+                           "achieved_GBps": round(by_ * n / (ms * 1e-3) / 1e9, 1) if ms > 0 and by_ > 0 else None,
+                           "hbm_frac": round(by_ * n / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 3) if ms > 0 and by_ > 0 else None,
+                           "tflops": round(fl_ * n / (ms * 1e-3) / 1e12, 1) if ms > 0 and fl_ > 0 else None}
+                          for ms, s_, n, fl_, by_ in sorted(site_rows, reverse=True) if ms >= 0.02 * tot_sites]}
         T1, T2 = batch["raw_tokens"].shape[1], batch["tokens"].shape[1]
         fl, by = algorithmic_work(MODEL, args.batch, T1, T2, args.atoms)
         t_step = dt / args.steps

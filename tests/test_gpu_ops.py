@@ -295,6 +295,60 @@ def test_barlow_head_vs_oracle():
     assert float(dS[3].abs().max()) == 0.0
 
 
+def test_barlow_config3_size_eight_rank_shares():
+    """configs[3] size: E = 256, 8 ranks x 1024 rows.  The 8 rank shares run as 8 threads on the one device; the injected
+    all-reduce sums the threads' tensors behind a barrier, i.e. every exchange of the head (column statistics twice, the
+    E x E cross-correlation, the backward statistics) carries real partial sums.  Against the oracle on the concatenated
+    8192 x 256 batch (PARITY UNPINNED: the reference holds no Barlow code; oracle.barlow_loss is the restatement)."""
+    import threading
+    from oracle import coati_oracle as O
+    from coati_amd.barlow import barlow_head
+    W, B, E = 8, 1024, 256
+    g = torch.Generator().manual_seed(33)
+    a = torch.randn(W * B, E, generator=g) * 1.5 + 0.3
+    b = 0.6 * a + 0.8 * torch.randn(W * B, E, generator=g)
+    bad = torch.zeros(W * B, dtype=torch.bool)
+    bad[torch.randint(0, W * B, (40,), generator=g)] = True
+    ar, br = a.clone().double().requires_grad_(True), b.clone().double().requires_grad_(True)
+    ref = O.barlow_loss(ar, br, bad)
+    ref.sum().backward()
+    slots, bar, out, errs = [None] * W, threading.Barrier(W), [None] * W, []
+
+    def make_all_reduce(r):
+        def all_reduce(t):
+            slots[r] = t.clone()
+            torch.cuda.synchronize()
+            bar.wait()
+            t.copy_(torch.stack(slots).sum(0))
+            torch.cuda.synchronize()
+            bar.wait()
+            return t
+        return all_reduce
+
+    def rank(r):
+        try:
+            sl = slice(r * B, (r + 1) * B)
+            out[r] = barlow_head(a[sl].to(DEV), b[sl].to(DEV), bad[sl].to(DEV), lam=5e-3, gscale=1.0, distributed=True,
+                                 all_reduce=make_all_reduce(r))
+        except Exception as e:   # noqa: BLE001
+            errs.append(e)
+            bar.abort()
+
+    ths = [threading.Thread(target=rank, args=(r,)) for r in range(W)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert not errs, errs
+    for r in range(W):
+        check(f"barlow 8x1024x256 loss (rank {r})", out[r][0].cpu().double(), ref.detach(), 6e-7)   # measured <= 1.4e-7 (fp32 sums over 8192 rows against the float64 oracle)
+    dS = torch.cat([out[r][1].cpu() for r in range(W)]).double()
+    dC = torch.cat([out[r][2].cpu() for r in range(W)]).double()
+    check("barlow 8x1024x256 d/da", dS, ar.grad, 5e-6)   # measured 2.0e-6
+    check("barlow 8x1024x256 d/db", dC, br.grad, 5e-6)
+    assert float(dS[bad].abs().max()) == 0.0
+
+
 def test_barlow_train_step_runs():
     from coati_amd.engine import Engine, ModelConfig
     from coati_amd.synthetic import make_batch
