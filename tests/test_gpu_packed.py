@@ -101,6 +101,9 @@ def _both_steps(kw, batch, up, seed):
 @pytest.mark.parametrize("name,kw,shape,same_kernels", [
     ("medium", dict(n_layer_e3gnn=2, n_layer_xformer=3, n_hidden_xformer=128, n_hidden_e3nn=128, n_embd_common=128, n_head=8, n_seq=64, n_tok=300), (24, 40, 12), True),
     ("wide", dict(n_layer_e3gnn=1, n_layer_xformer=2, n_hidden_xformer=256, n_hidden_e3nn=256, n_embd_common=256, n_head=16, n_seq=250, n_tok=1003), (700, 83, 16), False),
+    # ~47 000 packed rows: the 16-row-slab row-block kernel (LayerNorm fused) and the one-round ring kernel, against the padded
+    # 91 300 rows on the 32-row row-block kernel and the 160-row ring blocks
+    ("wide2", dict(n_layer_e3gnn=1, n_layer_xformer=2, n_hidden_xformer=256, n_hidden_e3nn=256, n_embd_common=256, n_head=16, n_seq=250, n_tok=1003), (1100, 83, 16), False),
     ("hs32", dict(n_layer_e3gnn=1, n_layer_xformer=2, n_hidden_xformer=128, n_hidden_e3nn=64, n_embd_common=128, n_head=4, n_seq=140, n_tok=200), (20, 130, 9), True),
 ])
 def test_packed_step_equals_padded_step(name, kw, shape, same_kernels):
