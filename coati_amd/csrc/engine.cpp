@@ -159,6 +159,14 @@ struct coati_engine {
   const void* wtab_ws = nullptr;                      // workspace the cached tables were built for
   long long carve_sig = -1;                           // (B, T1, T2, A) of the last carve: the cached tables die with any other shape
   int wtab_rr = 0;                                    // round-robin slot of the next table upload
+  // E(3)-GNN node-level weight gradients as ONE split-table launch at the end of gnn_bwd: per-layer copies of the three
+  // gradient operands the layers otherwise overwrite, the table (cached like d_wtab)
+  bool gnn_wg_group = false;
+  std::vector<bf16_t*> gl_DO16, gl_du, gl_dP;
+  WgradTile* d_gtab = nullptr;
+  int gtab_cap = 0, gtab_n = 0;
+  long long gtab_sig = -1;
+  const void* gtab_ws = nullptr;
   float* nce = nullptr;
   size_t nce_cap = 0;
   float* opt_partial;
@@ -520,6 +528,21 @@ size_t carve(coati_engine* e, Arena& ar, int B, int T1, int T2, int A, int Bg) {
     // same (B, T1, T2, A) is carved again
     const long long csig = (((long long)B * 1000003 + T1) * 1000003 + T2) * 1000003 + A;
     if (!e->wg_group || csig != e->carve_sig) for (auto& k : e->wtab_key) k = coati_engine::WTabKey();
+    {
+      static const bool goff = getenv("COATI_GNN_WGRAD_GROUP") != nullptr && atoi(getenv("COATI_GNN_WGRAD_GROUP")) == 0;   // A/B switch
+      e->gnn_wg_group = !goff && !off && H % 128 == 0 && BA >= 4096 && Lg > 0;
+      e->gl_DO16.assign(Lg, nullptr); e->gl_du.assign(Lg, nullptr); e->gl_dP.assign(Lg, nullptr);
+      if (e->gnn_wg_group) {
+        for (int l = 0; l < Lg; ++l) { e->gl_DO16[l] = ar.take<bf16_t>(BA * H); e->gl_du[l] = ar.take<bf16_t>(BA * H); e->gl_dP[l] = ar.take<bf16_t>(BA * 2 * H); }
+        e->gtab_cap = 4 * (2 + Lg * 5) * cdiv(H, 128) * cdiv(H, 128);   // 4 slices x (2 decoder + per layer 3 of H x H and one of H x 2H) tiles
+        WgradTile* t = ar.take<WgradTile>((size_t)e->gtab_cap);
+        if (t != e->d_gtab || ar.base != e->gtab_ws || csig != e->carve_sig) e->gtab_sig = -1;
+        e->d_gtab = t;
+        e->gtab_ws = ar.base;
+      } else {
+        e->gtab_sig = -1;
+      }
+    }
     e->carve_sig = csig;
   }
   if (c.use_fp8) {   // the quantised A operand of one product (at most 4 C wide) + its block scales
@@ -818,31 +841,71 @@ int gnn_fwd(coati_engine* e, const long long* atoms, const float* coords, hipStr
   return launch_gnn_readout(e->g_o2, e->g_mask, e->hpoint, B, A, H, s);
 }
 
+// The node-level weight gradients of the point encoder (2 decoder Linears + 4 per layer, 16 384 rows each) as ONE launch at the end of
+// gnn_bwd: a table of (problem, 128 x 128 tile, slice of M) entries, cached while the workspace layout stays the same
+int gnn_wgrad_group(coati_engine* e, hipStream_t s) {
+  const coati_config& c = e->cfg;
+  const int H = c.n_hidden_e3nn, Lg = c.n_layer_e3gnn, BA = e->B * e->A;
+  const long long sig = (((long long)e->B * 1000003 + e->T1) * 1000003 + e->T2) * 1000003 + e->A;
+  if (e->gtab_sig != sig) {
+    std::vector<WgradTile> tab;
+    auto add = [&](const bf16_t* A_, int lda, const bf16_t* B_, int ldb, int N, int K, float* dW, int64_t ldw, float* db) -> int {
+      WgradArgs a;
+      a.A = A_; a.lda = lda; a.B = B_; a.ldb = ldb; a.M = BA; a.N = N; a.K = K; a.dW = dW; a.ldw = ldw; a.dbias = db; a.n_out = 0;
+      return wgrad_table_append_split(tab, a, 4);
+    };
+    COATI_TRY(add(e->g_do2, H, e->g_td, H, H, H, e->G + e->gd3w, H, e->G + e->gd3b));
+    COATI_TRY(add(e->g_dtd, H, e->g_hfin16, H, H, H, e->G + e->gd0w, H, e->G + e->gd0b));
+    for (int l = Lg - 1; l >= 0; --l) {
+      const GLayerP& w = e->gl[l];
+      COATI_TRY(add(e->gl_DO16[l], H, e->g_t[l], H, H, H, e->G + w.n3w, H, e->G + w.n3b));
+      COATI_TRY(add(e->gl_du[l], H, e->g_hcat[l], 2 * H, H, 2 * H, e->G + w.n0w, 2 * H, e->G + w.n0b));
+      COATI_TRY(add(e->gl_dP[l], 2 * H, e->g_hcat[l], 2 * H, H, H, e->G + w.e0w, 2 * H + 1, nullptr));
+      COATI_TRY(add(e->gl_dP[l] + H, 2 * H, e->g_hcat[l], 2 * H, H, H, e->G + w.e0w + H, 2 * H + 1, nullptr));
+    }
+    COATI_CHECK_ARG((int)tab.size() <= e->gtab_cap, "gnn wgrad group: table overflow (%zu > %d)", tab.size(), e->gtab_cap);
+    if (hipMemcpyAsync(e->d_gtab, tab.data(), tab.size() * sizeof(WgradTile), hipMemcpyHostToDevice, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
+      coati_set_error("gnn wgrad group: table upload failed");
+      return COATI_EHIP;
+    }
+    e->gtab_n = (int)tab.size();
+    e->gtab_sig = sig;
+  }
+  const double nprob = 2.0 + 4.0 * Lg + Lg;   // (the H x 2H product counts twice)
+  ProfScope ps(e, SITE_GNN_WGRAD, 2.0 * BA * H * H * nprob, s, nprob * ((double)BA * H * 4 + (double)H * H * 8));
+  return launch_wgrad_split_table(e->d_gtab, e->gtab_n, s);
+}
+
 int gnn_bwd(coati_engine* e, const float* dhpoint, hipStream_t s) {
   const coati_config& c = e->cfg;
   const int H = c.n_hidden_e3nn, Lg = c.n_layer_e3gnn, B = e->B, A = e->A, BA = B * A, Me = BA * A;
   float *DH = e->g_DH, *DO = e->g_DO;
+  const bool grp = e->gnn_wg_group;
   {
     ProfScope ps(e, SITE_GNN_ELEMWISE, 0, s);
     COATI_TRY(launch_gnn_readout_bwd(dhpoint, e->g_mask, e->g_do2, B, A, H, s));
   }
   COATI_TRY(gemm(e, SITE_GNN_NODE_GEMM, e->g_do2, 0, H, e->S + e->gd3T, H, BA, H, H, e->g_dtd, H, nullptr, EPI_DSILU, e->g_dpre, nullptr, H, s));
-  COATI_TRY(wgrad(e, SITE_GNN_WGRAD, e->g_do2, 0, H, e->g_td, H, BA, H, H, e->G + e->gd3w, H, e->G + e->gd3b, 0, s));
+  if (!grp) COATI_TRY(wgrad(e, SITE_GNN_WGRAD, e->g_do2, 0, H, e->g_td, H, BA, H, H, e->G + e->gd3w, H, e->G + e->gd3b, 0, s));
   COATI_TRY(gemm(e, SITE_GNN_NODE_GEMM, e->g_dtd, 0, H, e->S + e->gd0T, H, BA, H, H, DH, H, nullptr, EPI_F32, nullptr, nullptr, 0, s));
-  COATI_TRY(wgrad(e, SITE_GNN_WGRAD, e->g_dtd, 0, H, e->g_hfin16, H, BA, H, H, e->G + e->gd0w, H, e->G + e->gd0b, 0, s));
+  if (!grp) COATI_TRY(wgrad(e, SITE_GNN_WGRAD, e->g_dtd, 0, H, e->g_hfin16, H, BA, H, H, e->G + e->gd0w, H, e->G + e->gd0b, 0, s));
   for (int l = Lg - 1; l >= 0; --l) {
     const GLayerP& w = e->gl[l];
+    // grouped weight gradients: this layer's gradient operands stay alive in their own buffers until the launch at the end
+    bf16_t* const DO16 = grp ? e->gl_DO16[l] : e->g_DO16;
+    bf16_t* const du = grp ? e->gl_du[l] : e->g_du;
+    bf16_t* const dP = grp ? e->gl_dP[l] : e->g_dP;
     {
       ProfScope ps(e, SITE_GNN_ELEMWISE, 0, s);
-      COATI_TRY(launch_layernorm_bwd(DH, 1, H, e->g_h32[l + 1], H, 1, nullptr, e->g_rstd[l + 1], nullptr, nullptr, DO, e->g_DO16, nullptr, nullptr, e->ln_partial, BA, H, s));
+      COATI_TRY(launch_layernorm_bwd(DH, 1, H, e->g_h32[l + 1], H, 1, nullptr, e->g_rstd[l + 1], nullptr, nullptr, DO, DO16, nullptr, nullptr, e->ln_partial, BA, H, s));
     }
     // o = h + t W4^T + b4
-    COATI_TRY(gemm(e, SITE_GNN_NODE_GEMM, e->g_DO16, 0, H, e->S + w.n3T, H, BA, H, H, e->g_du, H, nullptr, EPI_DSILU, e->g_upre[l], nullptr, H, s));
-    COATI_TRY(wgrad(e, SITE_GNN_WGRAD, e->g_DO16, 0, H, e->g_t[l], H, BA, H, H, e->G + w.n3w, H, e->G + w.n3b, 0, s));
+    COATI_TRY(gemm(e, SITE_GNN_NODE_GEMM, DO16, 0, H, e->S + w.n3T, H, BA, H, H, du, H, nullptr, EPI_DSILU, e->g_upre[l], nullptr, H, s));
+    if (!grp) COATI_TRY(wgrad(e, SITE_GNN_WGRAD, DO16, 0, H, e->g_t[l], H, BA, H, H, e->G + w.n3w, H, e->G + w.n3b, 0, s));
     // u = [h | mi] W3^T + b3 ; W3T is [2H rows][H]
-    COATI_TRY(gemm(e, SITE_GNN_NODE_GEMM, e->g_du, 0, H, e->S + w.n0T, H, BA, H, H, DO, H, nullptr, EPI_ACC_F32, nullptr, nullptr, 0, s));
-    COATI_TRY(gemm(e, SITE_GNN_NODE_GEMM, e->g_du, 0, H, e->S + w.n0T + (int64_t)H * H, H, BA, H, H, e->g_dmi, H, nullptr, EPI_BF16, nullptr, nullptr, 0, s));
-    COATI_TRY(wgrad(e, SITE_GNN_WGRAD, e->g_du, 0, H, e->g_hcat[l], 2 * H, BA, H, 2 * H, e->G + w.n0w, 2 * H, e->G + w.n0b, 0, s));
+    COATI_TRY(gemm(e, SITE_GNN_NODE_GEMM, du, 0, H, e->S + w.n0T, H, BA, H, H, DO, H, nullptr, EPI_ACC_F32, nullptr, nullptr, 0, s));
+    COATI_TRY(gemm(e, SITE_GNN_NODE_GEMM, du, 0, H, e->S + w.n0T + (int64_t)H * H, H, BA, H, H, e->g_dmi, H, nullptr, EPI_BF16, nullptr, nullptr, 0, s));
+    if (!grp) COATI_TRY(wgrad(e, SITE_GNN_WGRAD, du, 0, H, e->g_hcat[l], 2 * H, BA, H, 2 * H, e->G + w.n0w, 2 * H, e->G + w.n0b, 0, s));
     {
       ProfScope ps(e, SITE_GNN_ELEMWISE, 0, s);
       COATI_TRY(launch_gnn_edge_reduce_bwd_c(e->g_dmi, H, e->g_s2[l], e->g_seg, e->g_ew, e->g_ds2, BA, H, s));
@@ -866,13 +929,16 @@ int gnn_bwd(coati_engine* e, const float* dhpoint, hipStream_t s) {
     }
     {
       ProfScope ps(e, SITE_GNN_ELEMWISE, 0, s);
-      COATI_TRY(launch_gnn_edge_pre_bwd_c(e->g_dpre1, e->g_seg, e->g_erev, e->g_ed2, e->g_dP, 2 * H, e->G + w.e0w + 2 * H, 2 * H + 1, e->G + w.e0b, BA, H, s));
+      COATI_TRY(launch_gnn_edge_pre_bwd_c(e->g_dpre1, e->g_seg, e->g_erev, e->g_ed2, dP, 2 * H, e->G + w.e0w + 2 * H, 2 * H + 1, e->G + w.e0b, BA, H, s));
     }
-    COATI_TRY(gemm(e, SITE_GNN_NODE_GEMM, e->g_dP, 0, 2 * H, e->S + w.w1abT, 2 * H, BA, H, 2 * H, DO, H, nullptr, EPI_ACC_F32, nullptr, nullptr, 0, s));
-    COATI_TRY(wgrad(e, SITE_GNN_WGRAD, e->g_dP, 0, 2 * H, e->g_hcat[l], 2 * H, BA, H, H, e->G + w.e0w, 2 * H + 1, nullptr, 0, s));
-    COATI_TRY(wgrad(e, SITE_GNN_WGRAD, e->g_dP + H, 0, 2 * H, e->g_hcat[l], 2 * H, BA, H, H, e->G + w.e0w + H, 2 * H + 1, nullptr, 0, s));
+    COATI_TRY(gemm(e, SITE_GNN_NODE_GEMM, dP, 0, 2 * H, e->S + w.w1abT, 2 * H, BA, H, 2 * H, DO, H, nullptr, EPI_ACC_F32, nullptr, nullptr, 0, s));
+    if (!grp) {
+      COATI_TRY(wgrad(e, SITE_GNN_WGRAD, dP, 0, 2 * H, e->g_hcat[l], 2 * H, BA, H, H, e->G + w.e0w, 2 * H + 1, nullptr, 0, s));
+      COATI_TRY(wgrad(e, SITE_GNN_WGRAD, dP + H, 0, 2 * H, e->g_hcat[l], 2 * H, BA, H, H, e->G + w.e0w + H, 2 * H + 1, nullptr, 0, s));
+    }
     float* t = DH; DH = DO; DO = t;
   }
+  if (grp) COATI_TRY(gnn_wgrad_group(e, s));
   {
     ProfScope ps(e, SITE_GNN_ELEMWISE, 0, s);
     COATI_TRY(launch_layernorm_bwd(DH, 1, H, e->g_h32[0], H, 1, nullptr, e->g_rstd[0], nullptr, nullptr, DO, nullptr, nullptr, nullptr, e->ln_partial, BA, H, s));

@@ -764,7 +764,7 @@ __device__ __forceinline__ void wgrad_dma_body(const WgradArgs& p, int tiles_k, 
   __syncthreads();
   // the bias atomics go first: all workgroups of a tile row hit the same 128 addresses at the same time, and that
   // serialised chain then runs in the L2 underneath the (much larger) tile commit below
-  if (BIAS && tid < 128) {
+  if (BIAS && tid < 128 && p.dbias != nullptr) {
     float t = 0.f;
 #pragma unroll
     for (int w = 0; w < 8; ++w) t += bsum[w * 128 + tid];
@@ -821,6 +821,16 @@ __global__ __launch_bounds__(512, 1) void wgrad_dma_table_kernel(const WgradTile
   WgradArgs p = d.p;
   if (M_rt > 0) p.M = M_rt;   // the rows of THIS launch (the cached table holds the largest count: packed rows change every batch)
   wgrad_dma_body<BIAS, NS, true>(p, d.tiles_k, d.tile, 0, (p.M + WD_CH - 1) / WD_CH, smem);
+}
+
+// Grouped launch for small row counts (round 3: the E(3)-GNN's 22 node-level weight gradients, 16 384 rows each, were 22
+// launches of ~22 us that each filled a fraction of the machine): one entry per (problem, tile, slice of M); the slices of a tile
+// meet in fp32 atomics like the ungrouped kernel's splits.
+template <int NS>
+__global__ __launch_bounds__(512, 1) void wgrad_dma_split_table_kernel(const WgradTile* __restrict__ table) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const WgradTile& d = table[blockIdx.x];
+  wgrad_dma_body<true, NS, false>(d.p, d.tiles_k, d.tile, d.c_begin, d.c_end, smem);
 }
 
 // =================================================================================================
@@ -1055,6 +1065,41 @@ int wgrad_table_append(std::vector<WgradTile>& tab, const WgradArgs& a, int tile
   const int tiles_n = cdiv(a.N, BM), tiles_k = cdiv(a.K, BN);
   const int n = tiles_n * tiles_k;
   for (int t = 0; t < n; ++t) tab.push_back(WgradTile{a, tiles_k, t});
+  return COATI_OK;
+}
+
+int wgrad_table_append_split(std::vector<WgradTile>& tab, const WgradArgs& a, int n_splits) {
+  COATI_CHECK_ARG(a.A && a.B && a.dW, "wgrad_table(split): null operand");
+  COATI_CHECK_SHAPE(a.M > 0 && a.N % 8 == 0 && a.K % 8 == 0 && a.lda % 8 == 0 && a.ldb % 8 == 0 && a.m_dev == nullptr, "wgrad_table(split): shape / alignment");
+  const int tiles_n = cdiv(a.N, BM), tiles_k = cdiv(a.K, BN), nchunks = cdiv(a.M, WD_CH);
+  if (n_splits > cdiv(nchunks, 4)) n_splits = cdiv(nchunks, 4);
+  if (n_splits < 1) n_splits = 1;
+  const int cps = cdiv(nchunks, n_splits);
+  for (int c0 = 0; c0 < nchunks; c0 += cps)
+    for (int t = 0; t < tiles_n * tiles_k; ++t) {
+      WgradTile w{a, tiles_k, t};
+      w.c_begin = c0;
+      w.c_end = c0 + cps < nchunks ? c0 + cps : nchunks;
+      tab.push_back(w);
+    }
+  return COATI_OK;
+}
+
+int launch_wgrad_split_table(const WgradTile* dev_table, int n_entries, hipStream_t s) {
+  COATI_CHECK_ARG(dev_table && n_entries > 0, "wgrad_table(split): empty table");
+  static bool attr_set = false;
+  auto kern = wgrad_dma_split_table_kernel<3>;
+  constexpr int lds = 3 * WD_STAGE_BYTES;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) {
+      coati_set_error("wgrad(split table): hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+      return COATI_EHIP;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(n_entries), dim3(512), lds, s, dev_table);
+  COATI_LAUNCH_CHECK("wgrad_split_table");
   return COATI_OK;
 }
 

@@ -121,12 +121,17 @@ struct WgradTile {
   WgradArgs p;
   int tiles_k;   // 128-column tiles along K of this problem
   int tile;      // tile index inside the problem (tile_n * tiles_k + tile_k)
+  int c_begin = 0, c_end = 0;   // split tables only: the 64-row chunks [c_begin, c_end) of M this entry streams
 };
 int launch_wgrad_table(const WgradTile* dev_table, int n_tiles, hipStream_t s, int tile_size = 128, int M_rt = 0);   // M_rt > 0: rows of this launch (<= the M of the table entries)   // every entry of a table has the same tile size
 bool wgrad_table_tile256_ok(const WgradArgs& a);
+// Grouped form for SMALL row counts (the E(3)-GNN's node-level Linears: 16 384 rows): the entries of a problem's 128 x 128 tiles
+// are repeated over n_splits slices of M, every entry adds its partial tile with fp32 atomics (dbias may be null)
+int launch_wgrad_split_table(const WgradTile* dev_table, int n_entries, hipStream_t s);
 #ifdef __cplusplus
 #include <vector>
 int wgrad_table_append(std::vector<WgradTile>& tab, const WgradArgs& a, int tile_size = 128);   // host: appends the tiles of one problem
+int wgrad_table_append_split(std::vector<WgradTile>& tab, const WgradArgs& a, int n_splits);    // host: tiles x M slices of one problem
 #endif
 
 // C[M,N] (f32) = sum_k A(m,k) B(k,n) [+ bias[n]] [+ C];  A(m,k) = A[m*ars + k*acs], B(k,n) = B[k*brs + n*bcs]
