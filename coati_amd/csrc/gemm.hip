@@ -282,6 +282,7 @@ int launch_gemm_nt(const GemmArgs& a, int a_f32, int epi, hipStream_t s) {
     static const bool no_rb = getenv("COATI_NO_RB") != nullptr;   // A/B switch for benchmarking
     // N = 256 with a bf16 / residual epilogue: the ring kernel, also at K = 256 (proj forward 57 -> 44 us against the
     // row-block kernel); every other K = 256 product: the row-block kernel
+    if (!no_rb && gemm_rb16_resident_supported(a, a_f32, epi)) return launch_gemm_rb16_resident(a, epi, s);
     if (gemm_ring256_supported(a, a_f32, epi)) return launch_gemm_ring256(a, epi, s);
     if (!no_rb && gemm_rb16_supported(a, a_f32, epi)) return launch_gemm_rb16(a, epi, s);
     if (!no_rb && gemm_rb256_supported(a, a_f32, epi)) return launch_gemm_rb256(a, epi, s);

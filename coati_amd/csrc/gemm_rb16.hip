@@ -270,6 +270,143 @@ __global__ __launch_bounds__(64 * R16_MAXW, 1) void gemm_rb16_kernel(GemmArgs p,
   }
 }
 
+// ---- weight-resident form for N <= 256 (round 3): the E(3)-GNN's edge-level products ------------------------------------
+// K = 256, N = 256: the whole weight (128 KiB) stays in LDS for the lifetime of a PERSISTENT workgroup; the waves then walk over
+// 16-row slabs independently -- no tile barriers at all.  The row count of the edge products is data dependent (compacted
+// neighbour list, read on the device): the 32-row kernel sized its grid for the worst case (all A (A - 1) pairs) and the
+// ~125 000 edges of a batch became 1.5 rounds of 10-slab workgroups; here every workgroup derives its equal share of the slabs
+// that exist from the device-side count.  Epilogues: bf16 (+ bias) and the GNN's dSiLU(recomputed pre-activation) multiply
+// (EPI_EDGE_DPRE; its per-column constants w1c / b1 staged in LDS next to the bias).
+#define R16_RES_TILES 4
+template <int EPI>
+__global__ __launch_bounds__(64 * R16_MAXW, 1) void gemm_rb16_resident_kernel(GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int MAP = 0;
+  bf16_t* const Bs = reinterpret_cast<bf16_t*>(smem);
+  float* const BiasS = reinterpret_cast<float*>(smem + R16_RES_TILES * R16_TILE_HALFS * 2);   // bias[256]
+  float* const ColS = BiasS + R16_RES_TILES * R16_BN;                                          // EPI_EDGE_DPRE: per tile [64 w1c | 64 b1]
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), W = blockDim.x >> 6;
+  const int fr = lane & 15, kq = lane >> 4;
+  const int ntiles = (p.N + R16_BN - 1) / R16_BN;
+  const int M = __builtin_amdgcn_readfirstlane(p.m_dev != nullptr ? *p.m_dev : p.M);   // (scalar: everything derived from it stays on the scalar unit)
+  const bool has_bias = p.bias != nullptr;
+  if (M <= 0) return;
+  for (int c = tid; c < ntiles * R16_BN; c += blockDim.x) {
+    BiasS[c] = (has_bias && c < p.N) ? p.bias[c] : 0.f;
+    if constexpr (EPI == EPI_EDGE_DPRE) {
+      const int jt = c / R16_BN, e = c % R16_BN;
+      ColS[jt * 128 + e] = c < p.N ? p.w1c[(long long)c * p.w1c_stride] : 0.f;
+      ColS[jt * 128 + 64 + e] = c < p.N ? p.b1[c] : 0.f;
+    }
+  }
+  typedef __attribute__((address_space(3))) void lds_void;
+  typedef __attribute__((address_space(1))) const void gbl_void;
+  // the whole weight: ntiles x 32 pieces of 1 KiB (two 512-B rows), piece k by wave k % W; chunk c of row r at position c ^ f(r)
+  for (int k = wave; k < ntiles * (R16_BN / 2); k += W) {
+    const int r = 2 * k + (lane >> 5), q = lane & 31;     // r = weight row (all tiles), 0 .. 64 ntiles - 1
+    const int gc = r < p.N ? r : p.N - 1;
+    const bf16_t* src = p.B + (long long)gc * p.ldb + ((q ^ r16_swz<MAP>(r & 63)) * 8);
+    __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(Bs + k * 512), 16, 0, 0);
+  }
+  __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0)
+  __syncthreads();
+
+  int wofs[4], wsw[4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    const int n = r16_wrow<MAP>(a, fr);
+    wofs[a] = n * R16_K;
+    wsw[a] = r16_swz<MAP>(n);
+  }
+  const int colA = 8 * kq, colB = 32 + 8 * kq;
+  GemmArgs q = p;
+  q.bias = nullptr;   // folded into the accumulator initialisation
+  q.M = M;
+
+  // this workgroup's equal share of the slabs that exist; its waves take them round-robin
+  const int slabs = (M + 15) / 16, per_wg = (slabs + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int s_begin = blockIdx.x * per_wg, s_end = s_begin + per_wg < slabs ? s_begin + per_wg : slabs;
+  for (int sl = s_begin + wave; sl < s_end; sl += W) {
+    const int m0 = sl * 16, row_l = m0 + fr, rc = row_l < M ? row_l : M - 1;
+    const bool rowok = row_l < M;
+    bf16x8 af[8];
+    {
+      const bf16_t* ap = reinterpret_cast<const bf16_t*>(p.A) + (long long)rc * p.lda + kq * 8;
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) af[ks] = *reinterpret_cast<const bf16x8*>(ap + ks * 32);
+    }
+    for (int jt = 0; jt < ntiles; ++jt) {
+      const bf16_t* cur = Bs + jt * R16_TILE_HALFS;
+      f32x4_t acc[4];
+      acc[0] = *reinterpret_cast<const f32x4_t*>(BiasS + jt * R16_BN + colA);
+      acc[1] = *reinterpret_cast<const f32x4_t*>(BiasS + jt * R16_BN + colA + 4);
+      acc[2] = *reinterpret_cast<const f32x4_t*>(BiasS + jt * R16_BN + colB);
+      acc[3] = *reinterpret_cast<const f32x4_t*>(BiasS + jt * R16_BN + colB + 4);
+      {
+        // operand fragments: two sets in flight (bf16 epilogue) or one (EPI_EDGE_DPRE: its gathers need the 16 registers; the
+        // other three waves of the SIMD cover the LDS latency)
+        constexpr int WFD = (EPI == EPI_EDGE_DPRE) ? 1 : 2;
+        bf16x8 wf[WFD][4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) wf[0][a] = *reinterpret_cast<const bf16x8*>(cur + wofs[a] + ((kq ^ wsw[a]) * 8));
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+          if (WFD == 2 && ks + 1 < 8) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a) wf[(ks + 1) % WFD][a] = *reinterpret_cast<const bf16x8*>(cur + wofs[a] + (((4 * (ks + 1) + kq) ^ wsw[a]) * 8));
+          }
+#pragma unroll
+          for (int a = 0; a < 4; ++a) acc[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks % WFD][a], af[ks], acc[a], 0, 0, 0);
+          if (WFD == 1 && ks + 1 < 8) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a) wf[0][a] = *reinterpret_cast<const bf16x8*>(cur + wofs[a] + (((4 * (ks + 1) + kq) ^ wsw[a]) * 8));
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      float v0[8] = {acc[0][0], acc[0][1], acc[0][2], acc[0][3], acc[1][0], acc[1][1], acc[1][2], acc[1][3]};
+      float v1[8] = {acc[2][0], acc[2][1], acc[2][2], acc[2][3], acc[3][0], acc[3][1], acc[3][2], acc[3][3]};
+      const int c0 = jt * R16_BN + colA, c1 = jt * R16_BN + colB;
+      const void* st0 = nullptr;
+      const void* st1 = nullptr;
+      if constexpr (EPI == EPI_EDGE_DPRE) { st0 = ColS + jt * 128 + colA; st1 = ColS + jt * 128 + colB; }
+      epilogue8<EPI>(q, row_l, c0, v0, rowok, jt, ntiles, st0);
+      __builtin_amdgcn_sched_barrier(0);   // one 8-column group after the other: interleaved, the two gathers of EPI_EDGE_DPRE spill
+      epilogue8<EPI>(q, row_l, c1, v1, rowok, jt, ntiles, st1);
+    }
+  }
+}
+
+bool gemm_rb16_resident_supported(const GemmArgs& a, int a_f32, int epi) {
+  static const bool off = getenv("COATI_NO_RB16_RES") != nullptr;   // A/B switch: the 32-row kernel with its worst-case grid
+  if (off || a_f32 || a.K != R16_K || a.m_dev == nullptr) return false;
+  if (epi != EPI_BF16 && epi != EPI_EDGE_DPRE) return false;
+  if (a.N % 16 != 0 || a.N > R16_RES_TILES * R16_BN || a.q8_out != nullptr || a.ln_x != nullptr) return false;
+  return a.M >= 16 * 256;
+}
+
+template <int EPI>
+static int launch_rb16_resident_t(const GemmArgs& a, hipStream_t s) {
+  static bool attr_set = false;
+  auto kern = gemm_rb16_resident_kernel<EPI>;
+  constexpr size_t lds = (size_t)R16_RES_TILES * R16_TILE_HALFS * 2 + (size_t)R16_RES_TILES * R16_BN * 4 + (size_t)R16_RES_TILES * 128 * 4;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+      coati_set_error("gemm_rb16(resident): hipFuncSetAttribute failed");
+      return COATI_EHIP;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(256), dim3(64 * R16_MAXW), lds, s, a);
+  COATI_LAUNCH_CHECK("gemm_rb16_resident");
+  return COATI_OK;
+}
+
+int launch_gemm_rb16_resident(const GemmArgs& a, int epi, hipStream_t s) {
+  if (epi == EPI_EDGE_DPRE) return launch_rb16_resident_t<EPI_EDGE_DPRE>(a, s);
+  return launch_rb16_resident_t<EPI_BF16>(a, s);
+}
+
 // waves per workgroup for M rows: one round of one workgroup per CU
 static int rb16_waves(int M) {
   const int slabs = (M + 15) / 16;

@@ -91,6 +91,9 @@ int gemm_ce_tile_width(const GemmArgs& a);
 int launch_gemm_rb256(const GemmArgs& a, int epi, hipStream_t s);
 // the same on 16-row slabs / 13-16 waves per workgroup (gemm_rb16.hip): packed batch sizes (36 865 .. 65 536 rows)
 bool gemm_rb16_supported(const GemmArgs& a, int a_f32, int epi);
+// weight-resident persistent form for N <= 256 with a device-side row count (the GNN's edge products)
+bool gemm_rb16_resident_supported(const GemmArgs& a, int a_f32, int epi);
+int launch_gemm_rb16_resident(const GemmArgs& a, int epi, hipStream_t s);
 int launch_gemm_rb16(const GemmArgs& a, int epi, hipStream_t s);
 // ring kernel for N = 256, long K (gemm_ring.hip)
 bool gemm_ring256_supported(const GemmArgs& a, int a_f32, int epi);
