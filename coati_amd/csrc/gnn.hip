@@ -569,7 +569,9 @@ int launch_gnn_edge_reduce_bwd_c(const bf16_t* dmi, long long lddmi, const bf16_
 // backward of the gather-add on the list: dPa[bj] = sum over the receiver's segment of dpre[e]; dPb[bj] = the same sum over
 // the REVERSE edges (sender bj: rows e_rev[e]), dw1c += sum dpre[e] d2[e], db1 += sum dpre[e].  Persistent workgroups: the
 // two column sums stay in registers across receivers, one atomic per channel and workgroup.
-__global__ __launch_bounds__(256) void gnn_edge_pre_bwd_c_kernel(const bf16_t* __restrict__ dpre, const int* __restrict__ seg,
+#define EPB_WAVES 16   // waves per workgroup: the loads of a receiver are a latency chain, so the CU needs many receivers in flight; the
+                       // number of WORKGROUPS (= atomics per channel) stays at 512
+__global__ __launch_bounds__(64 * EPB_WAVES) void gnn_edge_pre_bwd_c_kernel(const bf16_t* __restrict__ dpre, const int* __restrict__ seg,
                                                                  const int* __restrict__ e_rev, const float* __restrict__ e_d2,
                                                                  bf16_t* __restrict__ dP, long long lddp, float* __restrict__ dw1c,
                                                                  long long dw1c_stride, float* __restrict__ db1, int BA, int H) {
@@ -581,7 +583,7 @@ __global__ __launch_bounds__(256) void gnn_edge_pre_bwd_c_kernel(const bf16_t* _
     const bool act = c0 + lane * 4 < H;
     const int c = act ? c0 + lane * 4 : 0;
     float sw[4] = {0.f, 0.f, 0.f, 0.f}, sb[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int bj = blockIdx.x * 4 + wave; bj < BA; bj += gridDim.x * 4) {
+    for (int bj = blockIdx.x * EPB_WAVES + wave; bj < BA; bj += gridDim.x * EPB_WAVES) {
       const int e0 = seg[bj], n = seg[bj + 1] - e0;
       float a[4] = {0.f, 0.f, 0.f, 0.f}, bsum[4] = {0.f, 0.f, 0.f, 0.f};
       for (int base = 0; base < n; base += 64) {
@@ -619,7 +621,7 @@ __global__ __launch_bounds__(256) void gnn_edge_pre_bwd_c_kernel(const bf16_t* _
     }
     // column sums: the 4 waves of the workgroup add up through LDS, then ONE atomic per channel and workgroup (thousands of
     // same-address atomics serialise in the L2: 2048 workgroups x 4 waves made this kernel 1 ms)
-    __shared__ float red[2][4][256];
+    __shared__ float red[2][EPB_WAVES][256];
 #pragma unroll
     for (int i = 0; i < 4; ++i) { red[0][wave][lane * 4 + i] = act ? sw[i] : 0.f; red[1][wave][lane * 4 + i] = act ? sb[i] : 0.f; }
     __syncthreads();
@@ -627,8 +629,11 @@ __global__ __launch_bounds__(256) void gnn_edge_pre_bwd_c_kernel(const bf16_t* _
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int k = lane * 4 + i;
-        atomicAdd(dw1c + (long long)(c + i) * dw1c_stride, red[0][0][k] + red[0][1][k] + red[0][2][k] + red[0][3][k]);
-        atomicAdd(db1 + c + i, red[1][0][k] + red[1][1][k] + red[1][2][k] + red[1][3][k]);
+        float t0 = 0.f, t1 = 0.f;
+#pragma unroll
+        for (int w = 0; w < EPB_WAVES; ++w) { t0 += red[0][w][k]; t1 += red[1][w][k]; }
+        atomicAdd(dw1c + (long long)(c + i) * dw1c_stride, t0);
+        atomicAdd(db1 + c + i, t1);
       }
     }
     __syncthreads();
@@ -638,9 +643,9 @@ int launch_gnn_edge_pre_bwd_c(const bf16_t* dpre, const int* seg, const int* e_r
                               float* dw1c, long long dw1c_stride, float* db1, int BA, int H, hipStream_t s) {
   COATI_CHECK_ARG(dpre && seg && e_rev && e_d2 && dP && dw1c && db1, "gnn_edge_pre_bwd_c: null operand");
   COATI_CHECK_SHAPE(H % 4 == 0 && lddp % 4 == 0, "gnn_edge_pre_bwd_c: alignment");
-  int blocks = cdiv(BA, 4);
+  int blocks = cdiv(BA, EPB_WAVES);
   if (blocks > 512) blocks = 512;   // 2 resident workgroups per CU, each loops over its receivers: 512 atomics per channel
-  hipLaunchKernelGGL(gnn_edge_pre_bwd_c_kernel, dim3(blocks), dim3(256), 0, s, dpre, seg, e_rev, e_d2, dP, lddp, dw1c, dw1c_stride, db1, BA, H);
+  hipLaunchKernelGGL(gnn_edge_pre_bwd_c_kernel, dim3(blocks), dim3(64 * EPB_WAVES), 0, s, dpre, seg, e_rev, e_d2, dP, lddp, dw1c, dw1c_stride, db1, BA, H);
   COATI_LAUNCH_CHECK("gnn_edge_pre_bwd_c");
   return COATI_OK;
 }
