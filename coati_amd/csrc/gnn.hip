@@ -644,7 +644,10 @@ int launch_gnn_edge_pre_bwd_c(const bf16_t* dpre, const int* seg, const int* e_r
   COATI_CHECK_ARG(dpre && seg && e_rev && e_d2 && dP && dw1c && db1, "gnn_edge_pre_bwd_c: null operand");
   COATI_CHECK_SHAPE(H % 4 == 0 && lddp % 4 == 0, "gnn_edge_pre_bwd_c: alignment");
   int blocks = cdiv(BA, EPB_WAVES);
-  if (blocks > 512) blocks = 512;   // 2 resident workgroups per CU, each loops over its receivers: 512 atomics per channel
+  // ONE 16-wave workgroup per CU, each looping over its receivers.  Measured (gnn_elemwise per step): 64 workgroups 1.19 ms,
+  // 128 / 256: 1.04, 512: 1.17, 1024: 1.44 -- and the same with the column sums taken out of the atomics (a two-stage form:
+  // 1.05 / 1.17 / 1.36): it is the gathers of the reverse rows that degrade with more waves in flight, not the atomics
+  if (blocks > 256) blocks = 256;
   hipLaunchKernelGGL(gnn_edge_pre_bwd_c_kernel, dim3(blocks), dim3(64 * EPB_WAVES), 0, s, dpre, seg, e_rev, e_d2, dP, lddp, dw1c, dw1c_stride, db1, BA, H);
   COATI_LAUNCH_CHECK("gnn_edge_pre_bwd_c");
   return COATI_OK;
