@@ -19,7 +19,7 @@ export PMC_COMMAND="rocprofv3 --pmc <FETCH_SIZE|WRITE_SIZE> --kernel-trace -- py
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_$c -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-other-layout > /dev/null 2>&1
 done
-python $R/tools/pmc_to_json.py xf_wgrad _table_kernel $(find $OUT/${TAG}_pmc_FETCH_SIZE $OUT/${TAG}_pmc_WRITE_SIZE -name "*counter_collection.csv") > $OUT/${TAG}_pmc_summary.json
+python $R/tools/pmc_to_json.py xf_wgrad wgrad256_table_kernel $(find $OUT/${TAG}_pmc_FETCH_SIZE $OUT/${TAG}_pmc_WRITE_SIZE -name "*counter_collection.csv") > $OUT/${TAG}_pmc_summary.json
 # configs[4] shape (d = 512, 16 heads of 32, batch 2048): bf16 and MXFP8 operand lines
 python $R/bench.py --config coati2_shape --batch 2048 --steps 5 --warmup 2 --no-cpu-baseline --no-other-layout --all-sites > $OUT/${TAG}_bench_coati2_bf16.json 2> $OUT/${TAG}_bench_coati2_bf16_sites.txt
 python $R/bench.py --config coati2_shape --batch 2048 --fp8 --steps 5 --warmup 2 --no-cpu-baseline --no-other-layout --all-sites > $OUT/${TAG}_bench_coati2_fp8.json 2> $OUT/${TAG}_bench_coati2_fp8_sites.txt
