@@ -516,6 +516,198 @@ static int launch_ring1_t(const GemmArgs& a, int R, hipStream_t s) {
   return COATI_OK;
 }
 
+
+// ---- one round, 64 x 128 wave tiles (round 3): 57 345 .. 65 536 rows ------------------------------------------------------
+// The 32 x 128 wave tile of the kernels above reads 5 KiB of LDS fragments per 4 MFMAs -- 160 B/clk per CU at full matrix-core
+// rate against the 128 the LDS delivers.  A 64 x 128 tile reads 6 KiB per 8 MFMAs (96 B/clk): 8 waves = 4 row groups of 64 x 2 column
+// halves, 128 accumulator registers per wave (2 waves per SIMD), spans of <= 256 rows, A ring of 3 x 32 KiB + weight ring of 2 x 32 KiB
+// = exactly the 160 KiB of LDS.  Same DMA / wait choreography as gemm_ring1_kernel (4 A pieces + 4 weight pieces per wave and stage).
+#define R2W_GROUPS 4
+#define R2W_BR (64 * R2W_GROUPS)
+#define R2W_WAVES (2 * R2W_GROUPS)
+#define R2W_A_BYTES (R2W_BR * RG_BK * 2)                                // 32 KiB
+#define R2W_LDS_BYTES (3 * R2W_A_BYTES + 2 * RG_W_BYTES)                // 163,840 B
+
+__device__ __forceinline__ void r2w_wait_vm(int n) {   // s_waitcnt vmcnt(n), n = 0 .. 4
+  if (n >= 4) __builtin_amdgcn_s_waitcnt(0x0f74);
+  else if (n == 3) __builtin_amdgcn_s_waitcnt(0x0f73);
+  else if (n == 2) __builtin_amdgcn_s_waitcnt(0x0f72);
+  else if (n == 1) __builtin_amdgcn_s_waitcnt(0x0f71);
+  else __builtin_amdgcn_s_waitcnt(0x0f70);
+}
+
+template <int EPI>
+__global__ __launch_bounds__(64 * R2W_WAVES, 1) void gemm_ring1w_kernel(GemmArgs p, int R) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  typedef __attribute__((address_space(3))) unsigned char lds_u8;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int nk = p.K / RG_BK;
+  const int row0 = blockIdx.x * R;
+  if (row0 >= p.M) return;
+  const int row_end = row0 + R < p.M ? row0 + R : p.M, nvalid = row_end - row0;
+  const bf16_t* A = reinterpret_cast<const bf16_t*>(p.A);
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_u8*)smem);
+  const unsigned ldsW = lds0 + 3 * R2W_A_BYTES;
+
+  // DMA pieces of 8 rows x 128 B: A pieces {wave + 8 i}, weight pieces {wave + 8 i}, i = 0 .. 3 (all of one parity)
+  const int lrow = lane >> 3;
+  const int cg = (lane & 7) ^ ((((wave & 1) << 2) + (lane >> 4)) & 7);
+  const unsigned offa = (unsigned)((lrow * (int)p.lda + cg * 8) * 2);
+  const unsigned offw = (unsigned)((lrow * (int)p.ldb + cg * 8) * 2);
+  int amode[4], nA = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int q = wave + R2W_WAVES * i;
+    amode[i] = 8 * q + 8 <= nvalid ? 2 : (8 * q < nvalid ? 1 : 0);
+    nA += amode[i] != 0;
+  }
+  const bool ROT = (EPI != EPI_RES_F32) && nk >= 8;
+  const int kk0 = ROT ? (int)(blockIdx.x % (unsigned)nk) : 0;
+  const bf16_t* const pa = A + (long long)row0 * p.lda;
+  auto issue_a_piece = [&](int i, int kk, unsigned slot) __attribute__((always_inline)) {
+    const int q = wave + R2W_WAVES * i;
+    if (amode[i] == 2) {
+      rg_dma16s(pa + (long long)8 * q * p.lda + kk * RG_BK, offa, slot + q * 1024);
+    } else if (amode[i] == 1) {
+      int r = row0 + 8 * q + lrow;
+      r = r < row_end ? r : row_end - 1;
+      rg_dma16(A + (long long)r * p.lda + kk * RG_BK + cg * 8, slot + q * 1024);
+    }
+  };
+  auto issue_w2 = [&](int half, int kk, unsigned slot) __attribute__((always_inline)) {   // weight pieces 2 half, 2 half + 1 of this wave
+    const bf16_t* wb = p.B + (long long)8 * (wave + R2W_WAVES * 2 * half) * p.ldb + kk * RG_BK;
+    const long long w_p = 8LL * R2W_WAVES * p.ldb;
+    rg_dma16s(wb, offw, slot + (wave + R2W_WAVES * 2 * half) * 1024);
+    rg_dma16s(wb + w_p, offw, slot + (wave + R2W_WAVES * (2 * half + 1)) * 1024);
+  };
+  auto kwrap = [&](int k) { return k >= nk ? k - nk : k; };
+
+  const int fr = lane & 31, kg = lane >> 5, swz = (fr >> 1) & 7;
+  unsigned xo[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) xo[ks] = (unsigned)(fr * 128 + (((2 * ks + kg) ^ swz) << 4));
+  const unsigned a_row = (unsigned)(wm * 64 * 128), w_row = (unsigned)(wn * 128 * 128);
+
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float b = p.bias != nullptr ? p.bias[wn * 128 + j * 32 + fr] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[0][j][r] = b; acc[1][j][r] = b; }
+  }
+
+  // prologue: A(0), W(0), A(1)
+#pragma unroll
+  for (int i = 0; i < 4; ++i) issue_a_piece(i, kk0, lds0);
+  issue_w2(0, kk0, ldsW);
+  issue_w2(1, kk0, ldsW);
+  if (nk > 1) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) issue_a_piece(i, kwrap(kk0 + 1), lds0 + R2W_A_BYTES);
+  }
+  int sa = 0, sw = 0;
+  int kk1 = kwrap(kk0 + 1), kk2 = kwrap(kk1 + 1);
+  for (int s = 0; s < nk; ++s) {
+    r2w_wait_vm(s + 1 < nk ? nA : 0);
+    __builtin_amdgcn_s_barrier();
+    const unsigned char* SA = smem + sa * R2W_A_BYTES;
+    const unsigned char* SW = smem + 3 * R2W_A_BYTES + sw * RG_W_BYTES;
+    const int sa2 = sa == 0 ? 2 : sa - 1;                        // (sa + 2) % 3
+    {
+      bf16x8 fa[2][2], fw[2][4];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) fa[0][i] = *reinterpret_cast<const bf16x8*>(SA + a_row + i * 4096 + xo[0]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fw[0][j] = *reinterpret_cast<const bf16x8*>(SW + w_row + j * 4096 + xo[0]);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const int cur = ks & 1, nxt = cur ^ 1;
+        // issue order inside the stage: W(s + 1) at k steps 0 and 1, then the A pieces of stage s + 2 at k steps 2 and 3
+        if (ks < 2) { if (s + 1 < nk) issue_w2(ks, kk1, ldsW + (sw ^ 1) * RG_W_BYTES); }
+        else if (s + 2 < nk) { issue_a_piece(2 * (ks - 2), kk2, lds0 + sa2 * R2W_A_BYTES); issue_a_piece(2 * (ks - 2) + 1, kk2, lds0 + sa2 * R2W_A_BYTES); }
+        if (ks < 3) {
+#pragma unroll
+          for (int i = 0; i < 2; ++i) fa[nxt][i] = *reinterpret_cast<const bf16x8*>(SA + a_row + i * 4096 + xo[ks + 1]);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) fw[nxt][j] = *reinterpret_cast<const bf16x8*>(SW + w_row + j * 4096 + xo[ks + 1]);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][i], fw[cur][j], acc[i][j], 0, 0, 0);
+        if (ks < 3) {
+#pragma unroll
+          for (int g = 0; g < 6; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          }
+        }
+      }
+    }
+    sa = sa == 2 ? 0 : sa + 1;
+    sw ^= 1;
+    kk1 = kk2;
+    kk2 = kwrap(kk2 + 1);
+  }
+
+  // ---- write-out straight from the accumulator layout
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int wrow0 = row0 + wm * 64 + i * 32;
+    const bool full = wm * 64 + (i + 1) * 32 <= nvalid;   // wave-uniform
+    if (EPI == EPI_RES_F32) {
+      const float* res = reinterpret_cast<const float*>(p.aux_in) + wn * 128 + fr;
+      float* out = reinterpret_cast<float*>(p.C) + wn * 128 + fr;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        float x[8][4];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          const int row = wrow0 + rg_frag_row(8 * h + r, lane), rc = (full || row < row_end) ? row : row_end - 1;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) x[r][j] = res[(long long)rc * p.ld_aux + j * 32];
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          const int row = wrow0 + rg_frag_row(8 * h + r, lane);
+          if (full || row < row_end) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) out[(long long)row * p.ldc + j * 32] = acc[i][j][8 * h + r] + x[r][j];
+          }
+        }
+      }
+    } else {
+      bf16_t* out = reinterpret_cast<bf16_t*>(p.C) + wn * 128 + fr;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wrow0 + rg_frag_row(r, lane);
+        if (full || row < row_end) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) out[(long long)row * p.ldc + j * 32] = f2bf(acc[i][j][r]);
+        }
+      }
+    }
+  }
+}
+
+template <int EPI>
+static int launch_ring1w_t(const GemmArgs& a, int R, hipStream_t s) {
+  static bool attr_set = false;
+  auto kern = gemm_ring1w_kernel<EPI>;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, R2W_LDS_BYTES);
+    if (e != hipSuccess) {
+      coati_set_error("gemm_ring1w: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+      return COATI_EHIP;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(cdiv(a.M, R)), dim3(64 * R2W_WAVES), R2W_LDS_BYTES, s, a, R);
+  COATI_LAUNCH_CHECK("gemm_ring1w");
+  return COATI_OK;
+}
+
 int launch_gemm_ring256(const GemmArgs& a, int epi, hipStream_t s) {
   // block height: rows the busiest of the 256 persistent workgroups walks = rounds x block rows; ties go to the 160-row form
   // (less weight re-streaming per row).  COATI_RING_ROWS = 128 | 160 forces one (A/B switch).
@@ -523,6 +715,11 @@ int launch_gemm_ring256(const GemmArgs& a, int epi, hipStream_t s) {
   // more than one round of 160-row blocks, at most 224 rows per CU: the one-round kernel (COATI_RING_ROWS = 224 forces it for
   // smaller M too; any other value switches it off)
   const int R = cdiv(cdiv(a.M, 256), 8) * 8;
+  // 57 345 .. 65 536 rows (spans of 225 .. 256 rows): the 8-wave form with 64 x 128 wave tiles.  Its time hardly depends on the rows
+  // (K = 1024, bf16 out: 39.4 / 38.8 / 39.2 us at 40 960 / 50 000 / 65 536 rows: two waves per SIMD leave the per-stage latency
+  // exposed), so it only pays where the alternative is two rounds of 128-row blocks (65 536 rows: 42.6 us) -- at 50 000 rows the
+  // 14-wave kernel below takes 33.8
+  if (R <= R2W_BR && (force ? force == 256 : R > R1_BR)) return epi == EPI_RES_F32 ? launch_ring1w_t<EPI_RES_F32>(a, R, s) : launch_ring1w_t<EPI_BF16>(a, R, s);
   if (R <= R1_BR && (force ? force == 224 : a.M > 256 * 160))
     return epi == EPI_RES_F32 ? launch_ring1_t<EPI_RES_F32>(a, R, s) : launch_ring1_t<EPI_BF16>(a, R, s);
   const long long busiest160 = (long long)cdiv(cdiv(a.M, 160), 256) * 160, busiest128 = (long long)cdiv(cdiv(a.M, 128), 256) * 128;

@@ -29,7 +29,8 @@ def gelu(x):
 # the last three rows take the N = 256 ring kernel (bf16 / residual epilogues): full blocks, a ragged last block, K = 512
 @pytest.mark.parametrize("M,N,K", [(300, 192, 256), (128, 768, 64), (1000, 130, 128), (64, 64, 1024), (2000, 192, 256), (1411, 1024, 256), (40000, 256, 256), (33000, 768, 256), (50001, 320, 256),
                                    (40960, 256, 1024), (30011, 256, 768), (24000, 256, 512),
-                                   (50003, 256, 1024), (45000, 256, 256), (57344, 256, 512)])   # one-round ring kernel (spans of <= 224 rows, ragged last span)
+                                   (50003, 256, 1024), (45000, 256, 256), (57344, 256, 512),   # one-round ring kernel (spans of <= 224 rows, ragged last span)
+                                   (61003, 256, 768)])                                          # its 8-wave form (spans of <= 256 rows)
 def test_gemm_epilogues(ops, M, N, K):
     g = torch.Generator(device="cpu").manual_seed(M + N + K)
     A = rbf(torch.randn(M, K, generator=g)).to(DEV)
