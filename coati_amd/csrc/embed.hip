@@ -156,6 +156,21 @@ __global__ __launch_bounds__(256) void scatter_rows_add_kernel(const float* __re
   }
 }
 
+// dst[(row of sequence b at position pos[b])] = src[b] (bf16 rows; dst was zeroed by the caller)
+__global__ __launch_bounds__(256) void scatter_rows_bf16_kernel(const bf16_t* __restrict__ src, const int* __restrict__ pos,
+                                                                bf16_t* __restrict__ dst, int B, int T, int C, const int* __restrict__ off) {
+  const int lane = threadIdx.x & 63, b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;
+  bf16_t* d = dst + ((off ? (long long)off[b] : (long long)b * T) + pos[b]) * C;
+  for (int c = lane * 8; c < C; c += 512) *reinterpret_cast<uint4*>(d + c) = *reinterpret_cast<const uint4*>(src + (long long)b * C + c);
+}
+int launch_scatter_rows_bf16(const bf16_t* src, const int* pos, bf16_t* dst, int B, int T, int C, hipStream_t s, const int* off) {
+  COATI_CHECK_ARG(src && pos && dst && C % 8 == 0, "scatter_rows_bf16: null operand / C % 8");
+  hipLaunchKernelGGL(scatter_rows_bf16_kernel, dim3(cdiv(B, 4)), dim3(256), 0, s, src, pos, dst, B, T, C, off);
+  COATI_LAUNCH_CHECK("scatter_rows_bf16");
+  return COATI_OK;
+}
+
 int launch_scatter_rows_add(const float* dout, const int* pos, float* dx, int B, int T, int C, hipStream_t s, const int* off) {
   COATI_CHECK_ARG(dout && pos && dx, "scatter_rows_add: null operand");
   hipLaunchKernelGGL(scatter_rows_add_kernel, dim3(cdiv(B, 4)), dim3(256), 0, s, dout, pos, dx, B, T, C, off);

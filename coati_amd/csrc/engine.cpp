@@ -76,6 +76,13 @@ struct XPass {  // saved activations of one transformer pass
   std::vector<unsigned char*> hpre;   // NewGELU'(pre-activation) as 8-bit fixed point (common.h packq8)
   float *meanf, *rstdf, *xf32;
   bf16_t* af;
+  // Encoder pass of a training step: only the [STOP] row of every sequence leaves the transformer (smiles_xformer.py:50-68,
+  // clip_e2e.py:448-452), so everything behind the LAST layer's attention + c_proj -- ln_2, the MLP, the residual add and ln_f --
+  // runs on those B rows alone ("tail"); their backward likewise.  The rows' buffers:
+  bool tail = false;
+  float *t_xmid, *t_xL, *t_xf, *t_mean2, *t_rstd2, *t_meanf, *t_rstdf;   // [B, C] f32 / [B]
+  bf16_t *t_a2, *t_g;                                                   // [B, C], [B, 4C]
+  unsigned char* t_hpre;                                                // [B, 4C]
 };
 
 struct Arena {
@@ -161,6 +168,9 @@ struct coati_engine {
   int wtab_rr = 0;                                    // round-robin slot of the next table upload
   // E(3)-GNN node-level weight gradients as ONE split-table launch at the end of gnn_bwd: per-layer copies of the three
   // gradient operands the layers otherwise overwrite, the table (cached like d_wtab)
+  // backward of the encoder pass's [STOP]-row tail (XPass::tail)
+  float* t_dx = nullptr;                              // [B, C] f32 residual-stream gradient of the tail rows
+  bf16_t *t_dxa = nullptr, *t_dxb = nullptr, *t_dh4 = nullptr, *t_da = nullptr;   // [B, C], [B, C], [B, 4C], [B, C]
   bool gnn_wg_group = false;
   std::vector<bf16_t*> gl_DO16, gl_du, gl_dP;
   WgradTile* d_gtab = nullptr;
@@ -444,6 +454,10 @@ void carve_pass(coati_engine* e, Arena& ar, XPass& p, int B, int T) {
   p.meanf = ar.take<float>(M); p.rstdf = ar.take<float>(M);
   p.xf32 = ar.take<float>(M * C);
   p.af = ar.take<bf16_t>(M * C);
+  p.t_xmid = ar.take<float>((size_t)B * C); p.t_xL = ar.take<float>((size_t)B * C); p.t_xf = ar.take<float>((size_t)B * C);
+  p.t_mean2 = ar.take<float>(B); p.t_rstd2 = ar.take<float>(B); p.t_meanf = ar.take<float>(B); p.t_rstdf = ar.take<float>(B);
+  p.t_a2 = ar.take<bf16_t>((size_t)B * C); p.t_g = ar.take<bf16_t>((size_t)B * 4 * C); p.t_hpre = ar.take<unsigned char>((size_t)B * 4 * C);
+  p.tail = false;
   p.packed = false;
   p.off = ar.take<int>((size_t)B + 1); p.row_src = ar.take<int>(M); p.row_t = ar.take<int>(M); p.ypk = ar.take<long long>(M);
 }
@@ -503,6 +517,8 @@ size_t carve(coati_engine* e, Arena& ar, int B, int T1, int T2, int A, int Bg) {
   e->g_do2 = ar.take<bf16_t>(BA * H); e->g_dtd = ar.take<bf16_t>(BA * H); e->g_du = ar.take<bf16_t>(BA * H);
   e->g_dmi = ar.take<bf16_t>(BA * H); e->g_ds2 = ar.take<bf16_t>(Me * H); e->g_dpre1 = ar.take<bf16_t>(Me * H);
   e->g_dP = ar.take<bf16_t>(BA * 2 * H);
+  e->t_dx = ar.take<float>((size_t)B * C); e->t_dxa = ar.take<bf16_t>((size_t)B * C); e->t_dxb = ar.take<bf16_t>((size_t)B * C);
+  e->t_dh4 = ar.take<bf16_t>((size_t)B * 4 * C); e->t_da = ar.take<bf16_t>((size_t)B * C);
   // deferred weight gradients: 9C bf16 per token and layer (6 GB at B*T = 81,920, L = 16: 288 GB of HBM make this free)
   {
     static const bool off = getenv("COATI_WGRAD_GROUP") != nullptr && atoi(getenv("COATI_WGRAD_GROUP")) == 0;   // A/B switch
@@ -632,6 +648,19 @@ int xformer_fwd(coati_engine* e, XPass& p, const float* injection, hipStream_t s
       COATI_TRY(launch_attn_fwd(p.qkv[l], p.y[l], p.lse[l], p.B, p.T, c.n_head, C / c.n_head, s, p.packed ? p.off : nullptr));
     }
     COATI_TRY(gemm(e, SITE_PROJ_FWD, p.y[l], 0, C, e->S + w.projw, C, M, C, C, p.xmid[l], C, e->P + w.projb, EPI_RES_F32, p.x[l], nullptr, C, s));
+    if (p.tail && l == L - 1) {
+      // the [STOP] rows alone from here on: gather, ln_2, MLP + residual, ln_f (B rows instead of M)
+      const int B = p.B;
+      COATI_TRY(launch_gather_rows(p.xmid[l], e->stop_pos, p.t_xmid, B, p.T, C, s, p.packed ? p.off : nullptr));
+      {
+        ProfScope ps(e, SITE_LN_FWD, 0, s, (double)B * C * 6 + (double)B * 8);
+        COATI_TRY(launch_layernorm_fwd(p.t_xmid, C, e->P + w.ln2w, e->P + w.ln2b, p.t_a2, C, nullptr, 0, p.t_mean2, p.t_rstd2, B, C, s));
+      }
+      COATI_TRY(gemm(e, SITE_FC1_FWD, p.t_a2, 0, C, e->S + w.fc1w, C, B, 4 * C, C, p.t_g, 4 * C, e->P + w.fc1b, EPI_GELU_GRAD, nullptr, p.t_hpre, 4 * C, s));
+      COATI_TRY(gemm(e, SITE_FC2_FWD, p.t_g, 0, 4 * C, e->S + w.fc2w, 4 * C, B, C, 4 * C, p.t_xL, C, e->P + w.fc2b, EPI_RES_F32, p.t_xmid, nullptr, C, s));
+      ProfScope ps(e, SITE_LN_FWD, 0, s, (double)B * C * 8 + (double)B * 8);
+      return launch_layernorm_fwd(p.t_xL, C, e->P + e->lnfw, e->P + e->lnfb, nullptr, 0, p.t_xf, C, p.t_meanf, p.t_rstdf, B, C, s);
+    }
     {
       // hpre holds NewGELU'(pre-activation), not the pre-activation: the backward multiplies instead of re-evaluating the
       // sigmoid (the activation epilogues are VALU-bound: 2 quarter-rate transcendentals per element).  ln_2 is fused into
@@ -662,7 +691,7 @@ int xformer_wgrad_group(coati_engine* e, XPass& p, int l_lo, int l_hi, hipStream
   // the table is built for the padded row count of the pass (it only fixes operand addresses and tile indices); the rows a
   // launch really streams (fewer with packed rows, different every batch) are a kernel argument
   const int C = e->cfg.n_hidden_xformer, M = p.M, Mtab = p.B * p.T;
-  const long long sig = (((long long)e->B * 1000003 + e->T1) * 1000003 + e->T2) * 1000003 + e->A;
+  const long long sig = ((((long long)e->B * 1000003 + e->T1) * 1000003 + e->T2) * 1000003 + e->A) * 2 + (p.tail ? 1 : 0);
   int slot = -1;
   for (int i = 0; i < 4; ++i)
     if (e->wtab_key[i].pass == &p && e->wtab_key[i].lo == l_lo && e->wtab_key[i].hi == l_hi && e->wtab_key[i].M == Mtab && e->wtab_key[i].sig == sig) slot = i;
@@ -682,6 +711,7 @@ int xformer_wgrad_group(coati_engine* e, XPass& p, int l_lo, int l_hi, hipStream
       const XLayerP& w = e->xl[l];
       COATI_TRY(add(e->w_dqkv[l], 3 * C, p.a1[l], C, 3 * C, C, w.attnw, w.attnb));
       COATI_TRY(add(e->w_dxb[l], C, p.y[l], C, C, C, w.projw, w.projb));
+      if (p.tail && l == e->cfg.n_layer_xformer - 1) continue;   // the tail layer's MLP ran on the [STOP] rows only: its two gradients are small launches in xformer_bwd
       COATI_TRY(add(e->w_dh4[l], 4 * C, p.a2[l], C, 4 * C, C, w.fc1w, w.fc1b));
       COATI_TRY(add(e->w_dxa[l], C, p.g[l], 4 * C, C, 4 * C, w.fc2w, w.fc2b));
     }
@@ -724,7 +754,11 @@ int xformer_bwd(coati_engine* e, XPass& p, const void* dyf, int dyf_f32, float* 
   // Weight gradients: immediately, one launch per Linear (small shapes), or deferred to ONE grouped launch at the end of
   // this call (grouped = every activation gradient of the layer range stays alive in its own buffer).
   const bool grp = e->wg_group && M >= 4096;
-  if (l_hi == L) {
+  if (l_hi == L && p.tail) {
+    // ln_f backward on the B tail rows (dyf = [B, C]); not deferred: its partial sums have their own row count
+    ProfScope ps(e, SITE_LN_BWD, 0, s, (double)p.B * C * ((dyf_f32 ? 4 : 2) + 4 + 4 + 2));
+    COATI_TRY(launch_layernorm_bwd(dyf, dyf_f32, C, p.t_xL, C, 0, p.t_meanf, p.t_rstdf, e->P + e->lnfw, nullptr, e->t_dx, e->t_dxa, e->G + e->lnfw, e->G + e->lnfb, e->ln_partial, p.B, C, s));
+  } else if (l_hi == L) {
     ProfScope ps(e, SITE_LN_BWD, 0, s, (double)M * C * ((dyf_f32 ? 4 : 2) + 4 + 4 + 2));
     COATI_TRY(ln_bwd(dyf, dyf_f32, p.x[L], p.meanf, p.rstdf, e->P + e->lnfw, nullptr, e->lnfw, e->lnfb, grp ? e->w_dxa[L - 1] : e->DX16));
   }
@@ -735,28 +769,49 @@ int xformer_bwd(coati_engine* e, XPass& p, const void* dyf, int dyf_f32, float* 
     bf16_t* const dh4 = grp ? e->w_dh4[l] : e->dh4;
     bf16_t* const dqkv = grp ? e->w_dqkv[l] : e->dqkv;
     bf16_t* const dx_out = grp ? (l > 0 ? e->w_dxa[l - 1] : e->DX16) : e->DX16;   // d x[l] for the layer below
-    // x[l+1] = xmid + g W2^T + b2
-    if (c.use_fp8) {   // input gradients on MXFP8: the gradient rows are quantised like the activations (e4m3, block of 32 along k)
-      GemmArgs a;
-      memset(&a, 0, sizeof(a));
-      a.C = dh4; a.ldc = 4 * C; a.aux_in = p.hpre[l]; a.ld_aux = 4 * C;
-      COATI_TRY(gemm8(e, SITE_FC2_DGRAD, w, 7, dxa, C, M, 4 * C, C, a, EPI_MUL_AUX, s, true));   // + d hidden as MXFP8 for the FC1 input gradient
-      memset(&a, 0, sizeof(a));
-      a.C = e->da; a.ldc = C;
-      COATI_TRY(gemm8(e, SITE_FC1_DGRAD, w, 6, nullptr, 4 * C, M, C, 4 * C, a, EPI_BF16, s));
+    if (p.tail && l == L - 1) {
+      // the last layer's MLP and ln_2 exist on the B [STOP] rows only (XPass::tail): their backward on those rows, the two weight
+      // gradients as small launches of their own (the grouped table leaves them out), then the residual-stream gradient is
+      // spread back over the M rows -- zero everywhere else -- for the attention half of the layer
+      const int Bt = p.B;
+      COATI_TRY(gemm(e, SITE_FC2_DGRAD, e->t_dxa, 0, C, e->S + w.fc2T, C, Bt, 4 * C, C, e->t_dh4, 4 * C, nullptr, EPI_MUL_AUX, p.t_hpre, nullptr, 4 * C, s));
+      COATI_TRY(gemm(e, SITE_FC1_DGRAD, e->t_dh4, 0, 4 * C, e->S + w.fc1T, 4 * C, Bt, C, 4 * C, e->t_da, C, nullptr, EPI_BF16, nullptr, nullptr, 0, s));
+      COATI_TRY(wgrad(e, SITE_XF_WGRAD, e->t_dh4, 0, 4 * C, p.t_a2, C, Bt, 4 * C, C, e->G + w.fc1w, C, e->G + w.fc1b, 0, s));
+      COATI_TRY(wgrad(e, SITE_XF_WGRAD, e->t_dxa, 0, C, p.t_g, 4 * C, Bt, C, 4 * C, e->G + w.fc2w, 4 * C, e->G + w.fc2b, 0, s));
+      {
+        ProfScope ps(e, SITE_LN_BWD, 0, s, (double)Bt * C * (2 + 4 + 4 + 4 + 2));
+        COATI_TRY(launch_layernorm_bwd(e->t_da, 0, C, p.t_xmid, C, 0, p.t_mean2, p.t_rstd2, e->P + w.ln2w, e->t_dx, e->t_dx, e->t_dxb, e->G + w.ln2w, e->G + w.ln2b, e->ln_partial, Bt, C, s));
+        if (hipMemsetAsync(DX, 0, (size_t)M * C * sizeof(float), s) != hipSuccess || hipMemsetAsync(dxb, 0, (size_t)M * C * sizeof(bf16_t), s) != hipSuccess) {
+          coati_set_error("xformer_bwd: hipMemsetAsync failed");
+          return COATI_EHIP;
+        }
+        COATI_TRY(launch_scatter_rows_add(e->t_dx, e->stop_pos, DX, Bt, p.T, C, s, p.packed ? p.off : nullptr));
+        COATI_TRY(launch_scatter_rows_bf16(e->t_dxb, e->stop_pos, dxb, Bt, p.T, C, s, p.packed ? p.off : nullptr));
+      }
     } else {
-    COATI_TRY(gemm(e, SITE_FC2_DGRAD, dxa, 0, C, e->S + w.fc2T, C, M, 4 * C, C, dh4, 4 * C, nullptr, EPI_MUL_AUX, p.hpre[l], nullptr, 4 * C, s));
-    // hpre = a2 W1^T + b1
-    COATI_TRY(gemm(e, SITE_FC1_DGRAD, dh4, 0, 4 * C, e->S + w.fc1T, 4 * C, M, C, 4 * C, e->da, C, nullptr, EPI_BF16, nullptr, nullptr, 0, s));
-    }
-    if (!grp) {
-      COATI_TRY(wgrad(e, SITE_XF_WGRAD, dh4, 0, 4 * C, p.a2[l], C, M, 4 * C, C, e->G + w.fc1w, C, e->G + w.fc1b, 0, s));
-      // (the fc2 weight gradient runs after the two consumers of dh4, so that dh4 is re-read while it is still warm)
-      COATI_TRY(wgrad(e, SITE_XF_WGRAD, dxa, 0, C, p.g[l], 4 * C, M, C, 4 * C, e->G + w.fc2w, 4 * C, e->G + w.fc2b, 0, s));
-    }
-    {
-      ProfScope ps(e, SITE_LN_BWD, 0, s, (double)M * C * (2 + 4 + 4 + 4 + 2));   // dy16, x, dres in; dx, dx16 out
-      COATI_TRY(ln_bwd(e->da, 0, p.xmid[l], p.mean2[l], p.rstd2[l], e->P + w.ln2w, DX, w.ln2w, w.ln2b, dxb));
+      // x[l+1] = xmid + g W2^T + b2
+      if (c.use_fp8) {   // input gradients on MXFP8: the gradient rows are quantised like the activations (e4m3, block of 32 along k)
+        GemmArgs a;
+        memset(&a, 0, sizeof(a));
+        a.C = dh4; a.ldc = 4 * C; a.aux_in = p.hpre[l]; a.ld_aux = 4 * C;
+        COATI_TRY(gemm8(e, SITE_FC2_DGRAD, w, 7, dxa, C, M, 4 * C, C, a, EPI_MUL_AUX, s, true));   // + d hidden as MXFP8 for the FC1 input gradient
+        memset(&a, 0, sizeof(a));
+        a.C = e->da; a.ldc = C;
+        COATI_TRY(gemm8(e, SITE_FC1_DGRAD, w, 6, nullptr, 4 * C, M, C, 4 * C, a, EPI_BF16, s));
+      } else {
+      COATI_TRY(gemm(e, SITE_FC2_DGRAD, dxa, 0, C, e->S + w.fc2T, C, M, 4 * C, C, dh4, 4 * C, nullptr, EPI_MUL_AUX, p.hpre[l], nullptr, 4 * C, s));
+      // hpre = a2 W1^T + b1
+      COATI_TRY(gemm(e, SITE_FC1_DGRAD, dh4, 0, 4 * C, e->S + w.fc1T, 4 * C, M, C, 4 * C, e->da, C, nullptr, EPI_BF16, nullptr, nullptr, 0, s));
+      }
+      if (!grp) {
+        COATI_TRY(wgrad(e, SITE_XF_WGRAD, dh4, 0, 4 * C, p.a2[l], C, M, 4 * C, C, e->G + w.fc1w, C, e->G + w.fc1b, 0, s));
+        // (the fc2 weight gradient runs after the two consumers of dh4, so that dh4 is re-read while it is still warm)
+        COATI_TRY(wgrad(e, SITE_XF_WGRAD, dxa, 0, C, p.g[l], 4 * C, M, C, 4 * C, e->G + w.fc2w, 4 * C, e->G + w.fc2b, 0, s));
+      }
+      {
+        ProfScope ps(e, SITE_LN_BWD, 0, s, (double)M * C * (2 + 4 + 4 + 4 + 2));   // dy16, x, dres in; dx, dx16 out
+        COATI_TRY(ln_bwd(e->da, 0, p.xmid[l], p.mean2[l], p.rstd2[l], e->P + w.ln2w, DX, w.ln2w, w.ln2b, dxb));
+      }
     }
     // xmid = x[l] + y Wp^T + bp
     if (c.use_fp8) {
@@ -1156,13 +1211,20 @@ int coati_engine_forward(coati_engine* e, void* workspace, int64_t workspace_byt
     COATI_TRY(gnn_fwd(e, e->atoms, coords, s));
   }
   // ---- encoder pass (clip_e2e.py:448-452) ----
+  // (the [STOP] positions first: a training step runs the tail of the last layer on those rows only, XPass::tail)
+  COATI_TRY(launch_find_stop(e->p1.idx, c.stop_token, e->stop_pos, e->err_flag, B, T1, s));
+  {
+    static const bool no_tail = getenv("COATI_NO_TAIL") != nullptr;   // A/B switch: every row through the whole last layer and ln_f
+    e->p1.tail = train && !no_tail && !c.use_fp8;
+    e->p2.tail = false;
+  }
   COATI_TRY(xformer_fwd(e, e->p1, nullptr, s));
   if (ovl) COATI_TRY(join_side(e, s));
   COATI_TRY(launch_layernorm_fwd(e->hpoint, H, e->P + e->p2c_lnw, e->P + e->p2c_lnb, nullptr, 0, e->hp_ln, H, e->hp_mean, e->hp_rstd, B, H, s));
   COATI_TRY(launch_sgemm(e->hp_ln, H, 1, e->P + e->p2c_w, 1, H, e->h_e3gnn, E, B, E, H, e->P + e->p2c_b, 1.f, 0, s));
   // ---- smiles_to_clip ----
-  COATI_TRY(launch_find_stop(e->p1.idx, c.stop_token, e->stop_pos, e->err_flag, B, T1, s));
-  COATI_TRY(launch_gather_rows(e->p1.xf32, e->stop_pos, e->hstop, B, T1, C, s, e->p1.packed ? e->p1.off : nullptr));
+  if (e->p1.tail) HIPCHK(hipMemcpyAsync(e->hstop, e->p1.t_xf, (size_t)B * C * sizeof(float), hipMemcpyDeviceToDevice, s));
+  else COATI_TRY(launch_gather_rows(e->p1.xf32, e->stop_pos, e->hstop, B, T1, C, s, e->p1.packed ? e->p1.off : nullptr));
   COATI_TRY(launch_layernorm_fwd(e->hstop, C, e->P + e->s2c_lnw, e->P + e->s2c_lnb, nullptr, 0, e->hs_ln, C, e->hs_mean, e->hs_rstd, B, C, s));
   COATI_TRY(launch_sgemm(e->hs_ln, C, 1, e->P + e->s2c_w, 1, C, e->h_smiles, E, B, E, C, e->P + e->s2c_b, 1.f, 0, s));
   // ---- special token (clip_e2e.py:800-808) ----
@@ -1334,11 +1396,15 @@ int coati_engine_backward(coati_engine* e, const float* dh_smiles, const float* 
   }
   if (stage == 0 || stage == 2 || stage == 4) {
     // ---- encoder pass: gradient enters at the [STOP] rows of ln_f's output ----
-    float* dxf = reinterpret_cast<float*>(e->dh4);  // [M1, C] f32 scratch (dh4 is idle here: 4C bf16 >= C f32)
-    HIPCHK(hipMemsetAsync(dxf, 0, (size_t)e->p1.M * C * sizeof(float), s));
-    COATI_TRY(launch_scatter_rows_add(e->dhstop, e->stop_pos, dxf, B, e->T1, C, s, e->p1.packed ? e->p1.off : nullptr));
-    // xformer_bwd consumes dyf in its first kernel (ln_f backward) before dh4 is rewritten
-    COATI_TRY(xformer_bwd(e, e->p1, dxf, 1, nullptr, s, Lx, stage == 4 ? Lmid : 0));
+    if (e->p1.tail) {   // the gradient of the B [STOP] rows goes in as it is
+      COATI_TRY(xformer_bwd(e, e->p1, e->dhstop, 1, nullptr, s, Lx, stage == 4 ? Lmid : 0));
+    } else {
+      float* dxf = reinterpret_cast<float*>(e->dh4);  // [M1, C] f32 scratch (dh4 is idle here: 4C bf16 >= C f32)
+      HIPCHK(hipMemsetAsync(dxf, 0, (size_t)e->p1.M * C * sizeof(float), s));
+      COATI_TRY(launch_scatter_rows_add(e->dhstop, e->stop_pos, dxf, B, e->T1, C, s, e->p1.packed ? e->p1.off : nullptr));
+      // xformer_bwd consumes dyf in its first kernel (ln_f backward) before dh4 is rewritten
+      COATI_TRY(xformer_bwd(e, e->p1, dxf, 1, nullptr, s, Lx, stage == 4 ? Lmid : 0));
+    }
   }
   if (stage == 5) COATI_TRY(xformer_bwd(e, e->p1, nullptr, 1, nullptr, s, Lmid, 0));
   if (ovl_bwd && stage == 4) {

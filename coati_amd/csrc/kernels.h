@@ -201,6 +201,7 @@ int launch_find_stop(const long long* idx, int stop_token, int* pos, int* err, i
 int launch_gather_rows(const float* x, const int* pos, float* out, int B, int T, int C, hipStream_t s, const int* off = nullptr);
 // dx[b, pos[b], :] += dout[b, :]
 int launch_scatter_rows_add(const float* dout, const int* pos, float* dx, int B, int T, int C, hipStream_t s, const int* off = nullptr);
+int launch_scatter_rows_bf16(const bf16_t* src, const int* pos, bf16_t* dst, int B, int T, int C, hipStream_t s, const int* off = nullptr);
 // bad[b] = sum_t tokens[b,t] < 1
 int launch_bad_rows(const long long* tokens, unsigned char* bad, int B, int T, hipStream_t s);
 // inference decode (decode.hip)
