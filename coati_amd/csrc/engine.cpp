@@ -42,12 +42,12 @@ enum Site {
   SITE_QKV_FWD = 0, SITE_PROJ_FWD, SITE_FC1_FWD, SITE_FC2_FWD, SITE_ATTN_FWD, SITE_LN_FWD, SITE_LMHEAD_FWD,
   SITE_FC2_DGRAD, SITE_FC1_DGRAD, SITE_PROJ_DGRAD, SITE_QKV_DGRAD, SITE_XF_WGRAD, SITE_ATTN_BWD, SITE_LN_BWD,
   SITE_LMHEAD_DLOGITS, SITE_LMHEAD_DGRAD, SITE_LMHEAD_WGRAD, SITE_GNN_EDGE_GEMM, SITE_GNN_NODE_GEMM,
-  SITE_GNN_WGRAD, SITE_GNN_ELEMWISE, SITE_EMBED, SITE_OPTIM, SITE_COUNT
+  SITE_GNN_WGRAD, SITE_GNN_ELEMWISE, SITE_EMBED, SITE_OPTIM, SITE_XF_TAIL, SITE_COUNT
 };
 const char* kSiteNames[SITE_COUNT] = {
     "qkv_fwd", "proj_fwd", "fc1_fwd", "fc2_fwd", "attn_fwd", "ln_fwd", "lmhead_fwd", "fc2_dgrad", "fc1_dgrad",
     "proj_dgrad", "qkv_dgrad", "xf_wgrad", "attn_bwd", "ln_bwd", "lmhead_dlogits", "lmhead_dgrad", "lmhead_wgrad",
-    "gnn_edge_gemm", "gnn_node_gemm", "gnn_wgrad", "gnn_elemwise", "embed", "optim"};
+    "gnn_edge_gemm", "gnn_node_gemm", "gnn_wgrad", "gnn_elemwise", "embed", "optim", "xf_tail"};   // xf_tail: the [STOP]-row tail of the encoder pass (B-row launches)
 
 struct XLayerP {  // offsets into the flat parameter buffer
   int64_t ln1w, ln1b, attnw, attnb, projw, projb, ln2w, ln2b, fc1w, fc1b, fc2w, fc2b;
@@ -653,12 +653,12 @@ int xformer_fwd(coati_engine* e, XPass& p, const float* injection, hipStream_t s
       const int B = p.B;
       COATI_TRY(launch_gather_rows(p.xmid[l], e->stop_pos, p.t_xmid, B, p.T, C, s, p.packed ? p.off : nullptr));
       {
-        ProfScope ps(e, SITE_LN_FWD, 0, s, (double)B * C * 6 + (double)B * 8);
+        ProfScope ps(e, SITE_XF_TAIL, 0, s, (double)B * C * 6 + (double)B * 8);
         COATI_TRY(launch_layernorm_fwd(p.t_xmid, C, e->P + w.ln2w, e->P + w.ln2b, p.t_a2, C, nullptr, 0, p.t_mean2, p.t_rstd2, B, C, s));
       }
-      COATI_TRY(gemm(e, SITE_FC1_FWD, p.t_a2, 0, C, e->S + w.fc1w, C, B, 4 * C, C, p.t_g, 4 * C, e->P + w.fc1b, EPI_GELU_GRAD, nullptr, p.t_hpre, 4 * C, s));
-      COATI_TRY(gemm(e, SITE_FC2_FWD, p.t_g, 0, 4 * C, e->S + w.fc2w, 4 * C, B, C, 4 * C, p.t_xL, C, e->P + w.fc2b, EPI_RES_F32, p.t_xmid, nullptr, C, s));
-      ProfScope ps(e, SITE_LN_FWD, 0, s, (double)B * C * 8 + (double)B * 8);
+      COATI_TRY(gemm(e, SITE_XF_TAIL, p.t_a2, 0, C, e->S + w.fc1w, C, B, 4 * C, C, p.t_g, 4 * C, e->P + w.fc1b, EPI_GELU_GRAD, nullptr, p.t_hpre, 4 * C, s));
+      COATI_TRY(gemm(e, SITE_XF_TAIL, p.t_g, 0, 4 * C, e->S + w.fc2w, 4 * C, B, C, 4 * C, p.t_xL, C, e->P + w.fc2b, EPI_RES_F32, p.t_xmid, nullptr, C, s));
+      ProfScope ps(e, SITE_XF_TAIL, 0, s, (double)B * C * 8 + (double)B * 8);
       return launch_layernorm_fwd(p.t_xL, C, e->P + e->lnfw, e->P + e->lnfb, nullptr, 0, p.t_xf, C, p.t_meanf, p.t_rstdf, B, C, s);
     }
     {
@@ -756,7 +756,7 @@ int xformer_bwd(coati_engine* e, XPass& p, const void* dyf, int dyf_f32, float* 
   const bool grp = e->wg_group && M >= 4096;
   if (l_hi == L && p.tail) {
     // ln_f backward on the B tail rows (dyf = [B, C]); not deferred: its partial sums have their own row count
-    ProfScope ps(e, SITE_LN_BWD, 0, s, (double)p.B * C * ((dyf_f32 ? 4 : 2) + 4 + 4 + 2));
+    ProfScope ps(e, SITE_XF_TAIL, 0, s, (double)p.B * C * ((dyf_f32 ? 4 : 2) + 4 + 4 + 2));
     COATI_TRY(launch_layernorm_bwd(dyf, dyf_f32, C, p.t_xL, C, 0, p.t_meanf, p.t_rstdf, e->P + e->lnfw, nullptr, e->t_dx, e->t_dxa, e->G + e->lnfw, e->G + e->lnfb, e->ln_partial, p.B, C, s));
   } else if (l_hi == L) {
     ProfScope ps(e, SITE_LN_BWD, 0, s, (double)M * C * ((dyf_f32 ? 4 : 2) + 4 + 4 + 2));
@@ -774,12 +774,12 @@ int xformer_bwd(coati_engine* e, XPass& p, const void* dyf, int dyf_f32, float* 
       // gradients as small launches of their own (the grouped table leaves them out), then the residual-stream gradient is
       // spread back over the M rows -- zero everywhere else -- for the attention half of the layer
       const int Bt = p.B;
-      COATI_TRY(gemm(e, SITE_FC2_DGRAD, e->t_dxa, 0, C, e->S + w.fc2T, C, Bt, 4 * C, C, e->t_dh4, 4 * C, nullptr, EPI_MUL_AUX, p.t_hpre, nullptr, 4 * C, s));
-      COATI_TRY(gemm(e, SITE_FC1_DGRAD, e->t_dh4, 0, 4 * C, e->S + w.fc1T, 4 * C, Bt, C, 4 * C, e->t_da, C, nullptr, EPI_BF16, nullptr, nullptr, 0, s));
-      COATI_TRY(wgrad(e, SITE_XF_WGRAD, e->t_dh4, 0, 4 * C, p.t_a2, C, Bt, 4 * C, C, e->G + w.fc1w, C, e->G + w.fc1b, 0, s));
-      COATI_TRY(wgrad(e, SITE_XF_WGRAD, e->t_dxa, 0, C, p.t_g, 4 * C, Bt, C, 4 * C, e->G + w.fc2w, 4 * C, e->G + w.fc2b, 0, s));
+      COATI_TRY(gemm(e, SITE_XF_TAIL, e->t_dxa, 0, C, e->S + w.fc2T, C, Bt, 4 * C, C, e->t_dh4, 4 * C, nullptr, EPI_MUL_AUX, p.t_hpre, nullptr, 4 * C, s));
+      COATI_TRY(gemm(e, SITE_XF_TAIL, e->t_dh4, 0, 4 * C, e->S + w.fc1T, 4 * C, Bt, C, 4 * C, e->t_da, C, nullptr, EPI_BF16, nullptr, nullptr, 0, s));
+      COATI_TRY(wgrad(e, SITE_XF_TAIL, e->t_dh4, 0, 4 * C, p.t_a2, C, Bt, 4 * C, C, e->G + w.fc1w, C, e->G + w.fc1b, 0, s));
+      COATI_TRY(wgrad(e, SITE_XF_TAIL, e->t_dxa, 0, C, p.t_g, 4 * C, Bt, C, 4 * C, e->G + w.fc2w, 4 * C, e->G + w.fc2b, 0, s));
       {
-        ProfScope ps(e, SITE_LN_BWD, 0, s, (double)Bt * C * (2 + 4 + 4 + 4 + 2));
+        ProfScope ps(e, SITE_XF_TAIL, 0, s, (double)Bt * C * (2 + 4 + 4 + 4 + 2));
         COATI_TRY(launch_layernorm_bwd(e->t_da, 0, C, p.t_xmid, C, 0, p.t_mean2, p.t_rstd2, e->P + w.ln2w, e->t_dx, e->t_dx, e->t_dxb, e->G + w.ln2w, e->G + w.ln2b, e->ln_partial, Bt, C, s));
         if (hipMemsetAsync(DX, 0, (size_t)M * C * sizeof(float), s) != hipSuccess || hipMemsetAsync(dxb, 0, (size_t)M * C * sizeof(bf16_t), s) != hipSuccess) {
           coati_set_error("xformer_bwd: hipMemsetAsync failed");
