@@ -191,4 +191,4 @@ def test_stop_row_tail_equals_full_last_layer(tmp_path):
     worst = sorted(((float((a["grads"][k] - b["grads"][k]).abs().max()) / max(float(b["grads"][k].abs().max()), 1e-30), k)
                     for k in b["grads"] if float(b["grads"][k].abs().max()) > 0), reverse=True)
     log(f"tail vs full last layer: losses {a['losses']} / {b['losses']}; worst gradient deviations {worst[:3]}")
-    assert worst[0][0] <= 5e-6, worst[:5]      # measured 1.4e-6 (fp32 atomics order)
+    assert worst[0][0] <= 1e-5, worst[:5]      # measured 1.4e-6 .. 3e-6 over runs (fp32 atomics in arrival order)
