@@ -40,6 +40,20 @@ def build(force=False, verbose=True):
         return LIB
     os.makedirs(LIBDIR, exist_ok=True)
     os.makedirs(OBJDIR, exist_ok=True)
+    # several ranks of one node import the package at the same time (torch.distributed.run): one of them builds, the others
+    # wait on the lock and then find the library up to date
+    import fcntl
+    with open(os.path.join(LIBDIR, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not needs_build():
+                return LIB
+            return _build_locked(verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(verbose):
     hipcc = _hipcc()
 
     def compile_one(unit):
