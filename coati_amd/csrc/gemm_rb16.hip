@@ -5,7 +5,7 @@
 // the same 5 k cycles per tile with 2 waves per SIMD as with 3).  A wave's own MFMAs and VALU work do not overlap, other waves'
 // do (tools/probes/overlap_probe.hip): the kernel lacks waves, not issue slots.  Here a wave owns 16 rows on
 // v_mfma_f32_16x16x32_bf16: half the A slab (32 VGPRs), a quarter of the accumulators (16), half the epilogue per tile -- 128
-// VGPRs, 13-16 waves per workgroup, 4 waves per SIMD.  A packed batch brings ~200 rows per CU = 13 slabs: one workgroup per CU,
+// VGPRs, 9-16 waves per workgroup, up to 4 waves per SIMD.  A packed batch brings ~200 rows per CU = 13 slabs: one workgroup per CU,
 // one round.  Same structure otherwise: A-stationary slab in registers (LayerNorm evaluated inside the slab load for the QKV /
 // FC1 products, basic_transformer.py:165-173), 64-column weight tiles L2 -> LDS by global_load_lds, double-buffered, one
 // workgroup barrier per tile.  The product is issued TRANSPOSED (weight rows as the MFMA's row operand, the slab as its column
