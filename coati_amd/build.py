@@ -12,7 +12,9 @@ LIB = os.path.join(LIBDIR, "libcoati_hip.so")
 OBJDIR = os.path.join(HERE, "build")
 HIP_UNITS = ["gemm.hip", "gemm_rb.hip", "gemm_rb16.hip", "gemm_ring.hip", "gemm_mx8.hip", "norm.hip", "attention.hip", "embed.hip", "gnn.hip", "loss.hip", "optim.hip", "batch.hip", "decode.hip"]
 CPP_UNITS = ["engine.cpp", "capi.cpp", "tokenizer.cpp"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"] + os.environ.get("COATI_AMD_CXXFLAGS", "").split()   # (probe builds: -DCOATI_RB_TRACE)
+# -amdgpu-mfma-vgpr-form: MFMA results in VGPRs (gfx950 has one unified register file).  Where the compiler picked the AGPR form
+# (the attention forward kernels) 13 % of the instructions were v_accvgpr_read / write moves in a VALU-bound kernel
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-mllvm", "-amdgpu-mfma-vgpr-form=1"] + os.environ.get("COATI_AMD_CXXFLAGS", "").split()   # (probe builds: -DCOATI_RB_TRACE)
 
 
 def _hipcc():
