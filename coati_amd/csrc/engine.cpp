@@ -681,8 +681,10 @@ int xformer_fwd(coati_engine* e, XPass& p, const float* injection, hipStream_t s
     }
     COATI_TRY(gemm(e, SITE_FC2_FWD, p.g[l], 0, 4 * C, e->S + w.fc2w, 4 * C, M, C, 4 * C, p.x[l + 1], C, e->P + w.fc2b, EPI_RES_F32, p.xmid[l], nullptr, C, s));
   }
-  ProfScope ps(e, SITE_LN_FWD, 0, s, (double)M * C * 10 + (double)M * 8);
-  return launch_layernorm_fwd(p.x[L], C, e->P + e->lnfw, e->P + e->lnfb, p.af, C, p.xf32, C, p.meanf, p.rstdf, M, C, s);
+  // the f32 copy of ln_f's output is what the [STOP] rows are gathered from: encoder pass only (the decoder pass feeds lm_head: bf16)
+  float* const y32 = (&p == &e->p1) ? p.xf32 : nullptr;
+  ProfScope ps(e, SITE_LN_FWD, 0, s, (double)M * C * (y32 ? 8 : 6) + (double)M * 8);
+  return launch_layernorm_fwd(p.x[L], C, e->P + e->lnfw, e->P + e->lnfb, y32 ? nullptr : p.af, C, y32, C, p.meanf, p.rstdf, M, C, s);
 }
 
 // One launch for the 4 (l_hi - l_lo) weight gradients of a layer range (bias gradients included): the tile table is built
