@@ -770,7 +770,7 @@ int xformer_bwd(coati_engine* e, XPass& p, const void* dyf, int dyf_f32, float* 
     bf16_t* const dxb = grp ? e->w_dxb[l] : e->DX16;      // d xmid[l]
     bf16_t* const dh4 = grp ? e->w_dh4[l] : e->dh4;
     bf16_t* const dqkv = grp ? e->w_dqkv[l] : e->dqkv;
-    bf16_t* const dx_out = grp ? (l > 0 ? e->w_dxa[l - 1] : e->DX16) : e->DX16;   // d x[l] for the layer below
+    bf16_t* const dx_out = l == 0 ? nullptr : (grp ? e->w_dxa[l - 1] : e->DX16);   // d x[l] (bf16) for the layer below; below layer 0 the embedding backward reads the f32 stream
     if (p.tail && l == L - 1) {
       // the last layer's MLP and ln_2 exist on the B [STOP] rows only (XPass::tail): their backward on those rows, the two weight
       // gradients as small launches of their own (the grouped table leaves them out), then the residual-stream gradient is
