@@ -196,6 +196,7 @@ struct coati_engine {
   bool gnn_side_pending = false;   // stage 4 forked it; stage 5 joins
   // profiling
   int prof_site = -1;
+  bool prof_keep_overlap = false;   // timed-region profiling: events around the selected site, the step itself runs as the product does (side stream on)
   std::vector<hipEvent_t> ev;
   int ev_used = 0;
   double prof_flops = 0.0;
@@ -1205,7 +1206,7 @@ int coati_engine_forward(coati_engine* e, void* workspace, int64_t workspace_byt
   }
 
   // ---- point encoder (clip_e2e.py:454-461): on the side stream, concurrent with the encoder pass ----
-  const bool ovl = e->overlap && e->prof_site < 0;
+  const bool ovl = e->overlap && (e->prof_site < 0 || e->prof_keep_overlap);
   if (ovl) {
     COATI_TRY(fork_side(e, s));
     COATI_TRY(gnn_fwd(e, e->atoms, coords, e->side));
@@ -1389,7 +1390,7 @@ int coati_engine_backward(coati_engine* e, const float* dh_smiles, const float* 
   // stages 4 / 5 = the encoder stage in two halves (upper / lower half of the layers), so that the caller can start the
   // all-reduce of the upper layers' finished gradients underneath the lower half
   const int Lx = c.n_layer_xformer, Lmid = Lx / 2;
-  const bool ovl_bwd = (stage == 0 || stage == 2 || stage == 4) && e->overlap && e->prof_site < 0;
+  const bool ovl_bwd = (stage == 0 || stage == 2 || stage == 4) && e->overlap && (e->prof_site < 0 || e->prof_keep_overlap);
   if (stage == 0 || stage == 1) { e->gnn_bwd_done = false; e->gnn_side_pending = false; }
   if (ovl_bwd) {
     // the point-encoder backward only needs dhpoint (ready here) and writes its own gradient slice: side stream
@@ -1447,9 +1448,19 @@ int coati_engine_prof_select(coati_engine* e, int site) {
     }
   }
   e->prof_site = site;
+  e->prof_keep_overlap = false;
   e->ev_used = 0;
   e->prof_flops = 0.0;
   e->prof_bytes = 0.0;
+  return COATI_OK;
+}
+
+// keep != 0: the selected site is timed while the step runs exactly as the product runs it (point encoder on the side stream,
+// concurrent with the transformer passes); the default (0) serialises the point encoder onto the launch stream so that a
+// site's events bracket that site's kernels alone.  Reset by every prof_select.
+int coati_engine_prof_keep_overlap(coati_engine* e, int keep) {
+  COATI_CHECK_ARG(e, "prof_keep_overlap: null engine");
+  e->prof_keep_overlap = keep != 0;
   return COATI_OK;
 }
 

@@ -356,9 +356,14 @@ class Engine:
     def site_names(self):
         return [self.l.coati_engine_site_name(i).decode() for i in range(self.l.coati_engine_site_count())]
 
-    def prof_select(self, site):
+    def prof_select(self, site, keep_overlap=False):
+        """HIP events around every launch of `site` (-1: off).  keep_overlap: the step keeps running as the product runs it
+        (point encoder concurrent on the side stream) -- bench.py's timed region; default: the point encoder is serialised
+        so that a site's events bracket its kernels alone (the per-site table)."""
         idx = self.site_names().index(site) if isinstance(site, str) else site
         _lib.check(self.l.coati_engine_prof_select(self.h, idx), "prof_select")
+        if keep_overlap:
+            _lib.check(self.l.coati_engine_prof_keep_overlap(self.h, 1), "prof_keep_overlap")
 
     def prof_collect(self):
         ms, n, fl = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double()

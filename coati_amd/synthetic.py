@@ -20,14 +20,19 @@ def packed_rows(raw_tokens, tokens, y_next=None):
     """Host-side row counts of the packed layout (include/coati_hip.h, coati_engine_forward rows1 / rows2): per row
     1 + the last position that holds a non-[PAD] token (or, for `tokens`, a target that is not -1), summed over the batch.
     The batch assembler calls this while the tokens are still on the host; on device tensors it costs one synchronisation."""
-    def count(tok, y):
+    l1, l2 = packed_lengths(raw_tokens, tokens, y_next)
+    return int(l1.sum().item()), int(l2.sum().item())
+
+
+def packed_lengths(raw_tokens, tokens, y_next=None):
+    """Per-row lengths of the packed layout: [B] int32 for each of the two passes (their sums are packed_rows)."""
+    def length(tok, y):
         live = tok != PAD
         if y is not None:
             live = live | (y >= 0)
         T = tok.shape[1]
-        last = (live.to(torch.int32) * torch.arange(1, T + 1, device=tok.device, dtype=torch.int32)).amax(dim=1)
-        return int(last.sum().item())
-    return count(raw_tokens, None), count(tokens, y_next)
+        return (live.to(torch.int32) * torch.arange(1, T + 1, device=tok.device, dtype=torch.int32)).amax(dim=1)
+    return length(raw_tokens, None), length(tokens, y_next)
 
 
 def make_batch(B, T, A, V, seed=1234, n_special=1596, p_clip=0.9, p_bad=0.01, min_len=16, device="cpu", with_rows=False):

@@ -317,6 +317,9 @@ int coati_engine_optimizer_step(coati_engine* e, float lr, float beta1, float be
 
 /* per-site kernel timing with HIP events on the launch stream (bench.py roofline leg) */
 int coati_engine_prof_select(coati_engine* e, int site);              /* -1 disables */
+/* keep != 0: time the selected site while the step runs as the product runs it (point encoder concurrent on the side stream);
+ * 0 (default after every prof_select): the point encoder is serialised onto the launch stream, a site's events bracket its kernels alone */
+int coati_engine_prof_keep_overlap(coati_engine* e, int keep);
 int coati_engine_prof_collect(coati_engine* e, double* total_ms, int64_t* launches, double* flops_per_launch);
 /* algorithmic HBM bytes per launch (operands read once, results written once) of the site collected last */
 int coati_engine_prof_last_bytes(coati_engine* e, double* bytes_per_launch);
