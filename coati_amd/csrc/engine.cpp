@@ -260,41 +260,61 @@ void build_layout(coati_engine* e) {
   e->lnfw = add_entry(e, "xformer.transformer.ln_f.weight", C, 0);
   e->lnfb = add_entry(e, "xformer.transformer.ln_f.bias", C, 0);
   e->lmhead = add_entry(e, "xformer.lm_head.weight", V, C);
-  // --- point encoder (e3gnn_clip.py:75-104, e_gcl_sparse.py:130-150) ---
-  e->gembw = add_entry(e, "point_encoder.embedding.weight", H, 28);
-  e->gembb = add_entry(e, "point_encoder.embedding.bias", H, 0);
-  e->gd0w = add_entry(e, "point_encoder.node_dec.0.weight", H, H);
-  e->gd0b = add_entry(e, "point_encoder.node_dec.0.bias", H, 0);
-  e->gd3w = add_entry(e, "point_encoder.node_dec.3.weight", H, H);
-  e->gd3b = add_entry(e, "point_encoder.node_dec.3.bias", H, 0);
-  e->gl.resize(c.n_layer_e3gnn);
-  for (int l = 0; l < c.n_layer_e3gnn; ++l) {
-    const std::string p = "point_encoder.gcl_" + std::to_string(l) + ".";
-    GLayerP& g = e->gl[l];
-    g.e0w = add_entry(e, p + "edge_mlp.0.weight", H, 2 * H + 1);
-    g.e0b = add_entry(e, p + "edge_mlp.0.bias", H, 0);
-    g.e3w = add_entry(e, p + "edge_mlp.3.weight", H, H);
-    g.e3b = add_entry(e, p + "edge_mlp.3.bias", H, 0);
-    g.n0w = add_entry(e, p + "node_mlp.0.weight", H, 2 * H);
-    g.n0b = add_entry(e, p + "node_mlp.0.bias", H, 0);
-    g.n3w = add_entry(e, p + "node_mlp.3.weight", H, H);
-    g.n3b = add_entry(e, p + "node_mlp.3.bias", H, 0);
-  }
+  // --- point encoder (e3gnn_clip.py:75-104, e_gcl_sparse.py:130-150) + point_to_clip (clip_e2e.py:405-422) ---
+  auto add_point = [&]() {
+    e->gembw = add_entry(e, "point_encoder.embedding.weight", H, 28);
+    e->gembb = add_entry(e, "point_encoder.embedding.bias", H, 0);
+    e->gd0w = add_entry(e, "point_encoder.node_dec.0.weight", H, H);
+    e->gd0b = add_entry(e, "point_encoder.node_dec.0.bias", H, 0);
+    e->gd3w = add_entry(e, "point_encoder.node_dec.3.weight", H, H);
+    e->gd3b = add_entry(e, "point_encoder.node_dec.3.bias", H, 0);
+    e->gl.resize(c.n_layer_e3gnn);
+    for (int l = 0; l < c.n_layer_e3gnn; ++l) {
+      const std::string p = "point_encoder.gcl_" + std::to_string(l) + ".";
+      GLayerP& g = e->gl[l];
+      g.e0w = add_entry(e, p + "edge_mlp.0.weight", H, 2 * H + 1);
+      g.e0b = add_entry(e, p + "edge_mlp.0.bias", H, 0);
+      g.e3w = add_entry(e, p + "edge_mlp.3.weight", H, H);
+      g.e3b = add_entry(e, p + "edge_mlp.3.bias", H, 0);
+      g.n0w = add_entry(e, p + "node_mlp.0.weight", H, 2 * H);
+      g.n0b = add_entry(e, p + "node_mlp.0.bias", H, 0);
+      g.n3w = add_entry(e, p + "node_mlp.3.weight", H, H);
+      g.n3b = add_entry(e, p + "node_mlp.3.bias", H, 0);
+    }
+    // norm_clips: LayerNorm -> Linear (state_dict .0 / .1); otherwise a plain Linear (clip_e2e.py:405-428)
+    if (c.norm_clips) {
+      e->p2c_lnw = add_entry(e, "point_to_clip.0.weight", H, 0);
+      e->p2c_lnb = add_entry(e, "point_to_clip.0.bias", H, 0);
+      e->p2c_w = add_entry(e, "point_to_clip.1.weight", E, H);
+      e->p2c_b = add_entry(e, "point_to_clip.1.bias", E, 0);
+    } else {
+      e->p2c_w = add_entry(e, "point_to_clip.weight", E, H);
+      e->p2c_b = add_entry(e, "point_to_clip.bias", E, 0);
+    }
+  };
+  // use_point_encoder = False (clip_e2e.py:454-463): encode_points returns zeros, so the point encoder and point_to_clip never
+  // receive a gradient (p.grad is None: torch's clip_grad_norm_ / AdamW skip them).  Their parameters exist in the state_dict
+  // all the same: they go BEHIND n_trainable, next to coord_mlp
+  if (c.use_point_encoder) add_point();
   // --- heads (clip_e2e.py:419-435) ---
-  e->p2c_lnw = add_entry(e, "point_to_clip.0.weight", H, 0);
-  e->p2c_lnb = add_entry(e, "point_to_clip.0.bias", H, 0);
-  e->p2c_w = add_entry(e, "point_to_clip.1.weight", E, H);
-  e->p2c_b = add_entry(e, "point_to_clip.1.bias", E, 0);
-  e->s2c_lnw = add_entry(e, "smiles_to_clip.0.weight", E, 0);
-  e->s2c_lnb = add_entry(e, "smiles_to_clip.0.bias", E, 0);
-  e->s2c_w = add_entry(e, "smiles_to_clip.1.weight", E, C);
-  e->s2c_b = add_entry(e, "smiles_to_clip.1.bias", E, 0);
-  e->tokw = add_entry(e, "point_clip_to_special_tokens.1.weight", E, E);
-  e->tokb = add_entry(e, "point_clip_to_special_tokens.1.bias", E, 0);
+  if (c.norm_clips) {
+    e->s2c_lnw = add_entry(e, "smiles_to_clip.0.weight", E, 0);
+    e->s2c_lnb = add_entry(e, "smiles_to_clip.0.bias", E, 0);
+    e->s2c_w = add_entry(e, "smiles_to_clip.1.weight", E, C);
+    e->s2c_b = add_entry(e, "smiles_to_clip.1.bias", E, 0);
+  } else {
+    e->s2c_w = add_entry(e, "smiles_to_clip.weight", E, C);
+    e->s2c_b = add_entry(e, "smiles_to_clip.bias", E, 0);
+  }
+  if (c.token_mlp) {   // SiLU -> Linear; otherwise nn.Identity (no parameters)
+    e->tokw = add_entry(e, "point_clip_to_special_tokens.1.weight", E, E);
+    e->tokb = add_entry(e, "point_clip_to_special_tokens.1.bias", E, 0);
+  }
   // coord_mlp is evaluated and discarded by the reference (e3gnn_clip.py:132): its parameters never receive a gradient
   // (p.grad is None), so torch's clip_grad_norm_ / AdamW skip them entirely -- no weight decay either.  They are kept for
   // state_dict parity at the END of the flat buffers, behind n_trainable: the optimizer kernels stop in front of them.
   e->n_trainable = e->n_params;
+  if (!c.use_point_encoder) add_point();
   for (int l = 0; l < c.n_layer_e3gnn; ++l) {
     const std::string p = "point_encoder.gcl_" + std::to_string(l) + ".";
     GLayerP& g = e->gl[l];
@@ -1045,6 +1065,29 @@ int join_side(coati_engine* e, hipStream_t main) {
   return COATI_OK;
 }
 
+// point_to_clip / smiles_to_clip (clip_e2e.py:405-428): LayerNorm -> Linear (norm_clips) or a plain Linear, f32 on [B, *] rows
+int point_head_fwd(coati_engine* e, float* out, hipStream_t s) {
+  const coati_config& c = e->cfg;
+  const int H = c.n_hidden_e3nn, E = c.n_embd_common, B = e->B;
+  if (!c.use_point_encoder) return COATI_OK;   // zeros, written by the caller
+  const float* x = e->hpoint;
+  if (c.norm_clips) {
+    COATI_TRY(launch_layernorm_fwd(e->hpoint, H, e->P + e->p2c_lnw, e->P + e->p2c_lnb, nullptr, 0, e->hp_ln, H, e->hp_mean, e->hp_rstd, B, H, s));
+    x = e->hp_ln;
+  }
+  return launch_sgemm(x, H, 1, e->P + e->p2c_w, 1, H, out, E, B, E, H, e->P + e->p2c_b, 1.f, 0, s);
+}
+int smiles_head_fwd(coati_engine* e, float* out, hipStream_t s) {
+  const coati_config& c = e->cfg;
+  const int C = c.n_hidden_xformer, E = c.n_embd_common, B = e->B;
+  const float* x = e->hstop;
+  if (c.norm_clips) {
+    COATI_TRY(launch_layernorm_fwd(e->hstop, C, e->P + e->s2c_lnw, e->P + e->s2c_lnb, nullptr, 0, e->hs_ln, C, e->hs_mean, e->hs_rstd, B, C, s));
+    x = e->hs_ln;
+  }
+  return launch_sgemm(x, C, 1, e->P + e->s2c_w, 1, C, out, E, B, E, C, e->P + e->s2c_b, 1.f, 0, s);
+}
+
 }  // namespace
 
 // =====================================================================================================
@@ -1206,8 +1249,11 @@ int coati_engine_forward(coati_engine* e, void* workspace, int64_t workspace_byt
   }
 
   // ---- point encoder (clip_e2e.py:454-461): on the side stream, concurrent with the encoder pass ----
-  const bool ovl = e->overlap && (e->prof_site < 0 || e->prof_keep_overlap);
-  if (ovl) {
+  const bool ovl = e->overlap && (e->prof_site < 0 || e->prof_keep_overlap) && c.use_point_encoder;
+  if (!c.use_point_encoder) {
+    // encode_points returns zeros (clip_e2e.py:462-463)
+    HIPCHK(hipMemsetAsync(e->h_e3gnn, 0, (size_t)B * E * sizeof(float), s));
+  } else if (ovl) {
     COATI_TRY(fork_side(e, s));
     COATI_TRY(gnn_fwd(e, e->atoms, coords, e->side));
   } else {
@@ -1223,19 +1269,22 @@ int coati_engine_forward(coati_engine* e, void* workspace, int64_t workspace_byt
   }
   COATI_TRY(xformer_fwd(e, e->p1, nullptr, s));
   if (ovl) COATI_TRY(join_side(e, s));
-  COATI_TRY(launch_layernorm_fwd(e->hpoint, H, e->P + e->p2c_lnw, e->P + e->p2c_lnb, nullptr, 0, e->hp_ln, H, e->hp_mean, e->hp_rstd, B, H, s));
-  COATI_TRY(launch_sgemm(e->hp_ln, H, 1, e->P + e->p2c_w, 1, H, e->h_e3gnn, E, B, E, H, e->P + e->p2c_b, 1.f, 0, s));
+  COATI_TRY(point_head_fwd(e, e->h_e3gnn, s));
   // ---- smiles_to_clip ----
   if (e->p1.tail) HIPCHK(hipMemcpyAsync(e->hstop, e->p1.t_xf, (size_t)B * C * sizeof(float), hipMemcpyDeviceToDevice, s));
   else COATI_TRY(launch_gather_rows(e->p1.xf32, e->stop_pos, e->hstop, B, T1, C, s, e->p1.packed ? e->p1.off : nullptr));
-  COATI_TRY(launch_layernorm_fwd(e->hstop, C, e->P + e->s2c_lnw, e->P + e->s2c_lnb, nullptr, 0, e->hs_ln, C, e->hs_mean, e->hs_rstd, B, C, s));
-  COATI_TRY(launch_sgemm(e->hs_ln, C, 1, e->P + e->s2c_w, 1, C, e->h_smiles, E, B, E, C, e->P + e->s2c_b, 1.f, 0, s));
-  // ---- special token (clip_e2e.py:800-808) ----
-  COATI_TRY(launch_silu_fwd(e->h_e3gnn, e->sa, (long long)B * E, s));
-  COATI_TRY(launch_silu_fwd(e->h_smiles, e->sb, (long long)B * E, s));
-  COATI_TRY(launch_sgemm(e->sa, E, 1, e->P + e->tokw, 1, E, e->ptok, E, B, E, E, e->P + e->tokb, 1.f, 0, s));
-  COATI_TRY(launch_sgemm(e->sb, E, 1, e->P + e->tokw, 1, E, e->stok, E, B, E, E, e->P + e->tokb, 1.f, 0, s));
-  COATI_TRY(launch_select_rows(use_point, e->ptok, e->stok, e->cliptok, B, E, s));
+  COATI_TRY(smiles_head_fwd(e, e->h_smiles, s));
+  // ---- special token (clip_e2e.py:800-808): SiLU -> Linear of either embedding, or the embeddings themselves (token_mlp = False:
+  // nn.Identity, clip_e2e.py:436-437) ----
+  const float *ptok = e->h_e3gnn, *stok = e->h_smiles;
+  if (c.token_mlp) {
+    COATI_TRY(launch_silu_fwd(e->h_e3gnn, e->sa, (long long)B * E, s));
+    COATI_TRY(launch_silu_fwd(e->h_smiles, e->sb, (long long)B * E, s));
+    COATI_TRY(launch_sgemm(e->sa, E, 1, e->P + e->tokw, 1, E, e->ptok, E, B, E, E, e->P + e->tokb, 1.f, 0, s));
+    COATI_TRY(launch_sgemm(e->sb, E, 1, e->P + e->tokw, 1, E, e->stok, E, B, E, E, e->P + e->tokb, 1.f, 0, s));
+    ptok = e->ptok; stok = e->stok;
+  }
+  COATI_TRY(launch_select_rows(use_point, ptok, stok, e->cliptok, B, E, s));
   // ---- decoder pass with injection (smiles_xformer.py:426-452) ----
   COATI_TRY(xformer_fwd(e, e->p2, e->cliptok, s));
   if (bad_rows) COATI_TRY(launch_bad_rows(e->p2.idx, bad_rows, B, T2, s));
@@ -1287,17 +1336,19 @@ int coati_engine_encode(coati_engine* e, void* workspace, int64_t workspace_byte
   HIPCHK(hipMemsetAsync(e->err_flag, 0, 4 * sizeof(int), s));
   if (do_pts) {
     e->atoms = reinterpret_cast<const long long*>(atoms);
-    COATI_TRY(gnn_fwd(e, e->atoms, coords, s));
-    COATI_TRY(launch_layernorm_fwd(e->hpoint, H, e->P + e->p2c_lnw, e->P + e->p2c_lnb, nullptr, 0, e->hp_ln, H, e->hp_mean, e->hp_rstd, B, H, s));
-    COATI_TRY(launch_sgemm(e->hp_ln, H, 1, e->P + e->p2c_w, 1, H, h_e3gnn, E, B, E, H, e->P + e->p2c_b, 1.f, 0, s));
+    if (c.use_point_encoder) {
+      COATI_TRY(gnn_fwd(e, e->atoms, coords, s));
+      COATI_TRY(point_head_fwd(e, h_e3gnn, s));
+    } else {
+      HIPCHK(hipMemsetAsync(h_e3gnn, 0, (size_t)B * E * sizeof(float), s));   // clip_e2e.py:462-463
+    }
   }
   if (do_tok) {
     e->p1.idx = reinterpret_cast<const long long*>(raw_tokens);
     COATI_TRY(xformer_fwd(e, e->p1, nullptr, s));
     COATI_TRY(launch_find_stop(e->p1.idx, c.stop_token, e->stop_pos, e->err_flag, B, T1, s));
     COATI_TRY(launch_gather_rows(e->p1.xf32, e->stop_pos, e->hstop, B, T1, C, s));
-    COATI_TRY(launch_layernorm_fwd(e->hstop, C, e->P + e->s2c_lnw, e->P + e->s2c_lnb, nullptr, 0, e->hs_ln, C, e->hs_mean, e->hs_rstd, B, C, s));
-    COATI_TRY(launch_sgemm(e->hs_ln, C, 1, e->P + e->s2c_w, 1, C, h_smiles, E, B, E, C, e->P + e->s2c_b, 1.f, 0, s));
+    COATI_TRY(smiles_head_fwd(e, h_smiles, s));
     HIPCHK(hipMemcpyAsync(scal + 6, e->err_flag, sizeof(int), hipMemcpyDeviceToDevice, s));
   }
   return COATI_OK;
@@ -1366,31 +1417,46 @@ int coati_engine_backward(coati_engine* e, const float* dh_smiles, const float* 
     // ---- decoder pass ----
     HIPCHK(hipMemsetAsync(e->dcliptok, 0, (size_t)B * E * sizeof(float), s));
     COATI_TRY(xformer_bwd(e, e->p2, e->da, 0, e->dcliptok, s));
-    // ---- special-token head: cliptok = where(use_point, ptok, stok) ----
-    HIPCHK(hipMemsetAsync(e->dptok, 0, (size_t)B * E * sizeof(float), s));
-    HIPCHK(hipMemsetAsync(e->dstok, 0, (size_t)B * E * sizeof(float), s));
-    COATI_TRY(launch_select_rows_bwd(e->use_point, e->dcliptok, e->dptok, e->dstok, B, E, s));
-    COATI_TRY(head_linear_bwd(e, e->dptok, e->sa, e->tokw, e->tokb, e->dsa, B, E, E, s));
-    COATI_TRY(head_linear_bwd(e, e->dstok, e->sb, e->tokw, e->tokb, e->dsb, B, E, E, s));
-    // dh = external (contrastive) gradient + SiLU' path
+    // dh = external (contrastive) gradient + the special-token path
     if (dh_e3gnn) HIPCHK(hipMemcpyAsync(e->dhe, dh_e3gnn, (size_t)B * E * sizeof(float), hipMemcpyDeviceToDevice, s));
     else HIPCHK(hipMemsetAsync(e->dhe, 0, (size_t)B * E * sizeof(float), s));
     if (dh_smiles) HIPCHK(hipMemcpyAsync(e->dhs, dh_smiles, (size_t)B * E * sizeof(float), hipMemcpyDeviceToDevice, s));
     else HIPCHK(hipMemsetAsync(e->dhs, 0, (size_t)B * E * sizeof(float), s));
-    COATI_TRY(launch_silu_bwd(e->h_e3gnn, e->dsa, e->dhe, (long long)B * E, 1, s));
-    COATI_TRY(launch_silu_bwd(e->h_smiles, e->dsb, e->dhs, (long long)B * E, 1, s));
-    // smiles_to_clip / point_to_clip: Linear then LayerNorm backward
-    COATI_TRY(head_linear_bwd(e, e->dhs, e->hs_ln, e->s2c_w, e->s2c_b, e->dhs_ln, B, E, C, s));
-    COATI_TRY(launch_layernorm_bwd(e->dhs_ln, 1, C, e->hstop, C, 0, e->hs_mean, e->hs_rstd, e->P + e->s2c_lnw, nullptr, e->dhstop, nullptr, e->G + e->s2c_lnw, e->G + e->s2c_lnb, e->ln_partial, B, C, s));
-    COATI_TRY(head_linear_bwd(e, e->dhe, e->hp_ln, e->p2c_w, e->p2c_b, e->dhp_ln, B, E, H, s));
-    COATI_TRY(launch_layernorm_bwd(e->dhp_ln, 1, H, e->hpoint, H, 0, e->hp_mean, e->hp_rstd, e->P + e->p2c_lnw, nullptr, e->dhpoint, nullptr, e->G + e->p2c_lnw, e->G + e->p2c_lnb, e->ln_partial, B, H, s));
+    // ---- special-token head: cliptok = where(use_point, ptok, stok) ----
+    if (c.token_mlp) {
+      HIPCHK(hipMemsetAsync(e->dptok, 0, (size_t)B * E * sizeof(float), s));
+      HIPCHK(hipMemsetAsync(e->dstok, 0, (size_t)B * E * sizeof(float), s));
+      COATI_TRY(launch_select_rows_bwd(e->use_point, e->dcliptok, e->dptok, e->dstok, B, E, s));
+      COATI_TRY(head_linear_bwd(e, e->dptok, e->sa, e->tokw, e->tokb, e->dsa, B, E, E, s));
+      COATI_TRY(head_linear_bwd(e, e->dstok, e->sb, e->tokw, e->tokb, e->dsb, B, E, E, s));
+      COATI_TRY(launch_silu_bwd(e->h_e3gnn, e->dsa, e->dhe, (long long)B * E, 1, s));
+      COATI_TRY(launch_silu_bwd(e->h_smiles, e->dsb, e->dhs, (long long)B * E, 1, s));
+    } else {
+      // nn.Identity: the token IS the embedding, its gradient adds straight into d h_e3gnn / d h_smiles
+      COATI_TRY(launch_select_rows_bwd(e->use_point, e->dcliptok, e->dhe, e->dhs, B, E, s));
+    }
+    // smiles_to_clip / point_to_clip: Linear then (norm_clips) LayerNorm backward
+    if (c.norm_clips) {
+      COATI_TRY(head_linear_bwd(e, e->dhs, e->hs_ln, e->s2c_w, e->s2c_b, e->dhs_ln, B, E, C, s));
+      COATI_TRY(launch_layernorm_bwd(e->dhs_ln, 1, C, e->hstop, C, 0, e->hs_mean, e->hs_rstd, e->P + e->s2c_lnw, nullptr, e->dhstop, nullptr, e->G + e->s2c_lnw, e->G + e->s2c_lnb, e->ln_partial, B, C, s));
+    } else {
+      COATI_TRY(head_linear_bwd(e, e->dhs, e->hstop, e->s2c_w, e->s2c_b, e->dhstop, B, E, C, s));
+    }
+    if (c.use_point_encoder) {   // (use_point_encoder = False: h_e3gnn is a constant, nothing upstream of it)
+      if (c.norm_clips) {
+        COATI_TRY(head_linear_bwd(e, e->dhe, e->hp_ln, e->p2c_w, e->p2c_b, e->dhp_ln, B, E, H, s));
+        COATI_TRY(launch_layernorm_bwd(e->dhp_ln, 1, H, e->hpoint, H, 0, e->hp_mean, e->hp_rstd, e->P + e->p2c_lnw, nullptr, e->dhpoint, nullptr, e->G + e->p2c_lnw, e->G + e->p2c_lnb, e->ln_partial, B, H, s));
+      } else {
+        COATI_TRY(head_linear_bwd(e, e->dhe, e->hpoint, e->p2c_w, e->p2c_b, e->dhpoint, B, E, H, s));
+      }
+    }
   }
   // whole backward (stage 0) or the encoder stage of the staged (multi-GPU) backward: the point-encoder backward runs on
   // the side stream underneath the encoder pass; stage 3 then has nothing left to do
   // stages 4 / 5 = the encoder stage in two halves (upper / lower half of the layers), so that the caller can start the
   // all-reduce of the upper layers' finished gradients underneath the lower half
   const int Lx = c.n_layer_xformer, Lmid = Lx / 2;
-  const bool ovl_bwd = (stage == 0 || stage == 2 || stage == 4) && e->overlap && (e->prof_site < 0 || e->prof_keep_overlap);
+  const bool ovl_bwd = (stage == 0 || stage == 2 || stage == 4) && e->overlap && (e->prof_site < 0 || e->prof_keep_overlap) && c.use_point_encoder;
   if (stage == 0 || stage == 1) { e->gnn_bwd_done = false; e->gnn_side_pending = false; }
   if (ovl_bwd) {
     // the point-encoder backward only needs dhpoint (ready here) and writes its own gradient slice: side stream
@@ -1417,7 +1483,7 @@ int coati_engine_backward(coati_engine* e, const float* dh_smiles, const float* 
     e->gnn_bwd_done = true;
     e->gnn_side_pending = false;
   } else if ((stage == 0 || stage == 3) && !e->gnn_bwd_done) {
-    COATI_TRY(gnn_bwd(e, e->dhpoint, s));
+    if (c.use_point_encoder) COATI_TRY(gnn_bwd(e, e->dhpoint, s));
     e->gnn_bwd_done = true;
   }
   return COATI_OK;
@@ -1431,7 +1497,7 @@ int coati_engine_optimizer_step(coati_engine* e, float lr, float beta1, float be
   {
     ProfScope ps(e, SITE_OPTIM, 0, s);
     COATI_TRY(launch_grad_sqnorm(e->G, e->n_trainable, e->opt_partial, 1024, scal + 5, max_norm, scal + 8, s));
-    COATI_TRY(launch_adamw(e->P, e->G, e->Mo, e->Vo, e->S, e->n_trainable, lr, beta1, beta2, eps, weight_decay, step, scal + 8, 1.f, s));
+    COATI_TRY(launch_adamw(e->P, e->G, e->Mo, e->Vo, e->S, e->n_trainable, lr, beta1, beta2, eps, weight_decay, step, scal + 8, 1.f, s, e->err_flag));
   }
   return refresh_shadows_impl(e, stream, true);
 }

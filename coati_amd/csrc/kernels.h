@@ -288,7 +288,7 @@ int launch_standardize_bwd(const float* dzt, const float* zt, const unsigned cha
 int launch_grad_sqnorm(const float* g, long long n, float* partial, int n_partial, float* out_norm, float max_norm,
                        float* out_coef, hipStream_t s);
 int launch_adamw(float* p, const float* g, float* m, float* v, bf16_t* shadow, long long n, float lr, float b1,
-                 float b2, float eps, float wd, int step, const float* coef, float gscale, hipStream_t s);
+                 float b2, float eps, float wd, int step, const float* coef, float gscale, hipStream_t s, const int* skip = nullptr);
 int launch_cast_bf16(const float* src, bf16_t* dst, long long n, hipStream_t s);
 // dst[c*ld_dst + r] = bf16(src[r*ld_src + c]) for r<rows, c<cols; pad rows [cols, cols_pad) x... see optim.hip
 int launch_transpose_cast(const float* src, long long ld_src, bf16_t* dst, long long ld_dst, int rows, int cols,

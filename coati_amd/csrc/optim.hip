@@ -53,7 +53,10 @@ int launch_grad_sqnorm(const float* g, long long n, float* partial, int n_partia
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, bf16_t* __restrict__ shadow, long long n, float lr,
                                                     float b1, float b2, float eps, float wd, float inv_bc1, float inv_sqrt_bc2,
-                                                    const float* __restrict__ coef, float gscale) {
+                                                    const float* __restrict__ coef, float gscale, const int* __restrict__ skip) {
+  // skip: the step's device-side error word (missing [STOP] / packed-row mismatch, engine.cpp err_flag): a step that ran on
+  // wrong rows must not reach the weights -- the update is dropped here and the host raises when it reads the losses
+  if (skip != nullptr && skip[0] != 0) return;
   const float cs = (coef ? coef[0] : 1.f) * gscale;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
     const float gi = g[i] * cs;
@@ -68,13 +71,13 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
 }
 
 int launch_adamw(float* p, const float* g, float* m, float* v, bf16_t* shadow, long long n, float lr, float b1,
-                 float b2, float eps, float wd, int step, const float* coef, float gscale, hipStream_t s) {
+                 float b2, float eps, float wd, int step, const float* coef, float gscale, hipStream_t s, const int* skip) {
   COATI_CHECK_ARG(p && g && m && v && n > 0 && step >= 1, "adamw: bad argument");
   const double bc1 = 1.0 - pow((double)b1, (double)step), bc2 = 1.0 - pow((double)b2, (double)step);
   long long blocks = (n + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(adamw_kernel, dim3((int)blocks), dim3(256), 0, s, p, g, m, v, shadow, n, lr, b1, b2, eps, wd,
-                     (float)(1.0 / bc1), (float)(1.0 / sqrt(bc2)), coef, gscale);
+                     (float)(1.0 / bc1), (float)(1.0 / sqrt(bc2)), coef, gscale, skip);
   COATI_LAUNCH_CHECK("adamw");
   return COATI_OK;
 }

@@ -85,10 +85,17 @@ def grad_buckets(eng):
     """(name, start, end) element ranges of the flat gradient buffer, by the backward stage that completes them."""
     lay = eng.layout
     lm0 = lay["xformer.lm_head.weight"][0]
-    pe0 = lay["point_encoder.embedding.weight"][0]
-    hd0 = lay["point_to_clip.0.weight"][0]
     L = sum(1 for k in lay if k.startswith("xformer.transformer.h.") and k.endswith(".ln_1.weight"))
     mid = lay[f"xformer.transformer.h.{L // 2}.ln_1.weight"][0]   # first entry of layer L/2: [0, mid) = embeddings + lower layers
+    rest0 = min(off for k, (off, _) in lay.items() if not k.startswith("xformer."))   # first entry behind lm_head
+    if not eng.cfg.use_point_encoder:
+        # the point encoder never receives a gradient (it sits behind n_trainable with coord_mlp): one bucket for the heads,
+        # none for the point encoder (clip_e2e.py:454-463)
+        hd_end = lay["point_encoder.embedding.weight"][0]
+        return {"xformer_lo": (0, mid), "xformer_hi": (mid, lm0), "lm_head": (lm0, rest0), "gnn": (hd_end, hd_end),
+                "heads": (rest0, hd_end)}
+    pe0 = lay["point_encoder.embedding.weight"][0]
+    hd0 = lay["point_to_clip.0.weight" if eng.cfg.norm_clips else "point_to_clip.weight"][0]
     return {"xformer_lo": (0, mid), "xformer_hi": (mid, lm0), "lm_head": (lm0, pe0), "gnn": (pe0, hd0),
             "heads": (hd0, eng.n_params)}
 
@@ -162,7 +169,8 @@ def distributed_train_step(eng, batch, use_point, lr, do_clip=True, optimizer=Tr
     def launch(name):
         if reduce_grads:
             a, b = bk[name]
-            works.append(all_reduce_avg_async(eng.grads[a:b]))
+            if b > a:
+                works.append(all_reduce_avg_async(eng.grads[a:b]))
 
     eng.backward(dS, dC, stage=1)
     launch("lm_head"); launch("heads")
@@ -209,7 +217,22 @@ def global_losses(eng):
     """all-reduced loss scalars (every rank must call this)."""
     s = eng.scal.clone()
     all_reduce_sum(s[:4])
+    # the device-side error word of the step (bit 0: a row without [STOP]; bit 1: the packed-row counts passed to forward() differ
+    # from what the device found) -- MAX over the ranks, so that every rank raises together (the optimizer kernel has already
+    # dropped the update on the rank that saw it: csrc/optim.hip adamw_kernel `skip`)
+    err = s[6:7].view(torch.int32).to(torch.float32)
+    if _gloo() and err.is_cuda:
+        h = err.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.MAX)
+        err = h
+    else:
+        dist.all_reduce(err, op=dist.ReduceOp.MAX)
     s = s.cpu()
+    err = int(err.cpu()[0])
+    if err & 1:
+        raise RuntimeError("Some smiles in the batch do not have stop tokens. Did some tokenizations fail?")
+    if err & 2:
+        raise RuntimeError("packed rows: the row counts passed to forward() differ from what the device found in the tokens")
     ar = float(s[0] / s[1]) if s[1] > 0 else 0.0
     nv = float(s[4])
     clip = float(0.5 * (s[2] + s[3]) / nv) if nv > 0 else 0.0

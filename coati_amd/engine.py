@@ -30,6 +30,11 @@ class ModelConfig:
     stop_token: int = 1
     unk_token: int = 7
     fp8: bool = False     # BASELINE.json configs[4]: the transformer's Linear forward / input-gradient products on MXFP8 (needs C % 128 == 0)
+    # constructor flags of the reference model (clip_e2e.py:370-376): grande_closed sets all three (train_grande.py:21-35);
+    # the reference's own do_args() defaults are norm_clips=False, token_mlp=False (train_coati.py:520-523)
+    norm_clips: bool = True
+    token_mlp: bool = True
+    use_point_encoder: bool = True
 
 
 # COATI_PACK_ROWS=0 ignores the batches' packed-row counts: every step then runs on the padded [B, T] layout (A/B switch)
@@ -48,7 +53,8 @@ class Engine:
         self.l = _lib.lib()
         c = _lib.CoatiConfig(cfg.n_layer_xformer, cfg.n_layer_e3gnn, cfg.n_hidden_xformer, cfg.n_hidden_e3nn,
                              cfg.n_embd_common, cfg.n_head, cfg.n_seq, cfg.n_tok, cfg.msg_cutoff, cfg.pad_token,
-                             cfg.stop_token, cfg.unk_token, 1 if cfg.fp8 else 0)
+                             cfg.stop_token, cfg.unk_token, 1 if cfg.fp8 else 0, 1 if cfg.norm_clips else 0,
+                             1 if cfg.token_mlp else 0, 1 if cfg.use_point_encoder else 0)
         h = ctypes.c_void_p()
         _lib.check(self.l.coati_engine_create(ctypes.byref(c), ctypes.byref(h)), "coati_engine_create")
         self.h = h

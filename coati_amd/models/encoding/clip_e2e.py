@@ -58,7 +58,7 @@ def reference_parameter_order(names):
             sub = {"ln_1": (0, 0), "attn": (1, {"c_attn": 0, "c_proj": 1}.get(p[5], 0)), "ln_2": (2, 0),
                    "mlpf": (3, int(p[5]) if p[4] == "mlpf" else 0)}[p[4]]
             return (top, 1, layer, sub[0], sub[1], wb)
-        return (top, int(p[1]), 0, 0, 0, wb)
+        return (top, int(p[1]) if len(p) == 3 else 0, 0, 0, 0, wb)   # (norm_clips=False: a plain Linear, 'point_to_clip.weight')
     return sorted(names, key=key)
 
 
@@ -93,12 +93,15 @@ class e3gnn_smiles_clip_e2e(nn.Module):
                  use_point_encoder: bool = True, old_architecture: bool = False,
                  device: torch.device = torch.device("cuda:0"), dtype: torch.dtype = torch.float):
         super().__init__()
-        unsupported = dict(biases=not biases, torch_emb=torch_emb, residual=residual, norm_clips=not norm_clips,
-                           norm_embed=norm_embed, token_mlp=not token_mlp, use_point_encoder=not use_point_encoder,
+        # norm_clips / token_mlp / use_point_encoder follow the reference in both settings (clip_e2e.py:405-437, 454-463;
+        # the reference's own do_args() defaults are norm_clips=False, token_mlp=False: train_coati.py:520-523).  The remaining
+        # flags select layers no released COATI checkpoint uses (bias-free transformer, torch.nn.Embedding atom table, residual
+        # E(3)-GNN coordinates, embedding LayerNorm, the pre-release head order)
+        unsupported = dict(biases=not biases, torch_emb=torch_emb, residual=residual, norm_embed=norm_embed,
                            old_architecture=old_architecture)
         bad = [k for k, v in unsupported.items() if v]
         if bad:
-            raise NotImplementedError(f"coati_amd implements the grande/closed architecture only; unsupported flags: {bad}")
+            raise NotImplementedError(f"coati_amd: unsupported constructor flags: {bad}")
         if dtype not in (torch.float, torch.float32):
             raise NotImplementedError("parameters are fp32 master weights (bf16 is an internal operand format)")
         self.embed_dim = n_embd_common
@@ -107,7 +110,8 @@ class e3gnn_smiles_clip_e2e(nn.Module):
         # its e_gcl_sparse layers, so the effective cutoff is 5.0.
         cfg = ModelConfig(n_layer_e3gnn=n_layer_e3gnn, n_layer_xformer=n_layer_xformer, n_hidden_xformer=n_hidden_xformer,
                           n_hidden_e3nn=n_hidden_e3nn, n_embd_common=n_embd_common, n_head=n_head, n_seq=n_seq, n_tok=n_tok,
-                          msg_cutoff=5.0)
+                          msg_cutoff=5.0, norm_clips=bool(norm_clips), token_mlp=bool(token_mlp),
+                          use_point_encoder=bool(use_point_encoder))
         eng = Engine(cfg, self.device, train=True)
         object.__setattr__(self, "engine", eng)
         grads = eng.named_views("grads")
@@ -121,7 +125,9 @@ class e3gnn_smiles_clip_e2e(nn.Module):
         # generation entry point of the reference's RotarySmilesTransformer (smiles_xformer.py:272-351), KV-cached here
         object.__setattr__(self.xformer, "generate_top_k_with_inj_batch", eng.generate_top_k_with_inj_batch)
         self.point_encoder.hidden_nf = n_hidden_e3nn
-        self.use_point_encoder = True
+        self.use_point_encoder = bool(use_point_encoder)
+        if not token_mlp:
+            self.point_clip_to_special_tokens = nn.Identity()   # clip_e2e.py:436-437
         self.clip_loss = clip_loss(eng)
         self.reset_parameters()
         self.register_load_state_dict_post_hook(lambda module, incompatible: module.engine.refresh_shadows())
@@ -198,6 +204,8 @@ class e3gnn_smiles_clip_e2e(nn.Module):
         """point_clip_to_special_tokens = SiLU -> Linear (clip_e2e.py:432-435) on [B, E] embeddings (HIP silu + f32 GEMM)."""
         from ... import _lib, ops
         h = h_clip.to(self.device, torch.float32).contiguous()
+        if not self.engine.cfg.token_mlp:
+            return h          # nn.Identity (clip_e2e.py:436-437)
         a = torch.empty_like(h)
         _lib.call("coati_silu", ops.ptr(h), ops.ptr(a), h.numel(), ops.stream())
         lin = self.point_clip_to_special_tokens._modules["1"]

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define COATI_ABI_VERSION 2
+#define COATI_ABI_VERSION 3
 
 const char* coati_last_error(void);
 int coati_abi_version(void);
@@ -244,6 +244,12 @@ typedef struct coati_config {
   int32_t pad_token, stop_token, unk_token;
   int32_t use_fp8;          /* 1: the four Linear layers of every transformer block run their forward and input-gradient
                                products on MXFP8 (coati_gemm_mx8); needs C % 128 == 0 and coati_engine_bind_fp8 */
+  /* constructor flags of e3gnn_smiles_clip_e2e (clip_e2e.py:370-376, 405-435); grande_closed = 1 / 1 / 1, the reference's own
+     do_args() defaults (train_coati.py:520-523) = 0 / 0 / 1 */
+  int32_t norm_clips;        /* 1: point_to_clip / smiles_to_clip = LayerNorm -> Linear (state_dict .0 / .1); 0: plain Linear */
+  int32_t token_mlp;         /* 1: point_clip_to_special_tokens = SiLU -> Linear; 0: Identity (no parameters) */
+  int32_t use_point_encoder; /* 0: encode_points returns zeros (clip_e2e.py:454-463); the point encoder's and point_to_clip's
+                                parameters exist in the state_dict but never receive a gradient (skipped by clip-norm / AdamW) */
 } coati_config;
 
 typedef struct coati_engine coati_engine;

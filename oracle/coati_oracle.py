@@ -113,6 +113,11 @@ class OracleConfig:
     middle_token: int = 6
     unk_token: int = 7
     clip_token: int = 8
+    # constructor flags (clip_e2e.py:370-376, 405-437, 454-463); grande_closed sets all three, the reference's do_args()
+    # defaults are norm_clips=False, token_mlp=False (train_coati.py:520-523)
+    norm_clips: bool = True
+    token_mlp: bool = True
+    use_point_encoder: bool = True
 
 
 # --------------------------------------------------------------------------------------
@@ -364,27 +369,34 @@ def point_encoder(atoms: Tensor, coords: Tensor, P: Params, cfg: OracleConfig, p
 # --------------------------------------------------------------------------------------
 # heads, forward_dist, losses  (clip_e2e.py, train_coati.py)
 # --------------------------------------------------------------------------------------
-def ln_linear(x: Tensor, P: Params, pre: str) -> Tensor:
-    """point_to_clip / smiles_to_clip = LayerNorm -> Linear (clip_e2e.py:419-427). fp32."""
+def ln_linear(x: Tensor, P: Params, pre: str, norm_clips: bool = True) -> Tensor:
+    """point_to_clip / smiles_to_clip = LayerNorm -> Linear (clip_e2e.py:419-427), or a plain Linear when norm_clips is
+    False (clip_e2e.py:428-430). fp32."""
+    if not norm_clips:
+        return x @ P[pre + "weight"].t() + P[pre + "bias"]
     C = x.shape[-1]
     y = F.layer_norm(x, (C,), P[pre + "0.weight"], P[pre + "0.bias"], 1e-5)
     return y @ P[pre + "1.weight"].t() + P[pre + "1.bias"]
 
 
-def silu_linear(x: Tensor, P: Params, pre: str = "point_clip_to_special_tokens.") -> Tensor:
-    """point_clip_to_special_tokens = SiLU -> Linear (clip_e2e.py:431-435). fp32."""
+def silu_linear(x: Tensor, P: Params, pre: str = "point_clip_to_special_tokens.", token_mlp: bool = True) -> Tensor:
+    """point_clip_to_special_tokens = SiLU -> Linear (clip_e2e.py:431-435), nn.Identity when token_mlp is False (:436-437). fp32."""
+    if not token_mlp:
+        return x
     return F.silu(x) @ P[pre + "1.weight"].t() + P[pre + "1.bias"]
 
 
 def encode_points(atoms, coords, P, cfg):
-    """clip_e2e.py:454-463."""
-    return ln_linear(point_encoder(atoms, coords, P, cfg), P, "point_to_clip.")
+    """clip_e2e.py:454-463 (zeros when the point encoder is not used)."""
+    if not cfg.use_point_encoder:
+        return torch.zeros(atoms.shape[0], cfg.n_embd_common)
+    return ln_linear(point_encoder(atoms, coords, P, cfg), P, "point_to_clip.", cfg.norm_clips)
 
 
 def encode_tokens(idx, P, cfg):
     """clip_e2e.py:448-452."""
     x = xformer(idx, P, cfg)
-    return ln_linear(stop_token_embs(x, idx, cfg.stop_token), P, "smiles_to_clip.")
+    return ln_linear(stop_token_embs(x, idx, cfg.stop_token), P, "smiles_to_clip.", cfg.norm_clips)
 
 
 def forward_dist(
@@ -401,8 +413,8 @@ def forward_dist(
     the device RNG draw `rand(B) > p_clip_emb_smi` (clip_e2e.py:802-808)."""
     h_e3gnn = encode_points(atoms, coords, P, cfg)
     h_smiles = encode_tokens(raw_tokens, P, cfg)
-    point_tok = silu_linear(h_e3gnn, P)
-    smiles_tok = silu_linear(h_smiles, P)
+    point_tok = silu_linear(h_e3gnn, P, token_mlp=cfg.token_mlp)
+    smiles_tok = silu_linear(h_smiles, P, token_mlp=cfg.token_mlp)
     clip_token = torch.where(use_point.unsqueeze(-1), point_tok, smiles_tok)
     xf = xformer(augmented_tokens, P, cfg, injection=clip_token)
     bad_rows = augmented_tokens.sum(-1) < 1
@@ -539,16 +551,23 @@ def param_shapes(cfg: OracleConfig) -> Dict[str, Tuple[int, ...]]:
     s["xformer.transformer.ln_f.weight"] = (C,)
     s["xformer.transformer.ln_f.bias"] = (C,)
     s["xformer.lm_head.weight"] = (V, C)
-    s["point_to_clip.0.weight"] = (H,)
-    s["point_to_clip.0.bias"] = (H,)
-    s["point_to_clip.1.weight"] = (E, H)
-    s["point_to_clip.1.bias"] = (E,)
-    s["smiles_to_clip.0.weight"] = (E,)
-    s["smiles_to_clip.0.bias"] = (E,)
-    s["smiles_to_clip.1.weight"] = (E, C)
-    s["smiles_to_clip.1.bias"] = (E,)
-    s["point_clip_to_special_tokens.1.weight"] = (E, E)
-    s["point_clip_to_special_tokens.1.bias"] = (E,)
+    if cfg.norm_clips:
+        s["point_to_clip.0.weight"] = (H,)
+        s["point_to_clip.0.bias"] = (H,)
+        s["point_to_clip.1.weight"] = (E, H)
+        s["point_to_clip.1.bias"] = (E,)
+        s["smiles_to_clip.0.weight"] = (E,)
+        s["smiles_to_clip.0.bias"] = (E,)
+        s["smiles_to_clip.1.weight"] = (E, C)
+        s["smiles_to_clip.1.bias"] = (E,)
+    else:   # plain Linear heads (clip_e2e.py:428-430)
+        s["point_to_clip.weight"] = (E, H)
+        s["point_to_clip.bias"] = (E,)
+        s["smiles_to_clip.weight"] = (E, C)
+        s["smiles_to_clip.bias"] = (E,)
+    if cfg.token_mlp:   # nn.Identity otherwise: no parameters (clip_e2e.py:436-437)
+        s["point_clip_to_special_tokens.1.weight"] = (E, E)
+        s["point_clip_to_special_tokens.1.bias"] = (E,)
     return s
 
 

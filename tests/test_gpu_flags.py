@@ -1,0 +1,96 @@
+"""Constructor flags outside the grande setting (norm_clips / token_mlp / use_point_encoder, clip_e2e.py:405-437, 454-463) on
+the HIP engine against vectors the REFERENCE produced with those flags (tests/golden/gen_golden_flags.py), and the trainer with
+the reference's own do_args() defaults (norm_clips=False, token_mlp=False: train_coati.py:520-523)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from tests.gpu_util import check, log  # noqa: E402
+from tests.test_flags_cpu import CASES, SMALL, load_case  # noqa: E402
+
+DEV = "cuda:0"
+# the golden-step tolerances of tests/test_gpu_engine.py; gradients 5e-2 instead of 3.8e-2: the "mixed" case (5 rows, gradient
+# norm 44.7 -- four times the golden step's) measured 4.1e-2 on point_encoder.node_dec.3.bias, the other three cases <= 2.2e-2
+TOL_FWD, TOL_GRAD, TOL_LOSS, TOL_GRADNORM = 6.5e-3, 5e-2, 1e-3, 1.3e-2
+
+
+@pytest.mark.parametrize("case", list(CASES))
+def test_engine_flags_vs_reference(golden_dir, case):
+    from coati_amd.engine import Engine, ModelConfig
+    d, batch, up = load_case(golden_dir, case)
+    eng = Engine(ModelConfig(**SMALL, **CASES[case]), DEV)
+    P = {k[2:]: v for k, v in d.items() if k.startswith("w.")}
+    assert set(eng.layout) == set(P)                      # state_dict names of the reference model built with these flags
+    assert all(tuple(P[k].shape) == tuple(shape) for k, (_, shape) in eng.layout.items())
+    eng.load_state_dict(P)
+    b = {k: v.to(DEV) for k, v in batch.items()}
+    he, hs, bad = eng.forward(b["raw_tokens"], b["tokens"], b["atoms"], b["coords"], up.to(DEV), y_next=b["y_next"], train=False)
+    check(f"{case} h_e3gnn", he.cpu(), d["h_e3gnn"], TOL_FWD) if CASES[case]["use_point_encoder"] else None
+    if not CASES[case]["use_point_encoder"]:
+        assert float(he.abs().max()) == 0.0
+    check(f"{case} h_smiles", hs.cpu(), d["h_smiles"], TOL_FWD)
+    check(f"{case} logits", eng.logits().cpu(), d["logits"], TOL_FWD)
+    assert torch.equal(bad.cpu().bool(), d["bad"])
+    # the training step: losses, every gradient, clip-norm, AdamW
+    eng.step_count = 0
+    eng.train_step(b, up.to(DEV), lr=5e-4)
+    L = eng.losses()
+    check(f"{case} ar", torch.tensor([L["ar_loss"]]), d["ar"].reshape(1), TOL_LOSS)
+    check(f"{case} clip", torch.tensor([L["clip_loss"]]), d["clip"].reshape(1), TOL_LOSS)
+    check(f"{case} loss", torch.tensor([L["loss"]]), d["loss"].reshape(1), TOL_LOSS)
+    check(f"{case} gradnorm", torch.tensor([L["grad_norm"]]), d["gradnorm"].reshape(1).float(), TOL_GRADNORM)
+    grads = eng.named_views("grads")
+    worst = 0.0
+    for k in sorted(eng.layout):
+        g = grads[k].cpu()
+        if "nograd." + k in d:     # p.grad is None in the reference
+            assert float(g.abs().max()) == 0.0, k
+            continue
+        ref = d["grad." + k]
+        scale = max(float(ref.abs().max()), 1e-30)
+        e = float((g - ref).abs().max()) / scale
+        worst = max(worst, e)
+        assert e <= TOL_GRAD, f"{case} grad {k}: {e:.3e}"
+    log(f"{case}: worst parameter gradient vs reference {worst:.3e}")
+    after = eng.named_views("params")
+    for k in sorted(eng.layout):
+        a = after[k].cpu().reshape(-1)[::13]
+        ref = d["after1." + k]
+        if "nograd." + k in d:
+            assert torch.equal(a, P[k].reshape(-1)[::13]), f"{case}: {k} has no gradient in the reference and must not move (no weight decay either)"
+            continue
+        # the first AdamW step moves every element by ~ lr sign(g): the displacement vectors must point the same way (elements
+        # whose gradient is ~ 0 may flip under bf16 operand rounding; the kernel itself is pinned by test_adamw_and_clipnorm_*)
+        p0 = P[k].reshape(-1)[::13]
+        da, dr = (a - p0).double(), (ref - p0).double()
+        if float(dr.norm()) > 0:
+            cos = float((da * dr).sum() / (da.norm() * dr.norm() + 1e-30))
+            assert cos >= 0.85, f"{case} adamw {k}: displacement cosine {cos:.3f}"
+
+
+def test_trainer_with_reference_default_args(tmp_path):
+    """train_autoencoder(do_args()) without train_grande.py's overrides: norm_clips=False, token_mlp=False."""
+    from coati.training.train_coati import train_autoencoder, do_args
+    from coati.data.dataset import COATI_dataset
+    from coati_amd.data.dataset import SyntheticTokenizer
+    args = do_args([])
+    assert args.norm_clips is False and args.token_mlp is False
+    args.nodes, args.nr, args.gpus, args.world_size = 1, 0, 1, 1
+    args.n_layer_e3gnn, args.n_layer_xformer, args.max_n_seq, args.n_seq = 2, 2, 40, 24      # (depth only: keep the test short)
+    args.batch_size, args.n_epochs, args.test_interval = 16, 2, 1
+    args.log_batch_loss, args.log_interval = 1, 1
+    args.output_dir, args.model_dir, args.data_dir = str(tmp_path / "logs"), str(tmp_path / "ckpt"), str(tmp_path)
+    args.run_name = "d"
+    tk = SyntheticTokenizer(n_seq=24, n_token=200, n_special=12)
+    ds = COATI_dataset(cache_dir=str(tmp_path), tokenizer=tk, n_batches=6, n_atoms=8)
+    model = train_autoencoder(0, args, dataset=ds, tokenizer=tk)
+    names = set(model.state_dict())
+    assert "point_to_clip.weight" in names and "smiles_to_clip.bias" in names
+    assert not any(n.startswith("point_clip_to_special_tokens") for n in names)
+    recs = open(os.path.join(args.output_dir, "d", "log.json")).read().strip().split("\n")
+    losses = [eval(r.rstrip(","), {"null": None})["value"] for r in recs if "train_batch_loss" in r]
+    assert len(losses) == 12 and all(np.isfinite(losses)) and losses[-1] < losses[0]
