@@ -160,6 +160,80 @@ def test_two_gpu_rccl_step_equals_global_batch(tmp_path):
     _compare_grads(eng, r[0]["grads"], 5e-3, "two-GPU RCCL step")
 
 
+def _nccl_w1_worker(rank, port, out_dir):
+    """ONE rank on the "nccl" backend (= RCCL): distributed_train_step against Engine.train_step on the same batch."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        from coati_amd.engine import Engine, ModelConfig
+        from coati_amd import distributed as D
+        from coati_amd.synthetic import packed_rows
+        res = {}
+        for head in ("infonce", "barlow"):
+            b, up = _rank_batch(0, mask_ar=False)
+            db = {k: v.to(DEV) for k, v in b.items()}
+            db["rows"] = torch.tensor(packed_rows(b["raw_tokens"], b["tokens"], b["y_next"]))   # packed rows, as the bench runs it
+            engs = []
+            for mode in ("dist", "plain"):
+                eng = Engine(ModelConfig(**KW), DEV)
+                _weights(eng)
+                p0 = eng.params.clone()
+                # the gradients of the step alone, then the complete step (same weights: same gradients, + clip-norm + AdamW)
+                for optimizer in (False, True):
+                    if mode == "dist":
+                        D.distributed_train_step(eng, db, up.to(DEV), lr=1e-3, head=head, weight_decay=0.05, max_norm=1.0, optimizer=optimizer)
+                    else:
+                        eng.train_step(db, up.to(DEV), lr=1e-3, head=head, weight_decay=0.05, max_norm=1.0, optimizer=optimizer)
+                    if not optimizer:
+                        eng.g1 = eng.grads.clone()
+                torch.cuda.synchronize()
+                engs.append(eng)
+            Ld, Lp = D.global_losses(engs[0]), engs[1].losses()
+            res[head] = dict(params_rel=float((engs[0].params - engs[1].params).abs().sum() / (engs[1].params - p0).abs().sum()),
+                             grads_maxdiff=float((engs[0].g1 - engs[1].g1).abs().max()),
+                             grads_scale=float(engs[1].g1.abs().max()),
+                             ar=(Ld["ar_loss"], Lp["ar_loss"]), clip=(Ld["clip_loss"], Lp["clip_loss"]),
+                             barlow=(float(engs[0].barlow_loss), float(engs[1].barlow_loss)) if head == "barlow" else None)
+        import json
+        with open(os.path.join(out_dir, "w1.json"), "w") as f:
+            json.dump(res, f)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world_size_one_nccl_step_equals_train_step(tmp_path):
+    """The RCCL branch of coati_amd.distributed (all_gather_into_tensor / reduce_scatter_tensor / asynchronous all_reduce(AVG)
+    buckets on device memory, the staged backward) executed on the "nccl" backend at world size 1 -- the one size a one-GPU box
+    allows: it must reproduce Engine.train_step on the same packed batch for the InfoNCE and the Barlow head: losses and
+    gradients at 1e-6, the parameter displacement of the optimizer step at 1e-4 in L1 (not bit for bit: the embedding-table
+    gradient is accumulated with fp32 atomics, DESIGN section 5 item 8 -- two runs of the SAME step differ by ~ 1e-8 of the gradient
+    scale, and AdamW's g / (sqrt(v) + eps) amplifies that on elements whose gradient is ~ eps).
+    Reference: autograd_funs.py:5-25, train_coati.py:204-206."""
+    import json
+    from tests.gpu_util import log
+    ctx = mp.get_context("spawn")
+    p = ctx.Process(target=_nccl_w1_worker, args=(0, 29661, str(tmp_path)))
+    p.start()
+    p.join(timeout=600)
+    if p.is_alive():
+        p.kill()
+        pytest.fail("nccl world-size-1 worker hung")
+    assert p.exitcode == 0, f"worker exit code {p.exitcode}"
+    res = json.load(open(os.path.join(str(tmp_path), "w1.json")))
+    for head, r in res.items():
+        log(f"nccl W=1 {head}: {r}")
+        assert abs(r["ar"][0] - r["ar"][1]) <= 1e-6 * max(1.0, abs(r["ar"][1]))
+        assert abs(r["clip"][0] - r["clip"][1]) <= 1e-6 * max(1.0, abs(r["clip"][1]))
+        if r["barlow"] is not None:
+            assert abs(r["barlow"][0] - r["barlow"][1]) <= 1e-6 * max(1.0, abs(r["barlow"][1]))
+        assert r["grads_maxdiff"] <= 1e-6 * r["grads_scale"], r
+        assert r["params_rel"] <= 1e-4, r
+
+
 def test_two_process_barlow_distributed_equals_global_batch(tmp_path):
     """configs[3]: barlow_head(distributed=True) -- all-reduce of the batch statistics, the E x E cross-correlation and the
     backward statistics -- against the single-process head on the concatenated batch (parity unpinned: no reference code;

@@ -18,8 +18,9 @@ GRANDE = dict(n_layer_e3gnn=5, n_layer_xformer=16, n_hidden_xformer=256, n_hidde
               n_head=16, n_seq=250, n_tok=10322)
 
 
-@pytest.fixture(scope="module")
-def big():
+@pytest.fixture(scope="module", params=["padded", "packed"])
+def big(request):
+    """both row layouts: "packed" (batch["rows"]: the transformer passes on the rows' real prefixes) is what bench.py times"""
     from coati_amd.engine import Engine, ModelConfig
     from coati_amd.synthetic import make_batch
     eng = Engine(ModelConfig(**GRANDE), DEV)
@@ -34,13 +35,14 @@ def big():
             else:
                 v.copy_((0.01 * torch.randn(shape, generator=g)).to(DEV))
     eng.refresh_shadows()
-    batch, up = make_batch(1024, 80, 16, GRANDE["n_tok"], seed=77)
-    return eng, {k: v.to(DEV) for k, v in batch.items()}, up.to(DEV)
+    batch, up = make_batch(1024, 80, 16, GRANDE["n_tok"], seed=77, with_rows=request.param == "packed")
+    log(f"fullsize fixture: {request.param} layout, rows {batch['rows'].tolist() if 'rows' in batch else [1024 * 78, 1024 * 80]}")
+    return eng, {k: (v.to(DEV) if k != "rows" else v) for k, v in batch.items()}, up.to(DEV)
 
 
 def total_loss(eng, batch, up):
     h_e, h_s, bad = eng.forward(batch["raw_tokens"], batch["tokens"], batch["atoms"], batch["coords"], up,
-                                y_next=batch["y_next"], train=False)
+                                y_next=batch["y_next"], train=False, rows=batch.get("rows"))
     eng.infonce(h_s, h_e, h_s, h_e, bad, row0=0, gscale=1.0)
     return eng.losses(), h_e.clone(), h_s.clone()
 
@@ -49,7 +51,7 @@ def test_batch_permutation(big):
     eng, batch, up = big
     L0, he0, hs0 = total_loss(eng, batch, up)
     perm = torch.randperm(1024, generator=torch.Generator().manual_seed(1)).to(DEV)
-    pb = {k: v[perm].contiguous() for k, v in batch.items()}
+    pb = {k: (v[perm].contiguous() if k != "rows" else v) for k, v in batch.items()}   # (the packed-row COUNTS are sums over the batch)
     L1, he1, hs1 = total_loss(eng, pb, up[perm].contiguous())
     assert torch.equal(he1, he0[perm]) and torch.equal(hs1, hs0[perm])          # per-molecule maths is row-independent
     assert abs(L1["ar_loss"] - L0["ar_loss"]) < 2e-5 * abs(L0["ar_loss"])        # sums re-associate (fp32 atomics)

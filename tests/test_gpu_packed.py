@@ -192,3 +192,45 @@ def test_stop_row_tail_equals_full_last_layer(tmp_path):
                     for k in b["grads"] if float(b["grads"][k].abs().max()) > 0), reverse=True)
     log(f"tail vs full last layer: losses {a['losses']} / {b['losses']}; worst gradient deviations {worst[:3]}")
     assert worst[0][0] <= 1e-5, worst[:5]      # measured 1.4e-6 .. 3e-6 over runs (fp32 atomics in arrival order)
+
+
+def test_wrong_row_counts_raise_and_leave_the_weights_alone():
+    """A caller that passes row counts the tokens do not have (include/coati_hip.h rows1 / rows2): the device flags the mismatch
+    (error word bit 1), the optimizer kernel DROPS the update of that step (csrc/optim.hip adamw_kernel `skip`) and the host
+    raises as soon as the losses are read -- at world size 1 (Engine.losses) and through coati_amd.distributed.global_losses."""
+    from coati_amd.engine import Engine, ModelConfig
+    from coati_amd.synthetic import make_batch
+    import torch.distributed as dist
+    from coati_amd import distributed as D
+    kw = dict(n_layer_e3gnn=1, n_layer_xformer=2, n_hidden_xformer=64, n_hidden_e3nn=64, n_embd_common=64, n_head=4, n_seq=40, n_tok=200)
+    eng = Engine(ModelConfig(**kw), DEV)
+    g = torch.Generator().manual_seed(3)
+    with torch.no_grad():
+        for name, (off, shape) in eng.layout.items():
+            eng.view(name).copy_((torch.randn(shape, generator=g) * 0.08).to(DEV))
+    eng.refresh_shadows()
+    b, up = make_batch(12, 24, 8, 200, seed=5, n_special=12, min_len=5, with_rows=True)
+    db = {k: (v.to(DEV) if k != "rows" else v) for k, v in b.items()}
+    eng.train_step(db, up.to(DEV), lr=1e-3)
+    eng.losses()                                  # the right counts: fine
+    p_before, m_before = eng.params.clone(), eng.adam_m.clone()
+    wrong = dict(db, rows=b["rows"] - torch.tensor([3, 0]))
+    eng.train_step(wrong, up.to(DEV), lr=1e-3)
+    torch.cuda.synchronize()
+    assert torch.equal(eng.params, p_before) and torch.equal(eng.adam_m, m_before), "a step on wrong rows reached the weights"
+    with pytest.raises(RuntimeError, match="packed rows"):
+        eng.losses()
+    # the collective reader (what the trainer calls at world size > 1): gloo world of one rank
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", "29671"
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        D.distributed_train_step(eng, wrong, up.to(DEV), lr=1e-3)
+        torch.cuda.synchronize()
+        assert torch.equal(eng.params, p_before)
+        with pytest.raises(RuntimeError, match="packed rows"):
+            D.global_losses(eng)
+        D.distributed_train_step(eng, db, up.to(DEV), lr=1e-3)
+        D.global_losses(eng)
+        assert not torch.equal(eng.params, p_before)
+    finally:
+        dist.destroy_process_group()
