@@ -69,9 +69,13 @@ def _build_locked(verbose):
 
     with ThreadPoolExecutor(max_workers=8) as ex:
         objs = list(ex.map(compile_one, HIP_UNITS + CPP_UNITS))
-    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-lpthread", "-o", LIB], capture_output=True, text=True)
+    # link next to the target and rename: a rank that arrives while another one is linking (the unlocked fast path above)
+    # must never dlopen a half-written library
+    tmp = LIB + f".tmp{os.getpid()}"
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-lpthread", "-o", tmp], capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stderr}")
+    os.replace(tmp, LIB)
     if verbose:
         print(f"[coati_amd] built {LIB}", file=sys.stderr)
     return LIB

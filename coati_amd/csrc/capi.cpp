@@ -83,9 +83,11 @@ int coati_wgrad_grouped(int n_problems, const uint16_t* const* A, const int64_t*
   }
   COATI_CHECK_ARG((int64_t)(tab.size() * sizeof(WgradTile)) <= workspace_bytes, "wgrad_grouped: workspace too small (%zu tiles)", tab.size());
   hipStream_t s = S_(stream);
-  // the tile table goes into the CALLER's device workspace (the library allocates nothing); pageable source: the runtime
-  // stages the copy before hipMemcpyAsync returns, so `tab` may go out of scope; the launch is ordered behind it on `s`
-  if (hipMemcpyAsync(workspace, tab.data(), tab.size() * sizeof(WgradTile), hipMemcpyHostToDevice, s) != hipSuccess) {
+  // the tile table goes into the CALLER's device workspace (the library allocates nothing); `tab` lives on this frame, so the
+  // upload is waited for before returning (this stand-alone entry point is not on the training step's path: the engine
+  // caches its tables, engine.cpp xformer_wgrad_group)
+  if (hipMemcpyAsync(workspace, tab.data(), tab.size() * sizeof(WgradTile), hipMemcpyHostToDevice, s) != hipSuccess ||
+      hipStreamSynchronize(s) != hipSuccess) {
     coati_set_error("wgrad_grouped: table upload failed");
     return COATI_EHIP;
   }

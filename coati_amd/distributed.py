@@ -88,54 +88,76 @@ def grad_buckets(eng):
     L = sum(1 for k in lay if k.startswith("xformer.transformer.h.") and k.endswith(".ln_1.weight"))
     mid = lay[f"xformer.transformer.h.{L // 2}.ln_1.weight"][0]   # first entry of layer L/2: [0, mid) = embeddings + lower layers
     rest0 = min(off for k, (off, _) in lay.items() if not k.startswith("xformer."))   # first entry behind lm_head
-    if not eng.cfg.use_point_encoder:
-        # the point encoder never receives a gradient (it sits behind n_trainable with coord_mlp): one bucket for the heads,
-        # none for the point encoder (clip_e2e.py:454-463)
-        hd_end = lay["point_encoder.embedding.weight"][0]
-        return {"xformer_lo": (0, mid), "xformer_hi": (mid, lm0), "lm_head": (lm0, rest0), "gnn": (hd_end, hd_end),
-                "heads": (rest0, hd_end)}
     pe0 = lay["point_encoder.embedding.weight"][0]
-    hd0 = lay["point_to_clip.0.weight" if eng.cfg.norm_clips else "point_to_clip.weight"][0]
+    s2c0 = lay["smiles_to_clip.0.weight" if "smiles_to_clip.0.weight" in lay else "smiles_to_clip.weight"][0]
+    if pe0 > s2c0:
+        # use_point_encoder = False: the point encoder + point_to_clip never receive a gradient and sit behind the trainable
+        # parameters with coord_mlp (clip_e2e.py:454-463, engine.cpp build_layout): one bucket for the heads, then the
+        # (all-zero) rest so that the buckets still tile the buffer
+        return {"xformer_lo": (0, mid), "xformer_hi": (mid, lm0), "lm_head": (lm0, rest0), "heads": (rest0, pe0),
+                "gnn": (pe0, eng.n_params)}
+    hd0 = lay["point_to_clip.0.weight" if "point_to_clip.0.weight" in lay else "point_to_clip.weight"][0]
     return {"xformer_lo": (0, mid), "xformer_hi": (mid, lm0), "lm_head": (lm0, pe0), "gnn": (pe0, hd0),
             "heads": (hd0, eng.n_params)}
 
 
-# COATI_DP_SPLIT=1: the encoder stage of the data-parallel backward in two halves (round-1 schedule, A/B switch)
-# Encoder stage of the staged backward in one piece or in two halves (see distributed_train_step).  COATI_DP_SPLIT=0 | 1 forces
-# a schedule; unset, the schedule is MEASURED: after 3 warm-up steps three steps of each form are timed (device-synchronised,
-# those six steps only) and the faster one -- MAX over ranks, so that every rank picks the same -- is kept.
+# Encoder stage of the staged backward in one piece or in two halves (see distributed_train_step).  COATI_DP_SPLIT=0 | 1 forces a
+# schedule; unset, the schedule is MEASURED per engine: after 3 warm-up steps three steps of each form are timed with device
+# events around the step (no host synchronisation until the decision) and the faster one -- MAX over ranks through the host-side
+# control group, so that every rank picks the same -- is kept.  The state lives on the engine (a second engine, or an eval step
+# in between, does not share counters).
 _SPLIT_ENV = os.environ.get("COATI_DP_SPLIT")
-_SPLIT_ENCODER_STAGE = _SPLIT_ENV == "1"
-_AUTO = {"step": 0, "t": [0.0, 0.0], "decided": _SPLIT_ENV is not None}
+_SPLIT_ENCODER_STAGE = _SPLIT_ENV == "1"      # the schedule of every engine that has not measured one
 
 
-def _schedule_begin():
-    """returns (use_split, timing_slot or None) for this step"""
-    if _AUTO["decided"] or not dist.is_initialized() or dist.get_backend() != "nccl":
-        return _SPLIT_ENCODER_STAGE, None
-    k = _AUTO["step"]
-    _AUTO["step"] += 1
-    if k < 3:
+class _Schedule:
+    WARMUP, PER_FORM = 3, 3
+
+    def __init__(self):
+        self.step = 0
+        self.events = [[], []]          # per form: (begin, end) device-event pairs
+        self.decided = _SPLIT_ENV is not None
+        self.split = _SPLIT_ENCODER_STAGE
+
+
+def _measurable():
+    """the schedule is only measured on the product backend (RCCL); gloo runs stage through the host and time nothing useful"""
+    return dist.is_initialized() and dist.get_backend() == "nccl"
+
+
+def _schedule_begin(eng):
+    """returns (use_split, timing slot or None) for this step of this engine"""
+    sch = getattr(eng, "_dp_schedule", None)
+    if sch is None:
+        sch = eng._dp_schedule = _Schedule()
+    if sch.decided or not _measurable():
+        return (sch.split if sch.decided and _SPLIT_ENV is None else _SPLIT_ENCODER_STAGE), None
+    k = sch.step
+    sch.step += 1
+    if k < sch.WARMUP:
         return False, None
-    if k < 9:
-        return (k - 3) >= 3, (0 if k - 3 < 3 else 1)
-    return _SPLIT_ENCODER_STAGE, None
+    form = 0 if k - sch.WARMUP < sch.PER_FORM else 1
+    ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+    ev[0].record()
+    sch.events[form].append(ev)
+    return form == 1, form
 
 
-def _schedule_end(slot, seconds):
-    global _SPLIT_ENCODER_STAGE
+def _schedule_end(eng, slot):
     if slot is None:
         return
-    _AUTO["t"][slot] += seconds
-    if _AUTO["step"] == 9:
-        t = torch.tensor(_AUTO["t"], dtype=torch.float64)
+    sch = eng._dp_schedule
+    sch.events[slot][-1][1].record()
+    if sch.step == sch.WARMUP + 2 * sch.PER_FORM:
+        torch.cuda.synchronize()
+        t = torch.tensor([sum(a.elapsed_time(b) for a, b in sch.events[f]) for f in (0, 1)], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=control_group())
-        _SPLIT_ENCODER_STAGE = bool(t[1] < t[0])
-        _AUTO["decided"] = True
+        sch.split = bool(t[1] < t[0])
+        sch.decided = True
+        sch.events = [[], []]
         if dist.get_rank() == 0:
-            print(f"[coati_amd.distributed] encoder stage of the data-parallel backward: one piece {1e3 * float(t[0]) / 3:.3f} ms/step, "
-                  f"two halves {1e3 * float(t[1]) / 3:.3f} ms/step -> {'two halves' if _SPLIT_ENCODER_STAGE else 'one piece'}", file=sys.stderr, flush=True)
-
+            print(f"[coati_amd.distributed] encoder stage of the data-parallel backward: one piece {float(t[0]) / sch.PER_FORM:.3f} ms/step, "
+                  f"two halves {float(t[1]) / sch.PER_FORM:.3f} ms/step -> {'two halves' if sch.split else 'one piece'}", file=sys.stderr, flush=True)
 
 
 def distributed_train_step(eng, batch, use_point, lr, do_clip=True, optimizer=True, head="infonce", reduce_grads=True,
@@ -145,11 +167,7 @@ def distributed_train_step(eng, batch, use_point, lr, do_clip=True, optimizer=Tr
     reduce_grads=False skips the four gradient all-reduces (bench.py's measurement of their exposed cost).
     opt_kw: weight_decay / max_norm / betas / eps for Engine.optimizer_step (train_coati.py:145-151, 276)."""
     W, rank = dist.get_world_size(), dist.get_rank()
-    split_stage, slot = _schedule_begin() if (reduce_grads and optimizer) else (_SPLIT_ENCODER_STAGE, None)
-    if slot is not None:
-        import time
-        torch.cuda.synchronize()
-        t_begin = time.perf_counter()
+    split_stage, slot = _schedule_begin(eng) if (reduce_grads and optimizer) else (_SPLIT_ENCODER_STAGE, None)
     h_e, h_s, bad = eng.forward(batch["raw_tokens"], batch["tokens"], batch["atoms"], batch["coords"], use_point,
                                 y_next=batch["y_next"], train=True, rows=batch.get("rows"))
     B = h_e.shape[0]
@@ -194,9 +212,7 @@ def distributed_train_step(eng, batch, use_point, lr, do_clip=True, optimizer=Tr
         w.wait()
     if optimizer:
         eng.optimizer_step(lr, **opt_kw)
-    if slot is not None:
-        torch.cuda.synchronize()
-        _schedule_end(slot, time.perf_counter() - t_begin)
+    _schedule_end(eng, slot)
     return h_e, h_s, bad
 
 

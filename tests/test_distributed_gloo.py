@@ -95,7 +95,9 @@ def test_row_sharded_infonce_equals_global_loss():
     assert _spawn(_infonce_worker, 29702) == {0: True, 1: True}
 
 
-def test_grad_buckets_cover_the_flat_buffer():
+@pytest.mark.parametrize("flags", [(1, 1, 1), (0, 0, 1), (0, 0, 0), (1, 1, 0), (1, 0, 1)])
+def test_grad_buckets_cover_the_flat_buffer(flags):
+    """(norm_clips, token_mlp, use_point_encoder): the buckets tile the flat gradient buffer for every head layout"""
     import ctypes
     from coati_amd import _lib
     from coati_amd import distributed as D
@@ -103,7 +105,7 @@ def test_grad_buckets_cover_the_flat_buffer():
     class Fake:
         pass
     l = _lib.lib()
-    cfg = _lib.CoatiConfig(2, 2, 64, 64, 64, 4, 24, 48, 5.0, 0, 1, 7)
+    cfg = _lib.CoatiConfig(2, 2, 64, 64, 64, 4, 24, 48, 5.0, 0, 1, 7, 0, *flags)
     h = ctypes.c_void_p()
     assert l.coati_engine_create(ctypes.byref(cfg), ctypes.byref(h)) == 0
     eng = Fake()

@@ -30,7 +30,7 @@ def test_bad_arguments_return_codes_not_exceptions():
     l = _lib.lib()
     rc = l.coati_gemm_nt(None, 0, 0, None, 0, 1, 1, 64, None, 0, 0, None, None, None, 0, 0, None)
     assert rc == -1 and b"null" in l.coati_last_error()
-    cfg = _lib.CoatiConfig(2, 2, 96, 64, 96, 4, 24, 48, 5.0, 0, 1, 7)   # head size 24: unsupported
+    cfg = _lib.CoatiConfig(2, 2, 96, 64, 96, 4, 24, 48, 5.0, 0, 1, 7, 0, 1, 1, 1)   # head size 24: unsupported
     h = ctypes.c_void_p()
     assert l.coati_engine_create(ctypes.byref(cfg), ctypes.byref(h)) == -2
     assert b"head size" in l.coati_last_error()
@@ -43,7 +43,7 @@ def test_layout_is_the_reference_state_dict_contract(golden_dir):
     for kw in (dict(n_layer_e3gnn=2, n_layer_xformer=2, n_hidden_xformer=64, n_hidden_e3nn=64, n_embd_common=64, n_head=4, n_seq=24, n_tok=48),
                dict(n_layer_e3gnn=5, n_layer_xformer=16, n_hidden_xformer=256, n_hidden_e3nn=256, n_embd_common=256, n_head=16, n_seq=250, n_tok=10322)):
         cfg = _lib.CoatiConfig(kw["n_layer_xformer"], kw["n_layer_e3gnn"], kw["n_hidden_xformer"], kw["n_hidden_e3nn"],
-                               kw["n_embd_common"], kw["n_head"], kw["n_seq"], kw["n_tok"], 5.0, 0, 1, 7)
+                               kw["n_embd_common"], kw["n_head"], kw["n_seq"], kw["n_tok"], 5.0, 0, 1, 7, 0, 1, 1, 1)
         h = ctypes.c_void_p()
         assert l.coati_engine_create(ctypes.byref(cfg), ctypes.byref(h)) == 0
         shapes = O.param_shapes(O.OracleConfig(**kw))
@@ -214,8 +214,11 @@ class _FakeEngine:
         self.calls = []
         self.layout = {"xformer.emb.tok_emb.weight": (0, (4, 4)), "xformer.transformer.h.0.ln_1.weight": (64, (4,)),
                        "xformer.transformer.h.1.ln_1.weight": (128, (4,)), "xformer.lm_head.weight": (192, (4, 4)),
-                       "point_encoder.embedding.weight": (256, (4, 4)), "point_to_clip.0.weight": (320, (4,))}
+                       "point_encoder.embedding.weight": (256, (4, 4)), "point_to_clip.0.weight": (320, (4,)),
+                       "smiles_to_clip.0.weight": (352, (4,))}
         self.n_params = 384
+        import types
+        self.cfg = types.SimpleNamespace(use_point_encoder=True, norm_clips=True, token_mlp=True)
         self.grads = torch.arange(384, dtype=torch.float32)
         self.scal = torch.zeros(16)
         self._train_step = Engine.train_step.__get__(self)
@@ -278,6 +281,66 @@ def test_optimizer_arguments_reach_the_optimizer():
         D.distributed_eval_step(e, batch, up)
         assert [c[0] for c in e.calls] == ["forward", "infonce"]
         assert D.all_agree(True, "cpu") and not D.all_agree(False, "cpu")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_measured_dp_schedule_is_per_engine_and_decided_once(monkeypatch):
+    """The run-time choice between one encoder stage and two halves (coati_amd.distributed._Schedule): 3 warm-up steps, 3 timed
+    steps of each form (device events), MAX over ranks, then the faster form for good -- with the backend check and the device
+    events replaced by host stand-ins so that the counters, the vote and the decision run on CPU.  The state belongs to the
+    engine: a second engine starts its own measurement, an evaluation step in between does not advance it."""
+    import torch.distributed as dist
+    from coati_amd import distributed as D
+    batch = {k: torch.zeros(3, 5, dtype=torch.long) for k in ("raw_tokens", "tokens", "atoms", "y_next")}
+    batch["coords"] = torch.zeros(3, 5, 3)
+    up = torch.ones(3, dtype=torch.bool)
+    clock = {"t": 0.0, "cost": {False: 5.0, True: 3.0}}     # ms per step of the two forms: the split form is faster here
+
+    class FakeEvent:
+        def __init__(self, enable_timing=False):
+            self.t = None
+
+        def record(self):
+            self.t = clock["t"]
+
+        def elapsed_time(self, other):
+            return other.t - self.t
+
+    monkeypatch.setattr(D, "_measurable", lambda: True)
+    monkeypatch.setattr(D, "_SPLIT_ENV", None)
+    monkeypatch.setattr(torch.cuda, "Event", FakeEvent)
+    monkeypatch.setattr(torch.cuda, "synchronize", lambda *a, **k: None)
+    monkeypatch.setattr(D, "control_group", lambda: None)
+    dist.init_process_group("gloo", rank=0, world_size=1, store=dist.HashStore())
+    try:
+        def run(e):
+            e.calls.clear()
+            real_backward = e.backward
+
+            def backward(dS, dC, stage=0):
+                if stage in (2, 4):      # the encoder stage is where the two forms differ
+                    clock["t"] += clock["cost"][stage == 4]
+                return real_backward(dS, dC, stage)
+            e.backward = backward
+            D.distributed_train_step(e, batch, up, 1e-3)
+            e.backward = real_backward
+            return [c[1] for c in e.calls if c[0] == "backward"]
+
+        e1, e2 = _FakeEngine(), _FakeEngine()
+        seq = [run(e1) for _ in range(3)]
+        assert seq == [[1, 2, 3]] * 3                              # warm-up: one piece, untimed
+        D.distributed_eval_step(e1, batch, up)                      # an evaluation step does not advance the measurement
+        assert [run(e1) for _ in range(3)] == [[1, 2, 3]] * 3      # form 0 timed
+        assert run(e2) == [1, 2, 3] and e2._dp_schedule.step == 1   # another engine: its own counters
+        assert [run(e1) for _ in range(3)] == [[1, 4, 5, 3]] * 3   # form 1 timed
+        assert e1._dp_schedule.decided and e1._dp_schedule.split    # 3 ms < 5 ms: two halves
+        assert run(e1) == [1, 4, 5, 3] and run(e1) == [1, 4, 5, 3]
+        assert not e2._dp_schedule.decided
+        clock["cost"] = {False: 2.0, True: 3.0}                    # on e2 the one-piece form wins
+        for _ in range(8):
+            run(e2)
+        assert e2._dp_schedule.decided and not e2._dp_schedule.split and run(e2) == [1, 2, 3]
     finally:
         dist.destroy_process_group()
 
