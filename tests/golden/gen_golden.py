@@ -418,6 +418,9 @@ def _clip_ar_xform_cases():
                        cases=cases), f)
 
 
+MID_STEP = 21   # (batch 21 % 8 = 5)
+
+
 def _loss_curve(n_steps=40):
     """north_star "loss-curve equivalent to reference": 40 optimiser steps of the reference (forward_dist + AR CE +
     InfoNCE * log2 V + backward + clip_grad_norm_(10) + AdamW(lr 5e-4, wd 0.1, betas (0.9, 0.99)): train_grande.py's
@@ -444,7 +447,17 @@ def _loss_curve(n_steps=40):
         c = cl(hs, he, bad).mean()
         loss = ar + c * teu
         loss.backward()
+        if step == MID_STEP:
+            # mid-curve pin that is not an envelope: the reference's OWN weights at the start of this step (in full) and the
+            # gradients it computes from them -- the engine reloads the weights and must reproduce the gradients of this one
+            # step at the single-step tolerance, wherever its own trajectory has drifted to by then
+            mid = {"w." + n: p.detach().clone() for n, p in model.named_parameters()}
+            mid.update({"g." + n: (p.grad.clone() if p.grad is not None else torch.zeros_like(p)) for n, p in model.named_parameters()})
+            mid.update(step=np.array(step), loss=loss.detach(), ar=ar.detach(), clip=c.detach())
         gn = torch.nn.utils.clip_grad_norm_(model.parameters(), 10.0)
+        if step == MID_STEP:
+            mid["gradnorm"] = gn
+            np.savez_compressed(os.path.join(OUT, "loss_curve_mid.npz"), **npify(mid))
         opt.step()
         rec["loss"].append(float(loss)); rec["ar"].append(float(ar)); rec["clip"].append(float(c)); rec["gradnorm"].append(float(gn))
     out = {f"b{i}_{k}": v for i, b in enumerate(batches) for k, v in b.items()}
@@ -499,7 +512,9 @@ def verify():
             print(("same     " if ok else "DIFFERENT") + " " + f)
             if not ok:
                 bad.append(f)
-        missing = [f for f in os.listdir(HERE) if f.endswith((".npz", ".json", ".pkl")) and f not in os.listdir(tmp)]
+        own = {"grande_golden.npz": "gen_golden_grande.py", "flags_golden.npz": "gen_golden_flags.py", "tokenizer_real.json": "gen_golden_tokenizer.py"}
+        missing = [f for f in os.listdir(HERE) if f.endswith((".npz", ".json", ".pkl")) and f not in os.listdir(tmp) and f not in own]
+        print("fixtures with their own generator (each has --verify):", own)
         print("fixtures without a generator:", missing)
         return not bad and not missing
 

@@ -36,6 +36,7 @@ GRANDE = dict(n_layer_e3gnn=5, n_layer_xformer=16, n_hidden_xformer=256, n_hidde
               n_seq=250, n_tok=10322)
 SEED = 16
 N_STEPS = 20
+MID_STEP = 10
 FULL_GRADS = [
     "xformer.transformer.h.0.attn.c_attn.weight", "xformer.transformer.h.0.attn.c_attn.bias",
     "xformer.transformer.h.0.ln_1.weight", "xformer.transformer.h.0.ln_1.bias",
@@ -144,6 +145,14 @@ def main():
         c = cl(hs, he, bad).mean()
         loss = ar + c * teu                                                                                     # train_coati.py:270
         loss.backward()
+        if step == MID_STEP:
+            # mid-curve pin: a strided sample of the weights the reference holds at the START of this step (every 97th element
+            # of each tensor) and the norm of every parameter's gradient at this step
+            for n, p in model.named_parameters():
+                out["mid.w." + n] = p.detach().flatten()[::97].clone()
+            out["mid_grad_norms"] = np.array([float((p.grad if p.grad is not None else torch.zeros_like(p)).double().norm())
+                                              for n, p in model.named_parameters()])
+            out["mid_step"] = np.array(step)
         if step == 0:
             gn_all, gp_all = [], []
             for n, p in model.named_parameters():

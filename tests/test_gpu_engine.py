@@ -183,6 +183,36 @@ def test_forty_step_loss_curve_vs_reference(golden_dir):
     assert dev_["gradnorm"].max() <= TOL_CURVE_GN_MAX and np.median(dev_["gradnorm"]) <= TOL_CURVE_GN_MEDIAN
 
 
+def test_mid_curve_step_from_the_references_weights(golden_dir):
+    """A mid-curve check that is NOT an envelope (tests/golden/loss_curve_mid.npz): the engine loads the weights the REFERENCE
+    held at the start of step 21 of its 40-step curve and must reproduce that one step -- losses, clip-norm and every parameter
+    gradient at the single-step tolerances -- wherever its own trajectory had drifted to by then."""
+    from coati_amd.engine import Engine, ModelConfig
+    m = np.load(os.path.join(golden_dir, "loss_curve_mid.npz"))
+    c = np.load(os.path.join(golden_dir, "loss_curve.npz"))
+    step = int(m["step"])
+    eng = Engine(ModelConfig(n_layer_e3gnn=2, n_layer_xformer=2, n_hidden_xformer=64, n_hidden_e3nn=64, n_embd_common=64,
+                             n_head=4, n_seq=24, n_tok=48), DEV)
+    eng.load_state_dict({k[2:]: torch.from_numpy(m[k]) for k in m.files if k.startswith("w.")})
+    b = {k: torch.from_numpy(c[f"b{step % 8}_{k}"]).to(DEV) for k in ("raw_tokens", "tokens", "atoms", "coords", "y_next")}
+    eng.train_step(b, torch.ones(b["atoms"].shape[0], dtype=torch.bool, device=DEV), lr=0.0, weight_decay=0.0, max_norm=10.0)
+    L = eng.losses()
+    check("mid-curve loss", torch.tensor([L["loss"]]), torch.from_numpy(m["loss"]).reshape(1), TOL_LOSS)
+    check("mid-curve ar", torch.tensor([L["ar_loss"]]), torch.from_numpy(m["ar"]).reshape(1), TOL_LOSS)
+    check("mid-curve clip", torch.tensor([L["clip_loss"]]), torch.from_numpy(m["clip"]).reshape(1), TOL_LOSS)
+    check("mid-curve clip-norm", torch.tensor([L["grad_norm"]]), torch.from_numpy(m["gradnorm"]).reshape(1).float(), TOL_GRADNORM)
+    grads = eng.named_views("grads")
+    worst = []
+    for k in sorted(eng.layout):
+        ref = torch.from_numpy(m["g." + k])
+        scale = float(ref.abs().max())
+        g = grads[k].cpu()
+        worst.append((float((g - ref).abs().max()) / scale if scale > 0 else float(g.abs().max()), k))
+    worst.sort(reverse=True)
+    log(f"mid-curve step (reference weights of step {step}): worst gradient deviations {worst[:3]}")
+    assert worst[0][0] <= TOL_GRAD, worst[:6]
+
+
 def test_medium_random_model_grads():
     """A wider config (C=H=128, 3+2 layers, V=300, T up to 40, A=12) with random weights, checked against the oracle
     in bf16-simulation mode: exercises partial tiles, several heads and the non-square GNN shapes."""

@@ -125,6 +125,45 @@ def test_step_grads_adamw_grande_vs_reference(gr, layout):
             assert cos > 0.9, (n, cos)     # measured >= 0.9528 (h.0.attn.c_attn.bias), 0.994+ for every matrix
 
 
+def _mid_curve_weights(g, P, names, eng, layout):
+    """Mid-curve pin on the WEIGHTS (not a loss envelope): every 97th element of every tensor the reference holds at the start of
+    step 10.  Ten AdamW steps move an element by <= 10 lr = 5e-3 whatever its gradient's size, so the displacement from the initial
+    weights is compared as a vector per tensor -- direction (cosine) and length; a backward that had gone wrong after step 0
+    (which test_step_grads_adamw pins in full) turns the displacement of the tensors it touches."""
+    views = eng.named_views("params")
+    cos_all, len_all, worst = [], [], []
+    for n_ in names:
+        ref = torch.from_numpy(g["mid.w." + n_]).double()
+        w0 = P[n_].flatten()[::97].double()
+        w = views[n_].detach().cpu().flatten()[::97].double()
+        dr, de = ref - w0, w - w0
+        if float(dr.norm()) == 0.0:
+            assert float(de.norm()) == 0.0, n_          # coord_mlp: never moves
+            continue
+        if dr.numel() < 64:
+            continue                                     # (too few samples of a small tensor for a direction)
+        c = float((dr * de).sum() / (dr.norm() * de.norm() + 1e-300))
+        cos_all.append(c); len_all.append(float(de.norm() / dr.norm())); worst.append((c, n_))
+    worst.sort()
+    log(f"grande mid-curve weights [{layout}]: displacement after 10 steps vs reference: cosine median {np.median(cos_all):.4f} min {worst[0][0]:.4f} "
+        f"({worst[0][1]}), length ratio {min(len_all):.3f} .. {max(len_all):.3f}")
+    assert np.median(cos_all) >= 0.97 and worst[0][0] >= 0.85, worst[:4]
+    assert 0.9 <= min(len_all) and max(len_all) <= 1.1, (min(len_all), max(len_all))
+
+
+def _mid_curve_grad_norms(g, names, eng, layout):
+    """every parameter's gradient norm at step 10 (pre-clip) against the reference's: median over the parameters -- a systematic
+    backward error shows in all of them, trajectory noise does not"""
+    grads = eng.named_views("grads")
+    ref = g["mid_grad_norms"]
+    dev = []
+    for i, n_ in enumerate(names):
+        if ref[i] > 0:
+            dev.append(abs(float(grads[n_].double().norm()) - ref[i]) / ref[i])
+    log(f"grande mid-curve gradient norms [{layout}] (step 10, {len(dev)} parameters): median deviation {np.median(dev):.3e}, 90th percentile {np.percentile(dev, 90):.3e}")
+    assert np.median(dev) <= 0.1, np.median(dev)
+
+
 @pytest.mark.parametrize("layout", ["padded", "packed"])
 def test_twenty_step_loss_curve_grande_vs_reference(gr, layout):
     """north_star "loss-curve equivalent to reference" AT THE HEADLINE ARCHITECTURE: 20 optimiser steps (clip-norm 10, AdamW
@@ -136,9 +175,14 @@ def test_twenty_step_loss_curve_grande_vs_reference(gr, layout):
     eng.adam_m.zero_(); eng.adam_v.zero_(); eng.step_count = 0
     n = int(g["n_steps"])
     rec = dict(loss=[], ar=[], clip=[], gradnorm=[])
+    mid = int(g["mid_step"])
     for step in range(n):
+        if step == mid:
+            _mid_curve_weights(g, P, names, eng, layout)
         eng.train_step(db[step % 4], masks[step].to(DEV), lr=5e-4, weight_decay=0.1, max_norm=10.0)
         L = eng.losses()
+        if step == mid:
+            _mid_curve_grad_norms(g, names, eng, layout)
         rec["loss"].append(L["loss"]); rec["ar"].append(L["ar_loss"]); rec["clip"].append(L["clip_loss"]); rec["gradnorm"].append(L["grad_norm"])
     dev_ = {k: np.abs(np.array(v) - g["curve_" + k]) / np.maximum(np.abs(g["curve_" + k]), 1e-6) for k, v in rec.items()}
     log("grande 20-step curve: reference ar " + " ".join(f"{x:.3f}" for x in g["curve_ar"]))

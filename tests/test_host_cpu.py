@@ -187,6 +187,43 @@ def test_trie_tokenizer_matches_reference_golden(golden_dir):
         assert t.split(c["text"]) == c["split"], (c["words"], c["text"])
 
 
+def test_trie_tokenizer_on_real_vocabulary_slice(golden_dir):
+    """The same on a 2 697-token slice of the reference's REAL `may_closedparen` vocabulary (multi-character SMILES fragments,
+    overlapping longest matches) and 640 rows: ids of every row, KeyError / oversize rows, batch_smiles on all 640 rows
+    (threaded C++ batch encoder) and decode -- vectors written by the reference's TrieTokenizer (gen_golden_tokenizer.py)."""
+    import contextlib
+    import io
+    import json
+    from coati_amd.models.encoding.tokenizers import TrieTokenizer
+    g = json.load(open(os.path.join(golden_dir, "tokenizer_real.json")))
+    assert len(g["special"]) + len(g["smiles"]) >= 2000 and len(g["cases"]) >= 500
+    assert max(len(t) for t in g["smiles"]) >= 16          # real multi-character fragments, not a toy alphabet
+    tk = TrieTokenizer(n_seq=g["n_seq"], smiles_tokens=g["smiles"], special_tokens=g["special"])
+    assert tk.n_token == len(g["special"]) + len(g["smiles"])
+    assert (tk.pad_token, tk.stop_token, tk.smiles_token, tk.suffix_token, tk.middle_token, tk.unk_token, tk.clip_token) == (0, 1, 2, 5, 6, 7, 8)
+    n_ok = 0
+    for c in g["cases"]:
+        text = "[SMILES]" + c["row"] + "[STOP]"
+        if "pieces" in c:
+            assert tk.pre_tokenize(text) == c["pieces"], c["row"]
+        with contextlib.redirect_stdout(io.StringIO()):
+            try:
+                r = ["ok", tk.tokenize_text(text, pad=False)]
+            except KeyError as e:
+                r = ["KeyError", str(e)]
+            except Exception as e:
+                r = ["Exception", str(e.args)]
+        assert r == c["result"], (c["row"], r, c["result"])
+        n_ok += r[0] == "ok"
+    assert n_ok >= 500
+    rows = [c["row"] for c in g["cases"]]
+    with contextlib.redirect_stdout(io.StringIO()):
+        bs, bad = tk.batch_smiles(rows, skip_failed=True)
+    assert bad == g["batch_bad"] and bs.tolist() == g["batch_tokens"]
+    okc = [c for c in g["cases"] if c["result"][0] == "ok"][:40]
+    assert [tk.decode(c["result"][1], special=sp) for c in okc for sp in (True, False)] == g["decoded"]
+
+
 def test_bench_gpus_flag_launches_that_many_ranks():
     """`python bench.py --gpus N` (the driver's command form) must become N ranks: the script re-executes itself under
     torch.distributed.run.  COATI_BENCH_LAUNCH_CHECK=1 stops each rank after the rendezvous (gloo here, no GPU)."""

@@ -217,6 +217,26 @@ def test_three_steps_loss_curve(vec, small, golden_dir):
         close(P[k], torch.from_numpy(A3[k]), tol=1e-4, name="after3 " + k)
 
 
+def test_mid_curve_step_from_the_references_weights(small, golden_dir):
+    """tests/golden/loss_curve_mid.npz: the reference's weights at the start of step 21 of its 40-step curve and the gradients
+    it computes from them (not an envelope along a trajectory: one step from pinned weights)."""
+    _, cfg = small
+    m = np.load(os.path.join(golden_dir, "loss_curve_mid.npz"))
+    c = np.load(os.path.join(golden_dir, "loss_curve.npz"))
+    step = int(m["step"])
+    P = {k[2:]: torch.from_numpy(m[k]).clone().requires_grad_(True) for k in m.files if k.startswith("w.")}
+    b = {k: torch.from_numpy(c[f"b{step % 8}_{k}"]) for k in ("raw_tokens", "tokens", "atoms", "coords", "y_next")}
+    loss, ar, cl, _ = O.step_loss(P, cfg, b, torch.ones(b["atoms"].shape[0], dtype=torch.bool))
+    close(loss, m["loss"], name="mid loss")
+    assert abs(float(m["loss"]) - float(c["loss"][step])) < 1e-6 * abs(float(m["loss"]))   # it IS the curve's step
+    loss.backward()
+    grads = {k: (P[k].grad if P[k].grad is not None else torch.zeros_like(P[k])) for k in P}
+    for k in P:
+        close(grads[k], torch.from_numpy(m["g." + k]), tol=1e-4, name="mid grad " + k)
+    norm, _ = O.clip_grad_norm(grads, 10.0)
+    close(norm, m["gradnorm"], tol=1e-4, name="mid gradnorm")
+
+
 def test_sim_bf16_is_close_to_fp32(vec, small):
     """The bf16-storage simulation stays within the tolerance the GPU tests use vs fp32."""
     P, cfg = small
