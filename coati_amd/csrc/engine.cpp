@@ -765,7 +765,7 @@ int xformer_bwd(coati_engine* e, XPass& p, const void* dyf, int dyf_f32, float* 
   const bool defer = 2 * L + 1 <= COATI_LN_MAX_SLOTS;
   const long long slot_stride = (long long)COATI_LN_PARTIAL_ROWS * 2 * C;
   LnFinishBatch fin;
-  fin.n = 0;
+  memset(&fin, 0, sizeof(fin));
   int nblk = 0;
   auto ln_bwd = [&](const void* dy, int dy_f32, const float* x, const float* mean, const float* rstd, const float* gamma,
                     const float* dres, size_t goff, size_t boff, bf16_t* dx16) -> int {
@@ -773,6 +773,28 @@ int xformer_bwd(coati_engine* e, XPass& p, const void* dyf, int dyf_f32, float* 
     fin.dg_off[fin.n] = (long long)goff;
     fin.db_off[fin.n] = (long long)boff;
     return launch_layernorm_bwd_deferred(dy, dy_f32, C, x, C, 0, mean, rstd, gamma, dres, DX, dx16, e->ln_part_x + (fin.n++) * slot_stride, &nblk, M, C, s);
+  };
+  // An input-gradient product whose result is the gradient w.r.t. a LayerNorm's OUTPUT (fc1 -> ln_2, c_attn -> ln_1) with that
+  // LayerNorm's backward in the product's write-out (gemm_ring.hip EPI_LNBWD): dy never visits HBM, one launch instead of two.
+  // Returns 1 when the fused launch ran, 0 when the shape does not take it (the caller then runs the two launches), < 0 on error.
+  auto dgrad_lnbwd = [&](int site, const bf16_t* dY, int K, const bf16_t* WT, const float* x, const float* mean, const float* rstd,
+                         const float* gamma, size_t goff, size_t boff, bf16_t* dx16) -> int {
+    if (!defer || c.use_fp8) return 0;
+    GemmArgs a;
+    memset(&a, 0, sizeof(a));
+    a.A = dY; a.lda = K; a.B = WT; a.ldb = K; a.M = M; a.N = C; a.K = K; a.C = DX; a.ldc = C; a.aux_in = DX; a.ld_aux = C; a.aux_out = dx16;
+    a.lnb_x = x; a.lnb_ldx = C; a.lnb_mean = mean; a.lnb_rstd = rstd; a.lnb_gamma = gamma;
+    int nwg = 0;
+    if (!gemm_ring_lnbwd_supported(a, &nwg) || nwg > COATI_LN_PARTIAL_ROWS) return 0;
+    a.lnb_partial = e->ln_part_x + fin.n * slot_stride;
+    fin.dg_off[fin.n] = (long long)goff;
+    fin.db_off[fin.n] = (long long)boff;
+    fin.nblk[fin.n] = nwg;
+    ++fin.n;
+    // algorithmic bytes: dY + weight in; x, dres in; dx (f32) + its bf16 copy out
+    ProfScope ps(e, site, 2.0 * M * C * K, s, (double)M * K * 2 + (double)C * K * 2 + (double)M * C * (4 + 4 + 4 + (dx16 ? 2 : 0)));
+    const int rc = launch_gemm_nt(a, 0, EPI_LNBWD, s);
+    return rc == COATI_OK ? 1 : rc;
   };
   // Weight gradients: immediately, one launch per Linear (small shapes), or deferred to ONE grouped launch at the end of
   // this call (grouped = every activation gradient of the layer range stays alive in its own buffer).
@@ -792,6 +814,7 @@ int xformer_bwd(coati_engine* e, XPass& p, const void* dyf, int dyf_f32, float* 
     bf16_t* const dh4 = grp ? e->w_dh4[l] : e->dh4;
     bf16_t* const dqkv = grp ? e->w_dqkv[l] : e->dqkv;
     bf16_t* const dx_out = l == 0 ? nullptr : (grp ? e->w_dxa[l - 1] : e->DX16);   // d x[l] (bf16) for the layer below; below layer 0 the embedding backward reads the f32 stream
+    int ln2_fused = 0, ln1_fused = 0;
     if (p.tail && l == L - 1) {
       // the last layer's MLP and ln_2 exist on the B [STOP] rows only (XPass::tail): their backward on those rows, the two weight
       // gradients as small launches of their own (the grouped table leaves them out), then the residual-stream gradient is
@@ -823,15 +846,17 @@ int xformer_bwd(coati_engine* e, XPass& p, const void* dyf, int dyf_f32, float* 
         COATI_TRY(gemm8(e, SITE_FC1_DGRAD, w, 6, nullptr, 4 * C, M, C, 4 * C, a, EPI_BF16, s));
       } else {
       COATI_TRY(gemm(e, SITE_FC2_DGRAD, dxa, 0, C, e->S + w.fc2T, C, M, 4 * C, C, dh4, 4 * C, nullptr, EPI_MUL_AUX, p.hpre[l], nullptr, 4 * C, s));
-      // hpre = a2 W1^T + b1
-      COATI_TRY(gemm(e, SITE_FC1_DGRAD, dh4, 0, 4 * C, e->S + w.fc1T, 4 * C, M, C, 4 * C, e->da, C, nullptr, EPI_BF16, nullptr, nullptr, 0, s));
+      // hpre = a2 W1^T + b1 ; at packed-batch sizes with ln_2's backward in the write-out
+      ln2_fused = dgrad_lnbwd(SITE_FC1_DGRAD, dh4, 4 * C, e->S + w.fc1T, p.xmid[l], p.mean2[l], p.rstd2[l], e->P + w.ln2w, w.ln2w, w.ln2b, dxb);
+      if (ln2_fused < 0) return ln2_fused;
+      if (!ln2_fused) COATI_TRY(gemm(e, SITE_FC1_DGRAD, dh4, 0, 4 * C, e->S + w.fc1T, 4 * C, M, C, 4 * C, e->da, C, nullptr, EPI_BF16, nullptr, nullptr, 0, s));
       }
       if (!grp) {
         COATI_TRY(wgrad(e, SITE_XF_WGRAD, dh4, 0, 4 * C, p.a2[l], C, M, 4 * C, C, e->G + w.fc1w, C, e->G + w.fc1b, 0, s));
         // (the fc2 weight gradient runs after the two consumers of dh4, so that dh4 is re-read while it is still warm)
         COATI_TRY(wgrad(e, SITE_XF_WGRAD, dxa, 0, C, p.g[l], 4 * C, M, C, 4 * C, e->G + w.fc2w, 4 * C, e->G + w.fc2b, 0, s));
       }
-      {
+      if (!ln2_fused) {
         ProfScope ps(e, SITE_LN_BWD, 0, s, (double)M * C * (2 + 4 + 4 + 4 + 2));   // dy16, x, dres in; dx, dx16 out
         COATI_TRY(ln_bwd(e->da, 0, p.xmid[l], p.mean2[l], p.rstd2[l], e->P + w.ln2w, DX, w.ln2w, w.ln2b, dxb));
       }
@@ -856,10 +881,12 @@ int xformer_bwd(coati_engine* e, XPass& p, const void* dyf, int dyf_f32, float* 
       a.C = e->da; a.ldc = C;
       COATI_TRY(gemm8(e, SITE_QKV_DGRAD, w, 4, dqkv, 3 * C, M, C, 3 * C, a, EPI_BF16, s));
     } else {
-    COATI_TRY(gemm(e, SITE_QKV_DGRAD, dqkv, 0, 3 * C, e->S + w.attnT, 3 * C, M, C, 3 * C, e->da, C, nullptr, EPI_BF16, nullptr, nullptr, 0, s));
+    ln1_fused = dgrad_lnbwd(SITE_QKV_DGRAD, dqkv, 3 * C, e->S + w.attnT, p.x[l], p.mean1[l], p.rstd1[l], e->P + w.ln1w, w.ln1w, w.ln1b, dx_out);
+    if (ln1_fused < 0) return ln1_fused;
+    if (!ln1_fused) COATI_TRY(gemm(e, SITE_QKV_DGRAD, dqkv, 0, 3 * C, e->S + w.attnT, 3 * C, M, C, 3 * C, e->da, C, nullptr, EPI_BF16, nullptr, nullptr, 0, s));
     }
     if (!grp) COATI_TRY(wgrad(e, SITE_XF_WGRAD, dqkv, 0, 3 * C, p.a1[l], C, M, 3 * C, C, e->G + w.attnw, C, e->G + w.attnb, 0, s));
-    {
+    if (!ln1_fused) {
       ProfScope ps(e, SITE_LN_BWD, 0, s, (double)M * C * (2 + 4 + 4 + 4 + 2));   // dy16, x, dres in; dx, dx16 out
       COATI_TRY(ln_bwd(e->da, 0, p.x[l], p.mean1[l], p.rstd1[l], e->P + w.ln1w, DX, w.ln1w, w.ln1b, dx_out));
     }

@@ -266,7 +266,11 @@ int launch_gemm_nt(const GemmArgs& a, int a_f32, int epi, hipStream_t s) {
   COATI_CHECK_ARG(a.C || epi == EPI_CE_PARTIAL, "gemm_nt: null output");
   COATI_CHECK_SHAPE(a.M > 0 && a.N > 0 && a.K > 0 && a.K % BK == 0, "gemm_nt: K=%d must be a positive multiple of %d", a.K, BK);
   COATI_CHECK_SHAPE(a.lda % (a_f32 ? 4 : 8) == 0 && a.ldb % 8 == 0, "gemm_nt: lda/ldb alignment (lda=%lld ldb=%lld)", a.lda, a.ldb);
-  const bool out_f32 = (epi == EPI_F32 || epi == EPI_RES_F32 || epi == EPI_ACC_F32);
+  const bool out_f32 = (epi == EPI_F32 || epi == EPI_RES_F32 || epi == EPI_ACC_F32 || epi == EPI_LNBWD);
+  if (epi == EPI_LNBWD) {   // the ring GEMM's fused LayerNorm backward: no other kernel has it (callers ask gemm_ring_lnbwd_supported first)
+    COATI_CHECK_ARG(!a_f32, "gemm_nt: EPI_LNBWD takes a bf16 A operand");
+    return launch_gemm_ring256(a, epi, s);
+  }
   if (epi != EPI_CE_PARTIAL)
     COATI_CHECK_SHAPE(a.ldc % (out_f32 ? 4 : 8) == 0, "gemm_nt: ldc=%lld alignment", a.ldc);
   COATI_CHECK_SHAPE(((long long)a.M + 128) * a.ldc < (1LL << 32) && ((long long)a.M + 128) * a.ld_aux < (1LL << 32),

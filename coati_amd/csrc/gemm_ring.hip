@@ -44,6 +44,19 @@ __device__ __forceinline__ void rg_dma16(const void* g, unsigned lds) {   // per
 __device__ __forceinline__ void rg_dma16s(const void* base, unsigned off, unsigned lds) {   // scalar base + lane offset
   asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(base), "s"(lds) : "memory", "m0");
 }
+// uniform base + 32-bit BYTE offset per lane + compile-time immediate: the global_load / global_store "saddr" form (one VGPR of
+// address per row instead of a 64-bit pair per access)
+template <typename T> __device__ __forceinline__ T rg_ld(const T* base, unsigned byte_off, int imm) {
+  return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_off + imm);
+}
+// (volatile: a second read of the same address must BE a second read -- the compiler otherwise keeps the first one's value alive in
+// registers it does not have)
+template <typename T> __device__ __forceinline__ T rg_ld_again(const T* base, unsigned byte_off, int imm) {
+  return *reinterpret_cast<const volatile T*>(reinterpret_cast<const char*>(base) + byte_off + imm);
+}
+template <typename T> __device__ __forceinline__ void rg_st(T* base, unsigned byte_off, int imm, T v) {
+  *reinterpret_cast<T*>(reinterpret_cast<char*>(base) + byte_off + imm) = v;
+}
 __device__ __forceinline__ int rg_frag_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
 // s_waitcnt vmcnt(n) for the values the ring uses (the count is an immediate); anything else waits for less
@@ -465,7 +478,154 @@ __global__ __launch_bounds__(64 * R1_WAVES, 1) void gemm_ring1_kernel(GemmArgs p
   // ---- write-out straight from the accumulator layout (one register: 32 consecutive columns of one row per half-wave)
   const int wrow0 = row0 + wm * 32;
   const bool full = (wm + 1) * 32 <= nvalid;   // wave-uniform
-  if (EPI == EPI_RES_F32) {
+  if (EPI == EPI_LNBWD) {
+    // The product IS dy of a LayerNorm over these 256 columns (fc1 / c_attn input gradients -> ln_2 / ln_1): its backward runs here
+    // on the accumulators instead of in a kernel of its own (one bf16 round trip of dy through HBM and 64 launches per pass less):
+    //   g = dy gamma ; c1 = mean_n g ; c2 = mean_n (g xhat) ; dx = rstd (g - c1 - xhat c2) + dres ; dgamma += dy xhat ; dbeta += dy
+    // A row's 256 columns live in the two waves (wn = 0 / 1) of its row group, 4 per lane: the two row sums are reduced over the 32
+    // lanes of a half-wave by a halving butterfly (8 values -> 9 shuffles) and exchanged with the partner wave through LDS (the ring
+    // is idle by now), 4 row slots ("a quarter") per exchange.  Registers are what bounds the write-out (128 per wave, 64 of them
+    // accumulators): the second half of the accumulators waits in LDS while the first half is written out, and the loads run one
+    // quarter ahead of their use -- x(q + 1) is issued slot by slot while quarter q is stored, dres(q) while its sums are reduced --
+    // so that no memory round trip sits between two barriers.
+    asm volatile("s_barrier" ::: "memory");     // every wave is done with the ring before its LDS becomes scratch
+    float* stash = reinterpret_cast<float*>(smem) + wave * 2048;         // [8 registers][64 lanes][4 column blocks] per wave: 8 KiB
+    float* red = reinterpret_cast<float*>(smem) + R1_WAVES * 2048;       // [4 quarters][14 waves][2 half-waves][8]
+    float* red2 = red + 4 * R1_WAVES * 16;                               // [7 row groups][512]: dgamma | dbeta partials
+    const int hw = lane >> 5;
+    // uniform base pointers + one 32-bit BYTE offset per row (x, dres, dx and dx16 share one row pitch: launch check)
+    const float* const xin = p.lnb_x;
+    const float* const res = reinterpret_cast<const float*>(p.aux_in);
+    float* const out = reinterpret_cast<float*>(p.C);
+    bf16_t* const out16 = reinterpret_cast<bf16_t*>(p.aux_out);   // (same row pitch in elements: byte offsets halve)
+    const bool has16 = p.aux_out != nullptr;
+    const unsigned col0 = (unsigned)(wn * 128 + fr);
+    float gm[4], dgam[4], dbet[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { gm[j] = p.lnb_gamma[col0 + j * 32]; dgam[j] = 0.f; dbet[j] = 0.f; }
+    const float invC = 1.0f / 256.0f;
+    if (!full) {   // rows behind the span hold whatever the unloaded LDS held: zero them in place, once (wave-uniform branch)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const bool rok = wrow0 + rg_frag_row(r, lane) < row_end;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j][r] = rok ? acc[j][r] : 0.f;
+      }
+    }
+    // accumulator registers 8 .. 15 (quarters 2, 3) wait in LDS
+#pragma unroll
+    for (int r = 8; r < 16; ++r)
+      *reinterpret_cast<float4*>(stash + ((r - 8) * 64 + lane) * 4) = make_float4(acc[0][r], acc[1][r], acc[2][r], acc[3][r]);
+    float xq[2][4][4], mu[2][4], rs[2][4];
+    unsigned ro[2][4];
+    auto issue_x = [&](int q, int i) __attribute__((always_inline)) {
+      const int b = q & 1;
+      const int row = wrow0 + i + 8 * q + 4 * hw;      // = wrow0 + rg_frag_row(4 q + i, lane)
+      const int rc = (full || row < row_end) ? row : row_end - 1;
+      ro[b][i] = ((unsigned)rc * (unsigned)p.ldc + col0) * 4u;
+      mu[b][i] = p.lnb_mean[rc]; rs[b][i] = p.lnb_rstd[rc];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) xq[b][i][j] = rg_ld(xin, ro[b][i], j * 128);
+    };
+#pragma unroll
+    for (int i = 0; i < 4; ++i) issue_x(0, i);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int b = q & 1;
+      if (q == 2) {   // quarters 0, 1 are out: their accumulators are dead, the other half comes back from LDS
+#pragma unroll
+        for (int r = 8; r < 16; ++r) {
+          const float4 t4 = *reinterpret_cast<const float4*>(stash + ((r - 8) * 64 + lane) * 4);
+          acc[0][r] = t4.x; acc[1][r] = t4.y; acc[2][r] = t4.z; acc[3][r] = t4.w;
+        }
+      }
+      // dres of this quarter: in flight while the sums are reduced
+      float dr[4][4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dr[i][j] = rg_ld(res, ro[b][i], j * 128);
+      float v[8];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float a = acc[j][4 * q + i];
+          const float xn = (xq[b][i][j] - mu[b][i]) * rs[b][i];
+          const float g = a * gm[j];
+          s1 += g; s2 += g * xn;
+          dgam[j] += a * xn; dbet[j] += a;
+          xq[b][i][j] = xn;
+        }
+        v[2 * i] = s1; v[2 * i + 1] = s2;
+      }
+      // pin the column sums HERE: left alone the compiler sinks all 128 updates to the end of the kernel (that is where they are
+      // used), which keeps every accumulator and every normalised value alive until then -- 200 spilled registers
+#pragma unroll
+      for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(dgam[j]), "+v"(dbet[j]));
+      // halving butterfly over the 32 lanes of the half-wave: lane l ends with the total of value (l >> 2) & 7
+      {
+        const bool b4 = (lane & 16) != 0, b3 = (lane & 8) != 0, b2 = (lane & 4) != 0;
+        float w[4], u[2], t;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float send = b4 ? v[i] : v[i + 4], mine = b4 ? v[i + 4] : v[i];
+          w[i] = mine + __shfl_xor(send, 16, 64);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const float send = b3 ? w[i] : w[i + 2], mine = b3 ? w[i + 2] : w[i];
+          u[i] = mine + __shfl_xor(send, 8, 64);
+        }
+        {
+          const float send = b2 ? u[0] : u[1], mine = b2 ? u[1] : u[0];
+          t = mine + __shfl_xor(send, 4, 64);
+        }
+        t += __shfl_xor(t, 2, 64);
+        t += __shfl_xor(t, 1, 64);
+        if ((lane & 3) == 0) red[((q * R1_WAVES + wave) * 2 + hw) * 8 + ((lane >> 2) & 7)] = t;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // the sums are in LDS before any wave reads its partner's
+      const float4* mine4 = reinterpret_cast<const float4*>(red + ((q * R1_WAVES + wave) * 2 + hw) * 8);
+      const float4* part4 = reinterpret_cast<const float4*>(red + ((q * R1_WAVES + (wave ^ 1)) * 2 + hw) * 8);
+      const float4 m0 = mine4[0], m1 = mine4[1], p0 = part4[0], p1 = part4[1];
+      const float c1[4] = {(m0.x + p0.x) * invC, (m0.z + p0.z) * invC, (m1.x + p1.x) * invC, (m1.z + p1.z) * invC};
+      const float c2[4] = {(m0.y + p0.y) * invC, (m0.w + p0.w) * invC, (m1.y + p1.y) * invC, (m1.w + p1.w) * invC};
+      // dx of the quarter, slot by slot; behind every slot the same slot of the NEXT quarter's x goes on its way
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = wrow0 + i + 8 * q + 4 * hw;
+        if (full || row < row_end) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float o = rs[b][i] * (acc[j][4 * q + i] * gm[j] - c1[i] - xq[b][i][j] * c2[i]) + dr[i][j];
+            rg_st(out, ro[b][i], j * 128, o);
+            if (has16) rg_st(out16, ro[b][i] >> 1, j * 64, f2bf(o));
+          }
+        }
+        if (q < 3) issue_x(q + 1, i);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    // dgamma | dbeta: the two half-waves hold different rows of the same columns; then the 7 row groups through LDS
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { dgam[j] += __shfl_xor(dgam[j], 32, 64); dbet[j] += __shfl_xor(dbet[j], 32, 64); }
+    if (hw == 0) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        red2[wm * 512 + col0 + j * 32] = dgam[j];
+        red2[wm * 512 + 256 + col0 + j * 32] = dbet[j];
+      }
+    }
+    __syncthreads();
+    if (tid < 512) {
+      float t = 0.f;
+#pragma unroll
+      for (int g = 0; g < R1_GROUPS; ++g) t += red2[g * 512 + tid];
+      p.lnb_partial[(long long)blockIdx.x * 512 + tid] = t;
+    }
+  } else if (EPI == EPI_RES_F32) {
     const float* res = reinterpret_cast<const float*>(p.aux_in) + wn * 128 + fr;
     float* out = reinterpret_cast<float*>(p.C) + wn * 128 + fr;
 #pragma unroll
@@ -708,7 +868,25 @@ static int launch_ring1w_t(const GemmArgs& a, int R, hipStream_t s) {
   return COATI_OK;
 }
 
+// EPI_LNBWD exists in the one-round kernel only (the packed batch: 40 961 .. 57 344 rows); every other size keeps the two launches
+bool gemm_ring_lnbwd_supported(const GemmArgs& a, int* nwg) {
+  static const bool off = getenv("COATI_NO_LNBWD_FUSE") != nullptr;   // A/B switch: bf16 product + stand-alone LayerNorm backward
+  if (off || a.m_dev || a.N != 256 || a.K % RG_BK != 0 || a.K < 256) return false;
+  if (130LL * a.lda >= (1LL << 30) || 260LL * a.ldb >= (1LL << 30)) return false;
+  const int R = cdiv(cdiv(a.M, 256), 8) * 8;
+  if (!(R <= R1_BR && a.M > 256 * 160)) return false;
+  if (nwg) *nwg = cdiv(a.M, R);
+  return true;
+}
+
 int launch_gemm_ring256(const GemmArgs& a, int epi, hipStream_t s) {
+  if (epi == EPI_LNBWD) {
+    int nwg = 0;
+    COATI_CHECK_SHAPE(gemm_ring_lnbwd_supported(a, &nwg), "gemm_ring: EPI_LNBWD needs N = 256 and 40 961 .. 57 344 rows (M=%d N=%d K=%d)", a.M, a.N, a.K);
+    COATI_CHECK_ARG(a.lnb_x && a.lnb_mean && a.lnb_rstd && a.lnb_gamma && a.lnb_partial && a.aux_in && a.C && a.bias == nullptr, "gemm_ring: EPI_LNBWD operands missing");
+    COATI_CHECK_SHAPE(a.lnb_ldx == a.ldc && a.ld_aux == a.ldc && ((long long)a.M + 8) * a.ldc * 4 < (1LL << 32), "gemm_ring: EPI_LNBWD wants one row pitch for x / dres / dx (ldx=%lld ld_aux=%lld ldc=%lld)", a.lnb_ldx, a.ld_aux, a.ldc);
+    return launch_ring1_t<EPI_LNBWD>(a, cdiv(cdiv(a.M, 256), 8) * 8, s);
+  }
   // block height: rows the busiest of the 256 persistent workgroups walks = rounds x block rows; ties go to the 160-row form
   // (less weight re-streaming per row).  COATI_RING_ROWS = 128 | 160 forces one (A/B switch).
   static const int force = getenv("COATI_RING_ROWS") ? atoi(getenv("COATI_RING_ROWS")) : 0;

@@ -21,7 +21,10 @@ enum CoatiEpi {
   EPI_QKV_ROPE = 11,   // C(bf16) = RoPE(acc + bias) on the q and k column blocks (cols < 2*rope_C), plain on v
   EPI_GELU_GRAD = 12,  // aux_out(u8 fixed point, common.h packq8) = NewGELU'(acc + bias) ; C(bf16) = NewGELU(acc + bias): the backward is EPI_MUL_AUX
   EPI_MUL_AUX = 13,    // C(bf16) = acc * dequant(aux_in(u8 fixed point))
-  EPI_COUNT = 14
+  EPI_LNBWD = 14,      // N = C, ring GEMM only: dy = acc is the gradient w.r.t. a LayerNorm's output; C(f32) = aux_in(f32) + LayerNorm-backward(dy | lnb_x, lnb_mean,
+                       // lnb_rstd, lnb_gamma) (aux_in may be C: the residual-stream gradient in place), aux_out(bf16, optional) = its bf16 copy,
+                       // lnb_partial[workgroup][2N] = the workgroup's dgamma | dbeta sums (added up by launch_ln_finish_batched)
+  EPI_COUNT = 15
 };
 
 struct GemmArgs {
@@ -79,11 +82,21 @@ struct GemmArgs {
   const float* ln_beta;     // [K]
   float* ln_mean;           // [M]
   float* ln_rstd;           // [M]
+  // EPI_LNBWD: the LayerNorm whose OUTPUT gradient this product computes
+  const float* lnb_x;       // [M, N] f32: the LayerNorm's input rows
+  long long lnb_ldx;
+  const float* lnb_mean;    // [M]
+  const float* lnb_rstd;    // [M]
+  const float* lnb_gamma;   // [N]
+  float* lnb_partial;       // [workgroups][2 N]
 };
 
 int launch_gemm_nt(const GemmArgs& a, int a_f32, int epi, hipStream_t s);
 // row-block kernel for K = 256 (gemm_rb.hip); launch_gemm_nt dispatches to it when supported
 bool gemm_rb256_supported(const GemmArgs& a, int a_f32, int epi);
+// EPI_LNBWD: true when the ring GEMM takes this shape with the LayerNorm backward in its write-out (gemm_ring.hip); *nwg = the
+// number of partial rows the launch will leave in lnb_partial
+bool gemm_ring_lnbwd_supported(const GemmArgs& a, int* nwg);
 // true when launch_gemm_nt(a, 0, epi) accepts the ln_* fields (LayerNorm fused into the operand load)
 bool gemm_rb256_ln_fusable(const GemmArgs& a, int epi);
 // column width of the EPI_CE_PARTIAL entries launch_gemm_nt writes for these arguments (64 or 128)
@@ -167,6 +180,8 @@ struct LnFinishBatch {
   int n;                                   // slots in use
   long long dg_off[COATI_LN_MAX_SLOTS];    // offsets of dgamma / dbeta of slot i from the gradient base pointer
   long long db_off[COATI_LN_MAX_SLOTS];
+  int nblk[COATI_LN_MAX_SLOTS];            // valid partial rows of slot i (0 = the launch's common count): the stand-alone kernel
+                                           // leaves one row per workgroup of ITS grid, the GEMM-fused backward one per ring workgroup
 };
 int launch_ln_finish_batched(const float* partial, long long slot_stride, int nblk, float* grad_base, const LnFinishBatch& b,
                              int C, hipStream_t s);

@@ -249,6 +249,7 @@ __global__ __launch_bounds__(256) void ln_bwd_finish_batched_kernel(const float*
   __shared__ float red[4][64];
   const int slot = blockIdx.z;
   const float* ps = partial + (long long)slot * slot_stride;
+  if (b.nblk[slot] > 0) nblk = b.nblk[slot];
   const int col = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
   const int per = (nblk + gridDim.y - 1) / gridDim.y;
   const int r0 = blockIdx.y * per;

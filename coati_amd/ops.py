@@ -49,6 +49,22 @@ def gemm_nt(A, W, bias=None, epi=EPI_BF16, aux_in=None, out=None, n_store=0):
     return (out, aux_out) if aux_out is not None else out
 
 
+def gemm_lnbwd(dY, WT, x, mean, rstd, gamma, dres, want16=True):
+    """dy = dY @ WT^T is the gradient w.r.t. the output of LayerNorm(x; gamma): returns (dx f32 = dres + LN-backward(dy), dx16 bf16 | None,
+    dgamma, dbeta) -- the ring GEMM with the LayerNorm backward in its write-out (coati_gemm_lnbwd)."""
+    import ctypes
+    _need_cuda(dY, WT, x)
+    M, K = dY.shape
+    dx = torch.empty(M, 256, device=dY.device, dtype=torch.float32)
+    dx16 = torch.empty(M, 256, device=dY.device, dtype=BF16) if want16 else None
+    partial = torch.zeros(256, 512, device=dY.device, dtype=torch.float32)
+    n = ctypes.c_int32(0)
+    _lib.call("coati_gemm_lnbwd", ptr(dY), dY.stride(0), ptr(WT), WT.stride(0), M, K, ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(dres),
+              ptr(dx), ptr(dx16), ptr(partial), ctypes.byref(n), stream())
+    s = partial[: n.value].sum(0)
+    return dx, dx16, s[:256], s[256:]
+
+
 def quant_mx8(x):
     """rows of bf16 / f32 x [M, K] -> (q [M, K] uint8 holding OCP e4m3, scales [M, K / 32] uint8 holding E8M0): MXFP8 blocks of 32 along k"""
     _need_cuda(x)

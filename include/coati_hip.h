@@ -61,6 +61,16 @@ int coati_gemm_nt(const void* A, int a_f32, int64_t lda, const uint16_t* B, int6
                   void* C, int64_t ldc, int n_store, const float* bias, const void* aux_in, void* aux_out,
                   int64_t ld_aux, int epi, void* stream);
 
+/* An input-gradient product whose result is the gradient w.r.t. a LayerNorm's OUTPUT, with that LayerNorm's backward in the
+ * product's write-out (c_fc -> ln_2 and c_attn -> ln_1 of basic_transformer.py:162-174): dy = dY[M,K] WT[256,K]^T never visits
+ * memory; dx[M,256] (f32) = dres + LayerNorm-backward(dy | x, mean, rstd, gamma) (dx may be dres: in place), dx16 (optional) its
+ * bf16 copy, partial[*n_partial_rows][512] per-workgroup sums of dgamma | dbeta (add the rows up).  Replaces F.linear's input
+ * gradient + nn.LayerNorm's backward.  256 columns, K % 64 == 0, 40 961 .. 57 344 rows (a packed batch; the engine runs the two
+ * kernels separately elsewhere): COATI_ESHAPE otherwise.  partial must hold 256 x 512 floats. */
+int coati_gemm_lnbwd(const uint16_t* dY, int64_t lda, const uint16_t* WT, int64_t ldw, int M, int K, const float* x, const float* mean,
+                     const float* rstd, const float* gamma, const float* dres, float* dx, uint16_t* dx16, float* partial,
+                     int32_t* n_partial_rows, void* stream);
+
 /* MXFP8 (OCP Microscaling: e4m3 elements, one E8M0 scale per 32 consecutive k) -- BASELINE.json configs[4] "fp8 MFMA GEMMs".
  * coati_quant_mx8: rows of bf16 (x_f32 = 0) or f32 x [M, K] -> q [M, K] e4m3 bytes + scales [M, K / 32] (K % 32 == 0; shared
  * exponent floor(log2 amax) - 8, saturating conversion).  coati_gemm_mx8: C[M, N] = epilogue(A W^T + bias) on

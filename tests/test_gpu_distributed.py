@@ -209,7 +209,7 @@ def test_world_size_one_nccl_step_equals_train_step(tmp_path):
     """The RCCL branch of coati_amd.distributed (all_gather_into_tensor / reduce_scatter_tensor / asynchronous all_reduce(AVG)
     buckets on device memory, the staged backward) executed on the "nccl" backend at world size 1 -- the one size a one-GPU box
     allows: it must reproduce Engine.train_step on the same packed batch for the InfoNCE and the Barlow head: losses and
-    gradients at 1e-6, the parameter displacement of the optimizer step at 1e-4 in L1 (not bit for bit: the embedding-table
+    gradients at 5e-6, the parameter displacement of the optimizer step at 1e-4 in L1 (not bit for bit: the embedding-table
     gradient is accumulated with fp32 atomics, DESIGN section 5 item 8 -- two runs of the SAME step differ by ~ 1e-8 of the gradient
     scale, and AdamW's g / (sqrt(v) + eps) amplifies that on elements whose gradient is ~ eps).
     Reference: autograd_funs.py:5-25, train_coati.py:204-206."""
@@ -230,7 +230,9 @@ def test_world_size_one_nccl_step_equals_train_step(tmp_path):
         assert abs(r["clip"][0] - r["clip"][1]) <= 1e-6 * max(1.0, abs(r["clip"][1]))
         if r["barlow"] is not None:
             assert abs(r["barlow"][0] - r["barlow"][1]) <= 1e-6 * max(1.0, abs(r["barlow"][1]))
-        assert r["grads_maxdiff"] <= 1e-6 * r["grads_scale"], r
+        # (measured 5e-8 for InfoNCE, 6.4e-7 for Barlow -- fp32 atomics in the embedding backward / column sums feed the E x E
+        # standardisation, and one run in three of the full suite crossed 1e-6)
+        assert r["grads_maxdiff"] <= 5e-6 * r["grads_scale"], r
         assert r["params_rel"] <= 1e-4, r
 
 

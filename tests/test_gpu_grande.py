@@ -147,7 +147,7 @@ def _mid_curve_weights(g, P, names, eng, layout):
     worst.sort()
     log(f"grande mid-curve weights [{layout}]: displacement after 10 steps vs reference: cosine median {np.median(cos_all):.4f} min {worst[0][0]:.4f} "
         f"({worst[0][1]}), length ratio {min(len_all):.3f} .. {max(len_all):.3f}")
-    assert np.median(cos_all) >= 0.97 and worst[0][0] >= 0.85, worst[:4]
+    assert np.median(cos_all) >= 0.99 and worst[0][0] >= 0.95, worst[:4]     # measured 0.9995 / 0.9983 (tok_emb)
     assert 0.9 <= min(len_all) and max(len_all) <= 1.1, (min(len_all), max(len_all))
 
 
@@ -161,7 +161,7 @@ def _mid_curve_grad_norms(g, names, eng, layout):
         if ref[i] > 0:
             dev.append(abs(float(grads[n_].double().norm()) - ref[i]) / ref[i])
     log(f"grande mid-curve gradient norms [{layout}] (step 10, {len(dev)} parameters): median deviation {np.median(dev):.3e}, 90th percentile {np.percentile(dev, 90):.3e}")
-    assert np.median(dev) <= 0.1, np.median(dev)
+    assert np.median(dev) <= 0.15, np.median(dev)     # measured 7.2e-2 (padded), 2.0e-2 (packed): the clip-norm there is ~ 5, see TOL_CURVE_GN_*
 
 
 @pytest.mark.parametrize("layout", ["padded", "packed"])

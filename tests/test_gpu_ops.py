@@ -168,6 +168,41 @@ def test_layernorm(ops, M, C, affine):
         check(f"ln bwd xhat {M}x{C}", dx, xr.grad, 4e-7)
 
 
+@pytest.mark.parametrize("M,K", [(50003, 1024), (45000, 768), (57344, 256), (40961, 1024)])
+def test_gemm_with_layernorm_backward_in_the_write_out(ops, M, K):
+    """coati_gemm_lnbwd (gemm_ring.hip EPI_LNBWD): the input-gradient product of c_fc / c_attn with the backward of the LayerNorm in
+    front of that Linear fused into its write-out, against fp32 torch: F.linear on the bf16 operands, then autograd through
+    F.layer_norm (basic_transformer.py:162-174).  Ragged last span, a span that ends inside a row group, K = 256 / 768 / 1024."""
+    g = torch.Generator().manual_seed(M + K)
+    dY = rbf(torch.randn(M, K, generator=g) * 0.5).to(DEV)
+    WT = rbf(torch.randn(256, K, generator=g) / math.sqrt(K)).to(DEV)
+    x = (torch.randn(M, 256, generator=g) * 1.7 + 0.2).to(DEV)
+    gamma = (1 + 0.2 * torch.randn(256, generator=g)).to(DEV)
+    beta = (0.1 * torch.randn(256, generator=g)).to(DEV)
+    dres = torch.randn(M, 256, generator=g).to(DEV)
+    _, _, mean, rstd = ops.layernorm_fwd(x, gamma, beta, want16=True, want32=False)
+    xr, gr, br = x.clone().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    y = torch.nn.functional.layer_norm(xr, (256,), gr, br, 1e-5)
+    dy = dY @ WT.t()                                  # fp32 product of the bf16-valued operands
+    y.backward(dy)
+    ref_dx = xr.grad + dres
+    dx, dx16, dg, db = ops.gemm_lnbwd(dY.bfloat16(), WT.bfloat16(), x, mean, rstd, gamma, dres)
+    check(f"gemm+ln bwd dx {M}x{K}", dx, ref_dx, 2e-6)
+    check(f"gemm+ln bwd dx16 {M}x{K}", dx16.float(), ref_dx, TB)
+    check(f"gemm+ln bwd dgamma {M}x{K}", dg, gr.grad, 3e-6)
+    check(f"gemm+ln bwd dbeta {M}x{K}", db, br.grad, 3e-6)
+    # in place (dx = dres, as the engine runs it on the residual-stream gradient) and without the bf16 copy
+    dres2 = dres.clone()
+    import ctypes
+    from coati_amd import _lib
+    from coati_amd.ops import ptr, stream
+    partial = torch.zeros(256, 512, device=DEV)
+    n = ctypes.c_int32(0)
+    _lib.call("coati_gemm_lnbwd", ptr(dY.bfloat16()), K, ptr(WT.bfloat16()), K, M, K, ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(dres2),
+              ptr(dres2), None, ptr(partial), ctypes.byref(n), stream())
+    assert torch.equal(dres2, dx)
+
+
 @pytest.mark.parametrize("B,T,nh,hs", [(3, 12, 4, 16), (5, 80, 16, 16), (2, 250, 4, 16), (4, 33, 2, 16),
                                         (3, 12, 4, 32), (3, 80, 16, 32), (2, 250, 3, 32), (4, 33, 2, 32),
                                         (2, 128, 5, 16), (2, 64, 6, 16), (2, 100, 3, 32), (2, 129, 5, 16)])
