@@ -75,6 +75,7 @@ _SIGS = {
     "coati_engine_refresh_shadows": [P, P],
     "coati_engine_bind_fp8": [P, P, L],
     "coati_engine_forward": [P, P, L, I, I, I, I, P, P, P, P, P, P, P, P, P, P, I, L, L, P],
+    "coati_engine_forward_decoder": [P, P],
     "coati_seq_pack": [P, P, I, I, I, I, P, P, P, P, P, P],
     "coati_attn_fwd_varlen": [P, P, P, P, I, I, I, I, P],
     "coati_attn_bwd_varlen": [P, P, P, P, P, P, P, P, P, I, I, I, I, P],

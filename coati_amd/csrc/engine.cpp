@@ -123,6 +123,7 @@ struct coati_engine {
   const int *lut_ix = nullptr, *lut_iy = nullptr;
   // per-step state (pointers into the caller's workspace)
   bool have_fwd = false;
+  bool decoder_pending = false;   // a forward stopped behind the heads (train | 2): coati_engine_forward_decoder runs the decoder pass
   bool have_ws = false;    // the workspace is carved (forward or encode): the InfoNCE / optimizer scratch pointers are valid
   int B = 0, T1 = 0, T2 = 0, A = 0;
   XPass p1, p2;
@@ -1229,12 +1230,43 @@ static int refresh_shadows_impl(coati_engine* e, void* stream, bool natural_done
 
 int coati_engine_refresh_shadows(coati_engine* e, void* stream) { return refresh_shadows_impl(e, stream, false); }
 
+// decoder pass with injection + lm_head / AR cross-entropy: the second half of coati_engine_forward
+static int forward_decoder_impl(coati_engine* e, hipStream_t s) {
+  const coati_config& c = e->cfg;
+  const int C = c.n_hidden_xformer;
+  float* const scal = e->scal;
+  // ---- decoder pass with injection (smiles_xformer.py:426-452) ----
+  COATI_TRY(xformer_fwd(e, e->p2, e->cliptok, s));
+  // ---- lm_head + AR cross-entropy, logits never materialised (smiles_xformer.py:453, train_coati.py:260-265) ----
+  if (e->y_next) {
+    const int M2 = e->p2.M;
+    GemmArgs a;
+    memset(&a, 0, sizeof(a));
+    a.A = e->p2.af; a.lda = C; a.B = e->S + e->lmhead; a.ldb = C; a.M = M2; a.N = c.n_tok; a.K = C; a.partial = e->ce_partial;
+    a.partial_tile = 64;   // ce_partial is sized for 64-column entries: the row-block kernel may take the product
+    const int tiles_v = cdiv(c.n_tok, gemm_ce_tile_width(a));
+    {
+      ProfScope ps(e, SITE_LMHEAD_FWD, 2.0 * M2 * c.n_tok * C, s, (double)M2 * C * 2 + (double)c.n_tok * C * 2);   // logits never leave the chip
+      COATI_TRY(launch_gemm_nt(a, 0, EPI_CE_PARTIAL, s));
+    }
+    COATI_TRY(launch_ce_finish(e->ce_partial, tiles_v, e->p2.af, C, e->S + e->lmhead, C, e->p2.packed ? e->p2.ypk : e->y_next, e->ce_lse, scal, M2, C, c.n_tok, s));
+  }
+  if (hipMemcpyAsync(scal + 6, e->err_flag, sizeof(int), hipMemcpyDeviceToDevice, s) != hipSuccess) {
+    coati_set_error("engine_forward: error-word copy failed");
+    return COATI_EHIP;
+  }
+  e->have_fwd = true;
+  return COATI_OK;
+}
+
 int coati_engine_forward(coati_engine* e, void* workspace, int64_t workspace_bytes, int B, int T1, int T2, int A,
                          const int64_t* raw_tokens, const int64_t* tokens, const int64_t* y_next,
                          const int64_t* atoms, const float* coords, const uint8_t* use_point, float* h_e3gnn,
                          float* h_smiles, uint8_t* bad_rows, float* scal, int train, int64_t rows1, int64_t rows2, void* stream) {
   COATI_CHECK_ARG(e && e->P && e->S, "engine_forward: engine not bound");
   COATI_CHECK_ARG(workspace && raw_tokens && tokens && atoms && coords && use_point && scal, "engine_forward: null argument");
+  const bool stop_after_heads = (train & 2) != 0;   // train | 2: return behind the heads, coati_engine_forward_decoder runs the rest
+  train &= 1;
   COATI_CHECK_ARG(!train || (e->G && y_next), "engine_forward: training needs grads and y_next");
   const coati_config& c = e->cfg;
   COATI_CHECK_SHAPE(B > 0 && T1 > 0 && T2 > 0 && A > 0 && T1 <= c.n_seq && T2 <= c.n_seq,
@@ -1255,6 +1287,7 @@ int coati_engine_forward(coati_engine* e, void* workspace, int64_t workspace_byt
   e->use_point = use_point;
   e->scal = scal;
   e->have_fwd = false;
+  e->decoder_pending = false;
 
 #define HIPCHK(x) do { hipError_t _h = (x); if (_h != hipSuccess) { coati_set_error("%s: %s", #x, hipGetErrorString(_h)); return COATI_EHIP; } } while (0)
   HIPCHK(hipMemsetAsync(scal, 0, 16 * sizeof(float), s));
@@ -1312,29 +1345,23 @@ int coati_engine_forward(coati_engine* e, void* workspace, int64_t workspace_byt
     ptok = e->ptok; stok = e->stok;
   }
   COATI_TRY(launch_select_rows(use_point, ptok, stok, e->cliptok, B, E, s));
-  // ---- decoder pass with injection (smiles_xformer.py:426-452) ----
-  COATI_TRY(xformer_fwd(e, e->p2, e->cliptok, s));
   if (bad_rows) COATI_TRY(launch_bad_rows(e->p2.idx, bad_rows, B, T2, s));
-  // ---- lm_head + AR cross-entropy, logits never materialised (smiles_xformer.py:453, train_coati.py:260-265) ----
-  if (y_next) {
-    const int M2 = e->p2.M;
-    GemmArgs a;
-    memset(&a, 0, sizeof(a));
-    a.A = e->p2.af; a.lda = C; a.B = e->S + e->lmhead; a.ldb = C; a.M = M2; a.N = c.n_tok; a.K = C; a.partial = e->ce_partial;
-    a.partial_tile = 64;   // ce_partial is sized for 64-column entries: the row-block kernel may take the product
-    const int tiles_v = cdiv(c.n_tok, gemm_ce_tile_width(a));
-    {
-      ProfScope ps(e, SITE_LMHEAD_FWD, 2.0 * M2 * c.n_tok * C, s, (double)M2 * C * 2 + (double)c.n_tok * C * 2);   // logits never leave the chip
-      COATI_TRY(launch_gemm_nt(a, 0, EPI_CE_PARTIAL, s));
-    }
-    COATI_TRY(launch_ce_finish(e->ce_partial, tiles_v, e->p2.af, C, e->S + e->lmhead, C, e->p2.packed ? e->p2.ypk : e->y_next, e->ce_lse, scal, M2, C, c.n_tok, s));
-  }
   if (h_e3gnn) HIPCHK(hipMemcpyAsync(h_e3gnn, e->h_e3gnn, (size_t)B * E * sizeof(float), hipMemcpyDeviceToDevice, s));
   if (h_smiles) HIPCHK(hipMemcpyAsync(h_smiles, e->h_smiles, (size_t)B * E * sizeof(float), hipMemcpyDeviceToDevice, s));
-  HIPCHK(hipMemcpyAsync(scal + 6, e->err_flag, sizeof(int), hipMemcpyDeviceToDevice, s));
-  e->have_fwd = true;
   e->have_ws = true;
-  return COATI_OK;
+  if (stop_after_heads) {
+    // the embeddings are out: the caller may run the contrastive head (+ its collectives) on another stream while
+    // coati_engine_forward_decoder enqueues the decoder pass on this one
+    e->decoder_pending = true;
+    return COATI_OK;
+  }
+  return forward_decoder_impl(e, s);
+}
+
+int coati_engine_forward_decoder(coati_engine* e, void* stream) {
+  COATI_CHECK_ARG(e && e->decoder_pending, "engine_forward_decoder: no forward stopped behind the heads (train | 2)");
+  e->decoder_pending = false;
+  return forward_decoder_impl(e, (hipStream_t)stream);
 }
 
 // Inference encoders alone (clip_e2e.py:448-452 encode_tokens, :454-463 encode_points): only the requested tower runs --

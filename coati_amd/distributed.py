@@ -169,18 +169,25 @@ def distributed_train_step(eng, batch, use_point, lr, do_clip=True, optimizer=Tr
     W, rank = dist.get_world_size(), dist.get_rank()
     split_stage, slot = _schedule_begin(eng) if (reduce_grads and optimizer) else (_SPLIT_ENCODER_STAGE, None)
     h_e, h_s, bad = eng.forward(batch["raw_tokens"], batch["tokens"], batch["atoms"], batch["coords"], use_point,
-                                y_next=batch["y_next"], train=True, rows=batch.get("rows"))
+                                y_next=batch["y_next"], train=True, rows=batch.get("rows"), stop_after_heads=True)
     B = h_e.shape[0]
-    dS = dC = None
-    if do_clip and head == "barlow":
-        from .barlow import barlow_head
-        eng.barlow_loss, dS, dC = barlow_head(h_s, h_e, bad, gscale=eng.token_entropy_unit() * W, distributed=True)
-    elif do_clip:
-        s_all, c_all, bad_all = all_gather_cat(h_s), all_gather_cat(h_e), all_gather_cat(bad)
-        # every rank's encoders receive W * d(global clip)/d(h_local); the mean all-reduce below divides by W
-        dS_all, dC_all = eng.infonce(h_s, h_e, s_all, c_all, bad_all, row0=rank * B,
-                                     gscale=0.5 * eng.token_entropy_unit() * W)
-        dS, dC = reduce_scatter_sum(dS_all), reduce_scatter_sum(dC_all)
+
+    def head_fn():
+        if do_clip and head == "barlow":
+            from .barlow import barlow_head
+            return barlow_head(h_s, h_e, bad, gscale=eng.token_entropy_unit() * W, distributed=True)
+        if do_clip:
+            s_all, c_all, bad_all = all_gather_cat(h_s), all_gather_cat(h_e), all_gather_cat(bad)
+            # every rank's encoders receive W * d(global clip)/d(h_local); the mean all-reduce below divides by W
+            dS_all, dC_all = eng.infonce(h_s, h_e, s_all, c_all, bad_all, row0=rank * B,
+                                         gscale=0.5 * eng.token_entropy_unit() * W)
+            return None, reduce_scatter_sum(dS_all), reduce_scatter_sum(dC_all)
+        return None, None, None
+    # the exchange step of the path -- embedding all-gather, local rows x global columns InfoNCE, reduce-scatter (or the Barlow
+    # head's statistics all-reduces) -- needs the embeddings only: it runs on a side stream underneath the decoder pass
+    loss_b, dS, dC = eng.contrastive_under_decoder(head_fn)
+    if head == "barlow" and do_clip:
+        eng.barlow_loss = loss_b
     bk = grad_buckets(eng)
     works = []
 

@@ -303,6 +303,13 @@ int coati_engine_forward(coati_engine* e, void* workspace, int64_t workspace_byt
                          const int64_t* raw_tokens, const int64_t* tokens, const int64_t* y_next,
                          const int64_t* atoms, const float* coords, const uint8_t* use_point, float* h_e3gnn,
                          float* h_smiles, uint8_t* bad_rows, float* scal, int train, int64_t rows1, int64_t rows2, void* stream);
+/* The same forward in two calls: coati_engine_forward(..., train | 2, ...) returns behind the heads -- point encoder, encoder pass,
+ * point_to_clip / smiles_to_clip / special token; h_e3gnn, h_smiles and bad_rows are final -- and coati_engine_forward_decoder
+ * enqueues the rest (decoder pass with the injected token, lm_head + AR cross-entropy).  Between the two the caller may put the
+ * contrastive head (the embedding all-gather, coati_engine_infonce, the reduce-scatter) on ANOTHER stream: it only needs the
+ * embeddings, so it runs underneath the decoder pass instead of in front of the backward (clip_e2e.py:772-814 computes the
+ * embeddings first as well; train_coati.py:256-258 gathers them after the whole forward). */
+int coati_engine_forward_decoder(coati_engine* e, void* stream);
 /* Inference encoders alone: e3gnn_smiles_clip_e2e.encode_tokens (clip_e2e.py:448-452) when raw_tokens + h_smiles are
  * given, .encode_points (clip_e2e.py:454-463) when atoms + coords + h_e3gnn are given (either pair may be null).  Only
  * the requested tower runs; workspace as for coati_engine_forward with T2 = 1.  scal[6] bit 0: a row without exactly

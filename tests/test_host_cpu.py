@@ -268,6 +268,14 @@ class _FakeEngine:
         self.calls.append(("forward", k.get("train")))
         return torch.ones(3, 4), torch.ones(3, 4), torch.zeros(3, dtype=torch.uint8)
 
+    def forward_decoder(self):
+        self.calls.append(("forward_decoder",))
+
+    def contrastive_under_decoder(self, head_fn):
+        """host stand-in for Engine.contrastive_under_decoder: the decoder pass is enqueued first, then the contrastive head"""
+        self.forward_decoder()
+        return head_fn()
+
     def infonce(self, s, c, sa, ca, bad, row0=0, gscale=1.0):
         self.calls.append(("infonce", row0, gscale, tuple(sa.shape)))
         return torch.ones_like(sa), torch.ones_like(ca)
@@ -300,7 +308,8 @@ def test_optimizer_arguments_reach_the_optimizer():
         D.distributed_train_step(e, batch, up, 2e-3, weight_decay=0.07, max_norm=3.0)
         names = [c[0] for c in e.calls]
         # decoder stage | ONE encoder stage (the pass's weight gradients are one grouped launch) | point-encoder stage
-        assert names == ["forward", "infonce", "backward", "backward", "backward", "optimizer_step"]
+        # (the contrastive head is enqueued BEHIND the decoder pass's launches: it runs on a side stream underneath them)
+        assert names == ["forward", "forward_decoder", "infonce", "backward", "backward", "backward", "optimizer_step"]
         assert [c[1] for c in e.calls if c[0] == "backward"] == [1, 2, 3]
         assert e.calls[-1] == ("optimizer_step", 2e-3, {"weight_decay": 0.07, "max_norm": 3.0})
         # the round-1 schedule (encoder stage in two halves) stays available behind COATI_DP_SPLIT=1
