@@ -57,9 +57,9 @@ _SIGS = {
     "coati_batch_tail": [P, I, I, I, P, P, P, I, P],
     "coati_gnn_embed": [P, P, P, P, P, P, P, L, P, P, I, I, P],
     "coati_gnn_geom": [P, P, F, P, P, I, I, P],
+    "coati_gnn_edge_pre": [P, L, P, P, P, P, L, P, P, I, I, P],
+    "coati_gnn_edge_reduce": [P, P, P, P, L, I, I, P],
     "coati_gnn_compact": [P, P, P, P, P, P, P, P, P, P, I, I, P],
-    "coati_gnn_edge_pre": [P, L, P, P, L, P, P, I, I, I, P],
-    "coati_gnn_edge_reduce": [P, P, P, L, I, I, I, P],
     "coati_infonce_rows": [P, L, I, I, I, P, P, P, F, P],
     "coati_count_valid": [P, I, P, P, P],
     "coati_colsum2": [P, P, P, P, I, I, P],

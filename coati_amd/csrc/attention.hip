@@ -880,10 +880,8 @@ int launch_attn_bwd(const bf16_t* qkv, const bf16_t* y, const bf16_t* dy, const 
   COATI_CHECK_ARG(qkv && y && dy && lse && dscratch && dqkv && cos_t && sin_t, "attn_bwd: null operand");
   COATI_CHECK_SHAPE(B > 0 && T > 0 && T <= 256 && n_head > 0 && (head_size == 16 || head_size == 32),
                     "attn_bwd: unsupported shape B=%d T=%d nh=%d hs=%d", B, T, n_head, head_size);
-  // T <= 128: the single-sweep kernel (grande: 120 vs 141 us); COATI_ATTN_FUSED_BWD=0 is the A/B switch back to the two
-  // kernels, which also serve longer sequences
-  static const bool fused = getenv("COATI_ATTN_FUSED_BWD") == nullptr || atoi(getenv("COATI_ATTN_FUSED_BWD")) != 0;
-  if (fused && T <= 128) {
+  // T <= 128: the single-sweep kernel (grande: 120 vs 141 us); longer sequences: the two kernels below
+  if (T <= 128) {
     const int nb = (T + 31) / 32;
     if (seq_off != nullptr) {   // packed rows: sequences of 1-2 blocks in one launch, of 3-4 blocks in another
 #define VL(H, HI, LO) return launch_attn_bwd_fused_varlen_t<H, HI, LO>(qkv, y, dy, lse, dqkv, cos_t, sin_t, B, T, n_head, s, seq_off)

@@ -220,12 +220,13 @@ int coati_gnn_compact(const float* w_dense, const float* d2_dense, int32_t* seg,
                       int32_t* e_rev, float* e_d2, float* e_w, int32_t* pos, int B, int A, void* stream) {
   return launch_gnn_compact(w_dense, d2_dense, seg, n_edges, e_bj, e_bk, e_rev, e_d2, e_w, pos, B, A, S_(stream));
 }
-int coati_gnn_edge_pre(const uint16_t* P, int64_t ldp, const float* d2, const float* w1c, int64_t w1c_stride,
-                       const float* b1, uint16_t* e1, int B, int A, int H, void* stream) {
-  return launch_gnn_edge_pre(P, ldp, d2, nullptr, w1c, w1c_stride, b1, e1, B, A, H, S_(stream));
+
+int coati_gnn_edge_pre(const uint16_t* P, int64_t ldp, const int32_t* seg, const int32_t* e_bk, const float* e_d2, const float* w1c,
+                       int64_t w1c_stride, const float* b1, uint16_t* e1, int BA, int H, void* stream) {
+  return launch_gnn_edge_pre_c(P, ldp, seg, e_bk, e_d2, w1c, w1c_stride, b1, e1, BA, H, S_(stream));
 }
-int coati_gnn_edge_reduce(const uint16_t* s2, const float* w, uint16_t* mi, int64_t ldmi, int B, int A, int H, void* stream) {
-  return launch_gnn_edge_reduce(s2, w, mi, ldmi, B, A, H, S_(stream));
+int coati_gnn_edge_reduce(const uint16_t* s2, const int32_t* seg, const float* e_w, uint16_t* mi, int64_t ldmi, int BA, int H, void* stream) {
+  return launch_gnn_edge_reduce_c(s2, seg, e_w, mi, ldmi, BA, H, S_(stream));
 }
 
 int coati_infonce_rows(float* logits, int64_t ld, int R, int N, int label0, const uint8_t* bad, float* loss_sum,

@@ -543,11 +543,9 @@ size_t carve(coati_engine* e, Arena& ar, int B, int T1, int T2, int A, int Bg) {
   e->t_dh4 = ar.take<bf16_t>((size_t)B * 4 * C); e->t_da = ar.take<bf16_t>((size_t)B * C);
   // deferred weight gradients: 9C bf16 per token and layer (6 GB at B*T = 81,920, L = 16: 288 GB of HBM make this free)
   {
-    static const bool off = getenv("COATI_WGRAD_GROUP") != nullptr && atoi(getenv("COATI_WGRAD_GROUP")) == 0;   // A/B switch
     const int L = c.n_layer_xformer;
-    e->wg_group = !off && C % 128 == 0 && Mmax >= 4096;
-    static const int want_tile = getenv("COATI_WGRAD_TILE") ? atoi(getenv("COATI_WGRAD_TILE")) : 256;                // A/B switch
-    e->wg_tile = (want_tile == 256 && C % 256 == 0 && 40LL * 4 * C < (1LL << 30)) ? 256 : 128;
+    e->wg_group = C % 128 == 0 && Mmax >= 4096;
+    e->wg_tile = (C % 256 == 0 && 40LL * 4 * C < (1LL << 30)) ? 256 : 128;
     e->w_dh4.assign(L, nullptr); e->w_dxa.assign(L, nullptr); e->w_dxb.assign(L, nullptr); e->w_dqkv.assign(L, nullptr);
     if (e->wg_group) {
       for (int l = 0; l < L; ++l) {
@@ -567,8 +565,7 @@ size_t carve(coati_engine* e, Arena& ar, int B, int T1, int T2, int A, int Bg) {
     const long long csig = (((long long)B * 1000003 + T1) * 1000003 + T2) * 1000003 + A;
     if (!e->wg_group || csig != e->carve_sig) for (auto& k : e->wtab_key) k = coati_engine::WTabKey();
     {
-      static const bool goff = getenv("COATI_GNN_WGRAD_GROUP") != nullptr && atoi(getenv("COATI_GNN_WGRAD_GROUP")) == 0;   // A/B switch
-      e->gnn_wg_group = !goff && !off && H % 128 == 0 && BA >= 4096 && Lg > 0;
+      e->gnn_wg_group = H % 128 == 0 && BA >= 4096 && Lg > 0;
       e->gl_DO16.assign(Lg, nullptr); e->gl_du.assign(Lg, nullptr); e->gl_dP.assign(Lg, nullptr);
       if (e->gnn_wg_group) {
         for (int l = 0; l < Lg; ++l) { e->gl_DO16[l] = ar.take<bf16_t>(BA * H); e->gl_du[l] = ar.take<bf16_t>(BA * H); e->gl_dP[l] = ar.take<bf16_t>(BA * 2 * H); }

@@ -283,13 +283,12 @@ int launch_gemm_nt(const GemmArgs& a, int a_f32, int epi, hipStream_t s) {
   if (epi == EPI_QKV_ROPE) COATI_CHECK_ARG(a.rope_cos && a.rope_sin && a.rope_T > 0 && a.rope_C > 0 && a.N % 16 == 0 && a.rope_C % 16 == 0 && (a.rope_hs == 0 || a.rope_hs == 16 || a.rope_hs == 32) && (a.rope_hs != 32 || a.rope_C % 32 == 0), "gemm_nt: rope operands missing / unsupported head size");
   if (epi == EPI_EDGE_DPRE) COATI_CHECK_ARG(a.P && a.d2 && a.w1c && a.b1 && a.natom > 0 && a.ldp % 8 == 0, "gemm_nt: edge operands missing");
   {
-    static const bool no_rb = getenv("COATI_NO_RB") != nullptr;   // A/B switch for benchmarking
     // N = 256 with a bf16 / residual epilogue: the ring kernel, also at K = 256 (proj forward 57 -> 44 us against the
     // row-block kernel); every other K = 256 product: the row-block kernel
-    if (!no_rb && gemm_rb16_resident_supported(a, a_f32, epi)) return launch_gemm_rb16_resident(a, epi, s);
+    if (gemm_rb16_resident_supported(a, a_f32, epi)) return launch_gemm_rb16_resident(a, epi, s);
     if (gemm_ring256_supported(a, a_f32, epi)) return launch_gemm_ring256(a, epi, s);
-    if (!no_rb && gemm_rb16_supported(a, a_f32, epi)) return launch_gemm_rb16(a, epi, s);
-    if (!no_rb && gemm_rb256_supported(a, a_f32, epi)) return launch_gemm_rb256(a, epi, s);
+    if (gemm_rb16_supported(a, a_f32, epi)) return launch_gemm_rb16(a, epi, s);
+    if (gemm_rb256_supported(a, a_f32, epi)) return launch_gemm_rb256(a, epi, s);
   }
 #define NT_CASE(E)                                                                  \
   case E:                                                                           \
@@ -1220,8 +1219,7 @@ int launch_wgrad(const WgradArgs& a, int a_f32, hipStream_t s) {
   if (a_f32) return a.dbias ? launch_wgrad_t<float, true>(a, s) : launch_wgrad_t<float, false>(a, s);
   // bf16 A: the LDS-DMA kernel (one 512-thread workgroup per CU) when the launch gives every CU a tile and a slice of at
   // least 16 stages; otherwise (few rows: GNN node level; many tiles: lm_head) the register-staged kernel.
-  // COATI_WGRAD_DMA: ring depth 3..5, 0 = register-staged kernel everywhere (A/B switch).
-  static const int dma = getenv("COATI_WGRAD_DMA") ? atoi(getenv("COATI_WGRAD_DMA")) : 3;
+  constexpr int dma = 3;   // ring depth (4 was measured equal, round 2)
   const int tiles = cdiv(a.N, BM) * cdiv(a.K, BN);
   // tiles <= 64: one round of 256 workgroups; 129..256 tiles (lm_head: 162): two rounds of up to 512; in between the
   // register-staged kernel's 512 half-CU slots fill the machine better

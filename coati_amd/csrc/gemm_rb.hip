@@ -365,16 +365,14 @@ static int rb_waves(int M) {
 }
 
 bool gemm_rb256_ln_fusable(const GemmArgs& a, int epi) {
-  static const bool off = getenv("COATI_NO_LN_FUSE") != nullptr || getenv("COATI_NO_RB") != nullptr;   // A/B switches
-  if (off || (epi != EPI_QKV_ROPE && epi != EPI_GELU_GRAD)) return false;
+  if (epi != EPI_QKV_ROPE && epi != EPI_GELU_GRAD) return false;
   GemmArgs b = a;
   b.ln_x = nullptr;
   return gemm_rb256_supported(b, 0, epi) && a.K == RB_K;
 }
 
 int gemm_ce_tile_width(const GemmArgs& a) {
-  static const bool no_rb = getenv("COATI_NO_RB") != nullptr;
-  return (!no_rb && gemm_rb256_supported(a, 0, EPI_CE_PARTIAL)) ? 64 : 128;
+  return gemm_rb256_supported(a, 0, EPI_CE_PARTIAL) ? 64 : 128;
 }
 
 // true when (a, epi) can run on the row-block kernel
@@ -411,9 +409,8 @@ static int launch_rb_shape(const GemmArgs& a, int W, hipStream_t s) {
     attr_set = true;
   }
   const int blocks = cdiv(cdiv(a.M, 32), W);
-  // rotated tile order: measured per epilogue (COATI_RB_ROT=0 | 1 forces it off / on everywhere, default: where it paid)
-  static const int rot_env = getenv("COATI_RB_ROT") ? atoi(getenv("COATI_RB_ROT")) : -1;
-  const int rot = rot_env >= 0 ? (rot_env != 0) : (EPI == EPI_MUL_AUX);
+  // rotated tile order: measured per epilogue (round 2), kept where it paid
+  const int rot = (EPI == EPI_MUL_AUX);
   if constexpr (MAXW == RB_HALF_W) {   // 8 + 4: the same 320 rows per workgroup as 10 full waves
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(64 * RB_HALF_W), tile_bytes + RB_HALF_W * per_wave, s, a, RB_HALF_W, 8, rot);
   } else {
@@ -428,10 +425,9 @@ static int launch_rb_t(const GemmArgs& a, hipStream_t s) {
   const int W = rb_waves(a.M);
   // 8 full + 4 half waves instead of 10 full ones: measured per epilogue (bench --all-sites, M = 81,920): FC1 + GELU/GELU' 3.65 ->
   // 3.51 ms/step, lm_head 0.78 -> 0.75 / 0.73 -> 0.72, but FC2 input gradient 2.41 -> 2.63 and QKV 2.37 -> 2.43 -- it pays only
-  // where the epilogue outweighs the extra MFMA block of a half wave.  COATI_RB_HALF=0 | 1 forces it off / on everywhere (A/B);
+  // where the epilogue outweighs the extra MFMA block of a half wave;
   // epilogues whose per-wave LDS does not fit 12 times keep 10 waves.
-  static const int half_env = getenv("COATI_RB_HALF") ? atoi(getenv("COATI_RB_HALF")) : -1;
-  const bool half_on = half_env >= 0 ? half_env != 0 : (EPI == EPI_GELU_GRAD || EPI == EPI_CE_PARTIAL || EPI == EPI_CE_BWD);
+  const bool half_on = (EPI == EPI_GELU_GRAD || EPI == EPI_CE_PARTIAL || EPI == EPI_CE_BWD);
   constexpr bool half_fits = 2 * 64 * RB_K * 2 + RB_HALF_W * rb_per_wave_bytes<EPI, 64>() <= 160 * 1024;
   const bool half = half_on && half_fits && W == RB_MAX_W && a.m_dev == nullptr;
   if constexpr (EPI == EPI_QKV_ROPE || EPI == EPI_GELU_GRAD) {

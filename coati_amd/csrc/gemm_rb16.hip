@@ -378,8 +378,7 @@ __global__ __launch_bounds__(64 * R16_MAXW, 1) void gemm_rb16_resident_kernel(Ge
 }
 
 bool gemm_rb16_resident_supported(const GemmArgs& a, int a_f32, int epi) {
-  static const bool off = getenv("COATI_NO_RB16_RES") != nullptr;   // A/B switch: the 32-row kernel with its worst-case grid
-  if (off || a_f32 || a.K != R16_K || a.m_dev == nullptr) return false;   // (the transformer's K = 256, N = 256 products: the ring kernel is faster -- proj dgrad 0.63 vs 0.66 ms per step)
+  if (a_f32 || a.K != R16_K || a.m_dev == nullptr) return false;   // (the transformer's K = 256, N = 256 products: the ring kernel is faster -- proj dgrad 0.63 vs 0.66 ms per step)
   if (epi != EPI_BF16 && epi != EPI_EDGE_DPRE) return false;   // (the GNN's node-level products, 16 384 rows, were tried here with 4-wave workgroups: 0.68 vs 0.64 ms per step on the tiled kernel)
   if (a.N % 16 != 0 || a.N > R16_RES_TILES * R16_BN || a.q8_out != nullptr || a.ln_x != nullptr) return false;
   return a.M >= 16 * 256;
@@ -414,8 +413,7 @@ static int rb16_waves(int M) {
 }
 
 bool gemm_rb16_supported(const GemmArgs& a, int a_f32, int epi) {
-  static const bool off = getenv("COATI_NO_RB16") != nullptr;   // A/B switch: the 32-row kernel everywhere
-  if (off || a_f32 || a.K != R16_K || a.m_dev != nullptr) return false;
+  if (a_f32 || a.K != R16_K || a.m_dev != nullptr) return false;
   if (epi != EPI_BF16 && epi != EPI_QKV_ROPE && epi != EPI_GELU_GRAD && epi != EPI_MUL_AUX && epi != EPI_CE_PARTIAL && epi != EPI_CE_BWD) return false;
   if (epi == EPI_CE_PARTIAL && a.partial_tile != 64) return false;
   if (epi == EPI_QKV_ROPE && a.rope_hs == 32) return false;

@@ -310,8 +310,7 @@ __global__ __launch_bounds__(64 * 2 * RGM, 1) void gemm_ring256_kernel(GemmArgs 
 
 bool gemm_ring256_supported(const GemmArgs& a, int a_f32, int epi) {
   if (a.m_dev) return false;   // data-dependent row counts: the row-block / tiled kernels read them on the device
-  static const bool off = getenv("COATI_NO_RING") != nullptr;   // A/B switch
-  if (off || a_f32) return false;
+  if (a_f32) return false;
   if (epi != EPI_BF16 && epi != EPI_RES_F32) return false;
   if (a.N != 256 || a.K % RG_BK != 0 || a.K < 256) return false;
   if (a.M < 256 * 160 / 2) return false;                        // fewer than half the CUs busy: the tiled kernel spreads better
@@ -888,20 +887,18 @@ int launch_gemm_ring256(const GemmArgs& a, int epi, hipStream_t s) {
     return launch_ring1_t<EPI_LNBWD>(a, cdiv(cdiv(a.M, 256), 8) * 8, s);
   }
   // block height: rows the busiest of the 256 persistent workgroups walks = rounds x block rows; ties go to the 160-row form
-  // (less weight re-streaming per row).  COATI_RING_ROWS = 128 | 160 forces one (A/B switch).
-  static const int force = getenv("COATI_RING_ROWS") ? atoi(getenv("COATI_RING_ROWS")) : 0;
-  // more than one round of 160-row blocks, at most 224 rows per CU: the one-round kernel (COATI_RING_ROWS = 224 forces it for
-  // smaller M too; any other value switches it off)
+  // (less weight re-streaming per row).
+  // more than one round of 160-row blocks, at most 224 rows per CU: the one-round kernel
   const int R = cdiv(cdiv(a.M, 256), 8) * 8;
   // 57 345 .. 65 536 rows (spans of 225 .. 256 rows): the 8-wave form with 64 x 128 wave tiles.  Its time hardly depends on the rows
   // (K = 1024, bf16 out: 39.4 / 38.8 / 39.2 us at 40 960 / 50 000 / 65 536 rows: two waves per SIMD leave the per-stage latency
   // exposed), so it only pays where the alternative is two rounds of 128-row blocks (65 536 rows: 42.6 us) -- at 50 000 rows the
   // 14-wave kernel below takes 33.8
-  if (R <= R2W_BR && (force ? force == 256 : R > R1_BR)) return epi == EPI_RES_F32 ? launch_ring1w_t<EPI_RES_F32>(a, R, s) : launch_ring1w_t<EPI_BF16>(a, R, s);
-  if (R <= R1_BR && (force ? force == 224 : a.M > 256 * 160))
+  if (R <= R2W_BR && R > R1_BR) return epi == EPI_RES_F32 ? launch_ring1w_t<EPI_RES_F32>(a, R, s) : launch_ring1w_t<EPI_BF16>(a, R, s);
+  if (R <= R1_BR && a.M > 256 * 160)
     return epi == EPI_RES_F32 ? launch_ring1_t<EPI_RES_F32>(a, R, s) : launch_ring1_t<EPI_BF16>(a, R, s);
   const long long busiest160 = (long long)cdiv(cdiv(a.M, 160), 256) * 160, busiest128 = (long long)cdiv(cdiv(a.M, 128), 256) * 128;
-  const bool small = force ? force == 128 : busiest128 < busiest160;
+  const bool small = busiest128 < busiest160;
   if (small) return epi == EPI_RES_F32 ? launch_ring_t<EPI_RES_F32, 4>(a, s) : launch_ring_t<EPI_BF16, 4>(a, s);
   return epi == EPI_RES_F32 ? launch_ring_t<EPI_RES_F32, 5>(a, s) : launch_ring_t<EPI_BF16, 5>(a, s);
 }

@@ -151,210 +151,12 @@ int launch_gnn_geom(const float* coords, const float* mask, float cutoff, float*
   return COATI_OK;
 }
 
-// ---- edge layer 1 (gather-add + SiLU): one wave per receiver (b, j), looping over its A senders ---------------------
-__global__ __launch_bounds__(256) void gnn_edge_pre_kernel(const bf16_t* __restrict__ P, long long ldp,
-                                                           const float* __restrict__ d2, const float* __restrict__ w1c,
-                                                           long long w1c_stride, const float* __restrict__ b1,
-                                                           bf16_t* __restrict__ e1, int BA, int A, int H) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int bj = blockIdx.x * 4 + wave;
-  if (bj >= BA) return;
-  const int b = bj / A;
-  for (int c = lane * 4; c < H; c += 256) {
-    const uint2 ua = *reinterpret_cast<const uint2*>(P + (long long)bj * ldp + c);
-    const float pa[4] = {bflo(ua.x), bfhi(ua.x), bflo(ua.y), bfhi(ua.y)};
-    float wc[4], bb[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { wc[i] = w1c[(long long)(c + i) * w1c_stride]; bb[i] = b1[c + i]; }
-    for (int k = 0; k < A; ++k) {
-      const long long row = (long long)bj * A + k;
-      const uint2 ub = *reinterpret_cast<const uint2*>(P + (long long)(b * A + k) * ldp + H + c);
-      const float pb[4] = {bflo(ub.x), bfhi(ub.x), bflo(ub.y), bfhi(ub.y)};
-      const float dd = d2[row];
-      float o[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) o[i] = silu_f(pa[i] + pb[i] + dd * wc[i] + bb[i]);
-      *reinterpret_cast<uint2*>(e1 + row * H + c) = make_uint2(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]));
-    }
-  }
-}
-
-int launch_gnn_edge_pre(const bf16_t* P, long long ldp, const float* d2, const float* w, const float* w1c,
-                        long long w1c_stride, const float* b1, bf16_t* e1, int B, int A, int H, hipStream_t s) {
-  (void)w;
-  COATI_CHECK_ARG(P && d2 && w1c && b1 && e1, "gnn_edge_pre: null operand");
-  COATI_CHECK_SHAPE(H % 4 == 0 && ldp % 4 == 0, "gnn_edge_pre: alignment");
-  hipLaunchKernelGGL(gnn_edge_pre_kernel, dim3(cdiv(B * A, 4)), dim3(256), 0, s, P, ldp, d2, w1c, w1c_stride, b1, e1, B * A, A, H);
-  COATI_LAUNCH_CHECK("gnn_edge_pre");
-  return COATI_OK;
-}
-
-// ---- message aggregation: mi[b,j,:] = sum_k SiLU(s2[b,j,k,:]) * w[b,j,k] ------------------------------------------------
-__global__ __launch_bounds__(256) void gnn_edge_reduce_kernel(const bf16_t* __restrict__ s2, const float* __restrict__ w,
-                                                              bf16_t* __restrict__ mi, long long ldmi, int BA, int A, int H) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int bj = blockIdx.x * 4 + wave;
-  if (bj >= BA) return;
-  for (int c = lane * 4; c < H; c += 256) {
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int k = 0; k < A; ++k) {
-      const long long row = (long long)bj * A + k;
-      const float ww = w[row];
-      if (ww == 0.f) continue;
-      const uint2 u = *reinterpret_cast<const uint2*>(s2 + row * H + c);
-      acc[0] += silu_f(bflo(u.x)) * ww; acc[1] += silu_f(bfhi(u.x)) * ww;
-      acc[2] += silu_f(bflo(u.y)) * ww; acc[3] += silu_f(bfhi(u.y)) * ww;
-    }
-    *reinterpret_cast<uint2*>(mi + (long long)bj * ldmi + c) = make_uint2(pack2bf(acc[0], acc[1]), pack2bf(acc[2], acc[3]));
-  }
-}
-
-int launch_gnn_edge_reduce(const bf16_t* s2, const float* w, bf16_t* mi, long long ldmi, int B, int A, int H,
-                           hipStream_t s) {
-  COATI_CHECK_ARG(s2 && w && mi, "gnn_edge_reduce: null operand");
-  COATI_CHECK_SHAPE(H % 4 == 0 && ldmi % 4 == 0, "gnn_edge_reduce: alignment");
-  hipLaunchKernelGGL(gnn_edge_reduce_kernel, dim3(cdiv(B * A, 4)), dim3(256), 0, s, s2, w, mi, ldmi, B * A, A, H);
-  COATI_LAUNCH_CHECK("gnn_edge_reduce");
-  return COATI_OK;
-}
-
-// ds2[b,j,k,:] = dmi[b,j,:] * w[b,j,k] * SiLU'(s2[b,j,k,:])
-__global__ __launch_bounds__(256) void gnn_edge_reduce_bwd_kernel(const bf16_t* __restrict__ dmi, long long lddmi,
-                                                                  const bf16_t* __restrict__ s2, const float* __restrict__ w,
-                                                                  bf16_t* __restrict__ ds2, int BA, int A, int H) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int bj = blockIdx.x * 4 + wave;
-  if (bj >= BA) return;
-  for (int c = lane * 4; c < H; c += 256) {
-    const uint2 ug = *reinterpret_cast<const uint2*>(dmi + (long long)bj * lddmi + c);
-    const float g[4] = {bflo(ug.x), bfhi(ug.x), bflo(ug.y), bfhi(ug.y)};
-    for (int k = 0; k < A; ++k) {
-      const long long row = (long long)bj * A + k;
-      const float ww = w[row];
-      uint2 o = make_uint2(0, 0);
-      if (ww != 0.f) {
-        const uint2 u = *reinterpret_cast<const uint2*>(s2 + row * H + c);
-        o = make_uint2(pack2bf(g[0] * ww * dsilu_f(bflo(u.x)), g[1] * ww * dsilu_f(bfhi(u.x))),
-                       pack2bf(g[2] * ww * dsilu_f(bflo(u.y)), g[3] * ww * dsilu_f(bfhi(u.y))));
-      }
-      *reinterpret_cast<uint2*>(ds2 + row * H + c) = o;
-    }
-  }
-}
-
-int launch_gnn_edge_reduce_bwd(const bf16_t* dmi, long long lddmi, const bf16_t* s2, const float* w, bf16_t* ds2,
-                               int B, int A, int H, hipStream_t s) {
-  COATI_CHECK_ARG(dmi && s2 && w && ds2, "gnn_edge_reduce_bwd: null operand");
-  COATI_CHECK_SHAPE(H % 4 == 0 && lddmi % 4 == 0, "gnn_edge_reduce_bwd: alignment");
-  hipLaunchKernelGGL(gnn_edge_reduce_bwd_kernel, dim3(cdiv(B * A, 4)), dim3(256), 0, s, dmi, lddmi, s2, w, ds2, B * A, A, H);
-  COATI_LAUNCH_CHECK("gnn_edge_reduce_bwd");
-  return COATI_OK;
-}
-
-// ---- backward of the gather-add: dPa[b,j] = sum_k dpre[b,j,k], dPb[b,k] = sum_j dpre[b,j,k], dw1c, db1 -------------
-// one block per molecule; thread = channel; sender sums are kept in LDS ([A][H] floats, own column per thread).
-__global__ __launch_bounds__(256) void gnn_edge_pre_bwd_kernel(const bf16_t* __restrict__ dpre, const float* __restrict__ d2,
-                                                               bf16_t* __restrict__ dP, long long lddp, float* __restrict__ dw1c,
-                                                               long long dw1c_stride, float* __restrict__ db1, int A, int H) {
-  extern __shared__ float accB[];  // [A][H]
-  const int b = blockIdx.x;
-  for (int i = threadIdx.x; i < A * H; i += blockDim.x) accB[i] = 0.f;
-  __syncthreads();
-  for (int c = threadIdx.x; c < H; c += blockDim.x) {
-    float sw = 0.f, sb = 0.f;
-    for (int j = 0; j < A; ++j) {
-      float accA = 0.f;
-      for (int k = 0; k < A; ++k) {
-        const long long row = ((long long)b * A + j) * A + k;
-        const float v = bf2f(dpre[row * H + c]);
-        accA += v;
-        accB[k * H + c] += v;
-        sw += v * d2[row];
-        sb += v;
-      }
-      dP[((long long)b * A + j) * lddp + c] = f2bf(accA);
-    }
-    for (int k = 0; k < A; ++k) dP[((long long)b * A + k) * lddp + H + c] = f2bf(accB[k * H + c]);
-    atomicAdd(dw1c + (long long)c * dw1c_stride, sw);
-    atomicAdd(db1 + c, sb);
-  }
-}
-
-// A = 16 specialisation: 128 threads per molecule, thread = 2 adjacent channels (4-B loads, 512-B rows), the 16 sender
-// sums live in registers (k loop fully unrolled: 16 independent loads in flight, no LDS), workgroups are persistent over
-// molecules and keep their dw1c / db1 partial sums in registers: 2 atomics per channel per WORKGROUP instead of per
-// molecule (1024-way same-address contention made the generic kernel 6x slower than its HBM time).
-__global__ __launch_bounds__(256) void gnn_edge_pre_bwd16_kernel(const bf16_t* __restrict__ dpre, const float* __restrict__ d2,
-                                                                 bf16_t* __restrict__ dP, long long lddp, float* __restrict__ dw1c,
-                                                                 long long dw1c_stride, float* __restrict__ db1, int B, int H) {
-  constexpr int A = 16;
-  const int per_mol = H / 2;                  // threads per molecule
-  const int mols_per_blk = blockDim.x / per_mol;
-  const int sub = threadIdx.x / per_mol, c = (threadIdx.x - sub * per_mol) * 2;
-  float sw0 = 0.f, sw1 = 0.f, sb0 = 0.f, sb1 = 0.f;
-  for (int b = blockIdx.x * mols_per_blk + sub; b < B; b += gridDim.x * mols_per_blk) {
-    float accB0[A], accB1[A];
-#pragma unroll
-    for (int k = 0; k < A; ++k) accB0[k] = accB1[k] = 0.f;
-    for (int j = 0; j < A; ++j) {
-      const long long row0 = ((long long)b * A + j) * A;
-      unsigned v[A];
-#pragma unroll
-      for (int k = 0; k < A; ++k) v[k] = *reinterpret_cast<const unsigned*>(dpre + (row0 + k) * H + c);
-      float a0 = 0.f, a1 = 0.f;
-#pragma unroll
-      for (int k = 0; k < A; ++k) {
-        const float x0 = bflo(v[k]), x1 = bfhi(v[k]), dd = d2[row0 + k];
-        a0 += x0; a1 += x1;
-        accB0[k] += x0; accB1[k] += x1;
-        sw0 = fmaf(x0, dd, sw0); sw1 = fmaf(x1, dd, sw1);
-      }
-      sb0 += a0; sb1 += a1;
-      *reinterpret_cast<unsigned*>(dP + ((long long)b * A + j) * lddp + c) = pack2bf(a0, a1);
-    }
-#pragma unroll
-    for (int k = 0; k < A; ++k) *reinterpret_cast<unsigned*>(dP + ((long long)b * A + k) * lddp + H + c) = pack2bf(accB0[k], accB1[k]);
-  }
-  atomicAdd(dw1c + (long long)c * dw1c_stride, sw0);
-  atomicAdd(dw1c + (long long)(c + 1) * dw1c_stride, sw1);
-  atomicAdd(db1 + c, sb0);
-  atomicAdd(db1 + c + 1, sb1);
-}
-
-int launch_gnn_edge_pre_bwd(const bf16_t* dpre, const float* d2, bf16_t* dP, long long lddp, float* dw1c,
-                            long long dw1c_stride, float* db1, int B, int A, int H, hipStream_t s) {
-  COATI_CHECK_ARG(dpre && d2 && dP && dw1c && db1, "gnn_edge_pre_bwd: null operand");
-  if (A == 16 && H % 2 == 0 && H <= 512 && 256 % (H / 2) == 0 && lddp % 2 == 0) {
-    const int mols_per_blk = 256 / (H / 2);
-    int blocks = cdiv(B, mols_per_blk);
-    if (blocks > 512) blocks = 512;   // 2 resident workgroups per CU, each loops over its molecules
-    hipLaunchKernelGGL(gnn_edge_pre_bwd16_kernel, dim3(blocks), dim3(256), 0, s, dpre, d2, dP, lddp, dw1c, dw1c_stride, db1, B, H);
-    COATI_LAUNCH_CHECK("gnn_edge_pre_bwd16");
-    return COATI_OK;
-  }
-  const size_t lds = (size_t)A * H * sizeof(float);
-  COATI_CHECK_SHAPE(lds <= 160 * 1024, "gnn_edge_pre_bwd: A*H=%d exceeds the LDS accumulator", A * H);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gnn_edge_pre_bwd_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) {
-      coati_set_error("gnn_edge_pre_bwd: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-      return COATI_EHIP;
-    }
-    attr_set = true;
-  }
-  hipLaunchKernelGGL(gnn_edge_pre_bwd_kernel, dim3(B), dim3(256), lds, s, dpre, d2, dP, lddp, dw1c, dw1c_stride, db1, A, H);
-  COATI_LAUNCH_CHECK("gnn_edge_pre_bwd");
-  return COATI_OK;
-}
-
 // =====================================================================================================================
-// Compacted edge list: the engine's path.  make_neighborlist (e_gcl_sparse.py:27-77) keeps only the pairs inside the
-// cutoff; the dense [B, A, A] grid above computes every slot (with n ~ U{8..16} atoms per 16-slot molecule and 85 % of the
-// pairs inside 5 A, 56 % of its rows are padding or out of range).  The list is built on the device from the dense weights
-// (w > 0 <=> edge), receiver-major, so that every per-receiver sum is a contiguous segment and nothing is atomic; its
-// length never visits the host (the edge-level GEMMs read it through GemmArgs::m_dev).
+// Compacted edge list.  make_neighborlist (e_gcl_sparse.py:27-77) keeps only the pairs inside the cutoff; a dense [B, A, A]
+// grid (round 1; its edge kernels were deleted in round 4) computes every slot: with n ~ U{8..16} atoms per 16-slot molecule
+// and 85 % of the pairs inside 5 A, 56 % of its rows are padding or out of range.  The list is built on the device from the
+// dense weights of gnn_geom (w > 0 <=> edge), receiver-major, so that every per-receiver sum is a contiguous segment and
+// nothing is atomic; its length never visits the host (the edge-level GEMMs read it through GemmArgs::m_dev).
 // =====================================================================================================================
 __global__ void gnn_compact_count_kernel(const float* __restrict__ w, int* __restrict__ cnt, int BA, int A) {
   const int bj = blockIdx.x * blockDim.x + threadIdx.x;

@@ -249,14 +249,6 @@ int launch_gnn_embed_bwd(const long long* atoms, const int* lut_ix, const int* l
                          float* dW, float* db, int BA, int H, hipStream_t s);
 int launch_gnn_geom(const float* coords, const float* mask, float cutoff, float* d2, float* w, int B, int A,
                     hipStream_t s);
-int launch_gnn_edge_pre(const bf16_t* P, long long ldp, const float* d2, const float* w, const float* w1c,
-                        long long w1c_stride, const float* b1, bf16_t* e1, int B, int A, int H, hipStream_t s);
-int launch_gnn_edge_reduce(const bf16_t* s2, const float* w, bf16_t* mi, long long ldmi, int B, int A, int H,
-                           hipStream_t s);
-int launch_gnn_edge_reduce_bwd(const bf16_t* dmi, long long lddmi, const bf16_t* s2, const float* w, bf16_t* ds2,
-                               int B, int A, int H, hipStream_t s);
-int launch_gnn_edge_pre_bwd(const bf16_t* dpre, const float* d2, bf16_t* dP, long long lddp, float* dw1c,
-                            long long dw1c_stride, float* db1, int B, int A, int H, hipStream_t s);
 // Compacted edge list (the reference's neighbour list, e_gcl_sparse.py:27-77, built on the device, no host sync):
 // edges in receiver-major order; seg[bj] .. seg[bj+1] = the edges received by node row bj; e_rev[e] = the edge (k -> j) of
 // edge e = (j -> k) (the edge set is symmetric); n_edges[0] = E.  pos is a B*A*A int scratch.

@@ -203,10 +203,15 @@ int coati_gnn_geom(const float* coords, const float* mask, float cutoff, float* 
  * All edge arrays must hold B*A*A entries.  No host sync: consumers read n_edges on the device. */
 int coati_gnn_compact(const float* w_dense, const float* d2_dense, int32_t* seg, int32_t* n_edges, int32_t* e_bj, int32_t* e_bk,
                       int32_t* e_rev, float* e_d2, float* e_w, int32_t* pos, int B, int A, void* stream);
-int coati_gnn_edge_pre(const uint16_t* P, int64_t ldp, const float* d2, const float* w1c, int64_t w1c_stride,
-                       const float* b1, uint16_t* e1, int B, int A, int H, void* stream);
-int coati_gnn_edge_reduce(const uint16_t* s2, const float* w, uint16_t* mi, int64_t ldmi, int B, int A, int H,
-                          void* stream);
+
+/* Edge model on the compacted list (e_gcl_sparse.py:169-215, factored: W1 [h_j, h_k, d2] = Pa[j] + Pb[k] + w1c d2):
+ * coati_gnn_edge_pre:    e1[e, :] = SiLU(P[bj, 0:H] + P[e_bk[e], H:2H] + e_d2[e] w1c + b1) for the edges e of every receiver row bj
+ *                        (seg [BA + 1]); P [BA, 2H] bf16 = (Pa | Pb), e1 [E, H] bf16
+ * coati_gnn_edge_reduce: mi[bj, :] = sum over the receiver's segment of SiLU(s2[e, :]) e_w[e]   (the cutoff-weighted message sum,
+ *                        e_gcl_sparse.py:204-207, as contiguous segment sums: no scatter_add_, no atomics) */
+int coati_gnn_edge_pre(const uint16_t* P, int64_t ldp, const int32_t* seg, const int32_t* e_bk, const float* e_d2, const float* w1c,
+                       int64_t w1c_stride, const float* b1, uint16_t* e1, int BA, int H, void* stream);
+int coati_gnn_edge_reduce(const uint16_t* s2, const int32_t* seg, const float* e_w, uint16_t* mi, int64_t ldmi, int BA, int H, void* stream);
 
 /* symmetric InfoNCE over local rows x global columns (clip_e2e.py:35-47).  logits [R,N] f32 is overwritten by its
  * gradient scaled by gscale * inv_count[0]; rows whose label (label0 + r) is a bad row are ignored. */

@@ -1,5 +1,5 @@
 """16-row-slab row-block GEMM (gemm_rb16.hip) at a packed batch size: quick A/B timing on the GPU box.
-   python tools/rb16_bench.py [M]      (COATI_NO_RB16=1: the same products on the 32-row kernel)"""
+   python tools/rb16_bench.py [M]"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))

@@ -12,7 +12,7 @@ torch.manual_seed(0)
 for K in (1024, 256):
     W = (torch.randn(256, K, device=dev) * 0.05).bfloat16()
     bias = torch.randn(256, device=dev)
-    rows_env = os.environ.get("COATI_RING_ROWS", "auto")   # (read once per process by the launcher: run the script once per value)
+    rows_env = "auto"
     for M in (32768, 36000, 40960, 50000, 65536, 81920):
         A = torch.randn(M, K, device=dev).bfloat16()
         res = torch.randn(M, 256, device=dev)
