@@ -10,13 +10,16 @@ Prints ONE JSON line on rank 0 (contract in the task statement): whole-job molec
 plus `roofline` (dominant kernel, timed live with HIP events on the launch stream) and, at N=1, `cpu_baseline`
 (the oracle's fp32 CPU step on a bounded sample of the same workload, on this box's host cores).
 
-roofline: the dominant launch site is the transformer weight-gradient kernel (`xf_wgrad`, 128 launches per step).  Its
-arithmetic intensity N*K/(N+K) = 128..205 flop/B is below the MI355X ridge (2.5 PFLOP/s / 8 TB/s = 312 flop/B), so the
-bound is HBM: achieved = algorithmic bytes per launch (both bf16 activation operands once + the f32 gradient
-read-modify-write) / average launch time.  `traffic` is the measured HBM bytes per launch of that
-kernel from the newest committed profiles/rNN_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over THIS
-command, `bench.py --steps 2 --warmup 1 --no-cpu-baseline`, collected by tools/profile_round.sh; `traffic_source` names the
-file and the round), null if there is none.  `step_roofline` prices the whole step: SURVEY 8(d)'s algorithmic FLOPs
+roofline: the dominant kernel of the step -- the top row of the rocprofv3 kernel table (profiles/rNN_bench_kernel_stats.csv) -- is
+`gemm_ring1_kernel<EPI_LNBWD>`: the N = 256 ring GEMM with the LayerNorm backward in its write-out, i.e. the launch sites
+`fc1_dgrad` + `qkv_dgrad` (63 launches per step).  Its arithmetic intensity is below the MI355X ridge (2.5 PFLOP/s / 8 TB/s =
+312 flop/B), so the bound is HBM: achieved = algorithmic bytes per launch (bf16 gradient operand + weight in; LayerNorm input and
+f32 residual gradient in; f32 residual gradient + its bf16 copy out) / average launch time, measured with HIP
+events around those launches over the timed region.  `traffic` is the measured HBM bytes per launch of that kernel from the newest
+committed profiles/rNN_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over THIS command, `bench.py --steps 2
+--warmup 1 --no-cpu-baseline`, collected by tools/profile_round.sh; `traffic_source` names the file and the round), null if there
+is none.  `site_roofline` lists every launch site of >= 2 % of the step the same way (the grouped weight gradient `xf_wgrad`, the
+nominated kernel of rounds 1-3, among them).  `step_roofline` prices the whole step: SURVEY 8(d)'s algorithmic FLOPs
 and HBM bytes per molecule evaluated on this batch / measured step time, against 2.5 PFLOP/s and 8 TB/s.
 
 `--gpus N` with N > 1 and no WORLD_SIZE in the environment re-executes this script under
@@ -167,7 +170,9 @@ def main():
     ap.add_argument("--batch", type=int, default=1024, help="molecules per GPU (BASELINE.json configs[1])")
     ap.add_argument("--seq", type=int, default=80)
     ap.add_argument("--atoms", type=int, default=16)
-    ap.add_argument("--roofline-site", type=str, default="xf_wgrad", help="engine launch site timed for the roofline entry (default: the dominant one)")
+    ap.add_argument("--roofline-site", type=str, default="fc1_dgrad,qkv_dgrad",
+                    help="engine launch site(s) timed for the roofline entry; default: the two sites of the step's top kernel, the ring GEMM "
+                         "with the LayerNorm backward in its write-out (padded layout: that kernel does not exist there -> xf_wgrad)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-mols", type=int, default=32)
     ap.add_argument("--all-sites", action="store_true", help="extra: per-site kernel time table on stderr")
@@ -264,6 +269,8 @@ def main():
 
     # (N > 1: the data-parallel schedule -- encoder stage of the backward in one piece or in two halves -- is measured by
     # coati_amd.distributed over steps 3..8 of the process; they are kept out of the timed region)
+    if args.roofline_site == "fc1_dgrad,qkv_dgrad" and (args.padded or args.config != "grande_closed" or args.fp8):
+        args.roofline_site = "xf_wgrad"      # the fused kernel serves the packed grande batch; elsewhere the grouped weight gradient leads
     for _ in range(max(args.warmup, 9) if dist_on else args.warmup):
         step()
     # HIP events around the nominated site's launches over the timed region; the step itself runs as the product runs it
@@ -359,19 +366,21 @@ def main():
                 raise OSError("PMC summaries are collected for the grande_closed B=1024 T=80 shapes only")
             cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
             with open(cands[-1]) as f:
-                ent = json.load(f).get(args.roofline_site, {})
+                ent = json.load(f).get({"fc1_dgrad,qkv_dgrad": "dgrad_lnbwd"}.get(args.roofline_site, args.roofline_site), {})
             if ent.get("layout", "padded") != ("padded" if args.padded else "packed"):
                 raise OSError("the newest PMC summary was collected on the other row layout")
             traffic = ent.get("hbm_bytes_per_launch")
             traffic_source = f"{os.path.relpath(cands[-1], ROOT)} ({ent.get('command', 'isolated launches, tools/prof_wgrad.py')}); static file, not this run"
         except (OSError, ValueError, IndexError):
             pass
+        kname = {"fc1_dgrad,qkv_dgrad": "gemm_ring1_kernel<EPI_LNBWD> (ring GEMM + LayerNorm backward; sites fc1_dgrad + qkv_dgrad)",
+                 "xf_wgrad": "wgrad256_table_kernel (site xf_wgrad)"}.get(args.roofline_site, args.roofline_site)
         if hbm_bound:
-            roof = {"bound": "hbm", "kernel": args.roofline_site, "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+            roof = {"bound": "hbm", "kernel": kname, "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                     "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": traffic, "traffic_source": traffic_source, "avg_launch_ms": round(avg_ms, 5), "launches": site_n,
                     "bytes_per_launch": site_bytes, "flops_per_launch": site_flops, "tflops": round(tflops, 1)}
         else:
-            roof = {"bound": "mfma", "kernel": args.roofline_site, "achieved": round(tflops, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+            roof = {"bound": "mfma", "kernel": kname, "achieved": round(tflops, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(tflops / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_source, "avg_launch_ms": round(avg_ms, 5), "launches": site_n,
                     "bytes_per_launch": site_bytes, "flops_per_launch": site_flops}
         out = {

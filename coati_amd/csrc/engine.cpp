@@ -196,7 +196,7 @@ struct coati_engine {
   bool gnn_bwd_done = false;   // staged backward: stage 2 already ran the point-encoder backward on the side stream
   bool gnn_side_pending = false;   // stage 4 forked it; stage 5 joins
   // profiling
-  int prof_site = -1;
+  unsigned long long prof_mask = 0;   // launch sites whose launches are bracketed by HIP events (bit = Site)
   bool prof_keep_overlap = false;   // timed-region profiling: events around the selected site, the step itself runs as the product does (side stream on)
   std::vector<hipEvent_t> ev;
   int ev_used = 0;
@@ -388,7 +388,7 @@ struct ProfScope {
   hipStream_t s;
   bool on;
   ProfScope(coati_engine* e_, int site, double flops, hipStream_t s_, double bytes = 0.0) : e(e_), s(s_), on(false) {
-    if (e->prof_site == site && e->ev_used + 2 <= (int)e->ev.size()) {
+    if (site >= 0 && ((e->prof_mask >> site) & 1ull) && e->ev_used + 2 <= (int)e->ev.size()) {
       on = true;
       hipEventRecord(e->ev[e->ev_used], s);
       e->prof_flops += flops;
@@ -1306,7 +1306,7 @@ int coati_engine_forward(coati_engine* e, void* workspace, int64_t workspace_byt
   }
 
   // ---- point encoder (clip_e2e.py:454-461): on the side stream, concurrent with the encoder pass ----
-  const bool ovl = e->overlap && (e->prof_site < 0 || e->prof_keep_overlap) && c.use_point_encoder;
+  const bool ovl = e->overlap && (e->prof_mask == 0 || e->prof_keep_overlap) && c.use_point_encoder;
   if (!c.use_point_encoder) {
     // encode_points returns zeros (clip_e2e.py:462-463)
     HIPCHK(hipMemsetAsync(e->h_e3gnn, 0, (size_t)B * E * sizeof(float), s));
@@ -1507,7 +1507,7 @@ int coati_engine_backward(coati_engine* e, const float* dh_smiles, const float* 
   // stages 4 / 5 = the encoder stage in two halves (upper / lower half of the layers), so that the caller can start the
   // all-reduce of the upper layers' finished gradients underneath the lower half
   const int Lx = c.n_layer_xformer, Lmid = Lx / 2;
-  const bool ovl_bwd = (stage == 0 || stage == 2 || stage == 4) && e->overlap && (e->prof_site < 0 || e->prof_keep_overlap) && c.use_point_encoder;
+  const bool ovl_bwd = (stage == 0 || stage == 2 || stage == 4) && e->overlap && (e->prof_mask == 0 || e->prof_keep_overlap) && c.use_point_encoder;
   if (stage == 0 || stage == 1) { e->gnn_bwd_done = false; e->gnn_side_pending = false; }
   if (ovl_bwd) {
     // the point-encoder backward only needs dhpoint (ready here) and writes its own gradient slice: side stream
@@ -1564,11 +1564,19 @@ int coati_engine_prof_select(coati_engine* e, int site) {
       }
     }
   }
-  e->prof_site = site;
+  e->prof_mask = site >= 0 ? (1ull << site) : 0ull;
   e->prof_keep_overlap = false;
   e->ev_used = 0;
   e->prof_flops = 0.0;
   e->prof_bytes = 0.0;
+  return COATI_OK;
+}
+
+// several launch sites at once (a kernel that serves more than one site, e.g. the ring GEMM with the LayerNorm backward in its
+// write-out = fc1_dgrad + qkv_dgrad): prof_select first (it creates the events), then OR further sites in
+int coati_engine_prof_add_site(coati_engine* e, int site) {
+  COATI_CHECK_ARG(e && site >= 0 && site < SITE_COUNT && e->prof_mask != 0, "prof_add_site: bad site / nothing selected");
+  e->prof_mask |= 1ull << site;
   return COATI_OK;
 }
 

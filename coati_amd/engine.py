@@ -401,8 +401,12 @@ class Engine:
         """HIP events around every launch of `site` (-1: off).  keep_overlap: the step keeps running as the product runs it
         (point encoder concurrent on the side stream) -- bench.py's timed region; default: the point encoder is serialised
         so that a site's events bracket its kernels alone (the per-site table)."""
-        idx = self.site_names().index(site) if isinstance(site, str) else site
-        _lib.check(self.l.coati_engine_prof_select(self.h, idx), "prof_select")
+        names = self.site_names()
+        sites = [s.strip() for s in site.split(",")] if isinstance(site, str) else [site]     # "fc1_dgrad,qkv_dgrad": several sites at once
+        idx = [names.index(s) if isinstance(s, str) else s for s in sites]
+        _lib.check(self.l.coati_engine_prof_select(self.h, idx[0]), "prof_select")
+        for i in idx[1:]:
+            _lib.check(self.l.coati_engine_prof_add_site(self.h, i), "prof_add_site")
         if keep_overlap:
             _lib.check(self.l.coati_engine_prof_keep_overlap(self.h, 1), "prof_keep_overlap")
 

@@ -345,6 +345,7 @@ int coati_engine_optimizer_step(coati_engine* e, float lr, float beta1, float be
 
 /* per-site kernel timing with HIP events on the launch stream (bench.py roofline leg) */
 int coati_engine_prof_select(coati_engine* e, int site);              /* -1 disables */
+int coati_engine_prof_add_site(coati_engine* e, int site);           /* after prof_select: time this site's launches as well */
 /* keep != 0: time the selected site while the step runs as the product runs it (point encoder concurrent on the side stream);
  * 0 (default after every prof_select): the point encoder is serialised onto the launch stream, a site's events bracket its kernels alone */
 int coati_engine_prof_keep_overlap(coati_engine* e, int keep);

@@ -234,3 +234,56 @@ def test_wrong_row_counts_raise_and_leave_the_weights_alone():
         assert not torch.equal(eng.params, p_before)
     finally:
         dist.destroy_process_group()
+
+
+_LNBWD_SCRIPT = """
+import sys, torch
+sys.path.insert(0, {root!r})
+from coati_amd.engine import Engine, ModelConfig
+from coati_amd.synthetic import make_batch
+kw = dict(n_layer_e3gnn=1, n_layer_xformer=2, n_hidden_xformer=256, n_hidden_e3nn=64, n_embd_common=256, n_head=16, n_seq=100, n_tok=600)
+eng = Engine(ModelConfig(**kw), "cuda:0")
+g = torch.Generator().manual_seed(11)
+with torch.no_grad():
+    for name, (off, shape) in eng.layout.items():
+        v = eng.view(name)
+        if len(shape) == 2:
+            v.copy_((torch.randn(shape, generator=g) * (0.05 if "tok_emb" not in name else 1.0)).to("cuda:0"))
+        elif (".ln_" in name and name.endswith("weight")) or name.endswith("clip.0.weight"):
+            v.copy_((1.0 + 0.1 * torch.randn(shape, generator=g)).to("cuda:0"))
+        else:
+            v.copy_((0.02 * torch.randn(shape, generator=g)).to("cuda:0"))
+eng.refresh_shadows()
+b, up = make_batch(1000, 82, 6, 600, seed=3, n_special=12, min_len=12, with_rows=True)     # ~ 47 000 / 49 000 packed rows: the one-round ring kernel
+db = {{k: (v.to("cuda:0") if k != "rows" else v) for k, v in b.items()}}
+eng.train_step(db, up.to("cuda:0"), lr=1e-3, optimizer=False)
+torch.cuda.synchronize()
+torch.save({{"rows": b["rows"], "losses": eng.losses(), "grads": {{k: v.cpu().clone() for k, v in eng.named_views("grads").items()}}}}, {out!r})
+"""
+
+
+def test_layernorm_backward_in_the_gemm_write_out_equals_the_two_kernels(tmp_path):
+    """The input-gradient products of c_fc / c_attn carry ln_2 / ln_1's backward in their write-out at packed-batch sizes
+    (gemm_ring.hip EPI_LNBWD); COATI_NO_LNBWD_FUSE=1 runs the bf16 product + the stand-alone LayerNorm backward instead.  The same
+    step at d = 256 on ~ 48 000 packed rows in two fresh processes: every gradient must agree to what the removed bf16 rounding of
+    dy explains (the fused form takes dy in fp32 from the accumulators)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for tag, env in (("fused", {}), ("two", {"COATI_NO_LNBWD_FUSE": "1"})):
+        out = str(tmp_path / f"{tag}.pt")
+        e = dict(os.environ, **env)
+        if tag == "fused":
+            e.pop("COATI_NO_LNBWD_FUSE", None)
+        r = subprocess.run([sys.executable, "-c", _LNBWD_SCRIPT.format(root=root, out=out)], env=e, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[tag] = torch.load(out)
+    a, b = res["fused"], res["two"]
+    r1, r2 = (int(x) for x in a["rows"])
+    assert 40960 < r1 <= 57344 and 40960 < r2 <= 57344, (r1, r2)     # both passes inside the fused kernel's row range
+    for k in ("ar_loss", "clip_loss"):
+        assert abs(a["losses"][k] - b["losses"][k]) <= 1e-6 * abs(b["losses"][k]), (k, a["losses"], b["losses"])    # same forward
+    worst = sorted(((float((a["grads"][k] - b["grads"][k]).abs().max()) / max(float(b["grads"][k].abs().max()), 1e-30), k)
+                    for k in b["grads"] if float(b["grads"][k].abs().max()) > 0), reverse=True)
+    log(f"LayerNorm backward fused into the ring GEMM vs two kernels ({r1} / {r2} rows): worst gradient deviations {worst[:3]}")
+    assert worst[0][0] <= 1e-2, worst[:5]
