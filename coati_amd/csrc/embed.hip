@@ -228,6 +228,16 @@ __global__ void seq_fill_kernel(const int* __restrict__ off, const long long* __
                                 int* __restrict__ row_t, long long* __restrict__ ypk, int B, int T, int cap) {
   const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= (long long)B * T) return;
+  // rows [total, cap) exist only when the host's count was too LARGE (flagged by the scan): they still have to index inside the
+  // matrices (row 0, position 0, no target) -- written here instead of by three memsets in front of every pack
+  {
+    const long long m = (long long)off[B] + g;
+    if (m < cap) {
+      row_src[m] = 0;
+      row_t[m] = 0;
+      if (ypk != nullptr) ypk[m] = -1;
+    }
+  }
   const int b = (int)(g / T), t = (int)(g - (long long)b * T);
   const int o = off[b];
   if (t >= off[b + 1] - o) return;
@@ -241,12 +251,6 @@ int launch_seq_pack(const long long* tok, const long long* y, int pad_token, int
                     int* row_src, int* row_t, long long* ypk, int* err, hipStream_t s) {
   COATI_CHECK_ARG(tok && off && row_src && row_t && err && (ypk == nullptr || y != nullptr), "seq_pack: null operand");
   COATI_CHECK_SHAPE(B > 0 && T > 0 && rows_expect > 0 && rows_expect <= (long long)B * T, "seq_pack: bad row count %d for %d x %d", rows_expect, B, T);
-  // rows the fill does not reach (a count mismatch: flagged) still have to index inside the matrices
-  if (hipMemsetAsync(row_src, 0, (size_t)rows_expect * sizeof(int), s) != hipSuccess || hipMemsetAsync(row_t, 0, (size_t)rows_expect * sizeof(int), s) != hipSuccess ||
-      (ypk != nullptr && hipMemsetAsync(ypk, 0xff, (size_t)rows_expect * sizeof(long long), s) != hipSuccess)) {
-    coati_set_error("seq_pack: memset failed");
-    return COATI_EHIP;
-  }
   hipLaunchKernelGGL(seq_len_kernel, dim3(cdiv(B, 4)), dim3(256), 0, s, tok, y, pad_token, off, B, T);
   hipLaunchKernelGGL(seq_scan_kernel, dim3(1), dim3(1024), 0, s, off, B, rows_expect, err);
   hipLaunchKernelGGL(seq_fill_kernel, dim3(cdiv((long long)B * T, 256)), dim3(256), 0, s, off, y, row_src, row_t, ypk, B, T, rows_expect);
