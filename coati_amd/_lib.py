@@ -21,7 +21,7 @@ class CoatiConfig(ctypes.Structure):
 
 _SIGS = {
     "coati_gemm_nt": [P, I, L, P, L, I, I, I, P, L, I, P, P, P, L, I, P],
-    "coati_gemm_lnbwd": [P, L, P, L, I, I, P, P, P, P, P, P, P, P, POINTER(c_int32), P],
+    "coati_gemm_lnbwd": [P, L, P, L, I, I, P, P, P, P, P, P, P, P, POINTER(c_int32), P, P, P],
     "coati_quant_mx8": [P, I, L, P, L, P, I, I, P],
     "coati_gemm_mx8": [P, L, P, P, L, P, I, I, I, P, L, P, P, P, L, I, P],
     "coati_gemm_ce_partial": [P, L, P, L, I, I, I, P, P],

@@ -23,12 +23,14 @@ int coati_gemm_nt(const void* A, int a_f32, int64_t lda, const uint16_t* B, int6
 
 int coati_gemm_lnbwd(const uint16_t* dY, int64_t lda, const uint16_t* WT, int64_t ldw, int M, int K, const float* x, const float* mean,
                      const float* rstd, const float* gamma, const float* dres, float* dx, uint16_t* dx16, float* partial,
-                     int32_t* n_partial_rows, void* stream) {
+                     int32_t* n_partial_rows, const uint16_t* chain_W, uint16_t* chain_C, void* stream) {
   COATI_CHECK_ARG(dY && WT && x && mean && rstd && gamma && dres && dx && partial && n_partial_rows, "gemm_lnbwd: null argument");
   GemmArgs a;
   memset(&a, 0, sizeof(a));
   a.A = dY; a.lda = lda; a.B = WT; a.ldb = ldw; a.M = M; a.N = 256; a.K = K; a.C = dx; a.ldc = 256; a.aux_in = dres; a.ld_aux = 256;
   a.aux_out = dx16; a.lnb_x = x; a.lnb_ldx = 256; a.lnb_mean = mean; a.lnb_rstd = rstd; a.lnb_gamma = gamma; a.lnb_partial = partial;
+  COATI_CHECK_ARG((chain_W == nullptr) == (chain_C == nullptr) && (chain_W == nullptr || dx16 != nullptr), "gemm_lnbwd: the chained product needs chain_W, chain_C and dx16");
+  a.chain_W = chain_W; a.chain_ldw = 256; a.chain_C = chain_C; a.chain_ldc = 256;
   int nwg = 0;
   COATI_CHECK_SHAPE(gemm_ring_lnbwd_supported(a, &nwg), "gemm_lnbwd: unsupported shape M=%d K=%d (256 columns, 40 961 .. 57 344 rows, K %% 64 == 0)", M, K);
   *n_partial_rows = nwg;

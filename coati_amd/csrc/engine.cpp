@@ -775,13 +775,17 @@ int xformer_bwd(coati_engine* e, XPass& p, const void* dyf, int dyf_f32, float* 
   // An input-gradient product whose result is the gradient w.r.t. a LayerNorm's OUTPUT (fc1 -> ln_2, c_attn -> ln_1) with that
   // LayerNorm's backward in the product's write-out (gemm_ring.hip EPI_LNBWD): dy never visits HBM, one launch instead of two.
   // Returns 1 when the fused launch ran, 0 when the shape does not take it (the caller then runs the two launches), < 0 on error.
+  // chainW / chainC: the product that consumes the LayerNorm backward's bf16 output (c_proj's input gradient behind ln_2) in the
+  // same launch
   auto dgrad_lnbwd = [&](int site, const bf16_t* dY, int K, const bf16_t* WT, const float* x, const float* mean, const float* rstd,
-                         const float* gamma, size_t goff, size_t boff, bf16_t* dx16) -> int {
+                         const float* gamma, size_t goff, size_t boff, bf16_t* dx16, const bf16_t* chainW = nullptr,
+                         bf16_t* chainC = nullptr) -> int {
     if (!defer || c.use_fp8) return 0;
     GemmArgs a;
     memset(&a, 0, sizeof(a));
     a.A = dY; a.lda = K; a.B = WT; a.ldb = K; a.M = M; a.N = C; a.K = K; a.C = DX; a.ldc = C; a.aux_in = DX; a.ld_aux = C; a.aux_out = dx16;
     a.lnb_x = x; a.lnb_ldx = C; a.lnb_mean = mean; a.lnb_rstd = rstd; a.lnb_gamma = gamma;
+    if (chainW != nullptr && dx16 != nullptr) { a.chain_W = chainW; a.chain_ldw = C; a.chain_C = chainC; a.chain_ldc = C; }
     int nwg = 0;
     if (!gemm_ring_lnbwd_supported(a, &nwg) || nwg > COATI_LN_PARTIAL_ROWS) return 0;
     a.lnb_partial = e->ln_part_x + fin.n * slot_stride;
@@ -790,7 +794,8 @@ int xformer_bwd(coati_engine* e, XPass& p, const void* dyf, int dyf_f32, float* 
     fin.nblk[fin.n] = nwg;
     ++fin.n;
     // algorithmic bytes: dY + weight in; x, dres in; dx (f32) + its bf16 copy out
-    ProfScope ps(e, site, 2.0 * M * C * K, s, (double)M * K * 2 + (double)C * K * 2 + (double)M * C * (4 + 4 + 4 + (dx16 ? 2 : 0)));
+    ProfScope ps(e, site, 2.0 * M * C * K + (a.chain_W ? 2.0 * M * C * C : 0.0), s,
+                 (double)M * K * 2 + (double)C * K * 2 + (double)M * C * (4 + 4 + 4 + (dx16 ? 2 : 0)) + (a.chain_W ? (double)M * C * 2 + (double)C * C * 2 : 0.0));
     const int rc = launch_gemm_nt(a, 0, EPI_LNBWD, s);
     return rc == COATI_OK ? 1 : rc;
   };
@@ -845,7 +850,9 @@ int xformer_bwd(coati_engine* e, XPass& p, const void* dyf, int dyf_f32, float* 
       } else {
       COATI_TRY(gemm(e, SITE_FC2_DGRAD, dxa, 0, C, e->S + w.fc2T, C, M, 4 * C, C, dh4, 4 * C, nullptr, EPI_MUL_AUX, p.hpre[l], nullptr, 4 * C, s));
       // hpre = a2 W1^T + b1 ; at packed-batch sizes with ln_2's backward in the write-out
-      ln2_fused = dgrad_lnbwd(SITE_FC1_DGRAD, dh4, 4 * C, e->S + w.fc1T, p.xmid[l], p.mean2[l], p.rstd2[l], e->P + w.ln2w, w.ln2w, w.ln2b, dxb);
+      // ... and, chained behind it in the same launch, the c_proj input gradient dyb = dxb Wp (the attention backward's dO)
+      ln2_fused = dgrad_lnbwd(SITE_FC1_DGRAD, dh4, 4 * C, e->S + w.fc1T, p.xmid[l], p.mean2[l], p.rstd2[l], e->P + w.ln2w, w.ln2w, w.ln2b, dxb,
+                              e->S + w.projT, e->dyb);
       if (ln2_fused < 0) return ln2_fused;
       if (!ln2_fused) COATI_TRY(gemm(e, SITE_FC1_DGRAD, dh4, 0, 4 * C, e->S + w.fc1T, 4 * C, M, C, 4 * C, e->da, C, nullptr, EPI_BF16, nullptr, nullptr, 0, s));
       }
@@ -865,7 +872,7 @@ int xformer_bwd(coati_engine* e, XPass& p, const void* dyf, int dyf_f32, float* 
       memset(&a, 0, sizeof(a));
       a.C = e->dyb; a.ldc = C;
       COATI_TRY(gemm8(e, SITE_PROJ_DGRAD, w, 5, dxb, C, M, C, C, a, EPI_BF16, s));
-    } else {
+    } else if (!ln2_fused) {   // (fused: the chained product of the launch above has written dyb)
     COATI_TRY(gemm(e, SITE_PROJ_DGRAD, dxb, 0, C, e->S + w.projT, C, M, C, C, e->dyb, C, nullptr, EPI_BF16, nullptr, nullptr, 0, s));
     }
     if (!grp) COATI_TRY(wgrad(e, SITE_XF_WGRAD, dxb, 0, C, p.y[l], C, M, C, C, e->G + w.projw, C, e->G + w.projb, 0, s));

@@ -490,7 +490,7 @@ __global__ __launch_bounds__(64 * R1_WAVES, 1) void gemm_ring1_kernel(GemmArgs p
     asm volatile("s_barrier" ::: "memory");     // every wave is done with the ring before its LDS becomes scratch
     float* stash = reinterpret_cast<float*>(smem) + wave * 2048;         // [8 registers][64 lanes][4 column blocks] per wave: 8 KiB
     float* red = reinterpret_cast<float*>(smem) + R1_WAVES * 2048;       // [4 quarters][14 waves][2 half-waves][8]
-    float* red2 = red + 4 * R1_WAVES * 16;                               // [7 row groups][512]: dgamma | dbeta partials
+    float* red2 = reinterpret_cast<float*>(smem);                        // [7 row groups][512]: dgamma | dbeta partials -- over the stash, which is dead by then
     const int hw = lane >> 5;
     // uniform base pointers + one 32-bit BYTE offset per row (x, dres, dx and dx16 share one row pitch: launch check)
     const float* const xin = p.lnb_x;
@@ -531,6 +531,15 @@ __global__ __launch_bounds__(64 * R1_WAVES, 1) void gemm_ring1_kernel(GemmArgs p
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int b = q & 1;
+      if (q == 2 && p.chain_W != nullptr) {
+        // chained product (below): its first weight stage goes on its way now -- weight slot 1 lies behind the stash and the sums
+        const bf16_t* wb = p.chain_W + (long long)8 * wave * p.chain_ldw;
+        const long long w_p = 8LL * R1_WAVES * p.chain_ldw;
+        const unsigned slot = ldsW + RG_W_BYTES, offw2 = (unsigned)(((lane >> 3) * (int)p.chain_ldw + ((lane & 7) ^ ((((wave & 1) << 2) + (lane >> 4)) & 7)) * 8) * 2);
+        rg_dma16s(wb, offw2, slot + wave * 1024);
+        rg_dma16s(wb + w_p, offw2, slot + (wave + R1_WAVES) * 1024);
+        if (nwp == 3) rg_dma16s(wb + 2 * w_p, offw2, slot + (wave + 2 * R1_WAVES) * 1024);
+      }
       if (q == 2) {   // quarters 0, 1 are out: their accumulators are dead, the other half comes back from LDS
 #pragma unroll
         for (int r = 8; r < 16; ++r) {
@@ -623,6 +632,99 @@ __global__ __launch_bounds__(64 * R1_WAVES, 1) void gemm_ring1_kernel(GemmArgs p
 #pragma unroll
       for (int g = 0; g < R1_GROUPS; ++g) t += red2[g * 512 + tid];
       p.lnb_partial[(long long)blockIdx.x * 512 + tid] = t;
+    }
+    if (p.chain_W != nullptr) {
+      // ---- chained product: chain_C = dx16 chain_W^T (N = K = 256: the c_proj input gradient that follows ln_2's backward) on the
+      // rows this workgroup has just written -- they come back from L2 by DMA as four 64-k slabs (the three A slots + weight slot 0),
+      // the weight streams through weight slot 1 in four 64-k stages; one launch and one trip of the rows through HBM less
+      __builtin_amdgcn_s_waitcnt(0x0f70);          // vmcnt(0): this wave's dx16 stores have left
+      __syncthreads();                            // ... every wave's; and red2 has been read
+      const bf16_t* const A2 = reinterpret_cast<const bf16_t*>(p.aux_out);
+      // the lane constants of the k loop again, from a laundered lane id: kept alive across the LayerNorm write-out they cost it 14
+      // spilled registers
+      int ln2 = lane;
+      asm volatile("" : "+v"(ln2));
+      const int lrow = ln2 >> 3, cg = (ln2 & 7) ^ ((((wave & 1) << 2) + (ln2 >> 4)) & 7);
+      const int fr = ln2 & 31, kg = ln2 >> 5, swz = (fr >> 1) & 7;
+      unsigned xo[4];
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) xo[ks] = (unsigned)(fr * 128 + (((2 * ks + kg) ^ swz) << 4));
+      const unsigned offa2 = (unsigned)((lrow * (int)p.ldc + cg * 8) * 2), offw2 = (unsigned)((lrow * (int)p.chain_ldw + cg * 8) * 2);
+      const bf16_t* const pa2 = A2 + (long long)row0 * p.ldc;
+      // LDS: slabs 0, 1, 2 in the three A slots, slab 3 follows slab 0 into A slot 0 once stage 0 has been multiplied; the weight
+      // stages alternate between the two weight slots (stage 0 -> slot 1, prefetched during the write-out above), each issued one
+      // stage ahead: the counted vmcnt waits leave exactly the younger transfers in flight
+      auto slab = [&](int kk) -> unsigned { return lds0 + (kk % 3) * R1_A_BYTES; };
+      auto wslot = [&](int kk) -> unsigned { return ldsW + ((kk & 1) ^ 1) * RG_W_BYTES; };
+      auto issue_a2 = [&](int q, int mode, int kk) __attribute__((always_inline)) {
+        if (mode == 2) {
+          rg_dma16s(pa2 + (long long)8 * q * p.ldc + kk * RG_BK, offa2, slab(kk) + q * 1024);
+        } else if (mode == 1) {
+          int r = row0 + 8 * q + lrow;
+          r = r < row_end ? r : row_end - 1;
+          rg_dma16(A2 + (long long)r * p.ldc + kk * RG_BK + cg * 8, slab(kk) + q * 1024);
+        }
+      };
+      auto issue_w2 = [&](int kk) __attribute__((always_inline)) {
+        const bf16_t* wb = p.chain_W + (long long)8 * wave * p.chain_ldw + kk * RG_BK;
+        const long long w_p = 8LL * R1_WAVES * p.chain_ldw;
+        const unsigned slot = wslot(kk);
+        rg_dma16s(wb, offw2, slot + wave * 1024);
+        rg_dma16s(wb + w_p, offw2, slot + (wave + R1_WAVES) * 1024);
+        if (nwp == 3) rg_dma16s(wb + 2 * w_p, offw2, slot + (wave + 2 * R1_WAVES) * 1024);
+      };
+      auto wait_vm = [&](int n) __attribute__((always_inline)) {   // s_waitcnt vmcnt(n), n = 0 .. 5 (the count is an immediate)
+        if (n >= 5) __builtin_amdgcn_s_waitcnt(0x0f75);
+        else if (n == 4) __builtin_amdgcn_s_waitcnt(0x0f74);
+        else if (n == 3) __builtin_amdgcn_s_waitcnt(0x0f73);
+        else if (n == 2) __builtin_amdgcn_s_waitcnt(0x0f72);
+        else if (n == 1) __builtin_amdgcn_s_waitcnt(0x0f71);
+        else __builtin_amdgcn_s_waitcnt(0x0f70);
+      };
+#pragma unroll
+      for (int kk = 0; kk < 3; ++kk) { issue_a2(q0, a0, kk); issue_a2(q1, a1, kk); }
+      issue_w2(1);   // (weight stage 0 has been on its way since the third quarter of the write-out)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        // in flight behind the wait: what was issued after this stage's operands -- stage 1: W(2) + slab 3; stage 2: W(3)
+        wait_vm(kk == 1 ? nwp + nA : (kk == 2 ? nwp : 0));
+        __builtin_amdgcn_s_barrier();
+        const unsigned char* SA = smem + (kk % 3) * R1_A_BYTES;
+        const unsigned char* SW = smem + 3 * R1_A_BYTES + ((kk & 1) ^ 1) * RG_W_BYTES;
+        bf16x8 fa[2], fw[2][4];
+        fa[0] = *reinterpret_cast<const bf16x8*>(SA + a_row + xo[0]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fw[0][j] = *reinterpret_cast<const bf16x8*>(SW + w_row + j * 4096 + xo[0]);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const int cur = ks & 1, nxt = cur ^ 1;
+          if (ks < 3) {
+            fa[nxt] = *reinterpret_cast<const bf16x8*>(SA + a_row + xo[ks + 1]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fw[nxt][j] = *reinterpret_cast<const bf16x8*>(SW + w_row + j * 4096 + xo[ks + 1]);
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur], fw[cur][j], acc[j], 0, 0, 0);
+        }
+        if (kk < 2) {
+          asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // every wave has read this stage's weight slot (and slab 0): they may be refilled
+          issue_w2(kk + 2);
+          if (kk == 0) { issue_a2(q0, a0, 3); issue_a2(q1, a1, 3); }
+        }
+      }
+      bf16_t* out2 = p.chain_C + wn * 128 + fr;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wrow0 + rg_frag_row(r, ln2);
+        if (full || row < row_end) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) out2[(long long)row * p.chain_ldc + j * 32] = f2bf(acc[j][r]);
+        }
+      }
     }
   } else if (EPI == EPI_RES_F32) {
     const float* res = reinterpret_cast<const float*>(p.aux_in) + wn * 128 + fr;
@@ -883,6 +985,8 @@ int launch_gemm_ring256(const GemmArgs& a, int epi, hipStream_t s) {
     int nwg = 0;
     COATI_CHECK_SHAPE(gemm_ring_lnbwd_supported(a, &nwg), "gemm_ring: EPI_LNBWD needs N = 256 and 40 961 .. 57 344 rows (M=%d N=%d K=%d)", a.M, a.N, a.K);
     COATI_CHECK_ARG(a.lnb_x && a.lnb_mean && a.lnb_rstd && a.lnb_gamma && a.lnb_partial && a.aux_in && a.C && a.bias == nullptr, "gemm_ring: EPI_LNBWD operands missing");
+    COATI_CHECK_ARG(a.chain_W == nullptr || (a.aux_out != nullptr && a.chain_C != nullptr && a.chain_ldw % 8 == 0 && a.chain_ldc % 8 == 0 && 260LL * a.chain_ldw < (1LL << 30)),
+                    "gemm_ring: EPI_LNBWD chained product needs the bf16 copy (aux_out), chain_C and aligned pitches");
     COATI_CHECK_SHAPE(a.lnb_ldx == a.ldc && a.ld_aux == a.ldc && ((long long)a.M + 8) * a.ldc * 4 < (1LL << 32), "gemm_ring: EPI_LNBWD wants one row pitch for x / dres / dx (ldx=%lld ld_aux=%lld ldc=%lld)", a.lnb_ldx, a.ld_aux, a.ldc);
     return launch_ring1_t<EPI_LNBWD>(a, cdiv(cdiv(a.M, 256), 8) * 8, s);
   }

@@ -89,6 +89,13 @@ struct GemmArgs {
   const float* lnb_rstd;    // [M]
   const float* lnb_gamma;   // [N]
   float* lnb_partial;       // [workgroups][2 N]
+  // EPI_LNBWD, optional: a SECOND product chained behind the LayerNorm backward in the same launch -- chain_C (bf16 [M, 256]) =
+  // dx16 chain_W^T with chain_W [256, 256] bf16 (the c_proj input gradient that consumes ln_2's backward output: the rows are
+  // re-read from L2 by the workgroup that has just written them); needs aux_out
+  const bf16_t* chain_W;
+  long long chain_ldw;
+  bf16_t* chain_C;
+  long long chain_ldc;
 };
 
 int launch_gemm_nt(const GemmArgs& a, int a_f32, int epi, hipStream_t s);

@@ -49,7 +49,7 @@ def gemm_nt(A, W, bias=None, epi=EPI_BF16, aux_in=None, out=None, n_store=0):
     return (out, aux_out) if aux_out is not None else out
 
 
-def gemm_lnbwd(dY, WT, x, mean, rstd, gamma, dres, want16=True):
+def gemm_lnbwd(dY, WT, x, mean, rstd, gamma, dres, want16=True, chain_W=None):
     """dy = dY @ WT^T is the gradient w.r.t. the output of LayerNorm(x; gamma): returns (dx f32 = dres + LN-backward(dy), dx16 bf16 | None,
     dgamma, dbeta) -- the ring GEMM with the LayerNorm backward in its write-out (coati_gemm_lnbwd)."""
     import ctypes
@@ -59,9 +59,12 @@ def gemm_lnbwd(dY, WT, x, mean, rstd, gamma, dres, want16=True):
     dx16 = torch.empty(M, 256, device=dY.device, dtype=BF16) if want16 else None
     partial = torch.zeros(256, 512, device=dY.device, dtype=torch.float32)
     n = ctypes.c_int32(0)
+    chain_C = torch.empty(M, 256, device=dY.device, dtype=BF16) if chain_W is not None else None
     _lib.call("coati_gemm_lnbwd", ptr(dY), dY.stride(0), ptr(WT), WT.stride(0), M, K, ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(dres),
-              ptr(dx), ptr(dx16), ptr(partial), ctypes.byref(n), stream())
+              ptr(dx), ptr(dx16), ptr(partial), ctypes.byref(n), ptr(chain_W), ptr(chain_C), stream())
     s = partial[: n.value].sum(0)
+    if chain_W is not None:        # + chain_C = dx16 @ chain_W^T, computed in the same launch
+        return dx, dx16, s[:256], s[256:], chain_C
     return dx, dx16, s[:256], s[256:]
 
 

@@ -66,10 +66,13 @@ int coati_gemm_nt(const void* A, int a_f32, int64_t lda, const uint16_t* B, int6
  * memory; dx[M,256] (f32) = dres + LayerNorm-backward(dy | x, mean, rstd, gamma) (dx may be dres: in place), dx16 (optional) its
  * bf16 copy, partial[*n_partial_rows][512] per-workgroup sums of dgamma | dbeta (add the rows up).  Replaces F.linear's input
  * gradient + nn.LayerNorm's backward.  256 columns, K % 64 == 0, 40 961 .. 57 344 rows (a packed batch; the engine runs the two
- * kernels separately elsewhere): COATI_ESHAPE otherwise.  partial must hold 256 x 512 floats. */
+ * kernels separately elsewhere): COATI_ESHAPE otherwise.  partial must hold 256 x 512 floats.
+ * chain_W [256, 256] / chain_C [M, 256] bf16 (optional, both or neither; needs dx16): a second product chained behind the LayerNorm
+ * backward in the same launch, chain_C = dx16 chain_W^T -- c_proj's input gradient, which consumes ln_2's backward output
+ * (basic_transformer.py:165-169 backward): the rows come back from L2 to the workgroup that has just written them. */
 int coati_gemm_lnbwd(const uint16_t* dY, int64_t lda, const uint16_t* WT, int64_t ldw, int M, int K, const float* x, const float* mean,
                      const float* rstd, const float* gamma, const float* dres, float* dx, uint16_t* dx16, float* partial,
-                     int32_t* n_partial_rows, void* stream);
+                     int32_t* n_partial_rows, const uint16_t* chain_W, uint16_t* chain_C, void* stream);
 
 /* MXFP8 (OCP Microscaling: e4m3 elements, one E8M0 scale per 32 consecutive k) -- BASELINE.json configs[4] "fp8 MFMA GEMMs".
  * coati_quant_mx8: rows of bf16 (x_f32 = 0) or f32 x [M, K] -> q [M, K] e4m3 bytes + scales [M, K / 32] (K % 32 == 0; shared

@@ -198,9 +198,15 @@ def test_gemm_with_layernorm_backward_in_the_write_out(ops, M, K):
     from coati_amd.ops import ptr, stream
     partial = torch.zeros(256, 512, device=DEV)
     n = ctypes.c_int32(0)
-    _lib.call("coati_gemm_lnbwd", ptr(dY.bfloat16()), K, ptr(WT.bfloat16()), K, M, K, ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(dres2),
-              ptr(dres2), None, ptr(partial), ctypes.byref(n), stream())
+    dY16, WT16 = dY.bfloat16(), WT.bfloat16()
+    _lib.call("coati_gemm_lnbwd", ptr(dY16), K, ptr(WT16), K, M, K, ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(dres2),
+              ptr(dres2), None, ptr(partial), ctypes.byref(n), None, None, stream())
     assert torch.equal(dres2, dx)
+    # the chained second product (c_proj's input gradient on the rows the launch has just written): dx16 @ Wc^T, bf16 out
+    Wc = rbf(torch.randn(256, 256, generator=g) / 16.0).to(DEV)
+    dx_c, dx16_c, dg_c, db_c, chain = ops.gemm_lnbwd(dY16, WT16, x, mean, rstd, gamma, dres, chain_W=Wc.bfloat16())
+    assert torch.equal(dx_c, dx) and torch.equal(dx16_c, dx16)
+    check(f"gemm+ln bwd chained product {M}x{K}", chain.float(), dx16.float() @ Wc.t(), TB)
 
 
 @pytest.mark.parametrize("B,T,nh,hs", [(3, 12, 4, 16), (5, 80, 16, 16), (2, 250, 4, 16), (4, 33, 2, 16),
