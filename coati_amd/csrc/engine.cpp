@@ -754,7 +754,10 @@ int xformer_wgrad_group(coati_engine* e, XPass& p, int l_lo, int l_hi, hipStream
 
 // dyf: gradient w.r.t. ln_f output, bf16 (decoder pass) or f32 (encoder pass)
 // layers [l_lo, l_hi) only, descending; the ln_f backward belongs to l_hi == L, the embedding backward to l_lo == 0
-int xformer_bwd(coati_engine* e, XPass& p, const void* dyf, int dyf_f32, float* dinjection, hipStream_t s, int l_hi = -1, int l_lo = 0) {
+// lmh_dlogits (decoder pass): d logits [M, Vpad] bf16 -- dyf (= e->da) has NOT been computed yet, xformer_bwd runs the lm_head's
+// input-gradient product itself (with ln_f's backward fused into it at packed-batch sizes)
+int xformer_bwd(coati_engine* e, XPass& p, const void* dyf, int dyf_f32, float* dinjection, hipStream_t s, int l_hi = -1, int l_lo = 0,
+                const bf16_t* lmh_dlogits = nullptr) {
   const coati_config& c = e->cfg;
   const int C = c.n_hidden_xformer, L = c.n_layer_xformer, M = p.M;
   if (l_hi < 0) l_hi = L;
@@ -779,11 +782,11 @@ int xformer_bwd(coati_engine* e, XPass& p, const void* dyf, int dyf_f32, float* 
   // same launch
   auto dgrad_lnbwd = [&](int site, const bf16_t* dY, int K, const bf16_t* WT, const float* x, const float* mean, const float* rstd,
                          const float* gamma, size_t goff, size_t boff, bf16_t* dx16, const bf16_t* chainW = nullptr,
-                         bf16_t* chainC = nullptr) -> int {
+                         bf16_t* chainC = nullptr, bool has_dres = true) -> int {
     if (!defer || c.use_fp8) return 0;
     GemmArgs a;
     memset(&a, 0, sizeof(a));
-    a.A = dY; a.lda = K; a.B = WT; a.ldb = K; a.M = M; a.N = C; a.K = K; a.C = DX; a.ldc = C; a.aux_in = DX; a.ld_aux = C; a.aux_out = dx16;
+    a.A = dY; a.lda = K; a.B = WT; a.ldb = K; a.M = M; a.N = C; a.K = K; a.C = DX; a.ldc = C; a.aux_in = has_dres ? DX : nullptr; a.ld_aux = C; a.aux_out = dx16;
     a.lnb_x = x; a.lnb_ldx = C; a.lnb_mean = mean; a.lnb_rstd = rstd; a.lnb_gamma = gamma;
     if (chainW != nullptr && dx16 != nullptr) { a.chain_W = chainW; a.chain_ldw = C; a.chain_C = chainC; a.chain_ldc = C; }
     int nwg = 0;
@@ -795,7 +798,7 @@ int xformer_bwd(coati_engine* e, XPass& p, const void* dyf, int dyf_f32, float* 
     ++fin.n;
     // algorithmic bytes: dY + weight in; x, dres in; dx (f32) + its bf16 copy out
     ProfScope ps(e, site, 2.0 * M * C * K + (a.chain_W ? 2.0 * M * C * C : 0.0), s,
-                 (double)M * K * 2 + (double)C * K * 2 + (double)M * C * (4 + 4 + 4 + (dx16 ? 2 : 0)) + (a.chain_W ? (double)M * C * 2 + (double)C * C * 2 : 0.0));
+                 (double)M * K * 2 + (double)C * K * 2 + (double)M * C * (4 + (has_dres ? 4 : 0) + 4 + (dx16 ? 2 : 0)) + (a.chain_W ? (double)M * C * 2 + (double)C * C * 2 : 0.0));
     const int rc = launch_gemm_nt(a, 0, EPI_LNBWD, s);
     return rc == COATI_OK ? 1 : rc;
   };
@@ -807,8 +810,19 @@ int xformer_bwd(coati_engine* e, XPass& p, const void* dyf, int dyf_f32, float* 
     ProfScope ps(e, SITE_XF_TAIL, 0, s, (double)p.B * C * ((dyf_f32 ? 4 : 2) + 4 + 4 + 2));
     COATI_TRY(launch_layernorm_bwd(dyf, dyf_f32, C, p.t_xL, C, 0, p.t_meanf, p.t_rstdf, e->P + e->lnfw, nullptr, e->t_dx, e->t_dxa, e->G + e->lnfw, e->G + e->lnfb, e->ln_partial, p.B, C, s));
   } else if (l_hi == L) {
-    ProfScope ps(e, SITE_LN_BWD, 0, s, (double)M * C * ((dyf_f32 ? 4 : 2) + 4 + 4 + 2));
-    COATI_TRY(ln_bwd(dyf, dyf_f32, p.x[L], p.meanf, p.rstdf, e->P + e->lnfw, nullptr, e->lnfw, e->lnfb, grp ? e->w_dxa[L - 1] : e->DX16));
+    // decoder pass: dyf is the lm_head's input gradient, not yet computed (lmh_dlogits != null): the product runs here, with ln_f's
+    // backward in its write-out where the shape takes it
+    int lnf_fused = 0;
+    if (lmh_dlogits != nullptr) {
+      lnf_fused = dgrad_lnbwd(SITE_LMHEAD_DGRAD, lmh_dlogits, e->Vpad, e->S + e->lmheadT, p.x[L], p.meanf, p.rstdf, e->P + e->lnfw, e->lnfw, e->lnfb,
+                              grp ? e->w_dxa[L - 1] : e->DX16, nullptr, nullptr, false);
+      if (lnf_fused < 0) return lnf_fused;
+      if (!lnf_fused) COATI_TRY(gemm(e, SITE_LMHEAD_DGRAD, lmh_dlogits, 0, e->Vpad, e->S + e->lmheadT, e->Vpad, M, C, e->Vpad, e->da, C, nullptr, EPI_BF16, nullptr, nullptr, 0, s));
+    }
+    if (!lnf_fused) {
+      ProfScope ps(e, SITE_LN_BWD, 0, s, (double)M * C * ((dyf_f32 ? 4 : 2) + 4 + 4 + 2));
+      COATI_TRY(ln_bwd(dyf, dyf_f32, p.x[L], p.meanf, p.rstdf, e->P + e->lnfw, nullptr, e->lnfw, e->lnfb, grp ? e->w_dxa[L - 1] : e->DX16));
+    }
   }
   for (int l = l_hi - 1; l >= l_lo; --l) {
     const XLayerP& w = e->xl[l];
@@ -1470,11 +1484,10 @@ int coati_engine_backward(coati_engine* e, const float* dh_smiles, const float* 
       ProfScope ps(e, SITE_LMHEAD_DLOGITS, 2.0 * M2 * c.n_tok * C, s, (double)M2 * C * 2 + (double)c.n_tok * C * 2 + (double)M2 * e->Vpad * 2);
       COATI_TRY(launch_gemm_nt(a, 0, EPI_CE_BWD, s));
     }
-    COATI_TRY(gemm(e, SITE_LMHEAD_DGRAD, e->dlogits, 0, e->Vpad, e->S + e->lmheadT, e->Vpad, M2, C, e->Vpad, e->da, C, nullptr, EPI_BF16, nullptr, nullptr, 0, s));
     COATI_TRY(wgrad(e, SITE_LMHEAD_WGRAD, e->dlogits, 0, e->Vpad, e->p2.af, C, M2, e->Vpad, C, e->G + e->lmhead, C, nullptr, c.n_tok, s));
-    // ---- decoder pass ----
+    // ---- decoder pass (its first launch: the lm_head's input gradient d(af) = dlogits W, + ln_f's backward) ----
     HIPCHK(hipMemsetAsync(e->dcliptok, 0, (size_t)B * E * sizeof(float), s));
-    COATI_TRY(xformer_bwd(e, e->p2, e->da, 0, e->dcliptok, s));
+    COATI_TRY(xformer_bwd(e, e->p2, e->da, 0, e->dcliptok, s, -1, 0, e->dlogits));
     // dh = external (contrastive) gradient + the special-token path
     if (dh_e3gnn) HIPCHK(hipMemcpyAsync(e->dhe, dh_e3gnn, (size_t)B * E * sizeof(float), hipMemcpyDeviceToDevice, s));
     else HIPCHK(hipMemsetAsync(e->dhe, 0, (size_t)B * E * sizeof(float), s));

@@ -495,6 +495,7 @@ __global__ __launch_bounds__(64 * R1_WAVES, 1) void gemm_ring1_kernel(GemmArgs p
     // uniform base pointers + one 32-bit BYTE offset per row (x, dres, dx and dx16 share one row pitch: launch check)
     const float* const xin = p.lnb_x;
     const float* const res = reinterpret_cast<const float*>(p.aux_in);
+    const bool has_res = p.aux_in != nullptr;                     // (ln_f: nothing joins the stream behind it)
     float* const out = reinterpret_cast<float*>(p.C);
     bf16_t* const out16 = reinterpret_cast<bf16_t*>(p.aux_out);   // (same row pitch in elements: byte offsets halve)
     const bool has16 = p.aux_out != nullptr;
@@ -552,7 +553,7 @@ __global__ __launch_bounds__(64 * R1_WAVES, 1) void gemm_ring1_kernel(GemmArgs p
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) dr[i][j] = rg_ld(res, ro[b][i], j * 128);
+        for (int j = 0; j < 4; ++j) dr[i][j] = has_res ? rg_ld(res, ro[b][i], j * 128) : 0.f;
       float v[8];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -984,10 +985,10 @@ int launch_gemm_ring256(const GemmArgs& a, int epi, hipStream_t s) {
   if (epi == EPI_LNBWD) {
     int nwg = 0;
     COATI_CHECK_SHAPE(gemm_ring_lnbwd_supported(a, &nwg), "gemm_ring: EPI_LNBWD needs N = 256 and 40 961 .. 57 344 rows (M=%d N=%d K=%d)", a.M, a.N, a.K);
-    COATI_CHECK_ARG(a.lnb_x && a.lnb_mean && a.lnb_rstd && a.lnb_gamma && a.lnb_partial && a.aux_in && a.C && a.bias == nullptr, "gemm_ring: EPI_LNBWD operands missing");
+    COATI_CHECK_ARG(a.lnb_x && a.lnb_mean && a.lnb_rstd && a.lnb_gamma && a.lnb_partial && a.C && a.bias == nullptr, "gemm_ring: EPI_LNBWD operands missing");
     COATI_CHECK_ARG(a.chain_W == nullptr || (a.aux_out != nullptr && a.chain_C != nullptr && a.chain_ldw % 8 == 0 && a.chain_ldc % 8 == 0 && 260LL * a.chain_ldw < (1LL << 30)),
                     "gemm_ring: EPI_LNBWD chained product needs the bf16 copy (aux_out), chain_C and aligned pitches");
-    COATI_CHECK_SHAPE(a.lnb_ldx == a.ldc && a.ld_aux == a.ldc && ((long long)a.M + 8) * a.ldc * 4 < (1LL << 32), "gemm_ring: EPI_LNBWD wants one row pitch for x / dres / dx (ldx=%lld ld_aux=%lld ldc=%lld)", a.lnb_ldx, a.ld_aux, a.ldc);
+    COATI_CHECK_SHAPE(a.lnb_ldx == a.ldc && (a.aux_in == nullptr || a.ld_aux == a.ldc) && ((long long)a.M + 8) * a.ldc * 4 < (1LL << 32), "gemm_ring: EPI_LNBWD wants one row pitch for x / dres / dx (ldx=%lld ld_aux=%lld ldc=%lld)", a.lnb_ldx, a.ld_aux, a.ldc);
     return launch_ring1_t<EPI_LNBWD>(a, cdiv(cdiv(a.M, 256), 8) * 8, s);
   }
   // block height: rows the busiest of the 256 persistent workgroups walks = rounds x block rows; ties go to the 160-row form

@@ -212,7 +212,10 @@ def distributed_train_step(eng, batch, use_point, lr, do_clip=True, optimizer=Tr
         # so the split costs 2 ms of compute per step to hide an all-reduce of 50 MB (round 2, world size 1 over RCCL:
         # 36.2 ms split).  The lm_head / head buckets still travel underneath this stage.
         eng.backward(None, None, stage=2)
-        launch("xformer_hi"); launch("xformer_lo")
+        # (one collective for the whole transformer range: the two halves are adjacent in the flat buffer, and every collective
+        #  costs a pair of stream hand-overs -- 0.13 ms each measured at world size 1)
+        if reduce_grads:
+            works.append(all_reduce_avg_async(eng.grads[bk["xformer_lo"][0]:bk["xformer_hi"][1]]))
     eng.backward(None, None, stage=3)
     launch("gnn")
     for w in works:
