@@ -20,6 +20,12 @@
 #include <cstdlib>
 #include "kernels.h"
 
+#ifndef RG_ABLATE
+#define RG_ABLATE 0     // probe builds (COATI_AMD_CXXFLAGS=-DRG_ABLATE=n): 1 = no weight stream, 2 = no A stream, 3 = neither (ring1 k loop)
+#endif
+#ifndef RG_ABLATE
+#define RG_ABLATE 0     // probe builds (COATI_AMD_CXXFLAGS=-DRG_ABLATE=n, tools/ring_ablate.py): 1 = no weight stream, 2 = no A stream, 3 = neither (gemm_ring1_kernel's k loop)
+#endif
 #ifndef RG_PRIO
 #define RG_PRIO 0   // (probe: MFMA section at raised priority -- within the noise on every ring site, unlike the row-block kernel)
 #endif
@@ -432,6 +438,11 @@ __global__ __launch_bounds__(64 * R1_WAVES, 1) void gemm_ring1_kernel(GemmArgs p
   }
   int sa = 0, sw = 0;                      // ring slots of the stage being multiplied
   int kk1 = kwrap(kk0 + 1), kk2 = kwrap(kk1 + 1);   // k chunks of stages s + 1, s + 2
+  // (Round 4, tools/ring_ablate.py: with NO operand stream behind the prologue -- -DRG_ABLATE=3 -- the K = 1024 launch takes 31.3 us
+  //  instead of 32.8: the k loop is bound by its own barrier / fragment-read / MFMA cadence, 1.6 us per stage against 0.85 us of MFMA
+  //  issue on the 4-wave SIMDs, not by HBM or L2.  Running the MFMA stream one k step behind the reads ACROSS the stage barrier, so
+  //  that the matrix core has 4 MFMAs per wave to chew on while the new stage's first fragments come out of LDS, was built and
+  //  measured on one box: 34.0-34.2 vs 34.4-34.9 us isolated, 22.42 vs 22.44 ms per step -- nothing; not kept.)
   for (int s = 0; s < nk; ++s) {
     // stage s has landed (this wave's pieces; the barrier covers the others) and every wave is done with stage s - 1, whose
     // slots the DMAs of this stage overwrite; in flight behind the wait: the A pieces of stage s + 1
@@ -449,8 +460,16 @@ __global__ __launch_bounds__(64 * R1_WAVES, 1) void gemm_ring1_kernel(GemmArgs p
       for (int ks = 0; ks < 4; ++ks) {
         const int cur = ks & 1, nxt = cur ^ 1;
         if (ks < 3) {
+#if RG_ABLATE == 1      // probe build: no weight stream behind the prologue (stale stage in LDS: timing only)
+          if (ks == 0) { }
+          else if (s + 2 < nk) issue_a_piece(ks == 1 ? q0 : q1, ks == 1 ? a0 : a1, kk2, lds0 + sa2 * R1_A_BYTES);
+#elif RG_ABLATE == 2    // probe build: no A stream behind the prologue
+          if (ks == 0) { if (s + 1 < nk) issue_w(kk1, ldsW + (sw ^ 1) * RG_W_BYTES); }
+#elif RG_ABLATE == 3    // probe build: neither
+#else
           if (ks == 0) { if (s + 1 < nk) issue_w(kk1, ldsW + (sw ^ 1) * RG_W_BYTES); }
           else if (s + 2 < nk) issue_a_piece(ks == 1 ? q0 : q1, ks == 1 ? a0 : a1, kk2, lds0 + sa2 * R1_A_BYTES);
+#endif
           fa[nxt] = *reinterpret_cast<const bf16x8*>(SA + a_row + xo[ks + 1]);
 #pragma unroll
           for (int j = 0; j < 4; ++j) fw[nxt][j] = *reinterpret_cast<const bf16x8*>(SW + w_row + j * 4096 + xo[ks + 1]);
