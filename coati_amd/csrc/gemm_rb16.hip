@@ -11,8 +11,14 @@
 // workgroup barrier per tile.  The product is issued TRANSPOSED (weight rows as the MFMA's row operand, the slab as its column
 // operand) with the tile's weight rows permuted among the MFMA blocks so that a lane ends with 8 / 16 CONSECUTIVE columns of one
 // output row: the epilogue (gemm_epi.h) runs straight out of the accumulators -- no LDS transpose, no per-wave LDS at all.
-// What bounds it now: every wave reads the whole 32-KiB tile out of LDS for 16 rows (twice the 32-row kernel's bytes per flop):
-// ~21 of the 40 us of the plain N = 1024 product are LDS-read cycles; the activation epilogues add their VALU time on top.
+// What bounds it (round 4, tools/rb16_ablate.py -> profiles/r04_rb16_ablate.txt; 50 000 rows, N = 1024, bf16 out: 41 us): with no
+// weight stream 38, with no stores 32, with one operand read per tile instead of eight 36, with all three gone 26 -- against 13.6 us
+// of MFMA issue on the SIMD that carries 4 of the 13 waves.  The NewGELU + codes write-out: 70 us, of which 22 are the activation's
+// VALU work (56 with the stores gone, 34 with the math gone too) and 14 the store stream.  An MFMA wave and a VALU (or LDS-read)
+// wave on ONE SIMD do not overlap on this chip (tools/probes/coissue_probe.hip -> profiles/r04_coissue_probe.txt: MFMA 489 us,
+// plain fma 263, both on one SIMD 693; exp2 258 -> 753; packed f32 fma runs at HALF rate, 487 -> 928), so the phases of a tile add
+// up whichever wave they sit in: static wave priorities (the waves of a SIMD taking turns: -DR16_PRIO=1) and a raised MFMA phase
+// (=2) change nothing, and neither does a workgroup of 12 instead of 13 waves (49 152 rows).
 #include <cstdlib>
 #include "gemm_epi.h"
 
@@ -21,7 +27,16 @@
 #define R16_TILE_HALFS (R16_BN * R16_K)          // 32 KiB per buffer
 #define R16_BIAS_MAX 4096                        // bias vectors up to this many columns are staged in LDS (longer: not this kernel)
 #define R16_MAXW 16
+#ifndef R16_PRIO
+#define R16_PRIO 0       // probe: 1 = static wave priority 3 - (wave >> 2) (the waves of a SIMD take turns), 2 = MFMA phase raised
+#endif
+#ifndef R16_ABLATE
+#define R16_ABLATE 0     // probe builds (COATI_AMD_CXXFLAGS=-DR16_ABLATE=bits, tools/rb16_ablate.py): timing only, results are wrong
+#endif
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
+#if R16_ABLATE & 16
+__device__ unsigned char r16_sink[512 * 4096];
+#endif
 
 // cur / nxt reach the tile body as __restrict__ parameters: the compiler otherwise waits for every pending global_load_lds
 // before an LDS read it cannot prove disjoint from the DMA's target
@@ -146,7 +161,20 @@ __global__ __launch_bounds__(64 * R16_MAXW, 1) void gemm_rb16_kernel(GemmArgs p,
   };
   GemmArgs q = p;
   q.bias = nullptr;   // folded into the accumulator initialisation
+#if R16_ABLATE & 16       // probe builds: bit 4 = every store goes to a 4-KiB region per workgroup (L2 hits, no HBM write stream)
+  q.C = r16_sink + (blockIdx.x & 255) * 4096; q.ldc = 0;
+  q.aux_out = r16_sink + (256 + (blockIdx.x & 255)) * 4096; q.ld_aux = 0;
+#define p q
+#endif
 
+#if R16_PRIO == 1
+  switch (__builtin_amdgcn_readfirstlane(wave) >> 2) {
+    case 0: __builtin_amdgcn_s_setprio(3); break;
+    case 1: __builtin_amdgcn_s_setprio(2); break;
+    case 2: __builtin_amdgcn_s_setprio(1); break;
+    default: __builtin_amdgcn_s_setprio(0); break;
+  }
+#endif
   const int j0 = rot ? (int)(blockIdx.x % (unsigned)ntiles) : 0;
   load_tile(j0 * R16_BN, Bs);
   __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0)
@@ -161,10 +189,16 @@ __global__ __launch_bounds__(64 * R16_MAXW, 1) void gemm_rb16_kernel(GemmArgs p,
     wsw[a] = r16_swz<MAP>(n);
   }
   const int colA = MAP == 0 ? 8 * kq : 16 * kq, colB = MAP == 0 ? 32 + 8 * kq : 16 * kq + 8;   // acc[0..1] -> colA .. + 7, acc[2..3] -> colB .. + 7
+#if R16_ABLATE & 2         // probe builds: bit 1 = no stores in the write-out
+  const bool rowok = row_l < 0;
+#else
   const bool rowok = row_l < p.M;
+#endif
 
   auto tile = [&](int jt, int jn, const bf16_t* cur, bf16_t* nxt) {
+#if !(R16_ABLATE & 1)     // probe builds (tools/rb16_ablate.py): bit 0 = no weight stream behind the first tile
     load_tile(jn * R16_BN, nxt);
+#endif
     uint4 xq = make_uint4(0, 0, 0, 0);
     if constexpr (EPI == EPI_MUL_AUX) {
       // the 16 saved NewGELU' codes of this lane's columns (MAP 0: two 8-B pieces), in flight during the MFMA phase
@@ -184,19 +218,32 @@ __global__ __launch_bounds__(64 * R16_MAXW, 1) void gemm_rb16_kernel(GemmArgs p,
       for (int a = 0; a < 4; ++a) acc[a] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     }
     {
+#if R16_PRIO == 2
+      __builtin_amdgcn_s_setprio(3);
+#endif
       bf16x8 wf[2][4];
 #pragma unroll
       for (int a = 0; a < 4; ++a) wf[0][a] = *reinterpret_cast<const bf16x8*>(cur + wofs[a] + ((kq ^ wsw[a]) * 8));
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) {
+#if R16_ABLATE & 4        // probe builds: bit 2 = one LDS operand read per tile instead of eight
+        if (ks == 0) {
+#pragma unroll
+          for (int a = 0; a < 4; ++a) wf[1][a] = wf[0][a];
+        }
+#else
         if (ks + 1 < 8) {
 #pragma unroll
           for (int a = 0; a < 4; ++a) wf[(ks + 1) & 1][a] = *reinterpret_cast<const bf16x8*>(cur + wofs[a] + (((4 * (ks + 1) + kq) ^ wsw[a]) * 8));
         }
+#endif
 #pragma unroll
         for (int a = 0; a < 4; ++a) acc[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks & 1][a], af[ks], acc[a], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
+#if R16_PRIO == 2
+      __builtin_amdgcn_s_setprio(0);
+#endif
     }
     __builtin_amdgcn_s_waitcnt(0x0f70);   // the next tile has landed (this wave's pieces): wait BEFORE this tile's stores are issued
     float v0[8] = {acc[0][0], acc[0][1], acc[0][2], acc[0][3], acc[1][0], acc[1][1], acc[1][2], acc[1][3]};
@@ -246,7 +293,14 @@ __global__ __launch_bounds__(64 * R16_MAXW, 1) void gemm_rb16_kernel(GemmArgs p,
         gelu_and_grad_f2(coati_v2f{v1[e], v1[e + 1]}, hh, dd);
         v1[e] = hh.x; v1[e + 1] = hh.y; d1[e] = dd.x; d1[e + 1] = dd.y;
       }
+#if R16_ABLATE & 8       // probe builds: bit 3 (with bit 1) = the activation math stays, its stores do not
+      float cks = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) cks += v0[e] + v1[e] + d0[e] + d1[e];
+      if ((rowok || cks == 1234.5f) && c0 + 16 <= p.N) {
+#else
       if (rowok && c0 + 16 <= p.N) {   // (N % 16 == 0)
+#endif
         const uint2 q0 = packq8(d0), q1 = packq8(d1);
         *reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(p.aux_out) + (unsigned)row_l * (unsigned)p.ld_aux + (unsigned)c0) = make_uint4(q0.x, q0.y, q1.x, q1.y);
         bf16_t* C = reinterpret_cast<bf16_t*>(p.C) + (unsigned)row_l * (unsigned)p.ldc + (unsigned)c0;
@@ -268,6 +322,9 @@ __global__ __launch_bounds__(64 * R16_MAXW, 1) void gemm_rb16_kernel(GemmArgs p,
     r16_call_restrict(tile, jt, jn, Bs + (j & 1) * R16_TILE_HALFS, Bs + ((j + 1) & 1) * R16_TILE_HALFS);
     jt = jn;
   }
+#if R16_ABLATE & 16
+#undef p
+#endif
 }
 
 // ---- weight-resident form for N <= 256 (round 3): the E(3)-GNN's edge-level products ------------------------------------
@@ -406,7 +463,9 @@ int launch_gemm_rb16_resident(const GemmArgs& a, int epi, hipStream_t s) {
   return launch_rb16_resident_t<EPI_BF16>(a, s);
 }
 
-// waves per workgroup for M rows: one round of one workgroup per CU
+// waves per workgroup for M rows: one round of one workgroup per CU.  (Round 4: TWO workgroups of half the waves per CU -- to fill
+// each other's barrier bubbles -- measured 23.04 vs 22.42 ms per step: each workgroup streams the whole weight, twice the L2 -> LDS
+// traffic per CU, and the bubbles are not where the time goes, see the header.)
 static int rb16_waves(int M) {
   const int slabs = (M + 15) / 16;
   return (slabs + 255) / 256;

@@ -21,9 +21,6 @@
 #include "kernels.h"
 
 #ifndef RG_ABLATE
-#define RG_ABLATE 0     // probe builds (COATI_AMD_CXXFLAGS=-DRG_ABLATE=n): 1 = no weight stream, 2 = no A stream, 3 = neither (ring1 k loop)
-#endif
-#ifndef RG_ABLATE
 #define RG_ABLATE 0     // probe builds (COATI_AMD_CXXFLAGS=-DRG_ABLATE=n, tools/ring_ablate.py): 1 = no weight stream, 2 = no A stream, 3 = neither (gemm_ring1_kernel's k loop)
 #endif
 #ifndef RG_PRIO
