@@ -19,6 +19,11 @@
 // plain fma 263, both on one SIMD 693; exp2 258 -> 753; packed f32 fma runs at HALF rate, 487 -> 928), so the phases of a tile add
 // up whichever wave they sit in: static wave priorities (the waves of a SIMD taking turns: -DR16_PRIO=1) and a raised MFMA phase
 // (=2) change nothing, and neither does a workgroup of 12 instead of 13 waves (49 152 rows).
+// Delayed stores -- a tile's packed outputs kept in registers across the tile barrier and stored at the top of the next tile, BEHIND
+// that tile's weight DMA, so that the wait after the MFMA phase becomes vmcnt(2 or 3) and never covers a store acknowledgement
+// (bare s_barrier instead of __syncthreads(), the saved-code loads of EPI_MUL_AUX from inline assembly: otherwise the compiler
+// drains vmcnt itself) -- were built, passed the parity tests and measured SLOWER: 22.55 vs 22.14 ms per step (A/B/A/B on one
+// box), 74.5 vs 70.7 us on the NewGELU launch.  The stores cost issue / write-path time, not acknowledgement latency.
 #include <cstdlib>
 #include "gemm_epi.h"
 
