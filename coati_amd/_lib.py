@@ -20,6 +20,14 @@ class CoatiConfig(ctypes.Structure):
 
 
 _SIGS = {
+    "coati_comm_unique_id": [P, I],
+    "coati_comm_init": [P, I, I, P],
+    "coati_comm_rank": [P],
+    "coati_comm_world": [P],
+    "coati_comm_destroy": [P],
+    "coati_allgather_rows": [P, P, P, L, L, I, P],
+    "coati_reducescatter_rows": [P, P, P, L, L, I, P],
+    "coati_allreduce_bucket": [P, P, L, I, I, P],
     "coati_gemm_nt": [P, I, L, P, L, I, I, I, P, L, I, P, P, P, L, I, P],
     "coati_gemm_lnbwd": [P, L, P, L, I, I, P, P, P, P, P, P, P, P, POINTER(c_int32), P, P, P],
     "coati_quant_mx8": [P, I, L, P, L, P, I, I, P],

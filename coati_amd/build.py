@@ -11,7 +11,7 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libcoati_hip.so")
 OBJDIR = os.path.join(HERE, "build")
 HIP_UNITS = ["gemm.hip", "gemm_rb.hip", "gemm_rb16.hip", "gemm_ring.hip", "gemm_mx8.hip", "norm.hip", "attention.hip", "embed.hip", "gnn.hip", "loss.hip", "optim.hip", "batch.hip", "decode.hip"]
-CPP_UNITS = ["engine.cpp", "capi.cpp", "tokenizer.cpp"]
+CPP_UNITS = ["engine.cpp", "capi.cpp", "tokenizer.cpp", "comm.cpp"]
 # -amdgpu-mfma-vgpr-form: MFMA results in VGPRs (gfx950 has one unified register file).  Where the compiler picked the AGPR form
 # (the attention forward kernels) 13 % of the instructions were v_accvgpr_read / write moves in a VALU-bound kernel
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-mllvm", "-amdgpu-mfma-vgpr-form=1"] + os.environ.get("COATI_AMD_CXXFLAGS", "").split()   # (probe builds: -DCOATI_RB_TRACE)
@@ -72,7 +72,7 @@ def _build_locked(verbose):
     # link next to the target and rename: a rank that arrives while another one is linking (the unlocked fast path above)
     # must never dlopen a half-written library
     tmp = LIB + f".tmp{os.getpid()}"
-    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-lpthread", "-o", tmp], capture_output=True, text=True)
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-lpthread", "-ldl", "-o", tmp], capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stderr}")
     os.replace(tmp, LIB)

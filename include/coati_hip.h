@@ -392,6 +392,28 @@ long long coati_tokenizer_pieces(const coati_tokenizer* tk, const char* text, lo
 int coati_tokenizer_encode_batch(const coati_tokenizer* tk, const char* const* rows, int n_rows, int n_seq, int64_t* out,
                                  int32_t* len, int n_threads);
 
+/* ---- data-parallel exchange for hosts without torch.distributed -----------------------------------------
+   Stream-ordered calls into RCCL (resolved with dlopen at the first call: no link-time dependency; $COATI_RCCL_LIB overrides the
+   library name).  One communicator per process = per GPU, bound to the HIP device that is current at coati_comm_init.  They are
+   the three collectives of the step: the embedding all-gather (reference AllGatherFunction.forward,
+   coati/models/autograd_funs/autograd_funs.py:10-14), the reduce-scatter of the embedding gradients (.backward, :16-21) and the
+   gradient-bucket all-reduce (DistributedDataParallel, coati/training/train_coati.py:71-76).  dtype: 0 = f32, 1 = bf16.
+   The Python host of this repository uses torch.distributed (backend "nccl" = the same library) instead. */
+#define COATI_COMM_ID_BYTES 128
+typedef struct coati_comm coati_comm;
+/* rank 0 draws the id and hands it to the other ranks by the host's own means (file, socket, MPI, ...) */
+int coati_comm_unique_id(void* id_out, int id_bytes);
+int coati_comm_init(const void* unique_id, int rank, int world, coati_comm** out);
+int coati_comm_rank(const coati_comm* c);
+int coati_comm_world(const coati_comm* c);
+int coati_comm_destroy(coati_comm* c);
+/* recv[world * rows, cols] <- the ranks' send[rows, cols], rank-major */
+int coati_allgather_rows(coati_comm* c, const void* send, void* recv, int64_t rows, int64_t cols, int dtype, void* stream);
+/* recv[rows, cols] <- this rank's row block of the SUM over ranks of send[world * rows, cols] */
+int coati_reducescatter_rows(coati_comm* c, const void* send, void* recv, int64_t rows, int64_t cols, int dtype, void* stream);
+/* buf[n] <- sum (average != 0: mean) over ranks, in place */
+int coati_allreduce_bucket(coati_comm* c, void* buf, int64_t n, int dtype, int average, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -398,3 +398,16 @@ def test_trainer_passes_args_to_the_step():
     src = inspect.getsource(T.train_autoencoder)
     assert "weight_decay=float(args.weight_decay)" in src and "max_norm=float(args.clip_grad)" in src
     assert "eval_step" in src and "distributed_eval_step" in src and "**opt_kw" in src
+
+
+def test_comm_entries_reject_bad_arguments_without_a_gpu():
+    """coati_comm_*: argument checks come before RCCL is touched (no GPU, possibly no librccl, here)"""
+    from coati_amd import _lib
+    l = _lib.lib()
+    assert l.coati_comm_unique_id(None, 128) == -1
+    assert l.coati_comm_unique_id(ctypes.create_string_buffer(16), 16) == -1 and b"128" in l.coati_last_error()
+    assert l.coati_comm_init(None, 0, 1, None) == -1
+    uid = ctypes.create_string_buffer(128)
+    assert l.coati_comm_init(uid, 2, 2, ctypes.byref(ctypes.c_void_p())) == -1 and b"rank 2 of 2" in l.coati_last_error()
+    assert l.coati_allgather_rows(None, None, None, 1, 1, 0, None) == -1
+    assert l.coati_comm_rank(None) == -1 and l.coati_comm_world(None) == -1 and l.coati_comm_destroy(None) == 0
