@@ -21,7 +21,7 @@
 #include "kernels.h"
 
 #ifndef RG_ABLATE
-#define RG_ABLATE 0     // probe builds (COATI_AMD_CXXFLAGS=-DRG_ABLATE=n, tools/ring_ablate.py): 1 = no weight stream, 2 = no A stream, 3 = neither (gemm_ring1_kernel's k loop)
+#define RG_ABLATE 0     // probe builds (COATI_AMD_CXXFLAGS=-DRG_ABLATE=n, tools/ring_ablate.py): 1 = no weight stream, 2 = no A stream, 3 = neither, 4 = one fragment read per stage, 7 = 3 + 4 (gemm_ring1_kernel's k loop)
 #endif
 #ifndef RG_PRIO
 #define RG_PRIO 0   // (probe: MFMA section at raised priority -- within the noise on every ring site, unlike the row-block kernel)
@@ -462,18 +462,24 @@ __global__ __launch_bounds__(64 * R1_WAVES, 1) void gemm_ring1_kernel(GemmArgs p
           else if (s + 2 < nk) issue_a_piece(ks == 1 ? q0 : q1, ks == 1 ? a0 : a1, kk2, lds0 + sa2 * R1_A_BYTES);
 #elif RG_ABLATE == 2    // probe build: no A stream behind the prologue
           if (ks == 0) { if (s + 1 < nk) issue_w(kk1, ldsW + (sw ^ 1) * RG_W_BYTES); }
-#elif RG_ABLATE == 3    // probe build: neither
+#elif RG_ABLATE == 3 || RG_ABLATE == 7   // probe build: neither (7: and one fragment read per stage instead of four)
 #else
           if (ks == 0) { if (s + 1 < nk) issue_w(kk1, ldsW + (sw ^ 1) * RG_W_BYTES); }
           else if (s + 2 < nk) issue_a_piece(ks == 1 ? q0 : q1, ks == 1 ? a0 : a1, kk2, lds0 + sa2 * R1_A_BYTES);
 #endif
+#if RG_ABLATE >= 4       // probe builds 4 / 7: the fragments of k step 0 serve the whole stage (one LDS read round instead of four)
+          fa[nxt] = fa[cur];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) fw[nxt][j] = fw[cur][j];
+#else
           fa[nxt] = *reinterpret_cast<const bf16x8*>(SA + a_row + xo[ks + 1]);
 #pragma unroll
           for (int j = 0; j < 4; ++j) fw[nxt][j] = *reinterpret_cast<const bf16x8*>(SW + w_row + j * 4096 + xo[ks + 1]);
+#endif
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur], fw[cur][j], acc[j], 0, 0, 0);
-        if (ks < 3) {
+        if (RG_ABLATE < 4 && ks < 3) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
           __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
 #pragma unroll
