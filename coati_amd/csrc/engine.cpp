@@ -1072,12 +1072,13 @@ int gnn_bwd(coati_engine* e, const float* dhpoint, hipStream_t s) {
 }
 
 // fp32 Linear backward on [B, *] head tensors: dW += dY^T X ; db += colsum(dY) ; dX = dY W
-int head_linear_bwd(coati_engine* e, const float* dY, const float* X, int64_t w_off, int64_t b_off, float* dX, int B,
-                    int N, int K, hipStream_t s) {
+// (the three products join a batch: independent heads share one launch, gemm.hip sgemm_batch_kernel)
+int head_linear_bwd(coati_engine* e, SgemmBatch& sb, const float* dY, const float* X, int64_t w_off, int64_t b_off, float* dX, int B,
+                    int N, int K) {
   const float* W = e->P + w_off;
-  COATI_TRY(launch_sgemm(dY, 1, N, X, K, 1, e->G + w_off, K, N, K, B, nullptr, 1.f, 1, s));          // dW[n,k] += sum_b dY[b,n] X[b,k]
-  COATI_TRY(launch_sgemm(e->ones, 0, 1, dY, N, 1, e->G + b_off, N, 1, N, B, nullptr, 1.f, 1, s));    // db[n] += sum_b dY[b,n]
-  if (dX) COATI_TRY(launch_sgemm(dY, N, 1, W, K, 1, dX, K, B, K, N, nullptr, 1.f, 0, s));            // dX[b,k] = sum_n dY[b,n] W[n,k]
+  COATI_TRY(sgemm_batch_add(sb, dY, 1, N, X, K, 1, e->G + w_off, K, N, K, B, nullptr, 1.f, 1));          // dW[n,k] += sum_b dY[b,n] X[b,k]
+  COATI_TRY(sgemm_batch_add(sb, e->ones, 0, 1, dY, N, 1, e->G + b_off, N, 1, N, B, nullptr, 1.f, 1));    // db[n] += sum_b dY[b,n]
+  if (dX) COATI_TRY(sgemm_batch_add(sb, dY, N, 1, W, K, 1, dX, K, B, K, N, nullptr, 1.f, 0));            // dX[b,k] = sum_n dY[b,n] W[n,k]
   return COATI_OK;
 }
 
@@ -1358,8 +1359,10 @@ int coati_engine_forward(coati_engine* e, void* workspace, int64_t workspace_byt
   if (c.token_mlp) {
     COATI_TRY(launch_silu_fwd(e->h_e3gnn, e->sa, (long long)B * E, s));
     COATI_TRY(launch_silu_fwd(e->h_smiles, e->sb, (long long)B * E, s));
-    COATI_TRY(launch_sgemm(e->sa, E, 1, e->P + e->tokw, 1, E, e->ptok, E, B, E, E, e->P + e->tokb, 1.f, 0, s));
-    COATI_TRY(launch_sgemm(e->sb, E, 1, e->P + e->tokw, 1, E, e->stok, E, B, E, E, e->P + e->tokb, 1.f, 0, s));
+    SgemmBatch sb;
+    COATI_TRY(sgemm_batch_add(sb, e->sa, E, 1, e->P + e->tokw, 1, E, e->ptok, E, B, E, E, e->P + e->tokb, 1.f, 0));
+    COATI_TRY(sgemm_batch_add(sb, e->sb, E, 1, e->P + e->tokw, 1, E, e->stok, E, B, E, E, e->P + e->tokb, 1.f, 0));
+    COATI_TRY(launch_sgemm_batch(sb, s));
     ptok = e->ptok; stok = e->stok;
   }
   COATI_TRY(launch_select_rows(use_point, ptok, stok, e->cliptok, B, E, s));
@@ -1454,16 +1457,28 @@ int coati_engine_infonce(coati_engine* e, const float* S_loc, const float* C_loc
   float* L2 = L1 + (size_t)B * Bg;
   COATI_TRY(launch_count_valid(bad_all, Bg, scal + 4, scal + 7, s));
   // L1 = S_loc C_all^T ; L2 = C_loc S_all^T     (clip_e2e.py:36-37, local rows only)
-  COATI_TRY(launch_sgemm(S_loc, E, 1, C_all, 1, E, L1, Bg, B, Bg, E, nullptr, 1.f, 0, s));
-  COATI_TRY(launch_sgemm(C_loc, E, 1, S_all, 1, E, L2, Bg, B, Bg, E, nullptr, 1.f, 0, s));
+  {
+    SgemmBatch sb;
+    COATI_TRY(sgemm_batch_add(sb, S_loc, E, 1, C_all, 1, E, L1, Bg, B, Bg, E, nullptr, 1.f, 0));
+    COATI_TRY(sgemm_batch_add(sb, C_loc, E, 1, S_all, 1, E, L2, Bg, B, Bg, E, nullptr, 1.f, 0));
+    COATI_TRY(launch_sgemm_batch(sb, s));
+  }
   COATI_TRY(launch_infonce_rows(L1, Bg, B, Bg, row0, bad_all, scal + 2, scal + 7, gscale, s));
   COATI_TRY(launch_infonce_rows(L2, Bg, B, Bg, row0, bad_all, scal + 3, scal + 7, gscale, s));
   // column-side gradients: dC_all = dL1^T S_loc ; dS_all = dL2^T C_loc
-  COATI_TRY(launch_sgemm(L1, 1, Bg, S_loc, E, 1, dC_all, E, Bg, E, B, nullptr, 1.f, 0, s));
-  COATI_TRY(launch_sgemm(L2, 1, Bg, C_loc, E, 1, dS_all, E, Bg, E, B, nullptr, 1.f, 0, s));
+  {
+    SgemmBatch sb;
+    COATI_TRY(sgemm_batch_add(sb, L1, 1, Bg, S_loc, E, 1, dC_all, E, Bg, E, B, nullptr, 1.f, 0));
+    COATI_TRY(sgemm_batch_add(sb, L2, 1, Bg, C_loc, E, 1, dS_all, E, Bg, E, B, nullptr, 1.f, 0));
+    COATI_TRY(launch_sgemm_batch(sb, s));
+  }
   // row-side gradients added into the local row block: dS_loc += dL1 C_all ; dC_loc += dL2 S_all
-  COATI_TRY(launch_sgemm(L1, Bg, 1, C_all, E, 1, dS_all + (size_t)row0 * E, E, B, E, Bg, nullptr, 1.f, 1, s));
-  COATI_TRY(launch_sgemm(L2, Bg, 1, S_all, E, 1, dC_all + (size_t)row0 * E, E, B, E, Bg, nullptr, 1.f, 1, s));
+  {
+    SgemmBatch sb;
+    COATI_TRY(sgemm_batch_add(sb, L1, Bg, 1, C_all, E, 1, dS_all + (size_t)row0 * E, E, B, E, Bg, nullptr, 1.f, 1));
+    COATI_TRY(sgemm_batch_add(sb, L2, Bg, 1, S_all, E, 1, dC_all + (size_t)row0 * E, E, B, E, Bg, nullptr, 1.f, 1));
+    COATI_TRY(launch_sgemm_batch(sb, s));
+  }
   return COATI_OK;
 }
 
@@ -1498,28 +1513,31 @@ int coati_engine_backward(coati_engine* e, const float* dh_smiles, const float* 
       HIPCHK(hipMemsetAsync(e->dptok, 0, (size_t)B * E * sizeof(float), s));
       HIPCHK(hipMemsetAsync(e->dstok, 0, (size_t)B * E * sizeof(float), s));
       COATI_TRY(launch_select_rows_bwd(e->use_point, e->dcliptok, e->dptok, e->dstok, B, E, s));
-      COATI_TRY(head_linear_bwd(e, e->dptok, e->sa, e->tokw, e->tokb, e->dsa, B, E, E, s));
-      COATI_TRY(head_linear_bwd(e, e->dstok, e->sb, e->tokw, e->tokb, e->dsb, B, E, E, s));
+      SgemmBatch sb;
+      COATI_TRY(head_linear_bwd(e, sb, e->dptok, e->sa, e->tokw, e->tokb, e->dsa, B, E, E));
+      COATI_TRY(head_linear_bwd(e, sb, e->dstok, e->sb, e->tokw, e->tokb, e->dsb, B, E, E));
+      COATI_TRY(launch_sgemm_batch(sb, s));
       COATI_TRY(launch_silu_bwd(e->h_e3gnn, e->dsa, e->dhe, (long long)B * E, 1, s));
       COATI_TRY(launch_silu_bwd(e->h_smiles, e->dsb, e->dhs, (long long)B * E, 1, s));
     } else {
       // nn.Identity: the token IS the embedding, its gradient adds straight into d h_e3gnn / d h_smiles
       COATI_TRY(launch_select_rows_bwd(e->use_point, e->dcliptok, e->dhe, e->dhs, B, E, s));
     }
-    // smiles_to_clip / point_to_clip: Linear then (norm_clips) LayerNorm backward
-    if (c.norm_clips) {
-      COATI_TRY(head_linear_bwd(e, e->dhs, e->hs_ln, e->s2c_w, e->s2c_b, e->dhs_ln, B, E, C, s));
-      COATI_TRY(launch_layernorm_bwd(e->dhs_ln, 1, C, e->hstop, C, 0, e->hs_mean, e->hs_rstd, e->P + e->s2c_lnw, nullptr, e->dhstop, nullptr, e->G + e->s2c_lnw, e->G + e->s2c_lnb, e->ln_partial, B, C, s));
-    } else {
-      COATI_TRY(head_linear_bwd(e, e->dhs, e->hstop, e->s2c_w, e->s2c_b, e->dhstop, B, E, C, s));
-    }
-    if (c.use_point_encoder) {   // (use_point_encoder = False: h_e3gnn is a constant, nothing upstream of it)
-      if (c.norm_clips) {
-        COATI_TRY(head_linear_bwd(e, e->dhe, e->hp_ln, e->p2c_w, e->p2c_b, e->dhp_ln, B, E, H, s));
-        COATI_TRY(launch_layernorm_bwd(e->dhp_ln, 1, H, e->hpoint, H, 0, e->hp_mean, e->hp_rstd, e->P + e->p2c_lnw, nullptr, e->dhpoint, nullptr, e->G + e->p2c_lnw, e->G + e->p2c_lnb, e->ln_partial, B, H, s));
-      } else {
-        COATI_TRY(head_linear_bwd(e, e->dhe, e->hpoint, e->p2c_w, e->p2c_b, e->dhpoint, B, E, H, s));
+    // smiles_to_clip / point_to_clip: Linear then (norm_clips) LayerNorm backward; the two heads' Linear backwards share a launch
+    {
+      SgemmBatch sb;
+      if (c.norm_clips) COATI_TRY(head_linear_bwd(e, sb, e->dhs, e->hs_ln, e->s2c_w, e->s2c_b, e->dhs_ln, B, E, C));
+      else COATI_TRY(head_linear_bwd(e, sb, e->dhs, e->hstop, e->s2c_w, e->s2c_b, e->dhstop, B, E, C));
+      if (c.use_point_encoder) {   // (use_point_encoder = False: h_e3gnn is a constant, nothing upstream of it)
+        if (c.norm_clips) COATI_TRY(head_linear_bwd(e, sb, e->dhe, e->hp_ln, e->p2c_w, e->p2c_b, e->dhp_ln, B, E, H));
+        else COATI_TRY(head_linear_bwd(e, sb, e->dhe, e->hpoint, e->p2c_w, e->p2c_b, e->dhpoint, B, E, H));
       }
+      COATI_TRY(launch_sgemm_batch(sb, s));
+    }
+    if (c.norm_clips) {
+      COATI_TRY(launch_layernorm_bwd(e->dhs_ln, 1, C, e->hstop, C, 0, e->hs_mean, e->hs_rstd, e->P + e->s2c_lnw, nullptr, e->dhstop, nullptr, e->G + e->s2c_lnw, e->G + e->s2c_lnb, e->ln_partial, B, C, s));
+      if (c.use_point_encoder)
+        COATI_TRY(launch_layernorm_bwd(e->dhp_ln, 1, H, e->hpoint, H, 0, e->hp_mean, e->hp_rstd, e->P + e->p2c_lnw, nullptr, e->dhpoint, nullptr, e->G + e->p2c_lnw, e->G + e->p2c_lnb, e->ln_partial, B, H, s));
     }
   }
   // whole backward (stage 0) or the encoder stage of the staged (multi-GPU) backward: the point-encoder backward runs on

@@ -159,6 +159,22 @@ int wgrad_table_append_split(std::vector<WgradTile>& tab, const WgradArgs& a, in
 
 // C[M,N] (f32) = sum_k A(m,k) B(k,n) [+ bias[n]] [+ C];  A(m,k) = A[m*ars + k*acs], B(k,n) = B[k*brs + n*bcs]
 // exact-f32 MFMA (v_mfma_f32_32x32x2_f32).  alpha scales the product.
+// several independent small f32 problems in one launch (gemm.hip): add problems, then launch
+#define SGEMM_BATCH_MAX 6
+struct SgemmProb {
+  const float *A, *B, *bias;
+  float* C;
+  long long ars, acs, brs, bcs, ldc;
+  int M, N, K, accumulate, ksplit, tx, ty, tz, wg0;
+  float alpha;
+};
+struct SgemmBatch {
+  int n = 0;
+  SgemmProb p[SGEMM_BATCH_MAX];
+};
+int sgemm_batch_add(SgemmBatch& b, const float* A, long long ars, long long acs, const float* B, long long brs, long long bcs,
+                    float* C, long long ldc, int M, int N, int K, const float* bias, float alpha, int accumulate);
+int launch_sgemm_batch(const SgemmBatch& b, hipStream_t s);
 int launch_sgemm(const float* A, long long ars, long long acs, const float* B, long long brs, long long bcs,
                  float* C, long long ldc, int M, int N, int K, const float* bias, float alpha, int accumulate,
                  hipStream_t s);
