@@ -1463,8 +1463,7 @@ int coati_engine_infonce(coati_engine* e, const float* S_loc, const float* C_loc
     COATI_TRY(sgemm_batch_add(sb, C_loc, E, 1, S_all, 1, E, L2, Bg, B, Bg, E, nullptr, 1.f, 0));
     COATI_TRY(launch_sgemm_batch(sb, s));
   }
-  COATI_TRY(launch_infonce_rows(L1, Bg, B, Bg, row0, bad_all, scal + 2, scal + 7, gscale, s));
-  COATI_TRY(launch_infonce_rows(L2, Bg, B, Bg, row0, bad_all, scal + 3, scal + 7, gscale, s));
+  COATI_TRY(launch_infonce_rows2(L1, L2, Bg, B, Bg, row0, bad_all, scal + 2, scal + 3, scal + 7, gscale, s));
   // column-side gradients: dC_all = dL1^T S_loc ; dS_all = dL2^T C_loc
   {
     SgemmBatch sb;

@@ -300,6 +300,8 @@ int launch_select_rows_bwd(const unsigned char* use_a, const float* dout, float*
 int launch_axpy(const float* x, float* y, float alpha, long long n, hipStream_t s);  // y += alpha*x
 // rows: logits[R, N] (f32, in place -> dlogits).  label of row r = label0 + r, ignored if bad[label].
 // sum of row losses -> scal_out[0] (+=); dlogits = (softmax - onehot) * (*gscale_ptr-free) handled by `gscale`.
+int launch_infonce_rows2(float* logits, float* logits2, long long ld, int R, int N, int label0, const unsigned char* bad,
+                         float* loss_sum, float* loss_sum2, const float* inv_count, float gscale, hipStream_t s);   // both directions in one launch
 int launch_infonce_rows(float* logits, long long ld, int R, int N, int label0, const unsigned char* bad,
                         float* loss_sum, const float* inv_count, float gscale, hipStream_t s);
 int launch_count_valid(const unsigned char* bad, int n, float* out_count, float* out_inv, hipStream_t s);

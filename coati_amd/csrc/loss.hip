@@ -67,41 +67,77 @@ int launch_axpy(const float* x, float* y, float alpha, long long n, hipStream_t 
 }
 
 // One wave per logits row.  label(r) = label0 + r; rows whose label is a bad row contribute nothing
-// (F.cross_entropy ignore_index=-1) but every column stays in the softmax as a negative.
-__global__ __launch_bounds__(256) void infonce_rows_kernel(float* __restrict__ logits, long long ld, int R, int N, int label0,
-                                                           const unsigned char* __restrict__ bad, float* __restrict__ loss_sum,
-                                                           const float* __restrict__ inv_count, float gscale) {
+// (F.cross_entropy ignore_index=-1) but every column stays in the softmax as a negative.  blockIdx.y = 0 / 1: the two directions
+// (logits / logits2, loss_sum / loss_sum2) in one launch.  NR > 0: the row (N <= 64 NR columns) is read ONCE and stays in registers
+// for the three passes (max, sum, gradient); NR = 0: any N, three passes over memory.
+template <int NR>
+__global__ __launch_bounds__(256) void infonce_rows_kernel(float* __restrict__ logits, float* __restrict__ logits2, long long ld, int R, int N,
+                                                           int label0, const unsigned char* __restrict__ bad, float* __restrict__ loss_sum,
+                                                           float* __restrict__ loss_sum2, const float* __restrict__ inv_count, float gscale) {
   const int lane = threadIdx.x & 63, r = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= R) return;
-  float* row = logits + (long long)r * ld;
+  float* row = (blockIdx.y ? logits2 : logits) + (long long)r * ld;
+  float* ls = blockIdx.y ? loss_sum2 : loss_sum;
   const int label = label0 + r;
   if (bad[label]) {
     for (int c = lane; c < N; c += 64) row[c] = 0.f;
     return;
   }
-  float mx = -INFINITY;
-  for (int c = lane; c < N; c += 64) mx = fmaxf(mx, row[c]);
-  mx = wave_max(mx);
-  float sm = 0.f;
-  for (int c = lane; c < N; c += 64) sm += __expf(row[c] - mx);
-  sm = wave_sum(sm);
-  const float lse = mx + __logf(sm);
   const float g = gscale * inv_count[0];
-  if (lane == 0) atomicAdd(loss_sum, lse - row[label]);
-  __builtin_amdgcn_wave_barrier();
-  for (int c = lane; c < N; c += 64) {
-    float p = __expf(row[c] - lse);
-    if (c == label) p -= 1.f;
-    row[c] = p * g;
+  if constexpr (NR > 0) {
+    float v[NR];
+#pragma unroll
+    for (int i = 0; i < NR; ++i) v[i] = lane + 64 * i < N ? row[lane + 64 * i] : -INFINITY;
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < NR; ++i) mx = fmaxf(mx, v[i]);
+    mx = wave_max(mx);
+    float sm = 0.f;
+#pragma unroll
+    for (int i = 0; i < NR; ++i) sm += __expf(v[i] - mx);   // (exp(-inf) = 0 for the columns past N)
+    sm = wave_sum(sm);
+    const float lse = mx + __logf(sm);
+    float at_label = 0.f;
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+      const int c = lane + 64 * i;
+      float p = __expf(v[i] - lse);
+      if (c == label) { at_label = v[i]; p -= 1.f; }
+      if (c < N) row[c] = p * g;
+    }
+    at_label = wave_sum(at_label);   // (one lane holds it)
+    if (lane == 0) atomicAdd(ls, lse - at_label);
+  } else {
+    float mx = -INFINITY;
+    for (int c = lane; c < N; c += 64) mx = fmaxf(mx, row[c]);
+    mx = wave_max(mx);
+    float sm = 0.f;
+    for (int c = lane; c < N; c += 64) sm += __expf(row[c] - mx);
+    sm = wave_sum(sm);
+    const float lse = mx + __logf(sm);
+    if (lane == 0) atomicAdd(ls, lse - row[label]);
+    __builtin_amdgcn_wave_barrier();
+    for (int c = lane; c < N; c += 64) {
+      float p = __expf(row[c] - lse);
+      if (c == label) p -= 1.f;
+      row[c] = p * g;
+    }
   }
+}
+int launch_infonce_rows2(float* logits, float* logits2, long long ld, int R, int N, int label0, const unsigned char* bad,
+                         float* loss_sum, float* loss_sum2, const float* inv_count, float gscale, hipStream_t s) {
+  COATI_CHECK_ARG(logits && bad && loss_sum && inv_count && (logits2 == nullptr || loss_sum2 != nullptr), "infonce_rows: null operand");
+  COATI_CHECK_SHAPE(R > 0 && N > 0 && label0 >= 0 && label0 + R <= N, "infonce_rows: labels out of range");
+  const dim3 grid(cdiv(R, 4), logits2 ? 2 : 1);
+  if (N <= 64 * 16) hipLaunchKernelGGL(infonce_rows_kernel<16>, grid, dim3(256), 0, s, logits, logits2, ld, R, N, label0, bad, loss_sum, loss_sum2, inv_count, gscale);
+  else if (N <= 64 * 32) hipLaunchKernelGGL(infonce_rows_kernel<32>, grid, dim3(256), 0, s, logits, logits2, ld, R, N, label0, bad, loss_sum, loss_sum2, inv_count, gscale);
+  else hipLaunchKernelGGL(infonce_rows_kernel<0>, grid, dim3(256), 0, s, logits, logits2, ld, R, N, label0, bad, loss_sum, loss_sum2, inv_count, gscale);
+  COATI_LAUNCH_CHECK("infonce_rows");
+  return COATI_OK;
 }
 int launch_infonce_rows(float* logits, long long ld, int R, int N, int label0, const unsigned char* bad,
                         float* loss_sum, const float* inv_count, float gscale, hipStream_t s) {
-  COATI_CHECK_ARG(logits && bad && loss_sum && inv_count, "infonce_rows: null operand");
-  COATI_CHECK_SHAPE(R > 0 && N > 0 && label0 >= 0 && label0 + R <= N, "infonce_rows: labels out of range");
-  hipLaunchKernelGGL(infonce_rows_kernel, dim3(cdiv(R, 4)), dim3(256), 0, s, logits, ld, R, N, label0, bad, loss_sum, inv_count, gscale);
-  COATI_LAUNCH_CHECK("infonce_rows");
-  return COATI_OK;
+  return launch_infonce_rows2(logits, nullptr, ld, R, N, label0, bad, loss_sum, nullptr, inv_count, gscale, s);
 }
 
 __global__ void count_valid_kernel(const unsigned char* __restrict__ bad, int n, float* __restrict__ out_count,
