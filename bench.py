@@ -170,9 +170,9 @@ def main():
     ap.add_argument("--batch", type=int, default=1024, help="molecules per GPU (BASELINE.json configs[1])")
     ap.add_argument("--seq", type=int, default=80)
     ap.add_argument("--atoms", type=int, default=16)
-    ap.add_argument("--roofline-site", type=str, default="fc1_dgrad,qkv_dgrad",
-                    help="engine launch site(s) timed for the roofline entry; default: the two sites of the step's top kernel, the ring GEMM "
-                         "with the LayerNorm backward in its write-out (padded layout: that kernel does not exist there -> xf_wgrad)")
+    ap.add_argument("--roofline-site", type=str, default="fc1_dgrad,qkv_dgrad,lmhead_dgrad",
+                    help="engine launch site(s) timed for the roofline entry; default: the three sites (64 launches per step) of the step's top "
+                         "kernel, the ring GEMM with the LayerNorm backward in its write-out (padded layout: that kernel does not exist there -> xf_wgrad)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-mols", type=int, default=32)
     ap.add_argument("--all-sites", action="store_true", help="extra: per-site kernel time table on stderr")
@@ -269,7 +269,7 @@ def main():
 
     # (N > 1: the data-parallel schedule -- encoder stage of the backward in one piece or in two halves -- is measured by
     # coati_amd.distributed over steps 3..8 of the process; they are kept out of the timed region)
-    if args.roofline_site == "fc1_dgrad,qkv_dgrad" and (args.padded or args.config != "grande_closed" or args.fp8):
+    if args.roofline_site == "fc1_dgrad,qkv_dgrad,lmhead_dgrad" and (args.padded or args.config != "grande_closed" or args.fp8):
         args.roofline_site = "xf_wgrad"      # the fused kernel serves the packed grande batch; elsewhere the grouped weight gradient leads
     for _ in range(max(args.warmup, 9) if dist_on else args.warmup):
         step()
@@ -366,14 +366,14 @@ def main():
                 raise OSError("PMC summaries are collected for the grande_closed B=1024 T=80 shapes only")
             cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
             with open(cands[-1]) as f:
-                ent = json.load(f).get({"fc1_dgrad,qkv_dgrad": "dgrad_lnbwd"}.get(args.roofline_site, args.roofline_site), {})
+                ent = json.load(f).get({"fc1_dgrad,qkv_dgrad,lmhead_dgrad": "dgrad_lnbwd"}.get(args.roofline_site, args.roofline_site), {})
             if ent.get("layout", "padded") != ("padded" if args.padded else "packed"):
                 raise OSError("the newest PMC summary was collected on the other row layout")
             traffic = ent.get("hbm_bytes_per_launch")
             traffic_source = f"{os.path.relpath(cands[-1], ROOT)} ({ent.get('command', 'isolated launches, tools/prof_wgrad.py')}); static file, not this run"
         except (OSError, ValueError, IndexError):
             pass
-        kname = {"fc1_dgrad,qkv_dgrad": "gemm_ring1_kernel<EPI_LNBWD> (ring GEMM + LayerNorm backward; sites fc1_dgrad + qkv_dgrad)",
+        kname = {"fc1_dgrad,qkv_dgrad,lmhead_dgrad": "gemm_ring1_kernel<EPI_LNBWD> (ring GEMM + LayerNorm backward; sites fc1_dgrad + qkv_dgrad + lmhead_dgrad = every launch of the kernel)",
                  "xf_wgrad": "wgrad256_table_kernel (site xf_wgrad)"}.get(args.roofline_site, args.roofline_site)
         if hbm_bound:
             roof = {"bound": "hbm", "kernel": kname, "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
