@@ -194,11 +194,17 @@ __device__ __forceinline__ void epilogue8(const GemmArgs& p, int row, int col0, 
     const float cnt = p.scal[1];
     const float inv = (tgt >= 0 && cnt > 0.f) ? 1.0f / cnt : 0.f;
     const float l = p.lse[row];
+    // (softmax(v) - onehot) / count in few VALU slots (they add to the tile time): the target's position relative to this lane's 8
+    // columns as ONE 32-bit value (anything outside 0..7 never matches).  exp(v - lse) keeps the subtraction FIRST: folded into
+    // exp2(fma(v, log2e, -lse log2e)) the argument carries the rounding of two numbers of size ~ 30, i.e. 1e-6 of absolute error
+    // per row, which is the size of (p_target - 1) on well-fitted tokens -- the mid-curve gradient norms of the 20-step reference
+    // curve moved by 30 % (tests/test_gpu_grande.py) when this was tried.
+    const long long rel = tgt - (long long)col0;
+    const int hit = (rel >= 0 && rel < 8) ? (int)rel : -1;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      float pr = __expf(v[e] - l);
-      if ((long long)(col0 + e) == tgt) pr -= 1.0f;
-      o[e] = pr * inv;
+      const float pr = __expf(v[e] - l);
+      o[e] = (pr - (hit == e ? 1.0f : 0.0f)) * inv;
     }
   } else if (EPI == EPI_EDGE_DPRE) {
     const int A = p.natom, H = p.H;

@@ -256,19 +256,29 @@ __global__ __launch_bounds__(64 * R16_MAXW, 1) void gemm_rb16_kernel(GemmArgs p,
     const int c0 = jt * R16_BN + colA, c1 = jt * R16_BN + colB;
     if constexpr (EPI == EPI_CE_PARTIAL) {
       // (max, sum exp) over the tile's 64 columns of row fr: 16 in this lane, the rest in lanes fr + 16, + 32, + 48
-      float mx = -INFINITY;
+      // (the activation write-outs add their VALU slots to the tile time -- an MFMA wave and a VALU wave of one SIMD do not overlap,
+      //  see the header -- so the column masks are paid only by the one tile that straddles N: V = 10 322 = 161 full tiles + 18 columns)
+      float mx = -INFINITY, sm = 0.f;
+      if ((jt + 1) * R16_BN <= p.N) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        if (c0 + e < p.N) mx = fmaxf(mx, v0[e]);
-        if (c1 + e < p.N) mx = fmaxf(mx, v1[e]);
-      }
-      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      float sm = 0.f;
+        for (int e = 0; e < 8; ++e) mx = fmaxf(mx, fmaxf(v0[e], v1[e]));
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        if (c0 + e < p.N) sm += __expf(v0[e] - mx);
-        if (c1 + e < p.N) sm += __expf(v1[e] - mx);
+        for (int e = 0; e < 8; ++e) sm += __expf(v0[e] - mx) + __expf(v1[e] - mx);   // (subtraction first: see EPI_CE_BWD in gemm_epi.h)
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          if (c0 + e < p.N) mx = fmaxf(mx, v0[e]);
+          if (c1 + e < p.N) mx = fmaxf(mx, v1[e]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          if (c0 + e < p.N) sm += __expf(v0[e] - mx);
+          if (c1 + e < p.N) sm += __expf(v1[e] - mx);
+        }
       }
       sm += __shfl_xor(sm, 16, 64);
       sm += __shfl_xor(sm, 32, 64);
