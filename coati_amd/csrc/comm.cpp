@@ -56,7 +56,8 @@ void load_rccl() {
 int need_rccl() {
   std::call_once(g_once, load_rccl);
   if (!g_rccl.ok) {
-    coati_set_error("coati_comm: librccl not found (tried $COATI_RCCL_LIB, librccl.so.1, librccl.so): %s", dlerror() ? dlerror() : "no loader message");
+    const char* why = dlerror();
+    coati_set_error("coati_comm: librccl not found (tried $COATI_RCCL_LIB, librccl.so.1, librccl.so): %s", why ? why : "no loader message");
     return COATI_EHIP;
   }
   return COATI_OK;
