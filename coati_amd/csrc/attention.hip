@@ -358,6 +358,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
   ATT_SEQ(0);
   attn_fwd_body<HS, NB>(qkv, y, lse, Tl, n_head, b, hq, T, row0);
 }
+// (Round 4 occupancy probe -- extra dynamic LDS per workgroup, profiles/r04_attn_occupancy.txt: 5 workgroups per CU 31.8 us per launch,
+// 3: 40.2, 2: 40.5, 1: 64.7 -- the kernel is close to its VALU / LDS throughput at 5, a persistent form that prefetches the next
+// sequence's operands would buy little.)
 // packed rows, T <= 32 * NBMAX <= 128: ONE launch; every workgroup runs the body compiled for its own sequence's block count
 // (separate launches per block count, the first form, serialised three under-filled grids: no gain over the padded batch)
 template <int HS, int NBMAX>
