@@ -24,6 +24,9 @@
 // (bare s_barrier instead of __syncthreads(), the saved-code loads of EPI_MUL_AUX from inline assembly: otherwise the compiler
 // drains vmcnt itself) -- were built, passed the parity tests and measured SLOWER: 22.55 vs 22.14 ms per step (A/B/A/B on one
 // box), 74.5 vs 70.7 us on the NewGELU launch.  The stores cost issue / write-path time, not acknowledgement latency.
+// Two weight tiles per workgroup barrier (2 x 64 KiB of tile buffers, the first tile's stores in flight during the second tile's MFMA
+// phase, half the barriers and DMA waits) were built and measured too: 42.3 / 75.6 / 35.5 us against 42.0 / 72.8 / 36.5 on the three
+// shapes of tools/rb16_ablate.py, 22.24 ms per step either way -- the barrier count is not the lever.
 #include <cstdlib>
 #include "gemm_epi.h"
 
