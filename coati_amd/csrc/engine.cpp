@@ -260,8 +260,11 @@ void build_layout(coati_engine* e) {
   }
   e->lnfw = add_entry(e, "xformer.transformer.ln_f.weight", C, 0);
   e->lnfb = add_entry(e, "xformer.transformer.ln_f.bias", C, 0);
-  e->lmhead = add_entry(e, "xformer.lm_head.weight", V, C);
-  // --- point encoder (e3gnn_clip.py:75-104, e_gcl_sparse.py:130-150) + point_to_clip (clip_e2e.py:405-422) ---
+  // Order of the flat buffers (round 4; entries are found by NAME everywhere, tests/test_host_cpu.py): transformer body | point
+  // encoder | lm_head | heads.  The data-parallel step then needs TWO gradient collectives instead of four: lm_head + heads are final
+  // behind the decoder stage of the backward and adjacent, transformer body + point encoder behind the encoder stage and adjacent
+  // (coati_amd/distributed.py grad_buckets; every collective costs ~ 0.13 ms of stream hand-over at world size 1).
+  // --- point encoder (e3gnn_clip.py:75-104, e_gcl_sparse.py:130-150) ---
   auto add_point = [&]() {
     e->gembw = add_entry(e, "point_encoder.embedding.weight", H, 28);
     e->gembb = add_entry(e, "point_encoder.embedding.bias", H, 0);
@@ -282,6 +285,9 @@ void build_layout(coati_engine* e) {
       g.n3w = add_entry(e, p + "node_mlp.3.weight", H, H);
       g.n3b = add_entry(e, p + "node_mlp.3.bias", H, 0);
     }
+  };
+  // --- point_to_clip (clip_e2e.py:405-422) ---
+  auto add_p2c = [&]() {
     // norm_clips: LayerNorm -> Linear (state_dict .0 / .1); otherwise a plain Linear (clip_e2e.py:405-428)
     if (c.norm_clips) {
       e->p2c_lnw = add_entry(e, "point_to_clip.0.weight", H, 0);
@@ -297,6 +303,8 @@ void build_layout(coati_engine* e) {
   // receive a gradient (p.grad is None: torch's clip_grad_norm_ / AdamW skip them).  Their parameters exist in the state_dict
   // all the same: they go BEHIND n_trainable, next to coord_mlp
   if (c.use_point_encoder) add_point();
+  e->lmhead = add_entry(e, "xformer.lm_head.weight", V, C);
+  if (c.use_point_encoder) add_p2c();
   // --- heads (clip_e2e.py:419-435) ---
   if (c.norm_clips) {
     e->s2c_lnw = add_entry(e, "smiles_to_clip.0.weight", E, 0);
@@ -315,7 +323,7 @@ void build_layout(coati_engine* e) {
   // (p.grad is None), so torch's clip_grad_norm_ / AdamW skip them entirely -- no weight decay either.  They are kept for
   // state_dict parity at the END of the flat buffers, behind n_trainable: the optimizer kernels stop in front of them.
   e->n_trainable = e->n_params;
-  if (!c.use_point_encoder) add_point();
+  if (!c.use_point_encoder) { add_point(); add_p2c(); }
   for (int l = 0; l < c.n_layer_e3gnn; ++l) {
     const std::string p = "point_encoder.gcl_" + std::to_string(l) + ".";
     GLayerP& g = e->gl[l];

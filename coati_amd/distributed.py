@@ -7,10 +7,10 @@ Exchange steps of the path (reference train_coati.py:256-258, autograd_funs.py:5
      computes the full Bg x Bg on every rank) and produces partial gradients for all Bg embeddings;
   3. reduce-scatter(sum) of those partials (what AllGatherFunction.backward does);
   4. bucketed gradient all-reduce (mean) over the flat fp32 gradient buffer, launched stage by stage so the
-     transfers run on RCCL's stream underneath the remaining backward kernels: the lm_head / head buckets underneath the
-     encoder stage; the transformer buckets after it (both passes add into the same weights, and the pass's weight
-     gradients are ONE grouped launch -- cutting the stage in two, the round-1 schedule, doubles that launch:
-     COATI_DP_SPLIT=1), the point-encoder bucket last.
+     transfers run on RCCL's stream underneath the remaining backward kernels: lm_head + heads (ONE collective: adjacent in
+     the flat buffer) underneath the encoder stage; transformer body + point encoder (ONE collective) after it (both passes
+     add into the same weights, and the pass's weight gradients are ONE grouped launch -- cutting the stage in two, the
+     round-1 schedule, doubles that launch: COATI_DP_SPLIT=1).
 The reference calls model.module.forward_dist and therefore never arms DDP's reducer: it does
 not average parameter gradients.  This implements the intended semantics.
 
@@ -82,23 +82,22 @@ def all_reduce_avg_async(t: torch.Tensor):
 
 
 def grad_buckets(eng):
-    """(name, start, end) element ranges of the flat gradient buffer, by the backward stage that completes them."""
+    """name -> (start, end) element ranges of the flat gradient buffer, by the backward stage that completes them.  The buckets tile
+    the buffer; the engine lays it out as transformer body | point encoder | lm_head | heads (csrc/engine.cpp build_layout), so the
+    ranges that become final together are adjacent: xformer_lo + xformer_hi + gnn behind the encoder stage (with the point encoder's
+    backward on its side stream underneath it), lm_head + heads behind the decoder stage."""
     lay = eng.layout
     lm0 = lay["xformer.lm_head.weight"][0]
     L = sum(1 for k in lay if k.startswith("xformer.transformer.h.") and k.endswith(".ln_1.weight"))
     mid = lay[f"xformer.transformer.h.{L // 2}.ln_1.weight"][0]   # first entry of layer L/2: [0, mid) = embeddings + lower layers
-    rest0 = min(off for k, (off, _) in lay.items() if not k.startswith("xformer."))   # first entry behind lm_head
     pe0 = lay["point_encoder.embedding.weight"][0]
-    s2c0 = lay["smiles_to_clip.0.weight" if "smiles_to_clip.0.weight" in lay else "smiles_to_clip.weight"][0]
-    if pe0 > s2c0:
+    lm1 = lm0 + lay["xformer.lm_head.weight"][1][0] * lay["xformer.lm_head.weight"][1][1]
+    lm1 = min([off for k, (off, _) in lay.items() if off >= lm1], default=eng.n_params)   # first entry behind lm_head (alignment gap included)
+    if pe0 > lm0:
         # use_point_encoder = False: the point encoder + point_to_clip never receive a gradient and sit behind the trainable
-        # parameters with coord_mlp (clip_e2e.py:454-463, engine.cpp build_layout): one bucket for the heads, then the
-        # (all-zero) rest so that the buckets still tile the buffer
-        return {"xformer_lo": (0, mid), "xformer_hi": (mid, lm0), "lm_head": (lm0, rest0), "heads": (rest0, pe0),
-                "gnn": (pe0, eng.n_params)}
-    hd0 = lay["point_to_clip.0.weight" if "point_to_clip.0.weight" in lay else "point_to_clip.weight"][0]
-    return {"xformer_lo": (0, mid), "xformer_hi": (mid, lm0), "lm_head": (lm0, pe0), "gnn": (pe0, hd0),
-            "heads": (hd0, eng.n_params)}
+        # parameters with coord_mlp (clip_e2e.py:454-463): the (all-zero) rest is one bucket so that the buckets still tile the buffer
+        return {"xformer_lo": (0, mid), "xformer_hi": (mid, lm0), "lm_head": (lm0, lm1), "heads": (lm1, pe0), "gnn": (pe0, eng.n_params)}
+    return {"xformer_lo": (0, mid), "xformer_hi": (mid, pe0), "gnn": (pe0, lm0), "lm_head": (lm0, lm1), "heads": (lm1, eng.n_params)}
 
 
 # Encoder stage of the staged backward in one piece or in two halves (see distributed_train_step).  COATI_DP_SPLIT=0 | 1 forces a
@@ -164,7 +163,7 @@ def distributed_train_step(eng, batch, use_point, lr, do_clip=True, optimizer=Tr
                            **opt_kw):
     """do_minibatch at world_size > 1.  Returns (h_e3gnn, h_smiles, bad_rows) of the local rows.
     head="barlow": Barlow-Twins head instead of InfoNCE (statistics / E x E matrix all-reduced, no embedding gather).
-    reduce_grads=False skips the four gradient all-reduces (bench.py's measurement of their exposed cost).
+    reduce_grads=False skips the gradient all-reduces (bench.py's measurement of their exposed cost).
     opt_kw: weight_decay / max_norm / betas / eps for Engine.optimizer_step (train_coati.py:145-151, 276)."""
     W, rank = dist.get_world_size(), dist.get_rank()
     split_stage, slot = _schedule_begin(eng) if (reduce_grads and optimizer) else (_SPLIT_ENCODER_STAGE, None)
@@ -191,14 +190,17 @@ def distributed_train_step(eng, batch, use_point, lr, do_clip=True, optimizer=Tr
     bk = grad_buckets(eng)
     works = []
 
-    def launch(name):
+    def launch(*names):
+        """ONE collective over the named buckets (adjacent in the flat buffer)"""
         if reduce_grads:
-            a, b = bk[name]
+            a, b = min(bk[n][0] for n in names), max(bk[n][1] for n in names)
+            assert sum(bk[n][1] - bk[n][0] for n in names) == b - a, names
             if b > a:
                 works.append(all_reduce_avg_async(eng.grads[a:b]))
 
+    point_trained = bk["gnn"][0] < bk["lm_head"][0]          # (use_point_encoder = False: the "gnn" range is the untrained rest)
     eng.backward(dS, dC, stage=1)
-    launch("lm_head"); launch("heads")
+    launch("lm_head", "heads")       # (use_point_encoder = False: the untrained rest holds zeros on every rank -- nothing to exchange)
     if split_stage:
         # the encoder stage in two halves: the upper layers' gradients (both passes are through them) travel underneath the
         # lower half of the backward
@@ -206,18 +208,20 @@ def distributed_train_step(eng, batch, use_point, lr, do_clip=True, optimizer=Tr
         launch("xformer_hi")
         eng.backward(None, None, stage=5)
         launch("xformer_lo")
+        eng.backward(None, None, stage=3)
+        if point_trained:
+            launch("gnn")
     else:
         # ONE encoder stage: the transformer's weight gradients of a pass are one grouped launch of 16 layers x 12 output
         # tiles, each tile streaming all rows -- a launch over half of the layers takes as long as the whole one (2.0 ms),
         # so the split costs 2 ms of compute per step to hide an all-reduce of 50 MB (round 2, world size 1 over RCCL:
         # 36.2 ms split).  The lm_head / head buckets still travel underneath this stage.
         eng.backward(None, None, stage=2)
-        # (one collective for the whole transformer range: the two halves are adjacent in the flat buffer, and every collective
-        #  costs a pair of stream hand-overs -- 0.13 ms each measured at world size 1)
-        if reduce_grads:
-            works.append(all_reduce_avg_async(eng.grads[bk["xformer_lo"][0]:bk["xformer_hi"][1]]))
-    eng.backward(None, None, stage=3)
-    launch("gnn")
+        # the point encoder's backward ran on its side stream underneath the encoder stage (engine.cpp: stage 3 then has nothing
+        # left to do), so its gradients are final here too: ONE collective for transformer body + point encoder (adjacent in the
+        # flat buffer; every collective costs a pair of stream hand-overs -- 0.13 ms each measured at world size 1)
+        eng.backward(None, None, stage=3)
+        launch("xformer_lo", "xformer_hi", "gnn") if point_trained else launch("xformer_lo", "xformer_hi")
     for w in works:
         w.wait()
     if optimizer:
