@@ -1491,7 +1491,7 @@ int coati_engine_infonce(coati_engine* e, const float* S_loc, const float* C_loc
 
 int coati_engine_backward(coati_engine* e, const float* dh_smiles, const float* dh_e3gnn, int stage, void* stream) {
   COATI_CHECK_ARG(e && e->have_fwd && e->G, "engine_backward: no forward / gradient buffer");
-  COATI_CHECK_ARG(stage >= 0 && stage <= 6, "engine_backward: bad stage");
+  COATI_CHECK_ARG(stage >= 0 && stage <= 5, "engine_backward: bad stage");
   hipStream_t s = (hipStream_t)stream;
   const coati_config& c = e->cfg;
   const int C = c.n_hidden_xformer, H = c.n_hidden_e3nn, E = c.n_embd_common, B = e->B;
@@ -1559,9 +1559,7 @@ int coati_engine_backward(coati_engine* e, const float* dh_smiles, const float* 
     COATI_TRY(fork_side(e, s));
     COATI_TRY(gnn_bwd(e, e->dhpoint, e->side));
   }
-  // (stage 6 = stage 2 WITHOUT the fork: the point encoder's backward is left to stage 3, so that a data-parallel caller has the
-  //  transformer's gradient all-reduce -- launched between the two -- in flight underneath it)
-  if (stage == 0 || stage == 2 || stage == 4 || stage == 6) {
+  if (stage == 0 || stage == 2 || stage == 4) {
     // ---- encoder pass: gradient enters at the [STOP] rows of ln_f's output ----
     if (e->p1.tail) {   // the gradient of the B [STOP] rows goes in as it is
       COATI_TRY(xformer_bwd(e, e->p1, e->dhstop, 1, nullptr, s, Lx, stage == 4 ? Lmid : 0));

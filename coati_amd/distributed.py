@@ -216,20 +216,12 @@ def distributed_train_step(eng, batch, use_point, lr, do_clip=True, optimizer=Tr
         # tiles, each tile streaming all rows -- a launch over half of the layers takes as long as the whole one (2.0 ms),
         # so the split costs 2 ms of compute per step to hide an all-reduce of 50 MB (round 2, world size 1 over RCCL:
         # 36.2 ms split).  The lm_head / head buckets still travel underneath this stage.
-        if point_trained:
-            # stage 6 = the encoder stage WITHOUT the point encoder's backward underneath it: the transformer body's collective
-            # (61 MB) is launched behind it and travels underneath the point encoder's backward (stage 3, ~ 1.6 ms of small
-            # kernels that leave RCCL's few workgroups their CUs); only the point encoder's own 8.5 MB stay exposed.  (Round 4;
-            # before, the point encoder ran on the side stream underneath the encoder stage and all 70 MB were exposed behind
-            # it: 0.6 ms at world size 1, where RCCL's copy kernel stands in for the wire.)
-            eng.backward(None, None, stage=6)
-            launch("xformer_lo", "xformer_hi")
-            eng.backward(None, None, stage=3)
-            launch("gnn")
-        else:
-            eng.backward(None, None, stage=2)
-            eng.backward(None, None, stage=3)
-            launch("xformer_lo", "xformer_hi")
+        eng.backward(None, None, stage=2)
+        # the point encoder's backward ran on its side stream underneath the encoder stage (engine.cpp: stage 3 then has nothing
+        # left to do), so its gradients are final here too: ONE collective for transformer body + point encoder (adjacent in the
+        # flat buffer; every collective costs a pair of stream hand-overs -- 0.13 ms each measured at world size 1)
+        eng.backward(None, None, stage=3)
+        launch("xformer_lo", "xformer_hi", "gnn") if point_trained else launch("xformer_lo", "xformer_hi")
     for w in works:
         w.wait()
     if optimizer:

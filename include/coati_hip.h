@@ -339,9 +339,7 @@ int coati_engine_infonce(coati_engine* e, const float* S_loc, const float* C_loc
 /* backward of the last forward.  dh_smiles / dh_e3gnn [B,E]: gradient of the contrastive term w.r.t. the two
  * embeddings.  stage: 0 = everything; 1 = lm_head + decoder pass + heads; 2 = encoder pass; 3 = point encoder
  * (1,2,3 in that order == 0; lets the caller overlap bucketed gradient all-reduces with the remaining stages);
- * 4, 5 = stage 2 in two halves (layers [L/2, L) incl. ln_f, then [0, L/2) incl. the embeddings): 1,4,5,3 == 0;
- * 6 = stage 2 with the point encoder's backward left to stage 3 instead of running underneath it on the side stream (the
- * transformer's gradient all-reduce, launched between 6 and 3, then travels underneath the point encoder's backward): 1,6,3 == 0. */
+ * 4, 5 = stage 2 in two halves (layers [L/2, L) incl. ln_f, then [0, L/2) incl. the embeddings): 1,4,5,3 == 0. */
 int coati_engine_backward(coati_engine* e, const float* dh_smiles, const float* dh_e3gnn, int stage, void* stream);
 
 /* clip_grad_norm_(max_norm) + AdamW + shadow refresh.  scal[5] receives the pre-clip gradient norm. */

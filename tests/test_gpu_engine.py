@@ -382,9 +382,7 @@ def test_staged_backward_equals_whole_backward():
     eng.grads.zero_()
     h_e, h_s, bad = eng.forward(db["raw_tokens"], db["tokens"], db["atoms"], db["coords"], up, y_next=db["y_next"], train=True)
     dS, dC = eng.infonce(h_s, h_e, h_s, h_e, bad, row0=0, gscale=0.5 * eng.token_entropy_unit())
-    # 4, 5 = the encoder stage in two halves; 6 = the encoder stage with the point encoder's backward left to stage 3 (what the
-    # data-parallel step runs: the transformer's gradient all-reduce then travels underneath the point encoder's backward)
-    for order in ((1, 2, 3), (1, 4, 5, 3), (1, 6, 3)):
+    for order in ((1, 2, 3), (1, 4, 5, 3)):   # 4, 5 = the encoder stage in two halves (what the data-parallel step runs)
         eng.grads.zero_()
         for stage in order:
             eng.backward(dS if stage == 1 else None, dC if stage == 1 else None, stage)

@@ -249,10 +249,9 @@ class _FakeEngine:
     def __init__(self):
         from coati_amd.engine import Engine
         self.calls = []
-        # the engine's order (csrc/engine.cpp build_layout): transformer body | point encoder | lm_head | heads
         self.layout = {"xformer.emb.tok_emb.weight": (0, (4, 4)), "xformer.transformer.h.0.ln_1.weight": (64, (4,)),
-                       "xformer.transformer.h.1.ln_1.weight": (128, (4,)), "point_encoder.embedding.weight": (192, (4, 4)),
-                       "xformer.lm_head.weight": (256, (4, 4)), "point_to_clip.0.weight": (320, (4,)),
+                       "xformer.transformer.h.1.ln_1.weight": (128, (4,)), "xformer.lm_head.weight": (192, (4, 4)),
+                       "point_encoder.embedding.weight": (256, (4, 4)), "point_to_clip.0.weight": (320, (4,)),
                        "smiles_to_clip.0.weight": (352, (4,))}
         self.n_params = 384
         import types
@@ -311,7 +310,7 @@ def test_optimizer_arguments_reach_the_optimizer():
         # decoder stage | ONE encoder stage (the pass's weight gradients are one grouped launch) | point-encoder stage
         # (the contrastive head is enqueued BEHIND the decoder pass's launches: it runs on a side stream underneath them)
         assert names == ["forward", "forward_decoder", "infonce", "backward", "backward", "backward", "optimizer_step"]
-        assert [c[1] for c in e.calls if c[0] == "backward"] == [1, 6, 3]   # 6 = the encoder stage with the point encoder left to stage 3
+        assert [c[1] for c in e.calls if c[0] == "backward"] == [1, 2, 3]
         assert e.calls[-1] == ("optimizer_step", 2e-3, {"weight_decay": 0.07, "max_norm": 3.0})
         # the round-1 schedule (encoder stage in two halves) stays available behind COATI_DP_SPLIT=1
         D._SPLIT_ENCODER_STAGE = True
@@ -366,7 +365,7 @@ def test_measured_dp_schedule_is_per_engine_and_decided_once(monkeypatch):
             real_backward = e.backward
 
             def backward(dS, dC, stage=0):
-                if stage in (6, 4):      # the encoder stage is where the two forms differ
+                if stage in (2, 4):      # the encoder stage is where the two forms differ
                     clock["t"] += clock["cost"][stage == 4]
                 return real_backward(dS, dC, stage)
             e.backward = backward
@@ -376,10 +375,10 @@ def test_measured_dp_schedule_is_per_engine_and_decided_once(monkeypatch):
 
         e1, e2 = _FakeEngine(), _FakeEngine()
         seq = [run(e1) for _ in range(3)]
-        assert seq == [[1, 6, 3]] * 3                              # warm-up: one piece, untimed
+        assert seq == [[1, 2, 3]] * 3                              # warm-up: one piece, untimed
         D.distributed_eval_step(e1, batch, up)                      # an evaluation step does not advance the measurement
-        assert [run(e1) for _ in range(3)] == [[1, 6, 3]] * 3      # form 0 timed
-        assert run(e2) == [1, 6, 3] and e2._dp_schedule.step == 1   # another engine: its own counters
+        assert [run(e1) for _ in range(3)] == [[1, 2, 3]] * 3      # form 0 timed
+        assert run(e2) == [1, 2, 3] and e2._dp_schedule.step == 1   # another engine: its own counters
         assert [run(e1) for _ in range(3)] == [[1, 4, 5, 3]] * 3   # form 1 timed
         assert e1._dp_schedule.decided and e1._dp_schedule.split    # 3 ms < 5 ms: two halves
         assert run(e1) == [1, 4, 5, 3] and run(e1) == [1, 4, 5, 3]
@@ -387,7 +386,7 @@ def test_measured_dp_schedule_is_per_engine_and_decided_once(monkeypatch):
         clock["cost"] = {False: 2.0, True: 3.0}                    # on e2 the one-piece form wins
         for _ in range(8):
             run(e2)
-        assert e2._dp_schedule.decided and not e2._dp_schedule.split and run(e2) == [1, 6, 3]
+        assert e2._dp_schedule.decided and not e2._dp_schedule.split and run(e2) == [1, 2, 3]
     finally:
         dist.destroy_process_group()
 
