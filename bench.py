@@ -146,7 +146,7 @@ def time_comm(eng, D, batch_size, steps=10):
     def timed(name, fn):
         for _ in range(2):
             fn()
-        torch.cuda.synchronize(); dist.barrier()
+        torch.cuda.synchronize(); dist.barrier(device_ids=[torch.cuda.current_device()])
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(steps):
@@ -222,7 +222,10 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        # NO device_id: binding the group to the device makes torch build the RCCL communicator eagerly, and from then on EVERY kernel of
+        # the process runs ~ 4 % slower (21.69 -> 22.57 ms for the plain step with no collective in it, tools/dp_overhead2.py with
+        # DP_DEVICE_ID=1, profiles/r04_dp_overhead.txt); the lazily built communicator of the first collective costs nothing
+        dist.init_process_group("nccl")
         assert dist.get_world_size() == world, (dist.get_world_size(), world)
         if torch.cuda.device_count() < world:
             raise SystemExit(f"bench.py: {world} ranks but only {torch.cuda.device_count()} visible GPU(s)")
@@ -264,7 +267,7 @@ def main():
 
     def sync():
         if dist_on:
-            torch.distributed.barrier()
+            torch.distributed.barrier(device_ids=[local_rank])
         torch.cuda.synchronize()
 
     # (N > 1: the data-parallel schedule -- encoder stage of the backward in one piece or in two halves -- is measured by
@@ -278,13 +281,16 @@ def main():
     eng.prof_select(args.roofline_site, keep_overlap=True)
     sync()
     smi = None
-    if rank == 0:   # one rocm-smi sample taken WHILE the timed steps run (cross-check for a GPU-activity sampler that reads nothing)
+    if rank == 0 and not os.environ.get("COATI_BENCH_NO_SMI"):   # one rocm-smi sample taken WHILE the timed steps run (cross-check for a GPU-activity sampler that reads nothing)
         try:
             smi = subprocess.Popen(["rocm-smi", "--showuse"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
         except Exception:   # noqa: BLE001
             smi = None
+    # the events bracket the site's launches on every 4th step of the timed region: an event pair costs ~ 3.7 us of queue time (a
+    # barrier packet each; 0.48 ms per step for the 64 launches when every step records them, tools/dp_overhead2.py)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        eng.prof_pause(i % 4 != 0)
         step()
     sync()
     dt = time.perf_counter() - t0
@@ -321,16 +327,22 @@ def main():
         # exposed cost of the gradient all-reduces: the same steps with those four collectives skipped (outside the timed
         # region; the replicas then drift apart, which no longer matters), then every collective alone
         k2 = max(3, min(args.steps, 10))
-        sync()
-        t1 = time.perf_counter()
-        for _ in range(k2):
-            step(reduce_grads=False)
-        sync()
-        t_nr = torch.tensor([(time.perf_counter() - t1) / k2], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(t_nr, op=torch.distributed.ReduceOp.MAX)
+        t_pair = []
+        for rg in (True, False):          # like for like: both loops here, without the site events of the timed region
+            for _ in range(2):
+                step(reduce_grads=rg)
+            sync()
+            t1 = time.perf_counter()
+            for _ in range(k2):
+                step(reduce_grads=rg)
+            sync()
+            t = torch.tensor([(time.perf_counter() - t1) / k2], device=dev, dtype=torch.float64)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            t_pair.append(float(t))
         comm = time_comm(eng, D, args.batch)
-        comm["step_without_grad_allreduce_ms"] = round(1e3 * float(t_nr), 3)
-        comm["exposed_grad_allreduce_ms"] = round(1e3 * (dt / args.steps - float(t_nr)), 3)
+        comm["step_with_grad_allreduce_ms"] = round(1e3 * t_pair[0], 3)
+        comm["step_without_grad_allreduce_ms"] = round(1e3 * t_pair[1], 3)
+        comm["exposed_grad_allreduce_ms"] = round(1e3 * (t_pair[0] - t_pair[1]), 3)
 
     # one step per launch site with HIP events around that site's launches (outside the timed region): the per-site table
     # (stderr with --all-sites) and the `site_roofline` list of the JSON line -- every site of >= 2 % of the step with its

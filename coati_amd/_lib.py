@@ -94,6 +94,7 @@ _SIGS = {
     "coati_engine_optimizer_step": [P, F, F, F, F, F, F, I, P, P],
     "coati_engine_prof_select": [P, I],
     "coati_engine_prof_keep_overlap": [P, I],
+    "coati_engine_prof_pause": [P, I],
     "coati_engine_prof_add_site": [P, I],
     "coati_engine_prof_collect": [P, POINTER(c_double), POINTER(c_int64), POINTER(c_double)],
     "coati_engine_prof_last_bytes": [P, POINTER(c_double)],

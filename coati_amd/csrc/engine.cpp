@@ -197,6 +197,7 @@ struct coati_engine {
   bool gnn_side_pending = false;   // stage 4 forked it; stage 5 joins
   // profiling
   unsigned long long prof_mask = 0;   // launch sites whose launches are bracketed by HIP events (bit = Site)
+  bool prof_paused = false;         // events suspended (the selection, its counters and the overlap setting stay): bench.py samples every 4th step
   bool prof_keep_overlap = false;   // timed-region profiling: events around the selected site, the step itself runs as the product does (side stream on)
   std::vector<hipEvent_t> ev;
   int ev_used = 0;
@@ -396,7 +397,7 @@ struct ProfScope {
   hipStream_t s;
   bool on;
   ProfScope(coati_engine* e_, int site, double flops, hipStream_t s_, double bytes = 0.0) : e(e_), s(s_), on(false) {
-    if (site >= 0 && ((e->prof_mask >> site) & 1ull) && e->ev_used + 2 <= (int)e->ev.size()) {
+    if (site >= 0 && !e->prof_paused && ((e->prof_mask >> site) & 1ull) && e->ev_used + 2 <= (int)e->ev.size()) {
       on = true;
       hipEventRecord(e->ev[e->ev_used], s);
       e->prof_flops += flops;
@@ -1611,6 +1612,7 @@ int coati_engine_prof_select(coati_engine* e, int site) {
   }
   e->prof_mask = site >= 0 ? (1ull << site) : 0ull;
   e->prof_keep_overlap = false;
+  e->prof_paused = false;
   e->ev_used = 0;
   e->prof_flops = 0.0;
   e->prof_bytes = 0.0;
@@ -1628,6 +1630,15 @@ int coati_engine_prof_add_site(coati_engine* e, int site) {
 // keep != 0: the selected site is timed while the step runs exactly as the product runs it (point encoder on the side stream,
 // concurrent with the transformer passes); the default (0) serialises the point encoder onto the launch stream so that a
 // site's events bracket that site's kernels alone.  Reset by every prof_select.
+// paused != 0: the selected sites record no events until resumed (selection, counters and the overlap setting stay).  A pair of
+// HIP events costs ~ 3.7 us of queue time on this chip (a barrier packet each: 0.48 ms per step for the 64 launches of the ring GEMM
+// with the LayerNorm backward, tools/dp_overhead2.py), so the bench samples a quarter of its timed steps.
+int coati_engine_prof_pause(coati_engine* e, int paused) {
+  COATI_CHECK_ARG(e, "prof_pause: null engine");
+  e->prof_paused = paused != 0;
+  return COATI_OK;
+}
+
 int coati_engine_prof_keep_overlap(coati_engine* e, int keep) {
   COATI_CHECK_ARG(e, "prof_keep_overlap: null engine");
   e->prof_keep_overlap = keep != 0;

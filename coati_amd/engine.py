@@ -410,6 +410,10 @@ class Engine:
         if keep_overlap:
             _lib.check(self.l.coati_engine_prof_keep_overlap(self.h, 1), "prof_keep_overlap")
 
+    def prof_pause(self, paused=True):
+        """suspend / resume the selected sites' events (selection and counters stay): sampling a subset of the steps"""
+        _lib.check(self.l.coati_engine_prof_pause(self.h, 1 if paused else 0), "prof_pause")
+
     def prof_collect(self):
         ms, n, fl = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double()
         _lib.check(self.l.coati_engine_prof_collect(self.h, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl)), "prof_collect")

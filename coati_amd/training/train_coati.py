@@ -173,7 +173,7 @@ def train_autoencoder(gpu, args, dataset=None, tokenizer=None):
     device = torch.device("cuda:" + str(gpu))
     torch.cuda.set_device(device)
     if world > 1:
-        dist.init_process_group(backend="nccl", init_method="env://", world_size=world, rank=rank, device_id=device)
+        dist.init_process_group(backend="nccl", init_method="env://", world_size=world, rank=rank)   # (no device_id: the eagerly built RCCL communicator slows every kernel of the process by ~ 4 %, bench.py)
     tokenizer = tokenizer or SyntheticTokenizer(n_seq=args.n_seq, n_token=getattr(args, "n_token", 10322))
     dataset = dataset or COATI_dataset(cache_dir=args.data_dir, tokenizer=tokenizer,
                                        n_batches=getattr(args, "synthetic_batches", 50))

@@ -352,6 +352,8 @@ int coati_engine_prof_add_site(coati_engine* e, int site);           /* after pr
 /* keep != 0: time the selected site while the step runs as the product runs it (point encoder concurrent on the side stream);
  * 0 (default after every prof_select): the point encoder is serialised onto the launch stream, a site's events bracket its kernels alone */
 int coati_engine_prof_keep_overlap(coati_engine* e, int keep);
+/* paused != 0: no events until resumed; the selection, its counters and the overlap setting stay (sampling a subset of the steps) */
+int coati_engine_prof_pause(coati_engine* e, int paused);
 int coati_engine_prof_collect(coati_engine* e, double* total_ms, int64_t* launches, double* flops_per_launch);
 /* algorithmic HBM bytes per launch (operands read once, results written once) of the site collected last */
 int coati_engine_prof_last_bytes(coati_engine* e, double* bytes_per_launch);

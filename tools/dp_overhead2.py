@@ -10,7 +10,7 @@ from coati_amd.engine import Engine, ModelConfig
 from coati_amd.synthetic import make_batch
 from coati_amd import distributed as D
 
-dist.init_process_group("nccl")
+dist.init_process_group("nccl", **({"device_id": torch.device("cuda:0")} if os.environ.get("DP_DEVICE_ID") else {}))
 dev = torch.device("cuda:0"); torch.cuda.set_device(dev)
 eng = Engine(ModelConfig(**bench.GRANDE), dev)
 g = torch.Generator(device="cpu").manual_seed(0)
@@ -45,4 +45,18 @@ for rep in range(2):
             fn()
         torch.cuda.synchronize()
         print(f"{name:48s} {1e3 * (time.perf_counter() - t0) / 30:7.3f} ms/step", flush=True)
+# the same with the bench's per-site events switched on (prof_select): bench.py times its steps that way
+eng.prof_select("fc1_dgrad,qkv_dgrad,lmhead_dgrad", keep_overlap=True)
+for name in ("V0 plain train_step", "V3 + gradient collectives"):
+    fn = variants[name]
+    for _ in range(8):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        fn()
+    torch.cuda.synchronize()
+    print(f"{name + ' [site events on]':48s} {1e3 * (time.perf_counter() - t0) / 20:7.3f} ms/step", flush=True)
+    eng.prof_collect()
+eng.prof_select(-1)
 dist.destroy_process_group()
