@@ -223,7 +223,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
         # NO device_id: binding the group to the device makes torch build the RCCL communicator eagerly, and from then on EVERY kernel of
-        # the process runs ~ 4 % slower (21.69 -> 22.57 ms for the plain step with no collective in it, tools/dp_overhead2.py with
+        # the process runs ~ 4 % slower (21.69 -> 22.57 ms for the plain step with no collective in it, tools/dp_overhead.py with
         # DP_DEVICE_ID=1, profiles/r04_dp_overhead.txt); the lazily built communicator of the first collective costs nothing
         dist.init_process_group("nccl")
         assert dist.get_world_size() == world, (dist.get_world_size(), world)
@@ -287,7 +287,7 @@ def main():
         except Exception:   # noqa: BLE001
             smi = None
     # the events bracket the site's launches on every 4th step of the timed region: an event pair costs ~ 3.7 us of queue time (a
-    # barrier packet each; 0.48 ms per step for the 64 launches when every step records them, tools/dp_overhead2.py)
+    # barrier packet each; 0.48 ms per step for the 64 launches when every step records them, tools/dp_overhead.py)
     t0 = time.perf_counter()
     for i in range(args.steps):
         eng.prof_pause(i % 4 != 0)

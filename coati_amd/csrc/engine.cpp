@@ -1632,7 +1632,7 @@ int coati_engine_prof_add_site(coati_engine* e, int site) {
 // site's events bracket that site's kernels alone.  Reset by every prof_select.
 // paused != 0: the selected sites record no events until resumed (selection, counters and the overlap setting stay).  A pair of
 // HIP events costs ~ 3.7 us of queue time on this chip (a barrier packet each: 0.48 ms per step for the 64 launches of the ring GEMM
-// with the LayerNorm backward, tools/dp_overhead2.py), so the bench samples a quarter of its timed steps.
+// with the LayerNorm backward, tools/dp_overhead.py), so the bench samples a quarter of its timed steps.
 int coati_engine_prof_pause(coati_engine* e, int paused) {
   COATI_CHECK_ARG(e, "prof_pause: null engine");
   e->prof_paused = paused != 0;

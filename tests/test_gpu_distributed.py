@@ -50,7 +50,7 @@ def _worker(rank, world, port, head, out_dir, backend="gloo"):
     if backend == "nccl":          # the product path: one GPU per rank, RCCL collectives on device memory
         DEV = f"cuda:{rank}"
         torch.cuda.set_device(rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(DEV))
+        dist.init_process_group("nccl", rank=rank, world_size=world)   # (no device_id: see bench.py)
     else:
         dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -167,7 +167,7 @@ def _nccl_w1_worker(rank, port, out_dir):
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     torch.cuda.set_device(0)
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    dist.init_process_group("nccl", rank=0, world_size=1)   # (no device_id: the eagerly built communicator slows every kernel of the process, bench.py)
     try:
         from coati_amd.engine import Engine, ModelConfig
         from coati_amd import distributed as D
