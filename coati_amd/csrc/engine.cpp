@@ -264,7 +264,7 @@ void build_layout(coati_engine* e) {
   // Order of the flat buffers (round 4; entries are found by NAME everywhere, tests/test_host_cpu.py): transformer body | point
   // encoder | lm_head | heads.  The data-parallel step then needs TWO gradient collectives instead of four: lm_head + heads are final
   // behind the decoder stage of the backward and adjacent, transformer body + point encoder behind the encoder stage and adjacent
-  // (coati_amd/distributed.py grad_buckets; every collective costs ~ 0.13 ms of stream hand-over at world size 1).
+  // (coati_amd/distributed.py grad_buckets; every collective costs a pair of stream hand-overs and a launch on RCCL's stream).
   // --- point encoder (e3gnn_clip.py:75-104, e_gcl_sparse.py:130-150) ---
   auto add_point = [&]() {
     e->gembw = add_entry(e, "point_encoder.embedding.weight", H, 28);

@@ -219,7 +219,7 @@ def distributed_train_step(eng, batch, use_point, lr, do_clip=True, optimizer=Tr
         eng.backward(None, None, stage=2)
         # the point encoder's backward ran on its side stream underneath the encoder stage (engine.cpp: stage 3 then has nothing
         # left to do), so its gradients are final here too: ONE collective for transformer body + point encoder (adjacent in the
-        # flat buffer; every collective costs a pair of stream hand-overs -- 0.13 ms each measured at world size 1)
+        # flat buffer; every collective costs a pair of stream hand-overs and a launch on RCCL's stream)
         eng.backward(None, None, stage=3)
         launch("xformer_lo", "xformer_hi", "gnn") if point_trained else launch("xformer_lo", "xformer_hi")
     for w in works:
