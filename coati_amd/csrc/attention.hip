@@ -886,7 +886,7 @@ int launch_attn_bwd(const bf16_t* qkv, const bf16_t* y, const bf16_t* dy, const 
   // T <= 128: the single-sweep kernel (grande: 120 vs 141 us); longer sequences: the two kernels below
   if (T <= 128) {
     const int nb = (T + 31) / 32;
-    if (seq_off != nullptr) {   // packed rows: sequences of 1-2 blocks in one launch, of 3-4 blocks in another
+    if (seq_off != nullptr) {   // packed rows: sequences of 1-2 blocks in one launch, of 3-4 blocks in another (ONE launch over 1-3 blocks, round 4: 2.44 vs 2.19 ms per step -- the short sequences lose the 4-workgroups-per-CU register budget)
 #define VL(H, HI, LO) return launch_attn_bwd_fused_varlen_t<H, HI, LO>(qkv, y, dy, lse, dqkv, cos_t, sin_t, B, T, n_head, s, seq_off)
 #define VL2(H, HI, LO) COATI_TRY((launch_attn_bwd_fused_varlen_t<H, HI, LO>(qkv, y, dy, lse, dqkv, cos_t, sin_t, B, T, n_head, s, seq_off)))
       if (head_size == 16) {
