@@ -87,6 +87,10 @@ _SIGS = {
     "coati_seq_pack": [P, P, I, I, I, I, P, P, P, P, P, P],
     "coati_attn_fwd_varlen": [P, P, P, P, I, I, I, I, P],
     "coati_attn_bwd_varlen": [P, P, P, P, P, P, P, P, P, I, I, I, I, P],
+    "coati_attn_groups": [P, I, I, P, P],
+    "coati_attn_block_fwd": [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, P],
+    "coati_ab_probe_swap": [P, P],
+    "coati_ab_trace_read": [P],
     "coati_engine_logits": [P, P, L, P],
     "coati_engine_encode": [P, P, L, I, I, I, P, P, P, P, P, P, P],
     "coati_engine_infonce": [P, P, P, P, P, P, I, I, I, F, P, P, P, P],

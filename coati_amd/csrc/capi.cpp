@@ -146,6 +146,20 @@ int coati_attn_bwd_varlen(const uint16_t* qkv, const uint16_t* y, const uint16_t
   COATI_CHECK_ARG(seq_off, "attn_bwd_varlen: null seq_off");
   return launch_attn_bwd(qkv, y, dy, lse, dscratch, dqkv, cos_t, sin_t, B, T, n_head, head_size, S_(stream), seq_off);
 }
+int coati_attn_groups(const int32_t* seq_off, int B, int T, int32_t* grp, void* stream) {
+  return launch_attn_groups(seq_off, B, T, grp, S_(stream));
+}
+int coati_attn_block_fwd(const float* x, float* xmid, const float* ln_g, const float* ln_b, float* mean, float* rstd, uint16_t* a1,
+                         const uint16_t* Wqkv, const float* bqkv, const uint16_t* Wproj, const float* bproj, uint16_t* qkv, uint16_t* y,
+                         float* lse, const float* cos_t, const float* sin_t, const int32_t* row_src, const int32_t* grp, int T, int M,
+                         void* stream) {
+  AttnBlockArgs a;
+  a.x = x; a.xmid = xmid; a.ln_g = ln_g; a.ln_b = ln_b; a.mean = mean; a.rstd = rstd; a.a1 = a1; a.Wqkv = Wqkv; a.bqkv = bqkv;
+  a.Wproj = Wproj; a.bproj = bproj; a.qkv = qkv; a.y = y; a.lse = lse; a.cos_t = cos_t; a.sin_t = sin_t; a.row_src = row_src;
+  a.grp = grp; a.Tl = T; a.M = M;
+  return launch_attn_block_fwd(a, S_(stream));
+}
+int coati_ab_probe_swap(uint32_t* out, void* stream) { return launch_ab_probe_swap(out, S_(stream)); }
 int coati_gemm_qkv_rope(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw, const float* bias, int M, int C,
                         uint16_t* qkv, int64_t ldc, const float* cos_t, const float* sin_t, int T, void* stream) {
   GemmArgs a;

@@ -42,12 +42,12 @@ enum Site {
   SITE_QKV_FWD = 0, SITE_PROJ_FWD, SITE_FC1_FWD, SITE_FC2_FWD, SITE_ATTN_FWD, SITE_LN_FWD, SITE_LMHEAD_FWD,
   SITE_FC2_DGRAD, SITE_FC1_DGRAD, SITE_PROJ_DGRAD, SITE_QKV_DGRAD, SITE_XF_WGRAD, SITE_ATTN_BWD, SITE_LN_BWD,
   SITE_LMHEAD_DLOGITS, SITE_LMHEAD_DGRAD, SITE_LMHEAD_WGRAD, SITE_GNN_EDGE_GEMM, SITE_GNN_NODE_GEMM,
-  SITE_GNN_WGRAD, SITE_GNN_ELEMWISE, SITE_EMBED, SITE_OPTIM, SITE_XF_TAIL, SITE_COUNT
+  SITE_GNN_WGRAD, SITE_GNN_ELEMWISE, SITE_EMBED, SITE_OPTIM, SITE_XF_TAIL, SITE_ATTN_BLOCK_FWD, SITE_COUNT
 };
 const char* kSiteNames[SITE_COUNT] = {
     "qkv_fwd", "proj_fwd", "fc1_fwd", "fc2_fwd", "attn_fwd", "ln_fwd", "lmhead_fwd", "fc2_dgrad", "fc1_dgrad",
     "proj_dgrad", "qkv_dgrad", "xf_wgrad", "attn_bwd", "ln_bwd", "lmhead_dlogits", "lmhead_dgrad", "lmhead_wgrad",
-    "gnn_edge_gemm", "gnn_node_gemm", "gnn_wgrad", "gnn_elemwise", "embed", "optim", "xf_tail"};   // xf_tail: the [STOP]-row tail of the encoder pass (B-row launches)
+    "gnn_edge_gemm", "gnn_node_gemm", "gnn_wgrad", "gnn_elemwise", "embed", "optim", "xf_tail", "attn_block_fwd"};   // xf_tail: the [STOP]-row tail of the encoder pass (B-row launches)
 
 struct XLayerP {  // offsets into the flat parameter buffer
   int64_t ln1w, ln1b, attnw, attnb, projw, projb, ln2w, ln2b, fc1w, fc1b, fc2w, fc2b;
@@ -69,6 +69,7 @@ struct XPass {  // saved activations of one transformer pass
   int* row_src = nullptr;    // [M] slot b * T + t of packed row m
   int* row_t = nullptr;      // [M] token position of packed row m (rotary embedding)
   long long* ypk = nullptr;  // [M] packed targets (decoder pass)
+  int* grp = nullptr;        // [B + 2] work list of the fused attention half (attn_block.hip launch_attn_groups): built by xformer_fwd
   std::vector<float*> x;      // L+1 residual-stream snapshots [M,C]
   std::vector<float*> xmid;   // L
   std::vector<float*> mean1, rstd1, mean2, rstd2, lse;
@@ -491,6 +492,7 @@ void carve_pass(coati_engine* e, Arena& ar, XPass& p, int B, int T) {
   p.tail = false;
   p.packed = false;
   p.off = ar.take<int>((size_t)B + 1); p.row_src = ar.take<int>(M); p.row_t = ar.take<int>(M); p.ypk = ar.take<long long>(M);
+  p.grp = ar.take<int>((size_t)B + 2);
 }
 
 size_t carve(coati_engine* e, Arena& ar, int B, int T1, int T2, int A, int Bg) {
@@ -620,8 +622,24 @@ int xformer_fwd(coati_engine* e, XPass& p, const float* injection, hipStream_t s
     ProfScope ps(e, SITE_EMBED, 0, s);
     COATI_TRY(launch_embed_fwd(p.idx, e->P + e->tok_emb, injection, c.unk_token, p.x[0], p.B, p.T, C, c.n_tok, s, p.packed ? p.row_src : nullptr, M));
   }
+  // The attention half of every block as ONE launch (attn_block.hip): ln_1 -> c_attn -> RoPE -> causal attention -> c_proj -> + x
+  // with qkv and y written once and never read back (d = 256, 16 heads, sequences of <= 128 rows); its work list -- groups of
+  // whole sequences -- is built on the device once per pass
+  const bool ab = !c.use_fp8 && attn_block_fwd_supported(p.B, p.T, C, c.n_head);
+  if (ab) COATI_TRY(launch_attn_groups(p.packed ? p.off : nullptr, p.B, p.T, p.grp, s));
   for (int l = 0; l < L; ++l) {
     const XLayerP& w = e->xl[l];
+    if (ab) {
+      AttnBlockArgs a;
+      a.x = p.x[l]; a.xmid = p.xmid[l]; a.ln_g = e->P + w.ln1w; a.ln_b = e->P + w.ln1b; a.mean = p.mean1[l]; a.rstd = p.rstd1[l];
+      a.a1 = p.a1[l]; a.Wqkv = e->S + w.attnw; a.bqkv = e->P + w.attnb; a.Wproj = e->S + w.projw; a.bproj = e->P + w.projb;
+      a.qkv = p.qkv[l]; a.y = p.y[l]; a.lse = p.lse[l]; a.cos_t = e->cos_t; a.sin_t = e->sin_t; a.row_src = p.packed ? p.row_src : nullptr;
+      a.grp = p.grp; a.Tl = p.T; a.M = M;
+      // algorithmic bytes: x in, a1 + qkv + y + xmid + lse + statistics out, both weights
+      ProfScope ps(e, SITE_ATTN_BLOCK_FWD, 2.0 * M * 4 * C * C + 4.0 * M * (double)p.T * C, s,
+                   (double)M * C * (4 + 2 + 6 + 2 + 4) + (double)M * (c.n_head * 4 + 8) + 4.0 * C * C * 2);
+      COATI_TRY(launch_attn_block_fwd(a, s));
+    }
     if (c.use_fp8) {
       // MXFP8 products (BASELINE.json configs[4]); LayerNorm, attention, residual stream and saved tensors as in the bf16 path
       GemmArgs a;
@@ -652,7 +670,7 @@ int xformer_fwd(coati_engine* e, XPass& p, const float* injection, hipStream_t s
       COATI_TRY(gemm8(e, SITE_FC2_FWD, w, 3, nullptr, 4 * C, M, C, 4 * C, a, EPI_RES_F32, s));
       continue;
     }
-    {
+    if (!ab) {
       // QKV projection with RoPE applied to the q,k blocks in the epilogue (saved qkv holds the ROTATED q,k).  Where the
       // row-block kernel takes the product, ln_1 is evaluated inside its operand load (x f32 in; a1, mean, rstd out): no
       // LayerNorm launch, no second trip of the normalised rows through HBM
@@ -671,11 +689,13 @@ int xformer_fwd(coati_engine* e, XPass& p, const float* injection, hipStream_t s
       ProfScope ps(e, SITE_QKV_FWD, 2.0 * M * 3 * C * C, s, (double)M * C * (fuse ? 6 : 2) + 3.0 * C * C * 2 + (double)M * 3 * C * 2);
       COATI_TRY(launch_gemm_nt(a, 0, EPI_QKV_ROPE, s));
     }
-    {
-      ProfScope ps(e, SITE_ATTN_FWD, 4.0 * M * (double)p.T * C, s, (double)M * 4 * C * 2 + (double)M * c.n_head * 4);   // qkv in, y + lse out
-      COATI_TRY(launch_attn_fwd(p.qkv[l], p.y[l], p.lse[l], p.B, p.T, c.n_head, C / c.n_head, s, p.packed ? p.off : nullptr));
+    if (!ab) {
+      {
+        ProfScope ps(e, SITE_ATTN_FWD, 4.0 * M * (double)p.T * C, s, (double)M * 4 * C * 2 + (double)M * c.n_head * 4);   // qkv in, y + lse out
+        COATI_TRY(launch_attn_fwd(p.qkv[l], p.y[l], p.lse[l], p.B, p.T, c.n_head, C / c.n_head, s, p.packed ? p.off : nullptr));
+      }
+      COATI_TRY(gemm(e, SITE_PROJ_FWD, p.y[l], 0, C, e->S + w.projw, C, M, C, C, p.xmid[l], C, e->P + w.projb, EPI_RES_F32, p.x[l], nullptr, C, s));
     }
-    COATI_TRY(gemm(e, SITE_PROJ_FWD, p.y[l], 0, C, e->S + w.projw, C, M, C, C, p.xmid[l], C, e->P + w.projb, EPI_RES_F32, p.x[l], nullptr, C, s));
     if (p.tail && l == L - 1) {
       // the [STOP] rows alone from here on: gather, ln_2, MLP + residual, ln_f (B rows instead of M)
       const int B = p.B;

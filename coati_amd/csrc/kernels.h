@@ -221,6 +221,35 @@ int launch_attn_bwd(const bf16_t* qkv, const bf16_t* y, const bf16_t* dy, const 
                     const float* cos, const float* sin, int B, int T, int n_head, int head_size, hipStream_t s,
                     const int* seq_off = nullptr);
 
+// The attention half of a block as one sequence-stationary kernel (attn_block.hip): xmid = x + c_proj(attention(RoPE(c_attn(ln_1(x))))),
+// d = 256, 16 heads of 16, sequences of <= 128 rows.  Saves what the backward reads: a1 = ln_1(x), mean / rstd, qkv (q, k rotated), y, lse.
+struct AttnBlockArgs {
+  const float* x;          // [M, 256] residual stream in
+  float* xmid;             // [M, 256] out
+  const float* ln_g;       // ln_1 weight / bias [256]
+  const float* ln_b;
+  float* mean;             // [M] ln_1 statistics
+  float* rstd;
+  bf16_t* a1;              // [M, 256] ln_1(x)
+  const bf16_t* Wqkv;      // [768, 256] bf16
+  const float* bqkv;       // [768]
+  const bf16_t* Wproj;     // [256, 256] bf16
+  const float* bproj;      // [256]
+  bf16_t* qkv;             // [M, 768] out: q, k rotated
+  bf16_t* y;               // [M, 256] out
+  float* lse;              // [B, 16, Tl]
+  const float* cos_t;      // [n_seq, 16]
+  const float* sin_t;
+  const int* row_src;      // [M] slot b * Tl + t of row m (null: padded layout, the row index itself)
+  const int* grp;          // launch_attn_groups: grp[0] = number of groups, grp[1 + g] = first row of group g (g = 0 .. groups)
+  int Tl, M;
+};
+bool attn_block_fwd_supported(int B, int T, int C, int n_head);
+// grp [B + 2] ints: groups of whole consecutive sequences with <= 128 rows each (seq_off [B + 1] or null = the padded layout b * T)
+int launch_attn_groups(const int* seq_off, int B, int T, int* grp, hipStream_t s);
+int launch_attn_block_fwd(const AttnBlockArgs& a, hipStream_t s);
+int launch_ab_probe_swap(unsigned* out, hipStream_t s);
+
 // ------------------------------------------------------------------------------------------------
 // embedding / token kernels (embed.hip)
 // ------------------------------------------------------------------------------------------------

@@ -288,3 +288,29 @@ def ce_bwd(a, W, target, lse, scal):
     _lib.call("coati_gemm_ce_bwd", ptr(a), a.stride(0), ptr(W), W.stride(0), M, V, K, ptr(d), Vpad, Vpad, ptr(lse),
               ptr(target), ptr(scal), stream())
     return d
+
+
+def attn_groups(off, B, T):
+    """work list of attn_block_fwd: groups of whole consecutive sequences with <= 128 rows (off: seq_pack's offsets or None)"""
+    dev = off.device if off is not None else torch.device("cuda")
+    grp = torch.zeros(B + 2, device=dev, dtype=torch.int32)
+    _lib.call("coati_attn_groups", ptr(off), B, T, ptr(grp), stream())
+    return grp
+
+
+def attn_block_fwd(x, ln_g, ln_b, Wqkv, bqkv, Wproj, bproj, cos, sin, B, T, off=None, row_src=None):
+    """xmid = x + c_proj(attention(RoPE(c_attn(ln_1(x))))) in one launch; returns (xmid, a1, mean, rstd, qkv, y, lse)"""
+    _need_cuda(x)
+    M, C = x.shape
+    dev = x.device
+    grp = attn_groups(off, B, T)
+    xmid = torch.zeros(M, C, device=dev, dtype=torch.float32)
+    a1 = torch.zeros(M, C, device=dev, dtype=BF16)
+    mean = torch.zeros(M, device=dev, dtype=torch.float32)
+    rstd = torch.zeros(M, device=dev, dtype=torch.float32)
+    qkv = torch.zeros(M, 3 * C, device=dev, dtype=BF16)
+    y = torch.zeros(M, C, device=dev, dtype=BF16)
+    lse = torch.zeros(B, 16, T, device=dev, dtype=torch.float32)
+    _lib.call("coati_attn_block_fwd", ptr(x), ptr(xmid), ptr(ln_g), ptr(ln_b), ptr(mean), ptr(rstd), ptr(a1), ptr(Wqkv), ptr(bqkv),
+              ptr(Wproj), ptr(bproj), ptr(qkv), ptr(y), ptr(lse), ptr(cos), ptr(sin), ptr(row_src), ptr(grp), T, M, stream())
+    return xmid, a1, mean, rstd, qkv, y, lse, grp

@@ -156,6 +156,20 @@ int coati_attn_fwd_varlen(const uint16_t* qkv, uint16_t* y, float* lse, const in
 int coati_attn_bwd_varlen(const uint16_t* qkv, const uint16_t* y, const uint16_t* dy, const float* lse, float* dscratch,
                           uint16_t* dqkv, const float* cos_t, const float* sin_t, const int32_t* seq_off, int B, int T,
                           int n_head, int head_size, void* stream);
+/* The attention half of a RotaryBlock as ONE launch (csrc/attn_block.hip; basic_transformer.py:126-154, 171-172; d = 256, 16 heads of
+ * 16, sequences of <= 128 rows): xmid = x + c_proj(causal_attention(RoPE(c_attn(ln_1(x))))).  x / xmid [M, 256] f32; a1 = ln_1(x)
+ * [M, 256] bf16, mean / rstd [M], qkv [M, 768] bf16 (q, k rotated), y [M, 256] bf16 and lse [B, 16, T] f32 are the tensors the
+ * backward reads (the same ones the three-launch path leaves).  row_src [M] (coati_seq_pack; null = padded layout).
+ * coati_attn_groups builds the launch's work list on the device: grp [B + 2] int32 -- groups of whole consecutive sequences with
+ * <= 128 rows (seq_off = coati_seq_pack's off, or null for the padded layout b * T). */
+int coati_attn_groups(const int32_t* seq_off, int B, int T, int32_t* grp, void* stream);
+int coati_attn_block_fwd(const float* x, float* xmid, const float* ln_g, const float* ln_b, float* mean, float* rstd, uint16_t* a1,
+                         const uint16_t* Wqkv, const float* bqkv, const uint16_t* Wproj, const float* bproj, uint16_t* qkv, uint16_t* y,
+                         float* lse, const float* cos_t, const float* sin_t, const int32_t* row_src, const int32_t* grp, int T, int M,
+                         void* stream);
+/* test probes: lane-half exchange semantics the kernel above relies on; its shader-clock phase trace (-DCOATI_AB_TRACE builds) */
+int coati_ab_probe_swap(uint32_t* out, void* stream);
+int coati_ab_trace_read(unsigned long long* out);
 int coati_attn_bwd_hs(const uint16_t* qkv, const uint16_t* y, const uint16_t* dy, const float* lse, float* dscratch,
                       uint16_t* dqkv, const float* cos_t, const float* sin_t, int B, int T, int n_head, int head_size,
                       void* stream);
