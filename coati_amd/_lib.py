@@ -96,6 +96,8 @@ _SIGS = {
     "coati_engine_infonce": [P, P, P, P, P, P, I, I, I, F, P, P, P, P],
     "coati_engine_backward": [P, P, P, I, P],
     "coati_engine_optimizer_step": [P, F, F, F, F, F, F, I, P, P],
+    "coati_engine_set_error_word": [P, P, P],
+    "coati_engine_reserve": [P, I, I, I, I],
     "coati_engine_prof_select": [P, I],
     "coati_engine_prof_keep_overlap": [P, I],
     "coati_engine_prof_pause": [P, I],
@@ -141,7 +143,7 @@ def lib():
         fn.restype = c_int
     l.coati_engine_destroy.argtypes = [P]
     l.coati_engine_destroy.restype = None
-    for name in ("coati_engine_param_elems", "coati_engine_shadow_elems"):
+    for name in ("coati_engine_param_elems", "coati_engine_shadow_elems", "coati_engine_trainable_elems"):
         getattr(l, name).argtypes = [P]
         getattr(l, name).restype = c_int64
     l.coati_engine_workspace_bytes.argtypes = [P, I, I, I, I, I]
@@ -173,7 +175,7 @@ def lib():
 
 def exported_symbols():
     return sorted(list(_SIGS) + ["coati_last_error", "coati_abi_version", "coati_engine_destroy",
-                                 "coati_engine_param_elems", "coati_engine_shadow_elems",
+                                 "coati_engine_param_elems", "coati_engine_shadow_elems", "coati_engine_trainable_elems",
                                  "coati_engine_workspace_bytes", "coati_engine_decode_workspace_bytes", "coati_engine_n_entries",
                                  "coati_wgrad_grouped_workspace_bytes", "coati_engine_fp8_bytes",
                                  "coati_tokenizer_create", "coati_tokenizer_destroy", "coati_tokenizer_encode",

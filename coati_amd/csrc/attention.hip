@@ -319,7 +319,7 @@ __device__ __forceinline__ void attn_fwd_body(const bf16_t* __restrict__ qkv, bf
             mloc = fmaxf(mloc, p[r]);
           }
         }
-        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+        mloc = half_xchg_max(mloc);
         const float m_new = fmaxf(m_run, mloc);
         const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * SCALE_LOG2E);
         const float mc = m_new * SCALE_LOG2E;
@@ -329,7 +329,7 @@ __device__ __forceinline__ void attn_fwd_body(const bf16_t* __restrict__ qkv, bf
           p[r] = __builtin_amdgcn_exp2f(fmaf(p[r], SCALE_LOG2E, -mc));
           lsum += p[r];
         }
-        lsum += __shfl_xor(lsum, 32, 64);
+        lsum = half_xchg_sum(lsum);
         l_run = l_run * alpha + lsum;
         m_run = m_new;
 #pragma unroll

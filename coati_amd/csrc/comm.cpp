@@ -9,10 +9,21 @@
 // never loads it, and inside a torch process the already loaded librccl is the one that answers.
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
-#include <rccl/rccl.h>
 #include <cstring>
 #include <mutex>
 #include "common.h"
+
+// The handful of RCCL (= NCCL API) types and enumerators these entries use, declared here: the library builds on a ROCm install
+// without the rccl development headers (a single-GPU host), and the values are the stable NCCL 2.x ABI (nccl.h: ncclResult_t 0 =
+// success; ncclDataType_t float32 = 7, bfloat16 = 9; ncclRedOp_t sum = 0, avg = 4; a 128-byte opaque unique id).
+extern "C" {
+typedef struct ncclComm* ncclComm_t;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclFloat32 = 7, ncclBfloat16 = 9 } ncclDataType_t;
+typedef enum { ncclSum = 0, ncclAvg = 4 } ncclRedOp_t;
+#define NCCL_UNIQUE_ID_BYTES 128
+typedef struct { char internal[NCCL_UNIQUE_ID_BYTES]; } ncclUniqueId;
+}
 
 namespace {
 struct Rccl {
@@ -125,12 +136,24 @@ int coati_comm_destroy(coati_comm* c) {
   return rc;
 }
 
+// the communicator belongs to the device that was current at coati_comm_init: a call from another device would enqueue on a stream
+// of the wrong GPU
+static int check_device(const coati_comm* c, const char* what) {
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev != c->device) {
+    coati_set_error("%s: current device %d, the communicator was created on device %d", what, dev, c->device);
+    return COATI_EARG;
+  }
+  return COATI_OK;
+}
+
 // recv[world * rows, cols] <- concatenation over ranks of send[rows, cols] (rank-major)
 int coati_allgather_rows(coati_comm* c, const void* send, void* recv, int64_t rows, int64_t cols, int dtype, void* stream) {
   COATI_CHECK_ARG(c && send && recv && rows >= 0 && cols >= 0, "coati_allgather_rows: bad argument");
   ncclDataType_t t;
   size_t b;
   COATI_CHECK_ARG(dtype_of(dtype, t, b), "coati_allgather_rows: dtype %d (0 = f32, 1 = bf16)", dtype);
+  COATI_TRY(check_device(c, "coati_allgather_rows"));
   return rc_of(g_rccl.AllGather(send, recv, (size_t)(rows * cols), t, c->comm, (hipStream_t)stream), "coati_allgather_rows");
 }
 
@@ -140,6 +163,7 @@ int coati_reducescatter_rows(coati_comm* c, const void* send, void* recv, int64_
   ncclDataType_t t;
   size_t b;
   COATI_CHECK_ARG(dtype_of(dtype, t, b), "coati_reducescatter_rows: dtype %d (0 = f32, 1 = bf16)", dtype);
+  COATI_TRY(check_device(c, "coati_reducescatter_rows"));
   return rc_of(g_rccl.ReduceScatter(send, recv, (size_t)(rows * cols), t, ncclSum, c->comm, (hipStream_t)stream), "coati_reducescatter_rows");
 }
 
@@ -149,6 +173,7 @@ int coati_allreduce_bucket(coati_comm* c, void* buf, int64_t n, int dtype, int a
   ncclDataType_t t;
   size_t b;
   COATI_CHECK_ARG(dtype_of(dtype, t, b), "coati_allreduce_bucket: dtype %d (0 = f32, 1 = bf16)", dtype);
+  COATI_TRY(check_device(c, "coati_allreduce_bucket"));
   return rc_of(g_rccl.AllReduce(buf, buf, (size_t)n, t, average ? ncclAvg : ncclSum, c->comm, (hipStream_t)stream), "coati_allreduce_bucket");
 }
 

@@ -155,4 +155,16 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// value + / max the value of lane ^ 32 (the other half-wave): v_permlane32_swap_b32 (gfx950: exchanges the upper half of its first
+// operand with the lower half of its second) instead of __shfl_xor's ds_bpermute trip through the LDS crossbar.  Same results bit for bit.
+typedef unsigned coati_v2u __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float half_xchg_sum(float v) {
+  const coati_v2u r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r.x) + __uint_as_float(r.y);
+}
+__device__ __forceinline__ float half_xchg_max(float v) {
+  const coati_v2u r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(r.x), __uint_as_float(r.y));
+}
+
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }

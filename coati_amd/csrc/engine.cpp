@@ -62,6 +62,7 @@ struct GLayerP {
 
 struct XPass {  // saved activations of one transformer pass
   int B, T, M;               // M = rows the pass runs on: B * T (padded layout) or the number of packed rows
+  int Mcap = 0;              // rows the pass's buffers are carved for (>= B * T: coati_engine_reserve); the cached weight-gradient tables are built on it
   const long long* idx;
   // packed rows (embed.hip launch_seq_pack): the pass runs on the concatenation of every row's real prefix
   bool packed = false;
@@ -166,7 +167,17 @@ struct coati_engine {
   struct WTabKey { const void* pass = nullptr; int lo = -1, hi = -1, M = 0, n = 0; long long sig = 0; };
   WTabKey wtab_key[4];
   const void* wtab_ws = nullptr;                      // workspace the cached tables were built for
-  long long carve_sig = -1;                           // (B, T1, T2, A) of the last carve: the cached tables die with any other shape
+  long long carve_sig = -1;                           // CAPACITY (B, T1, T2, A) of the last carve: the cached tables die with any other layout
+  // grow-only capacities (coati_engine_reserve): every buffer is carved for max(shape of the call, capacity), so that batches whose
+  // T / A differ from step to step -- clip_ar_xform truncates every batch to its longest row -- keep the SAME buffer addresses and the
+  // cached tables stay valid (rows are a kernel argument of the launches that use them)
+  int cap_B = 0, cap_T1 = 0, cap_T2 = 0, cap_A = 0;
+  // pinned host staging of the table uploads: 4 transformer slots + 2 for the point encoder, each with the event of its last upload
+  // (the uploads are asynchronous: no hipStreamSynchronize on a cache miss)
+  WgradTile* h_tab[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  size_t h_tab_cap[6] = {0, 0, 0, 0, 0, 0};
+  hipEvent_t h_tab_ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  int gtab_rr = 0;
   int wtab_rr = 0;                                    // round-robin slot of the next table upload
   // E(3)-GNN node-level weight gradients as ONE split-table launch at the end of gnn_bwd: per-layer copies of the three
   // gradient operands the layers otherwise overwrite, the table (cached like d_wtab)
@@ -461,10 +472,10 @@ int gemm8(coati_engine* e, int site, const XLayerP& w, int wi, const bf16_t* A, 
 }
 
 // ---- workspace carving -----------------------------------------------------------------------------------
-void carve_pass(coati_engine* e, Arena& ar, XPass& p, int B, int T) {
+void carve_pass(coati_engine* e, Arena& ar, XPass& p, int B_, int T_, int B, int T) {   // (B_, T_): the call's shape; (B, T) >= it: the capacity every buffer is sized for
   const int L = e->cfg.n_layer_xformer, C = e->cfg.n_hidden_xformer, nh = e->cfg.n_head;
   const size_t M = (size_t)B * T;
-  p.B = B; p.T = T; p.M = (int)M;
+  p.B = B_; p.T = T_; p.M = B_ * T_; p.Mcap = (int)M;
   p.x.assign(L + 1, nullptr); p.xmid.assign(L, nullptr);
   p.mean1.assign(L, nullptr); p.rstd1.assign(L, nullptr); p.mean2.assign(L, nullptr); p.rstd2.assign(L, nullptr);
   p.lse.assign(L, nullptr);
@@ -495,13 +506,16 @@ void carve_pass(coati_engine* e, Arena& ar, XPass& p, int B, int T) {
   p.grp = ar.take<int>((size_t)B + 2);
 }
 
-size_t carve(coati_engine* e, Arena& ar, int B, int T1, int T2, int A, int Bg) {
+size_t carve(coati_engine* e, Arena& ar, int B_, int T1_, int T2_, int A_, int Bg) {
   const coati_config& c = e->cfg;
+  // sizes below are CAPACITIES (coati_engine_reserve): the call's shape only sets the passes' B / T / M
+  const int B = B_ > e->cap_B ? B_ : e->cap_B, T1 = T1_ > e->cap_T1 ? T1_ : e->cap_T1, T2 = T2_ > e->cap_T2 ? T2_ : e->cap_T2,
+            A = A_ > e->cap_A ? A_ : e->cap_A;
   const int C = c.n_hidden_xformer, H = c.n_hidden_e3nn, E = c.n_embd_common, Lg = c.n_layer_e3gnn;
   const size_t Mmax = (size_t)B * (T1 > T2 ? T1 : T2), M2 = (size_t)B * T2;
   const size_t BA = (size_t)B * A, Me = BA * A;
-  carve_pass(e, ar, e->p1, B, T1);
-  carve_pass(e, ar, e->p2, B, T2);
+  carve_pass(e, ar, e->p1, B_, T1_, B, T1);
+  carve_pass(e, ar, e->p2, B_, T2_, B, T2);
   // heads
   e->hpoint = ar.take<float>((size_t)B * H); e->hp_ln = ar.take<float>((size_t)B * H);
   e->hp_mean = ar.take<float>(B); e->hp_rstd = ar.take<float>(B);
@@ -609,7 +623,7 @@ size_t carve(coati_engine* e, Arena& ar, int B, int T1, int T2, int A, int Bg) {
   // LAST region: InfoNCE logits of the local rows against the GLOBAL batch, [B, Bg] f32 x 2 (Bg = world_size * B at
   // workspace-sizing time).  coati_engine_forward does not know Bg: it hands this region whatever the caller's
   // workspace holds beyond everything above.
-  e->nce_cap = (size_t)2 * B * (Bg > B ? Bg : B);
+  e->nce_cap = (size_t)2 * B_ * (Bg > B_ ? Bg : B_);
   e->nce = ar.take<float>(e->nce_cap);
   return (ar.off + 255) & ~(size_t)255;
 }
@@ -735,13 +749,43 @@ int xformer_fwd(coati_engine* e, XPass& p, const float* injection, hipStream_t s
   return launch_layernorm_fwd(p.x[L], C, e->P + e->lnfw, e->P + e->lnfb, y32 ? nullptr : p.af, C, y32, C, p.meanf, p.rstdf, M, C, s);
 }
 
+// Asynchronous upload of a host-built table: the entries are copied into a PINNED staging buffer owned by the engine (one per slot;
+// before a slot's buffer is rewritten the host waits for the event of its previous upload -- four misses back, i.e. never in
+// practice) and hipMemcpyAsync runs from there in stream order.  No hipStreamSynchronize: a cache miss (another batch shape) used to
+// stall the host until the device had drained the step.
+int upload_table(coati_engine* e, int hslot, const std::vector<WgradTile>& tab, WgradTile* dst, hipStream_t s, const char* what) {
+  const size_t n = tab.size();
+  if (e->h_tab_ev[hslot] == nullptr && hipEventCreateWithFlags(&e->h_tab_ev[hslot], hipEventDisableTiming) != hipSuccess) {
+    coati_set_error("%s: event creation failed", what);
+    return COATI_EHIP;
+  } else if (e->h_tab[hslot] != nullptr && hipEventSynchronize(e->h_tab_ev[hslot]) != hipSuccess) {
+    coati_set_error("%s: waiting for the previous upload failed", what);
+    return COATI_EHIP;
+  }
+  if (e->h_tab_cap[hslot] < n) {
+    if (e->h_tab[hslot] != nullptr) hipHostFree(e->h_tab[hslot]);
+    e->h_tab[hslot] = nullptr;
+    if (hipHostMalloc(reinterpret_cast<void**>(&e->h_tab[hslot]), n * sizeof(WgradTile), hipHostMallocDefault) != hipSuccess) {
+      coati_set_error("%s: pinned staging allocation failed", what);
+      return COATI_EHIP;
+    }
+    e->h_tab_cap[hslot] = n;
+  }
+  memcpy(e->h_tab[hslot], tab.data(), n * sizeof(WgradTile));
+  if (hipMemcpyAsync(dst, e->h_tab[hslot], n * sizeof(WgradTile), hipMemcpyHostToDevice, s) != hipSuccess || hipEventRecord(e->h_tab_ev[hslot], s) != hipSuccess) {
+    coati_set_error("%s: table upload failed", what);
+    return COATI_EHIP;
+  }
+  return COATI_OK;
+}
+
 // One launch for the 4 (l_hi - l_lo) weight gradients of a layer range (bias gradients included): the tile table is built
 // once per (pass, range, shape) and cached in the workspace.
 int xformer_wgrad_group(coati_engine* e, XPass& p, int l_lo, int l_hi, hipStream_t s) {
   // the table is built for the padded row count of the pass (it only fixes operand addresses and tile indices); the rows a
   // launch really streams (fewer with packed rows, different every batch) are a kernel argument
-  const int C = e->cfg.n_hidden_xformer, M = p.M, Mtab = p.B * p.T;
-  const long long sig = ((((long long)e->B * 1000003 + e->T1) * 1000003 + e->T2) * 1000003 + e->A) * 2 + (p.tail ? 1 : 0);
+  const int C = e->cfg.n_hidden_xformer, M = p.M, Mtab = p.Mcap;
+  const long long sig = e->carve_sig * 2 + (p.tail ? 1 : 0);      // the capacity layout: a batch with another T / row count reuses the table
   int slot = -1;
   for (int i = 0; i < 4; ++i)
     if (e->wtab_key[i].pass == &p && e->wtab_key[i].lo == l_lo && e->wtab_key[i].hi == l_hi && e->wtab_key[i].M == Mtab && e->wtab_key[i].sig == sig) slot = i;
@@ -767,12 +811,7 @@ int xformer_wgrad_group(coati_engine* e, XPass& p, int l_lo, int l_hi, hipStream
     }
     COATI_CHECK_ARG((int)tab.size() <= e->wtab_cap, "wgrad group: table overflow (%zu > %d)", tab.size(), e->wtab_cap);
     slot = e->wtab_rr++ & 3;
-    // pageable source: the runtime stages the copy before hipMemcpyAsync returns, so `tab` may go out of scope
-    if (hipMemcpyAsync(e->d_wtab + (size_t)slot * e->wtab_cap, tab.data(), tab.size() * sizeof(WgradTile), hipMemcpyHostToDevice, s) != hipSuccess ||
-        hipStreamSynchronize(s) != hipSuccess) {
-      coati_set_error("wgrad group: table upload failed");
-      return COATI_EHIP;
-    }
+    COATI_TRY(upload_table(e, slot, tab, e->d_wtab + (size_t)slot * e->wtab_cap, s, "wgrad group"));
     coati_engine::WTabKey k;
     k.pass = &p; k.lo = l_lo; k.hi = l_hi; k.M = Mtab; k.n = (int)tab.size(); k.sig = sig;
     e->wtab_key[slot] = k;
@@ -999,7 +1038,8 @@ int gnn_fwd(coati_engine* e, const long long* atoms, const float* coords, hipStr
 int gnn_wgrad_group(coati_engine* e, hipStream_t s) {
   const coati_config& c = e->cfg;
   const int H = c.n_hidden_e3nn, Lg = c.n_layer_e3gnn, BA = e->B * e->A;
-  const long long sig = (((long long)e->B * 1000003 + e->T1) * 1000003 + e->T2) * 1000003 + e->A;
+  // (the split table slices M = B * A itself: the call's B and A belong to the key next to the capacity layout)
+  const long long sig = (e->carve_sig * 1000003 + e->B) * 1000003 + e->A;
   if (e->gtab_sig != sig) {
     std::vector<WgradTile> tab;
     auto add = [&](const bf16_t* A_, int lda, const bf16_t* B_, int ldb, int N, int K, float* dW, int64_t ldw, float* db) -> int {
@@ -1017,10 +1057,7 @@ int gnn_wgrad_group(coati_engine* e, hipStream_t s) {
       COATI_TRY(add(e->gl_dP[l] + H, 2 * H, e->g_hcat[l], 2 * H, H, H, e->G + w.e0w + H, 2 * H + 1, nullptr));
     }
     COATI_CHECK_ARG((int)tab.size() <= e->gtab_cap, "gnn wgrad group: table overflow (%zu > %d)", tab.size(), e->gtab_cap);
-    if (hipMemcpyAsync(e->d_gtab, tab.data(), tab.size() * sizeof(WgradTile), hipMemcpyHostToDevice, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
-      coati_set_error("gnn wgrad group: table upload failed");
-      return COATI_EHIP;
-    }
+    COATI_TRY(upload_table(e, 4 + (e->gtab_rr++ & 1), tab, e->d_gtab, s, "gnn wgrad group"));
     e->gtab_n = (int)tab.size();
     e->gtab_sig = sig;
   }
@@ -1195,10 +1232,15 @@ void coati_engine_destroy(coati_engine* e) {
   if (e->ev_fork) hipEventDestroy(e->ev_fork);
   if (e->ev_join) hipEventDestroy(e->ev_join);
   if (e->side) hipStreamDestroy(e->side);
+  for (int i = 0; i < 6; ++i) {
+    if (e->h_tab_ev[i]) hipEventDestroy(e->h_tab_ev[i]);
+    if (e->h_tab[i]) hipHostFree(e->h_tab[i]);
+  }
   delete e;
 }
 
 int64_t coati_engine_param_elems(const coati_engine* e) { return e ? e->n_params : 0; }
+int64_t coati_engine_trainable_elems(const coati_engine* e) { return e ? e->n_trainable : 0; }
 int coati_engine_n_entries(const coati_engine* e) { return e ? (int)e->entries.size() : 0; }
 int coati_engine_entry(const coati_engine* e, int i, char* name, int name_cap, int64_t* offset, int32_t* rows, int32_t* cols) {
   COATI_CHECK_ARG(e && i >= 0 && i < (int)e->entries.size() && name && name_cap > 0, "engine_entry: bad argument");
@@ -1210,6 +1252,18 @@ int coati_engine_entry(const coati_engine* e, int i, char* name, int name_cap, i
   return COATI_OK;
 }
 int64_t coati_engine_shadow_elems(const coati_engine* e) { return e ? e->n_shadow : 0; }
+
+// Grow-only capacities: every later carve (workspace_bytes / forward / encode) sizes its buffers for at least this shape, so that
+// batches of different T / A keep the same buffer addresses (see coati_engine::cap_B).  Values below the current capacity are ignored.
+int coati_engine_reserve(coati_engine* e, int B, int T1, int T2, int A) {
+  COATI_CHECK_ARG(e && B >= 0 && T1 >= 0 && T2 >= 0 && A >= 0, "engine_reserve: bad argument");
+  COATI_CHECK_SHAPE(T1 <= e->cfg.n_seq && T2 <= e->cfg.n_seq, "engine_reserve: T1=%d T2=%d beyond n_seq=%d", T1, T2, e->cfg.n_seq);
+  if (B > e->cap_B) e->cap_B = B;
+  if (T1 > e->cap_T1) e->cap_T1 = T1;
+  if (T2 > e->cap_T2) e->cap_T2 = T2;
+  if (A > e->cap_A) e->cap_A = A;
+  return COATI_OK;
+}
 
 int64_t coati_engine_workspace_bytes(const coati_engine* e, int B, int T1, int T2, int A, int Bg) {
   if (!e || B <= 0 || T1 <= 0 || T2 <= 0 || A <= 0) return 0;
@@ -1617,6 +1671,21 @@ int coati_engine_optimizer_step(coati_engine* e, float lr, float beta1, float be
     COATI_TRY(launch_adamw(e->P, e->G, e->Mo, e->Vo, e->S, e->n_trainable, lr, beta1, beta2, eps, weight_decay, step, scal + 8, 1.f, s, e->err_flag));
   }
   return refresh_shadows_impl(e, stream, true);
+}
+
+// Data-parallel training: the step's error word (bit 0: a row without [STOP]; bit 1: packed-row counts that differ from what the
+// device found) as reduced over ALL ranks replaces this rank's own one before coati_engine_optimizer_step, so that the AdamW kernel's
+// `skip` drops the update on every rank or on none (the all-reduced gradient is the same everywhere: a rank that skipped alone
+// would leave the replicas different).  word_dev: one int32 in device memory; also copied into scal[6] for losses().
+int coati_engine_set_error_word(coati_engine* e, const int32_t* word_dev, void* stream) {
+  COATI_CHECK_ARG(e && word_dev && e->have_ws && e->err_flag && e->scal, "set_error_word: no forward workspace");
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemcpyAsync(e->err_flag, word_dev, sizeof(int), hipMemcpyDeviceToDevice, s) != hipSuccess ||
+      hipMemcpyAsync(e->scal + 6, word_dev, sizeof(int), hipMemcpyDeviceToDevice, s) != hipSuccess) {
+    coati_set_error("set_error_word: copy failed");
+    return COATI_EHIP;
+  }
+  return COATI_OK;
 }
 
 int coati_engine_prof_select(coati_engine* e, int site) {

@@ -129,7 +129,8 @@ def _schedule_begin(eng):
     sch = getattr(eng, "_dp_schedule", None)
     if sch is None:
         sch = eng._dp_schedule = _Schedule()
-    if sch.decided or not _measurable():
+    if sch.decided or not _measurable() or sch.step >= sch.WARMUP + 2 * sch.PER_FORM:
+        # (the last clause: a measurement that never reached its decision -- an exception in between -- stops allocating events)
         return (sch.split if sch.decided and _SPLIT_ENV is None else _SPLIT_ENCODER_STAGE), None
     k = sch.step
     sch.step += 1
@@ -166,7 +167,13 @@ def distributed_train_step(eng, batch, use_point, lr, do_clip=True, optimizer=Tr
     reduce_grads=False skips the gradient all-reduces (bench.py's measurement of their exposed cost).
     opt_kw: weight_decay / max_norm / betas / eps for Engine.optimizer_step (train_coati.py:145-151, 276)."""
     W, rank = dist.get_world_size(), dist.get_rank()
-    split_stage, slot = _schedule_begin(eng) if (reduce_grads and optimizer) else (_SPLIT_ENCODER_STAGE, None)
+    if reduce_grads and optimizer:
+        split_stage, slot = _schedule_begin(eng)
+    else:
+        # not a timed step (bench.py's exposed-cost loops, eval-like calls): the schedule the engine has decided on, if any -- so that
+        # a comparison of two loops compares the SAME backward schedule
+        sch = getattr(eng, "_dp_schedule", None)
+        split_stage, slot = ((sch.split if (sch is not None and sch.decided and _SPLIT_ENV is None) else _SPLIT_ENCODER_STAGE), None)
     h_e, h_s, bad = eng.forward(batch["raw_tokens"], batch["tokens"], batch["atoms"], batch["coords"], use_point,
                                 y_next=batch["y_next"], train=True, rows=batch.get("rows"), stop_after_heads=True)
     B = h_e.shape[0]
@@ -187,6 +194,17 @@ def distributed_train_step(eng, batch, use_point, lr, do_clip=True, optimizer=Tr
     loss_b, dS, dC = eng.contrastive_under_decoder(head_fn)
     if head == "barlow" and do_clip:
         eng.barlow_loss = loss_b
+    # the step's error word (a row without [STOP] / packed-row mismatch), each bit MAX-reduced over the ranks underneath the
+    # backward: the AdamW kernel drops the update on EVERY rank or on none (a rank skipping alone would leave the replicas different)
+    err_bits, err_work = None, None
+    if optimizer and W > 1:
+        err_bits = eng.error_bits()
+        if _gloo() and err_bits.is_cuda:
+            h = err_bits.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.MAX)
+            err_bits = h.to(err_bits.device)
+        else:
+            err_work = dist.all_reduce(err_bits, op=dist.ReduceOp.MAX, async_op=True)
     bk = grad_buckets(eng)
     works = []
 
@@ -225,6 +243,10 @@ def distributed_train_step(eng, batch, use_point, lr, do_clip=True, optimizer=Tr
     for w in works:
         w.wait()
     if optimizer:
+        if err_bits is not None:
+            if err_work is not None:
+                err_work.wait()
+            eng.set_error_word(err_bits)
         eng.optimizer_step(lr, **opt_kw)
     _schedule_end(eng, slot)
     return h_e, h_s, bad
@@ -250,7 +272,8 @@ def global_losses(eng):
     # the device-side error word of the step (bit 0: a row without [STOP]; bit 1: the packed-row counts passed to forward() differ
     # from what the device found) -- MAX over the ranks, so that every rank raises together (the optimizer kernel has already
     # dropped the update on the rank that saw it: csrc/optim.hip adamw_kernel `skip`)
-    err = s[6:7].view(torch.int32).to(torch.float32)
+    w = s[6:7].view(torch.int32)
+    err = torch.cat([w & 1, (w >> 1) & 1]).to(torch.float32)      # one element per bit: MAX of the word itself would lose bit 0 behind bit 1
     if _gloo() and err.is_cuda:
         h = err.cpu()
         dist.all_reduce(h, op=dist.ReduceOp.MAX)
@@ -258,7 +281,8 @@ def global_losses(eng):
     else:
         dist.all_reduce(err, op=dist.ReduceOp.MAX)
     s = s.cpu()
-    err = int(err.cpu()[0])
+    err = err.cpu()
+    err = int(err[0] > 0) | (int(err[1] > 0) << 1)
     if err & 1:
         raise RuntimeError("Some smiles in the batch do not have stop tokens. Did some tokenizations fail?")
     if err & 2:

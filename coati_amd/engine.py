@@ -59,6 +59,7 @@ class Engine:
         _lib.check(self.l.coati_engine_create(ctypes.byref(c), ctypes.byref(h)), "coati_engine_create")
         self.h = h
         self.n_params = int(self.l.coati_engine_param_elems(h))
+        self.n_trainable = int(self.l.coati_engine_trainable_elems(h))
         self.n_shadow = int(self.l.coati_engine_shadow_elems(h))
         self.layout = {}
         buf = ctypes.create_string_buffer(256)
@@ -134,6 +135,13 @@ class Engine:
                 world = dist.get_world_size()
         except Exception:
             world = 1
+        # grow-only capacities: buffers are carved for the largest shape seen so far, so that batches of different width (every batch of
+        # clip_ar_xform has its own T) keep the same addresses -- cached launch tables stay valid, the workspace stops being re-sized
+        cap = getattr(self, "_cap", (0, 0, 0, 0))
+        new = tuple(max(a, b) for a, b in zip(cap, (B, T1, T2, A)))
+        if new != cap:
+            _lib.check(self.l.coati_engine_reserve(self.h, *new), "coati_engine_reserve")
+            self._cap = new
         need = int(self.l.coati_engine_workspace_bytes(self.h, B, T1, T2, A, B * world))
         if self.workspace is None or self.workspace.numel() < need:
             self.workspace = None
@@ -252,6 +260,18 @@ class Engine:
         self.step_count += 1
         _lib.check(self.l.coati_engine_optimizer_step(self.h, float(lr), betas[0], betas[1], eps, weight_decay, max_norm,
                                                       self.step_count, ptr(self.scal), stream()), "coati_engine_optimizer_step")
+
+    def error_bits(self):
+        """the step's device-side error word as two floats [a row without [STOP], packed-row mismatch] on the device (no sync)"""
+        w = self.scal[SCAL_ERR:SCAL_ERR + 1].view(torch.int32)
+        return torch.cat([w & 1, (w >> 1) & 1]).to(torch.float32)
+
+    def set_error_word(self, bits):
+        """bits: the two flags of error_bits() reduced over the ranks; replaces this rank's word before optimizer_step (every rank
+        drops the update or none does) and in scal, so that losses() raises on every rank"""
+        w = (bits[0:1] > 0).to(torch.int32) + 2 * (bits[1:2] > 0).to(torch.int32)
+        _lib.check(self.l.coati_engine_set_error_word(self.h, ptr(w), stream()), "coati_engine_set_error_word")
+        self._err_word_keepalive = w
 
     def token_entropy_unit(self):
         return math.log(float(self.cfg.n_tok)) / math.log(2.0)

@@ -43,8 +43,12 @@ def optimizer_state_dict(eng, lr, weight_decay, betas=(0.9, 0.99), eps=1e-8):
     from ..models.encoding.clip_e2e import reference_parameter_order
     names = reference_parameter_order(list(eng.layout))
     state = {}
+    n_trainable = int(getattr(eng, "n_trainable", 0) or 0)
     for i, n in enumerate(names):
-        if "coord_mlp" in n or eng.step_count == 0:
+        # parameters behind n_trainable never receive a gradient (coord_mlp always; the point encoder and point_to_clip when
+        # use_point_encoder = False): torch keeps no state entry for a parameter whose grad is None
+        untrained = ("coord_mlp" in n) or (n_trainable > 0 and eng.layout[n][0] >= n_trainable)
+        if untrained or eng.step_count == 0:
             continue
         state[i] = {"step": torch.tensor(float(eng.step_count)), "exp_avg": eng.view(n, "adam_m").detach().cpu().clone(),
                     "exp_avg_sq": eng.view(n, "adam_v").detach().cpu().clone()}
@@ -231,6 +235,7 @@ def train_autoencoder(gpu, args, dataset=None, tokenizer=None):
         # rows of the InfoNCE matrices) while the valid-row count is global, so the per-batch loss is formed only after the
         # sums of all ranks are added, once per epoch (same arithmetic as D.global_losses)
         acc = torch.zeros(1, device=device, dtype=torch.float64)
+        err_acc = torch.zeros(1, device=device, dtype=torch.int32)
         hist = []
         teu = eng.token_entropy_unit()
         pipe = dataset.get_data_pipe(batch_size=args.batch_size, partition=partition, distributed_rankmod_total=world,
@@ -268,6 +273,7 @@ def train_autoencoder(gpu, args, dataset=None, tokenizer=None):
             ngrad_updates += B          # both partitions, as train_coati.py:279-282
             ng += B
             hist.append(eng.scal[:5].double())
+            err_acc |= eng.scal[6:7].view(torch.int32)          # the step's error word, checked at the end of the epoch at the latest
             acc += (dev["tokens"] > 0).sum().double()
             log_now = (i % int(args.log_batch_loss)) == 0
             if log_now or i % args.log_interval == 0:
@@ -288,6 +294,17 @@ def train_autoencoder(gpu, args, dataset=None, tokenizer=None):
                                       offline_loss=offline_losses)
                 logger.log_pytorch(doc, tags={"train_epoch": str(epoch), "dataset_epoch": str(epoch)})
         n_toks += int(acc.cpu()[0])
+        # every step's error word (off the logging steps nothing else reads it; the optimizer kernel has dropped those updates): the
+        # reference raises on the step itself (smiles_xformer.py:63-66), here the epoch does at the latest -- on every rank together
+        ew = err_acc.cpu()
+        if world > 1:
+            eb = torch.tensor([float(int(ew[0]) & 1), float((int(ew[0]) >> 1) & 1)])
+            dist_all = D.dist.all_reduce(eb, op=D.dist.ReduceOp.MAX, group=D.control_group())
+            ew = torch.tensor([int(eb[0] > 0) | (int(eb[1] > 0) << 1)])
+        if int(ew[0]) & 1:
+            raise RuntimeError("Some smiles in the batch do not have stop tokens. Did some tokenizations fail?")
+        if int(ew[0]) & 2:
+            raise RuntimeError("packed rows: the row counts passed to forward() differ from what the device found in the tokens")
         if rank == 0:
             print(f"epoch completed in {ng} grads and {time.time()-t0} seconds")
         if not hist:

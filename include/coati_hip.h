@@ -291,11 +291,19 @@ void coati_engine_destroy(coati_engine* e);
 
 /* parameter table: entry i = (state_dict name, element offset into the flat f32 buffer, rows, cols) */
 int64_t coati_engine_param_elems(const coati_engine* e);
+/* leading elements of the flat buffers that receive gradients: the parameters behind it (coord_mlp; the point encoder and
+ * point_to_clip when use_point_encoder = 0) are never updated -- torch keeps no optimizer state for them (p.grad is None) */
+int64_t coati_engine_trainable_elems(const coati_engine* e);
 int coati_engine_n_entries(const coati_engine* e);
 int coati_engine_entry(const coati_engine* e, int i, char* name, int name_cap, int64_t* offset, int32_t* rows,
                        int32_t* cols);
 int64_t coati_engine_shadow_elems(const coati_engine* e);
 int64_t coati_engine_workspace_bytes(const coati_engine* e, int B, int T1, int T2, int A, int Bg);
+/* Grow-only buffer capacities: every later workspace_bytes / forward / encode sizes its buffers for at least (B, T1, T2, A), so that
+ * batches whose T / A change from step to step (clip_ar_xform truncates each batch to its longest row, clip_e2e.py:312-315) keep the
+ * same buffer addresses inside the caller's workspace and the engine's cached launch tables stay valid.  Call BEFORE
+ * coati_engine_workspace_bytes; values below the current capacity are ignored. */
+int coati_engine_reserve(coati_engine* e, int B, int T1, int T2, int A);
 
 /* bind caller-owned buffers: params/grads/adam m/adam v (f32, param_elems), shadow (bf16, shadow_elems, zeroed),
  * RoPE tables [n_seq,16] f32, periodic-table LUTs [120] int32 (one-hot indices, -1 = none). */
@@ -359,6 +367,10 @@ int coati_engine_backward(coati_engine* e, const float* dh_smiles, const float* 
 /* clip_grad_norm_(max_norm) + AdamW + shadow refresh.  scal[5] receives the pre-clip gradient norm. */
 int coati_engine_optimizer_step(coati_engine* e, float lr, float beta1, float beta2, float eps, float weight_decay,
                                 float max_norm, int step, float* scal, void* stream);
+/* Data-parallel hosts: replace this rank's error word of the step (bit 0: a row without [STOP], smiles_xformer.py:63-66; bit 1: packed
+ * row counts differ from the tokens) by the one reduced over all ranks BEFORE coati_engine_optimizer_step, whose AdamW kernel drops the
+ * update when the word is non-zero: every rank then skips or none does.  word_dev: one int32 in device memory. */
+int coati_engine_set_error_word(coati_engine* e, const int32_t* word_dev, void* stream);
 
 /* per-site kernel timing with HIP events on the launch stream (bench.py roofline leg) */
 int coati_engine_prof_select(coati_engine* e, int site);              /* -1 disables */

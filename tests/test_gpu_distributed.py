@@ -145,6 +145,58 @@ def test_two_process_distributed_step_equals_global_batch(tmp_path):
     _compare_grads(eng, r[0]["grads"], 5e-3, "two-process InfoNCE step")
 
 
+def _bad_row_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from coati_amd.engine import Engine, ModelConfig
+        from coati_amd import distributed as D
+        eng = Engine(ModelConfig(**KW), "cuda:0")
+        _weights(eng)
+        b, up = _rank_batch(rank)
+        if rank == 1:               # ONE rank sees a row without its [STOP] token (id 1): smiles_xformer.py:63-66 raises there
+            row = b["raw_tokens"][3]
+            row[row == 1] = 12
+        db = {k: v.to("cuda:0") for k, v in b.items()}
+        p0 = eng.params.clone()
+        D.distributed_train_step(eng, db, up.to("cuda:0"), lr=1e-2)
+        torch.cuda.synchronize()
+        moved = float((eng.params - p0).abs().max())
+        raised = ""
+        try:
+            D.global_losses(eng)
+        except RuntimeError as ex:
+            raised = str(ex)
+        np.savez(os.path.join(out_dir, f"bad{rank}.npz"), moved=moved, raised=np.array(raised), word=int(eng.scal[6:7].view(torch.int32)[0]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_a_bad_row_on_one_rank_drops_the_update_on_every_rank(tmp_path):
+    """The optimizer kernel skips the update when the step's error word is set; at world size > 1 the word is reduced over the ranks
+    first (distributed_train_step), so the replicas stay identical: here rank 1 has a row without [STOP], rank 0 a clean batch --
+    neither may move its weights, and both raise the reference's message."""
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_bad_row_worker, args=(r, 2, 29631, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=600)
+    for p in procs:
+        if p.is_alive():
+            p.kill()
+            pytest.fail("distributed worker hung")
+        assert p.exitcode == 0, f"worker exit code {p.exitcode}"
+    out = [np.load(os.path.join(str(tmp_path), f"bad{r}.npz")) for r in range(2)]
+    for r in range(2):
+        assert float(out[r]["moved"]) == 0.0, (r, float(out[r]["moved"]))
+        assert int(out[r]["word"]) & 1, (r, int(out[r]["word"]))
+        assert "stop tokens" in str(out[r]["raised"]), (r, str(out[r]["raised"]))
+
+
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two visible GPUs: RCCL refuses two ranks on one device")
 def test_two_gpu_rccl_step_equals_global_batch(tmp_path):
     """The same equivalence over REAL RCCL ("nccl" backend, one GPU per rank): all_gather_into_tensor, reduce_scatter_tensor and
