@@ -298,7 +298,17 @@ def main():
     site_ms, site_n, site_flops = eng.prof_collect()
     site_bytes = eng.prof_last_bytes()
     eng.prof_select(-1)
+    per_rank_ms, world_seen = None, None
     if dist_on:
+        # every rank's own wall time of the timed region (the line's value uses the MAX), and the world size RCCL itself reports: an
+        # all_reduce(SUM) of ones over the device communicator -- a launcher that started N processes which did not all join shows here
+        mine = torch.zeros(world, device=dev, dtype=torch.float64)
+        mine[rank] = dt
+        torch.distributed.all_reduce(mine, op=torch.distributed.ReduceOp.SUM)
+        per_rank_ms = [round(1e3 * float(x) / args.steps, 3) for x in mine.tolist()]
+        ones = torch.ones(1, device=dev)
+        torch.distributed.all_reduce(ones, op=torch.distributed.ReduceOp.SUM)
+        world_seen = int(round(float(ones)))
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t)
@@ -344,6 +354,15 @@ def main():
         comm["step_with_grad_allreduce_ms"] = round(1e3 * t_pair[0], 3)
         comm["step_without_grad_allreduce_ms"] = round(1e3 * t_pair[1], 3)
         comm["exposed_grad_allreduce_ms"] = round(1e3 * (t_pair[0] - t_pair[1]), 3)
+        comm["world_seen_by_rccl"] = world_seen
+        comm["per_rank_ms_per_step"] = per_rank_ms
+        sch = getattr(eng, "_dp_schedule", None)
+        comm["backward_schedule"] = {"decided": bool(sch is not None and sch.decided), "encoder_stage": ("two halves" if (sch is not None and sch.split) else "one piece"),
+                                     "forced_by_env": os.environ.get("COATI_DP_SPLIT")}
+        wire = os.environ.get("COATI_DP_WIRE", "fp32")
+        comm["gradient_wire_format"] = wire
+        comm["gradient_bytes_per_rank_MB"] = {k: round(v / 1e6, 2) for k, v in D.wire_bytes_per_rank(eng, wire).items()}
+        comm["embedding_exchange_bytes_per_rank_MB"] = round(2 * 2 * args.batch * eng.cfg.n_embd_common * 4 / 1e6, 3)   # all-gather of h_smiles, h_e3gnn + reduce-scatter of their gradients (fp32)
 
     # ---- extras on the same line (headline unchanged): what real training looks like -----------------------------------------
     # varying_batches: clip_ar_xform truncates every batch to ITS longest row (clip_e2e.py:312-315), so T1 / T2, the packed row counts

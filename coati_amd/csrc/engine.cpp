@@ -231,6 +231,9 @@ struct coati_engine {
     hipGraphExec_t graph[2] = {nullptr, nullptr};   // [0] tokens only, [1] tokens + injection
   } dec;
   double prof_bytes = 0.0;   // algorithmic HBM bytes (operands read once, results written once) of the selected site
+  // the E(3)-GNN's edge-level launches: their row count (the compacted neighbour list's length, g_ne[0]) lives on the device, so the
+  // sites book bytes and flops PER EDGE; coati_engine_prof_collect reads the count back (it synchronises anyway) and multiplies
+  double prof_bytes_e = 0.0, prof_flops_e = 0.0;
 };
 
 namespace {
@@ -408,12 +411,15 @@ struct ProfScope {
   coati_engine* e;
   hipStream_t s;
   bool on;
-  ProfScope(coati_engine* e_, int site, double flops, hipStream_t s_, double bytes = 0.0) : e(e_), s(s_), on(false) {
+  ProfScope(coati_engine* e_, int site, double flops, hipStream_t s_, double bytes = 0.0, double bytes_per_edge = 0.0, double flops_per_edge = 0.0)
+      : e(e_), s(s_), on(false) {
     if (site >= 0 && !e->prof_paused && ((e->prof_mask >> site) & 1ull) && e->ev_used + 2 <= (int)e->ev.size()) {
       on = true;
       hipEventRecord(e->ev[e->ev_used], s);
       e->prof_flops += flops;
       e->prof_bytes += bytes;
+      e->prof_bytes_e += bytes_per_edge;
+      e->prof_flops_e += flops_per_edge;
     }
   }
   ~ProfScope() {
@@ -993,7 +999,9 @@ int gnn_fwd(coati_engine* e, const long long* atoms, const float* coords, hipStr
   const coati_config& c = e->cfg;
   const int H = c.n_hidden_e3nn, Lg = c.n_layer_e3gnn, B = e->B, A = e->A, BA = B * A, Me = BA * A;
   {
-    ProfScope ps(e, SITE_GNN_ELEMWISE, 0, s);
+    // embedding: atoms in, h (f32 + bf16) + rstd + mask out; geometry: coords in, dense d2 / w [B, A, A] out; compaction: the dense
+    // grid in (twice: count, fill), the edge list (bj, bk, rev, d2, w: 20 B per edge) + offsets out
+    ProfScope ps(e, SITE_GNN_ELEMWISE, 0, s, (double)BA * (8 + H * 6 + 8) + (double)BA * 12 + (double)Me * 8 * 3 + (double)BA * 4, 20.0);
     bf16_t* h16 = Lg > 0 ? e->g_hcat[0] : e->g_hfin16;
     COATI_TRY(launch_gnn_embed(atoms, e->lut_ix, e->lut_iy, e->P + e->gembw, e->P + e->gembb, e->g_h32[0], h16, Lg > 0 ? 2 * H : H, e->g_rstd[0], e->g_mask, BA, H, s));
     COATI_TRY(launch_gnn_geom(coords, e->g_mask, c.msg_cutoff, e->g_d2, e->g_w, B, A, s));
@@ -1004,7 +1012,8 @@ int gnn_fwd(coati_engine* e, const long long* atoms, const float* coords, hipStr
     const GLayerP& w = e->gl[l];
     COATI_TRY(gemm(e, SITE_GNN_NODE_GEMM, e->g_hcat[l], 0, 2 * H, e->S + w.w1ab, H, BA, 2 * H, H, e->g_P[l], 2 * H, nullptr, EPI_BF16, nullptr, nullptr, 0, s));
     {
-      ProfScope ps(e, SITE_GNN_ELEMWISE, 0, s);
+      // per receiver its Pa row (bf16 H), per edge the GATHERED sender row Pb[bk] (bf16 H) + bk + d2 in, e1 (bf16 H) out
+      ProfScope ps(e, SITE_GNN_ELEMWISE, 0, s, (double)BA * (H * 2 + 4), (double)H * 4 + 8, 4.0 * H);
       COATI_TRY(launch_gnn_edge_pre_c(e->g_P[l], 2 * H, e->g_seg, e->g_ebk, e->g_ed2, e->P + w.e0w + 2 * H, 2 * H + 1, e->P + w.e0b, e->g_e1[l], BA, H, s));
     }
     {   // rows = the edges that exist (device-side count); Me only sizes the grid
@@ -1012,24 +1021,24 @@ int gnn_fwd(coati_engine* e, const long long* atoms, const float* coords, hipStr
       memset(&a, 0, sizeof(a));
       a.m_dev = e->g_ne;
       a.A = e->g_e1[l]; a.lda = H; a.B = e->S + w.e3w; a.ldb = H; a.M = Me; a.N = H; a.K = H; a.C = e->g_s2[l]; a.ldc = H; a.bias = e->P + w.e3b;
-      ProfScope ps(e, SITE_GNN_EDGE_GEMM, 0, s);
+      ProfScope ps(e, SITE_GNN_EDGE_GEMM, 0, s, (double)H * H * 2 + H * 4, (double)H * 4, 2.0 * H * H);   // e1 in, s2 out per edge; the weight once
       COATI_TRY(launch_gemm_nt(a, 0, EPI_BF16, s));
     }
     {
-      ProfScope ps(e, SITE_GNN_ELEMWISE, 0, s);
+      ProfScope ps(e, SITE_GNN_ELEMWISE, 0, s, (double)BA * (H * 2 + 4), (double)H * 2 + 4, 2.0 * H);   // s2 + w per edge in, the segment sums (bf16 H per node) out
       COATI_TRY(launch_gnn_edge_reduce_c(e->g_s2[l], e->g_seg, e->g_ew, e->g_hcat[l] + H, 2 * H, BA, H, s));
     }
     COATI_TRY(gemm(e, SITE_GNN_NODE_GEMM, e->g_hcat[l], 0, 2 * H, e->S + w.n0w, 2 * H, BA, H, 2 * H, e->g_t[l], H, e->P + w.n0b, EPI_SILU, nullptr, e->g_upre[l], H, s));
     COATI_TRY(gemm(e, SITE_GNN_NODE_GEMM, e->g_t[l], 0, H, e->S + w.n3w, H, BA, H, H, e->g_o, H, e->P + w.n3b, EPI_RES_F32, e->g_h32[l], nullptr, H, s));
     {
-      ProfScope ps(e, SITE_GNN_ELEMWISE, 0, s);
+      ProfScope ps(e, SITE_GNN_ELEMWISE, 0, s, (double)BA * (H * 4 + H * 4 + H * 2 + 4));   // o in, h (f32) + its bf16 copy + rstd out
       const bool last = (l + 1 == Lg);
       COATI_TRY(launch_layernorm_fwd(e->g_o, H, nullptr, nullptr, last ? e->g_hfin16 : e->g_hcat[l + 1], last ? H : 2 * H, e->g_h32[l + 1], H, nullptr, e->g_rstd[l + 1], BA, H, s));
     }
   }
   COATI_TRY(gemm(e, SITE_GNN_NODE_GEMM, e->g_hfin16, 0, H, e->S + e->gd0w, H, BA, H, H, e->g_td, H, e->P + e->gd0b, EPI_SILU, nullptr, e->g_dpre, H, s));
   COATI_TRY(gemm(e, SITE_GNN_NODE_GEMM, e->g_td, 0, H, e->S + e->gd3w, H, BA, H, H, e->g_o2, H, e->P + e->gd3b, EPI_F32, nullptr, nullptr, 0, s));
-  ProfScope ps(e, SITE_GNN_ELEMWISE, 0, s);
+  ProfScope ps(e, SITE_GNN_ELEMWISE, 0, s, (double)BA * (H * 4 + 4) + (double)B * H * 4);
   return launch_gnn_readout(e->g_o2, e->g_mask, e->hpoint, B, A, H, s);
 }
 
@@ -1072,7 +1081,7 @@ int gnn_bwd(coati_engine* e, const float* dhpoint, hipStream_t s) {
   float *DH = e->g_DH, *DO = e->g_DO;
   const bool grp = e->gnn_wg_group;
   {
-    ProfScope ps(e, SITE_GNN_ELEMWISE, 0, s);
+    ProfScope ps(e, SITE_GNN_ELEMWISE, 0, s, (double)B * H * 4 + (double)BA * (H * 2 + 4));
     COATI_TRY(launch_gnn_readout_bwd(dhpoint, e->g_mask, e->g_do2, B, A, H, s));
   }
   COATI_TRY(gemm(e, SITE_GNN_NODE_GEMM, e->g_do2, 0, H, e->S + e->gd3T, H, BA, H, H, e->g_dtd, H, nullptr, EPI_DSILU, e->g_dpre, nullptr, H, s));
@@ -1086,7 +1095,7 @@ int gnn_bwd(coati_engine* e, const float* dhpoint, hipStream_t s) {
     bf16_t* const du = grp ? e->gl_du[l] : e->g_du;
     bf16_t* const dP = grp ? e->gl_dP[l] : e->g_dP;
     {
-      ProfScope ps(e, SITE_GNN_ELEMWISE, 0, s);
+      ProfScope ps(e, SITE_GNN_ELEMWISE, 0, s, (double)BA * (H * 4 + H * 4 + 4 + H * 4 + H * 2));   // dy, xhat, rstd in; dx (f32 + bf16) out
       COATI_TRY(launch_layernorm_bwd(DH, 1, H, e->g_h32[l + 1], H, 1, nullptr, e->g_rstd[l + 1], nullptr, nullptr, DO, DO16, nullptr, nullptr, e->ln_partial, BA, H, s));
     }
     // o = h + t W4^T + b4
@@ -1097,7 +1106,7 @@ int gnn_bwd(coati_engine* e, const float* dhpoint, hipStream_t s) {
     COATI_TRY(gemm(e, SITE_GNN_NODE_GEMM, du, 0, H, e->S + w.n0T + (int64_t)H * H, H, BA, H, H, e->g_dmi, H, nullptr, EPI_BF16, nullptr, nullptr, 0, s));
     if (!grp) COATI_TRY(wgrad(e, SITE_GNN_WGRAD, du, 0, H, e->g_hcat[l], 2 * H, BA, H, 2 * H, e->G + w.n0w, 2 * H, e->G + w.n0b, 0, s));
     {
-      ProfScope ps(e, SITE_GNN_ELEMWISE, 0, s);
+      ProfScope ps(e, SITE_GNN_ELEMWISE, 0, s, (double)BA * (H * 2 + 4), (double)H * 4 + 4, 6.0 * H);   // d mi per receiver, s2 + w per edge in, d s2 per edge out
       COATI_TRY(launch_gnn_edge_reduce_bwd_c(e->g_dmi, H, e->g_s2[l], e->g_seg, e->g_ew, e->g_ds2, BA, H, s));
     }
     {
@@ -1107,18 +1116,20 @@ int gnn_bwd(coati_engine* e, const float* dhpoint, hipStream_t s) {
       a.P = e->g_P[l]; a.ldp = 2 * H; a.d2 = e->g_ed2; a.w1c = e->P + w.e0w + 2 * H; a.w1c_stride = 2 * H + 1;
       a.b1 = e->P + w.e0b; a.natom = A; a.H = H;
       a.m_dev = e->g_ne; a.e_bj = e->g_ebj; a.e_bk = e->g_ebk;
-      ProfScope ps(e, SITE_GNN_EDGE_GEMM, 0, s);
+      // d s2 in, d pre out, and the recomputed pre-activation's two GATHERED rows Pa[bj], Pb[bk] (bf16 H each) + the indices and d2 per edge
+      ProfScope ps(e, SITE_GNN_EDGE_GEMM, 0, s, (double)H * H * 2, (double)H * 8 + 12, 2.0 * H * H + 8.0 * H);
       COATI_TRY(launch_gemm_nt(a, 0, EPI_EDGE_DPRE, s));
     }
     {
       WgradArgs a;
       a.A = e->g_ds2; a.lda = H; a.B = e->g_e1[l]; a.ldb = H; a.M = Me; a.N = H; a.K = H; a.dW = e->G + w.e3w; a.ldw = H; a.dbias = e->G + w.e3b;
       a.n_out = 0; a.m_dev = e->g_ne;
-      ProfScope ps(e, SITE_GNN_WGRAD, 0, s);
+      ProfScope ps(e, SITE_GNN_WGRAD, 0, s, (double)H * H * 8, (double)H * 4, 2.0 * H * H);   // d s2 and e1 per edge in, the f32 gradient read-modify-write
       COATI_TRY(launch_wgrad(a, 0, s));
     }
     {
-      ProfScope ps(e, SITE_GNN_ELEMWISE, 0, s);
+      // d pre of an edge in (its own row for the receiver sum, the reverse edge's row GATHERED for the sender sum) + rev + d2; dP (bf16 2H per node) out
+      ProfScope ps(e, SITE_GNN_ELEMWISE, 0, s, (double)BA * (H * 4 + 4), (double)H * 4 + 8, 4.0 * H);
       COATI_TRY(launch_gnn_edge_pre_bwd_c(e->g_dpre1, e->g_seg, e->g_erev, e->g_ed2, dP, 2 * H, e->G + w.e0w + 2 * H, 2 * H + 1, e->G + w.e0b, BA, H, s));
     }
     COATI_TRY(gemm(e, SITE_GNN_NODE_GEMM, dP, 0, 2 * H, e->S + w.w1abT, 2 * H, BA, H, 2 * H, DO, H, nullptr, EPI_ACC_F32, nullptr, nullptr, 0, s));
@@ -1130,7 +1141,7 @@ int gnn_bwd(coati_engine* e, const float* dhpoint, hipStream_t s) {
   }
   if (grp) COATI_TRY(gnn_wgrad_group(e, s));
   {
-    ProfScope ps(e, SITE_GNN_ELEMWISE, 0, s);
+    ProfScope ps(e, SITE_GNN_ELEMWISE, 0, s, (double)BA * (H * 4 + H * 4 + 4 + H * 4) + (double)BA * (8 + H * 4) + 30.0 * H * 4);
     COATI_TRY(launch_layernorm_bwd(DH, 1, H, e->g_h32[0], H, 1, nullptr, e->g_rstd[0], nullptr, nullptr, DO, nullptr, nullptr, nullptr, e->ln_partial, BA, H, s));
     COATI_TRY(launch_gnn_embed_bwd(e->atoms, e->lut_ix, e->lut_iy, DO, e->G + e->gembw, e->G + e->gembb, BA, H, s));
   }
@@ -1748,11 +1759,20 @@ int coati_engine_prof_collect(coati_engine* e, double* total_ms, int64_t* launch
   }
   *total_ms = tot;
   *launches = e->ev_used / 2;
+  if ((e->prof_bytes_e > 0.0 || e->prof_flops_e > 0.0) && e->have_ws && e->g_ne != nullptr) {
+    int ne = 0;   // edges of the last step's neighbour list (every launch above has completed: the events were waited for)
+    if (hipMemcpy(&ne, e->g_ne, sizeof(int), hipMemcpyDeviceToHost) == hipSuccess && ne > 0) {
+      e->prof_bytes += e->prof_bytes_e * ne;
+      e->prof_flops += e->prof_flops_e * ne;
+    }
+  }
   if (flops_per_launch) *flops_per_launch = e->ev_used ? e->prof_flops / (e->ev_used / 2) : 0.0;
   e->prof_last_bytes = e->ev_used ? e->prof_bytes / (e->ev_used / 2) : 0.0;
   e->ev_used = 0;
   e->prof_flops = 0.0;
   e->prof_bytes = 0.0;
+  e->prof_bytes_e = 0.0;
+  e->prof_flops_e = 0.0;
   return COATI_OK;
 }
 

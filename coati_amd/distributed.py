@@ -81,6 +81,39 @@ def all_reduce_avg_async(t: torch.Tensor):
     return dist.all_reduce(t, op=dist.ReduceOp.AVG, async_op=True)
 
 
+class _Bf16Wire:
+    """all-reduce(AVG) of an fp32 gradient range on a bf16 wire: cast into a staging buffer, exchange half the bytes, cast back on
+    wait().  The average itself is formed by RCCL in bf16: every element carries one bf16 rounding (<= 2^-9 relative) before the
+    clip-norm -- tests/test_gpu_distributed.py holds it to 4e-3 of the tensor scale against the fp32 wire."""
+
+    def __init__(self, t, stage):
+        self.t, self.stage = t, stage
+        stage.copy_(t)
+        if _gloo():
+            h = stage.float().cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM)
+            stage.copy_((h / dist.get_world_size()).to(stage.dtype))
+            self.work = None
+        else:
+            self.work = dist.all_reduce(stage, op=dist.ReduceOp.AVG, async_op=True)
+
+    def wait(self):
+        if self.work is not None:
+            self.work.wait()
+        self.t.copy_(self.stage)
+        return True
+
+
+def wire_bytes_per_rank(eng, wire="fp32"):
+    """bytes every rank puts on the wire per step for the gradient exchange (ring all-reduce: 2 (W - 1) / W of the buffer; this returns
+    the buffer bytes) and for the exchange step of the contrastive head, by bucket -- DESIGN.md section 7"""
+    bk = grad_buckets(eng)
+    out = {}
+    for n, (a, b) in bk.items():
+        out[n] = (b - a) * (2 if (wire == "bf16" and n in ("xformer_lo", "xformer_hi")) else 4)
+    return out
+
+
 def grad_buckets(eng):
     """name -> (start, end) element ranges of the flat gradient buffer, by the backward stage that completes them.  The buckets tile
     the buffer; the engine lays it out as transformer body | point encoder | lm_head | heads (csrc/engine.cpp build_layout), so the
@@ -207,14 +240,27 @@ def distributed_train_step(eng, batch, use_point, lr, do_clip=True, optimizer=Tr
             err_work = dist.all_reduce(err_bits, op=dist.ReduceOp.MAX, async_op=True)
     bk = grad_buckets(eng)
     works = []
+    wire = opt_kw.pop("wire", None) or os.environ.get("COATI_DP_WIRE", "fp32")
 
     def launch(*names):
-        """ONE collective over the named buckets (adjacent in the flat buffer)"""
+        """ONE collective over the named buckets (adjacent in the flat buffer).  wire = "bf16" (COATI_DP_WIRE=bf16): the transformer
+        body -- 70 of the 81 MB, the one collective that is not hidden underneath a backward stage -- travels as bf16"""
         if reduce_grads:
-            a, b = min(bk[n][0] for n in names), max(bk[n][1] for n in names)
-            assert sum(bk[n][1] - bk[n][0] for n in names) == b - a, names
-            if b > a:
-                works.append(all_reduce_avg_async(eng.grads[a:b]))
+            groups = [names]
+            if wire == "bf16" and any(n.startswith("xformer_") for n in names):
+                groups = [tuple(n for n in names if n.startswith("xformer_")), tuple(n for n in names if not n.startswith("xformer_"))]
+            for grp in groups:
+                if not grp:
+                    continue
+                a, b = min(bk[n][0] for n in grp), max(bk[n][1] for n in grp)
+                assert sum(bk[n][1] - bk[n][0] for n in grp) == b - a, grp
+                if b > a and wire == "bf16" and grp[0].startswith("xformer_"):
+                    st = getattr(eng, "_wire16", None)
+                    if st is None or st.numel() < b - a:
+                        st = eng._wire16 = torch.empty(b - a, device=eng.grads.device, dtype=torch.bfloat16)
+                    works.append(_Bf16Wire(eng.grads[a:b], st[:b - a]))
+                elif b > a:
+                    works.append(all_reduce_avg_async(eng.grads[a:b]))
 
     point_trained = bk["gnn"][0] < bk["lm_head"][0]          # (use_point_encoder = False: the "gnn" range is the untrained rest)
     eng.backward(dS, dC, stage=1)

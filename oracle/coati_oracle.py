@@ -22,6 +22,10 @@ Two arithmetic modes:
     where the HIP path stores bf16 (GEMM operands / saved activations / activation
     grads), so kernel tests can use a tight tolerance that separates rounding from
     bugs.  bf16*bf16 products are exact in fp32, so only accumulation order differs.
+  * `with sim_fp8():` (on top of sim_bf16) -- the engine's fp8 mode (BASELINE.json configs[4]; NO reference code exists
+    for it, README.md:28: parity unpinned): the four Linear layers of every transformer block take both operands of their
+    forward and input-gradient products as OCP MXFP8 -- e4m3 elements, one E8M0 scale per 32 consecutive k, shared
+    exponent floor(log2 amax) - 8, round-to-nearest-even with saturation -- and keep bf16 operands for the weight gradient.
 """
 from __future__ import annotations
 
@@ -72,6 +76,60 @@ class _RoundGrad(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         return g.bfloat16().float()
+
+
+_SIM8 = {"on": False}
+
+
+@contextlib.contextmanager
+def sim_fp8(enabled: bool = True):
+    """MXFP8 operand simulation of the transformer blocks' four Linear layers (see the module docstring); implies sim_bf16."""
+    old8, old = _SIM8["on"], _SIM["on"]
+    _SIM8["on"] = enabled
+    _SIM["on"] = old or enabled
+    try:
+        yield
+    finally:
+        _SIM8["on"], _SIM["on"] = old8, old
+
+
+def mx8(x: Tensor) -> Tensor:
+    """x -> MXFP8 -> fp32 along the LAST dim (OCP Microscaling v1.0: blocks of 32, shared exponent floor(log2 max|x|) - 8 (emax of
+    e4m3), elements e4m3 round-to-nearest-even, saturating at +-448).  The last dim must be a multiple of 32."""
+    shp = x.shape
+    xb = x.float().reshape(-1, shp[-1] // 32, 32)
+    am = xb.abs().amax(-1)
+    e = torch.floor(torch.log2(torch.clamp(am, min=1e-45)))
+    e = torch.where(am > 0, e, torch.full_like(e, -127.0))
+    se = torch.clamp(e - 8, -127, 127)
+    q = (xb * torch.exp2(-se).unsqueeze(-1)).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).float()
+    return (q * torch.exp2(se).unsqueeze(-1)).reshape(shp)
+
+
+class _LinearMX8(torch.autograd.Function):
+    """y = mx8(x) mx8(w)^T; dx = mx8(dy) mx8(w^T)^T (both quantised along the contraction, i.e. the layer's output features);
+    dw = bf16(dy)^T bf16(x) -- the engine's fp8 mode keeps bf16 operands for the weight gradients."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        ctx.save_for_backward(x, w)
+        return mx8(x.bfloat16().float()) @ mx8(w.bfloat16().float()).t()
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dyb = dy.bfloat16().float()
+        dx = mx8(dyb) @ mx8(w.bfloat16().float().t().contiguous()).t()
+        dw = dyb.reshape(-1, dyb.shape[-1]).t() @ x.bfloat16().float().reshape(-1, x.shape[-1])
+        return dx, dw
+
+
+def linear8(x: Tensor, w: Tensor, b: Optional[Tensor] = None) -> Tensor:
+    """a transformer-block Linear: MXFP8 operands under sim_fp8(), else `linear`"""
+    if not _SIM8["on"]:
+        return linear(x, w, b)
+    y = _LinearMX8.apply(x, w)
+    return y if b is None else y + b
 
 
 def r(x: Tensor) -> Tensor:
@@ -225,7 +283,7 @@ def attention(x: Tensor, P: Params, pre: str, n_head: int, cos: Tensor, sin: Ten
     """RotarySelfAttention.forward, basic_transformer.py:126-154.  x is ln_1(x)."""
     B, T, C = x.shape
     hs = C // n_head
-    qkv = rb(linear(x, P[pre + "c_attn.weight"], P.get(pre + "c_attn.bias")))
+    qkv = rb(linear8(x, P[pre + "c_attn.weight"], P.get(pre + "c_attn.bias")))
     q, k, v = qkv.split(C, dim=2)
     q = q.view(B, T, n_head, hs).transpose(1, 2)
     k = k.view(B, T, n_head, hs).transpose(1, 2)
@@ -238,7 +296,7 @@ def attention(x: Tensor, P: Params, pre: str, n_head: int, cos: Tensor, sin: Ten
     att = F.softmax(att, dim=-1)
     y = r(att) @ v
     y = rb(y.transpose(1, 2).contiguous().view(B, T, C))
-    return linear(y, P[pre + "c_proj.weight"], P.get(pre + "c_proj.bias"))
+    return linear8(y, P[pre + "c_proj.weight"], P.get(pre + "c_proj.bias"))
 
 
 def block(x: Tensor, P: Params, pre: str, n_head: int, cos: Tensor, sin: Tensor) -> Tensor:
@@ -247,9 +305,9 @@ def block(x: Tensor, P: Params, pre: str, n_head: int, cos: Tensor, sin: Tensor)
     a1 = rb(F.layer_norm(x, (C,), P[pre + "ln_1.weight"], P[pre + "ln_1.bias"], 1e-5))
     x = x + attention(a1, P, pre + "attn.", n_head, cos, sin)
     a2 = rb(F.layer_norm(x, (C,), P[pre + "ln_2.weight"], P[pre + "ln_2.bias"], 1e-5))
-    h = linear(a2, P[pre + "mlpf.0.weight"], P.get(pre + "mlpf.0.bias"))
+    h = linear8(a2, P[pre + "mlpf.0.weight"], P.get(pre + "mlpf.0.bias"))
     g = rb(new_gelu(h))
-    x = x + linear(g, P[pre + "mlpf.2.weight"], P.get(pre + "mlpf.2.bias"))
+    x = x + linear8(g, P[pre + "mlpf.2.weight"], P.get(pre + "mlpf.2.bias"))
     return x
 
 

@@ -76,6 +76,10 @@ def test_gemm_mx8_vs_dequantised_fp32(ops, M, N, K):
     assert e < 8e-2
 
 
+# (relative loss tolerance, worst relative gradient deviation) against oracle.sim_fp8: <= 2 x the measured values
+FP8_SIM_TOL = {"d128": (5e-4, 0.144), "d512": (5e-4, 0.08)}      # measured: losses 2e-5 .. 1.8e-4, gradients 7.2e-2 / 3.9e-2 (values on an e4m3 boundary flip by one 6 % step)
+
+
 @pytest.mark.parametrize("name,kw,shape", [
     ("d128", dict(n_layer_e3gnn=1, n_layer_xformer=2, n_hidden_xformer=128, n_hidden_e3nn=128, n_embd_common=128, n_head=8, n_seq=64, n_tok=300), (48, 40, 10)),
     ("d512", dict(n_layer_e3gnn=1, n_layer_xformer=1, n_hidden_xformer=512, n_hidden_e3nn=512, n_embd_common=512, n_head=16, n_seq=250, n_tok=4266), (128, 80, 16)),
@@ -117,6 +121,24 @@ def test_engine_fp8_step_vs_bf16_path_and_oracle(name, kw, shape):
     worst8.sort(reverse=True); worst16.sort(reverse=True)
     log(f"fp8 [{name}] worst gradient deviations from the fp32 oracle: fp8 {worst8[:3]}  bf16 {worst16[:2]}")
     assert worst8[0][0] <= 0.25, worst8[:5]
+    # ... and against the oracle evaluated WITH the same quantisation (oracle.sim_fp8: e4m3 elements + one E8M0 scale per 32 k on both
+    # operands of the four Linear layers' forward and input-gradient products, bf16 elsewhere): what is left is accumulation order
+    # and the rounding of values that sit on a quantisation boundary -- a bound that separates rounding from bugs, as sim_bf16 does
+    # for the bf16 path
+    Ps = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    with O.sim_fp8():
+        loss_s, ar_s, cl_s, _ = O.step_loss(Ps, ocfg, {k: v for k, v in batch.items() if k != "rows"}, up)
+    loss_s.backward()
+    assert abs(L8["ar_loss"] - float(ar_s)) <= FP8_SIM_TOL[name][0] * abs(float(ar_s)) and abs(L8["clip_loss"] - float(cl_s)) <= FP8_SIM_TOL[name][0] * abs(float(cl_s)), (L8, float(ar_s), float(cl_s))
+    worst8s = []
+    for k in sorted(g8):
+        ref = Ps[k].grad if Ps[k].grad is not None else torch.zeros_like(P[k])
+        sc = float(ref.abs().max())
+        if sc > 0:
+            worst8s.append((float((g8[k] - ref).abs().max()) / sc, k))
+    worst8s.sort(reverse=True)
+    log(f"fp8 [{name}] vs the fp8-simulating oracle: losses {L8['ar_loss']:.5f} / {L8['clip_loss']:.5f} vs {float(ar_s):.5f} / {float(cl_s):.5f}; worst gradient deviations {worst8s[:3]}")
+    assert worst8s[0][0] <= FP8_SIM_TOL[name][1], worst8s[:5]
     # cosine of every gradient tensor with the oracle's: the direction survives e4m3
     for k in g8:
         ref = Pg[k].grad
