@@ -7,16 +7,28 @@
 //   bad_rows         augmented_tokens.sum(-1) < 1 (clip_e2e.py:813)
 #include "kernels.h"
 
+// mode 0: the gather (with the injection when given).  norm_embed models (the embedding is followed by a LayerNorm and the injection
+// overwrites its OUTPUT, basic_transformer.py:72-76, smiles_xformer.py:442-448) run the gather without injection, the LayerNorm, and
+// then mode 1: ONLY the [UNK] rows are written (the injected vector); mode 2: ONLY the [UNK] rows are written, with zeros (the
+// backward clears the gradient rows the injection replaced before the LayerNorm backward sums over the rows)
 __global__ __launch_bounds__(256) void embed_fwd_kernel(const long long* __restrict__ idx, const float* __restrict__ table,
                                                         const float* __restrict__ injection, int unk, float* __restrict__ x,
-                                                        int M, int T, int C, int V, const int* __restrict__ row_src) {
+                                                        int M, int T, int C, int V, const int* __restrict__ row_src, int mode) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int m = blockIdx.x * 4 + wave;
   if (m >= M) return;
   const int ms = row_src ? row_src[m] : m;   // packed rows: output row m is slot ms = b * T + t of the padded [B, T] token matrix
   long long tok = idx[ms];
   const float* src;
-  if (injection != nullptr && tok == unk) {
+  if (mode != 0) {
+    if (tok != unk) return;
+    float* dstz = x + (long long)m * C;
+    if (mode == 2) {
+      for (int c = lane * 4; c < C; c += 256) *reinterpret_cast<float4*>(dstz + c) = make_float4(0.f, 0.f, 0.f, 0.f);
+      return;
+    }
+    src = injection + (long long)(ms / T) * C;
+  } else if (injection != nullptr && tok == unk) {
     src = injection + (long long)(ms / T) * C;
   } else {
     if (tok < 0) tok = 0;
@@ -28,11 +40,11 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const long long* __restr
 }
 
 int launch_embed_fwd(const long long* idx, const float* table, const float* injection, int unk_token, float* x,
-                     int B, int T, int C, int V, hipStream_t s, const int* row_src, int rows) {
-  COATI_CHECK_ARG(idx && table && x, "embed_fwd: null operand");
+                     int B, int T, int C, int V, hipStream_t s, const int* row_src, int rows, int mode) {
+  COATI_CHECK_ARG(idx && x && (mode != 0 || table) && (mode != 1 || injection) && mode >= 0 && mode <= 2, "embed_fwd: null operand / bad mode");
   COATI_CHECK_SHAPE(B > 0 && T > 0 && C % 4 == 0 && V > 0, "embed_fwd: unsupported shape");
   const int M = row_src ? rows : B * T;
-  hipLaunchKernelGGL(embed_fwd_kernel, dim3(cdiv(M, 4)), dim3(256), 0, s, idx, table, injection, unk_token, x, M, T, C, V, row_src);
+  hipLaunchKernelGGL(embed_fwd_kernel, dim3(cdiv(M, 4)), dim3(256), 0, s, idx, table, injection, unk_token, x, M, T, C, V, row_src, mode);
   COATI_LAUNCH_CHECK("embed_fwd");
   return COATI_OK;
 }
@@ -44,7 +56,7 @@ int launch_embed_fwd(const long long* idx, const float* table, const float* inje
 #define EMB_RUN 32
 __global__ __launch_bounds__(256) void embed_bwd_kernel(const long long* __restrict__ idx, const float* __restrict__ dx,
                                                         float* __restrict__ dtable, float* __restrict__ dinj, int unk,
-                                                        int B, int T, int C, int V, const int* __restrict__ off) {
+                                                        int B, int T, int C, int V, const int* __restrict__ off, int inj_only) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int t = blockIdx.x;
   const int b0 = (blockIdx.y * 4 + wave) * EMB_RUN;
@@ -74,6 +86,7 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const long long* __restr
         m = o + t;
       }
       float* dst;
+      if (inj_only && tok != unk) continue;      // (norm_embed: the table's share goes through the LayerNorm backward first)
       if (dinj != nullptr && tok == unk) {
         dst = dinj + (long long)b * C;
       } else {
@@ -102,10 +115,10 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const long long* __restr
 }
 
 int launch_embed_bwd(const long long* idx, const float* dx, float* dtable, float* dinjection, int unk_token,
-                     int B, int T, int C, int V, hipStream_t s, const int* off) {
-  COATI_CHECK_ARG(idx && dx && dtable, "embed_bwd: null operand");
+                     int B, int T, int C, int V, hipStream_t s, const int* off, int inj_only) {
+  COATI_CHECK_ARG(idx && dx && (dtable || inj_only) && (!inj_only || dinjection), "embed_bwd: null operand");
   COATI_CHECK_SHAPE(B > 0 && T > 0 && C % 4 == 0 && V > 0, "embed_bwd: unsupported shape");
-  hipLaunchKernelGGL(embed_bwd_kernel, dim3(T, cdiv(B, 4 * EMB_RUN)), dim3(256), 0, s, idx, dx, dtable, dinjection, unk_token, B, T, C, V, off);
+  hipLaunchKernelGGL(embed_bwd_kernel, dim3(T, cdiv(B, 4 * EMB_RUN)), dim3(256), 0, s, idx, dx, dtable, dinjection, unk_token, B, T, C, V, off, inj_only);
   COATI_LAUNCH_CHECK("embed_bwd");
   return COATI_OK;
 }

@@ -77,6 +77,7 @@ struct XPass {  // saved activations of one transformer pass
   std::vector<bf16_t*> a1, qkv, y, a2, g;
   std::vector<unsigned char*> hpre;   // NewGELU'(pre-activation) as 8-bit fixed point (common.h packq8)
   float *meanf, *rstdf, *xf32;
+  float *x_emb = nullptr, *mean0 = nullptr, *rstd0 = nullptr;   // norm_embed: the raw embedding rows and their LayerNorm statistics
   bf16_t* af;
   // Encoder pass of a training step: only the [STOP] row of every sequence leaves the transformer (smiles_xformer.py:50-68,
   // clip_e2e.py:448-452), so everything behind the LAST layer's attention + c_proj -- ln_2, the MLP, the residual add and ln_f --
@@ -109,6 +110,7 @@ struct coati_engine {
   int Vpad = 0;
   // parameter offsets
   int64_t tok_emb = 0, lnfw = 0, lnfb = 0, lmhead = 0, lmheadT = 0;
+  int64_t emb_lnw = -1, emb_lnb = -1;   // norm_embed: the LayerNorm behind the token embedding (xformer.emb.tok_emb.1.*)
   std::vector<XLayerP> xl;
   std::vector<GLayerP> gl;
   int64_t gembw = 0, gembb = 0, gd0w = 0, gd0b = 0, gd3w = 0, gd3b = 0, gd0T = 0, gd3T = 0;
@@ -256,7 +258,13 @@ void build_layout(coati_engine* e) {
   const int C = c.n_hidden_xformer, H = c.n_hidden_e3nn, E = c.n_embd_common, V = c.n_tok;
   e->Vpad = (V + 63) & ~63;
   // --- transformer (smiles_xformer.py:71-100, basic_transformer.py:103-169) ---
-  e->tok_emb = add_entry(e, "xformer.emb.tok_emb.weight", V, C);
+  if (c.norm_embed) {   // tok_emb = Sequential(Embedding, LayerNorm) (basic_transformer.py:72-76)
+    e->tok_emb = add_entry(e, "xformer.emb.tok_emb.0.weight", V, C);
+    e->emb_lnw = add_entry(e, "xformer.emb.tok_emb.1.weight", C, 0);
+    e->emb_lnb = add_entry(e, "xformer.emb.tok_emb.1.bias", C, 0);
+  } else {
+    e->tok_emb = add_entry(e, "xformer.emb.tok_emb.weight", V, C);
+  }
   e->xl.resize(c.n_layer_xformer);
   for (int l = 0; l < c.n_layer_xformer; ++l) {
     const std::string p = "xformer.transformer.h." + std::to_string(l) + ".";
@@ -264,15 +272,15 @@ void build_layout(coati_engine* e) {
     x.ln1w = add_entry(e, p + "ln_1.weight", C, 0);
     x.ln1b = add_entry(e, p + "ln_1.bias", C, 0);
     x.attnw = add_entry(e, p + "attn.c_attn.weight", 3 * C, C);
-    x.attnb = add_entry(e, p + "attn.c_attn.bias", 3 * C, 0);
+    x.attnb = c.biases ? add_entry(e, p + "attn.c_attn.bias", 3 * C, 0) : -1;
     x.projw = add_entry(e, p + "attn.c_proj.weight", C, C);
-    x.projb = add_entry(e, p + "attn.c_proj.bias", C, 0);
+    x.projb = c.biases ? add_entry(e, p + "attn.c_proj.bias", C, 0) : -1;
     x.ln2w = add_entry(e, p + "ln_2.weight", C, 0);
     x.ln2b = add_entry(e, p + "ln_2.bias", C, 0);
     x.fc1w = add_entry(e, p + "mlpf.0.weight", 4 * C, C);
-    x.fc1b = add_entry(e, p + "mlpf.0.bias", 4 * C, 0);
+    x.fc1b = c.biases ? add_entry(e, p + "mlpf.0.bias", 4 * C, 0) : -1;
     x.fc2w = add_entry(e, p + "mlpf.2.weight", C, 4 * C);
-    x.fc2b = add_entry(e, p + "mlpf.2.bias", C, 0);
+    x.fc2b = c.biases ? add_entry(e, p + "mlpf.2.bias", C, 0) : -1;
   }
   e->lnfw = add_entry(e, "xformer.transformer.ln_f.weight", C, 0);
   e->lnfb = add_entry(e, "xformer.transformer.ln_f.bias", C, 0);
@@ -339,6 +347,10 @@ void build_layout(coati_engine* e) {
   // (p.grad is None), so torch's clip_grad_norm_ / AdamW skip them entirely -- no weight decay either.  They are kept for
   // state_dict parity at the END of the flat buffers, behind n_trainable: the optimizer kernels stop in front of them.
   e->n_trainable = e->n_params;
+  if (c.norm_embed) {   // the reference registers a second LayerNorm it never calls (smiles_xformer.py:81-82, 364): state_dict parity only
+    add_entry(e, "xformer.norm_embed.weight", C, 0);
+    add_entry(e, "xformer.norm_embed.bias", C, 0);
+  }
   if (!c.use_point_encoder) { add_point(); add_p2c(); }
   for (int l = 0; l < c.n_layer_e3gnn; ++l) {
     const std::string p = "point_encoder.gcl_" + std::to_string(l) + ".";
@@ -346,6 +358,18 @@ void build_layout(coati_engine* e) {
     g.c0w = add_entry(e, p + "coord_mlp.0.weight", H, H);
     g.c0b = add_entry(e, p + "coord_mlp.0.bias", H, 0);
     g.c2w = add_entry(e, p + "coord_mlp.2.weight", 1, H);
+  }
+
+  // biases = 0 (basic_transformer.py:113-115, 166-168 with config.biases = False): the four Linear layers of a block have no bias
+  // PARAMETER -- nothing in the table, nothing in the state_dict -- but every kernel of the path takes a bias pointer: it points at
+  // zeros behind n_trainable (never updated, never decayed, outside the clip-norm; the gradient sums written there are ignored)
+  if (!c.biases) {
+    auto hidden = [&](int n) {
+      const int64_t off = e->n_params;
+      e->n_params = (off + n + 63) & ~(int64_t)63;
+      return off;
+    };
+    for (auto& x : e->xl) { x.attnb = hidden(3 * C); x.projb = hidden(C); x.fc1b = hidden(4 * C); x.fc2b = hidden(C); }
   }
 
   // --- shadow extras ---
@@ -502,6 +526,7 @@ void carve_pass(coati_engine* e, Arena& ar, XPass& p, int B_, int T_, int B, int
   }
   p.meanf = ar.take<float>(M); p.rstdf = ar.take<float>(M);
   p.xf32 = ar.take<float>(M * C);
+  if (e->cfg.norm_embed) { p.x_emb = ar.take<float>(M * C); p.mean0 = ar.take<float>(M); p.rstd0 = ar.take<float>(M); }
   p.af = ar.take<bf16_t>(M * C);
   p.t_xmid = ar.take<float>((size_t)B * C); p.t_xL = ar.take<float>((size_t)B * C); p.t_xf = ar.take<float>((size_t)B * C);
   p.t_mean2 = ar.take<float>(B); p.t_rstd2 = ar.take<float>(B); p.t_meanf = ar.take<float>(B); p.t_rstdf = ar.take<float>(B);
@@ -640,7 +665,15 @@ int xformer_fwd(coati_engine* e, XPass& p, const float* injection, hipStream_t s
   const int C = c.n_hidden_xformer, L = c.n_layer_xformer, M = p.M;
   {
     ProfScope ps(e, SITE_EMBED, 0, s);
-    COATI_TRY(launch_embed_fwd(p.idx, e->P + e->tok_emb, injection, c.unk_token, p.x[0], p.B, p.T, C, c.n_tok, s, p.packed ? p.row_src : nullptr, M));
+    if (c.norm_embed) {
+      // x = LayerNorm(tok_emb[idx]); x[idx == [UNK]] = injection (smiles_xformer.py:442-448: the injection replaces the NORMALISED rows)
+      COATI_TRY(launch_embed_fwd(p.idx, e->P + e->tok_emb, nullptr, c.unk_token, p.x_emb, p.B, p.T, C, c.n_tok, s, p.packed ? p.row_src : nullptr, M));
+      COATI_TRY(launch_layernorm_fwd(p.x_emb, C, e->P + e->emb_lnw, e->P + e->emb_lnb, nullptr, 0, p.x[0], C, p.mean0, p.rstd0, M, C, s));
+      if (injection != nullptr)
+        COATI_TRY(launch_embed_fwd(p.idx, nullptr, injection, c.unk_token, p.x[0], p.B, p.T, C, c.n_tok, s, p.packed ? p.row_src : nullptr, M, 1));
+    } else {
+      COATI_TRY(launch_embed_fwd(p.idx, e->P + e->tok_emb, injection, c.unk_token, p.x[0], p.B, p.T, C, c.n_tok, s, p.packed ? p.row_src : nullptr, M));
+    }
   }
   // The attention half of every block as ONE launch (attn_block.hip): ln_1 -> c_attn -> RoPE -> causal attention -> c_proj -> + x
   // with qkv and y written once and never read back (d = 256, 16 heads, sequences of <= 128 rows); its work list -- groups of
@@ -991,6 +1024,17 @@ int xformer_bwd(coati_engine* e, XPass& p, const void* dyf, int dyf_f32, float* 
   }
   if (l_lo > 0) return COATI_OK;
   ProfScope ps(e, SITE_EMBED, 0, s);
+  if (c.norm_embed) {
+    // the injected rows' gradient goes to the injection and is CLEARED (the LayerNorm's output was overwritten there: nothing flows into
+    // it), then the embedding LayerNorm's backward over all rows (its output lands in x[0], dead by now), then the table scatter
+    if (dinjection != nullptr) {
+      COATI_TRY(launch_embed_bwd(p.idx, DX, nullptr, dinjection, c.unk_token, p.B, p.T, C, c.n_tok, s, p.packed ? p.off : nullptr, 1));
+      COATI_TRY(launch_embed_fwd(p.idx, nullptr, nullptr, c.unk_token, DX, p.B, p.T, C, c.n_tok, s, p.packed ? p.row_src : nullptr, M, 2));
+    }
+    COATI_TRY(launch_layernorm_bwd(DX, 1, C, p.x_emb, C, 0, p.mean0, p.rstd0, e->P + e->emb_lnw, nullptr, p.x[0], nullptr, e->G + e->emb_lnw, e->G + e->emb_lnb,
+                                   e->ln_partial, M, C, s));
+    return launch_embed_bwd(p.idx, p.x[0], e->G + e->tok_emb, nullptr, c.unk_token, p.B, p.T, C, c.n_tok, s, p.packed ? p.off : nullptr);
+  }
   return launch_embed_bwd(p.idx, DX, e->G + e->tok_emb, dinjection, c.unk_token, p.B, p.T, C, c.n_tok, s, p.packed ? p.off : nullptr);
 }
 
@@ -1844,7 +1888,13 @@ int decode_enqueue(coati_engine* e, const long long* tokens, const float* inject
   auto& d = e->dec;
   const coati_config& c = e->cfg;
   const int C = c.n_hidden_xformer, L = c.n_layer_xformer, B = d.B, hs = C / c.n_head;
-  COATI_TRY(launch_embed_fwd(tokens, e->P + e->tok_emb, injection, c.unk_token, d.x, B, 1, C, c.n_tok, s));
+  if (c.norm_embed) {
+    COATI_TRY(launch_embed_fwd(tokens, e->P + e->tok_emb, nullptr, c.unk_token, d.xmid, B, 1, C, c.n_tok, s));   // (xmid: free until the first block writes it)
+    COATI_TRY(launch_layernorm_fwd(d.xmid, C, e->P + e->emb_lnw, e->P + e->emb_lnb, nullptr, 0, d.x, C, d.mean, d.rstd, B, C, s));
+    if (injection != nullptr) COATI_TRY(launch_embed_fwd(tokens, nullptr, injection, c.unk_token, d.x, B, 1, C, c.n_tok, s, nullptr, 0, 1));
+  } else {
+    COATI_TRY(launch_embed_fwd(tokens, e->P + e->tok_emb, injection, c.unk_token, d.x, B, 1, C, c.n_tok, s));
+  }
   float* x = d.x;
   float* xm = d.xmid;
   for (int l = 0; l < L; ++l) {

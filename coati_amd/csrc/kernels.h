@@ -254,10 +254,12 @@ int launch_ab_probe_swap(unsigned* out, hipStream_t s);
 // embedding / token kernels (embed.hip)
 // ------------------------------------------------------------------------------------------------
 // row_src / off: packed rows (launch_seq_pack below); null = the padded [B, T] layout
+// mode 1 / 2: only the [UNK] rows are written -- the injected vector / zeros (norm_embed models, see embed.hip)
 int launch_embed_fwd(const long long* idx, const float* table, const float* injection, int unk_token, float* x,
-                     int B, int T, int C, int V, hipStream_t s, const int* row_src = nullptr, int rows = 0);
+                     int B, int T, int C, int V, hipStream_t s, const int* row_src = nullptr, int rows = 0, int mode = 0);
+// inj_only: only the [UNK] rows' gradient is collected (into dinjection)
 int launch_embed_bwd(const long long* idx, const float* dx, float* dtable, float* dinjection, int unk_token,
-                     int B, int T, int C, int V, hipStream_t s, const int* off = nullptr);
+                     int B, int T, int C, int V, hipStream_t s, const int* off = nullptr, int inj_only = 0);
 // Packed rows: the transformer passes run on the concatenation of every row's real prefix (embed.hip).  off [B + 1],
 // row_src / row_t [rows_expect] ints, ypk [rows_expect] (optional: the packed targets); err |= 2 when the device-side total
 // differs from rows_expect (the count the caller computed on the host)

@@ -48,8 +48,10 @@ def reference_parameter_order(names):
             layer = int(p[1].split("_")[1])
             return (top, 2, layer, {"edge_mlp": 0, "node_mlp": 1, "coord_mlp": 2}[p[2]], int(p[3]), wb)
         if p[0] == "xformer":
-            if p[1] == "emb":
-                return (top, 0, 0, 0, 0, wb)
+            if p[1] == "norm_embed":      # norm_embed = True: registered first, never called (smiles_xformer.py:81-84)
+                return (top, -1, 0, 0, 0, wb)
+            if p[1] == "emb":             # tok_emb.weight, or tok_emb.0.weight / tok_emb.1.{weight, bias} (basic_transformer.py:72-76)
+                return (top, 0, 0, 0, int(p[3]) if p[3].isdigit() else 0, wb)
             if p[1] == "lm_head":
                 return (top, 3, 0, 0, 0, wb)
             if p[2] == "ln_f":
@@ -95,10 +97,9 @@ class e3gnn_smiles_clip_e2e(nn.Module):
         super().__init__()
         # norm_clips / token_mlp / use_point_encoder follow the reference in both settings (clip_e2e.py:405-437, 454-463;
         # the reference's own do_args() defaults are norm_clips=False, token_mlp=False: train_coati.py:520-523).  The remaining
-        # flags select layers no released COATI checkpoint uses (bias-free transformer, torch.nn.Embedding atom table, residual
-        # E(3)-GNN coordinates, embedding LayerNorm, the pre-release head order)
-        unsupported = dict(biases=not biases, torch_emb=torch_emb, residual=residual, norm_embed=norm_embed,
-                           old_architecture=old_architecture)
+        # flags select layers no released COATI checkpoint uses (torch.nn.Embedding atom table, residual
+        # E(3)-GNN coordinates, the pre-release head order)
+        unsupported = dict(torch_emb=torch_emb, residual=residual, old_architecture=old_architecture)
         bad = [k for k, v in unsupported.items() if v]
         if bad:
             raise NotImplementedError(f"coati_amd: unsupported constructor flags: {bad}")
@@ -111,7 +112,7 @@ class e3gnn_smiles_clip_e2e(nn.Module):
         cfg = ModelConfig(n_layer_e3gnn=n_layer_e3gnn, n_layer_xformer=n_layer_xformer, n_hidden_xformer=n_hidden_xformer,
                           n_hidden_e3nn=n_hidden_e3nn, n_embd_common=n_embd_common, n_head=n_head, n_seq=n_seq, n_tok=n_tok,
                           msg_cutoff=5.0, norm_clips=bool(norm_clips), token_mlp=bool(token_mlp),
-                          use_point_encoder=bool(use_point_encoder))
+                          use_point_encoder=bool(use_point_encoder), biases=bool(biases), norm_embed=bool(norm_embed))
         eng = Engine(cfg, self.device, train=True)
         object.__setattr__(self, "engine", eng)
         grads = eng.named_views("grads")
@@ -145,7 +146,7 @@ class e3gnn_smiles_clip_e2e(nn.Module):
         g.manual_seed(torch.initial_seed() if seed is None else seed)
         for name, p in self.named_parameters():
             shape = tuple(p.shape)
-            if name.endswith("tok_emb.weight"):
+            if name.endswith("tok_emb.weight") or name.endswith("tok_emb.0.weight"):
                 v = torch.randn(shape, generator=g)
             elif name.endswith("coord_mlp.2.weight"):
                 bound = 1e-3 * math.sqrt(6.0 / (shape[0] + shape[1]))

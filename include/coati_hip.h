@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define COATI_ABI_VERSION 3
+#define COATI_ABI_VERSION 4
 
 const char* coati_last_error(void);
 int coati_abi_version(void);
@@ -282,6 +282,11 @@ typedef struct coati_config {
   int32_t token_mlp;         /* 1: point_clip_to_special_tokens = SiLU -> Linear; 0: Identity (no parameters) */
   int32_t use_point_encoder; /* 0: encode_points returns zeros (clip_e2e.py:454-463); the point encoder's and point_to_clip's
                                 parameters exist in the state_dict but never receive a gradient (skipped by clip-norm / AdamW) */
+  int32_t biases;            /* ABI v4.  0: the transformer blocks' four Linear layers have no bias (basic_transformer.py:113-115, 166-168 with
+                                config.biases = False): the parameter table holds no such entries; LayerNorm biases and lm_head are unaffected */
+  int32_t norm_embed;        /* ABI v4.  1: a LayerNorm follows the token embedding (basic_transformer.py:72-76: tok_emb = Sequential(Embedding,
+                                LayerNorm), entries xformer.emb.tok_emb.0.weight / .1.weight / .1.bias); the injection overwrites its output.  The
+                                reference also registers an unused xformer.norm_embed LayerNorm (smiles_xformer.py:81-82): in the table, never trained */
 } coati_config;
 
 typedef struct coati_engine coati_engine;

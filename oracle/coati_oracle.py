@@ -176,6 +176,8 @@ class OracleConfig:
     norm_clips: bool = True
     token_mlp: bool = True
     use_point_encoder: bool = True
+    norm_embed: bool = False  # True: tok_emb = Sequential(Embedding, LayerNorm) (basic_transformer.py:72-76) + an unused xformer.norm_embed LayerNorm
+    biases: bool = True  # False: c_attn / c_proj / mlpf.0 / mlpf.2 without bias (basic_transformer.py:113-115, 166-168)
 
 
 # --------------------------------------------------------------------------------------
@@ -325,7 +327,10 @@ def xformer(
     assert T <= cfg.n_seq
     C = cfg.n_hidden_xformer
     cos, sin = rope_tables(cfg.n_seq, C // cfg.n_head)
-    x = P[pre + "emb.tok_emb.weight"][idx]
+    if cfg.norm_embed:   # basic_transformer.py:72-81: the embedding module is Embedding -> LayerNorm; the injection below replaces its OUTPUT rows
+        x = F.layer_norm(P[pre + "emb.tok_emb.0.weight"][idx], (C,), P[pre + "emb.tok_emb.1.weight"], P[pre + "emb.tok_emb.1.bias"], 1e-5)
+    else:
+        x = P[pre + "emb.tok_emb.weight"][idx]
     if injection is not None:
         hole = idx == cfg.unk_token  # smiles_xformer.py:444-448
         x = torch.where(hole.unsqueeze(-1), injection.unsqueeze(1).expand(B, T, C), x)
@@ -591,21 +596,32 @@ def param_shapes(cfg: OracleConfig) -> Dict[str, Tuple[int, ...]]:
         s[p + "coord_mlp.0.weight"] = (H, H)
         s[p + "coord_mlp.0.bias"] = (H,)
         s[p + "coord_mlp.2.weight"] = (1, H)
-    s["xformer.emb.tok_emb.weight"] = (V, C)
+    if cfg.norm_embed:
+        s["xformer.norm_embed.weight"] = (C,)      # registered, never called (smiles_xformer.py:81-84, 364)
+        s["xformer.norm_embed.bias"] = (C,)
+        s["xformer.emb.tok_emb.0.weight"] = (V, C)
+        s["xformer.emb.tok_emb.1.weight"] = (C,)
+        s["xformer.emb.tok_emb.1.bias"] = (C,)
+    else:
+        s["xformer.emb.tok_emb.weight"] = (V, C)
     for l in range(cfg.n_layer_xformer):
         p = f"xformer.transformer.h.{l}."
         s[p + "ln_1.weight"] = (C,)
         s[p + "ln_1.bias"] = (C,)
         s[p + "attn.c_attn.weight"] = (3 * C, C)
-        s[p + "attn.c_attn.bias"] = (3 * C,)
+        if cfg.biases:
+            s[p + "attn.c_attn.bias"] = (3 * C,)
         s[p + "attn.c_proj.weight"] = (C, C)
-        s[p + "attn.c_proj.bias"] = (C,)
+        if cfg.biases:
+            s[p + "attn.c_proj.bias"] = (C,)
         s[p + "ln_2.weight"] = (C,)
         s[p + "ln_2.bias"] = (C,)
         s[p + "mlpf.0.weight"] = (4 * C, C)
-        s[p + "mlpf.0.bias"] = (4 * C,)
+        if cfg.biases:
+            s[p + "mlpf.0.bias"] = (4 * C,)
         s[p + "mlpf.2.weight"] = (C, 4 * C)
-        s[p + "mlpf.2.bias"] = (C,)
+        if cfg.biases:
+            s[p + "mlpf.2.bias"] = (C,)
     s["xformer.transformer.ln_f.weight"] = (C,)
     s["xformer.transformer.ln_f.bias"] = (C,)
     s["xformer.lm_head.weight"] = (V, C)
@@ -637,12 +653,12 @@ def init_params(cfg: OracleConfig, seed: int = 0, scale: float = 1.0) -> Params:
     g = torch.Generator().manual_seed(seed)
     P: Params = {}
     for name, shp in param_shapes(cfg).items():
-        if name.endswith("tok_emb.weight"):
+        if name.endswith("tok_emb.weight") or name.endswith("tok_emb.0.weight"):
             P[name] = torch.randn(shp, generator=g) * scale
         elif len(shp) == 2:
             bound = 1.0 / math.sqrt(shp[1])
             P[name] = (torch.rand(shp, generator=g) * 2 - 1) * bound * scale
-        elif ".ln_" in name and name.endswith("weight") or name.endswith("clip.0.weight"):
+        elif (".ln_" in name or "norm_embed" in name or "tok_emb.1" in name) and name.endswith("weight") or name.endswith("clip.0.weight"):
             P[name] = 1.0 + 0.1 * torch.randn(shp, generator=g)
         else:
             P[name] = 0.05 * torch.randn(shp, generator=g)

@@ -8,6 +8,9 @@ Golden vectors for the constructor flags of e3gnn_smiles_clip_e2e the grande con
                   encoder and point_to_clip never receive a gradient
   case "mixed"  : norm_clips=True,  token_mlp=False, use_point_encoder=True
   case "mlp_nopoint": norm_clips=True, token_mlp=True, use_point_encoder=False
+  case "nobias" : the grande flags with biases=False -- the blocks' four Linear layers without bias (basic_transformer.py:113-115, 166-168)
+  case "normembed": the grande flags with norm_embed=True -- LayerNorm behind the token embedding (basic_transformer.py:72-76), the
+                  injection overwrites its output; + the registered-but-unused xformer.norm_embed module (smiles_xformer.py:81-84)
 
 Per case (small model of gen_golden.py: d = 64, 2 + 2 layers, V = 48; batch of 5 rows incl. a bad row): the weights, forward_dist
 with a mixed injection mask (h_e3gnn, h_smiles, logits, bad_rows), the training step (train_coati.py:216-277: ar / clip / total
@@ -34,6 +37,8 @@ CASES = {
     "nopoint": dict(norm_clips=False, token_mlp=False, use_point_encoder=False),
     "mixed": dict(norm_clips=True, token_mlp=False, use_point_encoder=True),
     "mlp_nopoint": dict(norm_clips=True, token_mlp=True, use_point_encoder=False),
+    "nobias": dict(norm_clips=True, token_mlp=True, use_point_encoder=True, biases=False),
+    "normembed": dict(norm_clips=True, token_mlp=True, use_point_encoder=True, norm_embed=True),
 }
 
 

@@ -105,7 +105,7 @@ def test_grad_buckets_cover_the_flat_buffer(flags):
     class Fake:
         pass
     l = _lib.lib()
-    cfg = _lib.CoatiConfig(2, 2, 64, 64, 64, 4, 24, 48, 5.0, 0, 1, 7, 0, *flags)
+    cfg = _lib.CoatiConfig(2, 2, 64, 64, 64, 4, 24, 48, 5.0, 0, 1, 7, 0, *flags, 1)
     h = ctypes.c_void_p()
     assert l.coati_engine_create(ctypes.byref(cfg), ctypes.byref(h)) == 0
     eng = Fake()

@@ -14,6 +14,8 @@ CASES = {
     "nopoint": dict(norm_clips=False, token_mlp=False, use_point_encoder=False),
     "mixed": dict(norm_clips=True, token_mlp=False, use_point_encoder=True),
     "mlp_nopoint": dict(norm_clips=True, token_mlp=True, use_point_encoder=False),
+    "nobias": dict(norm_clips=True, token_mlp=True, use_point_encoder=True, biases=False),
+    "normembed": dict(norm_clips=True, token_mlp=True, use_point_encoder=True, norm_embed=True),
 }
 SMALL = dict(n_layer_e3gnn=2, n_layer_xformer=2, n_hidden_xformer=64, n_hidden_e3nn=64, n_embd_common=64, n_head=4, n_seq=24, n_tok=48)
 
@@ -72,4 +74,6 @@ def test_oracle_flags_vs_reference(golden_dir, case):
             p1, _, _ = O.adamw_update(P[k], trainable[k] * coef, torch.zeros_like(P[k]), torch.zeros_like(P[k]), step=1, lr=5e-4)
         else:
             p1 = P[k]
-        close(p1.reshape(-1)[::13], d["after1." + k], 2e-5, "adamw " + k)
+        # (the first AdamW step moves every element by ~ lr = 5e-4 times g / (|g| + eps): an element whose gradient is ~ 1e-8 turns a 1e-9
+        #  difference of the two fp32 gradient sums into a few percent of lr -- 3.0e-5 measured on one element of the normembed case)
+        close(p1.reshape(-1)[::13], d["after1." + k], 4e-5, "adamw " + k)

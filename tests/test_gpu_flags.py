@@ -67,6 +67,12 @@ def test_engine_flags_vs_reference(golden_dir, case):
         # whose gradient is ~ 0 may flip under bf16 operand rounding; the kernel itself is pinned by test_adamw_and_clipnorm_*)
         p0 = P[k].reshape(-1)[::13]
         da, dr = (a - p0).double(), (ref - p0).double()
+        # (judged on the elements whose reference gradient is not small against the tensor's largest: the step's SIGN is all that the
+        #  first AdamW update keeps of a gradient, and an element at 1e-2 of the scale flips under bf16 operand rounding -- with the
+        #  5 sampled elements of a 64-wide LayerNorm weight two such flips were a cosine of 0.6)
+        gref = d["grad." + k].reshape(-1)[::13].double().abs()
+        keep = gref > 0.05 * float(d["grad." + k].abs().max())
+        da, dr = da[keep], dr[keep]
         if float(dr.norm()) > 0:
             cos = float((da * dr).sum() / (da.norm() * dr.norm() + 1e-30))
             assert cos >= 0.85, f"{case} adamw {k}: displacement cosine {cos:.3f}"

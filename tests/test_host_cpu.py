@@ -19,7 +19,7 @@ def test_cabi_exports_every_declared_symbol():
     hdr = open(os.path.join(ROOT, "include", "coati_hip.h")).read()
     declared = set(re.findall(r"\b(coati_[a-z0-9_]+)\s*\(", hdr))
     l = _lib.lib()
-    assert l.coati_abi_version() == _lib.ABI_VERSION == 3
+    assert l.coati_abi_version() == _lib.ABI_VERSION == 4
     for sym in sorted(declared):
         assert hasattr(l, sym), f"libcoati_hip.so does not export {sym}"
     assert declared == set(_lib.exported_symbols())
@@ -30,7 +30,7 @@ def test_bad_arguments_return_codes_not_exceptions():
     l = _lib.lib()
     rc = l.coati_gemm_nt(None, 0, 0, None, 0, 1, 1, 64, None, 0, 0, None, None, None, 0, 0, None)
     assert rc == -1 and b"null" in l.coati_last_error()
-    cfg = _lib.CoatiConfig(2, 2, 96, 64, 96, 4, 24, 48, 5.0, 0, 1, 7, 0, 1, 1, 1)   # head size 24: unsupported
+    cfg = _lib.CoatiConfig(2, 2, 96, 64, 96, 4, 24, 48, 5.0, 0, 1, 7, 0, 1, 1, 1, 1)   # head size 24: unsupported
     h = ctypes.c_void_p()
     assert l.coati_engine_create(ctypes.byref(cfg), ctypes.byref(h)) == -2
     assert b"head size" in l.coati_last_error()
@@ -41,9 +41,10 @@ def test_layout_is_the_reference_state_dict_contract(golden_dir):
     from oracle import coati_oracle as O
     l = _lib.lib()
     for kw in (dict(n_layer_e3gnn=2, n_layer_xformer=2, n_hidden_xformer=64, n_hidden_e3nn=64, n_embd_common=64, n_head=4, n_seq=24, n_tok=48),
+               dict(n_layer_e3gnn=2, n_layer_xformer=2, n_hidden_xformer=64, n_hidden_e3nn=64, n_embd_common=64, n_head=4, n_seq=24, n_tok=48, biases=False),
                dict(n_layer_e3gnn=5, n_layer_xformer=16, n_hidden_xformer=256, n_hidden_e3nn=256, n_embd_common=256, n_head=16, n_seq=250, n_tok=10322)):
         cfg = _lib.CoatiConfig(kw["n_layer_xformer"], kw["n_layer_e3gnn"], kw["n_hidden_xformer"], kw["n_hidden_e3nn"],
-                               kw["n_embd_common"], kw["n_head"], kw["n_seq"], kw["n_tok"], 5.0, 0, 1, 7, 0, 1, 1, 1)
+                               kw["n_embd_common"], kw["n_head"], kw["n_seq"], kw["n_tok"], 5.0, 0, 1, 7, 0, 1, 1, 1, 1 if kw.get("biases", True) else 0)
         h = ctypes.c_void_p()
         assert l.coati_engine_create(ctypes.byref(cfg), ctypes.byref(h)) == 0
         shapes = O.param_shapes(O.OracleConfig(**kw))
