@@ -617,6 +617,10 @@ __global__ __launch_bounds__(1024) void attn_groups_kernel(const int* __restrict
 // kernels: 22.35 vs 21.82 ms per step on one box.  The phase trace says where a group's ~ 85 000 cycles go: attention 32 % (VALU
 // bound: 16 exponentials + ~ 90 VALU per lane and (key block, query block) pair, 4 query blocks x 16 heads x ~ 2 pairs per group),
 // the c_attn products 21 %, stage waits + barriers 26 %, LayerNorm + slab 9 %, c_proj 5 %, copies + write-out 9 %.
+// On COLD caches (as in the step: tools/probes/ab_trace.py cold) a launch takes 116.8 us against 102.7 with the rows in the Infinity
+// Cache: every workgroup reads its group's 128 KiB at the same moment, a 32-MB burst in which no CU computes (the three-launch path
+// spreads the same reads over thousands of workgroups).  Prefetching the NEXT group's rows into L2 from the copy waves (one dword per
+// line by global_load_lds into a sink) was built and measured: 114.9 us -- only every second group has a predecessor to prefetch under.
 bool attn_block_fwd_supported(int B, int T, int C, int n_head) {
   static const bool on = getenv("COATI_ATTN_BLOCK") != nullptr && getenv("COATI_ATTN_BLOCK")[0] == '1';
   return on && C == 256 && n_head == 16 && T <= AB_R && B <= ABG_MAXB && B > 0;

@@ -38,6 +38,17 @@ def timeit(f, n=20):
     return s.elapsed_time(e) / n * 1e3
 us = timeit(f)
 ng = int(grp[0])
+if len(sys.argv) > 1 and sys.argv[1] == "cold":
+    # every launch on cold caches, as in the training step (87 GB of traffic between two launches of a layer): a 1.5-GB buffer is
+    # rewritten between the timed launches (L2 4 MB x 8, Infinity Cache 256 MB)
+    junk = torch.empty(1536 * 1024 * 1024 // 4, device=dev)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(10)]
+    for a, b in ev:
+        junk.add_(1.0)
+        a.record(); f(); b.record()
+    torch.cuda.synchronize()
+    us = sum(a.elapsed_time(b) for a, b in ev) / len(ev) * 1e3
+    print("(cold caches between launches)")
 print(f"attn_block_fwd: {M} rows, {ng} groups, {us:.1f} us/launch")
 buf = (ctypes.c_uint64 * (16 * 8 * 8))()
 if lib.coati_ab_trace_read(buf) == 0:
