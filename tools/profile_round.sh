@@ -1,24 +1,24 @@
 #!/bin/bash
-# Round artefacts, run on the GPU box from the repo root (gpurun):  bash tools/profile_round.sh r04
+# Round artefacts, run on the GPU box from the repo root (gpurun):  bash tools/profile_round.sh r05
 # Writes everything under gpurun_out/<tag>_*; copy what should be judged into profiles/.
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 python $R/bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
-python $R/bench.py --steps 10 --warmup 3 --all-sites --no-cpu-baseline > $OUT/${TAG}_bench_nocpu.json 2> $OUT/${TAG}_bench_sites.txt
-python $R/bench.py --steps 10 --warmup 3 --all-sites --no-cpu-baseline --padded > $OUT/${TAG}_bench_padded.json 2> $OUT/${TAG}_bench_sites_padded.txt
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof -o bench -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-other-layout > $OUT/${TAG}_bench_under_rocprof.json 2> /dev/null
+python $R/bench.py --steps 10 --warmup 3 --all-sites --no-cpu-baseline --no-extras > $OUT/${TAG}_bench_nocpu.json 2> $OUT/${TAG}_bench_sites.txt
+python $R/bench.py --steps 10 --warmup 3 --all-sites --no-cpu-baseline --no-extras --padded > $OUT/${TAG}_bench_padded.json 2> $OUT/${TAG}_bench_sites_padded.txt
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof -o bench -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-other-layout --no-extras > $OUT/${TAG}_bench_under_rocprof.json 2> /dev/null
 cp $(find $OUT/${TAG}_prof -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_bench_kernel_stats.csv
 # HBM traffic from PMC passes over THE BENCH COMMAND itself (counters only with --kernel-trace; one counter per pass): the nominated
 # kernels per launch (gemm_ring1_kernel<14> = the ring GEMM with the LayerNorm backward in its write-out: top row of the kernel table;
 # the grouped weight gradient) and the whole step (2 x FETCH_SIZE + WRITE_SIZE over every kernel / steps in the trace)
 export PMC_LAYOUT=packed
-export PMC_COMMAND="rocprofv3 --pmc <FETCH_SIZE|WRITE_SIZE> --kernel-trace -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-other-layout (round $TAG)"
+export PMC_COMMAND="rocprofv3 --pmc <FETCH_SIZE|WRITE_SIZE> --kernel-trace -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-other-layout --no-extras (round $TAG)"
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_$c -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-other-layout > /dev/null 2>&1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_$c -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-other-layout --no-extras > /dev/null 2>&1
 done
 python $R/tools/pmc_to_json.py "dgrad_lnbwd=gemm_ring1_kernel<14>" "xf_wgrad=wgrad256_table_kernel" -- $(find $OUT/${TAG}_pmc_FETCH_SIZE $OUT/${TAG}_pmc_WRITE_SIZE -name "*counter_collection.csv") > $OUT/${TAG}_pmc_summary.json
 cp $(find $OUT/${TAG}_pmc_FETCH_SIZE -name "*counter_collection.csv" | head -1) $OUT/${TAG}_pmc_bench_FETCH_SIZE.csv
