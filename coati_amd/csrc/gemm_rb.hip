@@ -372,7 +372,8 @@ bool gemm_rb256_ln_fusable(const GemmArgs& a, int epi) {
 }
 
 int gemm_ce_tile_width(const GemmArgs& a) {
-  return gemm_rb256_supported(a, 0, EPI_CE_PARTIAL) ? 64 : 128;
+  // (the same order of questions as launch_gemm_nt's dispatch)
+  return (gemm_t32_supported(a, 0, EPI_CE_PARTIAL) || gemm_rb16_supported(a, 0, EPI_CE_PARTIAL) || gemm_rb256_supported(a, 0, EPI_CE_PARTIAL)) ? 64 : 128;
 }
 
 // true when (a, epi) can run on the row-block kernel

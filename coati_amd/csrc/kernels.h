@@ -115,6 +115,9 @@ bool gemm_rb16_supported(const GemmArgs& a, int a_f32, int epi);
 bool gemm_rb16_resident_supported(const GemmArgs& a, int a_f32, int epi);
 int launch_gemm_rb16_resident(const GemmArgs& a, int epi, hipStream_t s);
 int launch_gemm_rb16(const GemmArgs& a, int epi, hipStream_t s);
+// the same products on 32-row slabs in the TRANSPOSED form (gemm_t32.hip, round 5): 24 577 .. 65 536 rows; taken before the 16-row slabs
+bool gemm_t32_supported(const GemmArgs& a, int a_f32, int epi);
+int launch_gemm_t32(const GemmArgs& a, int epi, hipStream_t s);
 // ring kernel for N = 256, long K (gemm_ring.hip)
 bool gemm_ring256_supported(const GemmArgs& a, int a_f32, int epi);
 int launch_gemm_ring256(const GemmArgs& a, int epi, hipStream_t s);
