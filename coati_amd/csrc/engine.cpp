@@ -290,8 +290,13 @@ void build_layout(coati_engine* e) {
   // (coati_amd/distributed.py grad_buckets; every collective costs a pair of stream hand-overs and a launch on RCCL's stream).
   // --- point encoder (e3gnn_clip.py:75-104, e_gcl_sparse.py:130-150) ---
   auto add_point = [&]() {
-    e->gembw = add_entry(e, "point_encoder.embedding.weight", H, 28);
-    e->gembb = add_entry(e, "point_encoder.embedding.bias", H, 0);
+    if (c.torch_emb) {   // nn.Embedding(84, H) in front, embedding = nn.Identity (e3gnn_clip.py:49-56, 74-77)
+      e->gembw = add_entry(e, "point_encoder.emb.weight", 84, H);
+      e->gembb = -1;
+    } else {
+      e->gembw = add_entry(e, "point_encoder.embedding.weight", H, 28);
+      e->gembb = add_entry(e, "point_encoder.embedding.bias", H, 0);
+    }
     e->gd0w = add_entry(e, "point_encoder.node_dec.0.weight", H, H);
     e->gd0b = add_entry(e, "point_encoder.node_dec.0.bias", H, 0);
     e->gd3w = add_entry(e, "point_encoder.node_dec.3.weight", H, H);
@@ -313,7 +318,12 @@ void build_layout(coati_engine* e) {
   // --- point_to_clip (clip_e2e.py:405-422) ---
   auto add_p2c = [&]() {
     // norm_clips: LayerNorm -> Linear (state_dict .0 / .1); otherwise a plain Linear (clip_e2e.py:405-428)
-    if (c.norm_clips) {
+    if (c.norm_clips && c.old_architecture) {   // Linear -> LayerNorm (clip_e2e.py:409-413)
+      e->p2c_w = add_entry(e, "point_to_clip.0.weight", E, H);
+      e->p2c_b = add_entry(e, "point_to_clip.0.bias", E, 0);
+      e->p2c_lnw = add_entry(e, "point_to_clip.1.weight", H, 0);
+      e->p2c_lnb = add_entry(e, "point_to_clip.1.bias", H, 0);
+    } else if (c.norm_clips) {
       e->p2c_lnw = add_entry(e, "point_to_clip.0.weight", H, 0);
       e->p2c_lnb = add_entry(e, "point_to_clip.0.bias", H, 0);
       e->p2c_w = add_entry(e, "point_to_clip.1.weight", E, H);
@@ -330,7 +340,12 @@ void build_layout(coati_engine* e) {
   e->lmhead = add_entry(e, "xformer.lm_head.weight", V, C);
   if (c.use_point_encoder) add_p2c();
   // --- heads (clip_e2e.py:419-435) ---
-  if (c.norm_clips) {
+  if (c.norm_clips && c.old_architecture) {   // Linear -> LayerNorm (clip_e2e.py:414-417)
+    e->s2c_w = add_entry(e, "smiles_to_clip.0.weight", E, C);
+    e->s2c_b = add_entry(e, "smiles_to_clip.0.bias", E, 0);
+    e->s2c_lnw = add_entry(e, "smiles_to_clip.1.weight", E, 0);
+    e->s2c_lnb = add_entry(e, "smiles_to_clip.1.bias", E, 0);
+  } else if (c.norm_clips) {
     e->s2c_lnw = add_entry(e, "smiles_to_clip.0.weight", E, 0);
     e->s2c_lnb = add_entry(e, "smiles_to_clip.0.bias", E, 0);
     e->s2c_w = add_entry(e, "smiles_to_clip.1.weight", E, C);
@@ -1047,7 +1062,8 @@ int gnn_fwd(coati_engine* e, const long long* atoms, const float* coords, hipStr
     // grid in (twice: count, fill), the edge list (bj, bk, rev, d2, w: 20 B per edge) + offsets out
     ProfScope ps(e, SITE_GNN_ELEMWISE, 0, s, (double)BA * (8 + H * 6 + 8) + (double)BA * 12 + (double)Me * 8 * 3 + (double)BA * 4, 20.0);
     bf16_t* h16 = Lg > 0 ? e->g_hcat[0] : e->g_hfin16;
-    COATI_TRY(launch_gnn_embed(atoms, e->lut_ix, e->lut_iy, e->P + e->gembw, e->P + e->gembb, e->g_h32[0], h16, Lg > 0 ? 2 * H : H, e->g_rstd[0], e->g_mask, BA, H, s));
+    if (c.torch_emb) COATI_TRY(launch_gnn_embed(atoms, nullptr, nullptr, e->P + e->gembw, nullptr, e->g_h32[0], h16, Lg > 0 ? 2 * H : H, e->g_rstd[0], e->g_mask, BA, H, s));
+    else COATI_TRY(launch_gnn_embed(atoms, e->lut_ix, e->lut_iy, e->P + e->gembw, e->P + e->gembb, e->g_h32[0], h16, Lg > 0 ? 2 * H : H, e->g_rstd[0], e->g_mask, BA, H, s));
     COATI_TRY(launch_gnn_geom(coords, e->g_mask, c.msg_cutoff, e->g_d2, e->g_w, B, A, s));
     // neighbour list of the step (the coordinates do not change across the layers; the reference rebuilds it 5 times)
     COATI_TRY(launch_gnn_compact(e->g_w, e->g_d2, e->g_seg, e->g_ne, e->g_ebj, e->g_ebk, e->g_erev, e->g_ed2, e->g_ew, e->g_pos, B, A, s));
@@ -1187,7 +1203,8 @@ int gnn_bwd(coati_engine* e, const float* dhpoint, hipStream_t s) {
   {
     ProfScope ps(e, SITE_GNN_ELEMWISE, 0, s, (double)BA * (H * 4 + H * 4 + 4 + H * 4) + (double)BA * (8 + H * 4) + 30.0 * H * 4);
     COATI_TRY(launch_layernorm_bwd(DH, 1, H, e->g_h32[0], H, 1, nullptr, e->g_rstd[0], nullptr, nullptr, DO, nullptr, nullptr, nullptr, e->ln_partial, BA, H, s));
-    COATI_TRY(launch_gnn_embed_bwd(e->atoms, e->lut_ix, e->lut_iy, DO, e->G + e->gembw, e->G + e->gembb, BA, H, s));
+    if (e->cfg.torch_emb) COATI_TRY(launch_gnn_embed_bwd(e->atoms, nullptr, nullptr, DO, e->G + e->gembw, nullptr, BA, H, s));
+    else COATI_TRY(launch_gnn_embed_bwd(e->atoms, e->lut_ix, e->lut_iy, DO, e->G + e->gembw, e->G + e->gembb, BA, H, s));
   }
   return COATI_OK;
 }
@@ -1239,6 +1256,11 @@ int point_head_fwd(coati_engine* e, float* out, hipStream_t s) {
   const int H = c.n_hidden_e3nn, E = c.n_embd_common, B = e->B;
   if (!c.use_point_encoder) return COATI_OK;   // zeros, written by the caller
   const float* x = e->hpoint;
+  if (c.norm_clips && c.old_architecture) {
+    // Linear -> LayerNorm (clip_e2e.py:409-413): the Linear's output is kept in hp_ln ([B, H] = [B, E]) for the LayerNorm's backward
+    COATI_TRY(launch_sgemm(x, H, 1, e->P + e->p2c_w, 1, H, e->hp_ln, E, B, E, H, e->P + e->p2c_b, 1.f, 0, s));
+    return launch_layernorm_fwd(e->hp_ln, E, e->P + e->p2c_lnw, e->P + e->p2c_lnb, nullptr, 0, out, E, e->hp_mean, e->hp_rstd, B, E, s);
+  }
   if (c.norm_clips) {
     COATI_TRY(launch_layernorm_fwd(e->hpoint, H, e->P + e->p2c_lnw, e->P + e->p2c_lnb, nullptr, 0, e->hp_ln, H, e->hp_mean, e->hp_rstd, B, H, s));
     x = e->hp_ln;
@@ -1249,6 +1271,10 @@ int smiles_head_fwd(coati_engine* e, float* out, hipStream_t s) {
   const coati_config& c = e->cfg;
   const int C = c.n_hidden_xformer, E = c.n_embd_common, B = e->B;
   const float* x = e->hstop;
+  if (c.norm_clips && c.old_architecture) {   // Linear -> LayerNorm (clip_e2e.py:414-417); E == C
+    COATI_TRY(launch_sgemm(x, C, 1, e->P + e->s2c_w, 1, C, e->hs_ln, E, B, E, C, e->P + e->s2c_b, 1.f, 0, s));
+    return launch_layernorm_fwd(e->hs_ln, E, e->P + e->s2c_lnw, e->P + e->s2c_lnb, nullptr, 0, out, E, e->hs_mean, e->hs_rstd, B, E, s);
+  }
   if (c.norm_clips) {
     COATI_TRY(launch_layernorm_fwd(e->hstop, C, e->P + e->s2c_lnw, e->P + e->s2c_lnb, nullptr, 0, e->hs_ln, C, e->hs_mean, e->hs_rstd, B, C, s));
     x = e->hs_ln;
@@ -1272,6 +1298,7 @@ int coati_engine_create(const coati_config* cfg, coati_engine** out) {
   COATI_CHECK_SHAPE(cfg->n_seq > 0 && cfg->n_seq <= 256 && cfg->n_tok > 8, "engine_create: n_seq must be <= 256");
   COATI_CHECK_SHAPE(cfg->n_layer_xformer >= 1 && cfg->n_layer_e3gnn >= 0, "engine_create: bad layer counts");
   COATI_CHECK_SHAPE(!cfg->use_fp8 || C % 128 == 0, "engine_create: fp8 mode needs n_hidden_xformer %% 128 == 0 (C=%d)", C);
+  COATI_CHECK_SHAPE(!(cfg->old_architecture && cfg->norm_clips) || H == E, "engine_create: old_architecture needs n_hidden_e3nn == n_embd_common (%d, %d): point_to_clip's LayerNorm is sized by the one and applied to the other (clip_e2e.py:410-413)", H, E);
   coati_engine* e = new coati_engine();
   e->cfg = *cfg;
   build_layout(e);
@@ -1661,17 +1688,26 @@ int coati_engine_backward(coati_engine* e, const float* dh_smiles, const float* 
       COATI_TRY(launch_select_rows_bwd(e->use_point, e->dcliptok, e->dhe, e->dhs, B, E, s));
     }
     // smiles_to_clip / point_to_clip: Linear then (norm_clips) LayerNorm backward; the two heads' Linear backwards share a launch
+    const bool old_arch = c.norm_clips && c.old_architecture;
+    if (old_arch) {
+      // Linear -> LayerNorm: the LayerNorm's backward first (x = the Linear's output kept in hs_ln / hp_ln), its result in dhs_ln / dhp_ln
+      COATI_TRY(launch_layernorm_bwd(e->dhs, 1, E, e->hs_ln, E, 0, e->hs_mean, e->hs_rstd, e->P + e->s2c_lnw, nullptr, e->dhs_ln, nullptr, e->G + e->s2c_lnw, e->G + e->s2c_lnb, e->ln_partial, B, E, s));
+      if (c.use_point_encoder)
+        COATI_TRY(launch_layernorm_bwd(e->dhe, 1, E, e->hp_ln, E, 0, e->hp_mean, e->hp_rstd, e->P + e->p2c_lnw, nullptr, e->dhp_ln, nullptr, e->G + e->p2c_lnw, e->G + e->p2c_lnb, e->ln_partial, B, E, s));
+    }
     {
       SgemmBatch sb;
-      if (c.norm_clips) COATI_TRY(head_linear_bwd(e, sb, e->dhs, e->hs_ln, e->s2c_w, e->s2c_b, e->dhs_ln, B, E, C));
+      if (old_arch) COATI_TRY(head_linear_bwd(e, sb, e->dhs_ln, e->hstop, e->s2c_w, e->s2c_b, e->dhstop, B, E, C));
+      else if (c.norm_clips) COATI_TRY(head_linear_bwd(e, sb, e->dhs, e->hs_ln, e->s2c_w, e->s2c_b, e->dhs_ln, B, E, C));
       else COATI_TRY(head_linear_bwd(e, sb, e->dhs, e->hstop, e->s2c_w, e->s2c_b, e->dhstop, B, E, C));
       if (c.use_point_encoder) {   // (use_point_encoder = False: h_e3gnn is a constant, nothing upstream of it)
-        if (c.norm_clips) COATI_TRY(head_linear_bwd(e, sb, e->dhe, e->hp_ln, e->p2c_w, e->p2c_b, e->dhp_ln, B, E, H));
+        if (old_arch) COATI_TRY(head_linear_bwd(e, sb, e->dhp_ln, e->hpoint, e->p2c_w, e->p2c_b, e->dhpoint, B, E, H));
+        else if (c.norm_clips) COATI_TRY(head_linear_bwd(e, sb, e->dhe, e->hp_ln, e->p2c_w, e->p2c_b, e->dhp_ln, B, E, H));
         else COATI_TRY(head_linear_bwd(e, sb, e->dhe, e->hpoint, e->p2c_w, e->p2c_b, e->dhpoint, B, E, H));
       }
       COATI_TRY(launch_sgemm_batch(sb, s));
     }
-    if (c.norm_clips) {
+    if (c.norm_clips && !old_arch) {
       COATI_TRY(launch_layernorm_bwd(e->dhs_ln, 1, C, e->hstop, C, 0, e->hs_mean, e->hs_rstd, e->P + e->s2c_lnw, nullptr, e->dhstop, nullptr, e->G + e->s2c_lnw, e->G + e->s2c_lnb, e->ln_partial, B, C, s));
       if (c.use_point_encoder)
         COATI_TRY(launch_layernorm_bwd(e->dhp_ln, 1, H, e->hpoint, H, 0, e->hp_mean, e->hp_rstd, e->P + e->p2c_lnw, nullptr, e->dhpoint, nullptr, e->G + e->p2c_lnw, e->G + e->p2c_lnb, e->ln_partial, B, H, s));

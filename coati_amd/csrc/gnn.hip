@@ -25,7 +25,11 @@ __global__ __launch_bounds__(256) void gnn_embed_kernel(const long long* __restr
   if (lane == 0) mask[row] = z > 0 ? 1.f : 0.f;
   if (z < 0) z = 0;
   if (z > 119) z = 119;
-  const int ix = lut_ix[z], iy = lut_iy[z];
+  // lut_ix == nullptr: torch_emb (e3gnn_clip.py:49-56, 113-115) -- W is nn.Embedding(84, H)'s table, the row of the atomic number IS the
+  // node feature (embedding = Identity, no bias)
+  const bool table = lut_ix == nullptr;
+  if (table && z > 83) z = 83;
+  const int ix = table ? 0 : lut_ix[z], iy = table ? 0 : lut_iy[z];
   float e[16];
   float s = 0.f;
 #pragma unroll
@@ -33,9 +37,13 @@ __global__ __launch_bounds__(256) void gnn_embed_kernel(const long long* __restr
     const int c = lane + 64 * i;
     float v = 0.f;
     if (c < H) {
-      v = bias[c];
-      if (ix >= 0) v += W[c * 28 + ix];
-      if (iy >= 0) v += W[c * 28 + iy];
+      if (table) {
+        v = W[z * H + c];
+      } else {
+        v = bias[c];
+        if (ix >= 0) v += W[c * 28 + ix];
+        if (iy >= 0) v += W[c * 28 + iy];
+      }
     }
     e[i] = v;
     s += v;
@@ -61,7 +69,7 @@ __global__ __launch_bounds__(256) void gnn_embed_kernel(const long long* __restr
 int launch_gnn_embed(const long long* atoms, const int* lut_ix, const int* lut_iy, const float* W, const float* b,
                      float* h32, bf16_t* h16, long long ld16, float* rstd, float* mask, int BA, int H,
                      hipStream_t s) {
-  COATI_CHECK_ARG(atoms && lut_ix && lut_iy && W && b && h32 && h16 && rstd && mask, "gnn_embed: null operand");
+  COATI_CHECK_ARG(atoms && W && h32 && h16 && rstd && mask && ((lut_ix && lut_iy && b) || (!lut_ix && !lut_iy && !b)), "gnn_embed: null operand");
   COATI_CHECK_SHAPE(BA > 0 && H > 0 && H <= 1024, "gnn_embed: unsupported shape");
   hipLaunchKernelGGL(gnn_embed_kernel, dim3(cdiv(BA, 4)), dim3(256), 0, s, atoms, lut_ix, lut_iy, W, b, h32, h16, ld16, rstd, mask, BA, H);
   COATI_LAUNCH_CHECK("gnn_embed");
@@ -105,8 +113,40 @@ __global__ __launch_bounds__(256) void gnn_embed_bwd_kernel(const long long* __r
   for (int c = threadIdx.x; c < H; c += blockDim.x) atomicAdd(db + c, acc[28 * H + c]);
 }
 
+// torch_emb: dTable[z, :] += de[atom, :] over the atoms of atomic number z (nn.Embedding's backward).  A workgroup owns a chunk of atoms,
+// thread = channel; runs of equal atomic numbers are summed in a register before the atomic (hydrogens and carbons come in runs)
+__global__ __launch_bounds__(256) void gnn_embed_table_bwd_kernel(const long long* __restrict__ atoms, const float* __restrict__ de,
+                                                                  float* __restrict__ dT, int BA, int H, int rows_per_chunk) {
+  const int r0 = blockIdx.x * rows_per_chunk;
+  int r1 = r0 + rows_per_chunk;
+  if (r1 > BA) r1 = BA;
+  for (int c = threadIdx.x; c < H; c += blockDim.x) {
+    float run = 0.f;
+    long long zr = -1;
+    for (int row = r0; row < r1; ++row) {
+      long long z = atoms[row];
+      if (z < 0) z = 0;
+      if (z > 83) z = 83;
+      if (z != zr) {
+        if (zr >= 0 && run != 0.f) atomicAdd(dT + zr * H + c, run);
+        zr = z;
+        run = 0.f;
+      }
+      run += de[(long long)row * H + c];
+    }
+    if (zr >= 0 && run != 0.f) atomicAdd(dT + zr * H + c, run);
+  }
+}
+
 int launch_gnn_embed_bwd(const long long* atoms, const int* lut_ix, const int* lut_iy, const float* de,
                          float* dW, float* db, int BA, int H, hipStream_t s) {
+  if (lut_ix == nullptr && lut_iy == nullptr && db == nullptr) {   // torch_emb
+    COATI_CHECK_ARG(atoms && de && dW, "gnn_embed_bwd: null operand");
+    const int rpc = 32;
+    hipLaunchKernelGGL(gnn_embed_table_bwd_kernel, dim3(cdiv(BA, rpc)), dim3(256), 0, s, atoms, de, dW, BA, H, rpc);
+    COATI_LAUNCH_CHECK("gnn_embed_table_bwd");
+    return COATI_OK;
+  }
   COATI_CHECK_ARG(atoms && lut_ix && lut_iy && de && dW && db, "gnn_embed_bwd: null operand");
   COATI_CHECK_SHAPE((size_t)29 * H * 4 <= 64 * 1024, "gnn_embed_bwd: H=%d too wide for the LDS accumulator", H);
   const int chunks = BA >= 4096 ? 128 : (BA >= 256 ? 8 : 1);

@@ -41,7 +41,7 @@ def reference_parameter_order(names):
         top = {"point_encoder": 0, "xformer": 1, "point_to_clip": 2, "smiles_to_clip": 3, "point_clip_to_special_tokens": 4}[p[0]]
         wb = {"weight": 0, "bias": 1}[p[-1]]
         if p[0] == "point_encoder":
-            if p[1] == "embedding":
+            if p[1] in ("embedding", "emb"):   # (torch_emb: nn.Embedding `emb` is registered where the Linear `embedding` would be)
                 return (top, 0, 0, 0, 0, wb)
             if p[1] == "node_dec":
                 return (top, 1, 0, 0, int(p[2]), wb)
@@ -95,11 +95,11 @@ class e3gnn_smiles_clip_e2e(nn.Module):
                  use_point_encoder: bool = True, old_architecture: bool = False,
                  device: torch.device = torch.device("cuda:0"), dtype: torch.dtype = torch.float):
         super().__init__()
-        # norm_clips / token_mlp / use_point_encoder follow the reference in both settings (clip_e2e.py:405-437, 454-463;
-        # the reference's own do_args() defaults are norm_clips=False, token_mlp=False: train_coati.py:520-523).  The remaining
-        # flags select layers no released COATI checkpoint uses (torch.nn.Embedding atom table, residual
-        # E(3)-GNN coordinates, the pre-release head order)
-        unsupported = dict(torch_emb=torch_emb, residual=residual, old_architecture=old_architecture)
+        # norm_clips / token_mlp / use_point_encoder / biases / norm_embed / torch_emb / old_architecture follow the reference in both
+        # settings (clip_e2e.py:357-437, 454-463; the reference's own do_args() defaults are norm_clips=False, token_mlp=False:
+        # train_coati.py:520-523).  `residual` (the one-hot node features as a third input of every node MLP, e_gcl_sparse.py:141,
+        # 282-290) is the one constructor flag left out: no released COATI checkpoint uses it
+        unsupported = dict(residual=residual)
         bad = [k for k, v in unsupported.items() if v]
         if bad:
             raise NotImplementedError(f"coati_amd: unsupported constructor flags: {bad}")
@@ -112,7 +112,8 @@ class e3gnn_smiles_clip_e2e(nn.Module):
         cfg = ModelConfig(n_layer_e3gnn=n_layer_e3gnn, n_layer_xformer=n_layer_xformer, n_hidden_xformer=n_hidden_xformer,
                           n_hidden_e3nn=n_hidden_e3nn, n_embd_common=n_embd_common, n_head=n_head, n_seq=n_seq, n_tok=n_tok,
                           msg_cutoff=5.0, norm_clips=bool(norm_clips), token_mlp=bool(token_mlp),
-                          use_point_encoder=bool(use_point_encoder), biases=bool(biases), norm_embed=bool(norm_embed))
+                          use_point_encoder=bool(use_point_encoder), biases=bool(biases), norm_embed=bool(norm_embed),
+                          torch_emb=bool(torch_emb), old_architecture=bool(old_architecture))
         eng = Engine(cfg, self.device, train=True)
         object.__setattr__(self, "engine", eng)
         grads = eng.named_views("grads")

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define COATI_ABI_VERSION 4
+#define COATI_ABI_VERSION 5
 
 const char* coati_last_error(void);
 int coati_abi_version(void);
@@ -287,6 +287,12 @@ typedef struct coati_config {
   int32_t norm_embed;        /* ABI v4.  1: a LayerNorm follows the token embedding (basic_transformer.py:72-76: tok_emb = Sequential(Embedding,
                                 LayerNorm), entries xformer.emb.tok_emb.0.weight / .1.weight / .1.bias); the injection overwrites its output.  The
                                 reference also registers an unused xformer.norm_embed LayerNorm (smiles_xformer.py:81-82): in the table, never trained */
+  int32_t torch_emb;         /* ABI v5.  1: the point encoder's node features are rows of an nn.Embedding(84, H) (entry point_encoder.emb.weight) instead
+                                of Linear(one-hot period / group) (e3gnn_clip.py:49-56, 74-77, 113-115); atomic numbers above 83 read row 83 (the
+                                reference asserts / raises there) */
+  int32_t old_architecture;  /* ABI v5.  1 (with norm_clips): point_to_clip / smiles_to_clip = Linear -> LayerNorm (state_dict .0 = Linear, .1 =
+                                LayerNorm; clip_e2e.py:409-417) instead of LayerNorm -> Linear.  Needs H == E (the reference sizes the point head's
+                                LayerNorm by hidden_nf and applies it to the E-wide output) */
 } coati_config;
 
 typedef struct coati_engine coati_engine;

@@ -178,6 +178,8 @@ class OracleConfig:
     use_point_encoder: bool = True
     norm_embed: bool = False  # True: tok_emb = Sequential(Embedding, LayerNorm) (basic_transformer.py:72-76) + an unused xformer.norm_embed LayerNorm
     biases: bool = True  # False: c_attn / c_proj / mlpf.0 / mlpf.2 without bias (basic_transformer.py:113-115, 166-168)
+    torch_emb: bool = False  # True: nodes = nn.Embedding(84, H)(atoms), embedding = Identity (e3gnn_clip.py:49-56, 74-77, 113-115)
+    old_architecture: bool = False  # True (with norm_clips): the clip heads are Linear -> LayerNorm (clip_e2e.py:409-417)
 
 
 # --------------------------------------------------------------------------------------
@@ -416,9 +418,12 @@ def gcl_layer(h: Tensor, emask: Tensor, d: Tensor, P: Params, pre: str, rc: floa
 
 def point_encoder(atoms: Tensor, coords: Tensor, P: Params, cfg: OracleConfig, pre: str = "point_encoder.") -> Tensor:
     """e3gnn_clip.forward, e3gnn_clip.py:108-137."""
-    nodes = atom_onehot(atoms)
     node_mask = (atoms > 0).float()
-    h = rb(instance_norm(nodes @ P[pre + "embedding.weight"].t() + P[pre + "embedding.bias"]))
+    if cfg.torch_emb:   # e3gnn_clip.py:113-115 (the reference asserts atoms <= 84; nn.Embedding(84) raises at 84)
+        h = rb(instance_norm(P[pre + "emb.weight"][atoms.clamp(min=0)]))
+    else:
+        nodes = atom_onehot(atoms)
+        h = rb(instance_norm(nodes @ P[pre + "embedding.weight"].t() + P[pre + "embedding.bias"]))
     emask, d = neighbor_mask(coords, node_mask, cfg.msg_cutoff)
     for l in range(cfg.n_layer_e3gnn):
         h = gcl_layer(h, emask, d, P, f"{pre}gcl_{l}.", cfg.msg_cutoff)
@@ -432,11 +437,14 @@ def point_encoder(atoms: Tensor, coords: Tensor, P: Params, cfg: OracleConfig, p
 # --------------------------------------------------------------------------------------
 # heads, forward_dist, losses  (clip_e2e.py, train_coati.py)
 # --------------------------------------------------------------------------------------
-def ln_linear(x: Tensor, P: Params, pre: str, norm_clips: bool = True) -> Tensor:
-    """point_to_clip / smiles_to_clip = LayerNorm -> Linear (clip_e2e.py:419-427), or a plain Linear when norm_clips is
-    False (clip_e2e.py:428-430). fp32."""
+def ln_linear(x: Tensor, P: Params, pre: str, norm_clips: bool = True, old_architecture: bool = False) -> Tensor:
+    """point_to_clip / smiles_to_clip = LayerNorm -> Linear (clip_e2e.py:419-427), Linear -> LayerNorm with old_architecture
+    (clip_e2e.py:409-417), or a plain Linear when norm_clips is False (clip_e2e.py:428-430). fp32."""
     if not norm_clips:
         return x @ P[pre + "weight"].t() + P[pre + "bias"]
+    if old_architecture:
+        y = x @ P[pre + "0.weight"].t() + P[pre + "0.bias"]
+        return F.layer_norm(y, (y.shape[-1],), P[pre + "1.weight"], P[pre + "1.bias"], 1e-5)
     C = x.shape[-1]
     y = F.layer_norm(x, (C,), P[pre + "0.weight"], P[pre + "0.bias"], 1e-5)
     return y @ P[pre + "1.weight"].t() + P[pre + "1.bias"]
@@ -453,13 +461,13 @@ def encode_points(atoms, coords, P, cfg):
     """clip_e2e.py:454-463 (zeros when the point encoder is not used)."""
     if not cfg.use_point_encoder:
         return torch.zeros(atoms.shape[0], cfg.n_embd_common)
-    return ln_linear(point_encoder(atoms, coords, P, cfg), P, "point_to_clip.", cfg.norm_clips)
+    return ln_linear(point_encoder(atoms, coords, P, cfg), P, "point_to_clip.", cfg.norm_clips, cfg.old_architecture)
 
 
 def encode_tokens(idx, P, cfg):
     """clip_e2e.py:448-452."""
     x = xformer(idx, P, cfg)
-    return ln_linear(stop_token_embs(x, idx, cfg.stop_token), P, "smiles_to_clip.", cfg.norm_clips)
+    return ln_linear(stop_token_embs(x, idx, cfg.stop_token), P, "smiles_to_clip.", cfg.norm_clips, cfg.old_architecture)
 
 
 def forward_dist(
@@ -577,8 +585,11 @@ def adamw_update(p, g, m, v, step: int, lr: float, b1=0.9, b2=0.99, eps=1e-8, wd
 def param_shapes(cfg: OracleConfig) -> Dict[str, Tuple[int, ...]]:
     C, H, E, V = cfg.n_hidden_xformer, cfg.n_hidden_e3nn, cfg.n_embd_common, cfg.n_tok
     s: Dict[str, Tuple[int, ...]] = {}
-    s["point_encoder.embedding.weight"] = (H, 28)
-    s["point_encoder.embedding.bias"] = (H,)
+    if cfg.torch_emb:
+        s["point_encoder.emb.weight"] = (84, H)
+    else:
+        s["point_encoder.embedding.weight"] = (H, 28)
+        s["point_encoder.embedding.bias"] = (H,)
     s["point_encoder.node_dec.0.weight"] = (H, H)
     s["point_encoder.node_dec.0.bias"] = (H,)
     s["point_encoder.node_dec.3.weight"] = (H, H)
@@ -625,7 +636,16 @@ def param_shapes(cfg: OracleConfig) -> Dict[str, Tuple[int, ...]]:
     s["xformer.transformer.ln_f.weight"] = (C,)
     s["xformer.transformer.ln_f.bias"] = (C,)
     s["xformer.lm_head.weight"] = (V, C)
-    if cfg.norm_clips:
+    if cfg.norm_clips and cfg.old_architecture:   # Linear -> LayerNorm; the point head's LayerNorm is sized by H (clip_e2e.py:410-413)
+        s["point_to_clip.0.weight"] = (E, H)
+        s["point_to_clip.0.bias"] = (E,)
+        s["point_to_clip.1.weight"] = (H,)
+        s["point_to_clip.1.bias"] = (H,)
+        s["smiles_to_clip.0.weight"] = (E, C)
+        s["smiles_to_clip.0.bias"] = (E,)
+        s["smiles_to_clip.1.weight"] = (E,)
+        s["smiles_to_clip.1.bias"] = (E,)
+    elif cfg.norm_clips:
         s["point_to_clip.0.weight"] = (H,)
         s["point_to_clip.0.bias"] = (H,)
         s["point_to_clip.1.weight"] = (E, H)
@@ -658,7 +678,7 @@ def init_params(cfg: OracleConfig, seed: int = 0, scale: float = 1.0) -> Params:
         elif len(shp) == 2:
             bound = 1.0 / math.sqrt(shp[1])
             P[name] = (torch.rand(shp, generator=g) * 2 - 1) * bound * scale
-        elif (".ln_" in name or "norm_embed" in name or "tok_emb.1" in name) and name.endswith("weight") or name.endswith("clip.0.weight"):
+        elif (".ln_" in name or "norm_embed" in name or "tok_emb.1" in name) and name.endswith("weight") or name.endswith("clip.0.weight") or name.endswith("clip.1.weight"):
             P[name] = 1.0 + 0.1 * torch.randn(shp, generator=g)
         else:
             P[name] = 0.05 * torch.randn(shp, generator=g)

@@ -11,6 +11,9 @@ Golden vectors for the constructor flags of e3gnn_smiles_clip_e2e the grande con
   case "nobias" : the grande flags with biases=False -- the blocks' four Linear layers without bias (basic_transformer.py:113-115, 166-168)
   case "normembed": the grande flags with norm_embed=True -- LayerNorm behind the token embedding (basic_transformer.py:72-76), the
                   injection overwrites its output; + the registered-but-unused xformer.norm_embed module (smiles_xformer.py:81-84)
+  case "torchemb": the grande flags with torch_emb=True -- node features from nn.Embedding(84, H), embedding = Identity
+                  (e3gnn_clip.py:49-56, 74-77, 113-115)
+  case "oldarch": the grande flags with old_architecture=True -- point_to_clip / smiles_to_clip = Linear -> LayerNorm (clip_e2e.py:409-417)
 
 Per case (small model of gen_golden.py: d = 64, 2 + 2 layers, V = 48; batch of 5 rows incl. a bad row): the weights, forward_dist
 with a mixed injection mask (h_e3gnn, h_smiles, logits, bad_rows), the training step (train_coati.py:216-277: ar / clip / total
@@ -39,6 +42,8 @@ CASES = {
     "mlp_nopoint": dict(norm_clips=True, token_mlp=True, use_point_encoder=False),
     "nobias": dict(norm_clips=True, token_mlp=True, use_point_encoder=True, biases=False),
     "normembed": dict(norm_clips=True, token_mlp=True, use_point_encoder=True, norm_embed=True),
+    "torchemb": dict(norm_clips=True, token_mlp=True, use_point_encoder=True, torch_emb=True),
+    "oldarch": dict(norm_clips=True, token_mlp=True, use_point_encoder=True, old_architecture=True),
 }
 
 

@@ -16,6 +16,11 @@ DEV = "cuda:0"
 # the golden-step tolerances of tests/test_gpu_engine.py; gradients 5e-2 instead of 3.8e-2: the "mixed" case (5 rows, gradient
 # norm 44.7 -- four times the golden step's) measured 4.1e-2 on point_encoder.node_dec.3.bias, the other three cases <= 2.2e-2
 TOL_FWD, TOL_GRAD, TOL_LOSS, TOL_GRADNORM = 6.5e-3, 5e-2, 1e-3, 1.3e-2
+# "oldarch": the heads END in a LayerNorm, so the embeddings have norm sqrt(64) and clip_loss's raw dot products (clip_e2e.py:35-47)
+# reach ~ 64: the 2.9e-3 of bf16 operand rounding on h_smiles is ~ 0.2 on a logit.  Measured 2.8e-3 on the clip loss (bound: 2 x);
+# the loss arithmetic itself is held to the oracle's clip_loss on the engine's OWN embeddings at 2e-5 below
+TOL_CLIP = {"oldarch": 6e-3}
+TOL_GN = {"oldarch": 2.6e-2}      # same amplification on the gradient norm: 1.29e-2 measured (the other cases <= 6e-3)
 
 
 @pytest.mark.parametrize("case", list(CASES))
@@ -37,12 +42,16 @@ def test_engine_flags_vs_reference(golden_dir, case):
     assert torch.equal(bad.cpu().bool(), d["bad"])
     # the training step: losses, every gradient, clip-norm, AdamW
     eng.step_count = 0
-    eng.train_step(b, up.to(DEV), lr=5e-4)
+    he_t, hs_t, bad_t = eng.train_step(b, up.to(DEV), lr=5e-4)
+    he_t, hs_t, bad_t = he_t.cpu().clone(), hs_t.cpu().clone(), bad_t.cpu().bool().clone()
     L = eng.losses()
     check(f"{case} ar", torch.tensor([L["ar_loss"]]), d["ar"].reshape(1), TOL_LOSS)
-    check(f"{case} clip", torch.tensor([L["clip_loss"]]), d["clip"].reshape(1), TOL_LOSS)
-    check(f"{case} loss", torch.tensor([L["loss"]]), d["loss"].reshape(1), TOL_LOSS)
-    check(f"{case} gradnorm", torch.tensor([L["grad_norm"]]), d["gradnorm"].reshape(1).float(), TOL_GRADNORM)
+    check(f"{case} clip", torch.tensor([L["clip_loss"]]), d["clip"].reshape(1), TOL_CLIP.get(case, TOL_LOSS))
+    check(f"{case} loss", torch.tensor([L["loss"]]), d["loss"].reshape(1), TOL_CLIP.get(case, TOL_LOSS))
+    if case in TOL_CLIP:
+        from oracle import coati_oracle as O
+        check(f"{case} clip on the engine's own embeddings", torch.tensor([L["clip_loss"]]), O.clip_loss(hs_t, he_t, bad_t), 2e-5)
+    check(f"{case} gradnorm", torch.tensor([L["grad_norm"]]), d["gradnorm"].reshape(1).float(), TOL_GN.get(case, TOL_GRADNORM))
     grads = eng.named_views("grads")
     worst = 0.0
     for k in sorted(eng.layout):

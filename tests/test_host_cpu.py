@@ -19,7 +19,7 @@ def test_cabi_exports_every_declared_symbol():
     hdr = open(os.path.join(ROOT, "include", "coati_hip.h")).read()
     declared = set(re.findall(r"\b(coati_[a-z0-9_]+)\s*\(", hdr))
     l = _lib.lib()
-    assert l.coati_abi_version() == _lib.ABI_VERSION == 4
+    assert l.coati_abi_version() == _lib.ABI_VERSION == 5
     for sym in sorted(declared):
         assert hasattr(l, sym), f"libcoati_hip.so does not export {sym}"
     assert declared == set(_lib.exported_symbols())
