@@ -24,11 +24,13 @@ def load_e3gnn_smiles_clip_e2e(doc_url: str, device: str = "cuda:0", freeze: boo
     vocabulary files are user data and not shipped here: `vocab` (a {"special_tokens", "smiles_tokens"} dict or the
     path of such a JSON file) or a directory in $COATI_VOCAB_PATH holding <vocab_name>.json supplies it;
     `tokenizer_factory(vocab_name, n_seq)` overrides the construction.  With none of them the second value is None."""
-    if model_type != "default" or old_architecture:
-        raise NotImplementedError("only the default e3gnn_smiles_clip_e2e architecture is implemented")
+    if model_type != "default":
+        raise NotImplementedError("only the default e3gnn_smiles_clip_e2e model type is implemented (no fingerprint model)")
     with open(doc_url, "rb") as f_in:
         model_doc = CPU_Unpickler(f_in, encoding="UTF-8").load()
     model_kwargs = dict(model_doc["model_kwargs"])
+    if old_architecture:     # io/coati.py:75-76: Linear -> LayerNorm clip heads
+        model_kwargs["old_architecture"] = True
     if override_args:
         model_kwargs.update(override_args)
     model_kwargs["device"] = torch.device(device)
