@@ -16,7 +16,7 @@ class CoatiConfig(ctypes.Structure):
         ("n_tok", c_int32), ("msg_cutoff", c_float), ("pad_token", c_int32), ("stop_token", c_int32),
         ("unk_token", c_int32), ("use_fp8", c_int32), ("norm_clips", c_int32), ("token_mlp", c_int32),
         ("use_point_encoder", c_int32), ("biases", c_int32), ("norm_embed", c_int32), ("torch_emb", c_int32),
-        ("old_architecture", c_int32),
+        ("old_architecture", c_int32), ("residual", c_int32),
     ]
 
 

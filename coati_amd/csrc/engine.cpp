@@ -57,7 +57,7 @@ struct XLayerP {  // offsets into the flat parameter buffer
 };
 struct GLayerP {
   int64_t e0w, e0b, e3w, e3b, n0w, n0b, n3w, n3b, c0w, c0b, c2w;
-  int64_t w1ab, w1abT, e3T, n0T, n3T;  // shadow extras
+  int64_t w1ab, w1abT, e3T, n0T, n3T, n0p;  // shadow extras (n0p: residual = True, the [H][2H] part of node_mlp.0.weight packed)
 };
 
 struct XPass {  // saved activations of one transformer pass
@@ -309,7 +309,7 @@ void build_layout(coati_engine* e) {
       g.e0b = add_entry(e, p + "edge_mlp.0.bias", H, 0);
       g.e3w = add_entry(e, p + "edge_mlp.3.weight", H, H);
       g.e3b = add_entry(e, p + "edge_mlp.3.bias", H, 0);
-      g.n0w = add_entry(e, p + "node_mlp.0.weight", H, 2 * H);
+      g.n0w = add_entry(e, p + "node_mlp.0.weight", H, 2 * H + (c.residual ? 28 : 0));   // residual: + the one-hot node features (e_gcl_sparse.py:141)
       g.n0b = add_entry(e, p + "node_mlp.0.bias", H, 0);
       g.n3w = add_entry(e, p + "node_mlp.3.weight", H, H);
       g.n3b = add_entry(e, p + "node_mlp.3.bias", H, 0);
@@ -402,6 +402,7 @@ void build_layout(coati_engine* e) {
     g.e3T = add_shadow(e, (int64_t)H * H);
     g.n0T = add_shadow(e, (int64_t)2 * H * H);
     g.n3T = add_shadow(e, (int64_t)H * H);
+    g.n0p = c.residual ? add_shadow(e, (int64_t)2 * H * H) : -1;
   }
   e->gd0T = add_shadow(e, (int64_t)H * H);
   e->gd3T = add_shadow(e, (int64_t)H * H);
@@ -437,7 +438,8 @@ void build_layout(coati_engine* e) {
     job(w.e0w, 2 * H + 1, w.w1abT, 2 * H, H, H, 1);          // W1abT [H][2H]: T[k][n] = W1ab[n][k]
     job(w.e0w + H, 2 * H + 1, w.w1abT + H, 2 * H, H, H, 1);
     job(w.e3w, H, w.e3T, H, H, H, 1);
-    job(w.n0w, 2 * H, w.n0T, H, H, 2 * H, 1);
+    job(w.n0w, 2 * H + (c.residual ? 28 : 0), w.n0T, H, H, 2 * H, 1);
+    if (c.residual) job(w.n0w, 2 * H + 28, w.n0p, 2 * H, H, 2 * H, 0);   // (rows 2H + 28 apart are not 16-B aligned: the product reads a packed copy)
     job(w.n3w, H, w.n3T, H, H, H, 1);
   }
   job(e->gd0w, H, e->gd0T, H, H, H, 1);
@@ -1088,7 +1090,15 @@ int gnn_fwd(coati_engine* e, const long long* atoms, const float* coords, hipStr
       ProfScope ps(e, SITE_GNN_ELEMWISE, 0, s, (double)BA * (H * 2 + 4), (double)H * 2 + 4, 2.0 * H);   // s2 + w per edge in, the segment sums (bf16 H per node) out
       COATI_TRY(launch_gnn_edge_reduce_c(e->g_s2[l], e->g_seg, e->g_ew, e->g_hcat[l] + H, 2 * H, BA, H, s));
     }
-    COATI_TRY(gemm(e, SITE_GNN_NODE_GEMM, e->g_hcat[l], 0, 2 * H, e->S + w.n0w, 2 * H, BA, H, 2 * H, e->g_t[l], H, e->P + w.n0b, EPI_SILU, nullptr, e->g_upre[l], H, s));
+    if (c.residual) {
+      // node_mlp(cat([h, mi, h0])) (e_gcl_sparse.py:282-290): the [h | mi] columns as a product (f32 out, into g_o: rewritten by the next
+      // product), the one-hot h0 columns gathered on top, then the pre-activation / SiLU pair EPI_SILU writes otherwise
+      COATI_TRY(gemm(e, SITE_GNN_NODE_GEMM, e->g_hcat[l], 0, 2 * H, e->S + w.n0p, 2 * H, BA, H, 2 * H, e->g_o, H, e->P + w.n0b, EPI_F32, nullptr, nullptr, 0, s));
+      ProfScope ps(e, SITE_GNN_ELEMWISE, 0, s, (double)BA * (H * 4 + 8 + H * 4));
+      COATI_TRY(launch_gnn_node_res_silu(e->g_o, atoms, e->lut_ix, e->lut_iy, e->P + w.n0w + 2 * H, 2 * H + 28, e->g_upre[l], e->g_t[l], BA, H, s));
+    } else {
+      COATI_TRY(gemm(e, SITE_GNN_NODE_GEMM, e->g_hcat[l], 0, 2 * H, e->S + w.n0w, 2 * H, BA, H, 2 * H, e->g_t[l], H, e->P + w.n0b, EPI_SILU, nullptr, e->g_upre[l], H, s));
+    }
     COATI_TRY(gemm(e, SITE_GNN_NODE_GEMM, e->g_t[l], 0, H, e->S + w.n3w, H, BA, H, H, e->g_o, H, e->P + w.n3b, EPI_RES_F32, e->g_h32[l], nullptr, H, s));
     {
       ProfScope ps(e, SITE_GNN_ELEMWISE, 0, s, (double)BA * (H * 4 + H * 4 + H * 2 + 4));   // o in, h (f32) + its bf16 copy + rstd out
@@ -1121,7 +1131,7 @@ int gnn_wgrad_group(coati_engine* e, hipStream_t s) {
     for (int l = Lg - 1; l >= 0; --l) {
       const GLayerP& w = e->gl[l];
       COATI_TRY(add(e->gl_DO16[l], H, e->g_t[l], H, H, H, e->G + w.n3w, H, e->G + w.n3b));
-      COATI_TRY(add(e->gl_du[l], H, e->g_hcat[l], 2 * H, H, 2 * H, e->G + w.n0w, 2 * H, e->G + w.n0b));
+      COATI_TRY(add(e->gl_du[l], H, e->g_hcat[l], 2 * H, H, 2 * H, e->G + w.n0w, 2 * H + (c.residual ? 28 : 0), e->G + w.n0b));
       COATI_TRY(add(e->gl_dP[l], 2 * H, e->g_hcat[l], 2 * H, H, H, e->G + w.e0w, 2 * H + 1, nullptr));
       COATI_TRY(add(e->gl_dP[l] + H, 2 * H, e->g_hcat[l], 2 * H, H, H, e->G + w.e0w + H, 2 * H + 1, nullptr));
     }
@@ -1164,7 +1174,11 @@ int gnn_bwd(coati_engine* e, const float* dhpoint, hipStream_t s) {
     // u = [h | mi] W3^T + b3 ; W3T is [2H rows][H]
     COATI_TRY(gemm(e, SITE_GNN_NODE_GEMM, du, 0, H, e->S + w.n0T, H, BA, H, H, DO, H, nullptr, EPI_ACC_F32, nullptr, nullptr, 0, s));
     COATI_TRY(gemm(e, SITE_GNN_NODE_GEMM, du, 0, H, e->S + w.n0T + (int64_t)H * H, H, BA, H, H, e->g_dmi, H, nullptr, EPI_BF16, nullptr, nullptr, 0, s));
-    if (!grp) COATI_TRY(wgrad(e, SITE_GNN_WGRAD, du, 0, H, e->g_hcat[l], 2 * H, BA, H, 2 * H, e->G + w.n0w, 2 * H, e->G + w.n0b, 0, s));
+    if (!grp) COATI_TRY(wgrad(e, SITE_GNN_WGRAD, du, 0, H, e->g_hcat[l], 2 * H, BA, H, 2 * H, e->G + w.n0w, 2 * H + (c.residual ? 28 : 0), e->G + w.n0b, 0, s));
+    if (c.residual) {   // the h0 columns of node_mlp.0.weight: one-hot scatter of du
+      ProfScope ps(e, SITE_GNN_ELEMWISE, 0, s, (double)BA * (H * 2 + 8));
+      COATI_TRY(launch_gnn_onehot_wgrad(e->atoms, e->lut_ix, e->lut_iy, du, e->G + w.n0w + 2 * H, 2 * H + 28, BA, H, s));
+    }
     {
       ProfScope ps(e, SITE_GNN_ELEMWISE, 0, s, (double)BA * (H * 2 + 4), (double)H * 4 + 4, 6.0 * H);   // d mi per receiver, s2 + w per edge in, d s2 per edge out
       COATI_TRY(launch_gnn_edge_reduce_bwd_c(e->g_dmi, H, e->g_s2[l], e->g_seg, e->g_ew, e->g_ds2, BA, H, s));
@@ -1298,6 +1312,7 @@ int coati_engine_create(const coati_config* cfg, coati_engine** out) {
   COATI_CHECK_SHAPE(cfg->n_seq > 0 && cfg->n_seq <= 256 && cfg->n_tok > 8, "engine_create: n_seq must be <= 256");
   COATI_CHECK_SHAPE(cfg->n_layer_xformer >= 1 && cfg->n_layer_e3gnn >= 0, "engine_create: bad layer counts");
   COATI_CHECK_SHAPE(!cfg->use_fp8 || C % 128 == 0, "engine_create: fp8 mode needs n_hidden_xformer %% 128 == 0 (C=%d)", C);
+  COATI_CHECK_ARG(!(cfg->residual && cfg->torch_emb), "engine_create: residual and torch_emb together size the node MLPs for 28 one-hot features and feed them H embedding columns (the reference fails in its first forward: e3gnn_clip.py:100, e_gcl_sparse.py:289)");
   COATI_CHECK_SHAPE(!(cfg->old_architecture && cfg->norm_clips) || H == E, "engine_create: old_architecture needs n_hidden_e3nn == n_embd_common (%d, %d): point_to_clip's LayerNorm is sized by the one and applied to the other (clip_e2e.py:410-413)", H, E);
   coati_engine* e = new coati_engine();
   e->cfg = *cfg;

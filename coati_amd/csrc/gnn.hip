@@ -156,6 +156,76 @@ int launch_gnn_embed_bwd(const long long* atoms, const int* lut_ix, const int* l
   return COATI_OK;
 }
 
+// ---- residual = True (e3gnn_clip.py:97-100, e_gcl_sparse.py:141, 282-290): every node MLP also sees the one-hot node features h0 ---------
+// u = [h | mi] W3[:, :2H]^T + b3 comes from the GEMM (f32); the h0 columns of W3 are one-hot gathers: u += W3[:, 2H + ix] + W3[:, 2H + iy].
+// Then what EPI_SILU would have written: the pre-activation (bf16, for the backward) and silu(u) (bf16, the next product's operand).
+__global__ __launch_bounds__(256) void gnn_node_res_silu_kernel(const float* __restrict__ u32, const long long* __restrict__ atoms,
+                                                                const int* __restrict__ lut_ix, const int* __restrict__ lut_iy,
+                                                                const float* __restrict__ W3c, long long ldw, bf16_t* __restrict__ upre,
+                                                                bf16_t* __restrict__ t16, int BA, int H) {
+  const int row = blockIdx.x;
+  if (row >= BA) return;
+  long long z = atoms[row];
+  if (z < 0) z = 0;
+  if (z > 119) z = 119;
+  const int ix = lut_ix[z], iy = lut_iy[z];
+  for (int c = threadIdx.x; c < H; c += blockDim.x) {
+    float v = u32[(long long)row * H + c];
+    if (ix >= 0) v += W3c[c * ldw + ix];
+    if (iy >= 0) v += W3c[c * ldw + iy];
+    upre[(long long)row * H + c] = f2bf(v);
+    t16[(long long)row * H + c] = f2bf(silu_f(v));
+  }
+}
+
+int launch_gnn_node_res_silu(const float* u32, const long long* atoms, const int* lut_ix, const int* lut_iy, const float* W3c, long long ldw,
+                             bf16_t* upre, bf16_t* t16, int BA, int H, hipStream_t s) {
+  COATI_CHECK_ARG(u32 && atoms && lut_ix && lut_iy && W3c && upre && t16, "gnn_node_res_silu: null operand");
+  hipLaunchKernelGGL(gnn_node_res_silu_kernel, dim3(BA), dim3(256), 0, s, u32, atoms, lut_ix, lut_iy, W3c, ldw, upre, t16, BA, H);
+  COATI_LAUNCH_CHECK("gnn_node_res_silu");
+  return COATI_OK;
+}
+
+// dW3[:, 2H + i] += sum over the atoms whose one-hot has bit i of du[atom, :] (du bf16, dW3 rows ldw apart): gnn_embed_bwd_kernel's scheme
+__global__ __launch_bounds__(256) void gnn_onehot_wgrad_kernel(const long long* __restrict__ atoms, const int* __restrict__ lut_ix,
+                                                               const int* __restrict__ lut_iy, const bf16_t* __restrict__ du,
+                                                               float* __restrict__ dW, long long ldw, int BA, int H, int rows_per_chunk) {
+  extern __shared__ float acc[];   // [28][H]
+  for (int i = threadIdx.x; i < 28 * H; i += blockDim.x) acc[i] = 0.f;
+  __syncthreads();
+  const int r0 = blockIdx.x * rows_per_chunk;
+  int r1 = r0 + rows_per_chunk;
+  if (r1 > BA) r1 = BA;
+  for (int c = threadIdx.x; c < H; c += blockDim.x) {
+    for (int row = r0; row < r1; ++row) {
+      long long z = atoms[row];
+      if (z < 0) z = 0;
+      if (z > 119) z = 119;
+      const int ix = lut_ix[z], iy = lut_iy[z];
+      const float v = bf2f(du[(long long)row * H + c]);
+      if (ix >= 0) acc[ix * H + c] += v;
+      if (iy >= 0 && iy != ix) acc[iy * H + c] += v;
+    }
+  }
+  __syncthreads();
+  for (int f = threadIdx.x; f < 28 * H; f += blockDim.x) {
+    const int c = f / 28, i = f - c * 28;
+    const float v = acc[i * H + c];
+    if (v != 0.f) atomicAdd(dW + c * ldw + i, v);
+  }
+}
+
+int launch_gnn_onehot_wgrad(const long long* atoms, const int* lut_ix, const int* lut_iy, const bf16_t* du, float* dW, long long ldw, int BA,
+                            int H, hipStream_t s) {
+  COATI_CHECK_ARG(atoms && lut_ix && lut_iy && du && dW, "gnn_onehot_wgrad: null operand");
+  COATI_CHECK_SHAPE((size_t)28 * H * 4 <= 64 * 1024, "gnn_onehot_wgrad: H=%d too wide for the LDS accumulator", H);
+  const int chunks = BA >= 4096 ? 128 : (BA >= 256 ? 8 : 1);
+  const int rpc = cdiv(BA, chunks);
+  hipLaunchKernelGGL(gnn_onehot_wgrad_kernel, dim3(cdiv(BA, rpc)), dim3(256), (size_t)28 * H * 4, s, atoms, lut_ix, lut_iy, du, dW, ldw, BA, H, rpc);
+  COATI_LAUNCH_CHECK("gnn_onehot_wgrad");
+  return COATI_OK;
+}
+
 // ---- geometry: squared distances and smooth-cutoff edge weights ---------------------------------------------------
 __global__ void gnn_geom_kernel(const float* __restrict__ coords, const float* __restrict__ mask, float rc,
                                 float* __restrict__ d2o, float* __restrict__ wo, int B, int A) {

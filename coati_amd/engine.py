@@ -39,6 +39,7 @@ class ModelConfig:
     biases: bool = True   # False: c_attn / c_proj / mlpf.0 / mlpf.2 of every block without bias (basic_transformer.py:113-115, 166-168)
     torch_emb: bool = False   # True: node features = rows of nn.Embedding(84, H) instead of Linear(one-hot group / period) (e3gnn_clip.py:49-56, 113-115)
     old_architecture: bool = False   # True (with norm_clips): the two clip heads are Linear -> LayerNorm instead of LayerNorm -> Linear (clip_e2e.py:409-417)
+    residual: bool = False   # True: every node MLP also sees the one-hot node features (e3gnn_clip.py:97-100, e_gcl_sparse.py:141, 282-290)
 
 
 # COATI_PACK_ROWS=0 ignores the batches' packed-row counts: every step then runs on the padded [B, T] layout (A/B switch)
@@ -59,7 +60,7 @@ class Engine:
                              cfg.n_embd_common, cfg.n_head, cfg.n_seq, cfg.n_tok, cfg.msg_cutoff, cfg.pad_token,
                              cfg.stop_token, cfg.unk_token, 1 if cfg.fp8 else 0, 1 if cfg.norm_clips else 0,
                              1 if cfg.token_mlp else 0, 1 if cfg.use_point_encoder else 0, 1 if cfg.biases else 0, 1 if cfg.norm_embed else 0,
-                             1 if cfg.torch_emb else 0, 1 if cfg.old_architecture else 0)
+                             1 if cfg.torch_emb else 0, 1 if cfg.old_architecture else 0, 1 if cfg.residual else 0)
         h = ctypes.c_void_p()
         _lib.check(self.l.coati_engine_create(ctypes.byref(c), ctypes.byref(h)), "coati_engine_create")
         self.h = h

@@ -95,14 +95,9 @@ class e3gnn_smiles_clip_e2e(nn.Module):
                  use_point_encoder: bool = True, old_architecture: bool = False,
                  device: torch.device = torch.device("cuda:0"), dtype: torch.dtype = torch.float):
         super().__init__()
-        # norm_clips / token_mlp / use_point_encoder / biases / norm_embed / torch_emb / old_architecture follow the reference in both
-        # settings (clip_e2e.py:357-437, 454-463; the reference's own do_args() defaults are norm_clips=False, token_mlp=False:
-        # train_coati.py:520-523).  `residual` (the one-hot node features as a third input of every node MLP, e_gcl_sparse.py:141,
-        # 282-290) is the one constructor flag left out: no released COATI checkpoint uses it
-        unsupported = dict(residual=residual)
-        bad = [k for k, v in unsupported.items() if v]
-        if bad:
-            raise NotImplementedError(f"coati_amd: unsupported constructor flags: {bad}")
+        # every constructor flag follows the reference in both settings (clip_e2e.py:357-437, 454-463; the reference's own do_args()
+        # defaults are norm_clips=False, token_mlp=False: train_coati.py:520-523).  residual + torch_emb together are refused by the
+        # engine: the reference builds that model and fails in its first forward (28-wide node MLP input, H-wide features)
         if dtype not in (torch.float, torch.float32):
             raise NotImplementedError("parameters are fp32 master weights (bf16 is an internal operand format)")
         self.embed_dim = n_embd_common
@@ -113,7 +108,7 @@ class e3gnn_smiles_clip_e2e(nn.Module):
                           n_hidden_e3nn=n_hidden_e3nn, n_embd_common=n_embd_common, n_head=n_head, n_seq=n_seq, n_tok=n_tok,
                           msg_cutoff=5.0, norm_clips=bool(norm_clips), token_mlp=bool(token_mlp),
                           use_point_encoder=bool(use_point_encoder), biases=bool(biases), norm_embed=bool(norm_embed),
-                          torch_emb=bool(torch_emb), old_architecture=bool(old_architecture))
+                          torch_emb=bool(torch_emb), old_architecture=bool(old_architecture), residual=bool(residual))
         eng = Engine(cfg, self.device, train=True)
         object.__setattr__(self, "engine", eng)
         grads = eng.named_views("grads")

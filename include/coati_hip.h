@@ -293,6 +293,8 @@ typedef struct coati_config {
   int32_t old_architecture;  /* ABI v5.  1 (with norm_clips): point_to_clip / smiles_to_clip = Linear -> LayerNorm (state_dict .0 = Linear, .1 =
                                 LayerNorm; clip_e2e.py:409-417) instead of LayerNorm -> Linear.  Needs H == E (the reference sizes the point head's
                                 LayerNorm by hidden_nf and applies it to the E-wide output) */
+  int32_t residual;          /* ABI v5.  1: every node MLP of the point encoder also sees the one-hot node features h0 (e3gnn_clip.py:97-100,
+                                e_gcl_sparse.py:141, 282-290): node_mlp.0.weight is [H, 2H + 28].  Not together with torch_emb */
 } coati_config;
 
 typedef struct coati_engine coati_engine;

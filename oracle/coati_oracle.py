@@ -180,6 +180,7 @@ class OracleConfig:
     biases: bool = True  # False: c_attn / c_proj / mlpf.0 / mlpf.2 without bias (basic_transformer.py:113-115, 166-168)
     torch_emb: bool = False  # True: nodes = nn.Embedding(84, H)(atoms), embedding = Identity (e3gnn_clip.py:49-56, 74-77, 113-115)
     old_architecture: bool = False  # True (with norm_clips): the clip heads are Linear -> LayerNorm (clip_e2e.py:409-417)
+    residual: bool = False  # True: every node MLP also sees the one-hot node features h0 (e3gnn_clip.py:97-100, e_gcl_sparse.py:141, 282-290)
 
 
 # --------------------------------------------------------------------------------------
@@ -391,7 +392,7 @@ def instance_norm(h: Tensor) -> Tensor:
     return F.layer_norm(h, (h.shape[-1],), None, None, 1e-5)
 
 
-def gcl_layer(h: Tensor, emask: Tensor, d: Tensor, P: Params, pre: str, rc: float = 5.0) -> Tensor:
+def gcl_layer(h: Tensor, emask: Tensor, d: Tensor, P: Params, pre: str, rc: float = 5.0, h0: Tensor = None) -> Tensor:
     """e_gcl_sparse.forward restricted to the h output (e_gcl_sparse.py:169-215, 253-321).
     The 513->256 edge Linear is evaluated in its factored form
         W1 [h_j, h_k, d^2] + b1 = W1a h_j + W1b h_k + w1c d^2 + b1
@@ -410,7 +411,11 @@ def gcl_layer(h: Tensor, emask: Tensor, d: Tensor, P: Params, pre: str, rc: floa
     w = (cubic_cutoff(d, rc) * emask.float()).unsqueeze(-1)
     mij = F.silu(s2) * w
     mi = rb(mij.sum(2))  # sum over senders k -> [B,A,H]
-    u = rb(linear(torch.cat([hb, mi], -1), P[pre + "node_mlp.0.weight"], P[pre + "node_mlp.0.bias"]))
+    W3 = P[pre + "node_mlp.0.weight"]
+    if h0 is None:
+        u = rb(linear(torch.cat([hb, mi], -1), W3, P[pre + "node_mlp.0.bias"]))
+    else:   # node_mlp(cat([h, mi, h0])) (e_gcl_sparse.py:288-290); h0 is one-hot: its columns are added in fp32 (the HIP path gathers them)
+        u = rb(linear(torch.cat([hb, mi], -1), W3[:, : 2 * H], P[pre + "node_mlp.0.bias"]) + h0 @ W3[:, 2 * H :].t())
     t = rb(F.silu(u))
     out = h + linear(t, P[pre + "node_mlp.3.weight"], P[pre + "node_mlp.3.bias"])
     return rb(instance_norm(out))
@@ -419,6 +424,7 @@ def gcl_layer(h: Tensor, emask: Tensor, d: Tensor, P: Params, pre: str, rc: floa
 def point_encoder(atoms: Tensor, coords: Tensor, P: Params, cfg: OracleConfig, pre: str = "point_encoder.") -> Tensor:
     """e3gnn_clip.forward, e3gnn_clip.py:108-137."""
     node_mask = (atoms > 0).float()
+    nodes = None
     if cfg.torch_emb:   # e3gnn_clip.py:113-115 (the reference asserts atoms <= 84; nn.Embedding(84) raises at 84)
         h = rb(instance_norm(P[pre + "emb.weight"][atoms.clamp(min=0)]))
     else:
@@ -426,7 +432,7 @@ def point_encoder(atoms: Tensor, coords: Tensor, P: Params, cfg: OracleConfig, p
         h = rb(instance_norm(nodes @ P[pre + "embedding.weight"].t() + P[pre + "embedding.bias"]))
     emask, d = neighbor_mask(coords, node_mask, cfg.msg_cutoff)
     for l in range(cfg.n_layer_e3gnn):
-        h = gcl_layer(h, emask, d, P, f"{pre}gcl_{l}.", cfg.msg_cutoff)
+        h = gcl_layer(h, emask, d, P, f"{pre}gcl_{l}.", cfg.msg_cutoff, h0=nodes if cfg.residual else None)
     t = rb(F.silu(rb(linear(h, P[pre + "node_dec.0.weight"], P[pre + "node_dec.0.bias"]))))
     h = linear(t, P[pre + "node_dec.3.weight"], P[pre + "node_dec.3.bias"])
     h = h * node_mask.unsqueeze(-1)
@@ -600,7 +606,7 @@ def param_shapes(cfg: OracleConfig) -> Dict[str, Tuple[int, ...]]:
         s[p + "edge_mlp.0.bias"] = (H,)
         s[p + "edge_mlp.3.weight"] = (H, H)
         s[p + "edge_mlp.3.bias"] = (H,)
-        s[p + "node_mlp.0.weight"] = (H, 2 * H)
+        s[p + "node_mlp.0.weight"] = (H, 2 * H + (28 if cfg.residual else 0))
         s[p + "node_mlp.0.bias"] = (H,)
         s[p + "node_mlp.3.weight"] = (H, H)
         s[p + "node_mlp.3.bias"] = (H,)

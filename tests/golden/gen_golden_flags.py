@@ -14,6 +14,8 @@ Golden vectors for the constructor flags of e3gnn_smiles_clip_e2e the grande con
   case "torchemb": the grande flags with torch_emb=True -- node features from nn.Embedding(84, H), embedding = Identity
                   (e3gnn_clip.py:49-56, 74-77, 113-115)
   case "oldarch": the grande flags with old_architecture=True -- point_to_clip / smiles_to_clip = Linear -> LayerNorm (clip_e2e.py:409-417)
+  case "residual": the grande flags with residual=True -- the one-hot node features as a third input of every node MLP
+                  (e3gnn_clip.py:97-100, e_gcl_sparse.py:141, 282-290)
 
 Per case (small model of gen_golden.py: d = 64, 2 + 2 layers, V = 48; batch of 5 rows incl. a bad row): the weights, forward_dist
 with a mixed injection mask (h_e3gnn, h_smiles, logits, bad_rows), the training step (train_coati.py:216-277: ar / clip / total
@@ -44,6 +46,7 @@ CASES = {
     "normembed": dict(norm_clips=True, token_mlp=True, use_point_encoder=True, norm_embed=True),
     "torchemb": dict(norm_clips=True, token_mlp=True, use_point_encoder=True, torch_emb=True),
     "oldarch": dict(norm_clips=True, token_mlp=True, use_point_encoder=True, old_architecture=True),
+    "residual": dict(norm_clips=True, token_mlp=True, use_point_encoder=True, residual=True),
 }
 
 

@@ -18,6 +18,7 @@ CASES = {
     "normembed": dict(norm_clips=True, token_mlp=True, use_point_encoder=True, norm_embed=True),
     "torchemb": dict(norm_clips=True, token_mlp=True, use_point_encoder=True, torch_emb=True),
     "oldarch": dict(norm_clips=True, token_mlp=True, use_point_encoder=True, old_architecture=True),
+    "residual": dict(norm_clips=True, token_mlp=True, use_point_encoder=True, residual=True),
 }
 SMALL = dict(n_layer_e3gnn=2, n_layer_xformer=2, n_hidden_xformer=64, n_hidden_e3nn=64, n_embd_common=64, n_head=4, n_seq=24, n_tok=48)
 

@@ -323,15 +323,18 @@ def test_tall_closed_shape_vs_oracle():
     assert not bad, sorted(bad, reverse=True)[:8]
 
 
-def test_wide_batch_kernels_vs_oracle():
+@pytest.mark.parametrize("flags", [{}, {"residual": True}, {"torch_emb": True, "old_architecture": True}], ids=["grande_flags", "residual", "torch_emb+old_architecture"])
+def test_wide_batch_kernels_vs_oracle(flags):
     """57 720 token rows (481 x 120) at d = 256, one layer each: the size gates of the big-batch kernels are all open here
     -- row-block GEMMs with LayerNorm fused into the operand load, the N = 256 ring GEMM, the LDS-DMA weight gradient, the
-    fused attention backward at four 32-row blocks -- and the oracle still finishes in seconds."""
+    fused attention backward at four 32-row blocks -- and the oracle still finishes in seconds.  The constructor flags that
+    change the point encoder / the heads run here too: 7 696 atoms take the grouped point-encoder weight gradient
+    (node_mlp.0.weight with rows 2H + 28 apart under residual = True)."""
     from oracle import coati_oracle as O
     from coati_amd.engine import Engine, ModelConfig
     from coati_amd.synthetic import make_batch
     kw = dict(n_layer_e3gnn=1, n_layer_xformer=1, n_hidden_xformer=256, n_hidden_e3nn=256, n_embd_common=256, n_head=16,
-              n_seq=250, n_tok=600)
+              n_seq=250, n_tok=600, **flags)
     ocfg = O.OracleConfig(**kw)
     P = O.init_params(ocfg, seed=13)
     eng = Engine(ModelConfig(**kw), DEV)
@@ -346,7 +349,9 @@ def test_wide_batch_kernels_vs_oracle():
     loss.backward()
     log(f"wide losses hip {L} oracle ar {float(ar):.6f} clip {float(cl):.6f}")
     check("wide ar", torch.tensor([L["ar_loss"]]), ar.detach().reshape(1), TOL_LOSS_SIM)
-    check("wide clip", torch.tensor([L["clip_loss"]]), cl.detach().reshape(1), TOL_LOSS_SIM)
+    # (old_architecture: the heads end in a LayerNorm, clip_loss's raw dot products reach ~ 256 and the bf16 rounding of the embeddings
+    #  shows on the loss: 1.04e-3 measured, see tests/test_gpu_flags.py)
+    check("wide clip", torch.tensor([L["clip_loss"]]), cl.detach().reshape(1), 2.5e-3 if flags.get("old_architecture") else TOL_LOSS_SIM)
     grads = eng.named_views("grads")
     bad = []
     for k in sorted(eng.layout):
