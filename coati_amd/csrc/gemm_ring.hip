@@ -75,13 +75,13 @@ __device__ __forceinline__ void rg_wait_vm(int n) {
 // Probe build (-DCOATI_RB_TRACE, tools/probes/rb_trace.py): shader-clock totals per phase for the waves of the first 16
 // workgroups of the last launch: [wg][wave][before the loop, wait (vmcnt + barrier), MFMA + DMA issue, write-out].
 #ifdef COATI_RB_TRACE
-__device__ unsigned long long rg_trace_buf[16 * RG_MAXW * 8];
+__device__ unsigned long long rg_trace_buf[16 * 16 * 8];   // [wg][wave <= 16][8 phases]; the ring256 kernels fill [wave < 10][4], the one-round kernel [wave < 14][6]
 extern "C" int coati_rg_trace_read(unsigned long long* out) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(rg_trace_buf), sizeof(rg_trace_buf)) == hipSuccess ? 0 : -3;
 }
-#define RG_T0() unsigned long long rg_t_last = __builtin_amdgcn_s_memtime(), rg_t_acc[4] = {0, 0, 0, 0}
+#define RG_T0() unsigned long long rg_t_last = __builtin_amdgcn_s_memtime(), rg_t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
 #define RG_T(i) do { const unsigned long long rg_t_now = __builtin_amdgcn_s_memtime(); rg_t_acc[i] += rg_t_now - rg_t_last; rg_t_last = rg_t_now; } while (0)
-#define RG_TDUMP() do { if (blockIdx.x < 16 && lane == 0) { for (int i = 0; i < 4; ++i) rg_trace_buf[(blockIdx.x * RG_MAXW + wave) * 8 + i] = rg_t_acc[i]; } } while (0)
+#define RG_TDUMP() do { if (blockIdx.x < 16 && lane == 0) { for (int i = 0; i < 8; ++i) rg_trace_buf[(blockIdx.x * 16 + wave) * 8 + i] = rg_t_acc[i]; } } while (0)
 #else
 #define RG_T0() do { } while (0)
 #define RG_T(i) do { } while (0)
@@ -372,6 +372,7 @@ __global__ __launch_bounds__(64 * R1_WAVES, 1) void gemm_ring1_kernel(GemmArgs p
   const int nk = p.K / RG_BK;
   const int row0 = blockIdx.x * R;
   if (row0 >= p.M) return;
+  RG_T0();   // probe build: [before the loop, wait (vmcnt + barrier), MFMA + DMA issue, LayerNorm write-out (or the plain one), dgamma / dbeta, chained product]
   const int row_end = row0 + R < p.M ? row0 + R : p.M, nvalid = row_end - row0;
   const bf16_t* A = reinterpret_cast<const bf16_t*>(p.A);
   const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_u8*)smem);
@@ -440,11 +441,13 @@ __global__ __launch_bounds__(64 * R1_WAVES, 1) void gemm_ring1_kernel(GemmArgs p
   //  issue on the 4-wave SIMDs, not by HBM or L2.  Running the MFMA stream one k step behind the reads ACROSS the stage barrier, so
   //  that the matrix core has 4 MFMAs per wave to chew on while the new stage's first fragments come out of LDS, was built and
   //  measured on one box: 34.0-34.2 vs 34.4-34.9 us isolated, 22.42 vs 22.44 ms per step -- nothing; not kept.)
+  RG_T(0);
   for (int s = 0; s < nk; ++s) {
     // stage s has landed (this wave's pieces; the barrier covers the others) and every wave is done with stage s - 1, whose
     // slots the DMAs of this stage overwrite; in flight behind the wait: the A pieces of stage s + 1
     r1_wait_vm(s + 1 < nk ? nA : 0);
     __builtin_amdgcn_s_barrier();
+    RG_T(1);
     const unsigned char* SA = smem + sa * R1_A_BYTES;
     const unsigned char* SW = smem + 3 * R1_A_BYTES + sw * RG_W_BYTES;
     const int sa2 = sa == 0 ? 2 : sa - 1;                        // (sa + 2) % 3
@@ -494,6 +497,7 @@ __global__ __launch_bounds__(64 * R1_WAVES, 1) void gemm_ring1_kernel(GemmArgs p
     sw ^= 1;
     kk1 = kk2;
     kk2 = kwrap(kk2 + 1);
+    RG_T(2);
   }
 
   // ---- write-out straight from the accumulator layout (one register: 32 consecutive columns of one row per half-wave)
@@ -639,6 +643,7 @@ __global__ __launch_bounds__(64 * R1_WAVES, 1) void gemm_ring1_kernel(GemmArgs p
         __builtin_amdgcn_sched_barrier(0);
       }
     }
+    RG_T(3);
     // dgamma | dbeta: the two half-waves hold different rows of the same columns; then the 7 row groups through LDS
 #pragma unroll
     for (int j = 0; j < 4; ++j) { dgam[j] += __shfl_xor(dgam[j], 32, 64); dbet[j] += __shfl_xor(dbet[j], 32, 64); }
@@ -656,6 +661,7 @@ __global__ __launch_bounds__(64 * R1_WAVES, 1) void gemm_ring1_kernel(GemmArgs p
       for (int g = 0; g < R1_GROUPS; ++g) t += red2[g * 512 + tid];
       p.lnb_partial[(long long)blockIdx.x * 512 + tid] = t;
     }
+    RG_T(4);
     if (p.chain_W != nullptr) {
       // ---- chained product: chain_C = dx16 chain_W^T (N = K = 256: the c_proj input gradient that follows ln_2's backward) on the
       // rows this workgroup has just written -- they come back from L2 by DMA as four 64-k slabs (the three A slots + weight slot 0),
@@ -748,7 +754,10 @@ __global__ __launch_bounds__(64 * R1_WAVES, 1) void gemm_ring1_kernel(GemmArgs p
           for (int j = 0; j < 4; ++j) out2[(long long)row * p.chain_ldc + j * 32] = f2bf(acc[j][r]);
         }
       }
+      RG_T(5);
     }
+    RG_TDUMP();
+    return;
   } else if (EPI == EPI_RES_F32) {
     const float* res = reinterpret_cast<const float*>(p.aux_in) + wn * 128 + fr;
     float* out = reinterpret_cast<float*>(p.C) + wn * 128 + fr;
@@ -781,6 +790,8 @@ __global__ __launch_bounds__(64 * R1_WAVES, 1) void gemm_ring1_kernel(GemmArgs p
       }
     }
   }
+  RG_T(3);
+  RG_TDUMP();
 }
 
 template <int EPI>

@@ -37,9 +37,9 @@ us = timeit(f); dump("plain bf16 N=768", us)
 
 
 def dump_ring(tag, us):
-    buf = (ctypes.c_uint64 * (16 * 10 * 8))()
+    buf = (ctypes.c_uint64 * (16 * 16 * 8))()
     assert lib.coati_rg_trace_read(buf) == 0
-    a = np.array(buf, dtype=np.float64).reshape(16, 10, 8)[:, :, :4]
+    a = np.array(buf, dtype=np.float64).reshape(16, 16, 8)[:, :, :4]
     a = a[:, a.sum((0, 2)) > 0, :]                  # waves that ran (10, or 8 in the 128-row form)
     tot = a.sum(-1).mean()
     names = ["before loop", "wait (vmcnt + barrier)", "MFMA + DMA issue", "write-out"]
