@@ -30,6 +30,7 @@ _SIGS = {
     "coati_reducescatter_rows": [P, P, P, L, L, I, P],
     "coati_allreduce_bucket": [P, P, L, I, I, P],
     "coati_gemm_nt": [P, I, L, P, L, I, I, I, P, L, I, P, P, P, L, I, P],
+    "coati_mlp_fwd": [P, P, P, P, P, P, P, P, P, P, P, P, P, I, P],
     "coati_gemm_lnbwd": [P, L, P, L, I, I, P, P, P, P, P, P, P, P, POINTER(c_int32), P, P, P],
     "coati_quant_mx8": [P, I, L, P, L, P, I, I, P],
     "coati_gemm_mx8": [P, L, P, P, L, P, I, I, I, P, L, P, P, P, L, I, P],

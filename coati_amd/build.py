@@ -10,11 +10,15 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libcoati_hip.so")
 OBJDIR = os.path.join(HERE, "build")
-HIP_UNITS = ["gemm.hip", "gemm_rb.hip", "gemm_rb16.hip", "gemm_t32.hip", "gemm_ring.hip", "gemm_mx8.hip", "norm.hip", "attention.hip", "attn_block.hip", "embed.hip", "gnn.hip", "loss.hip", "optim.hip", "batch.hip", "decode.hip"]
+HIP_UNITS = ["gemm.hip", "gemm_rb.hip", "gemm_rb16.hip", "gemm_t32.hip", "mlp64.hip", "gemm_ring.hip", "gemm_mx8.hip", "norm.hip", "attention.hip", "attn_block.hip", "embed.hip", "gnn.hip", "loss.hip", "optim.hip", "batch.hip", "decode.hip"]
 CPP_UNITS = ["engine.cpp", "capi.cpp", "tokenizer.cpp", "comm.cpp"]
 # -amdgpu-mfma-vgpr-form: MFMA results in VGPRs (gfx950 has one unified register file).  Where the compiler picked the AGPR form
 # (the attention forward kernels) 13 % of the instructions were v_accvgpr_read / write moves in a VALU-bound kernel
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-mllvm", "-amdgpu-mfma-vgpr-form=1"] + os.environ.get("COATI_AMD_CXXFLAGS", "").split()   # (probe builds: -DCOATI_RB_TRACE)
+
+
+# mlp64.hip: one wave per SIMD with 256 accumulation registers next to 256 ordinary ones -- it needs the AGPR form of the MFMA results
+UNIT_DROP_FLAGS = {"mlp64.hip": ("-mllvm", "-amdgpu-mfma-vgpr-form=1")}
 
 
 def _hipcc():
@@ -61,7 +65,8 @@ def _build_locked(verbose):
     def compile_one(unit):
         src = os.path.join(CSRC, unit)
         obj = os.path.join(OBJDIR, unit + ".o")
-        cmd = [hipcc] + FLAGS + (["-x", "hip"] if unit.endswith(".cpp") else []) + ["-c", src, "-o", obj]
+        flags = [f for f in FLAGS if f not in UNIT_DROP_FLAGS.get(unit, ())]
+        cmd = [hipcc] + flags + (["-x", "hip"] if unit.endswith(".cpp") else []) + ["-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed on {unit}:\n{r.stderr}")

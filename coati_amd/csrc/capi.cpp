@@ -21,6 +21,15 @@ int coati_gemm_nt(const void* A, int a_f32, int64_t lda, const uint16_t* B, int6
   return launch_gemm_nt(a, a_f32, epi, S_(stream));
 }
 
+int coati_mlp_fwd(const float* x, const float* gamma, const float* beta, uint16_t* a2, float* mean, float* rstd, const uint16_t* W1,
+                  const float* b1, const uint16_t* W2, const float* b2, uint16_t* g, uint8_t* codes, float* out, int M, void* stream) {
+  COATI_CHECK_SHAPE(M >= 1 && M <= 65536, "mlp_fwd: M=%d out of range", M);
+  Mlp64Args a;
+  a.x = x; a.ldx = 256; a.gamma = gamma; a.beta = beta; a.a2 = a2; a.mean = mean; a.rstd = rstd; a.W1 = W1; a.b1 = b1; a.W2 = W2; a.b2 = b2;
+  a.g = g; a.codes = codes; a.out = out; a.ldo = 256; a.M = M;
+  return launch_mlp64_fwd(a, S_(stream));
+}
+
 int coati_gemm_lnbwd(const uint16_t* dY, int64_t lda, const uint16_t* WT, int64_t ldw, int M, int K, const float* x, const float* mean,
                      const float* rstd, const float* gamma, const float* dres, float* dx, uint16_t* dx16, float* partial,
                      int32_t* n_partial_rows, const uint16_t* chain_W, uint16_t* chain_C, void* stream) {

@@ -116,6 +116,27 @@ bool gemm_rb16_resident_supported(const GemmArgs& a, int a_f32, int epi);
 int launch_gemm_rb16_resident(const GemmArgs& a, int epi, hipStream_t s);
 int launch_gemm_rb16(const GemmArgs& a, int epi, hipStream_t s);
 // the same products on 32-row slabs in the TRANSPOSED form (gemm_t32.hip, round 5): 24 577 .. 65 536 rows; taken before the 16-row slabs
+// the MLP half of a block as one launch (mlp64.hip): out = x + c_proj(NewGELU(c_fc(ln_2(x)))), d = 256, hidden 1024
+struct Mlp64Args {
+  const float* x;          // [M, ldx] f32: the residual stream in front of ln_2
+  long long ldx;
+  const float* gamma;      // ln_2
+  const float* beta;
+  bf16_t* a2;              // [M, 256] bf16: ln_2(x) (the c_fc weight gradient's operand)
+  float* mean;             // [M]
+  float* rstd;             // [M]
+  const bf16_t* W1;        // c_fc.weight [1024, 256]
+  const float* b1;         // [1024]
+  const bf16_t* W2;        // c_proj.weight [256, 1024]
+  const float* b2;         // [256]
+  bf16_t* g;               // [M, 1024] bf16: NewGELU(c_fc(.)) (the c_proj weight gradient's operand)
+  unsigned char* codes;    // [M, 1024]: NewGELU' as 8-bit fixed point (common.h)
+  float* out;              // [M, ldo] f32
+  long long ldo;
+  int M;
+};
+bool mlp64_fwd_supported(int M, int C, int hidden);
+int launch_mlp64_fwd(const Mlp64Args& a, hipStream_t s);
 bool gemm_t32_supported(const GemmArgs& a, int a_f32, int epi);
 int launch_gemm_t32(const GemmArgs& a, int epi, hipStream_t s);
 // ring kernel for N = 256, long K (gemm_ring.hip)

@@ -68,6 +68,22 @@ def gemm_lnbwd(dY, WT, x, mean, rstd, gamma, dres, want16=True, chain_W=None):
     return dx, dx16, s[:256], s[256:]
 
 
+def mlp_fwd(x, gamma, beta, W1, b1, W2, b2):
+    """out = x + c_proj(NewGELU(c_fc(ln_2(x)))) in one launch (coati_mlp_fwd): returns (out f32, a2 bf16, mean, rstd, g bf16, codes u8)."""
+    _need_cuda(x, W1, W2)
+    M = x.shape[0]
+    dev = x.device
+    a2 = torch.empty(M, 256, device=dev, dtype=BF16)
+    mean = torch.empty(M, device=dev, dtype=torch.float32)
+    rstd = torch.empty(M, device=dev, dtype=torch.float32)
+    g = torch.empty(M, 1024, device=dev, dtype=BF16)
+    codes = torch.empty(M, 1024, device=dev, dtype=torch.uint8)
+    out = torch.empty(M, 256, device=dev, dtype=torch.float32)
+    _lib.call("coati_mlp_fwd", ptr(x), ptr(gamma), ptr(beta), ptr(a2), ptr(mean), ptr(rstd), ptr(W1), ptr(b1), ptr(W2), ptr(b2), ptr(g), ptr(codes),
+              ptr(out), M, stream())
+    return out, a2, mean, rstd, g, codes
+
+
 def quant_mx8(x):
     """rows of bf16 / f32 x [M, K] -> (q [M, K] uint8 holding OCP e4m3, scales [M, K / 32] uint8 holding E8M0): MXFP8 blocks of 32 along k"""
     _need_cuda(x)

@@ -61,6 +61,13 @@ int coati_gemm_nt(const void* A, int a_f32, int64_t lda, const uint16_t* B, int6
                   void* C, int64_t ldc, int n_store, const float* bias, const void* aux_in, void* aux_out,
                   int64_t ld_aux, int epi, void* stream);
 
+/* The MLP half of a transformer block as one launch (mlp64.hip): out = x + c_proj(NewGELU(c_fc(ln_2(x)))) for d = 256, hidden 1024
+ * (basic_transformer.py:103-123, 165-169 forward).  x [M, 256] f32; W1 = c_fc.weight [1024, 256], W2 = c_proj.weight [256, 1024] (bf16);
+ * also written: a2 = ln_2(x) (bf16), mean / rstd [M], g = NewGELU(c_fc(.)) [M, 1024] bf16, codes = NewGELU' as 8-bit fixed point [M, 1024]
+ * -- what the backward reads.  Replaces nn.LayerNorm + two F.linear + NewGELU + the residual add.  24 577 .. 65 536 rows. */
+int coati_mlp_fwd(const float* x, const float* gamma, const float* beta, uint16_t* a2, float* mean, float* rstd, const uint16_t* W1,
+                  const float* b1, const uint16_t* W2, const float* b2, uint16_t* g, uint8_t* codes, float* out, int M, void* stream);
+
 /* An input-gradient product whose result is the gradient w.r.t. a LayerNorm's OUTPUT, with that LayerNorm's backward in the
  * product's write-out (c_fc -> ln_2 and c_attn -> ln_1 of basic_transformer.py:162-174): dy = dY[M,K] WT[256,K]^T never visits
  * memory; dx[M,256] (f32) = dres + LayerNorm-backward(dy | x, mean, rstd, gamma) (dx may be dres: in place), dx16 (optional) its
