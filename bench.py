@@ -358,8 +358,9 @@ def main():
         comm["per_rank_ms_per_step"] = per_rank_ms
         sch = getattr(eng, "_dp_schedule", None)
         comm["backward_schedule"] = {"decided": bool(sch is not None and sch.decided), "encoder_stage": ("two halves" if (sch is not None and sch.split) else "one piece"),
-                                     "forced_by_env": os.environ.get("COATI_DP_SPLIT")}
-        wire = os.environ.get("COATI_DP_WIRE", "fp32")
+                                     "candidates": [("two halves" if c[0] else "one piece") + (" + bf16 wire" if c[1] == "bf16" else "") for c in (sch.cands if sch is not None else [])],
+                                     "forced_by_env": {"COATI_DP_SPLIT": os.environ.get("COATI_DP_SPLIT"), "COATI_DP_WIRE": os.environ.get("COATI_DP_WIRE")}}
+        wire = sch.wire if sch is not None else os.environ.get("COATI_DP_WIRE", "fp32")
         comm["gradient_wire_format"] = wire
         comm["gradient_bytes_per_rank_MB"] = {k: round(v / 1e6, 2) for k, v in D.wire_bytes_per_rank(eng, wire).items()}
         comm["embedding_exchange_bytes_per_rank_MB"] = round(2 * 2 * args.batch * eng.cfg.n_embd_common * 4 / 1e6, 3)   # all-gather of h_smiles, h_e3gnn + reduce-scatter of their gradients (fp32)

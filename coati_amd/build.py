@@ -10,7 +10,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libcoati_hip.so")
 OBJDIR = os.path.join(HERE, "build")
-HIP_UNITS = ["gemm.hip", "gemm_rb.hip", "gemm_rb16.hip", "gemm_t32.hip", "mlp64.hip", "gemm_ring.hip", "gemm_mx8.hip", "norm.hip", "attention.hip", "attn_block.hip", "embed.hip", "gnn.hip", "loss.hip", "optim.hip", "batch.hip", "decode.hip"]
+HIP_UNITS = ["gemm.hip", "gemm_rb.hip", "gemm_rb16.hip", "gemm_t32.hip", "mlp64.hip", "gemm_ring.hip", "gemm_mx8.hip", "norm.hip", "attention.hip", "attention16.hip", "attn_block.hip", "embed.hip", "gnn.hip", "loss.hip", "optim.hip", "batch.hip", "decode.hip"]
 CPP_UNITS = ["engine.cpp", "capi.cpp", "tokenizer.cpp", "comm.cpp"]
 # -amdgpu-mfma-vgpr-form: MFMA results in VGPRs (gfx950 has one unified register file).  Where the compiler picked the AGPR form
 # (the attention forward kernels) 13 % of the instructions were v_accvgpr_read / write moves in a VALU-bound kernel

@@ -244,6 +244,10 @@ int launch_attn_fwd(const bf16_t* qkv, bf16_t* y, float* lse, int B, int T, int 
 int launch_attn_bwd(const bf16_t* qkv, const bf16_t* y, const bf16_t* dy, const float* lse, float* dscratch, bf16_t* dqkv,
                     const float* cos, const float* sin, int B, int T, int n_head, int head_size, hipStream_t s,
                     const int* seq_off = nullptr);
+// head size 16, T <= 128 on 16-row causal granularity (attention16.hip); launch_attn_fwd / _bwd route there
+int launch_attn16_fwd(const bf16_t* qkv, bf16_t* y, float* lse, int B, int T, int n_head, hipStream_t s, const int* seq_off);
+int launch_attn16_bwd(const bf16_t* qkv, const bf16_t* y, const bf16_t* dy, const float* lse, bf16_t* dqkv, const float* cos_t,
+                      const float* sin_t, int B, int T, int n_head, hipStream_t s, const int* seq_off);
 
 // The attention half of a block as one sequence-stationary kernel (attn_block.hip): xmid = x + c_proj(attention(RoPE(c_attn(ln_1(x))))),
 // d = 256, 16 heads of 16, sequences of <= 128 rows.  Saves what the backward reads: a1 = ln_1(x), mean / rstd, qkv (q, k rotated), y, lse.

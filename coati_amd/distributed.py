@@ -123,7 +123,8 @@ def grad_buckets(eng):
     lm0 = lay["xformer.lm_head.weight"][0]
     L = sum(1 for k in lay if k.startswith("xformer.transformer.h.") and k.endswith(".ln_1.weight"))
     mid = lay[f"xformer.transformer.h.{L // 2}.ln_1.weight"][0]   # first entry of layer L/2: [0, mid) = embeddings + lower layers
-    pe0 = lay["point_encoder.embedding.weight"][0]
+    # first entry of the point encoder: `embedding.weight` (one-hot Linear) or, with torch_emb=True, `emb.weight` (e3gnn_clip.py:49-56)
+    pe0 = min(off for k, (off, _) in lay.items() if k.startswith("point_encoder."))
     lm1 = lm0 + lay["xformer.lm_head.weight"][1][0] * lay["xformer.lm_head.weight"][1][1]
     lm1 = min([off for k, (off, _) in lay.items() if off >= lm1], default=eng.n_params)   # first entry behind lm_head (alignment gap included)
     if pe0 > lm0:
@@ -133,13 +134,45 @@ def grad_buckets(eng):
     return {"xformer_lo": (0, mid), "xformer_hi": (mid, pe0), "gnn": (pe0, lm0), "lm_head": (lm0, lm1), "heads": (lm1, eng.n_params)}
 
 
-# Encoder stage of the staged backward in one piece or in two halves (see distributed_train_step).  COATI_DP_SPLIT=0 | 1 forces a
-# schedule; unset, the schedule is MEASURED per engine: after 3 warm-up steps three steps of each form are timed with device
-# events around the step (no host synchronisation until the decision) and the faster one -- MAX over ranks through the host-side
-# control group, so that every rank picks the same -- is kept.  The state lives on the engine (a second engine, or an eval step
-# in between, does not share counters).
+# Schedule of the data-parallel backward: (encoder stage in one piece | in two halves) x (fp32 | bf16 wire of the transformer bucket).
+# COATI_DP_SPLIT=0 | 1 forces the split, COATI_DP_WIRE=fp32 | bf16 the wire; what is not forced is MEASURED per engine: after 3 warm-up
+# steps three steps of each candidate are timed with device events around the step (no host synchronisation until the decision) and
+# the fastest one -- MAX over ranks through the host-side control group, so that every rank picks the same -- is kept.  The bf16 wire
+# costs one bf16 rounding per gradient element: it is only taken when it beats the best fp32 candidate by more than WIRE_MARGIN.
+# The state lives on the engine (a second engine, or an eval step in between, does not share counters).
 _SPLIT_ENV = os.environ.get("COATI_DP_SPLIT")
+_WIRE_ENV = os.environ.get("COATI_DP_WIRE")
 _SPLIT_ENCODER_STAGE = _SPLIT_ENV == "1"      # the schedule of every engine that has not measured one
+WIRE_MARGIN = 0.03
+
+
+def schedule_candidates(split_env=None, wire_env=None):
+    """[(split, wire)] the vote runs over: {one piece, two halves, two halves + bf16 wire} minus what the environment pins"""
+    c = [(False, "fp32"), (True, "fp32"), (True, "bf16")]
+    if split_env is not None:
+        c = [(bool(split_env == "1"), w) for w in ("fp32", "bf16")]
+    if wire_env is not None:
+        c = [x for x in c if x[1] == wire_env] or [(bool(split_env == "1"), wire_env)]
+    out = []
+    for x in c:
+        if x not in out:
+            out.append(x)
+    return out
+
+
+def schedule_pick(cands, ms, margin=WIRE_MARGIN):
+    """index of the candidate to keep, from the per-candidate times (already MAX-reduced over the ranks: every rank evaluates this
+    on identical numbers, so every rank returns the same index): the fastest fp32-wire candidate, unless a bf16-wire candidate is more
+    than `margin` faster than it"""
+    f32 = [i for i, c in enumerate(cands) if c[1] == "fp32"]
+    b16 = [i for i, c in enumerate(cands) if c[1] == "bf16"]
+    best32 = min(f32, key=lambda i: (ms[i], i)) if f32 else None
+    best16 = min(b16, key=lambda i: (ms[i], i)) if b16 else None
+    if best32 is None:
+        return best16
+    if best16 is not None and ms[best16] < (1.0 - margin) * ms[best32]:
+        return best16
+    return best32
 
 
 class _Schedule:
@@ -147,9 +180,10 @@ class _Schedule:
 
     def __init__(self):
         self.step = 0
-        self.events = [[], []]          # per form: (begin, end) device-event pairs
-        self.decided = _SPLIT_ENV is not None
-        self.split = _SPLIT_ENCODER_STAGE
+        self.cands = schedule_candidates(_SPLIT_ENV, _WIRE_ENV)
+        self.events = [[] for _ in self.cands]          # per candidate: (begin, end) device-event pairs
+        self.decided = len(self.cands) == 1
+        self.split, self.wire = self.cands[0] if self.decided else (_SPLIT_ENCODER_STAGE, _WIRE_ENV or "fp32")
 
 
 def _measurable():
@@ -158,39 +192,47 @@ def _measurable():
 
 
 def _schedule_begin(eng):
-    """returns (use_split, timing slot or None) for this step of this engine"""
+    """returns (use_split, wire, timing slot or None) for this step of this engine"""
     sch = getattr(eng, "_dp_schedule", None)
     if sch is None:
         sch = eng._dp_schedule = _Schedule()
-    if sch.decided or not _measurable() or sch.step >= sch.WARMUP + 2 * sch.PER_FORM:
+    n = len(sch.cands)
+    if sch.decided or not _measurable() or sch.step >= sch.WARMUP + n * sch.PER_FORM:
         # (the last clause: a measurement that never reached its decision -- an exception in between -- stops allocating events)
-        return (sch.split if sch.decided and _SPLIT_ENV is None else _SPLIT_ENCODER_STAGE), None
+        return sch.split, sch.wire, None
     k = sch.step
     sch.step += 1
     if k < sch.WARMUP:
-        return False, None
-    form = 0 if k - sch.WARMUP < sch.PER_FORM else 1
+        return sch.split, sch.wire, None
+    form = (k - sch.WARMUP) // sch.PER_FORM
     ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
     ev[0].record()
     sch.events[form].append(ev)
-    return form == 1, form
+    return sch.cands[form][0], sch.cands[form][1], form
 
 
 def _schedule_end(eng, slot):
     if slot is None:
         return
     sch = eng._dp_schedule
+    n = len(sch.cands)
     sch.events[slot][-1][1].record()
-    if sch.step == sch.WARMUP + 2 * sch.PER_FORM:
+    if sch.step == sch.WARMUP + n * sch.PER_FORM:
         torch.cuda.synchronize()
-        t = torch.tensor([sum(a.elapsed_time(b) for a, b in sch.events[f]) for f in (0, 1)], dtype=torch.float64)
+        t = torch.tensor([sum(a.elapsed_time(b) for a, b in sch.events[f]) / sch.PER_FORM for f in range(n)], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=control_group())
-        sch.split = bool(t[1] < t[0])
+        ms = [float(x) for x in t]
+        k = schedule_pick(sch.cands, ms)
+        sch.split, sch.wire = sch.cands[k]
         sch.decided = True
-        sch.events = [[], []]
+        sch.events = [[] for _ in sch.cands]
         if dist.get_rank() == 0:
-            print(f"[coati_amd.distributed] encoder stage of the data-parallel backward: one piece {float(t[0]) / sch.PER_FORM:.3f} ms/step, "
-                  f"two halves {float(t[1]) / sch.PER_FORM:.3f} ms/step -> {'two halves' if sch.split else 'one piece'}", file=sys.stderr, flush=True)
+            def name(c):
+                return ("two halves" if c[0] else "one piece") + (" + bf16 wire" if c[1] == "bf16" else "")
+            print("[coati_amd.distributed] data-parallel backward schedule (ms/step, MAX over ranks): "
+                  + ", ".join(f"{name(c)} {m:.3f}" for c, m in zip(sch.cands, ms)) + f" -> {name(sch.cands[k])}"
+                  + (f" (the bf16 wire must win by more than {WIRE_MARGIN:.0%})" if any(c[1] == "bf16" for c in sch.cands) else ""),
+                  file=sys.stderr, flush=True)
 
 
 def distributed_train_step(eng, batch, use_point, lr, do_clip=True, optimizer=True, head="infonce", reduce_grads=True,
@@ -201,12 +243,12 @@ def distributed_train_step(eng, batch, use_point, lr, do_clip=True, optimizer=Tr
     opt_kw: weight_decay / max_norm / betas / eps for Engine.optimizer_step (train_coati.py:145-151, 276)."""
     W, rank = dist.get_world_size(), dist.get_rank()
     if reduce_grads and optimizer:
-        split_stage, slot = _schedule_begin(eng)
+        split_stage, wire_sched, slot = _schedule_begin(eng)
     else:
         # not a timed step (bench.py's exposed-cost loops, eval-like calls): the schedule the engine has decided on, if any -- so that
         # a comparison of two loops compares the SAME backward schedule
         sch = getattr(eng, "_dp_schedule", None)
-        split_stage, slot = ((sch.split if (sch is not None and sch.decided and _SPLIT_ENV is None) else _SPLIT_ENCODER_STAGE), None)
+        split_stage, wire_sched, slot = (sch.split, sch.wire, None) if (sch is not None and sch.decided) else (_SPLIT_ENCODER_STAGE, _WIRE_ENV or "fp32", None)
     h_e, h_s, bad = eng.forward(batch["raw_tokens"], batch["tokens"], batch["atoms"], batch["coords"], use_point,
                                 y_next=batch["y_next"], train=True, rows=batch.get("rows"), stop_after_heads=True)
     B = h_e.shape[0]
@@ -240,7 +282,7 @@ def distributed_train_step(eng, batch, use_point, lr, do_clip=True, optimizer=Tr
             err_work = dist.all_reduce(err_bits, op=dist.ReduceOp.MAX, async_op=True)
     bk = grad_buckets(eng)
     works = []
-    wire = opt_kw.pop("wire", None) or os.environ.get("COATI_DP_WIRE", "fp32")
+    wire = opt_kw.pop("wire", None) or wire_sched
 
     def launch(*names):
         """ONE collective over the named buckets (adjacent in the flat buffer).  wire = "bf16" (COATI_DP_WIRE=bf16): the transformer
@@ -255,10 +297,14 @@ def distributed_train_step(eng, batch, use_point, lr, do_clip=True, optimizer=Tr
                 a, b = min(bk[n][0] for n in grp), max(bk[n][1] for n in grp)
                 assert sum(bk[n][1] - bk[n][0] for n in grp) == b - a, grp
                 if b > a and wire == "bf16" and grp[0].startswith("xformer_"):
+                    # the staging buffer spans the WHOLE transformer range and every collective stages into ITS OWN slice of it: in
+                    # the two-halves schedule both halves are in flight before either is waited for (round-5 advisor: one buffer
+                    # sliced from offset 0 let the second copy overwrite the first collective's memory)
+                    x0, x1 = bk["xformer_lo"][0], bk["xformer_hi"][1]
                     st = getattr(eng, "_wire16", None)
-                    if st is None or st.numel() < b - a:
-                        st = eng._wire16 = torch.empty(b - a, device=eng.grads.device, dtype=torch.bfloat16)
-                    works.append(_Bf16Wire(eng.grads[a:b], st[:b - a]))
+                    if st is None or st.numel() != x1 - x0:
+                        st = eng._wire16 = torch.empty(x1 - x0, device=eng.grads.device, dtype=torch.bfloat16)
+                    works.append(_Bf16Wire(eng.grads[a:b], st[a - x0:b - x0]))
                 elif b > a:
                     works.append(all_reduce_avg_async(eng.grads[a:b]))
 

@@ -28,8 +28,14 @@ TOL_CURVE = 8e-3         # 20-step curve: measured 3.4e-3 (loss), 1.7e-3 (ar), 4
 # within 4e-3.  The engine measured 2.7e-1 at step 11, median 4.6e-2.  So: the first five steps (norm > 90, well conditioned) are
 # held tightly, the rest to 2x that envelope plus a median bound.
 TOL_CURVE_GN_EARLY = 1.4e-2   # steps 0..4: measured 6.5e-3
-TOL_CURVE_GN_MAX = 4.6e-1
-TOL_CURVE_GN_MEDIAN = 9e-2
+# Round 6: the bound of the later steps is RELATIVE to what rounding alone does to this trajectory -- tests/golden/grande_curve_envelope.json
+# (tools/curve_bf16_sim_grande.py --envelope: per step, the largest deviation of the bf16-storage-simulating oracle and of three fp32
+# oracles started from weights perturbed by 1e-3): step i is held to ENVELOPE_FACTOR x envelope[i] (never tighter than the early-step
+# bound), the median over the steps to the envelope's own median.  The mid-curve step itself is pinned WITHOUT trajectory noise by
+# test_mid_curve_step_from_replayed_weights below.
+ENVELOPE_FACTOR = 3.0
+TOL_MID_GRADNORM_MEDIAN = 2.5e-3   # per-parameter gradient norms at step 10 from the replayed weights: measured 1.04e-3 (the bf16-storage-simulating oracle: 3.6e-3)
+TOL_MID_GRADNORM_MAX = 8e-3        # measured 3.3e-3 (bf16-sim oracle: 5.3e-3)
 
 
 @pytest.fixture(scope="module")
@@ -160,8 +166,11 @@ def _mid_curve_grad_norms(g, names, eng, layout):
     for i, n_ in enumerate(names):
         if ref[i] > 0:
             dev.append(abs(float(grads[n_].double().norm()) - ref[i]) / ref[i])
-    log(f"grande mid-curve gradient norms [{layout}] (step 10, {len(dev)} parameters): median deviation {np.median(dev):.3e}, 90th percentile {np.percentile(dev, 90):.3e}")
-    assert np.median(dev) <= 0.15, np.median(dev)     # measured 7.2e-2 (padded), 2.0e-2 (packed): the clip-norm there is ~ 5, see TOL_CURVE_GN_*
+    log(f"grande mid-curve gradient norms [{layout}] (step 10, {len(dev)} parameters, along the engine's OWN trajectory): median deviation {np.median(dev):.3e}, 90th percentile {np.percentile(dev, 90):.3e}")
+    # along the engine's own ten-step trajectory this number is trajectory noise (rounds 5-6 measured 2.0e-2 .. 1.5e-1 for arithmetic-
+    # equivalent kernels; the total gradient norm's envelope around this step is 0.25): logged, and bounded only against a
+    # backward that has gone wrong altogether.  The tight statement is test_mid_curve_step_from_replayed_weights.
+    assert np.median(dev) <= 0.5, np.median(dev)
 
 
 @pytest.mark.parametrize("layout", ["padded", "packed"])
@@ -193,7 +202,61 @@ def test_twenty_step_loss_curve_grande_vs_reference(gr, layout):
         assert dev_[k].max() <= TOL_CURVE, (k, dev_[k].max())
     log("grande 20-step curve: gradnorm deviation per step " + " ".join(f"{x:.1e}" for x in dev_["gradnorm"]))
     assert dev_["gradnorm"][:5].max() <= TOL_CURVE_GN_EARLY, dev_["gradnorm"][:5]
-    assert dev_["gradnorm"].max() <= TOL_CURVE_GN_MAX and np.median(dev_["gradnorm"]) <= TOL_CURVE_GN_MEDIAN, dev_["gradnorm"]
+    import json, os
+    env = np.array(json.load(open(os.path.join(os.path.dirname(__file__), "golden", "grande_curve_envelope.json")))["gradnorm_dev_max_per_step"])[:n]
+    # (an excursion's phase along the trajectory is as unpredictable as its size -- the four envelope runs peak at steps 9, 11-13, 15 --
+    #  so step i is held to the envelope's largest value within two steps of it)
+    env = np.array([env[max(0, i - 2):i + 3].max() for i in range(len(env))])
+    bound = np.maximum(ENVELOPE_FACTOR * env, TOL_CURVE_GN_EARLY)
+    bound[:5] = TOL_CURVE_GN_EARLY
+    log("grande 20-step curve: bound per step (3 x rounding envelope)  " + " ".join(f"{x:.1e}" for x in bound))
+    assert (dev_["gradnorm"] <= bound).all(), (dev_["gradnorm"] / bound)
+    assert np.median(dev_["gradnorm"]) <= np.median(env), (np.median(dev_["gradnorm"]), np.median(env))
+
+
+@pytest.mark.parametrize("layout", ["padded", "packed"])
+def test_mid_curve_step_from_replayed_weights(gr, layout):
+    """The mid-curve pin without trajectory noise.  The ORACLE (fp32, host) replays the reference's first ten optimiser steps -- it
+    reproduces the reference's curve to 8e-5 (tools/curve_bf16_sim_grande.py), and the weights it arrives at are checked here against
+    the strided sample of the reference's step-10 weights the fixture holds -- then the ENGINE evaluates ONE step from those weights
+    and every parameter's gradient norm is compared with the reference's at that step (`mid_grad_norms`).  A backward that is wrong
+    shows in all of them; ten steps of rounding history do not enter."""
+    from oracle import coati_oracle as O
+    g, ocfg, P, names, batches, masks, eng, db = gr
+    mid = int(g["mid_step"])
+    cache = getattr(test_mid_curve_step_from_replayed_weights, "_w", None)
+    if cache is None:
+        torch.set_num_threads(min(32, torch.get_num_threads()))
+        W = {k: v.clone() for k, v in P.items()}
+        M = {k: torch.zeros_like(v) for k, v in W.items()}
+        V = {k: torch.zeros_like(v) for k, v in W.items()}
+        for step in range(mid):
+            Pg = {k: v.clone().requires_grad_(True) for k, v in W.items()}
+            loss, *_ = O.step_loss(Pg, ocfg, batches[step % 4], masks[step])
+            loss.backward()
+            grads = {k: (Pg[k].grad if Pg[k].grad is not None else torch.zeros_like(Pg[k])) for k in Pg}
+            norm, coef = O.clip_grad_norm(grads, 10.0)
+            assert abs(float(norm) - float(g["curve_gradnorm"][step])) <= 2e-3 * float(g["curve_gradnorm"][step]), (step, float(norm))
+            for k in W:
+                if "coord_mlp" in k:
+                    continue
+                W[k], M[k], V[k] = O.adamw_update(W[k], grads[k] * coef, M[k], V[k], step=step + 1, lr=5e-4)
+        worst = max(float((W[n_].flatten()[::97] - torch.from_numpy(g["mid.w." + n_])).abs().max()) for n_ in names)
+        log(f"grande replayed weights at step {mid} vs the reference's strided sample: max |difference| {worst:.2e}")
+        assert worst <= 4e-5, worst      # measured 1.1e-5 (ten AdamW steps of fp32 summation-order differences between hosts)
+        test_mid_curve_step_from_replayed_weights._w = cache = W
+    db = _layout(db, batches, layout)
+    eng.load_state_dict(cache)
+    eng.train_step(db[mid % 4], masks[mid].to(DEV), lr=0.0, optimizer=False)
+    L = eng.losses()
+    grads = eng.named_views("grads")
+    ref = g["mid_grad_norms"]
+    dev = np.array([abs(float(grads[n_].double().norm()) - ref[i]) / ref[i] for i, n_ in enumerate(names) if ref[i] > 0])
+    log(f"grande step {mid} from the replayed weights [{layout}]: loss {L['loss']:.5f} (reference {float(g['curve_loss'][mid]):.5f}); per-parameter gradient norms: "
+        f"median deviation {np.median(dev):.3e}, 90th percentile {np.percentile(dev, 90):.3e}, max {dev.max():.3e}")
+    check(f"grande step {mid} loss from replayed weights [{layout}]", torch.tensor([L["loss"]]), torch.tensor([float(g["curve_loss"][mid])]), TOL_LOSS)
+    assert np.median(dev) <= TOL_MID_GRADNORM_MEDIAN and dev.max() <= TOL_MID_GRADNORM_MAX, (np.median(dev), dev.max())
+    eng.load_state_dict(P)
 
 
 def test_grande_step_vs_oracle_fp32_and_bf16_sim(gr):

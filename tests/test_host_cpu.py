@@ -333,8 +333,9 @@ def test_optimizer_arguments_reach_the_optimizer():
 
 
 def test_measured_dp_schedule_is_per_engine_and_decided_once(monkeypatch):
-    """The run-time choice between one encoder stage and two halves (coati_amd.distributed._Schedule): 3 warm-up steps, 3 timed
-    steps of each form (device events), MAX over ranks, then the faster form for good -- with the backend check and the device
+    """The run-time choice between {one encoder stage, two halves, two halves + bf16 wire} (coati_amd.distributed._Schedule): 3 warm-up
+    steps, 3 timed steps of each candidate (device events), MAX over ranks, then the winner for good (the bf16 wire only when it is
+    more than WIRE_MARGIN ahead of the best fp32 candidate) -- with the backend check and the device
     events replaced by host stand-ins so that the counters, the vote and the decision run on CPU.  The state belongs to the
     engine: a second engine starts its own measurement, an evaluation step in between does not advance it."""
     import torch.distributed as dist
@@ -356,6 +357,7 @@ def test_measured_dp_schedule_is_per_engine_and_decided_once(monkeypatch):
 
     monkeypatch.setattr(D, "_measurable", lambda: True)
     monkeypatch.setattr(D, "_SPLIT_ENV", None)
+    monkeypatch.setattr(D, "_WIRE_ENV", None)
     monkeypatch.setattr(torch.cuda, "Event", FakeEvent)
     monkeypatch.setattr(torch.cuda, "synchronize", lambda *a, **k: None)
     monkeypatch.setattr(D, "control_group", lambda: None)
@@ -381,15 +383,60 @@ def test_measured_dp_schedule_is_per_engine_and_decided_once(monkeypatch):
         assert [run(e1) for _ in range(3)] == [[1, 2, 3]] * 3      # form 0 timed
         assert run(e2) == [1, 2, 3] and e2._dp_schedule.step == 1   # another engine: its own counters
         assert [run(e1) for _ in range(3)] == [[1, 4, 5, 3]] * 3   # form 1 timed
-        assert e1._dp_schedule.decided and e1._dp_schedule.split    # 3 ms < 5 ms: two halves
+        assert not e1._dp_schedule.decided
+        assert [run(e1) for _ in range(3)] == [[1, 4, 5, 3]] * 3   # form 2 (two halves + bf16 wire) timed
+        # 3 ms < 5 ms: two halves; the bf16 wire is no faster here (the stand-in has no wire), so the fp32 wire stays
+        assert e1._dp_schedule.decided and e1._dp_schedule.split and e1._dp_schedule.wire == "fp32"
         assert run(e1) == [1, 4, 5, 3] and run(e1) == [1, 4, 5, 3]
         assert not e2._dp_schedule.decided
         clock["cost"] = {False: 2.0, True: 3.0}                    # on e2 the one-piece form wins
-        for _ in range(8):
+        for _ in range(11):
             run(e2)
         assert e2._dp_schedule.decided and not e2._dp_schedule.split and run(e2) == [1, 2, 3]
     finally:
         dist.destroy_process_group()
+
+
+def test_dp_schedule_candidates_and_pick():
+    """what the vote runs over, and the rule it decides by (every rank applies it to the same MAX-reduced numbers)"""
+    from coati_amd import distributed as D
+    three = [(False, "fp32"), (True, "fp32"), (True, "bf16")]
+    assert D.schedule_candidates(None, None) == three
+    assert D.schedule_candidates("0", None) == [(False, "fp32"), (False, "bf16")]
+    assert D.schedule_candidates(None, "fp32") == [(False, "fp32"), (True, "fp32")]
+    assert D.schedule_candidates("1", "bf16") == [(True, "bf16")]
+    assert D.schedule_candidates(None, "bf16") == [(True, "bf16")]
+    assert D.schedule_pick(three, [10.0, 9.0, 8.9]) == 1            # bf16 1 % ahead: not worth a rounding per element
+    assert D.schedule_pick(three, [10.0, 9.0, 8.5]) == 2            # 5.6 % ahead
+    assert D.schedule_pick(three, [8.0, 9.0, 8.5]) == 0
+    assert D.schedule_pick(three, [9.0, 9.0, 9.0]) == 0             # ties go to the first (simplest) candidate
+    assert D.schedule_pick([(True, "bf16")], [1.0]) == 0
+
+
+def test_grad_buckets_tile_the_buffer_for_every_flag_layout():
+    """grad_buckets on layouts as build_layout (csrc/engine.cpp) produces them for the constructor flags: torch_emb renames the
+    point encoder's first entry (`emb.weight`, round-5 advisor: a hard-coded `embedding.weight` raised KeyError under data
+    parallelism), use_point_encoder=False moves the point encoder behind the trainable range"""
+    from coati_amd import distributed as D
+    import types
+
+    def eng(pe_key, pe_first=True):
+        lay = {"xformer.emb.tok_emb.weight": (0, (4, 4)), "xformer.transformer.h.0.ln_1.weight": (64, (4,)),
+               "xformer.transformer.h.1.ln_1.weight": (128, (4,))}
+        if pe_first:
+            lay.update({pe_key: (192, (4, 4)), "point_encoder.node_dec.0.weight": (224, (4, 4)), "xformer.lm_head.weight": (256, (4, 4)),
+                        "point_to_clip.0.weight": (320, (4,)), "smiles_to_clip.0.weight": (352, (4,))})
+        else:
+            lay.update({"xformer.lm_head.weight": (192, (4, 4)), "smiles_to_clip.0.weight": (256, (4,)), pe_key: (320, (4, 4)),
+                        "point_encoder.node_dec.0.weight": (352, (4, 4))})
+        return types.SimpleNamespace(layout=lay, n_params=384)
+    for key in ("point_encoder.embedding.weight", "point_encoder.emb.weight"):
+        for first in (True, False):
+            bk = D.grad_buckets(eng(key, first))
+            r = sorted(bk.values())
+            assert r[0][0] == 0 and r[-1][1] == 384 and all(a[1] == b[0] for a, b in zip(r, r[1:])), (key, first, bk)
+            assert bk["gnn"][0] == (192 if first else 320)
+            assert set(D.wire_bytes_per_rank(eng(key, first), "bf16")) == set(bk)
 
 
 def test_trainer_passes_args_to_the_step():
