@@ -558,6 +558,13 @@ def main():
                 "alg_GB_per_step": round(be / 1e9, 2), "alg_GBps": round(be / t_step / 1e9, 1),
                 "hbm_frac": round(be / t_step / 1e9 / PEAK_HBM_GBS, 4),
                 "note": "same formulas on the rows' real lengths (attention t x t per row, lm_head on the decoder pass's real rows)"}
+            if MODEL["n_hidden_xformer"] // MODEL["n_head"] == 16 and max(T1, T2) <= 128:
+                from coati_amd.synthetic import attention_score_efficiency
+                both = torch.cat([l1, l2])
+                out["attention"] = {"useful_over_computed": round(attention_score_efficiency(both, 16), 4),
+                                    "useful_over_computed_32_row_blocks": round(attention_score_efficiency(both, 32), 4),
+                                    "note": "score elements of the causal triangle / score elements the kernel evaluates, both passes: head size 16 runs on "
+                                            "16-row blocks of v_mfma_f32_16x16x16_bf16 since round 6 (csrc/attention16.hip); rounds 1-5: 32-row blocks"}
         out.update(extras)
         if comm is not None:
             out["comm"] = comm

@@ -30,7 +30,6 @@ _SIGS = {
     "coati_reducescatter_rows": [P, P, P, L, L, I, P],
     "coati_allreduce_bucket": [P, P, L, I, I, P],
     "coati_gemm_nt": [P, I, L, P, L, I, I, I, P, L, I, P, P, P, L, I, P],
-    "coati_mlp_fwd": [P, P, P, P, P, P, P, P, P, P, P, P, P, I, P],
     "coati_gemm_lnbwd": [P, L, P, L, I, I, P, P, P, P, P, P, P, P, POINTER(c_int32), P, P, P],
     "coati_quant_mx8": [P, I, L, P, L, P, I, I, P],
     "coati_gemm_mx8": [P, L, P, P, L, P, I, I, I, P, L, P, P, P, L, I, P],
@@ -89,10 +88,6 @@ _SIGS = {
     "coati_seq_pack": [P, P, I, I, I, I, P, P, P, P, P, P],
     "coati_attn_fwd_varlen": [P, P, P, P, I, I, I, I, P],
     "coati_attn_bwd_varlen": [P, P, P, P, P, P, P, P, P, I, I, I, I, P],
-    "coati_attn_groups": [P, I, I, P, P],
-    "coati_attn_block_fwd": [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, P],
-    "coati_ab_probe_swap": [P, P],
-    "coati_ab_trace_read": [P],
     "coati_engine_logits": [P, P, L, P],
     "coati_engine_encode": [P, P, L, I, I, I, P, P, P, P, P, P, P],
     "coati_engine_infonce": [P, P, P, P, P, P, I, I, I, F, P, P, P, P],
@@ -108,8 +103,21 @@ _SIGS = {
     "coati_engine_prof_last_bytes": [P, POINTER(c_double)],
 }
 
+# operators of csrc/experimental/ -- only in libcoati_hip_x.so (COATI_AMD_EXPERIMENTAL=1, build.py); bound when the loaded library has them
+_EXPERIMENTAL_SIGS = {
+    "coati_mlp_fwd": [P, P, P, P, P, P, P, P, P, P, P, P, P, I, P],
+    "coati_attn_groups": [P, I, I, P, P],
+    "coati_attn_block_fwd": [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, P],
+    "coati_ab_probe_swap": [P, P],
+    "coati_ab_trace_read": [P],
+}
+
 _lib = None
 ABI_VERSION = 5
+
+
+def has_experimental():
+    return hasattr(lib(), "coati_attn_block_fwd")
 
 
 def lib():
@@ -143,6 +151,10 @@ def lib():
         fn = getattr(l, name)
         fn.argtypes = sig
         fn.restype = c_int
+    for name, sig in _EXPERIMENTAL_SIGS.items():
+        if hasattr(l, name):
+            getattr(l, name).argtypes = sig
+            getattr(l, name).restype = c_int
     l.coati_engine_destroy.argtypes = [P]
     l.coati_engine_destroy.restype = None
     for name in ("coati_engine_param_elems", "coati_engine_shadow_elems", "coati_engine_trainable_elems"):
@@ -176,7 +188,7 @@ def lib():
 
 
 def exported_symbols():
-    return sorted(list(_SIGS) + ["coati_last_error", "coati_abi_version", "coati_engine_destroy",
+    return sorted(list(_SIGS) + (list(_EXPERIMENTAL_SIGS) if _build.EXPERIMENTAL else []) + ["coati_last_error", "coati_abi_version", "coati_engine_destroy",
                                  "coati_engine_param_elems", "coati_engine_shadow_elems", "coati_engine_trainable_elems",
                                  "coati_engine_workspace_bytes", "coati_engine_decode_workspace_bytes", "coati_engine_n_entries",
                                  "coati_wgrad_grouped_workspace_bytes", "coati_engine_fp8_bytes",
@@ -192,4 +204,6 @@ def check(rc, what=""):
 
 
 def call(name, *args):
+    if name in _EXPERIMENTAL_SIGS and not hasattr(lib(), name):
+        raise RuntimeError(f"libcoati_hip: {name} is an operator of csrc/experimental/ -- build and load with COATI_AMD_EXPERIMENTAL=1")
     check(getattr(lib(), name)(*args), name)

@@ -8,17 +8,26 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
-LIB = os.path.join(LIBDIR, "libcoati_hip.so")
+LIB = os.path.join(LIBDIR, "libcoati_hip_x.so" if os.environ.get("COATI_AMD_EXPERIMENTAL") == "1" else "libcoati_hip.so")
 OBJDIR = os.path.join(HERE, "build")
-HIP_UNITS = ["gemm.hip", "gemm_rb.hip", "gemm_rb16.hip", "gemm_t32.hip", "mlp64.hip", "gemm_ring.hip", "gemm_mx8.hip", "norm.hip", "attention.hip", "attention16.hip", "attn_block.hip", "embed.hip", "gnn.hip", "loss.hip", "optim.hip", "batch.hip", "decode.hip"]
+HIP_UNITS = ["gemm.hip", "gemm_rb.hip", "gemm_rb16.hip", "gemm_ring.hip", "gemm_mx8.hip", "norm.hip", "attention.hip", "attention16.hip", "embed.hip", "gnn.hip", "loss.hip", "optim.hip", "batch.hip", "decode.hip"]
 CPP_UNITS = ["engine.cpp", "capi.cpp", "tokenizer.cpp", "comm.cpp"]
 # -amdgpu-mfma-vgpr-form: MFMA results in VGPRs (gfx950 has one unified register file).  Where the compiler picked the AGPR form
 # (the attention forward kernels) 13 % of the instructions were v_accvgpr_read / write moves in a VALU-bound kernel
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-mllvm", "-amdgpu-mfma-vgpr-form=1"] + os.environ.get("COATI_AMD_CXXFLAGS", "").split()   # (probe builds: -DCOATI_RB_TRACE)
 
 
+# COATI_AMD_EXPERIMENTAL=1: the three kernels of round 5 that are parity-green and SLOWER than what they would replace (the attention half of a
+# block as one launch, the MLP half as one launch, the K = 256 products on 32-row slabs: DESIGN.md section 3a / 9, profiles/r05_*_trace.txt) are
+# compiled in (csrc/experimental/, -DCOATI_EXPERIMENTAL) with their operators and their COATI_ATTN_BLOCK / COATI_MLP_FUSED / COATI_T32 switches;
+# the default library neither holds nor exports them
+EXPERIMENTAL = os.environ.get("COATI_AMD_EXPERIMENTAL") == "1"
+EXPERIMENTAL_UNITS = ["experimental/attn_block.hip", "experimental/mlp64.hip", "experimental/gemm_t32.hip"]
+if EXPERIMENTAL:
+    HIP_UNITS = HIP_UNITS + EXPERIMENTAL_UNITS
+    FLAGS = FLAGS + ["-DCOATI_EXPERIMENTAL"]
 # mlp64.hip: one wave per SIMD with 256 accumulation registers next to 256 ordinary ones -- it needs the AGPR form of the MFMA results
-UNIT_DROP_FLAGS = {"mlp64.hip": ("-mllvm", "-amdgpu-mfma-vgpr-form=1")}
+UNIT_DROP_FLAGS = {"experimental/mlp64.hip": ("-mllvm", "-amdgpu-mfma-vgpr-form=1")}
 
 
 def _hipcc():
@@ -29,7 +38,9 @@ def _hipcc():
 
 
 def _sources():
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)]
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if not os.path.isdir(os.path.join(CSRC, f))]
+    if EXPERIMENTAL:
+        deps += [os.path.join(CSRC, "experimental", f) for f in os.listdir(os.path.join(CSRC, "experimental"))]
     deps.append(os.path.join(os.path.dirname(HERE), "include", "coati_hip.h"))
     return deps
 
@@ -64,7 +75,7 @@ def _build_locked(verbose):
 
     def compile_one(unit):
         src = os.path.join(CSRC, unit)
-        obj = os.path.join(OBJDIR, unit + ".o")
+        obj = os.path.join(OBJDIR, unit.replace("/", "_") + (".x.o" if EXPERIMENTAL else ".o"))
         flags = [f for f in FLAGS if f not in UNIT_DROP_FLAGS.get(unit, ())]
         cmd = [hipcc] + flags + (["-x", "hip"] if unit.endswith(".cpp") else []) + ["-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)

@@ -21,6 +21,7 @@ int coati_gemm_nt(const void* A, int a_f32, int64_t lda, const uint16_t* B, int6
   return launch_gemm_nt(a, a_f32, epi, S_(stream));
 }
 
+#ifdef COATI_EXPERIMENTAL
 int coati_mlp_fwd(const float* x, const float* gamma, const float* beta, uint16_t* a2, float* mean, float* rstd, const uint16_t* W1,
                   const float* b1, const uint16_t* W2, const float* b2, uint16_t* g, uint8_t* codes, float* out, int M, void* stream) {
   COATI_CHECK_SHAPE(M >= 1 && M <= 65536, "mlp_fwd: M=%d out of range", M);
@@ -29,6 +30,7 @@ int coati_mlp_fwd(const float* x, const float* gamma, const float* beta, uint16_
   a.g = g; a.codes = codes; a.out = out; a.ldo = 256; a.M = M;
   return launch_mlp64_fwd(a, S_(stream));
 }
+#endif
 
 int coati_gemm_lnbwd(const uint16_t* dY, int64_t lda, const uint16_t* WT, int64_t ldw, int M, int K, const float* x, const float* mean,
                      const float* rstd, const float* gamma, const float* dres, float* dx, uint16_t* dx16, float* partial,
@@ -155,6 +157,7 @@ int coati_attn_bwd_varlen(const uint16_t* qkv, const uint16_t* y, const uint16_t
   COATI_CHECK_ARG(seq_off, "attn_bwd_varlen: null seq_off");
   return launch_attn_bwd(qkv, y, dy, lse, dscratch, dqkv, cos_t, sin_t, B, T, n_head, head_size, S_(stream), seq_off);
 }
+#ifdef COATI_EXPERIMENTAL
 int coati_attn_groups(const int32_t* seq_off, int B, int T, int32_t* grp, void* stream) {
   return launch_attn_groups(seq_off, B, T, grp, S_(stream));
 }
@@ -169,6 +172,7 @@ int coati_attn_block_fwd(const float* x, float* xmid, const float* ln_g, const f
   return launch_attn_block_fwd(a, S_(stream));
 }
 int coati_ab_probe_swap(uint32_t* out, void* stream) { return launch_ab_probe_swap(out, S_(stream)); }
+#endif
 int coati_gemm_qkv_rope(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw, const float* bias, int M, int C,
                         uint16_t* qkv, int64_t ldc, const float* cos_t, const float* sin_t, int T, void* stream) {
   GemmArgs a;

@@ -42,12 +42,20 @@ enum Site {
   SITE_QKV_FWD = 0, SITE_PROJ_FWD, SITE_FC1_FWD, SITE_FC2_FWD, SITE_ATTN_FWD, SITE_LN_FWD, SITE_LMHEAD_FWD,
   SITE_FC2_DGRAD, SITE_FC1_DGRAD, SITE_PROJ_DGRAD, SITE_QKV_DGRAD, SITE_XF_WGRAD, SITE_ATTN_BWD, SITE_LN_BWD,
   SITE_LMHEAD_DLOGITS, SITE_LMHEAD_DGRAD, SITE_LMHEAD_WGRAD, SITE_GNN_EDGE_GEMM, SITE_GNN_NODE_GEMM,
-  SITE_GNN_WGRAD, SITE_GNN_ELEMWISE, SITE_EMBED, SITE_OPTIM, SITE_XF_TAIL, SITE_ATTN_BLOCK_FWD, SITE_COUNT
+  SITE_GNN_WGRAD, SITE_GNN_ELEMWISE, SITE_EMBED, SITE_OPTIM, SITE_XF_TAIL,
+#ifdef COATI_EXPERIMENTAL
+  SITE_ATTN_BLOCK_FWD,
+#endif
+  SITE_COUNT
 };
 const char* kSiteNames[SITE_COUNT] = {
     "qkv_fwd", "proj_fwd", "fc1_fwd", "fc2_fwd", "attn_fwd", "ln_fwd", "lmhead_fwd", "fc2_dgrad", "fc1_dgrad",
     "proj_dgrad", "qkv_dgrad", "xf_wgrad", "attn_bwd", "ln_bwd", "lmhead_dlogits", "lmhead_dgrad", "lmhead_wgrad",
-    "gnn_edge_gemm", "gnn_node_gemm", "gnn_wgrad", "gnn_elemwise", "embed", "optim", "xf_tail", "attn_block_fwd"};   // xf_tail: the [STOP]-row tail of the encoder pass (B-row launches)
+    "gnn_edge_gemm", "gnn_node_gemm", "gnn_wgrad", "gnn_elemwise", "embed", "optim", "xf_tail",
+#ifdef COATI_EXPERIMENTAL
+    "attn_block_fwd",
+#endif
+};   // xf_tail: the [STOP]-row tail of the encoder pass (B-row launches)
 
 struct XLayerP {  // offsets into the flat parameter buffer
   int64_t ln1w, ln1b, attnw, attnb, projw, projb, ln2w, ln2b, fc1w, fc1b, fc2w, fc2b;
@@ -695,10 +703,15 @@ int xformer_fwd(coati_engine* e, XPass& p, const float* injection, hipStream_t s
   // The attention half of every block as ONE launch (attn_block.hip): ln_1 -> c_attn -> RoPE -> causal attention -> c_proj -> + x
   // with qkv and y written once and never read back (d = 256, 16 heads, sequences of <= 128 rows); its work list -- groups of
   // whole sequences -- is built on the device once per pass
+#ifdef COATI_EXPERIMENTAL
   const bool ab = !c.use_fp8 && attn_block_fwd_supported(p.B, p.T, C, c.n_head);
   if (ab) COATI_TRY(launch_attn_groups(p.packed ? p.off : nullptr, p.B, p.T, p.grp, s));
+#else
+  constexpr bool ab = false;
+#endif
   for (int l = 0; l < L; ++l) {
     const XLayerP& w = e->xl[l];
+#ifdef COATI_EXPERIMENTAL
     if (ab) {
       AttnBlockArgs a;
       a.x = p.x[l]; a.xmid = p.xmid[l]; a.ln_g = e->P + w.ln1w; a.ln_b = e->P + w.ln1b; a.mean = p.mean1[l]; a.rstd = p.rstd1[l];
@@ -710,6 +723,7 @@ int xformer_fwd(coati_engine* e, XPass& p, const float* injection, hipStream_t s
                    (double)M * C * (4 + 2 + 6 + 2 + 4) + (double)M * (c.n_head * 4 + 8) + 4.0 * C * C * 2);
       COATI_TRY(launch_attn_block_fwd(a, s));
     }
+#endif
     if (c.use_fp8) {
       // MXFP8 products (BASELINE.json configs[4]); LayerNorm, attention, residual stream and saved tensors as in the bf16 path
       GemmArgs a;

@@ -32,7 +32,7 @@
 // log-sum-exp table [128][16], its row index.  The a1 staging ([128][256] bf16, 64 KiB) lies over the images (rows 0..95) and the
 // ring slot of the stage consumed last (rows 96..127): both are idle between two groups.
 #include <cstdlib>
-#include "kernels.h"
+#include "../kernels.h"
 
 #define AB_R 128
 #define AB_STAGE 32768

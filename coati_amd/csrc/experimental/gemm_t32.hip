@@ -21,7 +21,7 @@
 //   * one barrier per tile; before a tile's stores are issued the wave waits for ITS pieces of the next tile (vmcnt counts the
 //     tile after that as still in flight), so the barrier never waits for a store acknowledgement
 #include <cstdlib>
-#include "gemm_epi.h"
+#include "../gemm_epi.h"
 
 #define T32_K 256
 #define T32_BN 64

@@ -20,7 +20,7 @@
 // step j + 1 (32 KiB of W1 + 32 KiB of W2 by global_load_lds) are on their way during the whole of step j.
 #include <cstdlib>
 #include <type_traits>
-#include "gemm_epi.h"
+#include "../gemm_epi.h"
 
 #define M64_HID 1024
 #define M64_C 256

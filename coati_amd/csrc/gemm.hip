@@ -287,7 +287,9 @@ int launch_gemm_nt(const GemmArgs& a, int a_f32, int epi, hipStream_t s) {
     // row-block kernel); every other K = 256 product: the row-block kernel
     if (gemm_rb16_resident_supported(a, a_f32, epi)) return launch_gemm_rb16_resident(a, epi, s);
     if (gemm_ring256_supported(a, a_f32, epi)) return launch_gemm_ring256(a, epi, s);
+#ifdef COATI_EXPERIMENTAL
     if (gemm_t32_supported(a, a_f32, epi)) return launch_gemm_t32(a, epi, s);
+#endif
     if (gemm_rb16_supported(a, a_f32, epi)) return launch_gemm_rb16(a, epi, s);
     if (gemm_rb256_supported(a, a_f32, epi)) return launch_gemm_rb256(a, epi, s);
   }

@@ -373,7 +373,10 @@ bool gemm_rb256_ln_fusable(const GemmArgs& a, int epi) {
 
 int gemm_ce_tile_width(const GemmArgs& a) {
   // (the same order of questions as launch_gemm_nt's dispatch)
-  return (gemm_t32_supported(a, 0, EPI_CE_PARTIAL) || gemm_rb16_supported(a, 0, EPI_CE_PARTIAL) || gemm_rb256_supported(a, 0, EPI_CE_PARTIAL)) ? 64 : 128;
+#ifdef COATI_EXPERIMENTAL
+  if (gemm_t32_supported(a, 0, EPI_CE_PARTIAL)) return 64;
+#endif
+  return (gemm_rb16_supported(a, 0, EPI_CE_PARTIAL) || gemm_rb256_supported(a, 0, EPI_CE_PARTIAL)) ? 64 : 128;
 }
 
 // true when (a, epi) can run on the row-block kernel

@@ -115,6 +115,7 @@ bool gemm_rb16_supported(const GemmArgs& a, int a_f32, int epi);
 bool gemm_rb16_resident_supported(const GemmArgs& a, int a_f32, int epi);
 int launch_gemm_rb16_resident(const GemmArgs& a, int epi, hipStream_t s);
 int launch_gemm_rb16(const GemmArgs& a, int epi, hipStream_t s);
+#ifdef COATI_EXPERIMENTAL   // csrc/experimental/: parity-green, slower than what they would replace; not in the default library (build.py)
 // the same products on 32-row slabs in the TRANSPOSED form (gemm_t32.hip, round 5): 24 577 .. 65 536 rows; taken before the 16-row slabs
 // the MLP half of a block as one launch (mlp64.hip): out = x + c_proj(NewGELU(c_fc(ln_2(x)))), d = 256, hidden 1024
 struct Mlp64Args {
@@ -139,6 +140,7 @@ bool mlp64_fwd_supported(int M, int C, int hidden);
 int launch_mlp64_fwd(const Mlp64Args& a, hipStream_t s);
 bool gemm_t32_supported(const GemmArgs& a, int a_f32, int epi);
 int launch_gemm_t32(const GemmArgs& a, int epi, hipStream_t s);
+#endif
 // ring kernel for N = 256, long K (gemm_ring.hip)
 bool gemm_ring256_supported(const GemmArgs& a, int a_f32, int epi);
 int launch_gemm_ring256(const GemmArgs& a, int epi, hipStream_t s);
@@ -249,6 +251,7 @@ int launch_attn16_fwd(const bf16_t* qkv, bf16_t* y, float* lse, int B, int T, in
 int launch_attn16_bwd(const bf16_t* qkv, const bf16_t* y, const bf16_t* dy, const float* lse, bf16_t* dqkv, const float* cos_t,
                       const float* sin_t, int B, int T, int n_head, hipStream_t s, const int* seq_off);
 
+#ifdef COATI_EXPERIMENTAL
 // The attention half of a block as one sequence-stationary kernel (attn_block.hip): xmid = x + c_proj(attention(RoPE(c_attn(ln_1(x))))),
 // d = 256, 16 heads of 16, sequences of <= 128 rows.  Saves what the backward reads: a1 = ln_1(x), mean / rstd, qkv (q, k rotated), y, lse.
 struct AttnBlockArgs {
@@ -277,6 +280,7 @@ bool attn_block_fwd_supported(int B, int T, int C, int n_head);
 int launch_attn_groups(const int* seq_off, int B, int T, int* grp, hipStream_t s);
 int launch_attn_block_fwd(const AttnBlockArgs& a, hipStream_t s);
 int launch_ab_probe_swap(unsigned* out, hipStream_t s);
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // embedding / token kernels (embed.hip)

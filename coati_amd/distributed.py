@@ -185,6 +185,10 @@ class _Schedule:
         self.decided = len(self.cands) == 1
         self.split, self.wire = self.cands[0] if self.decided else (_SPLIT_ENCODER_STAGE, _WIRE_ENV or "fp32")
 
+    def current(self):
+        """the schedule of a step outside the measurement: what was decided, else the module's defaults"""
+        return (self.split, self.wire) if self.decided else (_SPLIT_ENCODER_STAGE, _WIRE_ENV or "fp32")
+
 
 def _measurable():
     """the schedule is only measured on the product backend (RCCL); gloo runs stage through the host and time nothing useful"""
@@ -199,11 +203,11 @@ def _schedule_begin(eng):
     n = len(sch.cands)
     if sch.decided or not _measurable() or sch.step >= sch.WARMUP + n * sch.PER_FORM:
         # (the last clause: a measurement that never reached its decision -- an exception in between -- stops allocating events)
-        return sch.split, sch.wire, None
+        return sch.current() + (None,)
     k = sch.step
     sch.step += 1
     if k < sch.WARMUP:
-        return sch.split, sch.wire, None
+        return sch.current() + (None,)
     form = (k - sch.WARMUP) // sch.PER_FORM
     ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
     ev[0].record()
@@ -248,7 +252,7 @@ def distributed_train_step(eng, batch, use_point, lr, do_clip=True, optimizer=Tr
         # not a timed step (bench.py's exposed-cost loops, eval-like calls): the schedule the engine has decided on, if any -- so that
         # a comparison of two loops compares the SAME backward schedule
         sch = getattr(eng, "_dp_schedule", None)
-        split_stage, wire_sched, slot = (sch.split, sch.wire, None) if (sch is not None and sch.decided) else (_SPLIT_ENCODER_STAGE, _WIRE_ENV or "fp32", None)
+        split_stage, wire_sched, slot = (sch.current() + (None,)) if sch is not None else (_SPLIT_ENCODER_STAGE, _WIRE_ENV or "fp32", None)
     h_e, h_s, bad = eng.forward(batch["raw_tokens"], batch["tokens"], batch["atoms"], batch["coords"], use_point,
                                 y_next=batch["y_next"], train=True, rows=batch.get("rows"), stop_after_heads=True)
     B = h_e.shape[0]

@@ -35,6 +35,16 @@ def packed_lengths(raw_tokens, tokens, y_next=None):
     return length(raw_tokens, None), length(tokens, y_next)
 
 
+def attention_score_efficiency(lengths, block=16):
+    """useful / computed score elements of causal attention on `block`-row granularity (csrc/attention16.hip: block = 16; the 32-row
+    kernels of rounds 1-5: block = 32): a row of T positions needs T (T + 1) / 2 scores, the kernel evaluates nb (nb + 1) / 2 whole
+    block x block tiles with nb = ceil(T / block).  lengths: per-row lengths of a pass (packed_lengths)."""
+    t = torch.as_tensor(lengths).to(torch.int64)
+    t = t[t > 0]
+    nb = (t + block - 1) // block
+    return float((t * (t + 1) // 2).sum()) / float((nb * (nb + 1) // 2).sum() * block * block)
+
+
 def make_batch(B, T, A, V, seed=1234, n_special=1596, p_clip=0.9, p_bad=0.01, min_len=16, device="cpu", with_rows=False):
     """with_rows: add batch["rows"] = CPU int64 [rows1, rows2], the packed-row counts (packed_rows above) -- Engine.train_step
     then runs the transformer passes on the rows' real prefixes only."""

@@ -61,12 +61,14 @@ int coati_gemm_nt(const void* A, int a_f32, int64_t lda, const uint16_t* B, int6
                   void* C, int64_t ldc, int n_store, const float* bias, const void* aux_in, void* aux_out,
                   int64_t ld_aux, int epi, void* stream);
 
-/* The MLP half of a transformer block as one launch (mlp64.hip): out = x + c_proj(NewGELU(c_fc(ln_2(x)))) for d = 256, hidden 1024
+#ifdef COATI_EXPERIMENTAL   /* operators of csrc/experimental/ (slower than what they would replace): only in libcoati_hip_x.so, built under COATI_AMD_EXPERIMENTAL=1 */
+/* The MLP half of a transformer block as one launch (csrc/experimental/mlp64.hip): out = x + c_proj(NewGELU(c_fc(ln_2(x)))) for d = 256, hidden 1024
  * (basic_transformer.py:103-123, 165-169 forward).  x [M, 256] f32; W1 = c_fc.weight [1024, 256], W2 = c_proj.weight [256, 1024] (bf16);
  * also written: a2 = ln_2(x) (bf16), mean / rstd [M], g = NewGELU(c_fc(.)) [M, 1024] bf16, codes = NewGELU' as 8-bit fixed point [M, 1024]
  * -- what the backward reads.  Replaces nn.LayerNorm + two F.linear + NewGELU + the residual add.  24 577 .. 65 536 rows. */
 int coati_mlp_fwd(const float* x, const float* gamma, const float* beta, uint16_t* a2, float* mean, float* rstd, const uint16_t* W1,
                   const float* b1, const uint16_t* W2, const float* b2, uint16_t* g, uint8_t* codes, float* out, int M, void* stream);
+#endif
 
 /* An input-gradient product whose result is the gradient w.r.t. a LayerNorm's OUTPUT, with that LayerNorm's backward in the
  * product's write-out (c_fc -> ln_2 and c_attn -> ln_1 of basic_transformer.py:162-174): dy = dY[M,K] WT[256,K]^T never visits
@@ -163,7 +165,8 @@ int coati_attn_fwd_varlen(const uint16_t* qkv, uint16_t* y, float* lse, const in
 int coati_attn_bwd_varlen(const uint16_t* qkv, const uint16_t* y, const uint16_t* dy, const float* lse, float* dscratch,
                           uint16_t* dqkv, const float* cos_t, const float* sin_t, const int32_t* seq_off, int B, int T,
                           int n_head, int head_size, void* stream);
-/* The attention half of a RotaryBlock as ONE launch (csrc/attn_block.hip; basic_transformer.py:126-154, 171-172; d = 256, 16 heads of
+#ifdef COATI_EXPERIMENTAL
+/* The attention half of a RotaryBlock as ONE launch (csrc/experimental/attn_block.hip; basic_transformer.py:126-154, 171-172; d = 256, 16 heads of
  * 16, sequences of <= 128 rows): xmid = x + c_proj(causal_attention(RoPE(c_attn(ln_1(x))))).  x / xmid [M, 256] f32; a1 = ln_1(x)
  * [M, 256] bf16, mean / rstd [M], qkv [M, 768] bf16 (q, k rotated), y [M, 256] bf16 and lse [B, 16, T] f32 are the tensors the
  * backward reads (the same ones the three-launch path leaves).  row_src [M] (coati_seq_pack; null = padded layout).
@@ -177,6 +180,7 @@ int coati_attn_block_fwd(const float* x, float* xmid, const float* ln_g, const f
 /* test probes: lane-half exchange semantics the kernel above relies on; its shader-clock phase trace (-DCOATI_AB_TRACE builds) */
 int coati_ab_probe_swap(uint32_t* out, void* stream);
 int coati_ab_trace_read(unsigned long long* out);
+#endif
 int coati_attn_bwd_hs(const uint16_t* qkv, const uint16_t* y, const uint16_t* dy, const float* lse, float* dscratch,
                       uint16_t* dqkv, const float* cos_t, const float* sin_t, int B, int T, int n_head, int head_size,
                       void* stream);

@@ -1,4 +1,4 @@
-"""The opt-in 32-row-slab transposed K = 256 GEMM (csrc/gemm_t32.hip, COATI_T32=1): the operator tests whose shapes it takes
+"""The opt-in 32-row-slab transposed K = 256 GEMM (csrc/experimental/gemm_t32.hip, COATI_T32=1): the operator tests whose shapes it takes
 (24 577 .. 65 536 rows, K = 256: plain bf16, QKV + RoPE, NewGELU + derivative codes, FC2 input gradient, lm_head partial
 cross-entropy and its gradient) and the packed-against-padded engine steps at the wide sizes, re-run in a process that has
 the switch set (the library reads it once)."""
@@ -11,6 +11,14 @@ import torch
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(autouse=True)
+def _needs_experimental_build():
+    """the kernel under test lives in csrc/experimental/ and is only compiled under COATI_AMD_EXPERIMENTAL=1 (build.py)"""
+    from coati_amd import _lib
+    if not _lib.has_experimental():
+        pytest.skip("csrc/experimental/ is not in this library: build and run with COATI_AMD_EXPERIMENTAL=1")
 
 
 @pytest.mark.skipif(not torch.cuda.is_available(), reason="needs a GPU")
