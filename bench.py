@@ -162,6 +162,98 @@ def time_comm(eng, D, batch_size, steps=10):
     return out
 
 
+class _FeedPipe:
+    """make_batcher of the host-feed extras: synthetic ROWS (smiles text, ragged atoms / coords) -> the trainer's pipe: row filters,
+    stack_batch, clip_ar_xform with the training probabilities of examples/training/train_grande.py on the host (C++ trie tokenizer)"""
+
+    def __init__(self, vocab, batch, n_batches, n_seq=250, tokens=76, atoms=16):
+        self.vocab, self.batch, self.n_batches, self.n_seq, self.tokens, self.atoms = vocab, batch, n_batches, n_seq, tokens, atoms
+
+    def __call__(self, worker, n_workers):
+        import contextlib
+        import io
+        from coati_amd.data.feed import SyntheticRows, UrBatcher
+        from coati_amd.models.encoding.clip_e2e import clip_ar_xform
+        from coati_amd.models.encoding.tokenizers import TrieTokenizer
+        tk = TrieTokenizer(n_seq=self.n_seq, smiles_tokens=self.vocab["smiles"], special_tokens=self.vocab["special"])
+        rows = SyntheticRows(self.vocab["smiles"], self.batch * self.n_batches, tokens=self.tokens, atoms=self.atoms, seed=31)
+
+        def xf(X):
+            with contextlib.redirect_stdout(io.StringIO()):      # failed rows print, as in the reference
+                return clip_ar_xform(X, tk, p_dataset=0.3, p_formula=0.3, p_fim=0.5, p_graph=0.0, p_clip=0.9, p_clip_cut=0.3,
+                                     p_randsmiles=0.0, device="cpu")
+        return UrBatcher(rows, batch_size=self.batch, partition="train", xform_routine=xf, required_fields=["smiles"], worker=worker,
+                         n_workers=n_workers, seed=5)
+
+
+def feed_extras(eng, dev, args, MODEL):
+    """host_feed: molecules/s of the real host path (rows -> stack_batch -> clip_ar_xform -> pinned staging -> H2D) on 0 (inline) / 1 /
+    4 / 8 worker processes, no training step; end_to_end: the step loop of train_autoencoder fed by that path (8 workers) against
+    the same batches replayed from HBM.  Vocabulary: the 2 697-entry slice of `may_closedparen` committed as a test fixture (the
+    full tables are user data, $COATI_VOCAB_PATH); token ids therefore stay below 2 697 of the model's 10 322."""
+    from coati_amd.data.feed import BatchFeed
+    vp = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "tokenizer_real.json")
+    with open(vp) as f:
+        vocab = json.load(f)
+    B = args.batch
+    cores = os.cpu_count() or 1
+    out = {"host_feed": {"note": "rows -> UrBatcher (md5 row id, partition) -> stack_batch -> clip_ar_xform (p_dataset 0.3, p_formula 0.3, p_fim 0.5, "
+                                 "p_clip 0.9, p_clip_cut 0.3; canonicalisation = identity: no rdkit here) -> pinned staging -> H2D on a copy stream; "
+                                 "synthetic rows of 38..76 SMILES tokens, 8..16 atoms", "host_cores": cores, "workers": []}}
+    for w in (0, 1, 4, 8):
+        nb = 6 if w <= 1 else 24
+        feed = BatchFeed(_FeedPipe(vocab, B, nb), workers=w, depth=3, device=dev)
+        t0 = time.perf_counter()
+        n, toks = 0, 0
+        first = None
+        for b in feed:
+            if first is None:
+                first = time.perf_counter() - t0
+                t1 = time.perf_counter()
+            else:
+                n += 1
+            last = b
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t1
+        out["host_feed"]["workers"].append({"workers": w, "molecules_per_s": round(n * B / dt, 1), "first_batch_s": round(first, 3),
+                                            "T1": int(last["raw_tokens"].shape[1]), "T2": int(last["tokens"].shape[1]),
+                                            "mean_tokens_per_row": round(float((last["tokens"] > 0).sum()) / B, 1)})
+    # the step loop behind the feed
+    W, nb = 8, 40
+    up = torch.rand(B, device=dev) > 0.5
+    feed = BatchFeed(_FeedPipe(vocab, B, nb), workers=W, depth=3, device=dev)
+    kept, k, t1 = [], 0, None
+    for b in feed:
+        eng.train_step(b, up, lr=5e-4, head=args.head)
+        k += 1
+        if k == 8:                      # warm-up: worker start, workspace growth for the new shapes
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            w0 = feed.stats["wait_s"]
+        if k > 8 and len(kept) < 8:
+            kept.append(b)
+    torch.cuda.synchronize()
+    e2e = (time.perf_counter() - t1) / (k - 8)
+    waited = (feed.stats["wait_s"] - w0) / (k - 8)
+    rep = []
+    for b in kept:
+        eng.train_step(b, up, lr=5e-4, head=args.head)
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(3):
+            eng.train_step(b, up, lr=5e-4, head=args.head)
+        torch.cuda.synchronize()
+        rep.append((time.perf_counter() - t) / 3)
+    rep = sum(rep) / len(rep)
+    out["end_to_end"] = {"workers": W, "steps": k - 8, "ms_per_step": round(1e3 * e2e, 3), "ms_per_step_replayed": round(1e3 * rep, 3),
+                         "fed_over_replayed": round(e2e / rep, 4), "within_5pct": bool(e2e / rep <= 1.05),
+                         "step_loop_wait_for_batch_ms": round(1e3 * waited, 3), "molecules_per_s": round(B / e2e, 1),
+                         "rows": [int(x) for x in kept[0]["rows"].tolist()],
+                         "note": "train_autoencoder's step loop (data/feed.py BatchFeed -> Engine.train_step) on batches made by the host path "
+                                 "above, against 8 of the same batches replayed from HBM"}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -423,6 +515,10 @@ def main():
             del b, u
         extras["batch_sweep"] = {"note": "same engine, one synthetic batch per size replayed (3 warm-up + 8 timed steps); 160 = the reference's default per-GPU batch "
                                          "(examples/training/train_grande.py:45)", "sizes": sweep}
+        try:
+            extras.update(feed_extras(eng, dev, args, MODEL))
+        except Exception as ex:   # noqa: BLE001  (an extra must not take the headline line with it)
+            extras["host_feed"] = {"error": f"{type(ex).__name__}: {ex}"}
         for _ in range(2):
             step()          # back on the timed batch (the per-site pass below)
 

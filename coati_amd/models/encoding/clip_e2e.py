@@ -286,7 +286,16 @@ def clip_ar_xform(batch: Dict[str, Any], tokenizer, p_dataset: float = 0.2, p_fo
         assert need in batch
     canon = canon_smiles or (lambda s: s)
     n_seq = tokenizer.n_seq
-    enc = lambda text: tokenizer.tokenize_text(text, pad=False, range_check=False)   # noqa: E731
+    fixed = {}                      # the sentinel strings are encoded once per call, not once per row
+
+    def enc(text):
+        if text in fixed:
+            return list(fixed[text])
+        ids = tokenizer.tokenize_text(text, pad=False, range_check=False)
+        if text in ("[CLIP][UNK]", "[SUFFIX]", "[MIDDLE]", "[PREFIX]"):
+            fixed[text] = list(ids)
+        return ids
+
     tok_rows, raw_rows = [], []
 
     def fail_row():

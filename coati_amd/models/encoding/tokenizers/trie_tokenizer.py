@@ -47,11 +47,15 @@ class _Native:
     def encode(self, text: str):
         raw = text.encode("utf-8")
         cap = max(len(raw), 1)
-        out = (ctypes.c_int32 * cap)()
-        n = int(self.l.coati_tokenizer_encode(self.h, raw, len(raw), out, cap))
+        out = self._out          # one output buffer per handle, grown on demand (a fresh ctypes array per call costs more than the match)
+        if out is None or len(out) < cap:
+            out = self._out = (ctypes.c_int32 * max(cap, 1024))()
+        n = self.l.coati_tokenizer_encode(self.h, raw, len(raw), out, len(out))
         if n < 0:
             return None, -n - 1
-        return [int(out[k]) for k in range(n)], None
+        return out[:n], None
+
+    _out = None
 
 
 class Trie:
@@ -107,7 +111,7 @@ class TrieTokenizer:
 
     def tokenize_text(self, text: str, pad: bool = True, range_check: bool = True) -> List[int]:
         ids, bad_at = self._native.encode(text)
-        if ids is None or any(i < 0 for i in ids):
+        if ids is None or (ids and min(ids) < 0):
             pieces = self.pre_tokenize(text)
             bad = next((p for p, i in self._native.pieces(text) if i < 0), None)
             print("tokenize text exception... ", text, KeyError(bad), pieces)

@@ -17,7 +17,8 @@ import torch
 import torch.distributed as dist
 
 from ..data.dataset import COATI_dataset, SyntheticTokenizer
-from ..models.encoding.clip_e2e import e3gnn_smiles_clip_e2e
+from ..data.feed import BatchFeed
+from ..models.encoding.clip_e2e import clip_ar_xform, e3gnn_smiles_clip_e2e
 from .. import distributed as D
 
 
@@ -238,9 +239,24 @@ def train_autoencoder(gpu, args, dataset=None, tokenizer=None):
         err_acc = torch.zeros(1, device=device, dtype=torch.int32)
         hist = []
         teu = eng.token_entropy_unit()
-        pipe = dataset.get_data_pipe(batch_size=args.batch_size, partition=partition, distributed_rankmod_total=world,
-                                     distributed_rankmod_rank=rank, required_fields=["smiles"])
-        it = iter(pipe)
+        # train_coati.py:363-376 runs dataset.get_data_pipe(..., xform_routine=clip_ar_xform -> device) inside the step loop; here the
+        # same pipe runs in `feed_workers` processes AHEAD of the step (clip_ar_xform builds host tensors there) and the feed
+        # uploads each batch from pinned staging on a copy stream (data/feed.py); the batch stream is the same for any worker count
+        row_mode = getattr(dataset, "rows", None) is not None
+        xform_routine = (lambda X: clip_ar_xform(X, tokenizer, p_dataset=args.p_dataset, p_formula=args.p_formula, p_fim=args.p_fim,
+                                                 p_graph=args.p_graph, p_clip=args.p_clip, p_clip_cut=args.p_clip_cut,
+                                                 p_randsmiles=args.p_randsmiles, device="cpu")) if row_mode else (lambda X: X)
+
+        def make_batcher(worker, n_workers):
+            return dataset.get_data_pipe(batch_size=args.batch_size, partition=partition,
+                                         distributed_rankmod_total=world,
+                                         distributed_rankmod_rank=rank, required_fields=["smiles"], xform_routine=xform_routine,
+                                         worker=worker, n_workers=n_workers, seed=int(getattr(args, "feed_seed", 0)) + 7919 * epoch,
+                                         indexed=True)
+
+        feed = BatchFeed(make_batcher, workers=int(getattr(args, "feed_workers", 4 if row_mode else 1)),
+                         depth=int(getattr(args, "feed_depth", 3)), device=device)
+        it = iter(feed)
         i = -1
         while True:
             batch = next(it, None)
@@ -254,7 +270,7 @@ def train_autoencoder(gpu, args, dataset=None, tokenizer=None):
                 break
             i += 1
             if ok:
-                dev = {k: (v if k == "rows" else v.to(device)) for k, v in batch.items() if isinstance(v, torch.Tensor)}   # "rows": host-side packed-row counts
+                dev = batch                    # already on the device (the feed's copy stream); "rows" = host-side packed-row counts
                 B = dev["atoms"].shape[0]
             if not ok:
                 print("a row was lost, skipping batch")          # train_coati.py:229-234
@@ -294,6 +310,8 @@ def train_autoencoder(gpu, args, dataset=None, tokenizer=None):
                                       offline_loss=offline_losses)
                 logger.log_pytorch(doc, tags={"train_epoch": str(epoch), "dataset_epoch": str(epoch)})
         n_toks += int(acc.cpu()[0])
+        feed.close()
+        feed_stats.append({"partition": partition, "epoch": epoch, **feed.stats, "seconds": time.time() - t0, "molecules": ng})
         # every step's error word (off the logging steps nothing else reads it; the optimizer kernel has dropped those updates): the
         # reference raises on the step itself (smiles_xformer.py:63-66), here the epoch does at the latest -- on every rank together
         ew = err_acc.cpu()
@@ -316,6 +334,7 @@ def train_autoencoder(gpu, args, dataset=None, tokenizer=None):
         per_batch = H[:, 0] / H[:, 1].clamp(min=1.0) + 0.5 * (H[:, 2] + H[:, 3]) / H[:, 4].clamp(min=1.0) * teu
         return float(per_batch.mean())              # mean of the per-batch losses over EVERY batch (train_coati.py:383-396), identical on every rank
 
+    feed_stats = []
     res = {"best_test": 1e10, "best_epoch": 0, "best_model": None}
     for epoch in range(args.n_epochs):
         do_epoch(epoch, "train")
@@ -329,4 +348,5 @@ def train_autoencoder(gpu, args, dataset=None, tokenizer=None):
         logger.log_pytorch(doc, tags={"best": "best"})
     if world > 1:
         dist.destroy_process_group()
+    model.feed_stats = feed_stats        # per epoch: batches, seconds, time the step loop waited for a batch, H2D bytes
     return model

@@ -512,7 +512,7 @@ def verify():
             print(("same     " if ok else "DIFFERENT") + " " + f)
             if not ok:
                 bad.append(f)
-        own = {"grande_golden.npz": "gen_golden_grande.py", "flags_golden.npz": "gen_golden_flags.py", "tokenizer_real.json": "gen_golden_tokenizer.py"}
+        own = {"grande_golden.npz": "gen_golden_grande.py", "flags_golden.npz": "gen_golden_flags.py", "tokenizer_real.json": "gen_golden_tokenizer.py", "ur_batcher.json": "gen_golden_urbatcher.py"}
         missing = [f for f in os.listdir(HERE) if f.endswith((".npz", ".json", ".pkl")) and f not in os.listdir(tmp) and f not in own]
         print("fixtures with their own generator (each has --verify):", own)
         print("fixtures without a generator:", missing)
