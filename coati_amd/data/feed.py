@@ -13,7 +13,12 @@ running `clip_ar_xform` is slower than the MI355X engine (33-45 k molecules/s at
 * per-batch seeding (`seed`): Python / numpy / torch generators of the producing process are re-seeded from
   (seed, rank, partition, batch index) before `xform_routine` runs, so the augmentation draws do not depend on which worker made the batch.
 
-Workers never touch the GPU (xform_routine must build CPU tensors: pass device="cpu" to clip_ar_xform)."""
+Workers never touch the GPU (xform_routine must build CPU tensors: pass device="cpu" to clip_ar_xform), and they are NOT forked
+from the training process: children forked from a process that holds a HIP context slow that process's own HIP calls down for as
+long as they live (hipEventSynchronize on a finished copy 0.002 -> 4-9 ms, the training step 2.5 x slower:
+`tools/probes/feed_stage_probe.py`, `profiles/r06_feed_probe.txt`).  They come from a fork server that is itself a fresh interpreter
+(`multiprocessing` "forkserver", this module preloaded so that a worker starts in milliseconds); `make_batcher` therefore has to
+pickle (a module-level class instance; `TrieTokenizer` pickles as its vocabulary)."""
 import hashlib
 import os
 import queue
@@ -114,7 +119,6 @@ def _worker_main(make_batcher, worker, n_workers, out_q, stop_ev):
     finally:
         out_q.close()
         out_q.join_thread()
-        os._exit(0)               # no interpreter teardown in a forked child of a process that holds a HIP context
 
 
 class _Slot:
@@ -130,16 +134,17 @@ class _Slot:
         if b is None or b.dtype != t.dtype or b.numel() < n:
             b = torch.empty(max(n, 1), dtype=t.dtype).pin_memory()
             self.buf[name] = b
-        v = b[:n].view(t.shape)
-        v.copy_(t)
-        return v
+        # one memcpy through numpy: a torch copy_ of a few MB fans out over the intra-op pool, whose threads then spin next to the
+        # worker processes (measured on the 256-core box: 16-30 ms per batch in copy_, 0.3 ms as a memcpy: tools/feed_probe.py)
+        b.numpy()[:n] = t.contiguous().view(-1).numpy()
+        return b[:n].view(t.shape)
 
 
 class BatchFeed:
     """Iterator over device batches, produced ahead of their use.
 
     make_batcher(worker, n_workers) -> iterable of (batch_index, batch dict of CPU tensors) holding the batches with
-    index % n_workers == worker in increasing order (a `UrBatcher`); must be picklable for start methods other than fork.
+    index % n_workers == worker in increasing order (a `UrBatcher`); picklable (see the module docstring) unless workers = 0.
     workers = 0: the batcher runs inline in the feed thread (still ahead of the step, still pinned + asynchronous H2D).
     depth: batches in flight per worker queue and on the device side.  host_keys: entries left on the host (`rows`).
     device = "cpu": no staging, no streams (CPU tests of ordering and determinism)."""
@@ -148,9 +153,13 @@ class BatchFeed:
                  host_keys=("rows",), mp_context: Optional[str] = None):
         self.make_batcher, self.workers, self.depth = make_batcher, max(0, int(workers)), max(2, int(depth))
         self.device = torch.device(device)
+        if self.device.type == "cuda" and self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
         self.host_keys = set(host_keys)
-        self.ctx_name = mp_context or os.environ.get("COATI_FEED_MP", "fork")
-        self.stats = {"batches": 0, "wait_s": 0.0, "h2d_bytes": 0}
+        self.ctx_name = mp_context or os.environ.get("COATI_FEED_MP", "forkserver")
+        # wait_s: the consumer blocked in __next__; get_s: the feed thread blocked on the worker queues (or, inline, making the batch);
+        # stage_s: pinned staging + issuing the copies
+        self.stats = {"batches": 0, "wait_s": 0.0, "h2d_bytes": 0, "get_s": 0.0, "stage_s": 0.0}
         self._procs, self._queues, self._thread = [], [], None
         self._ready: "queue.Queue" = queue.Queue(maxsize=self.depth)
         self._stop = threading.Event()
@@ -160,8 +169,10 @@ class BatchFeed:
     def _start(self):
         self._started = True
         if self.workers > 0:
-            import torch.multiprocessing as mp
+            import multiprocessing as mp
             ctx = mp.get_context(self.ctx_name)
+            if self.ctx_name == "forkserver":
+                ctx.set_forkserver_preload(["coati_amd.data.feed", "coati_amd.models.encoding.clip_e2e"])
             self._mp_stop = ctx.Event()
             for w in range(self.workers):
                 q = ctx.Queue(maxsize=self.depth)
@@ -225,10 +236,21 @@ class BatchFeed:
 
     def _pump(self):
         try:
+            torch.set_num_threads(1)          # this thread's OpenMP setting only: the inline batcher's small tensor ops must not fan out
             if self.device.type == "cuda":
                 torch.cuda.set_device(self.device)
-            for k, b in enumerate(self._host_batches()):
+            it = self._host_batches()
+            k = 0
+            while True:
+                t0 = time.perf_counter()
+                b = next(it, None)
+                t1 = time.perf_counter()
+                if b is None:
+                    break
                 item = self._to_device(k, b)
+                k += 1
+                self.stats["get_s"] += t1 - t0
+                self.stats["stage_s"] += time.perf_counter() - t1
                 while not self._stop.is_set():
                     try:
                         self._ready.put(item, timeout=0.1)

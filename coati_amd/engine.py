@@ -143,16 +143,28 @@ class Engine:
             world = 1
         # grow-only capacities: buffers are carved for the largest shape seen so far, so that batches of different width (every batch of
         # clip_ar_xform has its own T) keep the same addresses -- cached launch tables stay valid, the workspace stops being re-sized
+        # A growth event is expensive (the workspace is re-allocated -- a device-wide synchronisation --, every buffer is re-carved and
+        # the cached launch tables are rebuilt: ~ 100 ms, tools/feed_e2e_probe.py), and in real training the widest row seen so far
+        # keeps creeping up for hundreds of batches: widths therefore grow in steps of 32 columns (at most n_seq / 32 events per run),
+        # and a trainer that knows its limits calls reserve() once up front.
         cap = getattr(self, "_cap", (0, 0, 0, 0))
         new = tuple(max(a, b) for a, b in zip(cap, (B, T1, T2, A)))
         if new != cap:
+            tmax = int(self.cfg.n_seq)
+            new = (new[0], min(max(tmax, new[1]), -(-new[1] // 32) * 32), min(max(tmax, new[2]), -(-new[2] // 32) * 32), new[3])
             _lib.check(self.l.coati_engine_reserve(self.h, *new), "coati_engine_reserve")
             self._cap = new
-        need = int(self.l.coati_engine_workspace_bytes(self.h, B, T1, T2, A, B * world))
+        cb, c1, c2, ca = self._cap
+        need = int(self.l.coati_engine_workspace_bytes(self.h, max(B, cb), max(T1, c1), max(T2, c2), max(A, ca), max(B, cb) * world))
         if self.workspace is None or self.workspace.numel() < need:
             self.workspace = None
             self.workspace = torch.empty(need, device=self.device, dtype=torch.uint8)
         return need
+
+    def reserve(self, B, T1, T2, A):
+        """Carve every buffer for batches of up to B molecules, T1 / T2 token columns and A atoms now (coati_engine_reserve): later
+        batches inside these limits never trigger a growth event."""
+        self._ensure_workspace(int(B), int(T1), int(T2), int(A))
 
     def forward(self, raw_tokens, tokens, atoms, coords, use_point, y_next=None, train=True, rows=None, stop_after_heads=False):
         """forward_dist (+ AR loss sums when y_next is given).  Returns (h_e3gnn, h_smiles, bad_rows).

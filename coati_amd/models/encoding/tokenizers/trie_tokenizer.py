@@ -106,6 +106,15 @@ class TrieTokenizer:
         mid = [self.vocab.get(t, -2) for t in self.smiles_tokens]
         self._native = _Native(self.special_tokens, sid, self.smiles_tokens, mid)
 
+    # pickling (the host feed's worker processes receive the tokenizer as an argument): the vocabulary travels, the native trie is
+    # rebuilt on the other side
+    def __getstate__(self):
+        return {"n_seq": self.n_seq, "smiles_tokens": self.smiles_tokens, "special_tokens": self.special_tokens,
+                "side_tasks": hasattr(self, "graph_token")}
+
+    def __setstate__(self, st):
+        self.__init__(**st)
+
     def pre_tokenize(self, text):
         return [p for p, _ in self._native.pieces(text)]
 

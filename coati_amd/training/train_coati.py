@@ -168,6 +168,26 @@ class _JsonlLogger:
         return name
 
 
+class _TrainerPipe:
+    """make_batcher of the trainer's BatchFeed (picklable: it crosses into the feed's worker processes): the reference's
+    dataset.get_data_pipe(..., xform_routine=clip_ar_xform) call (train_coati.py:363-376) with host tensors as the xform's output."""
+
+    def __init__(self, dataset, tokenizer, args, partition, world, rank, seed):
+        self.dataset, self.tokenizer, self.partition, self.world, self.rank, self.seed = dataset, tokenizer, partition, world, rank, seed
+        self.batch_size = args.batch_size
+        self.p = {k: getattr(args, k) for k in ("p_dataset", "p_formula", "p_fim", "p_graph", "p_clip", "p_clip_cut", "p_randsmiles")}
+
+    def xform(self, X):
+        if self.tokenizer is None:          # the synthetic batches are already in the post-xform format
+            return X
+        return clip_ar_xform(X, self.tokenizer, device="cpu", **self.p)
+
+    def __call__(self, worker, n_workers):
+        return self.dataset.get_data_pipe(batch_size=self.batch_size, partition=self.partition, distributed_rankmod_total=self.world,
+                                          distributed_rankmod_rank=self.rank, required_fields=["smiles"], xform_routine=self.xform,
+                                          worker=worker, n_workers=n_workers, seed=self.seed, indexed=True)
+
+
 def train_autoencoder(gpu, args, dataset=None, tokenizer=None):
     """train_coati.py:60-439.  `dataset` / `tokenizer` default to the synthetic stand-ins (no S3, no rdkit here)."""
     rank = args.nr * args.gpus + gpu
@@ -226,6 +246,8 @@ def train_autoencoder(gpu, args, dataset=None, tokenizer=None):
         return 0.5 * args.lr * (1.0 + math.cos(math.pi * epoch / max(args.n_epochs, 1)))
 
     opt_kw = dict(weight_decay=float(args.weight_decay), max_norm=float(args.clip_grad))   # train_coati.py:145-151, 276
+    if getattr(args, "reserve_seq", None):      # carve the step's buffers for the widest batch up front (Engine.reserve): no growth events later
+        eng.reserve(args.batch_size, int(args.reserve_seq), int(args.reserve_seq), int(getattr(args, "reserve_atoms", 1)))
 
     def do_epoch(epoch, partition="train"):
         nonlocal n_toks, ngrad_updates
@@ -243,17 +265,8 @@ def train_autoencoder(gpu, args, dataset=None, tokenizer=None):
         # same pipe runs in `feed_workers` processes AHEAD of the step (clip_ar_xform builds host tensors there) and the feed
         # uploads each batch from pinned staging on a copy stream (data/feed.py); the batch stream is the same for any worker count
         row_mode = getattr(dataset, "rows", None) is not None
-        xform_routine = (lambda X: clip_ar_xform(X, tokenizer, p_dataset=args.p_dataset, p_formula=args.p_formula, p_fim=args.p_fim,
-                                                 p_graph=args.p_graph, p_clip=args.p_clip, p_clip_cut=args.p_clip_cut,
-                                                 p_randsmiles=args.p_randsmiles, device="cpu")) if row_mode else (lambda X: X)
-
-        def make_batcher(worker, n_workers):
-            return dataset.get_data_pipe(batch_size=args.batch_size, partition=partition,
-                                         distributed_rankmod_total=world,
-                                         distributed_rankmod_rank=rank, required_fields=["smiles"], xform_routine=xform_routine,
-                                         worker=worker, n_workers=n_workers, seed=int(getattr(args, "feed_seed", 0)) + 7919 * epoch,
-                                         indexed=True)
-
+        make_batcher = _TrainerPipe(dataset, tokenizer if row_mode else None, args, partition, world, rank,
+                                    seed=int(getattr(args, "feed_seed", 0)) + 7919 * epoch)
         feed = BatchFeed(make_batcher, workers=int(getattr(args, "feed_workers", 4 if row_mode else 1)),
                          depth=int(getattr(args, "feed_depth", 3)), device=device)
         it = iter(feed)
