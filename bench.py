@@ -218,9 +218,12 @@ def feed_extras(eng, dev, args, MODEL):
         out["host_feed"]["workers"].append({"workers": w, "molecules_per_s": round(n * B / dt, 1), "first_batch_s": round(first, 3),
                                             "T1": int(last["raw_tokens"].shape[1]), "T2": int(last["tokens"].shape[1]),
                                             "mean_tokens_per_row": round(float((last["tokens"] > 0).sum()) / B, 1)})
-    # the step loop behind the feed
+    # the step loop behind the feed; like the trainer, reserve the buffers for the widest batch first (the rows re-segment to up to ~ 120
+    # tokens): a growth event inside the window re-allocates the 40-GB workspace (~ 1.3 s)
     W, nb = 8, 40
     up = torch.rand(B, device=dev) > 0.5
+    eng.reserve(B, 160, 160, args.atoms)
+    g0 = getattr(eng, "growth_events", 0)
     feed = BatchFeed(_FeedPipe(vocab, B, nb), workers=W, depth=3, device=dev)
     kept, k, t1 = [], 0, None
     for b in feed:
@@ -231,7 +234,7 @@ def feed_extras(eng, dev, args, MODEL):
             t1 = time.perf_counter()
             w0 = feed.stats["wait_s"]
         if k > 8 and len(kept) < 8:
-            kept.append(b)
+            kept.append({n: (v.clone() if v.is_cuda else v) for n, v in b.items()})      # a fed batch lives until the next one is taken
     torch.cuda.synchronize()
     e2e = (time.perf_counter() - t1) / (k - 8)
     waited = (feed.stats["wait_s"] - w0) / (k - 8)
@@ -248,6 +251,7 @@ def feed_extras(eng, dev, args, MODEL):
     out["end_to_end"] = {"workers": W, "steps": k - 8, "ms_per_step": round(1e3 * e2e, 3), "ms_per_step_replayed": round(1e3 * rep, 3),
                          "fed_over_replayed": round(e2e / rep, 4), "within_5pct": bool(e2e / rep <= 1.05),
                          "step_loop_wait_for_batch_ms": round(1e3 * waited, 3), "molecules_per_s": round(B / e2e, 1),
+                         "capacity": list(eng._cap), "growth_events_in_the_loop": getattr(eng, "growth_events", 0) - g0,
                          "rows": [int(x) for x in kept[0]["rows"].tolist()],
                          "note": "train_autoencoder's step loop (data/feed.py BatchFeed -> Engine.train_step) on batches made by the host path "
                                  "above, against 8 of the same batches replayed from HBM"}
@@ -255,6 +259,9 @@ def feed_extras(eng, dev, args, MODEL):
 
 
 def main():
+    if os.environ.get("COATI_BENCH_WATCHDOG"):      # debugging aid: dump every thread's stack and exit after N seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["COATI_BENCH_WATCHDOG"]), exit=True)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)

@@ -122,11 +122,22 @@ def _worker_main(make_batcher, worker, n_workers, out_q, stop_ev):
 
 
 class _Slot:
-    """one set of pinned staging buffers (grown on demand, kept) + the event of the last H2D copy that read them"""
+    """one set of pinned staging buffers + one set of device buffers (both grown on demand, kept: no allocator traffic per batch),
+    the event of the last H2D copy into them, and the consumer's "done with it" event"""
 
     def __init__(self):
         self.buf: Dict[str, torch.Tensor] = {}
+        self.dev: Dict[str, torch.Tensor] = {}
         self.event = None
+        self.done = None          # (batch number, event recorded by the consumer when it asked for the next batch)
+
+    def device_view(self, name, t: torch.Tensor, device) -> torch.Tensor:
+        n = t.numel()
+        d = self.dev.get(name)
+        if d is None or d.dtype != t.dtype or d.numel() < n:
+            d = torch.empty(max(n + n // 4, 1), dtype=t.dtype, device=device)
+            self.dev[name] = d
+        return d[:n].view(t.shape)
 
     def stage(self, name, t: torch.Tensor) -> torch.Tensor:
         n = t.numel()
@@ -147,7 +158,11 @@ class BatchFeed:
     index % n_workers == worker in increasing order (a `UrBatcher`); picklable (see the module docstring) unless workers = 0.
     workers = 0: the batcher runs inline in the feed thread (still ahead of the step, still pinned + asynchronous H2D).
     depth: batches in flight per worker queue and on the device side.  host_keys: entries left on the host (`rows`).
-    device = "cpu": no staging, no streams (CPU tests of ordering and determinism)."""
+    device = "cpu": no staging, no streams (CPU tests of ordering and determinism).
+
+    The device tensors of a batch are views into a ring of depth + 4 preallocated slots (no allocation per batch: a per-batch
+    allocation from the feed thread costs the training stream ~ 25 ms per step, tools/feed_e2e_probe.py): a batch is valid until
+    the NEXT call of __next__ -- work already enqueued on the consumer's stream at that moment is safe, later use needs a clone."""
 
     def __init__(self, make_batcher: Callable[[int, int], Iterable], workers: int = 2, depth: int = 3, device="cuda",
                  host_keys=("rows",), mp_context: Optional[str] = None):
@@ -164,6 +179,7 @@ class BatchFeed:
         self._ready: "queue.Queue" = queue.Queue(maxsize=self.depth)
         self._stop = threading.Event()
         self._started = False
+        self._last, self._taken = None, 0
 
     # ---- producer side -------------------------------------------------------------------------------------------------------
     def _start(self):
@@ -182,7 +198,7 @@ class BatchFeed:
                 self._queues.append(q)
         if self.device.type == "cuda":
             self._copy_stream = torch.cuda.Stream(device=self.device)
-            self._slots = [_Slot() for _ in range(self.depth + 1)]
+            self._slots = [_Slot() for _ in range(self.depth + 4)]
         self._thread = threading.Thread(target=self._pump, name="coati-feed", daemon=True)
         self._thread.start()
 
@@ -218,16 +234,28 @@ class BatchFeed:
     def _to_device(self, k: int, b: Dict[str, torch.Tensor]):
         if self.device.type != "cuda":
             return b, None
-        slot = self._slots[k % len(self._slots)]
+        R = len(self._slots)
+        slot = self._slots[k % R]
         if slot.event is not None:
             slot.event.synchronize()          # the copy that last read this slot's pinned buffers has finished
         out = {}
         with torch.cuda.stream(self._copy_stream):
+            if k >= R:
+                # the slot's device buffers held batch k - R: the copy stream waits (on the device) for the consumer's kernels that
+                # read it.  The consumer marks a batch done when it asks for the next one, and it is >= 2 batches past k - R by now
+                # (queue depth + the one in hand < R - 2); the loop below only guards that invariant.
+                while not (slot.done is not None and slot.done[0] == k - R):
+                    if self._stop.is_set():
+                        return None, None
+                    time.sleep(0.0005)
+                self._copy_stream.wait_event(slot.done[1])
             for name, t in b.items():
                 if name in self.host_keys:
                     out[name] = t
                     continue
-                out[name] = slot.stage(name, t).to(self.device, non_blocking=True)
+                d = slot.device_view(name, t, self.device)
+                d.copy_(slot.stage(name, t), non_blocking=True)
+                out[name] = d
                 self.stats["h2d_bytes"] += t.numel() * t.element_size()
             ev = torch.cuda.Event()
             ev.record(self._copy_stream)
@@ -270,6 +298,13 @@ class BatchFeed:
     def __next__(self) -> Dict[str, torch.Tensor]:
         if not self._started:
             self._start()
+        if self._last is not None:
+            # everything enqueued so far that reads the previous batch is in front of this event: its slot may be refilled behind it
+            k, slot = self._last
+            done = torch.cuda.Event()
+            done.record(torch.cuda.current_stream(self.device))
+            slot.done = (k, done)
+            self._last = None
         t0 = time.perf_counter()
         b, ev = self._ready.get()
         self.stats["wait_s"] += time.perf_counter() - t0
@@ -280,11 +315,9 @@ class BatchFeed:
             self.close()
             raise StopIteration
         if ev is not None:
-            cur = torch.cuda.current_stream(self.device)
-            cur.wait_event(ev)
-            for name, t in b.items():
-                if t.is_cuda:
-                    t.record_stream(cur)       # allocated on the copy stream, used on the consumer's
+            torch.cuda.current_stream(self.device).wait_event(ev)
+            self._last = (self._taken, self._slots[self._taken % len(self._slots)])
+        self._taken += 1
         self.stats["batches"] += 1
         return b
 

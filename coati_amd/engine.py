@@ -154,6 +154,7 @@ class Engine:
             new = (new[0], min(max(tmax, new[1]), -(-new[1] // 32) * 32), min(max(tmax, new[2]), -(-new[2] // 32) * 32), new[3])
             _lib.check(self.l.coati_engine_reserve(self.h, *new), "coati_engine_reserve")
             self._cap = new
+            self.growth_events = getattr(self, "growth_events", 0) + 1
         cb, c1, c2, ca = self._cap
         need = int(self.l.coati_engine_workspace_bytes(self.h, max(B, cb), max(T1, c1), max(T2, c2), max(A, ca), max(B, cb) * world))
         if self.workspace is None or self.workspace.numel() < need:
@@ -161,10 +162,23 @@ class Engine:
             self.workspace = torch.empty(need, device=self.device, dtype=torch.uint8)
         return need
 
-    def reserve(self, B, T1, T2, A):
+    def reserve(self, B, T1, T2, A, headroom=0.9):
         """Carve every buffer for batches of up to B molecules, T1 / T2 token columns and A atoms now (coati_engine_reserve): later
-        batches inside these limits never trigger a growth event."""
-        self._ensure_workspace(int(B), int(T1), int(T2), int(A))
+        batches inside these limits never trigger a growth event (a growth event re-allocates the workspace -- 34 -> 42 GB when the
+        width capacity goes from 128 to 160 columns at B = 1024 -- and costs ~ 1.3 s: profiles/r06_feed_e2e_probe.txt).  The buffers
+        are sized for the PADDED layout of the capacity (B x T rows per pass).  Returns False, and reserves nothing, when that
+        does not fit into `headroom` of the memory that is free now."""
+        B, T1, T2, A = int(B), min(int(T1), int(self.cfg.n_seq)), min(int(T2), int(self.cfg.n_seq)), int(A)
+        cap = getattr(self, "_cap", (0, 0, 0, 0))
+        want = tuple(max(a, b) for a, b in zip(cap, (B, T1, T2, A)))
+        need = int(self.l.coati_engine_workspace_bytes(self.h, *want, want[0]))
+        have = self.workspace.numel() if self.workspace is not None else 0
+        if need > have:
+            free, _ = torch.cuda.mem_get_info(self.device)
+            if need > headroom * (free + have):
+                return False
+        self._ensure_workspace(B, T1, T2, A)
+        return True
 
     def forward(self, raw_tokens, tokens, atoms, coords, use_point, y_next=None, train=True, rows=None, stop_after_heads=False):
         """forward_dist (+ AR loss sums when y_next is given).  Returns (h_e3gnn, h_smiles, bad_rows).

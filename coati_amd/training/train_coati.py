@@ -246,8 +246,12 @@ def train_autoencoder(gpu, args, dataset=None, tokenizer=None):
         return 0.5 * args.lr * (1.0 + math.cos(math.pi * epoch / max(args.n_epochs, 1)))
 
     opt_kw = dict(weight_decay=float(args.weight_decay), max_norm=float(args.clip_grad))   # train_coati.py:145-151, 276
-    if getattr(args, "reserve_seq", None):      # carve the step's buffers for the widest batch up front (Engine.reserve): no growth events later
-        eng.reserve(args.batch_size, int(args.reserve_seq), int(args.reserve_seq), int(getattr(args, "reserve_atoms", 1)))
+    # carve the step's buffers for the widest batch the tokenizer can emit, up front (Engine.reserve): every later growth of the
+    # width capacity would re-allocate a workspace of tens of GB in the middle of training (~ 1.3 s each at B = 1024)
+    rs = getattr(args, "reserve_seq", None)
+    rs = min(int(tokenizer.n_seq), int(model_kwargs["n_seq"])) if rs is None else int(rs)
+    if rs > 0 and not eng.reserve(args.batch_size, rs, rs, int(getattr(args, "reserve_atoms", 1))):
+        print(f"rank {rank}: no room to reserve the step's buffers for {rs} columns up front; they will grow with the batches")
 
     def do_epoch(epoch, partition="train"):
         nonlocal n_toks, ngrad_updates

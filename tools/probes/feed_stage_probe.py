@@ -3,7 +3,8 @@ import os, sys, time, json, torch, numpy as np, multiprocessing as mp
 sys.path.insert(0, os.getcwd())
 def child(q, ev):
     a = np.zeros((1024, 114), dtype=np.int64)
-    while not ev.is_set():
+    t_end = time.time() + 20.0          # never outlive the probe
+    while not ev.is_set() and time.time() < t_end:
         t=time.time()
         while time.time()-t < 0.02: pass     # busy 20 ms
         try: q.put({"a": a, "b": a, "c": a}, timeout=0.1)
@@ -49,3 +50,4 @@ if __name__ == "__main__":
     for m in ("fork", "spawn", "forkserver"):
         for n in (0, 4, 8):
             run(n, m)
+    os._exit(0)
