@@ -328,13 +328,13 @@ static int launch_attn_fwd_t(const bf16_t* qkv, bf16_t* y, float* lse, int B, in
   return COATI_OK;
 }
 
-int launch_attn_fwd(const bf16_t* qkv, bf16_t* y, float* lse, int B, int T, int n_head, int head_size, hipStream_t s, const int* seq_off) {
+int launch_attn_fwd(const bf16_t* qkv, bf16_t* y, float* lse, int B, int T, int n_head, int head_size, hipStream_t s, const int* seq_off, const int* seq_ord) {
   COATI_CHECK_ARG(qkv && y && lse, "attn_fwd: null operand");
   COATI_CHECK_SHAPE(B > 0 && T > 0 && T <= 256 && n_head > 0 && (head_size == 16 || head_size == 32),
                     "attn_fwd: unsupported shape B=%d T=%d nh=%d hs=%d", B, T, n_head, head_size);
   // round 6: head size 16, T <= 128 on 16-row causal granularity (attention16.hip); COATI_ATTN_BLOCK32=1 keeps the 32-row kernels for A/B runs
   static const bool block32 = getenv("COATI_ATTN_BLOCK32") != nullptr;
-  if (head_size == 16 && T <= 128 && !block32) return launch_attn16_fwd(qkv, y, lse, B, T, n_head, s, seq_off);
+  if (head_size == 16 && T <= 128 && !block32) return launch_attn16_fwd(qkv, y, lse, B, T, n_head, s, seq_off, seq_ord);
   const int nb = (T + 31) / 32;
 #define FWD_CASE(H, N) if (head_size == H && nb == N) return launch_attn_fwd_t<H, N>(qkv, y, lse, B, T, n_head, s, seq_off);
   FWD_CASE(16, 1) FWD_CASE(16, 2) FWD_CASE(16, 3) FWD_CASE(16, 4)
@@ -800,12 +800,12 @@ static int launch_attn_bwd_t(const bf16_t* qkv, const bf16_t* y, const bf16_t* d
 
 int launch_attn_bwd(const bf16_t* qkv, const bf16_t* y, const bf16_t* dy, const float* lse, float* dscratch,
                     bf16_t* dqkv, const float* cos_t, const float* sin_t, int B, int T, int n_head, int head_size, hipStream_t s,
-                    const int* seq_off) {
+                    const int* seq_off, const int* seq_ord) {
   COATI_CHECK_ARG(qkv && y && dy && lse && dscratch && dqkv && cos_t && sin_t, "attn_bwd: null operand");
   COATI_CHECK_SHAPE(B > 0 && T > 0 && T <= 256 && n_head > 0 && (head_size == 16 || head_size == 32),
                     "attn_bwd: unsupported shape B=%d T=%d nh=%d hs=%d", B, T, n_head, head_size);
   static const bool block32 = getenv("COATI_ATTN_BLOCK32") != nullptr;
-  if (head_size == 16 && T <= 128 && !block32) return launch_attn16_bwd(qkv, y, dy, lse, dqkv, cos_t, sin_t, B, T, n_head, s, seq_off);
+  if (head_size == 16 && T <= 128 && !block32) return launch_attn16_bwd(qkv, y, dy, lse, dqkv, cos_t, sin_t, B, T, n_head, s, seq_off, seq_ord);
   // T <= 128: the single-sweep kernel (grande: 120 vs 141 us); longer sequences: the two kernels below
   if (T <= 128) {
     const int nb = (T + 31) / 32;

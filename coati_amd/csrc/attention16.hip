@@ -225,8 +225,9 @@ __device__ __forceinline__ void att16_fwd_body(const bf16_t* __restrict__ qkv, b
 
 template <int NBMAX>
 __global__ __launch_bounds__(256) void att16_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ y, float* __restrict__ lse,
-                                                        int Tl, int n_head, int quads, const int* __restrict__ seq_off) {
-  const int b = blockIdx.x / quads, hq = blockIdx.x - b * quads;
+                                                        int Tl, int n_head, int quads, const int* __restrict__ seq_off, const int* __restrict__ seq_ord) {
+  const int bi = blockIdx.x / quads, hq = blockIdx.x - bi * quads;
+  const int b = seq_ord != nullptr ? seq_ord[bi] : bi;      // launch order: the long sequences first (embed.hip seq_scan_kernel)
   ATT_SEQ(0);
   const int nb = (T + 15) >> 4;   // uniform over the workgroup: it runs the body compiled for ITS sequence's block count
 #define A16_CASE(N)                                                                   \
@@ -241,16 +242,17 @@ __global__ __launch_bounds__(256) void att16_fwd_kernel(const bf16_t* __restrict
 
 size_t att16_fwd_lds(int T) { return (size_t)4 * ((size_t)3 * 16 * cdiv(T, 16) * 32 + ATT_PW_PAD); }
 
-int launch_attn16_fwd(const bf16_t* qkv, bf16_t* y, float* lse, int B, int T, int n_head, hipStream_t s, const int* seq_off) {
+int launch_attn16_fwd(const bf16_t* qkv, bf16_t* y, float* lse, int B, int T, int n_head, hipStream_t s, const int* seq_off, const int* seq_ord) {
+  if (seq_off == nullptr) seq_ord = nullptr;   // the padded layout has one length
   COATI_CHECK_SHAPE(T > 0 && T <= 128, "attn16_fwd: T=%d", T);
   const int quads = cdiv(n_head, 4), nb = cdiv(T, 16);
   size_t lds = att16_fwd_lds(T);
 #ifdef A16_PROBE_LDS_EXTRA
   lds += A16_PROBE_LDS_EXTRA;
 #endif
-  if (nb <= 3) hipLaunchKernelGGL((att16_fwd_kernel<3>), dim3(B * quads), dim3(256), lds, s, qkv, y, lse, T, n_head, quads, seq_off);
-  else if (nb <= 5) hipLaunchKernelGGL((att16_fwd_kernel<5>), dim3(B * quads), dim3(256), lds, s, qkv, y, lse, T, n_head, quads, seq_off);
-  else hipLaunchKernelGGL((att16_fwd_kernel<8>), dim3(B * quads), dim3(256), lds, s, qkv, y, lse, T, n_head, quads, seq_off);
+  if (nb <= 3) hipLaunchKernelGGL((att16_fwd_kernel<3>), dim3(B * quads), dim3(256), lds, s, qkv, y, lse, T, n_head, quads, seq_off, seq_ord);
+  else if (nb <= 5) hipLaunchKernelGGL((att16_fwd_kernel<5>), dim3(B * quads), dim3(256), lds, s, qkv, y, lse, T, n_head, quads, seq_off, seq_ord);
+  else hipLaunchKernelGGL((att16_fwd_kernel<8>), dim3(B * quads), dim3(256), lds, s, qkv, y, lse, T, n_head, quads, seq_off, seq_ord);
   COATI_LAUNCH_CHECK("attn16_fwd");
   return COATI_OK;
 }
@@ -430,8 +432,9 @@ __device__ __forceinline__ void att16_bwd_body(const bf16_t* __restrict__ qkv, c
 template <int NBMAX>
 __global__ __launch_bounds__(256, NBMAX <= 5 ? 4 : 2) void att16_bwd_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ y, const bf16_t* __restrict__ dy,
                                                         const float* __restrict__ lse, bf16_t* __restrict__ dqkv, const float* __restrict__ cos_t,
-                                                        const float* __restrict__ sin_t, int Tl, int n_head, int quads, const int* __restrict__ seq_off) {
-  const int b = blockIdx.x / quads, hq = blockIdx.x - b * quads;
+                                                        const float* __restrict__ sin_t, int Tl, int n_head, int quads, const int* __restrict__ seq_off, const int* __restrict__ seq_ord) {
+  const int bi = blockIdx.x / quads, hq = blockIdx.x - bi * quads;
+  const int b = seq_ord != nullptr ? seq_ord[bi] : bi;
   ATT_SEQ(0);
   const int nb = (T + 15) >> 4;
 #define A16_CASE(N)                                                                                  \
@@ -445,16 +448,17 @@ __global__ __launch_bounds__(256, NBMAX <= 5 ? 4 : 2) void att16_bwd_kernel(cons
 }
 
 int launch_attn16_bwd(const bf16_t* qkv, const bf16_t* y, const bf16_t* dy, const float* lse, bf16_t* dqkv, const float* cos_t,
-                      const float* sin_t, int B, int T, int n_head, hipStream_t s, const int* seq_off) {
+                      const float* sin_t, int B, int T, int n_head, hipStream_t s, const int* seq_off, const int* seq_ord) {
   COATI_CHECK_SHAPE(T > 0 && T <= 128, "attn16_bwd: T=%d", T);
+  if (seq_off == nullptr) seq_ord = nullptr;
   const int quads = cdiv(n_head, 4), nb = cdiv(T, 16);
   size_t lds = (size_t)4 * ((size_t)3 * 16 * nb * 32 + (size_t)2 * 16 * nb * 4 + 2 * 16 * A16_DST_PITCH * 2 + ATT_PW_PAD);
 #ifdef A16_PROBE_LDS_EXTRA
   lds += A16_PROBE_LDS_EXTRA;
 #endif
-  if (nb <= 3) hipLaunchKernelGGL((att16_bwd_kernel<3>), dim3(B * quads), dim3(256), lds, s, qkv, y, dy, lse, dqkv, cos_t, sin_t, T, n_head, quads, seq_off);
-  else if (nb <= 5) hipLaunchKernelGGL((att16_bwd_kernel<5>), dim3(B * quads), dim3(256), lds, s, qkv, y, dy, lse, dqkv, cos_t, sin_t, T, n_head, quads, seq_off);
-  else hipLaunchKernelGGL((att16_bwd_kernel<8>), dim3(B * quads), dim3(256), lds, s, qkv, y, dy, lse, dqkv, cos_t, sin_t, T, n_head, quads, seq_off);
+  if (nb <= 3) hipLaunchKernelGGL((att16_bwd_kernel<3>), dim3(B * quads), dim3(256), lds, s, qkv, y, dy, lse, dqkv, cos_t, sin_t, T, n_head, quads, seq_off, seq_ord);
+  else if (nb <= 5) hipLaunchKernelGGL((att16_bwd_kernel<5>), dim3(B * quads), dim3(256), lds, s, qkv, y, dy, lse, dqkv, cos_t, sin_t, T, n_head, quads, seq_off, seq_ord);
+  else hipLaunchKernelGGL((att16_bwd_kernel<8>), dim3(B * quads), dim3(256), lds, s, qkv, y, dy, lse, dqkv, cos_t, sin_t, T, n_head, quads, seq_off, seq_ord);
   COATI_LAUNCH_CHECK("attn16_bwd");
   return COATI_OK;
 }

@@ -227,14 +227,25 @@ __global__ __launch_bounds__(256) void seq_len_kernel(const long long* __restric
   if (lane == 0) len[b] = last;
 }
 // exclusive scan of len[0..B) in place -> off[0..B], off[B] = total; err |= 2 when the total differs from the host's count
-__global__ __launch_bounds__(1024) void seq_scan_kernel(int* __restrict__ off, int B, int expect, int* __restrict__ err) {
+// ord (optional): the sequences in order of DESCENDING 16-row block count (a counting sort over 0 .. 8+ blocks; ties in arbitrary order) --
+// the launch schedule of the attention kernels (attention16.hip): workgroups are dispatched in index order, so the long sequences
+// go first and the short ones fill the tail of the launch.  A schedule only: no result depends on it.
+__global__ __launch_bounds__(1024) void seq_scan_kernel(int* __restrict__ off, int B, int expect, int* __restrict__ err, int* __restrict__ ord) {
   __shared__ int part[1024];
+  __shared__ int cnt[10], cur[10];
   const int t = threadIdx.x, per = (B + 1023) / 1024;
   const int lo = t * per, hi = lo + per < B ? lo + per : B;
+  if (t < 10) cnt[t] = 0;
+  __syncthreads();
   int sum = 0;
-  for (int i = lo; i < hi; ++i) sum += off[i];
+  for (int i = lo; i < hi; ++i) {
+    const int l = off[i];
+    sum += l;
+    if (ord != nullptr) { const int nb = (l + 15) >> 4; atomicAdd(&cnt[9 - (nb < 9 ? nb : 9)], 1); }
+  }
   part[t] = sum;
   __syncthreads();
+  if (t == 0) { int run = 0; for (int k = 0; k < 10; ++k) { cur[k] = run; run += cnt[k]; } }
   for (int o = 1; o < 1024; o <<= 1) {
     const int v = t >= o ? part[t - o] : 0;
     __syncthreads();
@@ -242,7 +253,12 @@ __global__ __launch_bounds__(1024) void seq_scan_kernel(int* __restrict__ off, i
     __syncthreads();
   }
   int run = part[t] - sum;
-  for (int i = lo; i < hi; ++i) { const int l = off[i]; off[i] = run; run += l; }
+  for (int i = lo; i < hi; ++i) {
+    const int l = off[i];
+    off[i] = run;
+    run += l;
+    if (ord != nullptr) { const int nb = (l + 15) >> 4; ord[atomicAdd(&cur[9 - (nb < 9 ? nb : 9)], 1)] = i; }
+  }
   if (t == 1023) {
     off[B] = part[1023];
     if (part[1023] != expect) atomicOr(err, 2);
@@ -272,11 +288,11 @@ __global__ void seq_fill_kernel(const int* __restrict__ off, const long long* __
   if (ypk != nullptr) ypk[m] = y[g];
 }
 int launch_seq_pack(const long long* tok, const long long* y, int pad_token, int B, int T, int rows_expect, int* off,
-                    int* row_src, int* row_t, long long* ypk, int* err, hipStream_t s) {
+                    int* row_src, int* row_t, long long* ypk, int* err, hipStream_t s, int* ord) {
   COATI_CHECK_ARG(tok && off && row_src && row_t && err && (ypk == nullptr || y != nullptr), "seq_pack: null operand");
   COATI_CHECK_SHAPE(B > 0 && T > 0 && rows_expect > 0 && rows_expect <= (long long)B * T, "seq_pack: bad row count %d for %d x %d", rows_expect, B, T);
   hipLaunchKernelGGL(seq_len_kernel, dim3(cdiv(B, 4)), dim3(256), 0, s, tok, y, pad_token, off, B, T);
-  hipLaunchKernelGGL(seq_scan_kernel, dim3(1), dim3(1024), 0, s, off, B, rows_expect, err);
+  hipLaunchKernelGGL(seq_scan_kernel, dim3(1), dim3(1024), 0, s, off, B, rows_expect, err, ord);
   hipLaunchKernelGGL(seq_fill_kernel, dim3(cdiv((long long)B * T, 256)), dim3(256), 0, s, off, y, row_src, row_t, ypk, B, T, rows_expect);
   COATI_LAUNCH_CHECK("seq_pack");
   return COATI_OK;

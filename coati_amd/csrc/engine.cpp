@@ -75,6 +75,7 @@ struct XPass {  // saved activations of one transformer pass
   // packed rows (embed.hip launch_seq_pack): the pass runs on the concatenation of every row's real prefix
   bool packed = false;
   int* off = nullptr;        // [B + 1] first packed row of each sequence
+  int* ord = nullptr;        // [B] the sequences by descending 16-row block count: launch order of the attention kernels
   int* row_src = nullptr;    // [M] slot b * T + t of packed row m
   int* row_t = nullptr;      // [M] token position of packed row m (rotary embedding)
   long long* ypk = nullptr;  // [M] packed targets (decoder pass)
@@ -480,6 +481,11 @@ struct ProfScope {
 };
 
 // ---- GEMM helpers -------------------------------------------------------------------------------------
+// A/B switch of the attention launch order (COATI_ATTN_LPT=0: sequences in batch order)
+static bool lpt_on() {
+  static const bool on = []() { const char* v = getenv("COATI_ATTN_LPT"); return !(v && v[0] == '0'); }();
+  return on;
+}
 int gemm(coati_engine* e, int site, const void* A, int a_f32, int64_t lda, const bf16_t* Bm, int64_t ldb, int M,
          int N, int K, void* Cm, int64_t ldc, const float* bias, int epi, const void* aux_in, void* aux_out,
          int64_t ld_aux, hipStream_t s) {
@@ -558,7 +564,7 @@ void carve_pass(coati_engine* e, Arena& ar, XPass& p, int B_, int T_, int B, int
   p.t_a2 = ar.take<bf16_t>((size_t)B * C); p.t_g = ar.take<bf16_t>((size_t)B * 4 * C); p.t_hpre = ar.take<unsigned char>((size_t)B * 4 * C);
   p.tail = false;
   p.packed = false;
-  p.off = ar.take<int>((size_t)B + 1); p.row_src = ar.take<int>(M); p.row_t = ar.take<int>(M); p.ypk = ar.take<long long>(M);
+  p.off = ar.take<int>((size_t)B + 1); p.ord = ar.take<int>((size_t)B); p.row_src = ar.take<int>(M); p.row_t = ar.take<int>(M); p.ypk = ar.take<long long>(M);
   p.grp = ar.take<int>((size_t)B + 2);
 }
 
@@ -737,7 +743,7 @@ int xformer_fwd(coati_engine* e, XPass& p, const float* injection, hipStream_t s
       COATI_TRY(gemm8(e, SITE_QKV_FWD, w, 0, p.a1[l], C, M, 3 * C, C, a, EPI_QKV_ROPE, s));
       {
         ProfScope ps(e, SITE_ATTN_FWD, 4.0 * M * (double)p.T * C, s, (double)M * 4 * C * 2 + (double)M * c.n_head * 4);
-        COATI_TRY(launch_attn_fwd(p.qkv[l], p.y[l], p.lse[l], p.B, p.T, c.n_head, C / c.n_head, s, p.packed ? p.off : nullptr));
+        COATI_TRY(launch_attn_fwd(p.qkv[l], p.y[l], p.lse[l], p.B, p.T, c.n_head, C / c.n_head, s, p.packed ? p.off : nullptr, p.packed && lpt_on() ? p.ord : nullptr));
       }
       memset(&a, 0, sizeof(a));
       a.C = p.xmid[l]; a.ldc = C; a.bias = e->P + w.projb; a.aux_in = p.x[l]; a.ld_aux = C;
@@ -776,7 +782,7 @@ int xformer_fwd(coati_engine* e, XPass& p, const float* injection, hipStream_t s
     if (!ab) {
       {
         ProfScope ps(e, SITE_ATTN_FWD, 4.0 * M * (double)p.T * C, s, (double)M * 4 * C * 2 + (double)M * c.n_head * 4);   // qkv in, y + lse out
-        COATI_TRY(launch_attn_fwd(p.qkv[l], p.y[l], p.lse[l], p.B, p.T, c.n_head, C / c.n_head, s, p.packed ? p.off : nullptr));
+        COATI_TRY(launch_attn_fwd(p.qkv[l], p.y[l], p.lse[l], p.B, p.T, c.n_head, C / c.n_head, s, p.packed ? p.off : nullptr, p.packed && lpt_on() ? p.ord : nullptr));
       }
       COATI_TRY(gemm(e, SITE_PROJ_FWD, p.y[l], 0, C, e->S + w.projw, C, M, C, C, p.xmid[l], C, e->P + w.projb, EPI_RES_F32, p.x[l], nullptr, C, s));
     }
@@ -1030,7 +1036,7 @@ int xformer_bwd(coati_engine* e, XPass& p, const void* dyf, int dyf_f32, float* 
     if (!grp) COATI_TRY(wgrad(e, SITE_XF_WGRAD, dxb, 0, C, p.y[l], C, M, C, C, e->G + w.projw, C, e->G + w.projb, 0, s));
     {
       ProfScope ps(e, SITE_ATTN_BWD, 10.0 * M * (double)p.T * C, s, (double)M * 8 * C * 2 + (double)M * c.n_head * 8);   // qkv, y, dy in; dqkv out
-      COATI_TRY(launch_attn_bwd(p.qkv[l], p.y[l], e->dyb, p.lse[l], e->attnD, dqkv, e->cos_t, e->sin_t, p.B, p.T, c.n_head, C / c.n_head, s, p.packed ? p.off : nullptr));
+      COATI_TRY(launch_attn_bwd(p.qkv[l], p.y[l], e->dyb, p.lse[l], e->attnD, dqkv, e->cos_t, e->sin_t, p.B, p.T, c.n_head, C / c.n_head, s, p.packed ? p.off : nullptr, p.packed && lpt_on() ? p.ord : nullptr));
     }
     if (c.use_fp8) {
       GemmArgs a;
@@ -1509,8 +1515,8 @@ int coati_engine_forward(coati_engine* e, void* workspace, int64_t workspace_byt
   // ---- packed rows: both transformer passes run on the rows' real prefixes only (embed.hip, launch_seq_pack); the counts
   // come from the caller (the batch assembler knows them on the host: no device -> host sync here), the device checks them
   if (rows1 > 0) {
-    COATI_TRY(launch_seq_pack(e->p1.idx, nullptr, c.pad_token, B, T1, (int)rows1, e->p1.off, e->p1.row_src, e->p1.row_t, nullptr, e->err_flag, s));
-    COATI_TRY(launch_seq_pack(e->p2.idx, e->y_next, c.pad_token, B, T2, (int)rows2, e->p2.off, e->p2.row_src, e->p2.row_t, e->y_next ? e->p2.ypk : nullptr, e->err_flag, s));
+    COATI_TRY(launch_seq_pack(e->p1.idx, nullptr, c.pad_token, B, T1, (int)rows1, e->p1.off, e->p1.row_src, e->p1.row_t, nullptr, e->err_flag, s, e->p1.ord));
+    COATI_TRY(launch_seq_pack(e->p2.idx, e->y_next, c.pad_token, B, T2, (int)rows2, e->p2.off, e->p2.row_src, e->p2.row_t, e->y_next ? e->p2.ypk : nullptr, e->err_flag, s, e->p2.ord));
     e->p1.packed = e->p2.packed = true;
     e->p1.M = (int)rows1;
     e->p2.M = (int)rows2;

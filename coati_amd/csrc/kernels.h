@@ -241,15 +241,16 @@ int launch_ln_finish_batched(const float* partial, long long slot_stride, int nb
 // ------------------------------------------------------------------------------------------------
 // seq_off [B + 1] (optional): packed rows -- sequence b owns rows seq_off[b] .. seq_off[b + 1] of qkv / y / dy / dqkv and has
 // that many tokens (<= T); lse / dscratch keep the padded [B, nh, T] layout
+// seq_ord (packed rows, head size 16): the launch order of the sequences, longest first (launch_seq_pack)
 int launch_attn_fwd(const bf16_t* qkv, bf16_t* y, float* lse, int B, int T, int n_head, int head_size, hipStream_t s,
-                    const int* seq_off = nullptr);
+                    const int* seq_off = nullptr, const int* seq_ord = nullptr);
 int launch_attn_bwd(const bf16_t* qkv, const bf16_t* y, const bf16_t* dy, const float* lse, float* dscratch, bf16_t* dqkv,
                     const float* cos, const float* sin, int B, int T, int n_head, int head_size, hipStream_t s,
-                    const int* seq_off = nullptr);
+                    const int* seq_off = nullptr, const int* seq_ord = nullptr);
 // head size 16, T <= 128 on 16-row causal granularity (attention16.hip); launch_attn_fwd / _bwd route there
-int launch_attn16_fwd(const bf16_t* qkv, bf16_t* y, float* lse, int B, int T, int n_head, hipStream_t s, const int* seq_off);
+int launch_attn16_fwd(const bf16_t* qkv, bf16_t* y, float* lse, int B, int T, int n_head, hipStream_t s, const int* seq_off, const int* seq_ord = nullptr);
 int launch_attn16_bwd(const bf16_t* qkv, const bf16_t* y, const bf16_t* dy, const float* lse, bf16_t* dqkv, const float* cos_t,
-                      const float* sin_t, int B, int T, int n_head, hipStream_t s, const int* seq_off);
+                      const float* sin_t, int B, int T, int n_head, hipStream_t s, const int* seq_off, const int* seq_ord = nullptr);
 
 #ifdef COATI_EXPERIMENTAL
 // The attention half of a block as one sequence-stationary kernel (attn_block.hip): xmid = x + c_proj(attention(RoPE(c_attn(ln_1(x))))),
@@ -296,7 +297,7 @@ int launch_embed_bwd(const long long* idx, const float* dx, float* dtable, float
 // row_src / row_t [rows_expect] ints, ypk [rows_expect] (optional: the packed targets); err |= 2 when the device-side total
 // differs from rows_expect (the count the caller computed on the host)
 int launch_seq_pack(const long long* tok, const long long* y, int pad_token, int B, int T, int rows_expect, int* off,
-                    int* row_src, int* row_t, long long* ypk, int* err, hipStream_t s);
+                    int* row_src, int* row_t, long long* ypk, int* err, hipStream_t s, int* ord = nullptr);
 // pos[b] = position of the single stop token of row b; err[0] |= 1 if some row has != 1 stop tokens
 int launch_find_stop(const long long* idx, int stop_token, int* pos, int* err, int B, int T, hipStream_t s);
 int launch_gather_rows(const float* x, const int* pos, float* out, int B, int T, int C, hipStream_t s, const int* off = nullptr);
