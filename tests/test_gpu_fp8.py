@@ -80,6 +80,9 @@ def test_gemm_mx8_vs_dequantised_fp32(ops, M, N, K):
 FP8_SIM_TOL = {"d128": (5e-4, 0.144), "d512": (5e-4, 0.08)}      # measured: losses 2e-5 .. 1.8e-4, gradients 7.2e-2 / 3.9e-2 (values on an e4m3 boundary flip by one 6 % step)
 
 
+FP8_SIM_RMS_TOL = {"d128": 0.126, "d512": 0.084}   # 2 x measured (6.3e-2 / 4.2e-2: operands of the kernel and of the simulation round apart on many boundaries, not on a few)
+
+
 @pytest.mark.parametrize("name,kw,shape", [
     ("d128", dict(n_layer_e3gnn=1, n_layer_xformer=2, n_hidden_xformer=128, n_hidden_e3nn=128, n_embd_common=128, n_head=8, n_seq=64, n_tok=300), (48, 40, 10)),
     ("d512", dict(n_layer_e3gnn=1, n_layer_xformer=1, n_hidden_xformer=512, n_hidden_e3nn=512, n_embd_common=512, n_head=16, n_seq=250, n_tok=4266), (128, 80, 16)),
@@ -130,13 +133,20 @@ def test_engine_fp8_step_vs_bf16_path_and_oracle(name, kw, shape):
         loss_s, ar_s, cl_s, _ = O.step_loss(Ps, ocfg, {k: v for k, v in batch.items() if k != "rows"}, up)
     loss_s.backward()
     assert abs(L8["ar_loss"] - float(ar_s)) <= FP8_SIM_TOL[name][0] * abs(float(ar_s)) and abs(L8["clip_loss"] - float(cl_s)) <= FP8_SIM_TOL[name][0] * abs(float(cl_s)), (L8, float(ar_s), float(cl_s))
-    worst8s = []
+    worst8s, rms8s = [], []
     for k in sorted(g8):
         ref = Ps[k].grad if Ps[k].grad is not None else torch.zeros_like(P[k])
         sc = float(ref.abs().max())
         if sc > 0:
             worst8s.append((float((g8[k] - ref).abs().max()) / sc, k))
+            # the same deviation in the 2-norm of the whole tensor: an element that sits on an e4m3 boundary and flips by one 6 % step
+            # moves the MAX bound above, but a handful of flips is nothing in the norm -- while a wrong block scale on one Linear
+            # (a factor 2 on 1/16 of its k blocks) is >= 25 % of that Linear's gradient norm.  This is the bound that would catch it.
+            rms8s.append((float((g8[k].double() - ref.double()).norm()) / float(ref.double().norm()), k))
     worst8s.sort(reverse=True)
+    rms8s.sort(reverse=True)
+    log(f"fp8 [{name}] vs the fp8-simulating oracle, relative 2-norm deviation per tensor: worst {rms8s[:4]}")
+    assert rms8s[0][0] <= FP8_SIM_RMS_TOL[name], rms8s[:5]
     log(f"fp8 [{name}] vs the fp8-simulating oracle: losses {L8['ar_loss']:.5f} / {L8['clip_loss']:.5f} vs {float(ar_s):.5f} / {float(cl_s):.5f}; worst gradient deviations {worst8s[:3]}")
     assert worst8s[0][0] <= FP8_SIM_TOL[name][1], worst8s[:5]
     # cosine of every gradient tensor with the oracle's: the direction survives e4m3
