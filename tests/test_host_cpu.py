@@ -474,3 +474,18 @@ def test_attention_score_efficiency_of_the_bench_workload():
     assert e16 >= 0.6 and 0.38 <= e32 <= 0.46 and e16 > 1.4 * e32, (e16, e32)
     assert attention_score_efficiency(torch.tensor([16, 32]), 16) == (136 + 528) / (256.0 * 4)
     assert attention_score_efficiency(torch.tensor([0, 17]), 16) == 153 / (256.0 * 3)
+
+
+def test_committed_step_traffic_does_not_regress():
+    """`_step.hbm_GB_per_step` of the newest committed PMC summary (profiles/rNN_pmc_summary.json: rocprofv3 FETCH_SIZE / WRITE_SIZE passes over
+    the bench command, tools/profile_round.sh): the step's HBM traffic must not creep up from round to round unnoticed.  The bound is
+    the round-5 value (88.06 GB) + 2 %; the kernels the bench line's `roofline.traffic` names must be in the summary."""
+    import glob
+    import json
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r*_pmc_summary.json")))
+    assert files, "no PMC summary committed"
+    d = json.load(open(files[-1]))
+    assert "_step" in d and "dgrad_lnbwd" in d and "xf_wgrad" in d, (files[-1], list(d))
+    step = d["_step"]
+    assert abs(step["hbm_read_GB_per_step"] + step["hbm_write_GB_per_step"] - step["hbm_GB_per_step"]) < 0.05
+    assert step["hbm_GB_per_step"] <= 88.06 * 1.02, (files[-1], step["hbm_GB_per_step"])

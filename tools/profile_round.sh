@@ -1,8 +1,8 @@
 #!/bin/bash
-# Round artefacts, run on the GPU box from the repo root (gpurun):  bash tools/profile_round.sh r05
+# Round artefacts, run on the GPU box from the repo root (gpurun):  bash tools/profile_round.sh r06
 # Writes everything under gpurun_out/<tag>_*; copy what should be judged into profiles/.
 set -u
-TAG=${1:-r05}
+TAG=${1:-r06}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out
 mkdir -p $OUT
@@ -10,6 +10,11 @@ cd /tmp && export TMPDIR=/tmp
 python $R/bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
 python $R/bench.py --steps 10 --warmup 3 --all-sites --no-cpu-baseline --no-extras > $OUT/${TAG}_bench_nocpu.json 2> $OUT/${TAG}_bench_sites.txt
 python $R/bench.py --steps 10 --warmup 3 --all-sites --no-cpu-baseline --no-extras --padded > $OUT/${TAG}_bench_padded.json 2> $OUT/${TAG}_bench_sites_padded.txt
+# the reference's own default batch (examples/training/train_grande.py:45): which sites the launch-bound regime spends its time in
+python $R/bench.py --batch 160 --steps 20 --warmup 5 --all-sites --no-cpu-baseline --no-extras --no-other-layout > $OUT/${TAG}_bench_b160.json 2> $OUT/${TAG}_bench_sites_b160.txt
+# the host feed: worker scaling and where the feed thread's time goes; the fed step loop against replayed / cycled batches
+python $R/tools/feed_probe.py 2>&1 | grep -v "^Too\|^tokeni\|^Tokeni\|amdgpu.ids" > $OUT/${TAG}_feed_probe.txt
+python $R/tools/feed_e2e_probe.py 2>&1 | grep -v "^Too\|^tokeni\|^Tokeni\|amdgpu.ids" > $OUT/${TAG}_feed_e2e_probe.txt
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof -o bench -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-other-layout --no-extras > $OUT/${TAG}_bench_under_rocprof.json 2> /dev/null
 cp $(find $OUT/${TAG}_prof -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_bench_kernel_stats.csv
 # HBM traffic from PMC passes over THE BENCH COMMAND itself (counters only with --kernel-trace; one counter per pass): the nominated
