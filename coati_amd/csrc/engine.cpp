@@ -1084,7 +1084,7 @@ int gnn_fwd(coati_engine* e, const long long* atoms, const float* coords, hipStr
     // grid in (twice: count, fill), the edge list (bj, bk, rev, d2, w: 20 B per edge) + offsets out
     ProfScope ps(e, SITE_GNN_ELEMWISE, 0, s, (double)BA * (8 + H * 6 + 8) + (double)BA * 12 + (double)Me * 8 * 3 + (double)BA * 4, 20.0);
     bf16_t* h16 = Lg > 0 ? e->g_hcat[0] : e->g_hfin16;
-    if (c.torch_emb) COATI_TRY(launch_gnn_embed(atoms, nullptr, nullptr, e->P + e->gembw, nullptr, e->g_h32[0], h16, Lg > 0 ? 2 * H : H, e->g_rstd[0], e->g_mask, BA, H, s));
+    if (c.torch_emb) COATI_TRY(launch_gnn_embed(atoms, nullptr, nullptr, e->P + e->gembw, nullptr, e->g_h32[0], h16, Lg > 0 ? 2 * H : H, e->g_rstd[0], e->g_mask, BA, H, s, e->err_flag));
     else COATI_TRY(launch_gnn_embed(atoms, e->lut_ix, e->lut_iy, e->P + e->gembw, e->P + e->gembb, e->g_h32[0], h16, Lg > 0 ? 2 * H : H, e->g_rstd[0], e->g_mask, BA, H, s));
     COATI_TRY(launch_gnn_geom(coords, e->g_mask, c.msg_cutoff, e->g_d2, e->g_w, B, A, s));
     // neighbour list of the step (the coordinates do not change across the layers; the reference rebuilds it 5 times)

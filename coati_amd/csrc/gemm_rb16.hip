@@ -160,7 +160,7 @@ __global__ __launch_bounds__(64 * R16_MAXW, 1) void gemm_rb16_kernel(GemmArgs p,
   // weight tile: 32 pieces of 1 KiB (two 512-B rows), piece k by wave k % W; chunk c of row r at position c ^ f(r)
   auto load_tile = [&](int n0, bf16_t* S) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {      // W >= 8: 4 turns cover the 32 pieces
+    for (int i = 0; i < 7; ++i) {      // W >= 8: 4 turns cover the 32 pieces (W >= 5: 7; the surplus turns are one scalar compare each)
       const int k = wave + W * i;
       if (k < R16_BN / 2) {
         const int r = 2 * k + (lane >> 5), q = lane & 31;
@@ -491,6 +491,11 @@ static int rb16_waves(int M) {
   const int slabs = (M + 15) / 16;
   return (slabs + 255) / 256;
 }
+// fewest waves per workgroup the kernel is chosen for (probe knob COATI_RB16_MINW, >= 5; default 9 = 36 865 rows)
+static int rb16_min_waves() {
+  static const int v = []() { const char* e = getenv("COATI_RB16_MINW"); const int w = e ? atoi(e) : 9; return w < 5 ? 5 : w; }();
+  return v;
+}
 
 bool gemm_rb16_supported(const GemmArgs& a, int a_f32, int epi) {
   if (a_f32 || a.K != R16_K || a.m_dev != nullptr) return false;
@@ -503,7 +508,7 @@ bool gemm_rb16_supported(const GemmArgs& a, int a_f32, int epi) {
   if (epi == EPI_GELU_GRAD && a.n_store > a.N) return false;
   if (epi == EPI_QKV_ROPE && (a.rope_C % 32 != 0 || a.rope_pos != nullptr)) return false;   // 64-column tiles must not straddle 2C
   const int W = rb16_waves(a.M);
-  return W >= 9 && W <= R16_MAXW;   // 36 865 .. 65 536 rows: below, the 32-row kernel or the tiled one; above, the 32-row kernel
+  return W >= rb16_min_waves() && W <= R16_MAXW;   // 36 865 .. 65 536 rows: below, the 32-row kernel or the tiled one; above, the 32-row kernel
 }
 
 template <int EPI, bool LN>

@@ -1004,12 +1004,18 @@ static int launch_ring1w_t(const GemmArgs& a, int R, hipStream_t s) {
 }
 
 // EPI_LNBWD exists in the one-round kernel only (the packed batch: 40 961 .. 57 344 rows); every other size keeps the two launches
+// rows from which the one-round forms run (probe knob COATI_RING1_MINROWS; default: more than one round of 160-row blocks)
+static int ring1_min_rows() {
+  static const int v = []() { const char* e = getenv("COATI_RING1_MINROWS"); return e ? atoi(e) : 256 * 160 + 1; }();
+  return v;
+}
+
 bool gemm_ring_lnbwd_supported(const GemmArgs& a, int* nwg) {
   static const bool off = getenv("COATI_NO_LNBWD_FUSE") != nullptr;   // A/B switch: bf16 product + stand-alone LayerNorm backward
   if (off || a.m_dev || a.N != 256 || a.K % RG_BK != 0 || a.K < 256) return false;
   if (130LL * a.lda >= (1LL << 30) || 260LL * a.ldb >= (1LL << 30)) return false;
   const int R = cdiv(cdiv(a.M, 256), 8) * 8;
-  if (!(R <= R1_BR && a.M > 256 * 160)) return false;
+  if (!(R <= R1_BR && a.M >= ring1_min_rows())) return false;
   if (nwg) *nwg = cdiv(a.M, R);
   return true;
 }
@@ -1033,7 +1039,7 @@ int launch_gemm_ring256(const GemmArgs& a, int epi, hipStream_t s) {
   // exposed), so it only pays where the alternative is two rounds of 128-row blocks (65 536 rows: 42.6 us) -- at 50 000 rows the
   // 14-wave kernel below takes 33.8
   if (R <= R2W_BR && R > R1_BR) return epi == EPI_RES_F32 ? launch_ring1w_t<EPI_RES_F32>(a, R, s) : launch_ring1w_t<EPI_BF16>(a, R, s);
-  if (R <= R1_BR && a.M > 256 * 160)
+  if (R <= R1_BR && a.M >= ring1_min_rows())
     return epi == EPI_RES_F32 ? launch_ring1_t<EPI_RES_F32>(a, R, s) : launch_ring1_t<EPI_BF16>(a, R, s);
   const long long busiest160 = (long long)cdiv(cdiv(a.M, 160), 256) * 160, busiest128 = (long long)cdiv(cdiv(a.M, 128), 256) * 128;
   const bool small = busiest128 < busiest160;

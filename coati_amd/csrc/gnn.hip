@@ -17,12 +17,15 @@ __global__ __launch_bounds__(256) void gnn_embed_kernel(const long long* __restr
                                                         const int* __restrict__ lut_iy, const float* __restrict__ W,
                                                         const float* __restrict__ bias, float* __restrict__ h32,
                                                         bf16_t* __restrict__ h16, long long ld16, float* __restrict__ rstd_out,
-                                                        float* __restrict__ mask, int BA, int H) {
+                                                        float* __restrict__ mask, int BA, int H, int* __restrict__ err) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int row = blockIdx.x * 4 + wave;
   if (row >= BA) return;
   long long z = atoms[row];
   if (lane == 0) mask[row] = z > 0 ? 1.f : 0.f;
+  // torch_emb: nn.Embedding(84, H) has no row for Z > 83 (the reference asserts / raises there, e3gnn_clip.py:113-115): bit 2 of the
+  // step's error word -- the update is dropped and the host raises -- instead of silently training on row 83
+  if (lut_ix == nullptr && z > 83 && lane == 0 && err != nullptr) atomicOr(err, 4);
   if (z < 0) z = 0;
   if (z > 119) z = 119;
   // lut_ix == nullptr: torch_emb (e3gnn_clip.py:49-56, 113-115) -- W is nn.Embedding(84, H)'s table, the row of the atomic number IS the
@@ -68,10 +71,10 @@ __global__ __launch_bounds__(256) void gnn_embed_kernel(const long long* __restr
 
 int launch_gnn_embed(const long long* atoms, const int* lut_ix, const int* lut_iy, const float* W, const float* b,
                      float* h32, bf16_t* h16, long long ld16, float* rstd, float* mask, int BA, int H,
-                     hipStream_t s) {
+                     hipStream_t s, int* err) {
   COATI_CHECK_ARG(atoms && W && h32 && h16 && rstd && mask && ((lut_ix && lut_iy && b) || (!lut_ix && !lut_iy && !b)), "gnn_embed: null operand");
   COATI_CHECK_SHAPE(BA > 0 && H > 0 && H <= 1024, "gnn_embed: unsupported shape");
-  hipLaunchKernelGGL(gnn_embed_kernel, dim3(cdiv(BA, 4)), dim3(256), 0, s, atoms, lut_ix, lut_iy, W, b, h32, h16, ld16, rstd, mask, BA, H);
+  hipLaunchKernelGGL(gnn_embed_kernel, dim3(cdiv(BA, 4)), dim3(256), 0, s, atoms, lut_ix, lut_iy, W, b, h32, h16, ld16, rstd, mask, BA, H, err);
   COATI_LAUNCH_CHECK("gnn_embed");
   return COATI_OK;
 }
@@ -172,7 +175,7 @@ __global__ __launch_bounds__(256) void gnn_node_res_silu_kernel(const float* __r
   for (int c = threadIdx.x; c < H; c += blockDim.x) {
     float v = u32[(long long)row * H + c];
     if (ix >= 0) v += W3c[c * ldw + ix];
-    if (iy >= 0) v += W3c[c * ldw + iy];
+    if (iy >= 0 && iy != ix) v += W3c[c * ldw + iy];   // (group and period indices live in disjoint ranges; the guard mirrors gnn_onehot_wgrad_kernel)
     upre[(long long)row * H + c] = f2bf(v);
     t16[(long long)row * H + c] = f2bf(silu_f(v));
   }

@@ -331,7 +331,7 @@ int launch_ce_finish(const float2* partial, int tiles_n, const bf16_t* a, long l
 // ------------------------------------------------------------------------------------------------
 int launch_gnn_embed(const long long* atoms, const int* lut_ix, const int* lut_iy, const float* W, const float* b,
                      float* h32, bf16_t* h16, long long ld16, float* rstd, float* mask, int BA, int H,
-                     hipStream_t s);
+                     hipStream_t s, int* err = nullptr);
 int launch_gnn_node_res_silu(const float* u32, const long long* atoms, const int* lut_ix, const int* lut_iy, const float* W3c, long long ldw,
                              bf16_t* upre, bf16_t* t16, int BA, int H, hipStream_t s);
 int launch_gnn_onehot_wgrad(const long long* atoms, const int* lut_ix, const int* lut_iy, const bf16_t* du, float* dW, long long ldw, int BA,

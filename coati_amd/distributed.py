@@ -369,7 +369,7 @@ def global_losses(eng):
     # from what the device found) -- MAX over the ranks, so that every rank raises together (the optimizer kernel has already
     # dropped the update on the rank that saw it: csrc/optim.hip adamw_kernel `skip`)
     w = s[6:7].view(torch.int32)
-    err = torch.cat([w & 1, (w >> 1) & 1]).to(torch.float32)      # one element per bit: MAX of the word itself would lose bit 0 behind bit 1
+    err = torch.cat([w & 1, (w >> 1) & 1, (w >> 2) & 1]).to(torch.float32)      # one element per bit: MAX of the word itself would lose bit 0 behind bit 1
     if _gloo() and err.is_cuda:
         h = err.cpu()
         dist.all_reduce(h, op=dist.ReduceOp.MAX)
@@ -378,11 +378,14 @@ def global_losses(eng):
         dist.all_reduce(err, op=dist.ReduceOp.MAX)
     s = s.cpu()
     err = err.cpu()
-    err = int(err[0] > 0) | (int(err[1] > 0) << 1)
+    err = int(err[0] > 0) | (int(err[1] > 0) << 1) | (int(err[2] > 0) << 2)
     if err & 1:
         raise RuntimeError("Some smiles in the batch do not have stop tokens. Did some tokenizations fail?")
     if err & 2:
         raise RuntimeError("packed rows: the row counts passed to forward() differ from what the device found in the tokens")
+    if err & 4:
+        from .engine import ERR_Z_MESSAGE
+        raise RuntimeError(ERR_Z_MESSAGE)
     ar = float(s[0] / s[1]) if s[1] > 0 else 0.0
     nv = float(s[4])
     clip = float(0.5 * (s[2] + s[3]) / nv) if nv > 0 else 0.0

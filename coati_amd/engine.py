@@ -49,6 +49,9 @@ PACK_ROWS = _os.environ.get("COATI_PACK_ROWS", "1") != "0"
 SCAL_AR_SUM, SCAL_AR_COUNT, SCAL_CLIP1, SCAL_CLIP2, SCAL_NVALID, SCAL_GRADNORM, SCAL_ERR = 0, 1, 2, 3, 4, 5, 6
 
 
+ERR_Z_MESSAGE = "torch_emb: an atomic number above 83 has no row in nn.Embedding(84, H) (e3gnn_clip.py:113-115)"
+
+
 class Engine:
     def __init__(self, cfg: ModelConfig, device="cuda:0", train=True):
         if not torch.cuda.is_available():
@@ -294,14 +297,15 @@ class Engine:
                                                       self.step_count, ptr(self.scal), stream()), "coati_engine_optimizer_step")
 
     def error_bits(self):
-        """the step's device-side error word as two floats [a row without [STOP], packed-row mismatch] on the device (no sync)"""
+        """the step's device-side error word as one float per bit [a row without [STOP], packed-row mismatch, atomic number outside the
+        nn.Embedding table (torch_emb)] on the device (no sync)"""
         w = self.scal[SCAL_ERR:SCAL_ERR + 1].view(torch.int32)
-        return torch.cat([w & 1, (w >> 1) & 1]).to(torch.float32)
+        return torch.cat([w & 1, (w >> 1) & 1, (w >> 2) & 1]).to(torch.float32)
 
     def set_error_word(self, bits):
         """bits: the two flags of error_bits() reduced over the ranks; replaces this rank's word before optimizer_step (every rank
         drops the update or none does) and in scal, so that losses() raises on every rank"""
-        w = (bits[0:1] > 0).to(torch.int32) + 2 * (bits[1:2] > 0).to(torch.int32)
+        w = (bits[0:1] > 0).to(torch.int32) + 2 * (bits[1:2] > 0).to(torch.int32) + 4 * (bits[2:3] > 0).to(torch.int32)
         _lib.check(self.l.coati_engine_set_error_word(self.h, ptr(w), stream()), "coati_engine_set_error_word")
         self._err_word_keepalive = w
 
@@ -348,6 +352,8 @@ class Engine:
             raise RuntimeError("Some smiles in the batch do not have stop tokens. Did some tokenizations fail?")
         if err & 2:
             raise RuntimeError("packed rows: the row counts passed to forward() differ from what the device found in the tokens")
+        if err & 4:
+            raise RuntimeError(ERR_Z_MESSAGE)
         ar = float(s[SCAL_AR_SUM] / s[SCAL_AR_COUNT]) if s[SCAL_AR_COUNT] > 0 else 0.0
         nv = float(s[SCAL_NVALID])
         clip = float(0.5 * (s[SCAL_CLIP1] + s[SCAL_CLIP2]) / nv) if nv > 0 else 0.0

@@ -333,13 +333,16 @@ def train_autoencoder(gpu, args, dataset=None, tokenizer=None):
         # reference raises on the step itself (smiles_xformer.py:63-66), here the epoch does at the latest -- on every rank together
         ew = err_acc.cpu()
         if world > 1:
-            eb = torch.tensor([float(int(ew[0]) & 1), float((int(ew[0]) >> 1) & 1)])
+            eb = torch.tensor([float((int(ew[0]) >> k) & 1) for k in range(3)])
             dist_all = D.dist.all_reduce(eb, op=D.dist.ReduceOp.MAX, group=D.control_group())
-            ew = torch.tensor([int(eb[0] > 0) | (int(eb[1] > 0) << 1)])
+            ew = torch.tensor([sum(int(eb[k] > 0) << k for k in range(3))])
         if int(ew[0]) & 1:
             raise RuntimeError("Some smiles in the batch do not have stop tokens. Did some tokenizations fail?")
         if int(ew[0]) & 2:
             raise RuntimeError("packed rows: the row counts passed to forward() differ from what the device found in the tokens")
+        if int(ew[0]) & 4:
+            from ..engine import ERR_Z_MESSAGE
+            raise RuntimeError(ERR_Z_MESSAGE)
         if rank == 0:
             print(f"epoch completed in {ng} grads and {time.time()-t0} seconds")
         if not hist:

@@ -109,3 +109,24 @@ def test_trainer_with_reference_default_args(tmp_path):
     recs = open(os.path.join(args.output_dir, "d", "log.json")).read().strip().split("\n")
     losses = [eval(r.rstrip(","), {"null": None})["value"] for r in recs if "train_batch_loss" in r]
     assert len(losses) == 12 and all(np.isfinite(losses)) and losses[-1] < losses[0]
+
+
+def test_torch_emb_rejects_atomic_numbers_beyond_the_table(golden_dir):
+    """torch_emb: nn.Embedding(84, H) has no row for Z > 83 -- the reference asserts / raises in its forward (e3gnn_clip.py:113-115).
+    Here the step sets bit 2 of its device-side error word: the optimizer drops the update and losses() raises (round-5 advisor item:
+    the kernel used to clamp to row 83 and train on the wrong row)."""
+    from coati_amd.engine import Engine, ModelConfig
+    d, batch, up = load_case(golden_dir, "torchemb")
+    eng = Engine(ModelConfig(**SMALL, **CASES["torchemb"]), DEV)
+    eng.load_state_dict({k[2:]: v for k, v in d.items() if k.startswith("w.")})
+    b = {k: v.to(DEV) for k, v in batch.items()}
+    eng.train_step(b, up.to(DEV), lr=1e-3)
+    eng.losses()                                   # a clean batch raises nothing
+    before = eng.params.clone()
+    bad = dict(b, atoms=b["atoms"].clone())
+    bad["atoms"][1, 0] = 90
+    eng.train_step(bad, up.to(DEV), lr=1e-3)
+    assert torch.equal(eng.params, before)         # the update was dropped on the device
+    with pytest.raises(RuntimeError, match="above 83"):
+        eng.losses()
+    assert eng.error_bits().tolist() == [0.0, 0.0, 1.0]
