@@ -21,10 +21,10 @@
 //    too; per pair the LDS traffic is the 16 x 16 dS tile written as bf16 and read back transposed (the B operand of dQ^T += K^T dS^T);
 //  * results are written over the images they replace (O / dQ over Q's rows, dK over K, dV over dO -- the same 16 x 16 bf16 shape)
 //    and leave the workgroup after ONE barrier as whole 128-B row segments.
+//  * one workgroup per item, on purpose: a persistent workgroup that prefetches its next item into registers while it computes the current
+//    one was built and measured 17 % slower in three variants (profiles/r06_attn_persistent.txt; the kernel is in the git history).
 // q and k arrive rotated (the QKV product applies RoPE in its write-out); dq and dk are rotated back here.
 // Layout: qkv [B*T, 3C] bf16 (q | k | v, head h at columns 16 h ..), y / dy [B*T, C], lse [B, nh, Tl] (padded pitch in both row layouts).
-#include <algorithm>
-#include <cstdlib>
 #include "attn_img.h"
 
 typedef short v4s16 __attribute__((ext_vector_type(4)));
@@ -141,59 +141,6 @@ __device__ __forceinline__ void a16_unstage(const unsigned char* smem, unsigned 
   }
 }
 
-// The same three steps for a PERSISTENT workgroup that walks items of different lengths (att16_*_pers_kernel): the registers and the trip
-// counts are those of the launch's longest sequence (TPM rows), the image geometry (rows per image tp, bytes per head pw) is the
-// current item's.  Rows [T, tp) are zero-filled, rows >= tp do not exist (their tasks read a clamped address and write nothing).
-// (No branch around the LDS writes: a task without a row writes its 16 B into a per-thread dump slot behind the images.  With the writes
-//  predicated, the waits for the loads sit inside the branches, and at the point where the NEXT item's loads redefine the same registers the
-//  compiler has to assume they are still pending: it emitted s_waitcnt vmcnt(0) there -- which also waits for the previous item's output
-//  stores to be acknowledged, once per item.)
-template <int TPM> __host__ __device__ constexpr unsigned a16_dump_off() { return 4u * (3u * TPM * 32u + ATT_PW_PAD); }
-template <int TPM>
-__device__ __forceinline__ void a16_stage_store_rt(const A16Stage<TPM>& r, int T, int tp, unsigned char* smem, unsigned pw, int image, int heads_here, int tid) {
-  const unsigned dump = a16_dump_off<TPM>() + (unsigned)tid * 16u;
-#pragma unroll
-  for (int i = 0; i < A16Stage<TPM>::NF; ++i) {
-    const int task = tid + 256 * i, t = task >> 3, c = task & 7, w = c >> 1;
-    const unsigned keep = (t < T && w < heads_here) ? 0xffffffffu : 0u;
-    const unsigned off = t < tp ? w * pw + image * (tp * 32) + t * 32 + img_chunk<16>(t, c & 1) * 16 : dump;
-    *reinterpret_cast<uint4*>(smem + off) = make_uint4(r.v[i].x & keep, r.v[i].y & keep, r.v[i].z & keep, r.v[i].w & keep);
-  }
-  if constexpr (A16Stage<TPM>::HALF) {
-    const int task = A16Stage<TPM>::NF * 256 + (tid >> 1), t = task >> 3, c = task & 7, w = c >> 1;
-    const unsigned keep = (t < T && w < heads_here) ? 0xffffffffu : 0u;
-    const unsigned off = t < tp ? w * pw + image * (tp * 32) + t * 32 + img_chunk<16>(t, c & 1) * 16 + (tid & 1) * 8 : dump;
-    *reinterpret_cast<uint2*>(smem + off) = make_uint2(r.h.x & keep, r.h.y & keep);
-  }
-}
-template <int TPM>
-__device__ __forceinline__ void a16_unstage_rt(const unsigned char* smem, unsigned pw, int tp, int image, bf16_t* dst, unsigned stride_b, int T, int heads_here, int tid) {
-  char* base = reinterpret_cast<char*>(dst);
-#pragma unroll
-  for (int i = 0; i < A16Stage<TPM>::NF; ++i) {
-    const int task = tid + 256 * i, t = task >> 3, c = task & 7, w = c >> 1;
-    if (t < T && w < heads_here)
-      *reinterpret_cast<uint4*>(base + ((unsigned)t * stride_b + c * 16)) = *reinterpret_cast<const uint4*>(smem + w * pw + image * (tp * 32) + t * 32 + img_chunk<16>(t, c & 1) * 16);
-  }
-  if constexpr (A16Stage<TPM>::HALF) {
-    const int task = A16Stage<TPM>::NF * 256 + (tid >> 1), t = task >> 3, c = task & 7, w = c >> 1;
-    if (t < T && w < heads_here)
-      *reinterpret_cast<uint2*>(base + ((unsigned)t * stride_b + c * 16 + (tid & 1) * 8)) =
-          *reinterpret_cast<const uint2*>(smem + w * pw + image * (tp * 32) + t * 32 + img_chunk<16>(t, c & 1) * 16 + (tid & 1) * 8);
-  }
-}
-// item i of a launch over packed rows: sequence ord[i / quads] (the launch order, longest first), head quad i % quads; false when the
-// sequence is empty
-__device__ __forceinline__ bool a16_item(int i, int quads, const int* __restrict__ seq_off, const int* __restrict__ seq_ord, int& b, int& hq, int& T, long long& row0) {
-  const int bi = i / quads;
-  hq = i - bi * quads;
-  b = seq_ord != nullptr ? seq_ord[bi] : bi;
-  const int o = seq_off[b];
-  T = seq_off[b + 1] - o;
-  row0 = o;
-  return T > 0;
-}
-
 // ---------------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------------
@@ -305,87 +252,6 @@ __global__ __launch_bounds__(256) void att16_fwd_kernel(const bf16_t* __restrict
 #undef A16_CASE
 }
 
-// A workgroup barrier that orders LDS traffic only: __syncthreads() also releases the wave's GLOBAL stores at workgroup scope, i.e. it
-// waits (vmcnt(0)) for the previous item's output stores to be acknowledged and for the prefetch to land -- per item, on the critical
-// path.  This wave's LDS operations complete in order; lgkmcnt(0) retires them before the barrier.
-#define A16_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
-
-// Packed rows: a PERSISTENT workgroup walks items w, w + G, w + 2 G, ... of the longest-first list (every workgroup gets long and short
-// sequences alike) and loads item i + 1's operands into registers WHILE it computes item i.  Why: one workgroup per item spends half of
-// its wave cycles waiting on memory (profiles/r06_sq_counters.txt: SQ_WAIT_ANY 0.51 of the wave cycles, 0.21 issuing) -- load, barrier,
-// compute, barrier, store, with the bytes in flight per CU capped by the images the resident workgroups hold in LDS.  The prefetch lands in
-// the register file instead (plain loads survive the workgroup barriers), so the next item's round trip is paid underneath this item's
-// exponentials.  The registers and trip counts are those of the launch's longest sequence; an item's own block count picks its compute body.
-template <int NBMAX>
-__global__ __launch_bounds__(256) void att16_fwd_pers_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ y, float* __restrict__ lse,
-                                                             int Tl, int n_head, int quads, const int* __restrict__ seq_off,
-                                                             const int* __restrict__ seq_ord, int nitems) {
-  constexpr int TPM = 16 * NBMAX;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int C = n_head * 16;
-  int it = blockIdx.x, b = 0, hq = 0, T = 0;
-  long long row0 = 0;
-  while (it < nitems && !a16_item(it, quads, seq_off, seq_ord, b, hq, T, row0)) it += gridDim.x;
-  if (it >= nitems) return;
-  A16Stage<TPM> rq, rk, rv;
-  {
-    const int heads_here = (n_head - hq * 4) < 4 ? (n_head - hq * 4) : 4;
-    const bf16_t* base = qkv + row0 * (3LL * C) + hq * 64;
-    a16_stage_load<TPM>(rq, base, 6 * C, T, heads_here, threadIdx.x);
-    a16_stage_load<TPM>(rk, base + C, 6 * C, T, heads_here, threadIdx.x);
-    a16_stage_load<TPM>(rv, base + 2 * C, 6 * C, T, heads_here, threadIdx.x);
-  }
-  while (true) {
-    const int nb = (T + 15) >> 4, tp = 16 * nb;
-    const unsigned pw = 3 * tp * 32 + ATT_PW_PAD;
-    const int heads_here = (n_head - hq * 4) < 4 ? (n_head - hq * 4) : 4;
-    a16_stage_store_rt<TPM>(rq, T, tp, smem, pw, 0, heads_here, threadIdx.x);
-    a16_stage_store_rt<TPM>(rk, T, tp, smem, pw, 1, heads_here, threadIdx.x);
-    a16_stage_store_rt<TPM>(rv, T, tp, smem, pw, 2, heads_here, threadIdx.x);
-    A16_LDS_BARRIER();
-    // the next item of this workgroup: its loads are in flight during the compute phase below
-    int nit = it + gridDim.x, nb_ = 0, nhq = 0, nT = 0;
-    long long nrow0 = 0;
-    while (nit < nitems && !a16_item(nit, quads, seq_off, seq_ord, nb_, nhq, nT, nrow0)) nit += gridDim.x;
-    const bool more = nit < nitems;
-    if (more) {
-      const int nheads = (n_head - nhq * 4) < 4 ? (n_head - nhq * 4) : 4;
-      const bf16_t* base = qkv + nrow0 * (3LL * C) + nhq * 64;
-      a16_stage_load<TPM>(rq, base, 6 * C, nT, nheads, threadIdx.x);
-      a16_stage_load<TPM>(rk, base + C, 6 * C, nT, nheads, threadIdx.x);
-      a16_stage_load<TPM>(rv, base + 2 * C, 6 * C, nT, nheads, threadIdx.x);
-    }
-    __builtin_amdgcn_sched_barrier(0);   // the loads are issued HERE, not sunk behind the compute phase
-#define A16_CASE(N)                                                     \
-    if constexpr (NBMAX >= N)                                             \
-      if (nb == N) att16_fwd_compute<N>(smem, lse, Tl, n_head, b, hq, T);
-    A16_CASE(1) A16_CASE(2) A16_CASE(3) A16_CASE(4) A16_CASE(5) A16_CASE(6) A16_CASE(7) A16_CASE(8)
-#undef A16_CASE
-    A16_LDS_BARRIER();
-    a16_unstage_rt<TPM>(smem, pw, tp, 0, y + row0 * C + hq * 64, 2 * C, T, heads_here, threadIdx.x);
-    if (!more) break;
-    A16_LDS_BARRIER();   // every image has been read: the next item may overwrite them
-    it = nit; b = nb_; hq = nhq; T = nT; row0 = nrow0;
-  }
-}
-
-// A/B switch (COATI_ATTN_PERSIST=0: one workgroup per item) and the CU count of the current device
-static bool a16_persistent() {
-  static const bool on = []() { const char* v = getenv("COATI_ATTN_PERSIST"); return v && v[0] == '1'; }();   // measured slower: opt-in
-  return on;
-}
-static int a16_n_cu() {
-  static int n[16] = {0};
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
-  if (n[dev] == 0) {
-    int v = 0;
-    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
-    n[dev] = v;
-  }
-  return n[dev];
-}
-
 size_t att16_fwd_lds(int T) { return (size_t)4 * ((size_t)3 * 16 * cdiv(T, 16) * 32 + ATT_PW_PAD); }
 
 int launch_attn16_fwd(const bf16_t* qkv, bf16_t* y, float* lse, int B, int T, int n_head, hipStream_t s, const int* seq_off, const int* seq_ord) {
@@ -396,28 +262,6 @@ int launch_attn16_fwd(const bf16_t* qkv, bf16_t* y, float* lse, int B, int T, in
 #ifdef A16_PROBE_LDS_EXTRA
   lds += A16_PROBE_LDS_EXTRA;
 #endif
-  if (seq_off != nullptr && a16_persistent()) {
-    // persistent form: as many workgroups as fit the chip at once (LDS: the launch's longest sequence), each walking its share of the items
-    const int nitems = B * quads;
-    // (LDS: the images of the longest sequence the instantiation can take -- the dump slots sit at a compile-time offset behind them)
-    static int occ[3] = {0, 0, 0};        // resident workgroups per CU, per instantiation and LDS size (asked once per size)
-    static size_t occ_lds[3] = {0, 0, 0};
-    auto go = [&](auto kern, int k) {
-      if (occ[k] == 0 || occ_lds[k] != lds) {   // registers: 78 / 102 / 150 VGPRs for <3> / <5> / <8>
-        int per_cu = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, lds) != hipSuccess || per_cu <= 0) per_cu = 2;
-        occ[k] = per_cu;
-        occ_lds[k] = lds;
-      }
-      const int G = std::min(nitems, a16_n_cu() * occ[k]);
-      hipLaunchKernelGGL(kern, dim3(G), dim3(256), lds, s, qkv, y, lse, T, n_head, quads, seq_off, seq_ord, nitems);
-    };
-    if (nb <= 3) { lds = a16_dump_off<48>() + 4096; go(att16_fwd_pers_kernel<3>, 0); }
-    else if (nb <= 5) { lds = a16_dump_off<80>() + 4096; go(att16_fwd_pers_kernel<5>, 1); }
-    else { lds = a16_dump_off<128>() + 4096; go(att16_fwd_pers_kernel<8>, 2); }
-    COATI_LAUNCH_CHECK("attn16_fwd(persistent)");
-    return COATI_OK;
-  }
   if (nb <= 3) hipLaunchKernelGGL((att16_fwd_kernel<3>), dim3(B * quads), dim3(256), lds, s, qkv, y, lse, T, n_head, quads, seq_off, seq_ord);
   else if (nb <= 5) hipLaunchKernelGGL((att16_fwd_kernel<5>), dim3(B * quads), dim3(256), lds, s, qkv, y, lse, T, n_head, quads, seq_off, seq_ord);
   else hipLaunchKernelGGL((att16_fwd_kernel<8>), dim3(B * quads), dim3(256), lds, s, qkv, y, lse, T, n_head, quads, seq_off, seq_ord);
