@@ -164,7 +164,8 @@ def time_comm(eng, D, batch_size, steps=10):
 
 class _FeedPipe:
     """make_batcher of the host-feed extras: synthetic ROWS (smiles text, ragged atoms / coords) -> the trainer's pipe: row filters,
-    stack_batch, clip_ar_xform with the training probabilities of examples/training/train_grande.py on the host (C++ trie tokenizer)"""
+    stack_batch, clip_ar_xform on the host (C++ trie tokenizer) with p_dataset 0.3, p_formula 0.3, p_fim 0.5, p_clip 0.9, p_clip_cut 0.3 -- more augmentation work per
+    row than examples/training/train_grande.py asks for (0.2 / 0 / 0 / 0.9)"""
 
     def __init__(self, vocab, batch, n_batches, n_seq=250, tokens=76, atoms=16):
         self.vocab, self.batch, self.n_batches, self.n_seq, self.tokens, self.atoms = vocab, batch, n_batches, n_seq, tokens, atoms
