@@ -14,6 +14,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -481,6 +482,91 @@ struct ProfScope {
 };
 
 // ---- GEMM helpers -------------------------------------------------------------------------------------
+// ---- row-wise products of MORE rows than one round of the fused kernels takes (batch 2048: ~ 100 000 packed rows per pass) -------------
+// The 16-row-slab kernels (gemm_rb16.hip) and the one-round ring forms (gemm_ring.hip: the only ones with the LayerNorm backward in their
+// write-out) serve 40 961 .. 57 344 rows; above 65 536 rows launch_gemm_nt falls back to the 32-row-slab and multi-round kernels and the
+// step is 8.5 % slower PER ROW (batch_sweep, round 5).  Every one of these products is row-wise, so M rows run as n launches of the fast form on
+// equal row ranges: the plan below (rows per launch; 0 = one launch as before) and gemm_rows() which advances every per-row operand.
+// COATI_ROW_SPLIT=0 switches it off (A/B).
+static bool row_split_on() {
+  static const bool on = []() { const char* v = getenv("COATI_ROW_SPLIT"); return !(v && v[0] == '0'); }();
+  return on;
+}
+static int row_split_plan(const GemmArgs& a, int a_f32, int epi) {
+  if (!row_split_on() || a.m_dev != nullptr || a_f32 || a.M <= 65536 || a.q8_out != nullptr) return 0;
+  if (!(a.K == 256 || a.N == 256)) return 0;
+  // (EPI_QKV_ROPE stays one launch: at 97 k rows the 32-row-slab kernel takes 3.35 ms per step for the 32 QKV products, two 16-row-slab
+  //  launches 3.71 -- the one product of the family where the split loses, profiles/r06_row_split.txt)
+  if (epi != EPI_BF16 && epi != EPI_RES_F32 && epi != EPI_GELU_GRAD && epi != EPI_MUL_AUX && epi != EPI_CE_PARTIAL && epi != EPI_CE_BWD &&
+      epi != EPI_LNBWD) return 0;
+  const long long unit = 16;   // a launch starts on a 16-row slab
+  const int n = cdiv(a.M, 57344);
+  const long long rows = (cdiv(a.M, n) + unit - 1) / unit * unit;
+  if (rows <= 40960 || rows > 57344 || rows >= a.M) return 0;   // (40 960-row halves of a padded 1024 x 80 batch were tried: 33.3 vs 32.4 ms per step)
+  if (epi == EPI_CE_PARTIAL) {   // the per-(row, tile) entries of every launch must have the layout the caller's buffer was sized for
+    GemmArgs b = a;
+    b.M = (int)rows;
+    if (a.partial_tile != 64 || gemm_ce_tile_width(b) != 64) return 0;
+  }
+  return (int)rows;
+}
+static void advance_rows(GemmArgs& a, long long r0, int epi, int lnb_partial_rows_done) {
+  const bool out32 = (epi == EPI_F32 || epi == EPI_RES_F32 || epi == EPI_ACC_F32 || epi == EPI_LNBWD);
+  auto adv = [&](const void* q, long long bytes) -> const void* { return q ? reinterpret_cast<const char*>(q) + bytes : nullptr; };
+  a.A = adv(a.A, r0 * a.lda * 2);
+  a.C = const_cast<void*>(adv(a.C, r0 * a.ldc * (out32 ? 4 : 2)));
+  const long long aux_in_b = (epi == EPI_RES_F32 || epi == EPI_LNBWD) ? 4 : (epi == EPI_MUL_AUX ? 1 : 2);
+  const long long aux_out_b = (epi == EPI_GELU_GRAD) ? 1 : 2;
+  a.aux_in = adv(a.aux_in, r0 * a.ld_aux * aux_in_b);
+  a.aux_out = const_cast<void*>(adv(a.aux_out, r0 * a.ld_aux * aux_out_b));
+  if (a.lse) a.lse += r0;
+  if (a.target) a.target += r0;
+  if (a.partial) a.partial += r0 * cdiv(a.N, a.partial_tile > 0 ? a.partial_tile : 128);
+  if (a.rope_row_t) a.rope_row_t += r0;
+  if (a.ln_x) { a.ln_x += r0 * a.ln_ldx; a.ln_mean += r0; a.ln_rstd += r0; }
+  if (a.lnb_x) { a.lnb_x += r0 * a.lnb_ldx; a.lnb_mean += r0; a.lnb_rstd += r0; }
+  if (a.lnb_partial) a.lnb_partial += (long long)lnb_partial_rows_done * 2 * a.N;
+  if (a.chain_C) a.chain_C += r0 * a.chain_ldc;
+}
+// launch_gemm_nt on M rows, as n launches of `rows` rows where the plan says so.  lnb_rows (EPI_LNBWD): receives the number of partial rows
+// the launches have left in lnb_partial.
+static int gemm_rows(const GemmArgs& a, int a_f32, int epi, hipStream_t s, int* lnb_rows = nullptr) {
+  const int rows = row_split_plan(a, a_f32, epi);
+  if (rows == 0) {
+    if (lnb_rows) { int nwg = 0; gemm_ring_lnbwd_supported(a, &nwg); *lnb_rows = nwg; }
+    return launch_gemm_nt(a, a_f32, epi, s);
+  }
+  int done = 0;
+  for (long long r0 = 0; r0 < a.M; r0 += rows) {
+    GemmArgs b = a;
+    b.M = (int)std::min<long long>(rows, a.M - r0);
+    advance_rows(b, r0, epi, done);
+    if (epi == EPI_LNBWD) {
+      int nwg = 0;
+      if (!gemm_ring_lnbwd_supported(b, &nwg)) { coati_set_error("gemm_rows: a row range of %d rows does not take the fused LayerNorm backward", b.M); return COATI_ESHAPE; }
+      done += nwg;
+    }
+    COATI_TRY(launch_gemm_nt(b, a_f32, epi, s));
+  }
+  if (lnb_rows) *lnb_rows = done;
+  return COATI_OK;
+}
+// true when every launch of the plan (or the single launch) takes the fused LayerNorm backward; *nwg = partial rows in total
+static bool lnbwd_rows_supported(const GemmArgs& a, int* nwg) {
+  const int rows = row_split_plan(a, 0, EPI_LNBWD);
+  if (rows == 0) return gemm_ring_lnbwd_supported(a, nwg);
+  int total = 0;
+  for (long long r0 = 0; r0 < a.M; r0 += rows) {
+    GemmArgs b = a;
+    b.M = (int)std::min<long long>(rows, a.M - r0);
+    int k = 0;
+    if (!gemm_ring_lnbwd_supported(b, &k)) return false;
+    total += k;
+  }
+  if (nwg) *nwg = total;
+  return true;
+}
+
 // A/B switch of the attention launch order (COATI_ATTN_LPT=0: sequences in batch order)
 static bool lpt_on() {
   static const bool on = []() { const char* v = getenv("COATI_ATTN_LPT"); return !(v && v[0] == '0'); }();
@@ -500,7 +586,7 @@ int gemm(coati_engine* e, int site, const void* A, int a_f32, int64_t lda, const
   if (epi == EPI_GELU || epi == EPI_SILU || epi == EPI_DGELU || epi == EPI_DSILU) bytes += (double)M * N * 2;
   if (epi == EPI_GELU_GRAD || epi == EPI_MUL_AUX) bytes += (double)M * N;   // the saved NewGELU' is one byte per element
   ProfScope ps(e, site, 2.0 * M * N * K, s, bytes);
-  return launch_gemm_nt(a, a_f32, epi, s);
+  return gemm_rows(a, a_f32, epi, s);
 }
 int wgrad(coati_engine* e, int site, const void* A, int a_f32, int64_t lda, const bf16_t* Bm, int64_t ldb, int M,
           int N, int K, float* dW, int64_t ldw, float* dbias, int n_out, hipStream_t s) {
@@ -777,7 +863,7 @@ int xformer_fwd(coati_engine* e, XPass& p, const float* injection, hipStream_t s
         COATI_TRY(launch_layernorm_fwd(p.x[l], C, e->P + w.ln1w, e->P + w.ln1b, p.a1[l], C, nullptr, 0, p.mean1[l], p.rstd1[l], M, C, s));
       }
       ProfScope ps(e, SITE_QKV_FWD, 2.0 * M * 3 * C * C, s, (double)M * C * (fuse ? 6 : 2) + 3.0 * C * C * 2 + (double)M * 3 * C * 2);
-      COATI_TRY(launch_gemm_nt(a, 0, EPI_QKV_ROPE, s));
+      COATI_TRY(gemm_rows(a, 0, EPI_QKV_ROPE, s));
     }
     if (!ab) {
       {
@@ -815,7 +901,7 @@ int xformer_fwd(coati_engine* e, XPass& p, const float* injection, hipStream_t s
         COATI_TRY(launch_layernorm_fwd(p.xmid[l], C, e->P + w.ln2w, e->P + w.ln2b, p.a2[l], C, nullptr, 0, p.mean2[l], p.rstd2[l], M, C, s));
       }
       ProfScope ps(e, SITE_FC1_FWD, 2.0 * M * 4 * C * C, s, (double)M * C * (fuse ? 6 : 2) + 4.0 * C * C * 2 + (double)M * 4 * C * 3);
-      COATI_TRY(launch_gemm_nt(a, 0, EPI_GELU_GRAD, s));
+      COATI_TRY(gemm_rows(a, 0, EPI_GELU_GRAD, s));
     }
     COATI_TRY(gemm(e, SITE_FC2_FWD, p.g[l], 0, 4 * C, e->S + w.fc2w, 4 * C, M, C, 4 * C, p.x[l + 1], C, e->P + w.fc2b, EPI_RES_F32, p.xmid[l], nullptr, C, s));
   }
@@ -934,7 +1020,7 @@ int xformer_bwd(coati_engine* e, XPass& p, const void* dyf, int dyf_f32, float* 
     a.lnb_x = x; a.lnb_ldx = C; a.lnb_mean = mean; a.lnb_rstd = rstd; a.lnb_gamma = gamma;
     if (chainW != nullptr && dx16 != nullptr) { a.chain_W = chainW; a.chain_ldw = C; a.chain_C = chainC; a.chain_ldc = C; }
     int nwg = 0;
-    if (!gemm_ring_lnbwd_supported(a, &nwg) || nwg > COATI_LN_PARTIAL_ROWS) return 0;
+    if (!lnbwd_rows_supported(a, &nwg) || nwg > COATI_LN_PARTIAL_ROWS) return 0;
     a.lnb_partial = e->ln_part_x + fin.n * slot_stride;
     fin.dg_off[fin.n] = (long long)goff;
     fin.db_off[fin.n] = (long long)boff;
@@ -943,7 +1029,7 @@ int xformer_bwd(coati_engine* e, XPass& p, const void* dyf, int dyf_f32, float* 
     // algorithmic bytes: dY + weight in; x, dres in; dx (f32) + its bf16 copy out
     ProfScope ps(e, site, 2.0 * M * C * K + (a.chain_W ? 2.0 * M * C * C : 0.0), s,
                  (double)M * K * 2 + (double)C * K * 2 + (double)M * C * (4 + (has_dres ? 4 : 0) + 4 + (dx16 ? 2 : 0)) + (a.chain_W ? (double)M * C * 2 + (double)C * C * 2 : 0.0));
-    const int rc = launch_gemm_nt(a, 0, EPI_LNBWD, s);
+    const int rc = gemm_rows(a, 0, EPI_LNBWD, s);
     return rc == COATI_OK ? 1 : rc;
   };
   // Weight gradients: immediately, one launch per Linear (small shapes), or deferred to ONE grouped launch at the end of
@@ -1463,10 +1549,12 @@ static int forward_decoder_impl(coati_engine* e, hipStream_t s) {
     memset(&a, 0, sizeof(a));
     a.A = e->p2.af; a.lda = C; a.B = e->S + e->lmhead; a.ldb = C; a.M = M2; a.N = c.n_tok; a.K = C; a.partial = e->ce_partial;
     a.partial_tile = 64;   // ce_partial is sized for 64-column entries: the row-block kernel may take the product
-    const int tiles_v = cdiv(c.n_tok, gemm_ce_tile_width(a));
+    GemmArgs aw = a;             // (the width is a property of the kernel that runs: with a row split, of a launch's row range)
+    if (const int rows = row_split_plan(a, 0, EPI_CE_PARTIAL)) aw.M = rows;
+    const int tiles_v = cdiv(c.n_tok, gemm_ce_tile_width(aw));
     {
       ProfScope ps(e, SITE_LMHEAD_FWD, 2.0 * M2 * c.n_tok * C, s, (double)M2 * C * 2 + (double)c.n_tok * C * 2);   // logits never leave the chip
-      COATI_TRY(launch_gemm_nt(a, 0, EPI_CE_PARTIAL, s));
+      COATI_TRY(gemm_rows(a, 0, EPI_CE_PARTIAL, s));
     }
     COATI_TRY(launch_ce_finish(e->ce_partial, tiles_v, e->p2.af, C, e->S + e->lmhead, C, e->p2.packed ? e->p2.ypk : e->y_next, e->ce_lse, scal, M2, C, c.n_tok, s));
   }
@@ -1696,7 +1784,7 @@ int coati_engine_backward(coati_engine* e, const float* dh_smiles, const float* 
       a.A = e->p2.af; a.lda = C; a.B = e->S + e->lmhead; a.ldb = C; a.M = M2; a.N = c.n_tok; a.K = C;
       a.C = e->dlogits; a.ldc = e->Vpad; a.n_store = e->Vpad; a.lse = e->ce_lse; a.target = e->p2.packed ? e->p2.ypk : e->y_next; a.scal = e->scal;
       ProfScope ps(e, SITE_LMHEAD_DLOGITS, 2.0 * M2 * c.n_tok * C, s, (double)M2 * C * 2 + (double)c.n_tok * C * 2 + (double)M2 * e->Vpad * 2);
-      COATI_TRY(launch_gemm_nt(a, 0, EPI_CE_BWD, s));
+      COATI_TRY(gemm_rows(a, 0, EPI_CE_BWD, s));
     }
     COATI_TRY(wgrad(e, SITE_LMHEAD_WGRAD, e->dlogits, 0, e->Vpad, e->p2.af, C, M2, e->Vpad, C, e->G + e->lmhead, C, nullptr, c.n_tok, s));
     // ---- decoder pass (its first launch: the lm_head's input gradient d(af) = dlogits W, + ln_f's backward) ----

@@ -364,6 +364,43 @@ def test_wide_batch_kernels_vs_oracle(flags):
     assert not bad, sorted(bad, reverse=True)[:8]
 
 
+def test_row_split_products_vs_oracle():
+    """100 200 token rows (835 x 120, padded layout) at d = 256, one layer: above 65 536 rows every row-wise product of the passes runs as
+    TWO launches of the 16-row-slab / one-round ring kernels on equal row ranges (engine.cpp gemm_rows: LayerNorm fused into the operand
+    load, RoPE from the sequence boundary, NewGELU' codes, lm_head partials / dlogits, the fused LayerNorm backward with its partial rows
+    of both launches) -- against the oracle, losses and every gradient."""
+    from oracle import coati_oracle as O
+    from coati_amd.engine import Engine, ModelConfig
+    from coati_amd.synthetic import make_batch
+    kw = dict(n_layer_e3gnn=1, n_layer_xformer=1, n_hidden_xformer=256, n_hidden_e3nn=256, n_embd_common=256, n_head=16, n_seq=250, n_tok=600)
+    ocfg = O.OracleConfig(**kw)
+    P = O.init_params(ocfg, seed=14)
+    eng = Engine(ModelConfig(**kw), DEV)
+    eng.load_state_dict(P)
+    batch, up = make_batch(835, 120, 16, 600, seed=10, n_special=12, p_bad=0.02, min_len=100)
+    db = {k: v.to(DEV) for k, v in batch.items()}
+    eng.train_step(db, up.to(DEV), lr=1e-3, optimizer=False)
+    L = eng.losses()
+    Pg = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    with O.sim_bf16():
+        loss, ar, cl, _ = O.step_loss(Pg, ocfg, batch, up)
+    loss.backward()
+    log(f"row-split losses hip {L} oracle ar {float(ar):.6f} clip {float(cl):.6f}")
+    check("row-split ar", torch.tensor([L["ar_loss"]]), ar.detach().reshape(1), TOL_LOSS_SIM)
+    check("row-split clip", torch.tensor([L["clip_loss"]]), cl.detach().reshape(1), TOL_LOSS_SIM)
+    grads = eng.named_views("grads")
+    bad = []
+    for k in sorted(eng.layout):
+        ref = Pg[k].grad if Pg[k].grad is not None else torch.zeros_like(P[k])
+        scale = max(float(ref.abs().max()), 1e-30)
+        e = float((grads[k].cpu() - ref).abs().max()) / scale if float(ref.abs().max()) > 0 else float(grads[k].abs().max())
+        log(f"row-split grad {k:60s} relerr {e:.3e} scale {scale:.3e}")
+        if e > TOL_GRAD_SIM:
+            bad.append((e, k))
+    assert not bad, sorted(bad, reverse=True)[:8]
+
+
 def test_staged_backward_equals_whole_backward():
     """The multi-GPU step runs the backward in three stages (lm_head + decoder + heads | encoder (+ point encoder on the
     side stream) | remaining point-encoder work) so gradient buckets can be all-reduced as they complete: the staged
