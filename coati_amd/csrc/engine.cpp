@@ -567,6 +567,11 @@ static bool lnbwd_rows_supported(const GemmArgs& a, int* nwg) {
   return true;
 }
 
+// A/B switch of the point encoder's fused forward edge launch (COATI_GNN_EDGE_FUSED=0: the three launches)
+static bool gnn_edge_fused_on() {
+  static const bool on = []() { const char* v = getenv("COATI_GNN_EDGE_FUSED"); return !(v && v[0] == '0'); }();
+  return on;
+}
 // A/B switch of the attention launch order (COATI_ATTN_LPT=0: sequences in batch order)
 static bool lpt_on() {
   static const bool on = []() { const char* v = getenv("COATI_ATTN_LPT"); return !(v && v[0] == '0'); }();
@@ -1179,6 +1184,13 @@ int gnn_fwd(coati_engine* e, const long long* atoms, const float* coords, hipStr
   for (int l = 0; l < Lg; ++l) {
     const GLayerP& w = e->gl[l];
     COATI_TRY(gemm(e, SITE_GNN_NODE_GEMM, e->g_hcat[l], 0, 2 * H, e->S + w.w1ab, H, BA, 2 * H, H, e->g_P[l], 2 * H, nullptr, EPI_BF16, nullptr, nullptr, 0, s));
+    if (H == 256 && gnn_edge_fused_on()) {
+      // the three edge steps as ONE weight-resident launch (gemm_rb16.hip gnn_edge_fwd_fused_kernel): per edge the gathered sender row + bk + d2 + w
+      // in, e1 and s2 out (once each, for the backward); per receiver its Pa row in, the segment sum out; the weight once
+      ProfScope ps(e, SITE_GNN_EDGE_GEMM, 0, s, (double)BA * (H * 2 + 4 + H * 2) + (double)H * H * 2, (double)H * 2 + 12 + (double)H * 4, 2.0 * H * H + 6.0 * H);
+      COATI_TRY(launch_gnn_edge_fwd_fused(e->g_P[l], 2 * H, e->g_seg, e->g_ebk, e->g_ed2, e->g_ew, e->P + w.e0w + 2 * H, 2 * H + 1, e->P + w.e0b,
+                                          e->S + w.e3w, H, e->P + w.e3b, e->g_e1[l], e->g_s2[l], e->g_hcat[l] + H, 2 * H, BA, H, s));
+    } else {
     {
       // per receiver its Pa row (bf16 H), per edge the GATHERED sender row Pb[bk] (bf16 H) + bk + d2 in, e1 (bf16 H) out
       ProfScope ps(e, SITE_GNN_ELEMWISE, 0, s, (double)BA * (H * 2 + 4), (double)H * 4 + 8, 4.0 * H);
@@ -1195,6 +1207,7 @@ int gnn_fwd(coati_engine* e, const long long* atoms, const float* coords, hipStr
     {
       ProfScope ps(e, SITE_GNN_ELEMWISE, 0, s, (double)BA * (H * 2 + 4), (double)H * 2 + 4, 2.0 * H);   // s2 + w per edge in, the segment sums (bf16 H per node) out
       COATI_TRY(launch_gnn_edge_reduce_c(e->g_s2[l], e->g_seg, e->g_ew, e->g_hcat[l] + H, 2 * H, BA, H, s));
+    }
     }
     if (c.residual) {
       // node_mlp(cat([h, mi, h0])) (e_gcl_sparse.py:282-290): the [h | mi] columns as a product (f32 out, into g_o: rewritten by the next

@@ -484,6 +484,191 @@ int launch_gemm_rb16_resident(const GemmArgs& a, int epi, hipStream_t s) {
   return launch_rb16_resident_t<EPI_BF16>(a, s);
 }
 
+// ---- the point encoder's edge path, forward, as ONE launch per layer (round 6) ---------------------------------------------------------
+// e_gcl_sparse.edge_model + the per-receiver sum of e_gcl_sparse.forward (e_gcl_sparse.py:169-215, 297-321):
+//   e1[e] = SiLU(Pa[bj] + Pb[bk] + d2[e] w1c + b1)        (the first edge Linear, factored: P = [h W1a^T | h W1b^T] per node)
+//   s2[e] = e1[e] W3^T + b3                               (the second edge Linear)
+//   mi[bj] = sum over the receiver's edges of SiLU(s2[e]) w[e]
+// Three launches so far (gnn_edge_pre_c, the weight-resident product above, gnn_edge_reduce_c): e1 and s2 -- 107 MB each per layer at the
+// bench batch -- were written, read back by the next launch, and read again by the backward.  Here the same weight-resident workgroup owns
+// RECEIVERS: a wave builds the 16-edge slab of one receiver in its MFMA operand registers (the two gathers of P, SiLU), stores it as e1 for
+// the backward's weight gradient, runs the 256 x 256 product against the resident W3, stores s2 for the backward, and sums SiLU(s2) w over
+// the slab's rows with four DPP steps per value (the 16 rows of a slab are the 16 lanes of a DPP row) -- receivers with more than 16 edges
+// take more slabs, summed in the wave's LDS strip.  e1 and s2 are written once and not read back in the forward.  H = 256 only.
+template <int CTRL>
+__device__ __forceinline__ float r16_dpp(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float r16_row_sum(float v) {   // sum over the 16 lanes of a DPP row, every lane ends with the total
+  v += r16_dpp<0xB1>(v);    // quad_perm(1, 0, 3, 2)
+  v += r16_dpp<0x4E>(v);    // quad_perm(2, 3, 0, 1)
+  v += r16_dpp<0x141>(v);   // row_half_mirror
+  v += r16_dpp<0x140>(v);   // row_mirror
+  return v;
+}
+
+struct GnnEdgeFwdArgs {
+  const bf16_t* P; long long ldp;       // [BA, 2H] (Pa | Pb)
+  const int* seg;                       // [BA + 1] receiver segments of the compacted edge list
+  const int* e_bk; const float* e_d2; const float* e_w;
+  const float* w1c; long long w1c_stride; const float* b1;
+  const bf16_t* W3; long long ldw; const float* b3;   // [H, H] bf16 shadow, bias f32
+  bf16_t* e1; bf16_t* s2;               // [E, H] each (saved for the backward)
+  bf16_t* mi; long long ldmi;           // [BA, ldmi]
+  int BA;
+};
+
+__global__ __launch_bounds__(64 * R16_MAXW, 1) void gnn_edge_fwd_fused_kernel(GnnEdgeFwdArgs p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int MAP = 0, H = R16_K, NT = R16_RES_TILES;
+  bf16_t* const Bs = reinterpret_cast<bf16_t*>(smem);
+  float* const BiasS = reinterpret_cast<float*>(smem + NT * R16_TILE_HALFS * 2);   // b3[256]
+  float* const K1 = BiasS + H;                                                      // [w1c[256] | b1[256]]
+  float* const MS = K1 + 2 * H;                                                     // per wave: 256 partial sums
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), W = blockDim.x >> 6;
+  const int fr = lane & 15, kq = lane >> 4;
+  for (int c = tid; c < H; c += blockDim.x) {
+    BiasS[c] = p.b3[c];
+    K1[c] = p.w1c[(long long)c * p.w1c_stride];
+    K1[H + c] = p.b1[c];
+  }
+  typedef __attribute__((address_space(3))) void lds_void;
+  typedef __attribute__((address_space(1))) const void gbl_void;
+  for (int k = wave; k < NT * (R16_BN / 2); k += W) {
+    const int r = 2 * k + (lane >> 5), q = lane & 31;
+    const bf16_t* src = p.W3 + (long long)r * p.ldw + ((q ^ r16_swz<MAP>(r & 63)) * 8);
+    __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(Bs + k * 512), 16, 0, 0);
+  }
+  __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0)
+  __syncthreads();
+
+  int wofs[4], wsw[4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    const int n = r16_wrow<MAP>(a, fr);
+    wofs[a] = n * R16_K;
+    wsw[a] = r16_swz<MAP>(n);
+  }
+  const int colA = 8 * kq, colB = 32 + 8 * kq;
+  float* const ms = MS + wave * H;
+
+  const int per_wg = (p.BA + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int j_begin = blockIdx.x * per_wg, j_end = j_begin + per_wg < p.BA ? j_begin + per_wg : p.BA;
+  for (int bj = j_begin + wave; bj < j_end; bj += W) {
+    const int e0 = p.seg[bj], n = p.seg[bj + 1] - e0;
+    if (n <= 0) {   // a receiver without edges (a padding atom): mi = 0
+      *reinterpret_cast<uint2*>(p.mi + (long long)bj * p.ldmi + 4 * lane) = make_uint2(0u, 0u);
+      continue;
+    }
+    for (int ch = 0; ch * 16 < n; ++ch) {
+      const bool ok = ch * 16 + fr < n;
+      const int e = ok ? e0 + ch * 16 + fr : e0;
+      const int bk = p.e_bk[e];
+      const float d2 = p.e_d2[e];
+      const float w = ok ? p.e_w[e] : 0.f;
+      // ---- the slab: row fr = edge e, fragment ks = features 32 ks + 8 kq .. + 7 of e1[e]
+      bf16x8 af[8];
+      {
+        const bf16_t* pa = p.P + (long long)bj * p.ldp + kq * 8;
+        const bf16_t* pb = p.P + (long long)bk * p.ldp + H + kq * 8;
+        uint4 ua[8], ub[8];
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) { ua[ks] = *reinterpret_cast<const uint4*>(pa + ks * 32); ub[ks] = *reinterpret_cast<const uint4*>(pb + ks * 32); }
+        bf16_t* e1row = p.e1 + (long long)e * H + kq * 8;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+          float a8[8], b8[8], o[8];
+          unpack8(ua[ks], a8);
+          unpack8(ub[ks], b8);
+          const float4 c0 = *reinterpret_cast<const float4*>(K1 + ks * 32 + kq * 8), c1 = *reinterpret_cast<const float4*>(K1 + ks * 32 + kq * 8 + 4);
+          const float4 g0 = *reinterpret_cast<const float4*>(K1 + H + ks * 32 + kq * 8), g1 = *reinterpret_cast<const float4*>(K1 + H + ks * 32 + kq * 8 + 4);
+          const float wc[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w}, bb[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+#pragma unroll
+          for (int i = 0; i < 8; ++i) o[i] = silu_f(a8[i] + b8[i] + d2 * wc[i] + bb[i]);
+          const uint4 u = pack8(o);
+          af[ks] = __builtin_bit_cast(bf16x8, u);
+          if (ok) *reinterpret_cast<uint4*>(e1row + ks * 32) = u;
+        }
+      }
+      // ---- s2 = e1 W3^T + b3 against the resident weight, tile by tile; SiLU(s2) w summed over the slab's rows
+      for (int jt = 0; jt < NT; ++jt) {
+        const bf16_t* cur = Bs + jt * R16_TILE_HALFS;
+        f32x4_t acc[4];
+        acc[0] = *reinterpret_cast<const f32x4_t*>(BiasS + jt * R16_BN + colA);
+        acc[1] = *reinterpret_cast<const f32x4_t*>(BiasS + jt * R16_BN + colA + 4);
+        acc[2] = *reinterpret_cast<const f32x4_t*>(BiasS + jt * R16_BN + colB);
+        acc[3] = *reinterpret_cast<const f32x4_t*>(BiasS + jt * R16_BN + colB + 4);
+        {
+          bf16x8 wf[2][4];
+#pragma unroll
+          for (int a = 0; a < 4; ++a) wf[0][a] = *reinterpret_cast<const bf16x8*>(cur + wofs[a] + ((kq ^ wsw[a]) * 8));
+#pragma unroll
+          for (int ks = 0; ks < 8; ++ks) {
+            if (ks + 1 < 8) {
+#pragma unroll
+              for (int a = 0; a < 4; ++a) wf[(ks + 1) & 1][a] = *reinterpret_cast<const bf16x8*>(cur + wofs[a] + (((4 * (ks + 1) + kq) ^ wsw[a]) * 8));
+            }
+#pragma unroll
+            for (int a = 0; a < 4; ++a) acc[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks & 1][a], af[ks], acc[a], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+        float v0[8] = {acc[0][0], acc[0][1], acc[0][2], acc[0][3], acc[1][0], acc[1][1], acc[1][2], acc[1][3]};
+        float v1[8] = {acc[2][0], acc[2][1], acc[2][2], acc[2][3], acc[3][0], acc[3][1], acc[3][2], acc[3][3]};
+        const uint4 u0 = pack8(v0), u1 = pack8(v1);
+        if (ok) {
+          bf16_t* srow = p.s2 + (long long)e * H + jt * R16_BN;
+          *reinterpret_cast<uint4*>(srow + colA) = u0;
+          *reinterpret_cast<uint4*>(srow + colB) = u1;
+        }
+        // (SiLU of the ROUNDED value: what the backward re-evaluates from the saved bf16 s2)
+        unpack8(u0, v0);
+        unpack8(u1, v1);
+        float t0[8], t1[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { t0[i] = r16_row_sum(silu_f(v0[i]) * w); t1[i] = r16_row_sum(silu_f(v1[i]) * w); }
+        if (fr == 0) {
+          float* d0 = ms + jt * R16_BN + colA;
+          float* d1 = ms + jt * R16_BN + colB;
+          if (ch > 0) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { t0[i] += d0[i]; t1[i] += d1[i]; }
+          }
+          *reinterpret_cast<float4*>(d0) = make_float4(t0[0], t0[1], t0[2], t0[3]);
+          *reinterpret_cast<float4*>(d0 + 4) = make_float4(t0[4], t0[5], t0[6], t0[7]);
+          *reinterpret_cast<float4*>(d1) = make_float4(t1[0], t1[1], t1[2], t1[3]);
+          *reinterpret_cast<float4*>(d1 + 4) = make_float4(t1[4], t1[5], t1[6], t1[7]);
+        }
+      }
+    }
+    // the receiver's 256 sums: this wave's own LDS strip (LDS operations of one wave complete in order), 4 channels per lane
+    const float4 m4 = *reinterpret_cast<const float4*>(ms + 4 * lane);
+    *reinterpret_cast<uint2*>(p.mi + (long long)bj * p.ldmi + 4 * lane) = make_uint2(pack2bf(m4.x, m4.y), pack2bf(m4.z, m4.w));
+  }
+}
+
+int launch_gnn_edge_fwd_fused(const bf16_t* P, long long ldp, const int* seg, const int* e_bk, const float* e_d2, const float* e_w,
+                              const float* w1c, long long w1c_stride, const float* b1, const bf16_t* W3, long long ldw, const float* b3,
+                              bf16_t* e1, bf16_t* s2, bf16_t* mi, long long ldmi, int BA, int H, hipStream_t s) {
+  COATI_CHECK_ARG(P && seg && e_bk && e_d2 && e_w && w1c && b1 && W3 && b3 && e1 && s2 && mi, "gnn_edge_fwd_fused: null operand");
+  COATI_CHECK_SHAPE(H == R16_K && BA > 0 && ldp % 8 == 0 && ldw % 8 == 0 && ldmi % 4 == 0, "gnn_edge_fwd_fused: H = 256 only (H=%d)", H);
+  static bool attr_set = false;
+  constexpr size_t lds = (size_t)R16_RES_TILES * R16_TILE_HALFS * 2 + (size_t)R16_K * 4 * 3 + (size_t)R16_MAXW * R16_K * 4;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gnn_edge_fwd_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+      coati_set_error("gnn_edge_fwd_fused: hipFuncSetAttribute failed");
+      return COATI_EHIP;
+    }
+    attr_set = true;
+  }
+  GnnEdgeFwdArgs a;
+  a.P = P; a.ldp = ldp; a.seg = seg; a.e_bk = e_bk; a.e_d2 = e_d2; a.e_w = e_w; a.w1c = w1c; a.w1c_stride = w1c_stride; a.b1 = b1;
+  a.W3 = W3; a.ldw = ldw; a.b3 = b3; a.e1 = e1; a.s2 = s2; a.mi = mi; a.ldmi = ldmi; a.BA = BA;
+  hipLaunchKernelGGL(gnn_edge_fwd_fused_kernel, dim3(256), dim3(64 * R16_MAXW), lds, s, a);
+  COATI_LAUNCH_CHECK("gnn_edge_fwd_fused");
+  return COATI_OK;
+}
+
 // waves per workgroup for M rows: one round of one workgroup per CU.  (Round 4: TWO workgroups of half the waves per CU -- to fill
 // each other's barrier bubbles -- measured 23.04 vs 22.42 ms per step: each workgroup streams the whole weight, twice the L2 -> LDS
 // traffic per CU, and the bubbles are not where the time goes, see the header.)

@@ -348,6 +348,10 @@ int launch_gnn_compact(const float* w_dense, const float* d2_dense, int* seg, in
 int launch_gnn_edge_pre_c(const bf16_t* P, long long ldp, const int* seg, const int* e_bk, const float* e_d2, const float* w1c,
                           long long w1c_stride, const float* b1, bf16_t* e1, int BA, int H, hipStream_t s);
 int launch_gnn_edge_reduce_c(const bf16_t* s2, const int* seg, const float* e_w, bf16_t* mi, long long ldmi, int BA, int H, hipStream_t s);
+// the three forward edge steps (edge_pre_c, the second edge Linear, edge_reduce_c) as one weight-resident launch (gemm_rb16.hip), H = 256
+int launch_gnn_edge_fwd_fused(const bf16_t* P, long long ldp, const int* seg, const int* e_bk, const float* e_d2, const float* e_w,
+                              const float* w1c, long long w1c_stride, const float* b1, const bf16_t* W3, long long ldw, const float* b3,
+                              bf16_t* e1, bf16_t* s2, bf16_t* mi, long long ldmi, int BA, int H, hipStream_t s);
 int launch_gnn_edge_reduce_bwd_c(const bf16_t* dmi, long long lddmi, const bf16_t* s2, const int* seg, const float* e_w,
                                  bf16_t* ds2, int BA, int H, hipStream_t s);
 int launch_gnn_edge_pre_bwd_c(const bf16_t* dpre, const int* seg, const int* e_rev, const float* e_d2, bf16_t* dP, long long lddp,

@@ -248,14 +248,16 @@ def test_medium_random_model_grads():
     assert not bad, sorted(bad, reverse=True)[:8]
 
 
-def test_more_than_64_atoms_per_molecule_vs_oracle():
-    """Point clouds wider than one wavefront: the reference pads every batch to its largest molecule (batch_pipe.py:18) and
+@pytest.mark.parametrize("H", [128, 256], ids=["h128_three_launches", "h256_fused_edge_launch"])
+def test_more_than_64_atoms_per_molecule_vs_oracle(H):
+    """(H = 256 takes the fused forward edge launch, gemm_rb16.hip gnn_edge_fwd_fused_kernel: receivers with up to 71 edges = five 16-edge
+    slabs summed in the wave's LDS strip.)  Point clouds wider than one wavefront: the reference pads every batch to its largest molecule (batch_pipe.py:18) and
     hydrogenates by default, so a drug-like molecule can exceed 64 atoms.  72-slot clouds packed inside the 5 A cutoff give
     receivers with up to 71 edges: the compacted-edge kernels walk such a segment in two 64-edge chunks."""
     from oracle import coati_oracle as O
     from coati_amd.engine import Engine, ModelConfig
     from coati_amd.synthetic import make_batch
-    kw = dict(n_layer_e3gnn=2, n_layer_xformer=1, n_hidden_xformer=64, n_hidden_e3nn=128, n_embd_common=64, n_head=4, n_seq=32, n_tok=64)
+    kw = dict(n_layer_e3gnn=2, n_layer_xformer=1, n_hidden_xformer=64, n_hidden_e3nn=H, n_embd_common=64, n_head=4, n_seq=32, n_tok=64)
     ocfg = O.OracleConfig(**kw)
     P = O.init_params(ocfg, seed=21)
     eng = Engine(ModelConfig(**kw), DEV)
