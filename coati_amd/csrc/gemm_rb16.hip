@@ -160,7 +160,7 @@ __global__ __launch_bounds__(64 * R16_MAXW, 1) void gemm_rb16_kernel(GemmArgs p,
   // weight tile: 32 pieces of 1 KiB (two 512-B rows), piece k by wave k % W; chunk c of row r at position c ^ f(r)
   auto load_tile = [&](int n0, bf16_t* S) {
 #pragma unroll
-    for (int i = 0; i < 7; ++i) {      // W >= 8: 4 turns cover the 32 pieces (W >= 5: 7; the surplus turns are one scalar compare each)
+    for (int i = 0; i < 4; ++i) {      // W >= 8: 4 turns cover the 32 pieces.  (7 turns, to admit 5-wave workgroups for a threshold probe, cost the QKV launch 29 %: 46.5 -> 59.9 us)
       const int k = wave + W * i;
       if (k < R16_BN / 2) {
         const int r = 2 * k + (lane >> 5), q = lane & 31;
@@ -676,9 +676,9 @@ static int rb16_waves(int M) {
   const int slabs = (M + 15) / 16;
   return (slabs + 255) / 256;
 }
-// fewest waves per workgroup the kernel is chosen for (probe knob COATI_RB16_MINW, >= 5; default 9 = 36 865 rows)
+// fewest waves per workgroup the kernel is chosen for (probe knob COATI_RB16_MINW, >= 8: load_tile covers a tile in 4 turns; default 9 = 36 865 rows)
 static int rb16_min_waves() {
-  static const int v = []() { const char* e = getenv("COATI_RB16_MINW"); const int w = e ? atoi(e) : 9; return w < 5 ? 5 : w; }();
+  static const int v = []() { const char* e = getenv("COATI_RB16_MINW"); const int w = e ? atoi(e) : 9; return w < 8 ? 8 : w; }();
   return v;
 }
 
