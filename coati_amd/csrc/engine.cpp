@@ -495,11 +495,16 @@ static bool row_split_on() {
 static int row_split_plan(const GemmArgs& a, int a_f32, int epi) {
   if (!row_split_on() || a.m_dev != nullptr || a_f32 || a.M <= 65536 || a.q8_out != nullptr) return 0;
   if (!(a.K == 256 || a.N == 256)) return 0;
-  // (EPI_QKV_ROPE stays one launch: at 97 k rows the 32-row-slab kernel takes 3.35 ms per step for the 32 QKV products, two 16-row-slab
-  //  launches 3.71 -- the one product of the family where the split loses, profiles/r06_row_split.txt)
-  if (epi != EPI_BF16 && epi != EPI_RES_F32 && epi != EPI_GELU_GRAD && epi != EPI_MUL_AUX && epi != EPI_CE_PARTIAL && epi != EPI_CE_BWD &&
-      epi != EPI_LNBWD) return 0;
-  const long long unit = 16;   // a launch starts on a 16-row slab
+  if (epi != EPI_BF16 && epi != EPI_RES_F32 && epi != EPI_QKV_ROPE && epi != EPI_GELU_GRAD && epi != EPI_MUL_AUX && epi != EPI_CE_PARTIAL &&
+      epi != EPI_CE_BWD && epi != EPI_LNBWD) return 0;
+  // a launch starts on a 16-row slab and, in the padded layout of the rotary epilogue (row m sits at position m % rope_T), on a sequence
+  // boundary
+  long long unit = 16;
+  if (epi == EPI_QKV_ROPE && a.rope_row_t == nullptr && a.rope_pos == nullptr && a.rope_T > 0) {
+    long long g = unit, t = a.rope_T;
+    while (t) { const long long r = g % t; g = t; t = r; }
+    unit = unit / g * a.rope_T;
+  }
   const int n = cdiv(a.M, 57344);
   const long long rows = (cdiv(a.M, n) + unit - 1) / unit * unit;
   if (rows <= 40960 || rows > 57344 || rows >= a.M) return 0;   // (40 960-row halves of a padded 1024 x 80 batch were tried: 33.3 vs 32.4 ms per step)
