@@ -282,7 +282,9 @@ def test_layernorm_backward_in_the_gemm_write_out_equals_the_two_kernels(tmp_pat
     r1, r2 = (int(x) for x in a["rows"])
     assert 40960 < r1 <= 57344 and 40960 < r2 <= 57344, (r1, r2)     # both passes inside the fused kernel's row range
     for k in ("ar_loss", "clip_loss"):
-        assert abs(a["losses"][k] - b["losses"][k]) <= 1e-6 * abs(b["losses"][k]), (k, a["losses"], b["losses"])    # same forward
+        # same forward; the loss sums are f32 atomic adds over ~ 49 000 rows (ce_finish / infonce_rows): their order differs from run to
+        # run, 1.2e-6 was observed between two processes (the bound was 1e-6 for five rounds and held by luck)
+        assert abs(a["losses"][k] - b["losses"][k]) <= 5e-6 * abs(b["losses"][k]), (k, a["losses"], b["losses"])
     worst = sorted(((float((a["grads"][k] - b["grads"][k]).abs().max()) / max(float(b["grads"][k].abs().max()), 1e-30), k)
                     for k in b["grads"] if float(b["grads"][k].abs().max()) > 0), reverse=True)
     log(f"LayerNorm backward fused into the ring GEMM vs two kernels ({r1} / {r2} rows): worst gradient deviations {worst[:3]}")
