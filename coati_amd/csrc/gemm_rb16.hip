@@ -35,6 +35,9 @@
 #define R16_TILE_HALFS (R16_BN * R16_K)          // 32 KiB per buffer
 #define R16_BIAS_MAX 4096                        // bias vectors up to this many columns are staged in LDS (longer: not this kernel)
 #define R16_MAXW 16
+#ifndef R16_TURNS
+#define R16_TURNS 4    // probe builds: -DR16_TURNS=3 is exact for >= 11 waves
+#endif
 #ifndef R16_PRIO
 #define R16_PRIO 0       // probe: 1 = static wave priority 3 - (wave >> 2) (the waves of a SIMD take turns), 2 = MFMA phase raised
 #endif
@@ -160,7 +163,7 @@ __global__ __launch_bounds__(64 * R16_MAXW, 1) void gemm_rb16_kernel(GemmArgs p,
   // weight tile: 32 pieces of 1 KiB (two 512-B rows), piece k by wave k % W; chunk c of row r at position c ^ f(r)
   auto load_tile = [&](int n0, bf16_t* S) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {      // W >= 8: 4 turns cover the 32 pieces.  (7 turns, to admit 5-wave workgroups for a threshold probe, cost the QKV launch 29 %: 46.5 -> 59.9 us)
+    for (int i = 0; i < R16_TURNS; ++i) {      // W >= 8: 4 turns cover the 32 pieces.  (7 turns, to admit 5-wave workgroups for a threshold probe, cost the QKV launch 29 %: 46.5 -> 59.9 us)
       const int k = wave + W * i;
       if (k < R16_BN / 2) {
         const int r = 2 * k + (lane >> 5), q = lane & 31;
