@@ -45,8 +45,20 @@ def _sources():
     return deps
 
 
+def _stamp_path():
+    return LIB + ".flags"
+
+
 def needs_build():
     if not os.path.exists(LIB):
+        return True
+    # the compiler flags the library was built with (probe builds pass -D switches through COATI_AMD_CXXFLAGS): a library left behind by a
+    # probe build must not pass for the product (round 6: a -DR16_TURNS=3 build survived an un-forced rebuild and produced NaN at 9-10 waves)
+    try:
+        with open(_stamp_path()) as f:
+            if f.read() != " ".join(FLAGS):
+                return True
+    except OSError:
         return True
     t = os.path.getmtime(LIB)
     return any(os.path.getmtime(p) > t for p in _sources())
@@ -92,6 +104,8 @@ def _build_locked(verbose):
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stderr}")
     os.replace(tmp, LIB)
+    with open(_stamp_path(), "w") as f:
+        f.write(" ".join(FLAGS))
     if verbose:
         print(f"[coati_amd] built {LIB}", file=sys.stderr)
     return LIB
