@@ -3,6 +3,7 @@
 the longest row); positions behind a row's last token cannot influence a loss or a gradient under causal attention, so the
 packed step must reproduce the padded one: the row map bit-exactly, attention per sequence, losses and every gradient of the
 engine -- and the reference's own golden step."""
+import math
 import os
 
 import numpy as np
@@ -289,3 +290,37 @@ def test_layernorm_backward_in_the_gemm_write_out_equals_the_two_kernels(tmp_pat
                     for k in b["grads"] if float(b["grads"][k].abs().max()) > 0), reverse=True)
     log(f"LayerNorm backward fused into the ring GEMM vs two kernels ({r1} / {r2} rows): worst gradient deviations {worst[:3]}")
     assert worst[0][0] <= 1e-2, worst[:5]
+
+
+@pytest.mark.parametrize("B", [690, 800, 900, 1024, 1150, 1290])
+def test_packed_step_equals_padded_step_across_the_kernel_size_classes(B):
+    """One layer at d = 256, T = 80: the packed passes of these batches have ~ 33 k .. 63 k rows, i.e. 9, 10, 11, 13, 14 and 16 waves per
+    workgroup in the 16-row-slab kernels, the one-round ring forms from 40 961 rows, the 8-wave ring form above 57 344 -- every size class of
+    the packed step's GEMM dispatch.  Losses of the packed step against the padded step of the same batch (a probe build whose weight-tile
+    loop covered 30 of the 32 pieces at 9-10 waves gave NaN exactly in the first two classes and passed every other test of the suite)."""
+    from coati_amd.engine import Engine, ModelConfig
+    from coati_amd.synthetic import make_batch
+    kw = dict(n_layer_e3gnn=1, n_layer_xformer=1, n_hidden_xformer=256, n_hidden_e3nn=64, n_embd_common=256, n_head=16, n_seq=100, n_tok=600)
+    eng = Engine(ModelConfig(**kw), DEV)
+    g = torch.Generator().manual_seed(5)
+    with torch.no_grad():
+        for name, (off, shape) in eng.layout.items():
+            v = eng.view(name)
+            if len(shape) == 2:
+                v.copy_((torch.randn(shape, generator=g) * (0.05 if "tok_emb" not in name else 1.0)).to(DEV))
+            elif (".ln_" in name and name.endswith("weight")) or name.endswith("clip.0.weight"):
+                v.fill_(1.0)
+    eng.refresh_shadows()
+    b, up = make_batch(B, 80, 6, 600, seed=B, n_special=12, min_len=16, with_rows=True)
+    db = {k: (v if k == "rows" else v.to(DEV)) for k, v in b.items()}
+    eng.train_step(db, up.to(DEV), lr=1e-3, optimizer=False)
+    Lp = eng.losses()
+    gp = {k: v.clone() for k, v in eng.named_views("grads").items()}
+    eng.train_step({k: v for k, v in db.items() if k != "rows"}, up.to(DEV), lr=1e-3, optimizer=False)
+    Lq = eng.losses()
+    gq = eng.named_views("grads")
+    log(f"packed vs padded at B = {B} (rows {b['rows'].tolist()}): {Lp['ar_loss']:.6f} / {Lp['clip_loss']:.6f} vs {Lq['ar_loss']:.6f} / {Lq['clip_loss']:.6f}")
+    for k in ("ar_loss", "clip_loss"):
+        assert math.isfinite(Lp[k]) and abs(Lp[k] - Lq[k]) <= 2e-4 * abs(Lq[k]), (k, Lp, Lq)
+    worst = max(float((gp[k] - gq[k]).abs().max()) / max(float(gq[k].abs().max()), 1e-30) for k in gq if float(gq[k].abs().max()) > 0)
+    assert worst <= 2e-2, worst      # (different kernels on the two layouts: bf16 rounding of different intermediate sums)
