@@ -249,6 +249,8 @@ def feed_extras(eng, dev, args, MODEL):
         torch.cuda.synchronize()
         rep.append((time.perf_counter() - t) / 3)
     rep = sum(rep) / len(rep)
+    import math
+    assert all(math.isfinite(float(v)) for v in eng.losses().values()), "end_to_end: non-finite loss on the fed batches"
     out["end_to_end"] = {"workers": W, "steps": k - 8, "ms_per_step": round(1e3 * e2e, 3), "ms_per_step_replayed": round(1e3 * rep, 3),
                          "fed_over_replayed": round(e2e / rep, 4), "within_5pct": bool(e2e / rep <= 1.05),
                          "step_loop_wait_for_batch_ms": round(1e3 * waited, 3), "molecules_per_s": round(B / e2e, 1),
@@ -413,6 +415,9 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t)
     losses = D.global_losses(eng) if dist_on else eng.losses()
+    import math as _math
+    if not all(_math.isfinite(float(losses[k])) for k in ("ar_loss", "clip_loss", "loss")):
+        raise SystemExit(f"bench.py: the timed steps produced non-finite losses {losses}: the number would be a measurement of garbage")
     # the other row layout, outside the timed region: the same steps on the padded [B, T] matrices (what the reference
     # computes) when the line is the packed one, and vice versa -- so that the line carries both numbers
     other = batch_packed if args.padded else batch_padded
@@ -519,6 +524,7 @@ def main():
             for _ in range(3):
                 eng.train_step(b, u, lr=5e-4, head=args.head)
             t_b = timed_steps(b, u, 8)
+            assert all(_math.isfinite(float(v)) for v in eng.losses().values()), f"batch_sweep: non-finite loss at batch {Bs}"
             sweep.append({"batch": Bs, "ms_per_step": round(1e3 * t_b, 3), "molecules_per_s": round(Bs / t_b, 1), "rows": [int(x) for x in bc["rows"].tolist()]})
             del b, u
         extras["batch_sweep"] = {"note": "same engine, one synthetic batch per size replayed (3 warm-up + 8 timed steps); 160 = the reference's default per-GPU batch "
