@@ -489,3 +489,16 @@ def test_committed_step_traffic_does_not_regress():
     step = d["_step"]
     assert abs(step["hbm_read_GB_per_step"] + step["hbm_write_GB_per_step"] - step["hbm_GB_per_step"]) < 0.05
     assert step["hbm_GB_per_step"] <= 88.06 * 1.02, (files[-1], step["hbm_GB_per_step"])
+
+
+def test_a_probe_build_does_not_pass_for_the_product(monkeypatch):
+    """coati_amd/build.py: the library carries the compiler flags it was built with (libcoati_hip.so.flags); with other flags in the
+    environment's COATI_AMD_CXXFLAGS -- a probe build's -D switches -- or without the stamp, an un-forced build() rebuilds.  (Round 6: a
+    -DR16_TURNS=3 library survived `python coati_amd/build.py` because only source times were compared, and gave NaN at 9-10 waves.)"""
+    from coati_amd import build as B
+    B.build(verbose=False)            # (builds only if the library is missing or stale)
+    assert os.path.exists(B.LIB) and os.path.exists(B._stamp_path())
+    assert open(B._stamp_path()).read() == " ".join(B.FLAGS)
+    assert not B.needs_build()
+    monkeypatch.setattr(B, "FLAGS", B.FLAGS + ["-DR16_TURNS=3"])
+    assert B.needs_build()
